@@ -1,0 +1,216 @@
+"""ctypes front-end of oracle/liboracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product (opencv_contrib_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class TVL1Params(C.Structure):
+    _fields_ = [("tau", C.c_double), ("lambda_", C.c_double), ("theta", C.c_double),
+                ("epsilon", C.c_double), ("scale_step", C.c_double), ("gamma", C.c_double),
+                ("nscales", C.c_int), ("warps", C.c_int), ("inner_iterations", C.c_int),
+                ("outer_iterations", C.c_int), ("median_filtering", C.c_int),
+                ("use_initial_flow", C.c_int), ("semantics", C.c_int)]
+
+
+class TVL1Stats(C.Structure):
+    _fields_ = [("nscales_used", C.c_int), ("level_w", C.c_int * 32), ("level_h", C.c_int * 32),
+                ("iters", (C.c_int * 64) * 32)]
+
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        try:
+            build()
+        except Exception:
+            if not os.path.exists(_LIB_PATH):
+                raise
+        _lib = C.CDLL(_LIB_PATH)
+        L = _lib
+        L.orc_scaled_dim.restype = C.c_int
+        L.orc_scaled_dim.argtypes = [C.c_int, C.c_double]
+        L.orc_resize_linear_cv.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.orc_resize_linear_cuda.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_remap_cubic_cv.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int]
+        L.orc_median_blur.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int]
+        L.orc_cubic_table.restype = C.POINTER(C.c_float)
+        L.orc_tvl1_default_params.argtypes = [C.POINTER(TVL1Params)]
+        L.orc_tvl1_calc.restype = C.c_int
+        L.orc_tvl1_calc.argtypes = [C.POINTER(TVL1Params), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_long, _f32p, C.POINTER(TVL1Stats)]
+        L.orc_tvl1_centered_gradient.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
+        L.orc_tvl1_warp.argtypes = [C.c_int] + [_f32p] * 6 + [C.c_int, C.c_int] + [_f32p] * 5
+        L.orc_tvl1_iteration.restype = C.c_float
+        L.orc_tvl1_iteration.argtypes = [C.c_int] + [_f32p] * 4 + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 4
+    return _lib
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ---------------------------------------------------------------- image primitives
+def scaled_dim(n: int, f: float) -> int:
+    return lib().orc_scaled_dim(n, f)
+
+
+def resize_linear_cv(src, dsize=None, fx=0.0, fy=0.0):
+    """cv::resize(src, dst, dsize, fx, fy, INTER_LINEAR) for CV_32FC1."""
+    src = _c(src)
+    sh, sw = src.shape
+    if dsize is None:
+        dw, dh = scaled_dim(sw, fx), scaled_dim(sh, fy)
+        isx, isy = fx, fy
+    else:
+        dw, dh = dsize
+        isx, isy = dw / sw, dh / sh
+    dst = np.empty((dh, dw), np.float32)
+    lib().orc_resize_linear_cv(src, sw, sh, dst, dw, dh, 1.0 / isx, 1.0 / isy)
+    return dst
+
+
+def resize_linear_cuda(src, dsize=None, fx=0.0, fy=0.0):
+    """cv::cuda::resize(..., INTER_LINEAR) for CV_32FC1."""
+    src = _c(src)
+    sh, sw = src.shape
+    if dsize is None:
+        dw, dh = scaled_dim(sw, fx), scaled_dim(sh, fy)
+    else:
+        dw, dh = dsize
+        fx, fy = dw / sw, dh / sh
+    dst = np.empty((dh, dw), np.float32)
+    if (dw, dh) == (sw, sh):
+        return src.copy()
+    lib().orc_resize_linear_cuda(src, sw, sh, dst, dw, dh, np.float32(1.0 / fx), np.float32(1.0 / fy))
+    return dst
+
+
+def remap_cubic_cv(src, mapx, mapy):
+    src, mapx, mapy = _c(src), _c(mapx), _c(mapy)
+    sh, sw = src.shape
+    dh, dw = mapx.shape
+    dst = np.empty((dh, dw), np.float32)
+    lib().orc_remap_cubic_cv(src, sw, sh, mapx, mapy, dst, dw, dh)
+    return dst
+
+
+def median_blur(src, ksize=5):
+    src = _c(src)
+    h, w = src.shape
+    dst = np.empty_like(src)
+    lib().orc_median_blur(src, dst, w, h, ksize)
+    return dst
+
+
+def cubic_table():
+    p = lib().orc_cubic_table()
+    return np.ctypeslib.as_array(p, shape=(32, 4)).copy()
+
+
+# ---------------------------------------------------------------- TV-L1
+def tvl1_params(**kw) -> TVL1Params:
+    """CPU class defaults (optflow/src/tvl1flow.cpp:386-400), overridden by kw.
+    `iterations=N` is the cv::cuda spelling: inner=1, outer=N, median=1
+    (equivalence used by cudaoptflow/perf/perf_optflow.cpp:319-323)."""
+    p = TVL1Params()
+    lib().orc_tvl1_default_params(C.byref(p))
+    if "iterations" in kw:
+        p.inner_iterations, p.outer_iterations, p.median_filtering = 1, int(kw.pop("iterations")), 1
+    for k, v in kw.items():
+        k = "lambda_" if k in ("lambda", "lambda_") else k
+        if not hasattr(p, k):
+            raise TypeError(f"unknown TV-L1 parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+def tvl1_calc(I0, I1, params: TVL1Params | None = None, init_flow=None, return_stats=False):
+    p = params or tvl1_params()
+    I0 = np.ascontiguousarray(I0)
+    I1 = np.ascontiguousarray(I1)
+    if I0.dtype == np.uint8:
+        typ = 0
+    elif I0.dtype == np.float32:
+        typ = 1
+    else:
+        raise ValueError("I0 must be uint8 or float32")  # CV_Assert, optflow tvl1flow.cpp:417
+    if I0.shape != I1.shape or I0.dtype != I1.dtype:
+        raise ValueError("I0/I1 size or type mismatch")  # :418-419
+    h, w = I0.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    if p.use_initial_flow:
+        if init_flow is None or init_flow.shape != (h, w, 2):
+            raise ValueError("initial flow of the frame size required")  # :420
+        flow[...] = init_flow
+    st = TVL1Stats()
+    rc = lib().orc_tvl1_calc(C.byref(p), I0.ctypes.data, I1.ctypes.data, typ, w, h,
+                             I0.strides[0], flow.reshape(-1), C.byref(st))
+    if rc != 0:
+        raise ValueError(f"orc_tvl1_calc failed: {rc}")
+    if return_stats:
+        ns = st.nscales_used
+        stats = {"nscales": ns,
+                 "levels": [(st.level_w[s], st.level_h[s]) for s in range(ns)],
+                 "iters": [[st.iters[s][w_] for w_ in range(p.warps)] for s in range(ns)]}
+        return flow, stats
+    return flow
+
+
+def tvl1_centered_gradient(src):
+    src = _c(src)
+    h, w = src.shape
+    dx, dy = np.empty_like(src), np.empty_like(src)
+    lib().orc_tvl1_centered_gradient(src, w, h, dx, dy)
+    return dx, dy
+
+
+def tvl1_warp(semantics, I0, I1, I1x, I1y, u1, u2):
+    I0, I1, I1x, I1y, u1, u2 = map(_c, (I0, I1, I1x, I1y, u1, u2))
+    h, w = I0.shape
+    outs = [np.empty_like(I0) for _ in range(5)]
+    lib().orc_tvl1_warp(semantics, I0, I1, I1x, I1y, u1, u2, w, h, *outs)
+    return tuple(outs)  # I1w, I1wx, I1wy, grad, rho_c
+
+
+def tvl1_iteration(semantics, I1wx, I1wy, grad, rho_c, u1, u2, p11, p12, p21, p22, l_t, theta, taut,
+                   gamma=0.0, u3=None, p31=None, p32=None):
+    """In place on copies; returns (error, u1, u2, p11, p12, p21, p22[, u3, p31, p32])."""
+    st = [_c(a).copy() for a in (I1wx, I1wy, grad, rho_c)]
+    dyn = [_c(a).copy() for a in (u1, u2)]
+    u3c = _c(u3).copy() if u3 is not None else None
+    ps = [_c(a).copy() for a in (p11, p12, p21, p22)]
+    p3 = [_c(a).copy() if a is not None else None for a in (p31, p32)]
+    h, w = st[0].shape
+    ptr = lambda a: a.ctypes.data if a is not None else None
+    e = lib().orc_tvl1_iteration(semantics, *st, ptr(dyn[0]), ptr(dyn[1]), ptr(u3c), ptr(ps[0]), ptr(ps[1]),
+                                 ptr(ps[2]), ptr(ps[3]), ptr(p3[0]), ptr(p3[1]), w, h,
+                                 l_t, theta, taut, gamma)
+    out = (float(e), dyn[0], dyn[1], *ps)
+    if u3 is not None:
+        out = out + (u3c, p3[0], p3[1])
+    return out
