@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- frame-pairs/s of dense Dual TV-L1 flow at 1080p on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (mi_tvl1_calc_batch through the C-ABI) over one batch of
+`--batch` synthetic 1920x1080 CV_32FC1 pairs already resident in HBM.  Workload at N=1 is
+BASELINE.json configs[1] ("DualTVL1 dense flow, 1920x1080, 1xMI355X"); with --gpus N every rank
+processes its own batch (independent pairs, no data-path collective: weak scaling, configs[4]).
+
+Primary parameter set: the reference accuracy-test setting iterations=10 with epsilon=0
+(fixed work: cudaoptflow/test/test_optflow.cpp:450; CPU equivalent median=1, inner=1, outer=10)
+unless --defaults is given (class defaults: 300 iterations, epsilon 0.01, data-dependent exit).
+The JSON line carries N and the per-pair algorithmic bytes so the number can be read against
+BASELINE.md section 2.  Extra parameter sets are reported under "variants".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def level_pixels(w, h, nscales=5, step=0.8):
+    import numpy as np
+    px = []
+    for s in range(nscales):
+        if s:
+            w, h = int(np.rint(w * step)), int(np.rint(h * step))
+            if w < 16 or h < 16:
+                break
+        px.append(w * h)
+    return px
+
+
+def algo_bytes_per_pair(w, h, warps, iters_per_warp, nscales=5, step=0.8):
+    """sum_levels px * (12 + warps*(44 + 64*N))."""
+    return float(sum(p * (12 + warps * (44 + 64 * iters_per_warp)) for p in level_pixels(w, h, nscales, step)))
+
+
+def make_inputs(n, h, w, dev, distinct=4):
+    import torch
+    from opencv_contrib_amd import synth
+    base = [synth.flow_pair(h, w, seed=1234 + i) for i in range(min(n, distinct))]
+    I0 = torch.stack([torch.from_numpy(base[i % len(base)][0]) for i in range(n)]).to(dev)
+    I1 = torch.stack([torch.from_numpy(base[i % len(base)][1]) for i in range(n)]).to(dev)
+    return I0, I1, base
+
+
+def time_steps(alg, I0, I1, flows, steps, warmup, dist):
+    import torch
+    for _ in range(warmup):
+        alg.calc_batch(I0, I1, flows)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        alg.calc_batch(I0, I1, flows)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--iterations", type=int, default=10)
+    ap.add_argument("--epsilon", type=float, default=0.0)
+    ap.add_argument("--defaults", action="store_true", help="class defaults: 300 iterations, epsilon 0.01")
+    ap.add_argument("--fast-math", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-iterations", type=int, default=None)
+    args = ap.parse_args()
+    if args.defaults:
+        args.iterations, args.epsilon = 300, 0.01
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist = dist_
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from opencv_contrib_amd import cuda, synth
+
+    W, H, B = args.width, args.height, args.batch
+    I0, I1, base = make_inputs(B, H, W, dev)
+    flows = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+    warps = 5
+
+    def run(iterations, epsilon, steps, warmup, profile=False):
+        alg = cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon, exactMath=not args.fast_math)
+        alg.setProfiling(profile)
+        el = time_steps(alg, I0, I1, flows, steps, warmup, dist)
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        prof = alg.getProfile() if profile else None
+        its = alg.lastIterations(0)
+        return float(t.item()), prof, its, alg
+
+    el, prof, its, alg = run(args.iterations, args.epsilon, args.steps, args.warmup, profile=True)
+    pairs = B * world * args.steps
+    fps = pairs / el
+    # accuracy of what was just computed: EPE vs the analytic flow of pair 0
+    gt = base[0][2]
+    f0 = flows[0].cpu().numpy()
+    epe_gt = float(np.sqrt(((f0 - gt) ** 2).sum(-1))[40:-40, 40:-40].mean())
+
+    mean_it = float(np.mean(its))
+    ab_pair = algo_bytes_per_pair(W, H, warps, mean_it)
+    # dominant kernel: fused iteration; events bracket each warp's run of launches (last step's calc)
+    ms_total, launches, abytes = prof
+    if args.epsilon > 0:  # only executed launches move bytes; the no-op launches still cost their dispatch
+        exec_frac = mean_it / args.iterations
+        abytes *= exec_frac
+    roof = {"bound": "hbm", "kernel": "k_iterate (fused estimateU+estimateDualVariables)",
+            "achieved": abytes / (ms_total * 1e-3) / 1e9 if ms_total > 0 else None, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "traffic": None,
+            "avg_launch_us": 1e3 * ms_total / max(launches, 1), "launches_timed": launches,
+            "algorithmic_bytes_per_launch_level0": 64.0 * W * H * B}
+    roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
+
+    out = {"metric": "frame-pairs/sec dense TV-L1 flow @1080p", "value": fps, "unit": "pairs/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"DualTVL1 dense flow, {W}x{H} CV_32FC1, {B} pairs/GPU/step (BASELINE configs[1])",
+                      "iterations": args.iterations, "epsilon": args.epsilon, "warps": warps, "nscales": 5,
+                      "executed_iterations_per_warp_mean": mean_it, "semantics": "CPU_REF",
+                      "math": "fast" if args.fast_math else "exact",
+                      "algorithmic_GB_per_pair": ab_pair / 1e9},
+           "whole_job_algorithmic_GBps": ab_pair * fps / 1e9,
+           "whole_job_frac_of_hbm_peak": ab_pair * fps / 1e9 / HBM_PEAK_GBS,
+           "epe_vs_analytic_flow_px": epe_gt,
+           "roofline": roof}
+
+    if not args.no_variants and world == 1:
+        var = {}
+        for name, (it, eps) in {"iterations2_eps0": (2, 0.0), "iterations30_eps0": (30, 0.0),
+                                "defaults_300_eps0.01": (300, 0.01)}.items():
+            if (it, eps) == (args.iterations, args.epsilon):
+                continue
+            e2, _, its2, _ = run(it, eps, max(1, args.steps // 2), 1)
+            n2 = B * max(1, args.steps // 2)
+            m2 = float(np.mean(its2))
+            var[name] = {"pairs_per_s": n2 / e2, "executed_iterations_per_warp_mean": m2,
+                         "algorithmic_GB_per_pair": algo_bytes_per_pair(W, H, warps, m2) / 1e9,
+                         "frac_of_hbm_peak": algo_bytes_per_pair(W, H, warps, m2) * (n2 / e2) / 1e9 / HBM_PEAK_GBS}
+        out["variants"] = var
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        # CPU baseline: the oracle (a port of the reference CPU path; the reference itself cannot be
+        # built here) on ONE pair of the same workload, all host cores (OpenMP rows).
+        from oracle import oracle as O
+        cit = args.cpu_iterations or (args.iterations if args.epsilon == 0 else 300)
+        p = O.tvl1_params(iterations=cit, epsilon=args.epsilon)
+        t0 = time.perf_counter()
+        O.tvl1_calc(base[0][0], base[0][1], p)
+        ct = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"1 pair {W}x{H}, iterations={cit}, epsilon={args.epsilon}, {ct:.1f} s wall"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

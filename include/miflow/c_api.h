@@ -1,0 +1,153 @@
+/*
+ * miflow C-ABI -- the drop-in boundary of the MI355X-native dense-flow / stereo / SURF
+ * hot path (libmiflow.so).  Plain C: pointers, sizes, PODs; no C++/torch/OpenCV types.
+ *
+ * Each entry point replaces an internal (C++-linkage, PtrStepSz-by-value) device-layer
+ * function of the reference; the `Replaces:` line cites it (paths relative to the
+ * opencv_contrib tree).  The C++ shim in include/opencv2/ binds these under the
+ * reference's own cv::cuda class names; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - all image pointers are DEVICE pointers (HIP), pitched row-major, `step` in bytes
+ *     (GpuMat layout: element (y,x) at data + y*step + x*elemSize); step need not equal
+ *     cols*elemSize and data need only be element-aligned.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is
+ *     stream-ordered; no entry point synchronises the device unless documented.
+ *   - every function returns mi_status (0 = ok, <0 = error) and never throws;
+ *     mi_last_error() returns a thread-local message for the last failure.
+ *   - handles are not re-entrant (they own scratch memory); distinct handles are fully
+ *     independent (no global/__constant__ state) and may be used concurrently from
+ *     different host threads / streams with bit-identical results.
+ */
+#ifndef MIFLOW_C_API_H
+#define MIFLOW_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MI_API __attribute__((visibility("default")))
+#else
+#define MI_API
+#endif
+
+typedef enum mi_status {
+    MI_OK = 0,
+    MI_ERR_BAD_ARG = -1,   /* cv::Error::StsBadArg / failed CV_Assert on a parameter */
+    MI_ERR_BAD_TYPE = -2,  /* unsupported matrix type (CV_Assert on type()) */
+    MI_ERR_BAD_SIZE = -3,  /* size mismatch (CV_Assert on size()) */
+    MI_ERR_HIP = -4,       /* cv::Error::GpuApiCallError */
+    MI_ERR_OOM = -5,
+    MI_ERR_NOT_IMPL = -6,
+    MI_ERR_NO_DEVICE = -7
+} mi_status;
+
+/* OpenCV type codes (CV_MAKETYPE(depth, cn)), so GpuMat::type() passes straight through. */
+enum { MI_8UC1 = 0, MI_32SC1 = 4, MI_32FC1 = 5, MI_32FC2 = 13, MI_32SC4 = 28 };
+
+/* Device-side matrix view == cv::cuda::PtrStepSz<T> {data, step, cols, rows} + type.
+ * Replaces: opencv2/core/cuda_types.hpp PtrStepSz (main repo); in-tree twin
+ * modules/cudev/include/opencv2/cudev/ptr2d/glob.hpp:62-89. */
+typedef struct mi_mat {
+    void *data;
+    size_t step; /* bytes */
+    int rows, cols;
+    int type;
+} mi_mat;
+
+MI_API const char *mi_last_error(void);
+MI_API const char *mi_version(void);
+MI_API int mi_device_count(void);          /* cv::cuda::getCudaEnabledDeviceCount */
+MI_API int mi_set_device(int device);      /* cv::cuda::setDevice (cudaoptflow/test/test_optflow.cpp:62) */
+MI_API int mi_get_device(int *device);
+
+/* Device memory helpers for hosts without a HIP runtime binding (the C++ shim's GpuMat
+ * allocator uses them).  mi_malloc_pitch rounds the step up to 256 B. */
+MI_API int mi_malloc(void **dptr, size_t bytes);
+MI_API int mi_malloc_pitch(void **dptr, size_t *step, size_t width_bytes, int rows);
+MI_API int mi_free(void *dptr);
+MI_API int mi_memcpy_h2d(void *dst, size_t dstep, const void *src, size_t sstep, size_t width_bytes, int rows, void *stream);
+MI_API int mi_memcpy_d2h(void *dst, size_t dstep, const void *src, size_t sstep, size_t width_bytes, int rows, void *stream);
+MI_API int mi_memset(void *dst, size_t dstep, int value, size_t width_bytes, int rows, void *stream);
+MI_API int mi_stream_create(void **stream);
+MI_API int mi_stream_destroy(void *stream);
+MI_API int mi_stream_synchronize(void *stream);
+
+/* ===================================================================== Dual TV-L1 ===== */
+
+enum { MI_SEM_CPU_REF = 0,     /* arithmetic of cv::optflow::DualTVL1OpticalFlow (optflow/src/tvl1flow.cpp) */
+       MI_SEM_CUDA_COMPAT = 1  /* arithmetic of cv::cuda::OpticalFlowDual_TVL1 (cudaoptflow/src/cuda/tvl1flow.cu) */ };
+
+/* Parameters of cv::cuda::OpticalFlowDual_TVL1::create (cudaoptflow.hpp:375-385) plus the
+ * three CPU-class-only knobs (optflow.hpp:283-295).  `iterations` is the cv::cuda name for
+ * the outer count; the inner loop runs inner_iterations (cv::cuda equivalent: 1) times per
+ * outer iteration, with a median filter of u before each outer iteration when
+ * median_filtering > 1 (cv::cuda equivalent: 1 = off). */
+typedef struct mi_tvl1_params {
+    double tau, lambda, theta, epsilon, scale_step, gamma;
+    int nscales, warps, iterations;
+    int use_initial_flow;
+    int inner_iterations;
+    int median_filtering;
+    int semantics;       /* MI_SEM_* ; default CPU_REF (acceptance is against the CPU path) */
+    int exact_math;      /* 1: IEEE divide + f64 hypot (oracle-faithful); 0: fast reciprocal math */
+    int time_block;      /* inner iterations fused per HBM pass when epsilon == 0 (0 = auto) */
+} mi_tvl1_params;
+
+typedef struct mi_tvl1 mi_tvl1;
+
+MI_API void mi_tvl1_default_params(mi_tvl1_params *p);
+/* Replaces: cv::cuda::OpticalFlowDual_TVL1::create, cudaoptflow/src/tvl1flow.cpp:385-391 */
+MI_API int mi_tvl1_create(const mi_tvl1_params *p, mi_tvl1 **out);
+MI_API int mi_tvl1_set_params(mi_tvl1 *h, const mi_tvl1_params *p);
+MI_API int mi_tvl1_get_params(const mi_tvl1 *h, mi_tvl1_params *p);
+/* Replaces: OpticalFlowDual_TVL1_Impl::calc + calcImpl + procOneScale,
+ * cudaoptflow/src/tvl1flow.cpp:170-382 (CPU twin optflow/src/tvl1flow.cpp:402-533,1313-1408).
+ * I0,I1: MI_8UC1 or MI_32FC1 (floats in [0,1], scaled x255), same size/type.
+ * flow: MI_32FC2, same size; read as the initial flow when use_initial_flow.
+ * Fully stream-ordered: the convergence test runs on the device (no host read-back). */
+MI_API int mi_tvl1_calc(mi_tvl1 *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream);
+/* n independent pairs of identical size/type in one pass (blockIdx.z = pair). */
+MI_API int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream);
+/* Executed inner iterations per (scale, warp) of pair `pair` of the last calc
+ * (synchronises `stream`).  iters: [nscales_used][warps] row-major, capacity `cap` ints. */
+MI_API int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int *iters, int cap, void *stream);
+/* Kernel-level timing of the dominant kernel (the fused iteration) with HIP events recorded on the
+ * calc stream around each warp's run of iteration launches.  get_profile synchronises the events and
+ * returns, for the last calc: total ms inside those regions, the number of iteration launches inside
+ * them, and their algorithmic bytes (64 B x level pixels x batch per launch). */
+MI_API int mi_tvl1_set_profiling(mi_tvl1 *h, int enable);
+MI_API int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, double *algo_bytes);
+MI_API void mi_tvl1_destroy(mi_tvl1 *h);
+
+/* Stage-level entry points (dense or pitched MI_32FC1 planes) == the reference's internal
+ * device-layer boundary, exported for plane-by-plane parity tests.
+ * Replaces: tvl1flow::centeredGradient  cudaoptflow/src/cuda/tvl1flow.cu:59-81 */
+MI_API int mi_tvl1_centered_gradient(const mi_mat *src, mi_mat *dx, mi_mat *dy, void *stream);
+/* Replaces: tvl1flow::warpBackward  tvl1flow.cu:106-179  (CPU: 3x remap + calcGradRho,
+ * optflow/src/tvl1flow.cpp:1371-1376) */
+MI_API int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *I1, const mi_mat *I1x,
+                                 const mi_mat *I1y, const mi_mat *u1, const mi_mat *u2, mi_mat *I1w,
+                                 mi_mat *I1wx, mi_mat *I1wy, mi_mat *grad, mi_mat *rho);
+/* Replaces: tvl1flow::estimateU + estimateDualVariables  tvl1flow.cu:209-363, fused into
+ * one pass.  `niter` iterations from (u,p) in -> out (separate buffers); err_host[niter]
+ * (HOST pointer, may be NULL) receives the per-iteration sum of (du1^2 + du2^2); when it is
+ * non-NULL the call synchronises `stream` before returning (test hook). */
+MI_API int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1wx, const mi_mat *I1wy,
+                           const mi_mat *grad, const mi_mat *rho_c, const mi_mat *u_in /*[2]*/,
+                           const mi_mat *p_in /*[4]*/, mi_mat *u_out /*[2]*/, mi_mat *p_out /*[4]*/,
+                           float l_t, float theta, float taut, double *err_host, void *stream);
+/* Replaces: cv::cuda::resize(INTER_LINEAR) on CV_32FC1, cudawarping/src/resize.cpp:57-108
+ * (semantics CUDA_COMPAT) / cv::resize (semantics CPU_REF); inv_scale = fx given by the
+ * caller when `explicit_dsize` is 0, else dst/src.  dst *= post_scale afterwards. */
+MI_API int mi_resize_linear(int semantics, const mi_mat *src, mi_mat *dst, double fx, double fy,
+                            int explicit_dsize, float post_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIFLOW_C_API_H */

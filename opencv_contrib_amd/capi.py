@@ -1,0 +1,140 @@
+"""ctypes binding of libmiflow.so (the C-ABI in include/miflow/c_api.h).
+
+This is the only way Python reaches the product path; there is NO CPU fallback: if the HIP
+library is missing or no device is visible, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiflow.so")
+
+MI_8UC1, MI_32SC1, MI_32FC1, MI_32FC2, MI_32SC4 = 0, 4, 5, 13, 28
+MI_SEM_CPU_REF, MI_SEM_CUDA_COMPAT = 0, 1
+
+STATUS = {0: "MI_OK", -1: "MI_ERR_BAD_ARG", -2: "MI_ERR_BAD_TYPE", -3: "MI_ERR_BAD_SIZE", -4: "MI_ERR_HIP",
+          -5: "MI_ERR_OOM", -6: "MI_ERR_NOT_IMPL", -7: "MI_ERR_NO_DEVICE"}
+
+
+class MiError(RuntimeError):
+    """Raised for any non-zero mi_status (the C++ shim maps the same codes to cv::Exception)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Mat(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("step", C.c_size_t), ("rows", C.c_int), ("cols", C.c_int), ("type", C.c_int)]
+
+
+class TVL1Params(C.Structure):
+    _fields_ = [("tau", C.c_double), ("lambda_", C.c_double), ("theta", C.c_double), ("epsilon", C.c_double),
+                ("scale_step", C.c_double), ("gamma", C.c_double), ("nscales", C.c_int), ("warps", C.c_int),
+                ("iterations", C.c_int), ("use_initial_flow", C.c_int), ("inner_iterations", C.c_int),
+                ("median_filtering", C.c_int), ("semantics", C.c_int), ("exact_math", C.c_int),
+                ("time_block", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libmiflow.so.  torch (if it is going to be used) must be imported first so both
+    share one HIP runtime (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m opencv_contrib_amd.build` "
+                          "(there is no CPU fallback for the miflow product path)")
+    try:
+        import torch  # noqa: F401  (pins the HIP runtime the tensors live in)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i, f, d = C.c_void_p, C.c_int, C.c_float, C.c_double
+    PM = C.POINTER(Mat)
+    sig = {
+        "mi_last_error": (C.c_char_p, []),
+        "mi_version": (C.c_char_p, []),
+        "mi_device_count": (i, []),
+        "mi_set_device": (i, [i]),
+        "mi_get_device": (i, [C.POINTER(i)]),
+        "mi_malloc": (i, [C.POINTER(vp), C.c_size_t]),
+        "mi_malloc_pitch": (i, [C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, i]),
+        "mi_free": (i, [vp]),
+        "mi_memcpy_h2d": (i, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, i, vp]),
+        "mi_memcpy_d2h": (i, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, i, vp]),
+        "mi_memset": (i, [vp, C.c_size_t, i, C.c_size_t, i, vp]),
+        "mi_stream_create": (i, [C.POINTER(vp)]),
+        "mi_stream_destroy": (i, [vp]),
+        "mi_stream_synchronize": (i, [vp]),
+        "mi_tvl1_default_params": (None, [C.POINTER(TVL1Params)]),
+        "mi_tvl1_create": (i, [C.POINTER(TVL1Params), C.POINTER(vp)]),
+        "mi_tvl1_set_params": (i, [vp, C.POINTER(TVL1Params)]),
+        "mi_tvl1_get_params": (i, [vp, C.POINTER(TVL1Params)]),
+        "mi_tvl1_calc": (i, [vp, PM, PM, PM, vp]),
+        "mi_tvl1_calc_batch": (i, [vp, i, PM, PM, PM, vp]),
+        "mi_tvl1_last_iterations": (i, [vp, i, C.POINTER(i), C.POINTER(i), i, vp]),
+        "mi_tvl1_set_profiling": (i, [vp, i]),
+        "mi_tvl1_get_profile": (i, [vp, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
+        "mi_tvl1_destroy": (None, [vp]),
+        "mi_tvl1_centered_gradient": (i, [PM, PM, PM, vp]),
+        "mi_tvl1_warp_backward": (i, [i] + [PM] * 11),
+        "mi_tvl1_iterate": (i, [i, i, i, PM, PM, PM, PM, PM, PM, PM, PM, f, f, f, C.POINTER(d), vp]),
+        "mi_resize_linear": (i, [i, PM, PM, d, d, i, f, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """Every MI_API function include/miflow/c_api.h declares (parsed from the header)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "miflow", "c_api.h")
+    txt = open(hdr).read()
+    return sorted(set(re.findall(r"MI_API\s+[\w\s\*]+?\b(mi_\w+)\s*\(", txt)))
+
+
+def check(rc: int):
+    if rc != 0:
+        raise MiError(rc, lib().mi_last_error().decode())
+
+
+_TORCH_TYPES = None
+
+
+def mat_from_tensor(t) -> Mat:
+    """torch CUDA tensor -> mi_mat.  (H,W) uint8/float32/int32 -> 8UC1/32FC1/32SC1; (H,W,2) float32 -> 32FC2;
+    (H,W,4) int32 -> 32SC4.  Rows may be pitched (stride(0) arbitrary); inner dims must be dense."""
+    import torch
+    if not t.is_cuda:
+        raise MiError(-1, "tensor must live on the GPU (no CPU fallback)")
+    if t.dim() == 2:
+        cn = 1
+        if t.stride(1) != 1:
+            raise MiError(-1, "rows must be dense")
+    elif t.dim() == 3:
+        cn = t.shape[2]
+        if t.stride(2) != 1 or t.stride(1) != cn:
+            raise MiError(-1, "channels must be interleaved and dense")
+    else:
+        raise MiError(-3, "expected a 2-D or 3-D tensor")
+    key = (t.dtype, cn)
+    types = {(torch.uint8, 1): MI_8UC1, (torch.float32, 1): MI_32FC1, (torch.float32, 2): MI_32FC2,
+             (torch.int32, 1): MI_32SC1, (torch.int32, 4): MI_32SC4}
+    if key not in types:
+        raise MiError(-2, f"unsupported dtype/channels {key}")
+    return Mat(t.data_ptr(), t.stride(0) * t.element_size(), t.shape[0], t.shape[1], types[key])
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

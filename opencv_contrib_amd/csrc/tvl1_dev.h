@@ -1,0 +1,65 @@
+// Internal launch API of the TV-L1 HIP kernels (tvl1_kernels.hip).  Not part of the C-ABI.
+#pragma once
+#include "mi_common.h"
+
+namespace mi {
+namespace tvl1 {
+
+// All scratch planes of one pyramid level are dense float planes, `ld` floats per row
+// (multiple of 64), `ps` floats between consecutive pairs of the batch.
+struct Geo {
+    int w, h, ld;
+    long long ps;  // pair stride (floats)
+    int batch;
+};
+
+// Device-side loop control (epsilon > 0).  One slot per iteration launch q and pair b:
+//   S[b*Q + q] = {cur_in, active};  E[b*Q + q] = sum(du^2) of launch q, 2^-24 fixed point.
+struct Ctl {
+    int2 *S;
+    unsigned long long *E;
+    int Q;           // slots per pair
+    int q;           // this launch's slot
+    int q_prev;      // previous iteration launch's slot (-1: none, cur_in = 0)
+    int first_of_warp;   // error := max  => always active
+    int reset_cur;       // first launch of a scale: cur_in := 0
+    double thr;      // scaledEpsilon (already rounded through float for CPU_REF)
+};
+
+struct PtrTab {          // per-pair external image pointers (device array)
+    const void *a, *b;   // I0, I1 (convert) or unused
+    void *out;           // flow (pack)
+    long long step_a, step_b, step_out;  // bytes
+};
+
+struct IterPlanes {
+    const float *ix, *iy, *g, *rc;   // I1wx, I1wy, grad, rho_c
+    float *u[2][2];                  // [set][component]
+    float *p[2][4];                  // [set][p11,p12,p21,p22]
+};
+
+// type: MI_8UC1 (x1) or MI_32FC1 (x255)
+int convert(const PtrTab *tab_dev, int type, float *I0, float *I1, const Geo &g, hipStream_t s);
+// flow (MI_32FC2, tab.out) -> u1,u2
+int unpack_flow(const PtrTab *tab_dev, float *u1, float *u2, const Geo &g, hipStream_t s);
+// u (set resolved by ctl) -> flow (MI_32FC2)
+int pack_flow(const PtrTab *tab_dev, const float *u1[2], const float *u2[2], const Geo &g,
+              const Ctl *ctl, int cur_host, hipStream_t s);
+// nplanes (<=3) planes resized in one launch; src set resolved via ctl when src_sets == 2
+int resize(int semantics, int nplanes, const float *const src[3][2], int src_sets, float *const dst[3],
+           const Geo &gs, const Geo &gd, double inv_scale_x, double inv_scale_y,
+           const float post_scale[3], const Ctl *ctl, int cur_host, hipStream_t s);
+int gradient(const float *src, float *dx, float *dy, const Geo &g, hipStream_t s);
+int warp(int semantics, const float *I0, const float *I1, const float *I1x, const float *I1y,
+         const float *u1[2], const float *u2[2], float *I1w, float *I1wx, float *I1wy, float *grad,
+         float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
+         hipStream_t s);
+// one fused iteration (estimateU + estimateDualVariables), set cur -> set cur^1.
+// p_zero: p_in is known to be all-zero (first iteration of a scale) and is not read.
+int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut,
+            bool p_zero, const Ctl *ctl, int cur_host, hipStream_t s);
+
+void host_cubic_table(float tab[128]);  // cv::remap INTER_CUBIC phase table (a = -0.75)
+
+}  // namespace tvl1
+}  // namespace mi

@@ -1,0 +1,681 @@
+// Dual TV-L1 optical flow -- HIP kernels for gfx950 (MI355X, CDNA4), wave64.
+//
+// What the reference runs as 4 kernels + cuda::resize/multiply/setTo/merge/calcSum
+// (modules/cudaoptflow/src/cuda/tvl1flow.cu:59-363, src/tvl1flow.cpp:185-382) is
+// restructured here for an HBM-bound machine:
+//   * estimateU + estimateDualVariables are ONE pass (64 B/px instead of 88), written as a
+//     register row-streaming kernel: a wave owns a 252-px-wide column strip (dwordx4 per
+//     lane), walks down its row band carrying the previous row's p12/p22 and the next
+//     row's new u in VGPRs; x-neighbours come from the adjacent lane (cross-lane move), so
+//     there is no LDS, no barrier and every global access is a coalesced 16-B load/store.
+//   * the convergence test is evaluated on the device (per-launch control slots), so the
+//     whole calc() is stream-ordered -- the reference syncs the host at every check
+//     (src/tvl1flow.cpp:366-368).
+//   * parameters travel as kernel arguments (no __constant__ state): handles never race.
+// Compiled with -ffp-contract=off: the exact-math variants perform the same separately
+// rounded binary32 operations, in the same order, as the CPU reference
+// (modules/optflow/src/tvl1flow.cpp); fast-math variants use explicit fmaf/rcp.
+#include "tvl1_dev.h"
+#include <cfloat>
+
+namespace mi {
+namespace tvl1 {
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ float lane_prev(float v) { return __shfl_up(v, 1); }   // lane n <- n-1
+__device__ __forceinline__ float lane_next(float v) { return __shfl_down(v, 1); } // lane n <- n+1
+
+struct CtlK {  // by-value copy for kernels (Ctl may be absent)
+    int2 *S;
+    unsigned long long *E;
+    int Q, q, q_prev, first_of_warp, reset_cur;
+    double thr;
+};
+static CtlK make_ctlk(const Ctl *c)
+{
+    CtlK k;
+    memset(&k, 0, sizeof(k));
+    k.q_prev = -1;
+    if (c) { k.S = c->S; k.E = c->E; k.Q = c->Q; k.q = c->q; k.q_prev = c->q_prev;
+             k.first_of_warp = c->first_of_warp; k.reset_cur = c->reset_cur; k.thr = c->thr; }
+    return k;
+}
+__device__ __forceinline__ int resolve_cur_k(const CtlK &c, int b, int cur_host)
+{
+    if (!c.S) return cur_host;
+    if (c.q_prev < 0) return 0;
+    const int2 s = c.S[(long long)b * c.Q + c.q_prev];
+    return s.x ^ s.y;
+}
+
+#define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */
+
+// ------------------------------------------------------------------ convert / pack
+__global__ __launch_bounds__(256) void k_convert(const PtrTab *tab, int type, float *I0, float *I1, Geo g)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const PtrTab t = tab[b];
+    const long long o = (long long)b * g.ps + (long long)y * g.ld + x;
+    if (type == MI_8UC1) {
+        // convertTo(CV_32F, 1.0)  cudaoptflow/src/tvl1flow.cpp:200-201
+        I0[o] = (float)((const unsigned char *)t.a)[(long long)y * t.step_a + x];
+        I1[o] = (float)((const unsigned char *)t.b)[(long long)y * t.step_b + x];
+    } else {
+        I0[o] = ((const float *)((const char *)t.a + (long long)y * t.step_a))[x] * 255.0f;
+        I1[o] = ((const float *)((const char *)t.b + (long long)y * t.step_b))[x] * 255.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_flow(const PtrTab *tab, float *u1, float *u2, Geo g)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const PtrTab t = tab[b];
+    const float2 f = ((const float2 *)((const char *)t.out + (long long)y * t.step_out))[x];
+    const long long o = (long long)b * g.ps + (long long)y * g.ld + x;
+    u1[o] = f.x;
+    u2[o] = f.y;
+}
+
+__global__ __launch_bounds__(256) void k_pack_flow(const PtrTab *tab, const float *u1a, const float *u1b,
+                                                   const float *u2a, const float *u2b, Geo g, CtlK ctl, int cur_host)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const float *u1 = cur ? u1b : u1a, *u2 = cur ? u2b : u2a;
+    const PtrTab t = tab[b];
+    const long long o = (long long)b * g.ps + (long long)y * g.ld + x;
+    // cuda::merge -> CV_32FC2  cudaoptflow/src/tvl1flow.cpp:181-182
+    ((float2 *)((char *)t.out + (long long)y * t.step_out))[x] = make_float2(u1[o], u2[o]);
+}
+
+// ------------------------------------------------------------------ resize (pyramid / flow upsample)
+struct ResizeArgs {
+    const float *src[3][2];
+    float *dst[3];
+    float post[3];
+    int nsets;
+    Geo gs, gd;
+    double scale_x, scale_y;  // CPU_REF: 1/inv_scale (double).  CUDA_COMPAT: (float)(1/f) stored as double
+};
+
+template <int SEM>
+__global__ __launch_bounds__(256) void k_resize(ResizeArgs A, CtlK ctl, int cur_host)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int pl = blockIdx.z % 3, b = blockIdx.z / 3;
+    if (dx >= A.gd.w || dy >= A.gd.h || !A.dst[pl]) return;
+    const int cur = A.nsets == 2 ? resolve_cur_k(ctl, b, cur_host) : 0;
+    const float *S = A.src[pl][cur] + (long long)b * A.gs.ps;
+    const int sw = A.gs.w, sh = A.gs.h, ld = A.gs.ld;
+    float out;
+    if (SEM == MI_SEM_CPU_REF) {
+        // cv::resize INTER_LINEAR f32 (main repo imgproc/resize.cpp): half-pixel centres,
+        // coordinates in double -> float, horizontal pass then vertical pass in float.
+        float fx = (float)((dx + 0.5) * A.scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+        float fy = (float)((dy + 0.5) * A.scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        const int sx1 = min(sx + 1, sw - 1);
+        const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+        const float *R0 = S + (long long)y0 * ld, *R1 = S + (long long)y1 * ld;
+        const float h0 = R0[sx] * a0 + R0[sx1] * a1;
+        const float h1 = R1[sx] * a0 + R1[sx1] * a1;
+        out = h0 * b0 + h1 * b1;
+    } else {
+        // cudawarping/src/cuda/resize.cu:234-269
+        const float fx = (float)A.scale_x, fy = (float)A.scale_y;
+        const float src_x = (float)dx * fx, src_y = (float)dy * fy;
+        const int x1 = (int)floorf(src_x), y1 = (int)floorf(src_y);
+        const int x2 = x1 + 1, y2 = y1 + 1;
+        const int x2r = min(x2, sw - 1), y2r = min(y2, sh - 1);
+        out = 0.f;
+        out = out + S[(long long)y1 * ld + x1] * (((float)x2 - src_x) * ((float)y2 - src_y));
+        out = out + S[(long long)y1 * ld + x2r] * ((src_x - (float)x1) * ((float)y2 - src_y));
+        out = out + S[(long long)y2r * ld + x1] * (((float)x2 - src_x) * (src_y - (float)y1));
+        out = out + S[(long long)y2r * ld + x2r] * ((src_x - (float)x1) * (src_y - (float)y1));
+    }
+    const float ps = A.post[pl];
+    if (ps != 1.0f) out = out * ps;  // cuda::multiply(u, 1/scaleStep)  tvl1flow.cpp:299-300
+    A.dst[pl][(long long)b * A.gd.ps + (long long)dy * A.gd.ld + dx] = out;
+}
+
+// ------------------------------------------------------------------ centered gradient
+// tvl1flow.cu:59-69 == optflow/src/tvl1flow.cpp:688-770 (one-sided x0.5 at borders == clamp)
+__global__ __launch_bounds__(256) void k_gradient(const float *src, float *dxp, float *dyp, Geo g)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const float *S = src + (long long)b * g.ps;
+    const long long r = (long long)y * g.ld;
+    const float l = S[r + max(x - 1, 0)], rr = S[r + min(x + 1, g.w - 1)];
+    const float u = S[(long long)max(y - 1, 0) * g.ld + x], d = S[(long long)min(y + 1, g.h - 1) * g.ld + x];
+    const long long o = (long long)b * g.ps + r + x;
+    dxp[o] = 0.5f * (rr - l);
+    dyp[o] = 0.5f * (d - u);
+}
+
+// ------------------------------------------------------------------ warp
+struct WarpArgs {
+    const float *I0, *I1, *I1x, *I1y;
+    const float *u1[2], *u2[2];
+    float *I1w, *I1wx, *I1wy, *grad, *rho;
+    const float *tab;  // 32x4 cubic phase table (CPU_REF)
+    Geo g;
+};
+
+__device__ __forceinline__ float bicubic_coeff_cuda(float x_)
+{
+    // tvl1flow.cu:89-104 (Keys a = -0.5)
+    const float x = fabsf(x_);
+    if (x <= 1.0f) return x * x * (1.5f * x - 2.5f) + 1.0f;
+    else if (x < 2.0f) return x * (x * (-0.5f * x + 2.5f) - 4.0f) + 2.0f;
+    return 0.0f;
+}
+
+template <int SEM>
+__global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host)
+{
+    __shared__ float s_tab[128];
+    if (SEM == MI_SEM_CPU_REF) {
+        if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
+        __syncthreads();
+    }
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    if (x >= W || y >= H) return;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const long long pb = (long long)b * A.g.ps;
+    const long long o = pb + (long long)y * ld + x;
+    const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
+    const float *P0 = A.I1 + pb, *P1 = A.I1x + pb, *P2 = A.I1y + pb;
+    float v0, v1, v2;
+    if (SEM == MI_SEM_CPU_REF) {
+        // buildFlowMap + cv::remap(INTER_CUBIC, BORDER_CONSTANT 0):
+        // optflow/src/tvl1flow.cpp:650-666,1371-1374; map quantised to 1/32 px.
+        const float mx = (float)x + u1v, my = (float)y + u2v;
+        const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+        const int sx = min(max(qx >> 5, -32768), 32767) - 1;
+        const int sy = min(max(qy >> 5, -32768), 32767) - 1;
+        const float *wx = s_tab + (qx & 31) * 4, *wy = s_tab + (qy & 31) * 4;
+        float w[16];
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) w[k1 * 4 + k2] = wy[k1] * wx[k2];
+        if ((unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0)) {
+            const long long base = (long long)sy * ld + sx;
+            float s0, s1, s2;
+            {
+                const float *S = P0 + base;
+                s0 = S[0] * w[0] + S[1] * w[1] + S[2] * w[2] + S[3] * w[3]; S += ld;
+                s0 += S[0] * w[4] + S[1] * w[5] + S[2] * w[6] + S[3] * w[7]; S += ld;
+                s0 += S[0] * w[8] + S[1] * w[9] + S[2] * w[10] + S[3] * w[11]; S += ld;
+                s0 += S[0] * w[12] + S[1] * w[13] + S[2] * w[14] + S[3] * w[15];
+            }
+            {
+                const float *S = P1 + base;
+                s1 = S[0] * w[0] + S[1] * w[1] + S[2] * w[2] + S[3] * w[3]; S += ld;
+                s1 += S[0] * w[4] + S[1] * w[5] + S[2] * w[6] + S[3] * w[7]; S += ld;
+                s1 += S[0] * w[8] + S[1] * w[9] + S[2] * w[10] + S[3] * w[11]; S += ld;
+                s1 += S[0] * w[12] + S[1] * w[13] + S[2] * w[14] + S[3] * w[15];
+            }
+            {
+                const float *S = P2 + base;
+                s2 = S[0] * w[0] + S[1] * w[1] + S[2] * w[2] + S[3] * w[3]; S += ld;
+                s2 += S[0] * w[4] + S[1] * w[5] + S[2] * w[6] + S[3] * w[7]; S += ld;
+                s2 += S[0] * w[8] + S[1] * w[9] + S[2] * w[10] + S[3] * w[11]; S += ld;
+                s2 += S[0] * w[12] + S[1] * w[13] + S[2] * w[14] + S[3] * w[15];
+            }
+            v0 = s0; v1 = s1; v2 = s2;
+        } else if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
+            v0 = v1 = v2 = 0.f;
+        } else {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int yi = sy + i;
+                if (yi < 0 || yi >= H) continue;
+                for (int j = 0; j < 4; ++j) {
+                    const int xj = sx + j;
+                    if (xj < 0 || xj >= W) continue;
+                    const long long a = (long long)yi * ld + xj;
+                    s0 += (P0[a] - 0.f) * w[i * 4 + j];
+                    s1 += (P1[a] - 0.f) * w[i * 4 + j];
+                    s2 += (P2[a] - 0.f) * w[i * 4 + j];
+                }
+            }
+            v0 = s0; v1 = s1; v2 = s2;
+        }
+    } else {
+        // tvl1flow.cu:106-149: normalised bicubic, point-sampled clamp-addressed reads
+        const float wxp = (float)x + u1v, wyp = (float)y + u2v;
+        const int xmin = (int)ceilf(wxp - 2.0f), xmax = (int)floorf(wxp + 2.0f);
+        const int ymin = (int)ceilf(wyp - 2.0f), ymax = (int)floorf(wyp + 2.0f);
+        float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
+        for (int cy = ymin; cy <= ymax; ++cy)
+            for (int cx = xmin; cx <= xmax; ++cx) {
+                const float wgt = bicubic_coeff_cuda(wxp - (float)cx) * bicubic_coeff_cuda(wyp - (float)cy);
+                const long long a = (long long)min(max(cy, 0), H - 1) * ld + min(max(cx, 0), W - 1);
+                sum += wgt * P0[a];
+                sumx += wgt * P1[a];
+                sumy += wgt * P2[a];
+                wsum += wgt;
+            }
+        const float coeff = 1.0f / wsum;
+        v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
+    }
+    if (A.I1w) A.I1w[o] = v0;
+    A.I1wx[o] = v1;
+    A.I1wy[o] = v2;
+    // calcGradRho  optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163
+    const float Ix2 = v1 * v1, Iy2 = v2 * v2;
+    A.grad[o] = Ix2 + Iy2;
+    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
+}
+
+// ------------------------------------------------------------------ fused iteration
+// Per-pixel math.  EXACT: the CPU reference's operations (optflow/src/tvl1flow.cpp:989-1041
+// estimateV, :857-899 divergence, :1096-1112 estimateU, :1140-1181 dual update with hypot in
+// double) in reference order.  !EXACT: same formulas with fmaf + v_rcp/v_sqrt approximations.
+template <bool EXACT>
+__device__ __forceinline__ void px_update_u(float ix, float iy, float g, float rc, float u1, float u2,
+                                            float div1, float div2, float l_t, float theta,
+                                            float &u1n, float &u2n, float &err)
+{
+    float rho, d1 = 0.f, d2 = 0.f;
+    if (EXACT) rho = rc + (ix * u1 + iy * u2);
+    else rho = rc + fmaf(ix, u1, iy * u2);
+    const float ltg = l_t * g;
+    if (rho < -ltg) { d1 = l_t * ix; d2 = l_t * iy; }
+    else if (rho > ltg) { d1 = -l_t * ix; d2 = -l_t * iy; }
+    else if (g > FLT_EPSILON) {
+        const float fi = EXACT ? (-rho / g) : (-rho * __builtin_amdgcn_rcpf(g));
+        d1 = fi * ix; d2 = fi * iy;
+    }
+    if (EXACT) {
+        const float v1 = u1 + d1, v2 = u2 + d2;
+        u1n = v1 + theta * div1;
+        u2n = v2 + theta * div2;
+    } else {
+        u1n = fmaf(theta, div1, u1 + d1);
+        u2n = fmaf(theta, div2, u2 + d2);
+    }
+    const float e1 = u1n - u1, e2 = u2n - u2;
+    err = EXACT ? (e1 * e1 + e2 * e2) : fmaf(e1, e1, e2 * e2);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void px_update_p(float ux, float uy, float taut, float &pa, float &pb)
+{
+    if (EXACT) {
+        const float gn = (float)sqrt((double)ux * (double)ux + (double)uy * (double)uy);
+        const float ng = 1.0f + taut * gn;
+        pa = (pa + taut * ux) / ng;
+        pb = (pb + taut * uy) / ng;
+    } else {
+        const float gn = __builtin_sqrtf(fmaf(ux, ux, uy * uy));
+        const float r = __builtin_amdgcn_rcpf(fmaf(taut, gn, 1.0f));
+        pa = fmaf(taut, ux, pa) * r;
+        pb = fmaf(taut, uy, pb) * r;
+    }
+}
+
+struct IterArgs {
+    IterPlanes pl;
+    Geo g;
+    float l_t, theta, taut;
+    int rows_per_wave;
+};
+
+#define STRIP_W 252  // 63 lanes x 4 px own results; lane 63 only supplies u_new(x+1) to lane 62
+
+__device__ __forceinline__ float4 ld4(const float *p, long long off, bool ok)
+{
+    return ok ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void st4(float *p, long long off, bool ok, const float v[4])
+{
+    if (ok) *reinterpret_cast<float4 *>(p + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+struct RowIn {
+    float ix[4], iy[4], g[4], rc[4], u1[4], u2[4], p11[4], p12[4], p21[4], p22[4];
+};
+
+#define UNPACK4(dst, v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+
+template <bool PZ>
+__device__ __forceinline__ void load_row(RowIn &r, const IterArgs &A, const float *const u[2], const float *const p[4],
+                                         long long off, bool ok)
+{
+    float4 t;
+    t = ld4(A.pl.ix, off, ok); UNPACK4(r.ix, t);
+    t = ld4(A.pl.iy, off, ok); UNPACK4(r.iy, t);
+    t = ld4(A.pl.g, off, ok);  UNPACK4(r.g, t);
+    t = ld4(A.pl.rc, off, ok); UNPACK4(r.rc, t);
+    t = ld4(u[0], off, ok);    UNPACK4(r.u1, t);
+    t = ld4(u[1], off, ok);    UNPACK4(r.u2, t);
+    if (!PZ) {
+        t = ld4(p[0], off, ok); UNPACK4(r.p11, t);
+        t = ld4(p[1], off, ok); UNPACK4(r.p12, t);
+        t = ld4(p[2], off, ok); UNPACK4(r.p21, t);
+        t = ld4(p[3], off, ok); UNPACK4(r.p22, t);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.p11[j] = r.p12[j] = r.p21[j] = r.p22[j] = 0.f;
+    }
+}
+
+// u_new of one row.  up12/up22 = p12,p22 of the row above (unused when y == 0);
+// l11/l21 = p11,p21 at x-1 of this lane's first pixel.
+template <bool EXACT>
+__device__ __forceinline__ void row_update_u(const RowIn &r, const float up12[4], const float up22[4],
+                                             float l11, float l21, int xb, int y, float l_t, float theta,
+                                             float u1n[4], float u2n[4], float e[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = xb + j;
+        const float p11l = j ? r.p11[j - 1] : l11;
+        const float p21l = j ? r.p21[j - 1] : l21;
+        float d1, d2;
+        // divergence with first-row/column cases, optflow/src/tvl1flow.cpp:857-899
+        if (y > 0) {
+            if (x > 0) {
+                d1 = (r.p11[j] - p11l) + (r.p12[j] - up12[j]);
+                d2 = (r.p21[j] - p21l) + (r.p22[j] - up22[j]);
+            } else {
+                d1 = r.p11[j] + r.p12[j] - up12[j];
+                d2 = r.p21[j] + r.p22[j] - up22[j];
+            }
+        } else {
+            if (x > 0) {
+                d1 = r.p11[j] - p11l + r.p12[j];
+                d2 = r.p21[j] - p21l + r.p22[j];
+            } else {
+                d1 = r.p11[j] + r.p12[j];
+                d2 = r.p21[j] + r.p22[j];
+            }
+        }
+        px_update_u<EXACT>(r.ix[j], r.iy[j], r.g[j], r.rc[j], r.u1[j], r.u2[j], d1, d2, l_t, theta,
+                           u1n[j], u2n[j], e[j]);
+    }
+}
+
+template <bool EXACT, bool PZ, bool CHECK>
+__global__ __launch_bounds__(256) void k_iterate(IterArgs A, CtlK ctl, int cur_host)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x, b = blockIdx.z;
+    const int band = blockIdx.y * 4 + wave;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+
+    int cur = cur_host;
+    if (CHECK) {
+        // loop control of procOneScale (optflow/src/tvl1flow.cpp:1376-1390), evaluated per launch
+        int cur_in = 0, active = 1;
+        if (ctl.q_prev >= 0) {
+            const long long sp = (long long)b * ctl.Q + ctl.q_prev;
+            const int2 s = ctl.S[sp];
+            cur_in = ctl.reset_cur ? 0 : (s.x ^ s.y);
+            if (!ctl.first_of_warp) {
+                const double e = (double)ctl.E[sp] * (1.0 / ERR_FIX_SCALE);
+                active = s.y && (e > ctl.thr);
+            }
+        }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+            ctl.S[(long long)b * ctl.Q + ctl.q] = make_int2(cur_in, active);
+        if (!active) return;
+        cur = cur_in;
+    }
+
+    const int y0 = band * A.rows_per_wave;
+    if (y0 >= H) return;
+    const int y1 = min(y0 + A.rows_per_wave, H);
+    const int x0 = strip * STRIP_W;
+    const int xb = x0 + lane * 4;
+    const bool ok = xb < W;
+    const long long pb = (long long)b * A.g.ps;
+
+    const float *uin[2] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb};
+    const float *pin[4] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb};
+    float *uout[2] = {A.pl.u[cur ^ 1][0] + pb, A.pl.u[cur ^ 1][1] + pb};
+    float *pout[4] = {A.pl.p[cur ^ 1][0] + pb, A.pl.p[cur ^ 1][1] + pb, A.pl.p[cur ^ 1][2] + pb, A.pl.p[cur ^ 1][3] + pb};
+    IterArgs B = A;
+    B.pl.ix += pb; B.pl.iy += pb; B.pl.g += pb; B.pl.rc += pb;
+
+    // p12/p22 of row y0-1
+    float up12[4] = {0, 0, 0, 0}, up22[4] = {0, 0, 0, 0};
+    if (!PZ && y0 > 0) {
+        const long long off = (long long)(y0 - 1) * ld + xb;
+        float4 t = ld4(pin[1], off, ok); UNPACK4(up12, t);
+        t = ld4(pin[3], off, ok); UNPACK4(up22, t);
+    }
+
+    RowIn r;
+    float u1c[4], u2c[4], ec[4];
+    {
+        const long long off = (long long)y0 * ld + xb;
+        load_row<PZ>(r, B, uin, pin, off, ok);
+        float l11 = lane_prev(r.p11[3]), l21 = lane_prev(r.p21[3]);
+        if (!PZ && lane == 0 && x0 > 0) {
+            l11 = pin[0][(long long)y0 * ld + x0 - 1];
+            l21 = pin[2][(long long)y0 * ld + x0 - 1];
+        }
+        row_update_u<EXACT>(r, up12, up22, l11, l21, xb, y0, A.l_t, A.theta, u1c, u2c, ec);
+    }
+    float errsum = 0.f;
+    const bool own = lane < 63;
+
+    for (int y = y0; y < y1; ++y) {
+        // current row: r (inputs), u1c/u2c (new u), ec (error terms)
+        float p11c[4], p12c[4], p21c[4], p22c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { p11c[j] = r.p11[j]; p12c[j] = r.p12[j]; p21c[j] = r.p21[j]; p22c[j] = r.p22[j]; }
+        float u1d[4], u2d[4], ed[4];
+        const bool has_next = (y + 1 < H);
+        if (has_next) {
+            const long long off = (long long)(y + 1) * ld + xb;
+            // p12,p22 of the current row become the "row above" of the next row
+            float c12[4], c22[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c12[j] = r.p12[j]; c22[j] = r.p22[j]; }
+            load_row<PZ>(r, B, uin, pin, off, ok);
+            float l11 = lane_prev(r.p11[3]), l21 = lane_prev(r.p21[3]);
+            if (!PZ && lane == 0 && x0 > 0) {
+                l11 = pin[0][(long long)(y + 1) * ld + x0 - 1];
+                l21 = pin[2][(long long)(y + 1) * ld + x0 - 1];
+            }
+            row_update_u<EXACT>(r, c12, c22, l11, l21, xb, y + 1, A.l_t, A.theta, u1d, u2d, ed);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { u1d[j] = u1c[j]; u2d[j] = u2c[j]; ed[j] = 0.f; }
+        }
+        // forward differences (optflow/src/tvl1flow.cpp:775-840: 0 at the last row/col)
+        const float r1 = lane_next(u1c[0]), r2 = lane_next(u2c[0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = xb + j;
+            const float n1 = j < 3 ? u1c[j + 1] : r1;
+            const float n2 = j < 3 ? u2c[j + 1] : r2;
+            const float u1x = (x + 1 < W) ? n1 - u1c[j] : 0.f;
+            const float u2x = (x + 1 < W) ? n2 - u2c[j] : 0.f;
+            const float u1y = has_next ? u1d[j] - u1c[j] : 0.f;
+            const float u2y = has_next ? u2d[j] - u2c[j] : 0.f;
+            px_update_p<EXACT>(u1x, u1y, A.taut, p11c[j], p12c[j]);
+            px_update_p<EXACT>(u2x, u2y, A.taut, p21c[j], p22c[j]);
+            if (CHECK && own && x < W) errsum += ec[j];
+        }
+        const long long off = (long long)y * ld + xb;
+        const bool st = ok && own;
+        st4(uout[0], off, st, u1c);
+        st4(uout[1], off, st, u2c);
+        st4(pout[0], off, st, p11c);
+        st4(pout[1], off, st, p12c);
+        st4(pout[2], off, st, p21c);
+        st4(pout[3], off, st, p22c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { u1c[j] = u1d[j]; u2c[j] = u2d[j]; ec[j] = ed[j]; }
+    }
+
+    if (CHECK) {
+        double s = (double)errsum;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const unsigned long long f = (unsigned long long)(s * ERR_FIX_SCALE + 0.5);
+            atomicAdd(&ctl.E[(long long)b * ctl.Q + ctl.q], f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host launchers
+static inline dim3 grid2d(const Geo &g, int z) { return dim3(div_up(g.w, 64), div_up(g.h, 4), z); }
+
+int convert(const PtrTab *tab, int type, float *I0, float *I1, const Geo &g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_convert, grid2d(g, g.batch), dim3(256), 0, s, tab, type, I0, I1, g);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int unpack_flow(const PtrTab *tab, float *u1, float *u2, const Geo &g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_unpack_flow, grid2d(g, g.batch), dim3(256), 0, s, tab, u1, u2, g);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int pack_flow(const PtrTab *tab, const float *u1[2], const float *u2[2], const Geo &g, const Ctl *ctl,
+              int cur_host, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack_flow, grid2d(g, g.batch), dim3(256), 0, s, tab, u1[0], u1[1], u2[0], u2[1], g,
+                       make_ctlk(ctl), cur_host);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int resize(int semantics, int nplanes, const float *const src[3][2], int src_sets, float *const dst[3],
+           const Geo &gs, const Geo &gd, double inv_scale_x, double inv_scale_y, const float post_scale[3],
+           const Ctl *ctl, int cur_host, hipStream_t s)
+{
+    ResizeArgs A;
+    memset(&A, 0, sizeof(A));
+    for (int i = 0; i < 3; ++i) {
+        A.src[i][0] = i < nplanes ? src[i][0] : nullptr;
+        A.src[i][1] = i < nplanes ? src[i][src_sets == 2 ? 1 : 0] : nullptr;
+        A.dst[i] = i < nplanes ? dst[i] : nullptr;
+        A.post[i] = i < nplanes ? post_scale[i] : 1.f;
+    }
+    A.nsets = src_sets;
+    A.gs = gs;
+    A.gd = gd;
+    const CtlK ck = make_ctlk(ctl);
+    const dim3 grid(div_up(gd.w, 64), div_up(gd.h, 4), 3 * gd.batch);
+    if (semantics == MI_SEM_CPU_REF) {
+        A.scale_x = 1.0 / inv_scale_x;
+        A.scale_y = 1.0 / inv_scale_y;
+        hipLaunchKernelGGL(k_resize<MI_SEM_CPU_REF>, grid, dim3(256), 0, s, A, ck, cur_host);
+    } else {
+        A.scale_x = (double)(float)(1.0 / inv_scale_x);  // cudawarping/src/resize.cpp:107
+        A.scale_y = (double)(float)(1.0 / inv_scale_y);
+        hipLaunchKernelGGL(k_resize<MI_SEM_CUDA_COMPAT>, grid, dim3(256), 0, s, A, ck, cur_host);
+    }
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int gradient(const float *src, float *dx, float *dy, const Geo &g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gradient, grid2d(g, g.batch), dim3(256), 0, s, src, dx, dy, g);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int warp(int semantics, const float *I0, const float *I1, const float *I1x, const float *I1y,
+         const float *u1[2], const float *u2[2], float *I1w, float *I1wx, float *I1wy, float *grad, float *rho,
+         const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host, hipStream_t s)
+{
+    WarpArgs A;
+    A.I0 = I0; A.I1 = I1; A.I1x = I1x; A.I1y = I1y;
+    A.u1[0] = u1[0]; A.u1[1] = u1[1]; A.u2[0] = u2[0]; A.u2[1] = u2[1];
+    A.I1w = I1w; A.I1wx = I1wx; A.I1wy = I1wy; A.grad = grad; A.rho = rho;
+    A.tab = cubic_tab_dev;
+    A.g = g;
+    const CtlK ck = make_ctlk(ctl);
+    if (semantics == MI_SEM_CPU_REF)
+        hipLaunchKernelGGL(k_warp<MI_SEM_CPU_REF>, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
+    else
+        hipLaunchKernelGGL(k_warp<MI_SEM_CUDA_COMPAT>, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+static int pick_rows_per_wave(const Geo &g)
+{
+    // enough waves to fill 256 CUs x >=8 waves while keeping the 1-row halo overhead small
+    const int strips = div_up(g.w, STRIP_W);
+    int R = 32;
+    while (R > 8 && (long long)strips * div_up(g.h, R) * g.batch < 4096) R >>= 1;
+    return R;
+}
+
+template <bool EXACT, bool PZ>
+static void launch_iter(const IterArgs &A, const dim3 grid, const Ctl *ctl, int cur_host, hipStream_t s)
+{
+    const CtlK ck = make_ctlk(ctl);
+    if (ctl && ctl->S)
+        hipLaunchKernelGGL((k_iterate<EXACT, PZ, true>), grid, dim3(256), 0, s, A, ck, cur_host);
+    else
+        hipLaunchKernelGGL((k_iterate<EXACT, PZ, false>), grid, dim3(256), 0, s, A, ck, cur_host);
+}
+
+int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
+            const Ctl *ctl, int cur_host, hipStream_t s)
+{
+    IterArgs A;
+    A.pl = pl;
+    A.g = g;
+    A.l_t = l_t; A.theta = theta; A.taut = taut;
+    A.rows_per_wave = pick_rows_per_wave(g);
+    const dim3 grid(div_up(g.w, STRIP_W), div_up(div_up(g.h, A.rows_per_wave), 4), g.batch);
+    if (exact) { if (p_zero) launch_iter<true, true>(A, grid, ctl, cur_host, s); else launch_iter<true, false>(A, grid, ctl, cur_host, s); }
+    else       { if (p_zero) launch_iter<false, true>(A, grid, ctl, cur_host, s); else launch_iter<false, false>(A, grid, ctl, cur_host, s); }
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+void host_cubic_table(float tab[128])
+{
+    // interpolateCubic / initInterTab1D of cv::remap (main repo imgproc/imgwarp.cpp), A = -0.75
+    const float A = -0.75f, scale = 1.f / 32;
+    for (int i = 0; i < 32; ++i) {
+        const float x = (float)i * scale;
+        float *c = tab + i * 4;
+        c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+        c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+        c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+    }
+}
+
+}  // namespace tvl1
+}  // namespace mi

@@ -1,0 +1,181 @@
+"""Python mirror of the reference's `cv2.cuda` classes for the hot path, over the miflow C-ABI.
+
+Names, argument meaning and error behaviour follow the reference headers
+(modules/cudaoptflow/include/opencv2/cudaoptflow.hpp:305-386 for OpticalFlowDual_TVL1); device
+images are torch CUDA tensors standing in for cv::cuda::GpuMat (pitched row-major; see
+capi.mat_from_tensor).  torch is plumbing only: allocation, streams, distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import capi
+from .capi import MiError
+
+
+class OpticalFlowDual_TVL1:
+    """cv::cuda::OpticalFlowDual_TVL1 (cudaoptflow.hpp:305-386).
+
+    Extra, non-reference knobs (C-ABI extensions): `semantics` (0 = arithmetic of the CPU class
+    cv::optflow::DualTVL1OpticalFlow, the acceptance reference; 1 = arithmetic of the CUDA kernels),
+    `exactMath`, `innerIterations`/`medianFiltering` (CPU-class parameters).
+    """
+
+    def __init__(self, params: capi.TVL1Params):
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_tvl1_create(C.byref(params), C.byref(self._h)))
+        self._p = params
+
+    # -- factory with the reference's signature and defaults (cudaoptflow.hpp:375-385)
+    @staticmethod
+    def create(tau=0.25, lambda_=0.15, theta=0.3, nscales=5, warps=5, epsilon=0.01, iterations=300,
+               scaleStep=0.8, gamma=0.0, useInitialFlow=False, *, semantics=capi.MI_SEM_CPU_REF,
+               exactMath=True, innerIterations=1, medianFiltering=1, timeBlock=0) -> "OpticalFlowDual_TVL1":
+        p = capi.TVL1Params()
+        capi.lib().mi_tvl1_default_params(C.byref(p))
+        p.tau, p.lambda_, p.theta, p.nscales, p.warps = tau, lambda_, theta, nscales, warps
+        p.epsilon, p.iterations, p.scale_step, p.gamma = epsilon, iterations, scaleStep, gamma
+        p.use_initial_flow = int(bool(useInitialFlow))
+        p.semantics, p.exact_math = semantics, int(bool(exactMath))
+        p.inner_iterations, p.median_filtering, p.time_block = innerIterations, medianFiltering, timeBlock
+        return OpticalFlowDual_TVL1(p)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                capi.lib().mi_tvl1_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def getDefaultName(self) -> str:  # cudaoptflow/src/tvl1flow.cpp:122
+        return "DenseOpticalFlow.OpticalFlowDual_TVL1"
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+        capi.check(capi.lib().mi_tvl1_set_params(self._h, C.byref(self._p)))
+
+    # getters / setters, cudaoptflow/src/tvl1flow.cpp:90-118
+    def getTau(self): return self._p.tau
+    def setTau(self, v): self._set(tau=v)
+    def getLambda(self): return self._p.lambda_
+    def setLambda(self, v): self._set(lambda_=v)
+    def getGamma(self): return self._p.gamma
+    def setGamma(self, v): self._set(gamma=v)
+    def getTheta(self): return self._p.theta
+    def setTheta(self, v): self._set(theta=v)
+    def getNumScales(self): return self._p.nscales
+    def setNumScales(self, v): self._set(nscales=v)
+    def getNumWarps(self): return self._p.warps
+    def setNumWarps(self, v): self._set(warps=v)
+    def getEpsilon(self): return self._p.epsilon
+    def setEpsilon(self, v): self._set(epsilon=v)
+    def getNumIterations(self): return self._p.iterations
+    def setNumIterations(self, v): self._set(iterations=v)
+    def getScaleStep(self): return self._p.scale_step
+    def setScaleStep(self, v): self._set(scale_step=v)
+    def getUseInitialFlow(self): return bool(self._p.use_initial_flow)
+    def setUseInitialFlow(self, v): self._set(use_initial_flow=int(bool(v)))
+
+    def calc(self, I0, I1, flow=None, stream=None):
+        """DenseOpticalFlow::calc(I0, I1, flow, stream) (cudaoptflow.hpp:80).  Returns flow (H,W,2) f32."""
+        import torch
+        if flow is None:
+            if self._p.use_initial_flow:
+                raise MiError(-1, "useInitialFlow requires a flow argument")
+            flow = torch.empty((I0.shape[0], I0.shape[1], 2), dtype=torch.float32, device=I0.device)
+        m0, m1, mf = capi.mat_from_tensor(I0), capi.mat_from_tensor(I1), capi.mat_from_tensor(flow)
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        capi.check(capi.lib().mi_tvl1_calc(self._h, C.byref(m0), C.byref(m1), C.byref(mf), sp))
+        return flow
+
+    def calc_batch(self, I0s, I1s, flows=None, stream=None):
+        """n independent pairs in one pass (batched-frames mode).  I0s/I1s: sequences of tensors, or
+        one (N,H,W) tensor each; flows: list or (N,H,W,2)."""
+        import torch
+        n = len(I0s)
+        if flows is None:
+            flows = torch.empty((n, I0s[0].shape[0], I0s[0].shape[1], 2), dtype=torch.float32, device=I0s[0].device)
+        A0 = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in I0s])
+        A1 = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in I1s])
+        AF = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in flows])
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        capi.check(capi.lib().mi_tvl1_calc_batch(self._h, n, A0, A1, AF, sp))
+        return flows
+
+    def setProfiling(self, on=True):
+        capi.check(capi.lib().mi_tvl1_set_profiling(self._h, int(bool(on))))
+
+    def getProfile(self):
+        """(ms inside the iteration-launch regions, launches, algorithmic bytes) of the last calc."""
+        ms, n, by = C.c_double(), C.c_longlong(), C.c_double()
+        capi.check(capi.lib().mi_tvl1_get_profile(self._h, C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
+
+    def lastIterations(self, pair=0):
+        """Executed inner iterations [scale][warp] of the last calc (epsilon > 0: device-decided)."""
+        ns = C.c_int()
+        cap = 32 * 64
+        buf = (C.c_int * cap)()
+        capi.check(capi.lib().mi_tvl1_last_iterations(self._h, pair, C.byref(ns), buf, cap, capi.current_stream_ptr()))
+        nw = self._p.warps
+        return [[buf[s * nw + w] for w in range(nw)] for s in range(ns.value)]
+
+
+# ---------------------------------------------------------------------------------------------
+# stage-level functions (the reference's internal device-layer boundary), used by parity tests
+def _m(t):
+    return capi.mat_from_tensor(t)
+
+
+def tvl1_centeredGradient(src):
+    import torch
+    dx, dy = torch.empty_like(src), torch.empty_like(src)
+    capi.check(capi.lib().mi_tvl1_centered_gradient(C.byref(_m(src)), C.byref(_m(dx)), C.byref(_m(dy)), capi.current_stream_ptr()))
+    return dx, dy
+
+
+def tvl1_warpBackward(semantics, I0, I1, I1x, I1y, u1, u2):
+    import torch
+    torch.cuda.synchronize()
+    outs = [torch.empty_like(I0) for _ in range(5)]
+    args = [C.byref(_m(t)) for t in (I0, I1, I1x, I1y, u1, u2, *outs)]
+    capi.check(capi.lib().mi_tvl1_warp_backward(semantics, *args))
+    return tuple(outs)
+
+
+def tvl1_iterate(I1wx, I1wy, grad, rho_c, u, p, l_t, theta, taut, niter=1, exact=True, time_block=0, want_err=True):
+    """u: [u1,u2], p: [p11,p12,p21,p22] -> (u_out, p_out, err[niter])."""
+    import torch
+    u_out = [torch.empty_like(t) for t in u]
+    p_out = [torch.empty_like(t) for t in p]
+    U = (capi.Mat * 2)(*[_m(t) for t in u]); P = (capi.Mat * 4)(*[_m(t) for t in p])
+    UO = (capi.Mat * 2)(*[_m(t) for t in u_out]); PO = (capi.Mat * 4)(*[_m(t) for t in p_out])
+    err = (C.c_double * niter)()
+    capi.check(capi.lib().mi_tvl1_iterate(int(exact), time_block, niter, C.byref(_m(I1wx)), C.byref(_m(I1wy)),
+                                          C.byref(_m(grad)), C.byref(_m(rho_c)), U, P, UO, PO, l_t, theta, taut,
+                                          err if want_err else None, capi.current_stream_ptr()))
+    torch.cuda.synchronize()
+    return u_out, p_out, list(err)
+
+
+def resize_linear(src, dsize=None, fx=0.0, fy=0.0, semantics=capi.MI_SEM_CPU_REF, post_scale=1.0):
+    """cv::resize / cv::cuda::resize (INTER_LINEAR, CV_32FC1).  dsize = (width, height)."""
+    import torch
+    h, w = src.shape
+    if dsize is None:
+        dw, dh = int(round_half_even(w * fx)), int(round_half_even(h * fy))
+        explicit = 0
+    else:
+        dw, dh = dsize
+        explicit = 1
+    dst = torch.empty((dh, dw), dtype=torch.float32, device=src.device)
+    capi.check(capi.lib().mi_resize_linear(semantics, C.byref(_m(src)), C.byref(_m(dst)), fx, fy, explicit,
+                                           post_scale, capi.current_stream_ptr()))
+    return dst
+
+
+def round_half_even(v: float) -> int:
+    import numpy as np
+    return int(np.rint(v))

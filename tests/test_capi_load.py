@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/miflow/c_api.h declares; without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+
+import pytest
+
+from opencv_contrib_amd import capi
+
+
+def test_library_built_in_tree():
+    assert os.path.exists(capi.LIB_PATH), "run python -m opencv_contrib_amd.build"
+
+
+def test_exports_every_declared_symbol():
+    L = C.CDLL(capi.LIB_PATH)
+    declared = capi.declared_symbols()
+    assert len(declared) >= 20
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, f"declared in c_api.h but not exported: {missing}"
+
+
+def test_binding_covers_header():
+    L = capi.lib()
+    for s in capi.declared_symbols():
+        assert getattr(L, s).argtypes is not None, f"capi.py does not bind {s}"
+
+
+def test_default_params_match_reference():
+    # cv::cuda::OpticalFlowDual_TVL1::create defaults, cudaoptflow.hpp:375-385
+    p = capi.TVL1Params()
+    capi.lib().mi_tvl1_default_params(C.byref(p))
+    assert (p.tau, p.lambda_, p.theta, p.nscales, p.warps) == (0.25, 0.15, 0.3, 5, 5)
+    assert (p.epsilon, p.iterations, p.scale_step, p.gamma, p.use_initial_flow) == (0.01, 300, 0.8, 0.0, 0)
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = capi.lib()
+    assert L.mi_device_count() == 0
+    p = capi.TVL1Params()
+    L.mi_tvl1_default_params(C.byref(p))
+    h = C.c_void_p()
+    rc = L.mi_tvl1_create(C.byref(p), C.byref(h))
+    assert rc == -7 and b"no CPU fallback" in L.mi_last_error()
+    from opencv_contrib_amd import cuda
+    with pytest.raises(capi.MiError):
+        cuda.OpticalFlowDual_TVL1.create()
+
+
+def test_bad_params_rejected_before_device():
+    L = capi.lib()
+    p = capi.TVL1Params()
+    L.mi_tvl1_default_params(C.byref(p))
+    p.nscales = 0  # CV_Assert( nscales_ > 0 ), cudaoptflow/src/tvl1flow.cpp:191
+    h = C.c_void_p()
+    assert L.mi_tvl1_create(C.byref(p), C.byref(h)) == -1

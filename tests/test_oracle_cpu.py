@@ -1,0 +1,137 @@
+"""CPU tests of the oracle (test infrastructure): analytic properties of the restated main-repo
+primitives, TV-L1 accuracy against an analytic flow field, and the committed golden fixtures."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_scaled_dim_rounds_half_even(oracle):
+    # saturate_cast<int>(ssize*scale): pyramid of SURVEY 8a
+    dims = [(1920, 1080)]
+    for _ in range(4):
+        w, h = dims[-1]
+        dims.append((oracle.scaled_dim(w, 0.8), oracle.scaled_dim(h, 0.8)))
+    assert dims == [(1920, 1080), (1536, 864), (1229, 691), (983, 553), (786, 442)]
+    assert oracle.scaled_dim(5, 0.5) == 2 and oracle.scaled_dim(7, 0.5) == 4  # 2.5 -> 2, 3.5 -> 4
+
+
+def test_resize_cv_reproduces_linear_ramp(oracle):
+    # half-pixel-centre bilinear resampling is exact on an affine image away from the clamped border
+    h, w = 40, 50
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = (3 * x + 2 * y + 1).astype(np.float32)
+    out = oracle.resize_linear_cv(img, fx=0.8, fy=0.8)
+    assert out.shape == (32, 40)
+    yy, xx = np.mgrid[0:32, 0:40]
+    sx = (xx + 0.5) * 1.25 - 0.5
+    sy = (yy + 0.5) * 1.25 - 0.5
+    np.testing.assert_allclose(out[1:-1, 1:-1], (3 * sx + 2 * sy + 1)[1:-1, 1:-1], rtol=0, atol=2e-4)
+
+
+def test_resize_cv_identity_and_upsample_border(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.random((17, 23), dtype=np.float32)
+    np.testing.assert_array_equal(oracle.resize_linear_cv(img, dsize=(23, 17)), img)
+    up = oracle.resize_linear_cv(img, dsize=(46, 34))
+    # first/last output columns sample left/right of the outermost centres -> clamped to the edge pixel
+    np.testing.assert_allclose(up[0, 0], img[0, 0], rtol=1e-6)
+    np.testing.assert_allclose(up[-1, -1], img[-1, -1], rtol=1e-6)
+
+
+def test_resize_cuda_convention_has_no_half_pixel_shift(oracle):
+    img = np.arange(20, dtype=np.float32)[None, :].repeat(8, 0)
+    out = oracle.resize_linear_cuda(img, fx=0.5, fy=0.5)  # src_x = dst_x * 2
+    np.testing.assert_array_equal(out[0], np.arange(0, 20, 2, dtype=np.float32))
+    out_cv = oracle.resize_linear_cv(img, fx=0.5, fy=0.5)  # src_x = dst_x*2 + 0.5
+    np.testing.assert_allclose(out_cv[0], np.arange(0, 20, 2, dtype=np.float32) + 0.5)
+
+
+def test_cubic_table_is_keys_minus_075(oracle):
+    t = oracle.cubic_table()
+    np.testing.assert_array_equal(t[0], np.array([0, 1, 0, 0], np.float32))
+    np.testing.assert_allclose(t.sum(1), 1.0, atol=1e-6)
+    np.testing.assert_allclose(t[16], [-0.09375, 0.59375, 0.59375, -0.09375], atol=1e-7)  # x = 0.5, A = -0.75
+
+
+def test_remap_integer_shift_and_constant_border(oracle):
+    rng = np.random.default_rng(1)
+    img = rng.random((20, 30), dtype=np.float32)
+    y, x = np.mgrid[0:20, 0:30].astype(np.float32)
+    out = oracle.remap_cubic_cv(img, x + 3, y - 2)
+    np.testing.assert_array_equal(out[2:, :27], img[:-2, 3:])  # phase 0 weights are exactly (0,1,0,0)
+    assert np.all(out[:2, :] == 0) and np.all(out[:, 27:] == 0)  # BORDER_CONSTANT 0
+    far = oracle.remap_cubic_cv(img, x + 100, y)
+    assert np.all(far == 0)
+
+
+def test_remap_quantises_to_one_32nd(oracle):
+    img = np.random.default_rng(2).random((16, 16), dtype=np.float32)
+    y, x = np.mgrid[0:16, 0:16].astype(np.float32)
+    a = oracle.remap_cubic_cv(img, x + 0.25, y)
+    b = oracle.remap_cubic_cv(img, x + 0.25 + 1 / 128, y)  # rounds to the same 1/32 phase
+    np.testing.assert_array_equal(a, b)
+
+
+def test_median_blur(oracle):
+    img = np.zeros((9, 9), np.float32)
+    img[4, 4] = 100
+    assert oracle.median_blur(img, 5).max() == 0
+    ramp = np.arange(81, dtype=np.float32).reshape(9, 9)
+    np.testing.assert_array_equal(oracle.median_blur(ramp, 5)[2:-2, 2:-2], ramp[2:-2, 2:-2])
+
+
+def test_centered_gradient_borders(oracle):
+    img = np.random.default_rng(3).random((7, 9), dtype=np.float32)
+    dx, dy = oracle.tvl1_centered_gradient(img)
+    np.testing.assert_array_equal(dx[:, 0], 0.5 * (img[:, 1] - img[:, 0]))   # optflow tvl1flow.cpp:745-746
+    np.testing.assert_array_equal(dy[-1, :], 0.5 * (img[-1, :] - img[-2, :]))
+    np.testing.assert_array_equal(dx[:, 1:-1], 0.5 * (img[:, 2:] - img[:, :-2]))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_tvl1_oracle_recovers_analytic_flow(oracle, dtype):
+    I0, I1, gt = synth.flow_pair(240, 320, seed=1234, dtype=dtype)
+    flow = oracle.tvl1_calc(I0, I1, oracle.tvl1_params())  # CPU class defaults
+    d = np.sqrt(((flow - gt) ** 2).sum(-1))
+    assert d[20:-20, 20:-20].mean() < 0.08
+    assert synth.ccorr_dissimilarity(flow[20:-20, 20:-20], gt[20:-20, 20:-20]) < 1e-3
+
+
+def test_tvl1_oracle_fixed_iterations_and_stats(oracle):
+    I0, I1, _ = synth.flow_pair(96, 128, seed=5)
+    flow, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=7, epsilon=0.0), return_stats=True)
+    assert st["levels"][0] == (128, 96) and all(all(i == 7 for i in lv) for lv in st["iters"])
+    assert np.isfinite(flow).all()
+
+
+def test_tvl1_oracle_argument_errors(oracle):
+    I0 = np.zeros((32, 32), np.float32)
+    with pytest.raises(ValueError):
+        oracle.tvl1_calc(I0, np.zeros((32, 33), np.float32))
+    with pytest.raises(ValueError):
+        oracle.tvl1_calc(I0.astype(np.float64), I0.astype(np.float64))
+    with pytest.raises(ValueError):
+        oracle.tvl1_calc(I0, I0, oracle.tvl1_params(nscales=0))
+
+
+def test_tvl1_oracle_stops_pyramid_below_16px(oracle):
+    I0, I1, _ = synth.flow_pair(24, 40, seed=9)
+    _, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=2, epsilon=0.0), return_stats=True)
+    # 24x40 -> 19x32 -> 15x26 (rows < 16: level dropped)  cudaoptflow/src/tvl1flow.cpp:243-247
+    assert st["nscales"] == 2
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "tvl1_*.npz"))))
+def test_tvl1_oracle_matches_golden(oracle, path):
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    flow, st = oracle.tvl1_calc(z["I0"], z["I1"], oracle.tvl1_params(**kw), return_stats=True)
+    np.testing.assert_array_equal(np.array(st["iters"], np.int32), z["iters"])
+    np.testing.assert_allclose(flow, z["flow"], rtol=0, atol=1e-6)

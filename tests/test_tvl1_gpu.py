@@ -1,0 +1,305 @@
+"""GPU parity tests of the TV-L1 hot path: HIP (through the C-ABI) vs the CPU oracle.
+
+Tolerances (stated, float path):
+  * stage level, exact math: <= 2 ulp-scale absolute differences (same IEEE ops, same order);
+  * full calc, exact math, vs oracle / golden: mean EPE <= 2e-3 px and |1-CCORR| <= 1e-5 -- far
+    inside the reference's own CUDA-vs-CPU acceptance |1-CCORR| <= 4e-3
+    (cudaoptflow/test/test_optflow.cpp:465).  Not bit-exact: cv::remap quantises the warp
+    coordinates to 1/32 px, so a last-bit difference in u can flip a quantisation bucket;
+  * fast math vs exact math: mean EPE <= 5e-3 px.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ stage level
+@pytest.mark.parametrize("shape", [(48, 64), (97, 131), (1, 70)])
+def test_centered_gradient(gpu, oracle, shape):
+    from opencv_contrib_amd import cuda
+    img = np.random.default_rng(0).random(shape, dtype=np.float32) * 255
+    if shape[0] < 3:
+        pytest.skip("oracle needs >= 3 rows")
+    dx, dy = cuda.tvl1_centeredGradient(T(img, gpu))
+    rx, ry = oracle.tvl1_centered_gradient(img)
+    np.testing.assert_array_equal(N(dx), rx)
+    np.testing.assert_array_equal(N(dy), ry)
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+@pytest.mark.parametrize("shape,f", [((96, 128), 0.8), ((691, 1229), 0.8), ((55, 77), 0.5), ((40, 50), 0.3)])
+def test_resize_down(gpu, oracle, sem, shape, f):
+    from opencv_contrib_amd import cuda
+    img = np.random.default_rng(1).random(shape, dtype=np.float32) * 255
+    ref = (oracle.resize_linear_cv if sem == 0 else oracle.resize_linear_cuda)(img, fx=f, fy=f)
+    out = cuda.resize_linear(T(img, gpu), fx=f, fy=f, semantics=sem)
+    assert tuple(out.shape) == ref.shape
+    np.testing.assert_array_equal(N(out), ref)
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_resize_up_explicit_dsize_with_scale(gpu, oracle, sem):
+    from opencv_contrib_amd import cuda
+    img = np.random.default_rng(2).standard_normal((442, 786)).astype(np.float32)
+    ref = (oracle.resize_linear_cv if sem == 0 else oracle.resize_linear_cuda)(img, dsize=(983, 553))
+    ref = ref * np.float32(1 / 0.8)
+    out = cuda.resize_linear(T(img, gpu), dsize=(983, 553), semantics=sem, post_scale=float(np.float32(1 / 0.8)))
+    np.testing.assert_array_equal(N(out), ref)
+
+
+def _warp_inputs(h, w, seed, amp):
+    rng = np.random.default_rng(seed)
+    I0 = synth.texture(h, w, seed).astype(np.float32)
+    I1 = synth.texture(h, w, seed + 1).astype(np.float32)
+    u1 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    u2 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    return I0, I1, u1, u2
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+@pytest.mark.parametrize("shape,amp", [((64, 80), 1.5), ((101, 77), 6.0), ((48, 64), 40.0)])
+def test_warp_backward(gpu, oracle, sem, shape, amp):
+    """amp 6 and 40 push many samples across and far beyond the border (constant-0 / clamp paths)."""
+    from opencv_contrib_amd import cuda
+    I0, I1, u1, u2 = _warp_inputs(*shape, seed=3, amp=amp)
+    I1x, I1y = oracle.tvl1_centered_gradient(I1)
+    ref = oracle.tvl1_warp(sem, I0, I1, I1x, I1y, u1, u2)
+    out = cuda.tvl1_warpBackward(sem, *[T(a, gpu) for a in (I0, I1, I1x, I1y, u1, u2)])
+    names = ["I1w", "I1wx", "I1wy", "grad", "rho_c"]
+    for nm, o, r in zip(names, out, ref):
+        if sem == 0:
+            np.testing.assert_array_equal(N(o), r, err_msg=nm)
+        else:  # 1/wsum and up to 25 products: allow a few ulp
+            np.testing.assert_allclose(N(o), r, rtol=2e-5, atol=2e-3, err_msg=nm)
+
+
+def _iter_inputs(h, w, seed):
+    rng = np.random.default_rng(seed)
+    f = lambda s: (rng.standard_normal((h, w)) * s).astype(np.float32)
+    I1wx, I1wy = f(8), f(8)
+    grad = (I1wx * I1wx + I1wy * I1wy).astype(np.float32)
+    grad[rng.random((h, w)) < 0.05] = 0  # exercise the grad <= eps branch
+    rho = f(5)
+    u = [f(1), f(1)]
+    p = [f(0.3) for _ in range(4)]
+    return I1wx, I1wy, grad, rho, u, p
+
+
+@pytest.mark.parametrize("shape", [(40, 64), (67, 253), (33, 300), (1080 // 8, 1920 // 4 + 3)])
+@pytest.mark.parametrize("niter", [1, 4])
+def test_iterate_exact_matches_oracle(gpu, oracle, shape, niter):
+    from opencv_contrib_amd import cuda
+    I1wx, I1wy, grad, rho, u, p = _iter_inputs(*shape, seed=4)
+    l_t, theta, taut = np.float32(0.15 * 0.3), np.float32(0.3), np.float32(0.25 / 0.3)
+    ru, rp, errs = [a.copy() for a in u], [a.copy() for a in p], []
+    for _ in range(niter):
+        e, ru[0], ru[1], rp[0], rp[1], rp[2], rp[3] = oracle.tvl1_iteration(0, I1wx, I1wy, grad, rho, ru[0], ru[1], *rp,
+                                                                          l_t, theta, taut)
+        errs.append(e)
+    uo, po, ge = cuda.tvl1_iterate(T(I1wx, gpu), T(I1wy, gpu), T(grad, gpu), T(rho, gpu), [T(a, gpu) for a in u],
+                                   [T(a, gpu) for a in p], float(l_t), float(theta), float(taut), niter=niter, exact=True)
+    for k in range(2):
+        np.testing.assert_allclose(N(uo[k]), ru[k], rtol=0, atol=2e-6 * niter, err_msg=f"u{k+1}")
+    for k in range(4):
+        np.testing.assert_allclose(N(po[k]), rp[k], rtol=0, atol=2e-6 * niter, err_msg=f"p{k}")
+    np.testing.assert_allclose(ge, errs, rtol=2e-5)
+
+
+def test_iterate_fast_close_to_exact(gpu):
+    from opencv_contrib_amd import cuda
+    I1wx, I1wy, grad, rho, u, p = _iter_inputs(135, 483, seed=5)
+    args = [T(I1wx, gpu), T(I1wy, gpu), T(grad, gpu), T(rho, gpu), [T(a, gpu) for a in u], [T(a, gpu) for a in p],
+            0.045, 0.3, 0.25 / 0.3]
+    ue, pe, _ = cuda.tvl1_iterate(*args, niter=5, exact=True)
+    uf, pf, _ = cuda.tvl1_iterate(*args, niter=5, exact=False)
+    for a, b in zip(ue + pe, uf + pf):
+        np.testing.assert_allclose(N(b), N(a), rtol=0, atol=5e-5)
+
+
+# ------------------------------------------------------------------ full calc
+def _run(gpu, I0, I1, **kw):
+    from opencv_contrib_amd import cuda
+    alg = cuda.OpticalFlowDual_TVL1.create(**kw)
+    flow = alg.calc(T(I0, gpu), T(I1, gpu))
+    import torch
+    torch.cuda.synchronize()
+    return N(flow), alg
+
+
+def _assert_flow_close(flow, ref, mean_epe=2e-3, ccorr=1e-5, frac_within=(0.01, 0.995)):
+    assert np.isfinite(flow).all()
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= mean_epe, f"mean EPE {d.mean()}"
+    assert synth.ccorr_dissimilarity(flow, ref) <= ccorr
+    thr, frac = frac_within
+    assert (d <= thr).mean() >= frac, f"only {(d <= thr).mean():.4f} of pixels within {thr} px"
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "tvl1_*.npz"))))
+def test_calc_matches_golden(gpu, path):
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    flow, alg = _run(gpu, z["I0"], z["I1"], iterations=kw["iterations"], epsilon=kw["epsilon"],
+                     semantics=kw.get("semantics", 0))
+    if kw.get("semantics", 0) == 1:
+        _assert_flow_close(flow, z["flow"], mean_epe=5e-2, ccorr=4e-3, frac_within=(0.1, 0.95))
+    else:
+        _assert_flow_close(flow, z["flow"])
+    it = np.array(alg.lastIterations(), np.int32)
+    if kw["epsilon"] == 0:
+        np.testing.assert_array_equal(it, z["iters"])
+    else:  # data-dependent exit: the oracle's serial-float error sum may differ in the last iteration
+        assert np.abs(it - z["iters"]).max() <= 2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+@pytest.mark.parametrize("shape", [(388, 584), (240, 320)])  # RubberWhale size, and config-1 size / 2
+def test_calc_matches_oracle_reference_test_setting(gpu, oracle, dtype, shape):
+    """Mirror of CUDA_OptFlow/OpticalFlowDual_TVL1.Accuracy (cudaoptflow/test/test_optflow.cpp:440-466):
+    iterations = 10 vs CPU medianFiltering=1, innerIterations=1, outerIterations=10."""
+    I0, I1, _ = synth.flow_pair(*shape, seed=77, dtype=dtype)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10))
+    flow, _ = _run(gpu, I0, I1, iterations=10)
+    _assert_flow_close(flow, ref)
+    assert synth.ccorr_dissimilarity(flow, ref) <= 4e-3  # the reference's own criterion
+
+
+def test_calc_default_parameters_device_side_convergence(gpu, oracle):
+    I0, I1, gt = synth.flow_pair(120, 160, seed=11)
+    ref, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=300), return_stats=True)
+    flow, alg = _run(gpu, I0, I1)  # reference defaults: eps 0.01, 300 iterations
+    it = np.array(alg.lastIterations())
+    assert it.max() < 300 and it.min() >= 1  # converged on the device, no host read-back
+    assert np.abs(it - np.array(st["iters"])).max() <= 2
+    _assert_flow_close(flow, ref)
+
+
+def test_calc_initial_flow(gpu, oracle):
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(96, 128, seed=21)
+    init = (gt + 0.3).astype(np.float32)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=5, epsilon=0.0, use_initial_flow=1), init_flow=init)
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=5, epsilon=0.0, useInitialFlow=True)
+    flow = T(init, gpu)
+    alg.calc(T(I0, gpu), T(I1, gpu), flow)
+    torch.cuda.synchronize()
+    _assert_flow_close(N(flow), ref)
+
+
+def test_calc_pitched_inputs_and_output(gpu, oracle):
+    """GpuMat rows are pitched: step != cols*elemSize must be honoured (SURVEY 8b data layout)."""
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(70, 90, seed=31, dtype="u8")
+    big0 = torch.zeros((70, 128), dtype=torch.uint8, device=gpu); big0[:, :90] = T(I0, gpu)
+    big1 = torch.zeros((70, 256), dtype=torch.uint8, device=gpu); big1[:, 3:93] = T(I1, gpu)
+    bigf = torch.full((70, 100, 2), -7.0, dtype=torch.float32, device=gpu)
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=4, epsilon=0.0)
+    alg.calc(big0[:, :90], big1[:, 3:93], bigf[:, :90])
+    torch.cuda.synchronize()
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=4, epsilon=0.0))
+    _assert_flow_close(N(bigf[:, :90]), ref)
+    assert (N(bigf[:, 90:]) == -7.0).all()  # nothing written outside the ROI
+
+
+def test_batch_equals_single_and_is_deterministic(gpu):
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(100, 140, seed=s)[:2] for s in (1, 2, 3)]
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=6, epsilon=0.0)
+    singles = [N(alg.calc(T(a, gpu), T(b, gpu))) for a, b in pairs]
+    batch = N(alg.calc_batch([T(a, gpu) for a, _ in pairs], [T(b, gpu) for _, b in pairs]))
+    for i in range(3):
+        np.testing.assert_array_equal(batch[i], singles[i])
+    # default parameters (device-side convergence) are reproducible too
+    alg2 = cuda.OpticalFlowDual_TVL1.create()
+    a = N(alg2.calc(T(pairs[0][0], gpu), T(pairs[0][1], gpu)))
+    b = N(alg2.calc(T(pairs[0][0], gpu), T(pairs[0][1], gpu)))
+    np.testing.assert_array_equal(a, b)
+
+
+def test_concurrent_handles_on_streams_bit_identical(gpu):
+    """CUDA_OptFlow/OpticalFlowDual_TVL1.Async (cudaoptflow/test/test_optflow.cpp:468-528): N host threads,
+    each with its own stream and algorithm object, must reproduce the synchronous result exactly."""
+    import threading
+
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(120, 160, seed=41)
+    t0, t1 = T(I0, gpu), T(I1, gpu)
+    gold = N(cuda.OpticalFlowDual_TVL1.create(iterations=10).calc(t0, t1))
+    outs = [None] * 8
+
+    def work(i):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            alg = cuda.OpticalFlowDual_TVL1.create(iterations=10)
+            f = alg.calc(t0, t1)
+            s.synchronize()
+            outs[i] = N(f)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for o in outs:
+        np.testing.assert_array_equal(o, gold)
+
+
+def test_calc_argument_errors(gpu):
+    import torch
+    from opencv_contrib_amd import cuda
+    from opencv_contrib_amd.capi import MiError
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=1)
+    a = torch.zeros((32, 32), dtype=torch.float32, device=gpu)
+    with pytest.raises(MiError) as e:  # CV_Assert(I0.size() == I1.size())
+        alg.calc(a, torch.zeros((32, 33), dtype=torch.float32, device=gpu))
+    assert e.value.code == -3
+    with pytest.raises(MiError) as e:  # CV_Assert(I0.type() == I1.type())
+        alg.calc(a, torch.zeros((32, 32), dtype=torch.uint8, device=gpu))
+    assert e.value.code == -2
+    with pytest.raises(MiError):
+        alg.calc(a, a, torch.zeros((32, 32), dtype=torch.float32, device=gpu))  # flow must be CV_32FC2
+    with pytest.raises(MiError):
+        alg.setNumScales(0)  # CV_Assert(nscales_ > 0)
+    with pytest.raises(MiError):
+        alg.calc(a.cpu(), a.cpu())  # host memory: no CPU fallback
+
+
+def test_small_image_drops_levels(gpu, oracle):
+    I0, I1, _ = synth.flow_pair(24, 40, seed=9)
+    ref, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=3, epsilon=0.0), return_stats=True)
+    flow, alg = _run(gpu, I0, I1, iterations=3, epsilon=0.0)
+    assert len(alg.lastIterations()) == st["nscales"] == 2
+    _assert_flow_close(flow, ref)
+
+
+def test_1080p_properties(gpu):
+    """BASELINE config 2 size: the oracle is too slow here, so check size-independent properties:
+    accuracy against the analytic flow, exact-vs-fast agreement, batch consistency."""
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(1080, 1920, seed=1234)
+    t0, t1 = T(I0, gpu), T(I1, gpu)
+    fe = N(cuda.OpticalFlowDual_TVL1.create(iterations=30, epsilon=0.0, exactMath=True).calc(t0, t1))
+    ff = N(cuda.OpticalFlowDual_TVL1.create(iterations=30, epsilon=0.0, exactMath=False).calc(t0, t1))
+    d = np.sqrt(((fe - gt) ** 2).sum(-1))
+    assert d[40:-40, 40:-40].mean() < 0.15, d[40:-40, 40:-40].mean()
+    assert np.sqrt(((fe - ff) ** 2).sum(-1)).mean() < 5e-3
