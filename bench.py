@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--epsilon", type=float, default=0.0)
     ap.add_argument("--defaults", action="store_true", help="class defaults: 300 iterations, epsilon 0.01")
     ap.add_argument("--fast-math", action="store_true")
+    ap.add_argument("--time-block", type=int, default=0, help="iterations fused per HBM pass (fast math; 0 = auto, 1 = off)")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=None)
@@ -113,7 +114,8 @@ def main():
     warps = 5
 
     def run(iterations, epsilon, steps, warmup, profile=False):
-        alg = cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon, exactMath=not args.fast_math)
+        alg = cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon, exactMath=not args.fast_math,
+                                               timeBlock=args.time_block)
         alg.setProfiling(profile)
         el = time_steps(alg, I0, I1, flows, steps, warmup, dist)
         t = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -151,7 +153,7 @@ def main():
            "config": {"workload": f"DualTVL1 dense flow, {W}x{H} CV_32FC1, {B} pairs/GPU/step (BASELINE configs[1])",
                       "iterations": args.iterations, "epsilon": args.epsilon, "warps": warps, "nscales": 5,
                       "executed_iterations_per_warp_mean": mean_it, "semantics": "CPU_REF",
-                      "math": "fast" if args.fast_math else "exact",
+                      "math": "fast" if args.fast_math else "exact", "time_block": args.time_block,
                       "algorithmic_GB_per_pair": ab_pair / 1e9},
            "whole_job_algorithmic_GBps": ab_pair * fps / 1e9,
            "whole_job_frac_of_hbm_peak": ab_pair * fps / 1e9 / HBM_PEAK_GBS,

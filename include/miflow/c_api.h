@@ -147,6 +147,10 @@ MI_API int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_m
 MI_API int mi_resize_linear(int semantics, const mi_mat *src, mi_mat *dst, double fx, double fy,
                             int explicit_dsize, float post_scale, void *stream);
 
+/* Hardware self-test hook: out_host[0..63] = value received from lane n-1, out_host[64..127] = from
+ * lane n+1 when every lane n contributes n+100 (DPP wave shifts used by the blocked kernels). */
+MI_API int mi_dbg_lane_shift(int *out_host /*[128]*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,7 @@ def lib():
         "mi_tvl1_warp_backward": (i, [i] + [PM] * 11),
         "mi_tvl1_iterate": (i, [i, i, i, PM, PM, PM, PM, PM, PM, PM, PM, f, f, f, C.POINTER(d), vp]),
         "mi_resize_linear": (i, [i, PM, PM, d, d, i, f, vp]),
+        "mi_dbg_lane_shift": (i, [C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -371,8 +371,17 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
                 rc = next_event(&e0); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(h->ev_pool[e0], st));
             }
+            const bool blocked = !check && !P.exact_math && P.time_block != 1;
+            long long nlaunch = 0;
             for (int it = 0; it < iters_per_warp; ++it) {
-                if (check) {
+                ++nlaunch;
+                if (blocked) {
+                    // T iterations per HBM pass (tvl1_tb_kernels.hip)
+                    const int T = tb_pick_block(iters_per_warp - it, P.time_block > 0 ? P.time_block : tb_max_block());
+                    rc = iterate_tb(T, pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
+                    cur ^= 1;
+                    it += T - 1;
+                } else if (check) {
                     Ctl ic = ctl;
                     ic.q = q; ic.q_prev = q_last;
                     ic.first_of_warp = (it == 0);
@@ -390,7 +399,7 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
             if (e0 >= 0) {
                 rc = next_event(&e1); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(h->ev_pool[e1], st));
-                h->regions.push_back({e0, e1, (long long)iters_per_warp, 64.0 * g.w * g.h * B * iters_per_warp});
+                h->regions.push_back({e0, e1, nlaunch, 64.0 * g.w * g.h * B * iters_per_warp});
             }
         }
         Ctl ec = ctl;

@@ -59,6 +59,20 @@ int warp(int semantics, const float *I0, const float *I1, const float *I1x, cons
 int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut,
             bool p_zero, const Ctl *ctl, int cur_host, hipStream_t s);
 
+// Temporally blocked fast-math iteration (tvl1_tb_kernels.hip): T fused iterations in one HBM pass,
+// set cur -> cur^1.  Supported T: 1,2,3,4,5,6,8,10.  rows_per_band <= 0: auto.
+int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
+               int cur, int rows_per_band, hipStream_t s);
+int tb_max_block();
+// largest supported block <= n (n >= 1)
+inline int tb_pick_block(int n, int cap)
+{
+    static const int sup[] = {10, 8, 6, 5, 4, 3, 2, 1};
+    for (int t : sup) if (t <= n && t <= cap) return t;
+    return 1;
+}
+int dbg_lane_shift(int *out_dev, hipStream_t s);
+
 void host_cubic_table(float tab[128]);  // cv::remap INTER_CUBIC phase table (a = -0.75)
 
 }  // namespace tvl1

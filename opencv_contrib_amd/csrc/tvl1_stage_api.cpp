@@ -108,8 +108,9 @@ int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1w
                     float theta, float taut, double *err_host, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    (void)time_block;
     MI_REQUIRE(niter >= 1, MI_ERR_BAD_ARG, "niter must be >= 1");
+    const bool blocked = !exact_math && time_block > 0;
+    MI_REQUIRE(!(blocked && err_host), MI_ERR_BAD_ARG, "per-iteration error sums are not available from the blocked kernel");
     MI_REQUIRE(u_in && p_in && u_out && p_out, MI_ERR_BAD_ARG, "null plane array");
     const mi_mat *stat[4] = {I1wx, I1wy, grad, rho_c};
     for (int i = 0; i < 4; ++i) { TRY(check_f32(stat[i], "static plane")); MI_REQUIRE(stat[i]->rows == I1wx->rows && stat[i]->cols == I1wx->cols, MI_ERR_BAD_SIZE, "size mismatch"); }
@@ -135,10 +136,19 @@ int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1w
         ctl.thr = -1.0;  // always active
     }
     int cur = 0;
-    for (int it = 0; it < niter; ++it) {
+    for (int it = 0; it < niter;) {
+        if (blocked) {
+            const int T = tb_pick_block(niter - it, time_block);
+            TRY(iterate_tb(T, pl, g, l_t, theta, taut, false, cur, 0, st));
+            it += T;
+            cur ^= 1;
+            continue;
+        }
+        ++it;
         if (err_host) {
+            const int it0 = it - 1;
             Ctl c = ctl;
-            c.q = it; c.q_prev = it - 1; c.first_of_warp = (it == 0); c.reset_cur = (it == 0);
+            c.q = it0; c.q_prev = it0 - 1; c.first_of_warp = (it0 == 0); c.reset_cur = (it0 == 0);
             TRY(iterate(exact_math != 0, pl, g, l_t, theta, taut, false, &c, 0, st));
         } else {
             TRY(iterate(exact_math != 0, pl, g, l_t, theta, taut, false, nullptr, cur, st));
@@ -182,6 +192,20 @@ int mi_resize_linear(int semantics, const mi_mat *src, mi_mat *dst, double fx, d
     TRY(stage_out(d, gd, dst, st));
     MI_HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
+}
+
+int mi_dbg_lane_shift(int *out_host)
+{
+    MI_REQUIRE(out_host, MI_ERR_BAD_ARG, "null out");
+    int *d = nullptr;
+    MI_HIP_TRY(hipMalloc((void **)&d, 128 * sizeof(int)));
+    int rc = dbg_lane_shift(d, nullptr);
+    if (rc == MI_OK) {
+        hipError_t e = hipMemcpy(out_host, d, 128 * sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("hipMemcpy failed: %s", hipGetErrorString(e)); rc = MI_ERR_HIP; }
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 }  // extern "C"

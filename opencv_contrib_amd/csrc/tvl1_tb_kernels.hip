@@ -1,0 +1,385 @@
+// Dual TV-L1 -- temporally blocked fused iteration for gfx950 (wave64, 512 VGPR/lane budget).
+//
+// The reference runs 2 kernels per inner iteration (estimateU + estimateDualVariables,
+// modules/cudaoptflow/src/cuda/tvl1flow.cu:209-363), i.e. 88 B of HBM traffic per pixel per
+// iteration; the fused v1 kernel (tvl1_kernels.hip) needs 64 B.  Here T iterations are applied
+// in ONE pass over HBM (64 B per pixel per T iterations):
+//
+//   * a wave owns a column strip of 64*PPL pixels and streams DOWN the rows of its band;
+//   * iteration level t (1..T) is a pipeline stage that lags level t-1 by one row
+//     (dependency cone of one iteration is +-1 px: tvl1flow.cu:187-207 reads p at x-1/y-1,
+//     :322-327 reads u at x+1/y+1).  Each stage keeps one row of {u_t, p_(t-1), static planes}
+//     in VGPRs (10*PPL registers), so all T levels of a row band live in the register file;
+//   * x-neighbours come from the adjacent lane through DPP wave shifts (no LDS, no barriers);
+//   * the strip loses ceil(T/PPL)*PPL px of validity on each side and T rows at band top and
+//     bottom (recomputed by the neighbouring strip/band).
+//
+// Arithmetic: fast-math form of the CPU reference formulas (optflow/src/tvl1flow.cpp:989-1041,
+// 857-899, 1096-1112, 1140-1181): thresholding written as fi = clamp(-rho/g, +-l_t), reciprocals
+// via v_rcp_f32, |grad u| via v_sqrt_f32, fma contraction.  Parity of this path is tested
+// against the exact-math v1 kernel and the oracle with a stated tolerance.
+#include "tvl1_dev.h"
+#include <cfloat>
+
+namespace mi {
+namespace tvl1 {
+
+// lane n <- lane n-1 (wave_shr:1) / lane n <- lane n+1 (wave_shl:1); semantics verified on HW
+// by tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics through mi_dbg_lane_shift.
+__device__ __forceinline__ float dpp_from_prev(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_next(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+__global__ void k_dbg_lane_shift(int *out)
+{
+    const int l = threadIdx.x;
+    out[l] = __float_as_int(dpp_from_prev(__int_as_float(l + 100)));
+    out[64 + l] = __float_as_int(dpp_from_next(__int_as_float(l + 100)));
+}
+
+// Dynamic state of one pipeline stage: u_t(a) and p_(t-1)(a) of the row it holds.
+template <int PPL>
+struct Dyn {
+    float u1[PPL], u2[PPL], p11[PPL], p12[PPL], p21[PPL], p22[PPL];
+};
+template <int PPL>
+struct Stat {  // static planes of one row: I1wx, I1wy, 1/grad, rho_c
+    float ix[PPL], iy[PPL], rg[PPL], rc[PPL];
+};
+
+struct TbArgs {
+    IterPlanes pl;
+    Geo g;
+    float l_t, theta, taut;
+    int rows_per_band;
+    int cur;  // input set
+};
+
+template <int PPL>
+__device__ __forceinline__ void ldv(float dst[PPL], const float *p, long long off, bool ok)
+{
+    if (PPL == 2) {
+        float2 v = make_float2(0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float2 *>(p + off);
+        dst[0] = v.x; dst[1] = v.y;
+    } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4 *>(p + off);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+template <int PPL>
+__device__ __forceinline__ void stv(float *p, long long off, const float v[PPL])
+{
+    if (PPL == 2) *reinterpret_cast<float2 *>(p + off) = make_float2(v[0], v[1]);
+    else *reinterpret_cast<float4 *>(p + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+// per-wave LDS ring of static rows: slot layout [plane 0..3][64*PPL floats]
+template <int PPL>
+__device__ __forceinline__ void lds_put(float *slot, int lane, const Stat<PPL> &s)
+{
+    float *q = slot + lane * PPL;
+    if (PPL == 2) {
+        *reinterpret_cast<float2 *>(q) = make_float2(s.ix[0], s.ix[1]);
+        *reinterpret_cast<float2 *>(q + 128) = make_float2(s.iy[0], s.iy[1]);
+        *reinterpret_cast<float2 *>(q + 256) = make_float2(s.rg[0], s.rg[1]);
+        *reinterpret_cast<float2 *>(q + 384) = make_float2(s.rc[0], s.rc[1]);
+    } else {
+        *reinterpret_cast<float4 *>(q) = make_float4(s.ix[0], s.ix[1], s.ix[2], s.ix[3]);
+        *reinterpret_cast<float4 *>(q + 256) = make_float4(s.iy[0], s.iy[1], s.iy[2], s.iy[3]);
+        *reinterpret_cast<float4 *>(q + 512) = make_float4(s.rg[0], s.rg[1], s.rg[2], s.rg[3]);
+        *reinterpret_cast<float4 *>(q + 768) = make_float4(s.rc[0], s.rc[1], s.rc[2], s.rc[3]);
+    }
+}
+template <int PPL>
+__device__ __forceinline__ void lds_get(const float *slot, int lane, Stat<PPL> &s)
+{
+    const float *q = slot + lane * PPL;
+    if (PPL == 2) {
+        float2 a = *reinterpret_cast<const float2 *>(q), b = *reinterpret_cast<const float2 *>(q + 128);
+        float2 c = *reinterpret_cast<const float2 *>(q + 256), d = *reinterpret_cast<const float2 *>(q + 384);
+        s.ix[0] = a.x; s.ix[1] = a.y; s.iy[0] = b.x; s.iy[1] = b.y;
+        s.rg[0] = c.x; s.rg[1] = c.y; s.rc[0] = d.x; s.rc[1] = d.y;
+    } else {
+        float4 a = *reinterpret_cast<const float4 *>(q), b = *reinterpret_cast<const float4 *>(q + 256);
+        float4 c = *reinterpret_cast<const float4 *>(q + 512), d = *reinterpret_cast<const float4 *>(q + 768);
+        s.ix[0] = a.x; s.ix[1] = a.y; s.ix[2] = a.z; s.ix[3] = a.w;
+        s.iy[0] = b.x; s.iy[1] = b.y; s.iy[2] = b.z; s.iy[3] = b.w;
+        s.rg[0] = c.x; s.rg[1] = c.y; s.rg[2] = c.z; s.rg[3] = c.w;
+        s.rc[0] = d.x; s.rc[1] = d.y; s.rc[2] = d.z; s.rc[3] = d.w;
+    }
+}
+
+// One pipeline stage (iteration level t).  `in` = level t-1 row a (u, p), `st` = static row a,
+// `S` = what this stage holds (u_t(a-1), p_(t-1)(a-1)); writes the new held state (row a) to `N`
+// and replaces `in` by level t row a-1.  a, H are wave-uniform (SGPRs).
+template <int PPL>
+__device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const Dyn<PPL> &S, Dyn<PPL> &N, int a, int H,
+                                      bool has_left, bool has_right, bool x_is_zero, const bool right_ok[PPL],
+                                      float l_t, float theta, float taut)
+{
+    // has_left / has_right / a are wave-uniform: the border fix-ups are scalar branches that the
+    // interior strips and rows skip (the empty asm keeps the compiler from if-converting them
+    // into per-pixel selects).
+    // ---- u_t(a)
+    float dx1[PPL], dx2[PPL];  // backward x-differences of p11, p21
+    dx1[0] = in.p11[0] - dpp_from_prev(in.p11[PPL - 1]);
+    dx2[0] = in.p21[0] - dpp_from_prev(in.p21[PPL - 1]);
+#pragma unroll
+    for (int j = 1; j < PPL; ++j) { dx1[j] = in.p11[j] - in.p11[j - 1]; dx2[j] = in.p21[j] - in.p21[j - 1]; }
+    if (has_left) {  // first column: no p(x-1) term (optflow tvl1flow.cpp:893-894)
+        asm volatile("" ::: "memory");
+        if (x_is_zero) { dx1[0] = in.p11[0]; dx2[0] = in.p21[0]; }
+    }
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const float div1 = dx1[j] + (in.p12[j] - S.p12[j]);
+        const float div2 = dx2[j] + (in.p22[j] - S.p22[j]);
+        const float rho = fmaf(st.ix[j], in.u1[j], fmaf(st.iy[j], in.u2[j], st.rc[j]));
+        const float fi = __builtin_amdgcn_fmed3f(-rho * st.rg[j], -l_t, l_t);  // TH: clamp(-rho/grad, +-l_t)
+        N.u1[j] = fmaf(theta, div1, fmaf(fi, st.ix[j], in.u1[j]));
+        N.u2[j] = fmaf(theta, div2, fmaf(fi, st.iy[j], in.u2[j]));
+        N.p11[j] = in.p11[j]; N.p12[j] = in.p12[j]; N.p21[j] = in.p21[j]; N.p22[j] = in.p22[j];
+    }
+    if (a == H) {  // below the last row: forward y-difference is 0 (optflow tvl1flow.cpp:826-831)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { N.u1[j] = S.u1[j]; N.u2[j] = S.u2[j]; }
+    }
+    // ---- p_t(a-1)
+    const float r1 = dpp_from_next(S.u1[0]);
+    const float r2 = dpp_from_next(S.u2[0]);
+    float u1xv[PPL], u2xv[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const float n1 = (j < PPL - 1) ? S.u1[j + 1 < PPL ? j + 1 : j] : r1;
+        const float n2 = (j < PPL - 1) ? S.u2[j + 1 < PPL ? j + 1 : j] : r2;
+        u1xv[j] = n1 - S.u1[j];
+        u2xv[j] = n2 - S.u2[j];
+    }
+    if (has_right) {  // last column: forward x-difference is 0 (optflow tvl1flow.cpp:833-838)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { u1xv[j] = right_ok[j] ? u1xv[j] : 0.f; u2xv[j] = right_ok[j] ? u2xv[j] : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const float u1x = u1xv[j];
+        const float u2x = u2xv[j];
+        const float u1y = N.u1[j] - S.u1[j];
+        const float u2y = N.u2[j] - S.u2[j];
+        const float g1 = __builtin_amdgcn_sqrtf(fmaf(u1x, u1x, u1y * u1y));
+        const float g2 = __builtin_amdgcn_sqrtf(fmaf(u2x, u2x, u2y * u2y));
+        const float q1 = __builtin_amdgcn_rcpf(fmaf(taut, g1, 1.0f));
+        const float q2 = __builtin_amdgcn_rcpf(fmaf(taut, g2, 1.0f));
+        in.p11[j] = fmaf(taut, u1x, S.p11[j]) * q1;
+        in.p12[j] = fmaf(taut, u1y, S.p12[j]) * q1;
+        in.p21[j] = fmaf(taut, u2x, S.p21[j]) * q2;
+        in.p22[j] = fmaf(taut, u2y, S.p22[j]) * q2;
+        in.u1[j] = S.u1[j]; in.u2[j] = S.u2[j];
+    }
+    if (a <= 0) {  // the emitted row a-1 lies above the image: p(y-1) terms vanish at y == 0 (:889-890)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) in.p12[j] = in.p22[j] = 0.f;
+    }
+}
+
+template <int PPL, bool PZ>
+__device__ __forceinline__ void load_input_row(Dyn<PPL> &r, Stat<PPL> &st, const TbArgs &A, const float *const u[2],
+                                               const float *const p[4], int row, int H, long long xoff, bool xok)
+{
+    const bool ok = xok && row >= 0 && row < H;
+    const long long off = (long long)row * A.g.ld + xoff;
+    float g[PPL];
+    ldv<PPL>(st.ix, A.pl.ix, off, ok);
+    ldv<PPL>(st.iy, A.pl.iy, off, ok);
+    ldv<PPL>(g, A.pl.g, off, ok);
+    ldv<PPL>(st.rc, A.pl.rc, off, ok);
+    ldv<PPL>(r.u1, u[0], off, ok);
+    ldv<PPL>(r.u2, u[1], off, ok);
+    if (!PZ) {
+        ldv<PPL>(r.p11, p[0], off, ok);
+        ldv<PPL>(r.p12, p[1], off, ok);
+        ldv<PPL>(r.p21, p[2], off, ok);
+        ldv<PPL>(r.p22, p[3], off, ok);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) r.p11[j] = r.p12[j] = r.p21[j] = r.p22[j] = 0.f;
+    }
+    // 1/grad; grad == 0 -> huge, so that clamp() yields -+l_t*sign(rho) like the reference's first two branches
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) st.rg[j] = __builtin_amdgcn_rcpf(fmaxf(g[j], 1e-30f));
+}
+
+// One step of the whole pipeline: row `arow` of level 0 enters, row arow-T of level T leaves in `io`.
+template <int T, int PPL, int K>
+__device__ __forceinline__ void pipeline_step(Dyn<PPL> &io, const Stat<PPL> &st0, const Dyn<PPL> (&S)[T], Dyn<PPL> (&N)[T],
+                                              float *ring, int slot0, int lane, int arow, int H, bool has_left,
+                                              bool has_right, bool x_is_zero, const bool right_ok[PPL], float l_t,
+                                              float theta, float taut)
+{
+    lds_put<PPL>(ring + slot0 * (256 * PPL), lane, st0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        Stat<PPL> st;
+        if (t == 0) st = st0;
+        else {
+            int sl = slot0 - t;
+            if (sl < 0) sl += K;
+            lds_get<PPL>(ring + sl * (256 * PPL), lane, st);
+        }
+        stage<PPL>(io, st, S[t], N[t], arow - t, H, has_left, has_right, x_is_zero, right_ok, l_t, theta, taut);
+    }
+}
+
+template <int T, int PPL, bool PZ>
+__global__ __launch_bounds__(256) void k_iterate_tb(TbArgs A)
+{
+    constexpr int M = (T + PPL - 1) / PPL * PPL;    // validity margin per side (px)
+    constexpr int STRIDE = 64 * PPL - 2 * M;        // owned columns per strip
+    constexpr int K = T + 1;                        // ring slots (rows of static planes in flight)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x, b = blockIdx.z;
+    const int band = blockIdx.y * 4 + wave;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    const int y0 = band * A.rows_per_band;
+    float *ring = lds + wave * (K * 256 * PPL);
+    if (y0 >= H) return;
+    const int y1 = min(y0 + A.rows_per_band, H);
+    const int own_lo = strip * STRIDE, own_hi = min(own_lo + STRIDE, W);
+    const int xl = own_lo - M + lane * PPL;         // first pixel of this lane (may be < 0 or >= W)
+    const bool xok = xl >= 0 && xl < W;
+    const bool x_is_zero = (xl == 0);
+    bool right_ok[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) right_ok[j] = (xl + j + 1 < W);
+    const bool st_ok = xl >= own_lo && xl < own_hi;  // owned group (groups never straddle own_lo)
+    const bool has_left = (strip == 0);                              // wave-uniform: strip contains x == 0
+    const bool has_right = (own_lo - M + 64 * PPL >= W);             // wave-uniform: strip reaches x == W-1
+
+    const long long pb = (long long)b * A.g.ps;
+    const int cur = A.cur;
+    const float *uin[2] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb};
+    const float *pin[4] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb};
+    float *uout[2] = {A.pl.u[cur ^ 1][0] + pb, A.pl.u[cur ^ 1][1] + pb};
+    float *pout[4] = {A.pl.p[cur ^ 1][0] + pb, A.pl.p[cur ^ 1][1] + pb, A.pl.p[cur ^ 1][2] + pb, A.pl.p[cur ^ 1][3] + pb};
+    TbArgs B = A;
+    B.pl.ix += pb; B.pl.iy += pb; B.pl.g += pb; B.pl.rc += pb;
+
+    // zero state: rows above the first streamed row do not exist for this band
+    Dyn<PPL> SA[T], SB[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < PPL; ++j)
+            SA[t].u1[j] = SA[t].u2[j] = SA[t].p11[j] = SA[t].p12[j] = SA[t].p21[j] = SA[t].p22[j] = 0.f;
+    {
+        Stat<PPL> z;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) z.ix[j] = z.iy[j] = z.rg[j] = z.rc[j] = 0.f;
+        for (int k = 0; k < K; ++k) lds_put<PPL>(ring + k * (256 * PPL), lane, z);
+    }
+
+    const int ystart = y0 - T;
+    const int nsteps = (y1 - y0) + 2 * T;
+    Dyn<PPL> nxt;
+    Stat<PPL> nst;
+    load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart, H, xl, xok);
+    int slot0 = 0;
+
+    auto emit = [&](const Dyn<PPL> &r, int orow) {
+        if (orow >= y0 && orow < y1 && st_ok) {
+            const long long off = (long long)orow * ld + xl;
+            stv<PPL>(uout[0], off, r.u1);
+            stv<PPL>(uout[1], off, r.u2);
+            stv<PPL>(pout[0], off, r.p11);
+            stv<PPL>(pout[1], off, r.p12);
+            stv<PPL>(pout[2], off, r.p21);
+            stv<PPL>(pout[3], off, r.p22);
+        }
+    };
+
+    for (int s = 0; s < nsteps; s += 2) {
+        // even step: state SA -> SB
+        Dyn<PPL> io = nxt;
+        Stat<PPL> st0 = nst;
+        load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart + s + 1, H, xl, xok);
+        pipeline_step<T, PPL, K>(io, st0, SA, SB, ring, slot0, lane, ystart + s, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+        emit(io, ystart + s - T);
+        slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
+        // odd step: state SB -> SA (rows past the band end are computed but never stored)
+        io = nxt;
+        st0 = nst;
+        load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart + s + 2, H, xl, xok);
+        pipeline_step<T, PPL, K>(io, st0, SB, SA, ring, slot0, lane, ystart + s + 1, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+        emit(io, ystart + s + 1 - T);
+        slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+template <int T, int PPL>
+static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
+{
+    constexpr int M = (T + PPL - 1) / PPL * PPL;
+    constexpr int STRIDE = 64 * PPL - 2 * M;
+    const dim3 grid(div_up(A.g.w, STRIDE), div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
+    constexpr size_t lds_bytes = (size_t)4 * (T + 1) * 256 * PPL * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    if (pz) hipLaunchKernelGGL((k_iterate_tb<T, PPL, true>), grid, dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tb<T, PPL, false>), grid, dim3(256), lds_bytes, s, A);
+}
+
+int tb_max_block() { return 10; }
+
+// T fused iterations, set cur -> cur^1.  Returns MI_ERR_BAD_ARG for unsupported T.
+int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
+               int cur, int rows_per_band, hipStream_t s)
+{
+    TbArgs A;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur;
+    if (rows_per_band <= 0) {
+        // enough waves for 1024 SIMDs, but keep the 2T-row band overlap small
+        const int strips = div_up(g.w, 128 - 2 * ((T + 1) / 2 * 2));
+        int R = 256;
+        while (R > 32 && (long long)strips * div_up(g.h, R) * g.batch < 2048) R >>= 1;
+        rows_per_band = R;
+    }
+    A.rows_per_band = rows_per_band;
+    switch (T) {
+    case 1: launch_tb<1, 2>(A, p_zero, s); break;
+    case 2: launch_tb<2, 2>(A, p_zero, s); break;
+    case 3: launch_tb<3, 2>(A, p_zero, s); break;
+    case 4: launch_tb<4, 2>(A, p_zero, s); break;
+    case 5: launch_tb<5, 2>(A, p_zero, s); break;
+    case 6: launch_tb<6, 2>(A, p_zero, s); break;
+    case 8: launch_tb<8, 2>(A, p_zero, s); break;
+    case 10: launch_tb<10, 2>(A, p_zero, s); break;
+    default: set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG;
+    }
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int dbg_lane_shift(int *out_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dbg_lane_shift, dim3(1), dim3(64), 0, s, out_dev);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace tvl1
+}  // namespace mi

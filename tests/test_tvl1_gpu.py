@@ -30,6 +30,9 @@ def N(t):
     return t.detach().cpu().numpy()
 
 
+T_ = T
+
+
 # ------------------------------------------------------------------ stage level
 @pytest.mark.parametrize("shape", [(48, 64), (97, 131), (1, 70)])
 def test_centered_gradient(gpu, oracle, shape):
@@ -94,8 +97,10 @@ def _iter_inputs(h, w, seed):
     rng = np.random.default_rng(seed)
     f = lambda s: (rng.standard_normal((h, w)) * s).astype(np.float32)
     I1wx, I1wy = f(8), f(8)
+    flat = rng.random((h, w)) < 0.05  # textureless pixels: exercise the grad <= eps branch
+    I1wx[flat] = 0
+    I1wy[flat] = 0
     grad = (I1wx * I1wx + I1wy * I1wy).astype(np.float32)
-    grad[rng.random((h, w)) < 0.05] = 0  # exercise the grad <= eps branch
     rho = f(5)
     u = [f(1), f(1)]
     p = [f(0.3) for _ in range(4)]
@@ -131,6 +136,42 @@ def test_iterate_fast_close_to_exact(gpu):
     uf, pf, _ = cuda.tvl1_iterate(*args, niter=5, exact=False)
     for a, b in zip(ue + pe, uf + pf):
         np.testing.assert_allclose(N(b), N(a), rtol=0, atol=5e-5)
+
+
+def test_dpp_wave_shift_semantics(gpu):
+    """The blocked kernel takes x-neighbours from adjacent lanes with DPP wave_shr:1 / wave_shl:1."""
+    import ctypes as C
+    from opencv_contrib_amd import capi
+    out = (C.c_int * 128)()
+    capi.check(capi.lib().mi_dbg_lane_shift(out))
+    prev, nxt = list(out[:64]), list(out[64:])
+    assert prev[1:] == [100 + i for i in range(63)], prev      # lane n receives lane n-1
+    assert nxt[:63] == [101 + i for i in range(63)], nxt       # lane n receives lane n+1
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 6, 8, 10])
+@pytest.mark.parametrize("shape", [(70, 100), (300, 531)])
+def test_iterate_blocked_matches_exact(gpu, T, shape):
+    """T iterations fused in one HBM pass (register-resident temporal blocking) vs T launches of the
+    exact v1 kernel.  (300, 531) spans several column strips and row bands (halo recomputation)."""
+    from opencv_contrib_amd import cuda
+    I1wx, I1wy, grad, rho, u, p = _iter_inputs(*shape, seed=6)
+    args = [T_(a, gpu) for a in (I1wx, I1wy, grad, rho)] + [[T_(a, gpu) for a in u], [T_(a, gpu) for a in p],
+                                                            0.045, 0.3, 0.25 / 0.3]
+    for niter in (T, 2 * T + 1):
+        ue, pe, _ = cuda.tvl1_iterate(*args, niter=niter, exact=True)
+        ub, pb_, _ = cuda.tvl1_iterate(*args, niter=niter, exact=False, time_block=T, want_err=False)
+        for nm, a, b in zip(["u1", "u2", "p11", "p12", "p21", "p22"], ue + pe, ub + pb_):
+            np.testing.assert_allclose(N(b), N(a), rtol=0, atol=2e-5 * niter, err_msg=f"{nm} T={T} niter={niter}")
+
+
+@pytest.mark.parametrize("tb", [0, 5])
+def test_calc_fast_blocked_matches_oracle(gpu, oracle, tb):
+    """Product fast path (fast math + temporal blocking) against the CPU oracle, stated tolerance."""
+    I0, I1, _ = synth.flow_pair(388, 584, seed=78)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0))
+    flow, _ = _run(gpu, I0, I1, iterations=10, epsilon=0.0, exactMath=False, timeBlock=tb)
+    _assert_flow_close(flow, ref, mean_epe=5e-3, ccorr=1e-5, frac_within=(0.02, 0.99))
 
 
 # ------------------------------------------------------------------ full calc
