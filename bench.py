@@ -81,7 +81,9 @@ def main():
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--epsilon", type=float, default=0.0)
     ap.add_argument("--defaults", action="store_true", help="class defaults: 300 iterations, epsilon 0.01")
-    ap.add_argument("--fast-math", action="store_true")
+    ap.add_argument("--exact-math", action="store_true",
+                    help="IEEE divide + f64 hypot, one iteration per HBM pass (oracle-faithful to ~1e-6 px); default is "
+                         "the product fast path: v_rcp/v_sqrt math + temporal blocking, parity-tested at mean EPE <= 5e-3 px")
     ap.add_argument("--time-block", type=int, default=0, help="iterations fused per HBM pass (fast math; 0 = auto, 1 = off)")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -113,8 +115,9 @@ def main():
     flows = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
     warps = 5
 
-    def run(iterations, epsilon, steps, warmup, profile=False):
-        alg = cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon, exactMath=not args.fast_math,
+    def run(iterations, epsilon, steps, warmup, profile=False, exact=None):
+        alg = cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon,
+                                               exactMath=args.exact_math if exact is None else exact,
                                                timeBlock=args.time_block)
         alg.setProfiling(profile)
         el = time_steps(alg, I0, I1, flows, steps, warmup, dist)
@@ -140,12 +143,31 @@ def main():
     if args.epsilon > 0:  # only executed launches move bytes; the no-op launches still cost their dispatch
         exec_frac = mean_it / args.iterations
         abytes *= exec_frac
-    roof = {"bound": "hbm", "kernel": "k_iterate (fused estimateU+estimateDualVariables)",
+    blocked = (not args.exact_math) and args.epsilon == 0 and args.time_block != 1
+    kname = ("k_iterate_tb (T fused estimateU+estimateDualVariables iterations per HBM pass)" if blocked
+             else "k_iterate (fused estimateU+estimateDualVariables)")
+    roof = {"bound": "hbm", "kernel": kname,
             "achieved": abytes / (ms_total * 1e-3) / 1e9 if ms_total > 0 else None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "traffic": None,
             "avg_launch_us": 1e3 * ms_total / max(launches, 1), "launches_timed": launches,
-            "algorithmic_bytes_per_launch_level0": 64.0 * W * H * B}
+            "iterations_per_launch_mean": mean_it * warps * len(its) / max(launches, 1),
+            "algorithmic_bytes_per_launch_mean": abytes / max(launches, 1),
+            "note": "achieved = algorithmic bytes (64 B x px x iterations executed by the launch, SURVEY 8d) / launch time; "
+                    "with temporal blocking one launch executes T iterations per HBM pass, so achieved may exceed the "
+                    "HBM peak -- `traffic` is the measured HBM bytes per launch"}
     roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
+    # measured HBM traffic per launch of the dominant kernel: collected in separate rocprofv3 --pmc passes
+    # (FETCH_SIZE, WRITE_SIZE) of this same command and committed under profiles/ (tools/pmc_summary.py)
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "tb" if blocked else "v1"
+            if key in tj:
+                roof["traffic"] = tj[key]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = tj[key].get("source")
+        except Exception:
+            pass
 
     out = {"metric": "frame-pairs/sec dense TV-L1 flow @1080p", "value": fps, "unit": "pairs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -153,7 +175,7 @@ def main():
            "config": {"workload": f"DualTVL1 dense flow, {W}x{H} CV_32FC1, {B} pairs/GPU/step (BASELINE configs[1])",
                       "iterations": args.iterations, "epsilon": args.epsilon, "warps": warps, "nscales": 5,
                       "executed_iterations_per_warp_mean": mean_it, "semantics": "CPU_REF",
-                      "math": "fast" if args.fast_math else "exact", "time_block": args.time_block,
+                      "math": "exact" if args.exact_math else "fast", "time_block": args.time_block,
                       "algorithmic_GB_per_pair": ab_pair / 1e9},
            "whole_job_algorithmic_GBps": ab_pair * fps / 1e9,
            "whole_job_frac_of_hbm_peak": ab_pair * fps / 1e9 / HBM_PEAK_GBS,
@@ -162,11 +184,12 @@ def main():
 
     if not args.no_variants and world == 1:
         var = {}
-        for name, (it, eps) in {"iterations2_eps0": (2, 0.0), "iterations30_eps0": (30, 0.0),
-                                "defaults_300_eps0.01": (300, 0.01)}.items():
-            if (it, eps) == (args.iterations, args.epsilon):
+        for name, (it, eps, ex) in {"iterations2_eps0": (2, 0.0, args.exact_math), "iterations30_eps0": (30, 0.0, args.exact_math),
+                                    "defaults_300_eps0.01": (300, 0.01, args.exact_math),
+                                    "iterations10_eps0_exact_math": (10, 0.0, True)}.items():
+            if (it, eps, ex) == (args.iterations, args.epsilon, args.exact_math):
                 continue
-            e2, _, its2, _ = run(it, eps, max(1, args.steps // 2), 1)
+            e2, _, its2, _ = run(it, eps, max(1, args.steps // 2), 1, exact=ex)
             n2 = B * max(1, args.steps // 2)
             m2 = float(np.mean(its2))
             var[name] = {"pairs_per_s": n2 / e2, "executed_iterations_per_warp_mean": m2,
@@ -180,11 +203,15 @@ def main():
         from oracle import oracle as O
         cit = args.cpu_iterations or (args.iterations if args.epsilon == 0 else 300)
         p = O.tvl1_params(iterations=cit, epsilon=args.epsilon)
-        t0 = time.perf_counter()
-        O.tvl1_calc(base[0][0], base[0][1], p)
+        npairs, t0 = 0, time.perf_counter()
+        while npairs < len(base) * 4 and (npairs == 0 or time.perf_counter() - t0 < 10.0):
+            b_ = base[npairs % len(base)]
+            O.tvl1_calc(b_[0], b_[1], p)
+            npairs += 1
         ct = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": f"1 pair {W}x{H}, iterations={cit}, epsilon={args.epsilon}, {ct:.1f} s wall"}
+        out["cpu_baseline"] = {"value": npairs / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{npairs} pair(s) {W}x{H} CV_32FC1, iterations={cit}, epsilon={args.epsilon}, "
+                                         f"{ct:.1f} s wall, oracle/tvl1_ref.c (OpenMP rows, all host cores)"}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
