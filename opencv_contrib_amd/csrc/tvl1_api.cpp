@@ -373,15 +373,20 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
             }
             const bool blocked = !check && !P.exact_math && P.time_block != 1;
             long long nlaunch = 0;
-            for (int it = 0; it < iters_per_warp; ++it) {
-                ++nlaunch;
-                if (blocked) {
-                    // T iterations per HBM pass (tvl1_tb_kernels.hip)
-                    const int T = tb_pick_block(iters_per_warp - it, P.time_block > 0 ? P.time_block : tb_max_block());
-                    rc = iterate_tb(T, pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
+            if (blocked) {
+                // T iterations per HBM pass (tvl1_tb_kernels.hip), decomposition by measured cost
+                std::vector<int> plan(iters_per_warp + 1);
+                const int nb = tb_plan(iters_per_warp, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), iters_per_warp);
+                for (int k = 0; k < nb; ++k) {
+                    ++nlaunch;
+                    rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
+                    if (rc) return rc;
                     cur ^= 1;
-                    it += T - 1;
-                } else if (check) {
+                    first_of_scale = false;
+                }
+            } else for (int it = 0; it < iters_per_warp; ++it) {
+                ++nlaunch;
+                if (check) {
                     Ctl ic = ctl;
                     ic.q = q; ic.q_prev = q_last;
                     ic.first_of_warp = (it == 0);

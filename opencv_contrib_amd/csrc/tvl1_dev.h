@@ -64,6 +64,8 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s);
 int tb_max_block();
+// cost-model decomposition of n iterations into supported blocks (largest first); returns the count
+int tb_plan(int n, int cap, int *blocks, int max_blocks);
 // largest supported block <= n (n >= 1)
 inline int tb_pick_block(int n, int cap)
 {

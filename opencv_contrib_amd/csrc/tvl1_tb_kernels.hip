@@ -20,6 +20,8 @@
 // against the exact-math v1 kernel and the oracle with a stated tolerance.
 #include "tvl1_dev.h"
 #include <cfloat>
+#include <vector>
+#include <cstdlib>
 
 namespace mi {
 namespace tvl1 {
@@ -63,7 +65,9 @@ struct TbArgs {
 template <int PPL>
 __device__ __forceinline__ void ldv(float dst[PPL], const float *p, long long off, bool ok)
 {
-    if (PPL == 2) {
+    if (PPL == 1) {
+        dst[0] = ok ? p[off] : 0.f;
+    } else if (PPL == 2) {
         float2 v = make_float2(0.f, 0.f);
         if (ok) v = *reinterpret_cast<const float2 *>(p + off);
         dst[0] = v.x; dst[1] = v.y;
@@ -76,7 +80,8 @@ __device__ __forceinline__ void ldv(float dst[PPL], const float *p, long long of
 template <int PPL>
 __device__ __forceinline__ void stv(float *p, long long off, const float v[PPL])
 {
-    if (PPL == 2) *reinterpret_cast<float2 *>(p + off) = make_float2(v[0], v[1]);
+    if (PPL == 1) p[off] = v[0];
+    else if (PPL == 2) *reinterpret_cast<float2 *>(p + off) = make_float2(v[0], v[1]);
     else *reinterpret_cast<float4 *>(p + off) = make_float4(v[0], v[1], v[2], v[3]);
 }
 // per-wave LDS ring of static rows: slot layout [plane 0..3][64*PPL floats]
@@ -84,7 +89,9 @@ template <int PPL>
 __device__ __forceinline__ void lds_put(float *slot, int lane, const Stat<PPL> &s)
 {
     float *q = slot + lane * PPL;
-    if (PPL == 2) {
+    if (PPL == 1) {
+        q[0] = s.ix[0]; q[64] = s.iy[0]; q[128] = s.rg[0]; q[192] = s.rc[0];
+    } else if (PPL == 2) {
         *reinterpret_cast<float2 *>(q) = make_float2(s.ix[0], s.ix[1]);
         *reinterpret_cast<float2 *>(q + 128) = make_float2(s.iy[0], s.iy[1]);
         *reinterpret_cast<float2 *>(q + 256) = make_float2(s.rg[0], s.rg[1]);
@@ -100,7 +107,9 @@ template <int PPL>
 __device__ __forceinline__ void lds_get(const float *slot, int lane, Stat<PPL> &s)
 {
     const float *q = slot + lane * PPL;
-    if (PPL == 2) {
+    if (PPL == 1) {
+        s.ix[0] = q[0]; s.iy[0] = q[64]; s.rg[0] = q[128]; s.rc[0] = q[192];
+    } else if (PPL == 2) {
         float2 a = *reinterpret_cast<const float2 *>(q), b = *reinterpret_cast<const float2 *>(q + 128);
         float2 c = *reinterpret_cast<const float2 *>(q + 256), d = *reinterpret_cast<const float2 *>(q + 384);
         s.ix[0] = a.x; s.ix[1] = a.y; s.iy[0] = b.x; s.iy[1] = b.y;
@@ -238,8 +247,8 @@ __device__ __forceinline__ void pipeline_step(Dyn<PPL> &io, const Stat<PPL> &st0
     }
 }
 
-template <int T, int PPL, bool PZ>
-__global__ __launch_bounds__(256) void k_iterate_tb(TbArgs A)
+template <int T, int PPL, bool PZ, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;    // validity margin per side (px)
     constexpr int STRIDE = 64 * PPL - 2 * M;        // owned columns per strip
@@ -326,7 +335,15 @@ __global__ __launch_bounds__(256) void k_iterate_tb(TbArgs A)
 }
 
 // ------------------------------------------------------------------ host side
-template <int T, int PPL>
+// A variant = (T iterations per pass, PPL pixels per lane, WPS = waves/SIMD the register allocator must
+// leave room for).  More waves per SIMD hide the s_waitcnt stalls (rocprofv3: 40 % of wave time at
+// 2 waves/SIMD), fewer registers per wave cap T: the table is the measured trade-off.
+struct TbVariant {
+    int T, PPL, WPS;
+    void (*launch)(const TbArgs &, bool, hipStream_t);
+};
+
+template <int T, int PPL, int WPS>
 static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
@@ -335,41 +352,100 @@ static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
     constexpr size_t lds_bytes = (size_t)4 * (T + 1) * 256 * PPL * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, true, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, false, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tb<T, PPL, true>), grid, dim3(256), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tb<T, PPL, false>), grid, dim3(256), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tb<T, PPL, true, WPS>), grid, dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tb<T, PPL, false, WPS>), grid, dim3(256), lds_bytes, s, A);
+}
+
+#define TBV(T, PPL, WPS) {T, PPL, WPS, launch_tb<T, PPL, WPS>}
+// first entry of each T = default; the others are selectable with MIFLOW_TB_VARIANT="ppl,wps" (tuning sweeps)
+static const TbVariant g_variants[] = {
+    TBV(1, 2, 1), TBV(2, 2, 1), TBV(3, 2, 1), TBV(4, 2, 1), TBV(5, 2, 1), TBV(6, 2, 1), TBV(8, 2, 1), TBV(10, 2, 1),
+    TBV(3, 2, 4), TBV(4, 2, 4), TBV(5, 2, 3), TBV(6, 2, 3),
+    TBV(2, 1, 8), TBV(3, 1, 8), TBV(4, 1, 8), TBV(5, 1, 8), TBV(5, 1, 6), TBV(6, 1, 6), TBV(6, 1, 5), TBV(8, 1, 5),
+    TBV(8, 1, 4), TBV(10, 1, 4), TBV(10, 1, 3),
+};
+
+static const TbVariant *pick_variant(int T)
+{
+    static int want_ppl = -1, want_wps = -1;
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        if (const char *e = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(e, "%d,%d", &want_ppl, &want_wps);
+    }
+    const TbVariant *def = nullptr;
+    for (const TbVariant &v : g_variants) {
+        if (v.T != T) continue;
+        if (!def) def = &v;
+        if (v.PPL == want_ppl && v.WPS == want_wps) return &v;
+    }
+    return def;
 }
 
 int tb_max_block() { return 10; }
+
+// Decompose n iterations into supported time blocks minimising the modelled cost.  cost[T] = measured
+// ps per pixel-iteration of k_iterate_tb<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01a_*):
+// deeper blocks save HBM passes but cost registers (occupancy) and halo recomputation.
+int tb_plan(int n, int cap, int *blocks, int max_blocks)
+{
+    static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
+    static const double cost[11] = {0, 16.0, 9.04, 6.07, 4.73, 4.24, 4.27, 0, 3.80, 0, 5.94};
+    if (n <= 0) return 0;
+    std::vector<double> best(n + 1, 1e300);
+    std::vector<int> pick(n + 1, 1);
+    best[0] = 0;
+    for (int i = 1; i <= n; ++i)
+        for (int t : sup) {
+            if (t > i || t > cap) continue;
+            const double c = best[i - t] + t * cost[t];
+            if (c < best[i]) { best[i] = c; pick[i] = t; }
+        }
+    int k = 0;
+    for (int i = n; i > 0 && k < max_blocks; i -= pick[i]) blocks[k++] = pick[i];
+    return k;
+}
 
 // T fused iterations, set cur -> cur^1.  Returns MI_ERR_BAD_ARG for unsupported T.
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s)
 {
+    const TbVariant *v = pick_variant(T);
+    if (!v) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
     TbArgs A;
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur;
     if (rows_per_band <= 0) {
-        // enough waves for 1024 SIMDs, but keep the 2T-row band overlap small
-        const int strips = div_up(g.w, 128 - 2 * ((T + 1) / 2 * 2));
-        int R = 256;
-        while (R > 32 && (long long)strips * div_up(g.h, R) * g.batch < 2048) R >>= 1;
-        rows_per_band = R;
+        // Band height: every wave streams rows_per_band + 2T rows.  Pick the band count that minimises
+        //   rounds x (rows + 2T),  rounds = ceil(waves / resident-wave capacity),
+        // so the grid fills the 1024 SIMDs in whole rounds (no half-empty tail round) while the 2T-row
+        // band overlap stays small.  Capacity: waves/SIMD allowed by the variant's VGPR count
+        // (-Rpass-analysis=kernel-resource-usage, gfx950), its LDS ring and the 8-wave hardware limit.
+        static const int wps_of_T_ppl2[11] = {8, 7, 5, 4, 3, 3, 2, 2, 2, 2, 2};
+        int wps = v->WPS > 1 ? v->WPS : (v->PPL == 2 ? wps_of_T_ppl2[T] : 4);
+        const int lds_blocks = (160 * 1024) / ((T + 1) * 4 * 256 * v->PPL * 4);
+        if (wps > lds_blocks) wps = lds_blocks;
+        if (const char *e = getenv("MIFLOW_TB_WPS")) wps = atoi(e) > 0 ? atoi(e) : wps;
+        const long long cap = 1024LL * wps;
+        const int M = (T + v->PPL - 1) / v->PPL * v->PPL;
+        const long long per_band = (long long)div_up(g.w, 64 * v->PPL - 2 * M) * g.batch;
+        long long best_cost = -1;
+        int best_nb = 1;
+        for (int nb = 1; nb <= g.h; ++nb) {
+            const int R = div_up(g.h, nb);
+            if (R < 8 && nb > 1) break;
+            const long long rounds = (per_band * nb + cap - 1) / cap;
+            const long long cost = rounds * (R + 2 * T);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_nb = nb; }
+        }
+        rows_per_band = div_up(g.h, best_nb);
+        if (const char *e = getenv("MIFLOW_TB_ROWS")) rows_per_band = atoi(e) > 0 ? atoi(e) : rows_per_band;
     }
     A.rows_per_band = rows_per_band;
-    switch (T) {
-    case 1: launch_tb<1, 2>(A, p_zero, s); break;
-    case 2: launch_tb<2, 2>(A, p_zero, s); break;
-    case 3: launch_tb<3, 2>(A, p_zero, s); break;
-    case 4: launch_tb<4, 2>(A, p_zero, s); break;
-    case 5: launch_tb<5, 2>(A, p_zero, s); break;
-    case 6: launch_tb<6, 2>(A, p_zero, s); break;
-    case 8: launch_tb<8, 2>(A, p_zero, s); break;
-    case 10: launch_tb<10, 2>(A, p_zero, s); break;
-    default: set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG;
-    }
+    v->launch(A, p_zero, s);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

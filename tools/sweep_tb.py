@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--blocks", type=str, default="1,2,3,4,5,6,8,10")
+    ap.add_argument("--tag", type=str, default="")
+    ap.add_argument("--no-v1", action="store_true")
     args = ap.parse_args()
     import torch
     from opencv_contrib_amd import cuda
@@ -49,9 +51,12 @@ def main():
         res[f"T{T}"] = {"ms_N=T": 1e3 * a / B, "ms_N=2T": 1e3 * b / B,
                         "Gpxiter_per_s": px * 5 / per_iter / 1e9,
                         "pairs_per_s_at_N10_extrapolated": 1.0 / (t0 / B + 10 * per_iter)}
-    a, b = t(2, 1, exact=True), t(4, 1, exact=True)
-    res["v1_exact"] = {"Gpxiter_per_s": px * 5 / ((b - a) / 2 / B) / 1e9}
-    print(json.dumps(res, indent=1))
+    if not args.no_v1:
+        a, b = t(2, 1, exact=True), t(4, 1, exact=True)
+        res["v1_exact"] = {"Gpxiter_per_s": px * 5 / ((b - a) / 2 / B) / 1e9}
+    res["tag"] = args.tag
+    res["env"] = {k: v for k, v in os.environ.items() if k.startswith("MIFLOW_")}
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
