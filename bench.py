@@ -70,8 +70,62 @@ def time_steps(alg, I0, I1, flows, steps, warmup, dist):
     return time.perf_counter() - t0
 
 
+def bench_stereobm(args):
+    """BASELINE configs[2]: StereoBM 1920x1080, numDisparities=128, blockSize=15 (secondary workload;
+    the headline metric stays TV-L1).  One step = `--batch` stereo pairs through mi_stereobm_compute."""
+    import numpy as np
+    import torch
+    from opencv_contrib_amd import cuda, synth
+    dev = torch.device("cuda", 0)
+    W, H, B = args.width, args.height, args.batch
+    nd, bs = args.ndisp, args.block_size
+    left, right, _ = synth.stereo_pair(H, W, seed=42, max_disp=70)
+    L = [torch.from_numpy(left).to(dev) for _ in range(B)]
+    Rr = [torch.from_numpy(right).to(dev) for _ in range(B)]
+    D = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(B)]
+    bm = cuda.createStereoBM(nd, bs)
+    for _ in range(args.warmup):
+        for i in range(B):
+            bm.compute(L[i], Rr[i], D[i])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        for i in range(B):
+            bm.compute(L[i], Rr[i], D[i])
+    e1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n = B * args.steps
+    R = bs // 2
+    pxd = float((W - nd - 2 * R) * (H - 2 * R)) * nd
+    algo_bytes = 3.0 * W * H   # read left + right, write disparity (u8)
+    out = {"metric": "frames/sec StereoBM @1080p", "value": n / el, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"StereoBM {W}x{H} numDisparities={nd} blockSize={bs} (BASELINE configs[2]), {B} pairs/step",
+                      "texture_threshold": 3, "uniqueness_ratio": 0},
+           "pixel_disparities_per_s": pxd * n / el,
+           "roofline": {"bound": "hbm", "achieved": algo_bytes * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "not HBM-bound (SURVEY 8d config 3): 6.2 MB/pair of compulsory traffic; the limiter is "
+                                "integer VALU issue: see pixel_disparities_per_s and DESIGN.md"}}
+    if not args.no_cpu:
+        from oracle import oracle as O
+        t0 = time.perf_counter()
+        O.sbm_compute(left, right, O.sbm_params(num_disparities=nd, block_size=bs))
+        ct = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"1 pair {W}x{H}, {ct:.1f} s wall, oracle/stereobm_ref.c (OpenMP rows)"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["tvl1", "stereobm"], default="tvl1")
+    ap.add_argument("--ndisp", type=int, default=128)
+    ap.add_argument("--block-size", type=int, default=15)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -91,6 +145,8 @@ def main():
     args = ap.parse_args()
     if args.defaults:
         args.iterations, args.epsilon = 300, 0.01
+    if args.workload == "stereobm":
+        return bench_stereobm(args)
 
     import numpy as np
     import torch

@@ -147,6 +147,52 @@ MI_API int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_m
 MI_API int mi_resize_linear(int semantics, const mi_mat *src, mi_mat *dst, double fx, double fy,
                             int explicit_dsize, float post_scale, void *stream);
 
+/* ======================================================================= StereoBM ===== */
+
+/* cv::StereoBM::PREFILTER_* (main repo calib3d.hpp); -1 = no prefilter (the cv::cuda default preset_,
+ * cudastereo/src/stereobm.cpp:130) */
+enum { MI_PREFILTER_NONE = -1, MI_PREFILTER_NORMALIZED_RESPONSE = 0, MI_PREFILTER_XSOBEL = 1 };
+
+/* State of StereoBMImpl (cudastereo/src/stereobm.cpp:117-126) + one non-reference knob. */
+typedef struct mi_stereobm_params {
+    int num_disparities;      /* ndisp_: (0,256], multiple of 8 */
+    int block_size;           /* winSize_: odd, 3..51 */
+    int prefilter_type;       /* preset_: MI_PREFILTER_* */
+    int prefilter_cap;        /* preFilterCap_ (31) */
+    int prefilter_size;       /* preFilterSize_ (9), NORMALIZED_RESPONSE window */
+    float texture_threshold;  /* avergeTexThreshold_ (3); <= 0 disables the post-filter */
+    int uniqueness_ratio;     /* uniquenessRatio_ (0 = off) */
+    int emulate_cuda_edge;    /* 1 (default): bit-identical to the CUDA kernel, including the truncated right
+                                 half-window its 128-wide block mapping produces for columns X in [cols-2R, cols-R)
+                                 (stereobm.cu:77-89); 0: full window everywhere */
+} mi_stereobm_params;
+
+typedef struct mi_stereobm mi_stereobm;
+
+MI_API void mi_stereobm_default_params(mi_stereobm_params *p);
+/* Replaces: cv::cuda::createStereoBM, cudastereo/src/stereobm.cpp:194-197 */
+MI_API int mi_stereobm_create(const mi_stereobm_params *p, mi_stereobm **out);
+MI_API int mi_stereobm_set_params(mi_stereobm *h, const mi_stereobm_params *p);
+MI_API int mi_stereobm_get_params(const mi_stereobm *h, mi_stereobm_params *p);
+/* Replaces: StereoBMImpl::compute, cudastereo/src/stereobm.cpp:134-191.  left,right: MI_8UC1, same size;
+ * disp: MI_8UC1 of the same size (allocated by the caller / the C++ shim's OutputArray::create). */
+MI_API int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right, mi_mat *disp, void *stream);
+MI_API void mi_stereobm_destroy(mi_stereobm *h);
+
+/* Stage-level entry points == cv::cuda::device::stereobm:: functions (cudastereo/src/stereobm.cpp:54-63).
+ * Replaces: prefilter_xsobel  cudastereo/src/cuda/stereobm.cu:522-551 */
+MI_API int mi_stereobm_prefilter_xsobel(const mi_mat *src, mi_mat *dst, int prefilter_cap, void *stream);
+/* Replaces: prefilter_norm  stereobm.cu:557-599 */
+MI_API int mi_stereobm_prefilter_norm(const mi_mat *src, mi_mat *dst, int prefilter_cap, int winsize, void *stream);
+/* Replaces: stereoBM_CUDA  stereobm.cu:498-511 (memsets included).  min_ssd: MI_32SC1 scratch/out. */
+MI_API int mi_stereobm_block_match(const mi_mat *left, const mi_mat *right, mi_mat *disp, mi_mat *min_ssd, int ndisp,
+                                   int winsz, int uniqueness_ratio, int emulate_cuda_edge, void *stream);
+/* Replaces: postfilter_textureness  stereobm.cu:698-711 (exact-integer definition, see oracle/stereobm_ref.c) */
+MI_API int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, float avg_texture_threshold, void *stream);
+/* Hardware self-test hook: out_host[0..63] = wave-wide min of in_host[0..63] as seen by every lane,
+ * out_host[64] = lane picked by the reference's tie-break rule among the minima. */
+MI_API int mi_dbg_wave_min(const unsigned *in_host, unsigned *out_host /*[65]*/);
+
 /* Hardware self-test hook: out_host[0..63] = value received from lane n-1, out_host[64..127] = from
  * lane n+1 when every lane n contributes n+100 (DPP wave shifts used by the blocked kernels). */
 MI_API int mi_dbg_lane_shift(int *out_host /*[128]*/);

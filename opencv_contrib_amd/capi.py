@@ -38,6 +38,12 @@ class TVL1Params(C.Structure):
                 ("time_block", C.c_int)]
 
 
+class StereoBMParams(C.Structure):
+    _fields_ = [("num_disparities", C.c_int), ("block_size", C.c_int), ("prefilter_type", C.c_int),
+                ("prefilter_cap", C.c_int), ("prefilter_size", C.c_int), ("texture_threshold", C.c_float),
+                ("uniqueness_ratio", C.c_int), ("emulate_cuda_edge", C.c_int)]
+
+
 _lib = None
 
 
@@ -87,6 +93,17 @@ def lib():
         "mi_tvl1_iterate": (i, [i, i, i, PM, PM, PM, PM, PM, PM, PM, PM, f, f, f, C.POINTER(d), vp]),
         "mi_resize_linear": (i, [i, PM, PM, d, d, i, f, vp]),
         "mi_dbg_lane_shift": (i, [C.POINTER(i)]),
+        "mi_stereobm_default_params": (None, [C.POINTER(StereoBMParams)]),
+        "mi_stereobm_create": (i, [C.POINTER(StereoBMParams), C.POINTER(vp)]),
+        "mi_stereobm_set_params": (i, [vp, C.POINTER(StereoBMParams)]),
+        "mi_stereobm_get_params": (i, [vp, C.POINTER(StereoBMParams)]),
+        "mi_stereobm_compute": (i, [vp, PM, PM, PM, vp]),
+        "mi_stereobm_destroy": (None, [vp]),
+        "mi_stereobm_prefilter_xsobel": (i, [PM, PM, i, vp]),
+        "mi_stereobm_prefilter_norm": (i, [PM, PM, i, i, vp]),
+        "mi_stereobm_block_match": (i, [PM, PM, PM, PM, i, i, i, i, vp]),
+        "mi_stereobm_textureness": (i, [PM, PM, i, f, vp]),
+        "mi_dbg_wave_min": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

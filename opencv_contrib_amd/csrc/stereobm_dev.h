@@ -1,0 +1,23 @@
+// Internal launch API of the StereoBM HIP kernels (stereobm_kernels.hip).  Not part of the C-ABI.
+#pragma once
+#include "mi_common.h"
+
+namespace mi {
+namespace sbm {
+
+// SSD block matching + winner-take-all (+ uniqueness verification pass when uniqueness_ratio > 0).
+// disp must be zero-filled by the caller (stereobm.cu:506); minssd (rows x mstep uint32) is required when
+// uniqueness_ratio > 0, optional otherwise.
+int block_match(const unsigned char *left, long long lstep, const unsigned char *right, long long rstep, unsigned char *disp,
+                long long dstep, unsigned *minssd, long long mstep, int rows, int cols, int ndisp, int winsz,
+                int uniqueness_ratio, int emulate_edge, hipStream_t s);
+int prefilter_xsobel(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,
+                     int cap, hipStream_t s);
+int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,
+                   int cap, int winsize, hipStream_t s);
+int textureness(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, int rows, int cols,
+                int winsz, float avg_threshold, hipStream_t s);
+int dbg_wave_min(const unsigned *in_dev, unsigned *out_dev, hipStream_t s);
+
+}  // namespace sbm
+}  // namespace mi

@@ -1,0 +1,578 @@
+// Block-matching stereo (cv::cuda::StereoBM) -- HIP kernels for gfx950 (MI355X, CDNA4), wave64.
+//
+// Reference: modules/cudastereo/src/cuda/stereobm.cu:66-711 (SSD block matching in batches of 8
+// disparities with column sums in shared memory, prefilters, textureness post-filter) driven by
+// modules/cudastereo/src/stereobm.cpp:139-191.  Results are bit-identical to that code (integer
+// arithmetic; tie-breaking of stereobm.cu:118-127,349; the truncated right half-window of the 128-wide
+// block mapping, SURVEY Appendix B Q1, is reproduced when emulate_edge is set).
+//
+// MI355X formulation (not the reference's thread-per-column / smem-column-sum layout):
+//   * LANE = DISPARITY.  A wave holds 64 consecutive disparities of one image tile; a workgroup is
+//     ndisp/64 waves working on the same tile.  The left pixel is wave-uniform (LDS broadcast read), the
+//     right pixels of the 64 lanes are 64 consecutive bytes read backwards (x - d).
+//   * each lane keeps the vertical column sums of its disparity for all TW + 2R columns of the tile in
+//     VGPRs and slides them down the rows (add the entering row, subtract the leaving one); the
+//     horizontal window is a register sliding sum -- no shared-memory column sums, no per-batch barriers.
+//   * winner-take-all = wave-wide min over lanes (DPP row_shr / row_bcast) + a ballot that reproduces
+//     the reference's "last index inside a batch of 8, first batch across batches" rule with scalar bit
+//     operations.
+//   * uniqueness check (non-default) = closed form of the reference's sequential logic, evaluated by a
+//     second pass of the same kernel (MODE 1) against the winner of pass 0.
+// Rows of both images for the tile are staged in LDS once (byte copies: no alignment assumption on the
+// caller's GpuMat), then read as aligned dwords + v_alignbyte.
+#include "stereobm_dev.h"
+#include <climits>
+#include <cstdlib>
+#include <type_traits>
+
+namespace mi {
+namespace sbm {
+
+// ------------------------------------------------------------------ wave helpers
+// DPP source fetch with "0 for lanes without a source" (bound_ctrl:1 / old = 0): 0 is the identity of an
+// unsigned MAX, so the winner-take-all below runs as a max-reduction over complemented SSDs and every
+// step is a single v_max_u32_dpp with no preparatory v_mov.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+// max over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    v = max(v, dpp_u32<0x111, 0xf>(v));  // row_shr:1
+    v = max(v, dpp_u32<0x112, 0xf>(v));  // row_shr:2
+    v = max(v, dpp_u32<0x114, 0xf>(v));  // row_shr:4
+    v = max(v, dpp_u32<0x118, 0xf>(v));  // row_shr:8   -> lane 15 of each row = row max
+    v = max(v, dpp_u32<0x142, 0xa>(v));  // row_bcast:15 into rows 1,3
+    v = max(v, dpp_u32<0x143, 0xc>(v));  // row_bcast:31 into rows 2,3 -> lane 63 = wave max
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
+// four independent reductions, step-interleaved so the DPP read-after-write wait states of one chain are
+// filled by the other three
+__device__ __forceinline__ void wave_max_u32x4(const unsigned in[4], unsigned out[4])
+{
+    unsigned v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = in[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], dpp_u32<0x111, 0xf>(v[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], dpp_u32<0x112, 0xf>(v[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], dpp_u32<0x114, 0xf>(v[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], dpp_u32<0x118, 0xf>(v[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], dpp_u32<0x142, 0xa>(v[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], dpp_u32<0x143, 0xc>(v[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (unsigned)__builtin_amdgcn_readlane((int)v[k], 63);
+}
+// Among the lanes flagged in `mask` (bit = lane = disparity - 64*set): the reference keeps the LAST
+// index inside a batch of 8 (stereobm.cu:120-125) and the FIRST batch (strict <, :349,426).
+__device__ __forceinline__ int pick_lane(unsigned long long mask)
+{
+    const int first = __builtin_ctzll(mask);
+    const int batch = first >> 3;
+    const unsigned byte = (unsigned)(mask >> (batch * 8)) & 0xffu;
+    return batch * 8 + (31 - __builtin_clz(byte));
+}
+
+// lane `i` of `acc` := wave-uniform value v (v_writelane_b32 semantics)
+__device__ __forceinline__ unsigned put_lane(unsigned acc, unsigned v, int i, int lane)
+{
+    return lane == i ? v : acc;
+}
+
+__global__ void k_dbg_wave_min(const unsigned *in, unsigned *out)
+{
+    const unsigned v = in[threadIdx.x];
+    const unsigned m = wave_min_u32(v);   // = ~max(~v)
+    const unsigned long long mk = __ballot(v == m);
+    out[threadIdx.x] = m;
+    if (threadIdx.x == 0) out[64] = (unsigned)pick_lane(mk);
+}
+
+// ------------------------------------------------------------------ block matching
+struct BmArgs {
+    const unsigned char *left, *right;
+    long long lstep, rstep;
+    unsigned char *disp;
+    long long dstep;
+    unsigned *minssd;      // [rows][mstep] winner SSD (pass 0 writes, pass 1 reads); may be null in pass 0
+    long long mstep;       // elements
+    int rows, cols, ndisp, nsets, rb;
+    int emulate_edge;
+    float thresh_scale;    // (float)(1.0 + uniquenessRatio / 100.0f)  stereobm.cu:273
+};
+
+template <int R>
+struct Cfg {
+    static constexpr int TWr = (64 - 2 * R) & ~3;
+    static constexpr int TW = TWr < 16 ? 16 : TWr;   // output columns per tile
+    static constexpr int NC = TW + 2 * R;            // column sums per lane
+    static constexpr int LS = (NC + 15) / 16 * 16;   // LDS bytes per staged left row
+    static constexpr int NLW = LS / 4;               // dwords per left row
+    static constexpr int NRW = (NC + 3) / 4 + 1;     // aligned dwords a lane reads per right row
+};
+
+// MODE 0: winner-take-all.  MODE 1: uniqueness verification of the pass-0 winner.
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void k_block_match(BmArgs A)
+{
+    using C = Cfg<R>;
+    constexpr int TW = C::TW, NC = C::NC, LS = C::LS, NLW = C::NLW, NRW = C::NRW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wset = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nsets = A.nsets;
+    const int ndp = nsets * 64;                        // padded disparity range
+    const int d = wset * 64 + lane;
+    const bool active = d < A.ndisp;
+    const int X0 = A.ndisp + R + blockIdx.x * TW;      // first output column of the tile
+    const int Y0 = R + blockIdx.y * A.rb;              // first output row
+    const int nrows = min(A.rb, A.rows - R - Y0);
+    const int ncols = min(TW, A.cols - R - X0);        // valid output columns (X < cols - R)
+    if (nrows <= 0 || ncols <= 0) return;
+    const int srows = nrows + 2 * R;                   // staged rows: Y0-R .. Y0+nrows+R-1
+    const int RS = (NC + ndp - 1 + 3) / 4 * 4 + 4;     // LDS bytes per staged right row
+    unsigned char *Ls = smem;
+    unsigned char *Rs = smem + (size_t)(A.rb + 2 * R) * LS;
+    unsigned *comb = reinterpret_cast<unsigned *>(Rs + (size_t)(A.rb + 2 * R) * RS);  // [2][nsets][2][64]
+
+    // ---- stage the tile rows (byte copies; columns outside the image read as 0 and are never used
+    //      by an active lane / valid column)
+    {
+        const int xl0 = X0 - R;                 // left columns xl0 .. xl0+NC-1
+        const int xr0 = X0 - R - (ndp - 1);     // right columns xr0 .. xl0+NC-1
+        const int nthreads = blockDim.x;
+        const int lw = LS, rw = RS;
+        for (int i = threadIdx.x; i < srows * lw; i += nthreads) {
+            const int r = i / lw, c = i - r * lw;
+            const int x = xl0 + c, y = Y0 - R + r;
+            Ls[i] = (x < A.cols) ? A.left[(long long)y * A.lstep + x] : (unsigned char)0;
+        }
+        for (int i = threadIdx.x; i < srows * rw; i += nthreads) {
+            const int r = i / rw, c = i - r * rw;
+            const int x = xr0 + c, y = Y0 - R + r;
+            Rs[i] = (x >= 0 && x < A.cols) ? A.right[(long long)y * A.rstep + x] : (unsigned char)0;
+        }
+    }
+    __syncthreads();
+
+    // lane's byte offset inside a staged right row for column c: c + (ndp-1-d)
+    const int off = ndp - 1 - d;
+    const int q0 = off >> 2, sh = off & 3;
+    const unsigned *Lw = reinterpret_cast<const unsigned *>(Ls);
+    const unsigned *Rw = reinterpret_cast<const unsigned *>(Rs) + q0;
+    const int RSW = RS / 4;
+
+    unsigned cs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cs[c] = 0;
+
+    // inactive lanes (d >= ndisp) carry a bias above any real SSD (max 51*51*255^2 < 2^28) so they never win
+    const unsigned bias = active ? 0u : 0x40000000u;
+    // wave-uniform facts about the tile
+    const bool edge_tile = A.emulate_edge && (X0 + ncols + R > A.cols - R);   // some X + R >= cols - R
+
+    unsigned vd = 0, vo = 0;   // MODE 1: per-lane (lane = tile column) winner disparity / SSD of the row
+
+    const int nsteps = nrows + 2 * R;
+    for (int s = 0; s < nsteps; ++s) {
+        // ---- vertical: add staged row s, subtract staged row s-(2R+1)
+        {
+            unsigned rw[NRW];
+            const unsigned *rp = Rw + s * RSW;
+#pragma unroll
+            for (int i = 0; i < NRW; ++i) rw[i] = rp[i];
+            const unsigned *lp = Lw + s * NLW;
+#pragma unroll
+            for (int i = 0; i < NRW - 1; ++i) {
+                const unsigned rr = __builtin_amdgcn_alignbyte(rw[i + 1], rw[i], sh);
+                const unsigned ll = lp[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = i * 4 + k;
+                    if (c < NC) {
+                        const int e = (int)((ll >> (8 * k)) & 0xff) - (int)((rr >> (8 * k)) & 0xff);
+                        cs[c] += (unsigned)(e * e);
+                    }
+                }
+            }
+        }
+        if (s >= 2 * R + 1) {
+            const int so = s - (2 * R + 1);
+            unsigned rw[NRW];
+            const unsigned *rp = Rw + so * RSW;
+#pragma unroll
+            for (int i = 0; i < NRW; ++i) rw[i] = rp[i];
+            const unsigned *lp = Lw + so * NLW;
+#pragma unroll
+            for (int i = 0; i < NRW - 1; ++i) {
+                const unsigned rr = __builtin_amdgcn_alignbyte(rw[i + 1], rw[i], sh);
+                const unsigned ll = lp[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = i * 4 + k;
+                    if (c < NC) {
+                        const int e = (int)((ll >> (8 * k)) & 0xff) - (int)((rr >> (8 * k)) & 0xff);
+                        cs[c] -= (unsigned)(e * e);
+                    }
+                }
+            }
+        }
+        if (s < 2 * R) continue;
+        const int y = Y0 + s - 2 * R;     // output row
+
+        if (MODE == 1) {
+            // winner of pass 0 for this row: lane i <- tile column i
+            const bool ok = lane < ncols;
+            vd = ok ? A.disp[(long long)y * A.dstep + X0 + lane] : 0u;
+            vo = ok ? A.minssd[(long long)y * A.mstep + X0 + lane] : 0u;
+        }
+
+        // ---- horizontal window + winner per output column (all TW columns: results of columns past
+        //      ncols are discarded at the store, so the TW reductions form one branch-free block the
+        //      scheduler can interleave)
+        unsigned resm = UINT_MAX, resd = 0;   // lane i collects the result of tile column i
+        auto row_stage = [&](auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            // nwin = ~(window SSD) = UINT_MAX - SSD, slid in complemented form (same op count)
+            unsigned nwin = ~bias;
+#pragma unroll
+            for (int c = 0; c < 2 * R; ++c) nwin -= cs[c];
+            unsigned nhalf = ~bias;   // ~(columns i .. i+R: left half + centre), only for the edge emulation
+            if (EDGE) {
+#pragma unroll
+                for (int c = 0; c < R; ++c) nhalf -= cs[c];
+            }
+#pragma unroll
+            for (int i0 = 0; i0 < TW; i0 += 4) {
+                unsigned nsd[4];   // complemented SSD of the 4 columns
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k;
+                    nwin -= cs[i + 2 * R];
+                    nsd[k] = nwin;
+                    if (EDGE) {
+                        nhalf -= cs[i + R];
+                        // stereobm.cu:77-89: threads t < 128-R take the right half-window from thread t+R, whose
+                        // own test X+R < cols-R fails near the right image edge -> the right half is dropped
+                        const int X = X0 + i;
+                        const int t = (X - A.ndisp - R) & 127;
+                        nsd[k] = (t < 128 - R && X + R >= A.cols - R) ? nhalf : nwin;
+                        nhalf += cs[i];
+                    }
+                    nwin += cs[i];
+                }
+                if (MODE == 0) {
+                    unsigned m[4];
+                    wave_max_u32x4(nsd, m);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned long long mk = __ballot(nsd[k] == m[k]);
+                        const int dl = wset * 64 + pick_lane(mk);
+                        resm = put_lane(resm, ~m[k], i0 + k, lane);
+                        resd = put_lane(resd, (unsigned)dl, i0 + k, lane);
+                    }
+                } else {
+                    // closed form of the sequential uniqueness logic (stereobm.cu:311-346,390-422): with
+                    // b* = batch of the final winner, the winner is rejected iff
+                    //   (a) the best candidate of the batches before b* (same tie rules) lies outside
+                    //       dtest+-1 and its SSD <= thresh, or
+                    //   (b) some disparity d >= 8b*-2 outside dtest+-1 has SSD <= thresh,
+                    // thresh = thresh_scale * (float)opt.
+                    unsigned pv[4], pm[4];
+                    bool before[4];
+                    unsigned long long ex[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int dtest = __builtin_amdgcn_readlane((int)vd, i0 + k);
+                        const unsigned opt = (unsigned)__builtin_amdgcn_readlane((int)vo, i0 + k);
+                        const float thresh = A.thresh_scale * (float)opt;
+                        const int b8 = dtest & ~7;
+                        const bool outside = (d < dtest - 1) || (d > dtest + 1);
+                        const bool le = (float)(~nsd[k]) <= thresh;
+                        ex[k] = __ballot(active && d >= b8 - 2 && outside && le);
+                        before[k] = active && d < b8;
+                        pv[k] = before[k] ? nsd[k] : 0u;
+                    }
+                    wave_max_u32x4(pv, pm);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned long long pk = __ballot(before[k] && pv[k] == pm[k]);
+                        const int pd = pk ? wset * 64 + pick_lane(pk ? pk : 1ull) : -1;
+                        // resm: previous-best SSD of this set (UINT_MAX: none); resd: its disparity | exists flag << 16
+                        resm = put_lane(resm, ~pm[k], i0 + k, lane);
+                        resd = put_lane(resd, (unsigned)((pd & 0xffff) | (ex[k] ? 0x10000 : 0)), i0 + k, lane);
+                    }
+                }
+            }
+        };
+        if (edge_tile) row_stage(std::true_type{});
+        else row_stage(std::false_type{});
+
+        // ---- combine the disparity sets of the workgroup (earlier set wins ties) and store
+        unsigned *cb = comb + (size_t)((s & 1) * nsets) * 128;
+        if (nsets > 1) {
+            cb[wset * 128 + lane] = resm;
+            cb[wset * 128 + 64 + lane] = resd;
+            __syncthreads();
+        }
+        if (wset == 0 && lane < ncols) {
+            unsigned bm = resm, bd = resd;
+            if (MODE == 0) {
+                for (int w = 1; w < nsets; ++w) {
+                    const unsigned m = cb[w * 128 + lane];
+                    if (m < bm) { bm = m; bd = cb[w * 128 + 64 + lane]; }
+                }
+                A.disp[(long long)y * A.dstep + X0 + lane] = (unsigned char)bd;
+                if (A.minssd) A.minssd[(long long)y * A.mstep + X0 + lane] = bm;
+            } else {
+                bool ex = (bd >> 16) & 1;
+                int pd = (int)(short)(bd & 0xffff);
+                for (int w = 1; w < nsets; ++w) {
+                    const unsigned m = cb[w * 128 + lane];
+                    const unsigned dd = cb[w * 128 + 64 + lane];
+                    ex = ex || ((dd >> 16) & 1);
+                    if (m < bm) { bm = m; pd = (int)(short)(dd & 0xffff); }
+                }
+                const int dtest = (int)vd;
+                const float thresh = A.thresh_scale * (float)vo;
+                bool reject = ex;
+                if (pd >= 0 && (pd < dtest - 1 || pd > dtest + 1) && ((float)bm <= thresh)) reject = true;
+                if (reject) A.disp[(long long)y * A.dstep + X0 + lane] = 0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ prefilters
+// stereobm.cu:522-536
+__global__ __launch_bounds__(256) void k_prefilter_xsobel(const unsigned char *src, long long sstep, unsigned char *dst,
+                                                          long long dstep, int rows, int cols, int cap)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const unsigned char *r0 = src + (long long)max(0, y - 1) * sstep;
+    const unsigned char *r1 = src + (long long)y * sstep;
+    const unsigned char *r2 = src + (long long)min(y + 1, rows - 1) * sstep;
+    const int xl = max(0, x - 1), xr = min(x + 1, cols - 1);
+    int conv = r0[xl] * (-1) + r0[xr] * (1) + r1[xl] * (-2) + r1[xr] * (2) + r2[xl] * (-1) + r2[xr] * (1);
+    conv = min(min(max(-cap, conv), cap) + cap, 255);
+    dst[(long long)y * dstep + x] = (unsigned char)(conv & 0xFF);
+}
+
+// stereobm.cu:557-581 (x+1 used twice in the 5-point term, :568-570).  One wave per 64 columns walks
+// down a band of rows keeping the winsize x winsize box sum as column sums in LDS-free registers:
+// column sums are recomputed per row from a sliding vertical sum held by the lane.
+__global__ __launch_bounds__(256) void k_prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst,
+                                                        long long dstep, int rows, int cols, int cap, int scale_g,
+                                                        int scale_s, int winsize)
+{
+    __shared__ int colsum[4][64 + 64];   // per wave: 64 own columns + up to 32 halo columns each side
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W2 = winsize / 2;          // host guarantees W2 <= 32
+    const int x = blockIdx.x * 64 + lane;
+    const int yb = (blockIdx.y * 4 + wv) * 32;
+    if (yb >= rows) return;
+    const int ye = min(yb + 32, rows);
+    // lane owns column sums of x (at index 32 + lane) and of one halo column
+    const int xh = lane < 32 ? blockIdx.x * 64 - 32 + lane : blockIdx.x * 64 + 64 + (lane - 32);
+    const int xc = min(max(x, 0), cols - 1), xhc = min(max(xh, 0), cols - 1);
+    int s0 = 0, s1 = 0;
+    for (int i = -W2; i <= W2; ++i) {
+        const long long r = (long long)min(max(yb + i, 0), rows - 1) * sstep;
+        s0 += src[r + xc];
+        s1 += src[r + xhc];
+    }
+    int *cs = colsum[wv];
+    for (int y = yb; y < ye; ++y) {
+        cs[32 + lane] = s0;
+        cs[lane < 32 ? lane : 64 + lane] = s1;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are visible to its own reads
+        __builtin_amdgcn_wave_barrier();
+        if (x < cols) {
+            int cov2 = 0;
+            for (int j = -W2; j <= W2; ++j) cov2 += cs[32 + lane + j];
+            const unsigned char *ru = src + (long long)max(y - 1, 0) * sstep;
+            const unsigned char *rc = src + (long long)y * sstep;
+            const unsigned char *rd = src + (long long)min(y + 1, rows - 1) * sstep;
+            const int xr = min(x + 1, cols - 1);
+            const int cov1 = ru[x] * 1 + rc[xr] * 1 + rc[x] * 4 + rc[xr] * 1 + rd[x] * 1;
+            int res = (cov1 * scale_g - cov2 * scale_s) >> 10;
+            res = min(max(res, -cap), cap) + cap;
+            dst[(long long)y * dstep + x] = (unsigned char)res;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // slide the column sums one row down (clamped rows, like the reference's clamp())
+        const long long ra = (long long)min(max(y + 1 + W2, 0), rows - 1) * sstep;
+        const long long rs = (long long)min(max(y - W2, 0), rows - 1) * sstep;
+        s0 += (int)src[ra + xc] - (int)src[rs + xc];
+        s1 += (int)src[ra + xhc] - (int)src[rs + xhc];
+    }
+}
+
+// ------------------------------------------------------------------ textureness post-filter
+// stereobm.cu:606-711 under the exact-integer definition of oracle/stereobm_ref.c (orc_sbm_textureness):
+// B = 2x2 box sum (the reference's half-pixel bilinear texture fetch x 4 x 255), S = |x-Sobel of B|,
+// zero the disparity when (float)(window sum of S) * 0.25f < avgTexThreshold * winsz^2.
+__device__ __forceinline__ int tex_box4(const unsigned char *img, long long step, int rows, int cols, int x, int y)
+{
+    const int x0 = min(max(x - 1, 0), cols - 1), x1 = min(max(x, 0), cols - 1);
+    const long long r0 = (long long)min(max(y - 1, 0), rows - 1) * step, r1 = (long long)min(max(y, 0), rows - 1) * step;
+    return img[r0 + x0] + img[r0 + x1] + img[r1 + x0] + img[r1 + x1];
+}
+__device__ __forceinline__ int tex_sobel(const unsigned char *img, long long step, int rows, int cols, int x, int y)
+{
+    const int c = -tex_box4(img, step, rows, cols, x - 1, y - 1) + tex_box4(img, step, rows, cols, x + 1, y - 1)
+                  - 2 * tex_box4(img, step, rows, cols, x - 1, y) + 2 * tex_box4(img, step, rows, cols, x + 1, y)
+                  - tex_box4(img, step, rows, cols, x - 1, y + 1) + tex_box4(img, step, rows, cols, x + 1, y + 1);
+    return abs(c);
+}
+
+__global__ __launch_bounds__(256) void k_textureness(const unsigned char *img, long long istep, unsigned char *disp,
+                                                     long long dstep, int rows, int cols, int winsz, float threshold)
+{
+    __shared__ int colsum[4][64 + 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W2 = winsz / 2;   // <= 25
+    const int x = blockIdx.x * 64 + lane;
+    const int yb = (blockIdx.y * 4 + wv) * 32;
+    if (yb >= rows) return;
+    const int ye = min(yb + 32, rows);
+    const int xh = lane < 32 ? blockIdx.x * 64 - 32 + lane : blockIdx.x * 64 + 64 + (lane - 32);
+    int s0 = 0, s1 = 0;
+    for (int i = -W2; i <= W2; ++i) {
+        s0 += tex_sobel(img, istep, rows, cols, x, yb + i);
+        s1 += tex_sobel(img, istep, rows, cols, xh, yb + i);
+    }
+    int *cs = colsum[wv];
+    for (int y = yb; y < ye; ++y) {
+        cs[32 + lane] = s0;
+        cs[lane < 32 ? lane : 64 + lane] = s1;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (x < cols) {
+            const long long o = (long long)y * dstep + x;
+            if (disp[o]) {
+                long long sum = 0;
+                for (int j = -W2; j <= W2; ++j) sum += cs[32 + lane + j];
+                if ((float)sum * 0.25f < threshold) disp[o] = 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        s0 += tex_sobel(img, istep, rows, cols, x, y + 1 + W2) - tex_sobel(img, istep, rows, cols, x, y - W2);
+        s1 += tex_sobel(img, istep, rows, cols, xh, y + 1 + W2) - tex_sobel(img, istep, rows, cols, xh, y - W2);
+    }
+}
+
+// ------------------------------------------------------------------ host launchers
+template <int R>
+static int launch_bm(const BmArgs &A, int mode, hipStream_t s)
+{
+    using C = Cfg<R>;
+    const int RS = (C::NC + A.nsets * 64 - 1 + 3) / 4 * 4 + 4;
+    const size_t lds = (size_t)(A.rb + 2 * R) * (C::LS + RS) + (size_t)2 * A.nsets * 128 * sizeof(unsigned);
+    const dim3 grid(div_up(A.cols - A.ndisp - 2 * R, C::TW), div_up(A.rows - 2 * R, A.rb));
+    const dim3 block(64 * A.nsets);
+    if (mode == 0) {
+        (void)hipFuncSetAttribute((const void *)k_block_match<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_block_match<R, 0>), grid, block, lds, s, A);
+    } else {
+        (void)hipFuncSetAttribute((const void *)k_block_match<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_block_match<R, 1>), grid, block, lds, s, A);
+    }
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+template <int R>
+static int tile_w() { return Cfg<R>::TW; }
+
+typedef int (*bm_launch_t)(const BmArgs &, int, hipStream_t);
+#define L1(r) launch_bm<r>
+static const bm_launch_t g_bm[26] = {nullptr, L1(1), L1(2), L1(3), L1(4), L1(5), L1(6), L1(7), L1(8), L1(9), L1(10),
+                                     L1(11), L1(12), L1(13), L1(14), L1(15), L1(16), L1(17), L1(18), L1(19), L1(20),
+                                     L1(21), L1(22), L1(23), L1(24), L1(25)};
+
+static int tile_w_of(int R)
+{
+    const int t = (64 - 2 * R) & ~3;
+    return t < 16 ? 16 : t;
+}
+
+int block_match(const unsigned char *left, long long lstep, const unsigned char *right, long long rstep, unsigned char *disp,
+                long long dstep, unsigned *minssd, long long mstep, int rows, int cols, int ndisp, int winsz,
+                int uniqueness_ratio, int emulate_edge, hipStream_t s)
+{
+    const int R = winsz >> 1;
+    MI_REQUIRE(R >= 1 && R <= 25, MI_ERR_BAD_ARG, "Unsupported window size");   // stereobm.cu:503-504
+    BmArgs A;
+    A.left = left; A.right = right; A.lstep = lstep; A.rstep = rstep; A.disp = disp; A.dstep = dstep;
+    A.minssd = minssd; A.mstep = mstep; A.rows = rows; A.cols = cols; A.ndisp = ndisp;
+    A.nsets = div_up(ndisp, 64);
+    A.emulate_edge = emulate_edge;
+    A.thresh_scale = (float)(1.0 + uniqueness_ratio / 100.0f);
+    // rows per band: enough waves for the 1024 SIMDs (target ~3 per SIMD) but keep the 2R-row start-up
+    // of every band (column sums of the first window) a modest fraction of the work
+    const int xt = div_up(cols - ndisp - 2 * R, tile_w_of(R));
+    const int vrows = rows - 2 * R;
+    int bands = div_up(3072, xt * A.nsets);
+    int rb = div_up(vrows, bands > 0 ? bands : 1);
+    rb = rb < 2 * R + 2 ? 2 * R + 2 : rb;
+    rb = rb > 96 ? 96 : rb;
+    if (const char *e = getenv("MIFLOW_SBM_ROWS")) rb = atoi(e) > 0 ? atoi(e) : rb;
+    A.rb = rb;
+    int rc = g_bm[R](A, 0, s);
+    if (rc) return rc;
+    if (uniqueness_ratio > 0) rc = g_bm[R](A, 1, s);
+    return rc;
+}
+
+int prefilter_xsobel(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,
+                     int cap, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prefilter_xsobel, dim3(div_up(cols, 64), div_up(rows, 4)), dim3(256), 0, s, src, sstep, dst, dstep,
+                       rows, cols, cap);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,
+                   int cap, int winsize, hipStream_t s)
+{
+    MI_REQUIRE(winsize >= 1 && winsize / 2 <= 32, MI_ERR_BAD_ARG, "preFilterSize must be in [1,65]");
+    MI_REQUIRE(winsize * winsize / 8 > 0, MI_ERR_BAD_ARG, "preFilterSize too small (integer scale is 0)");
+    int scale_g = winsize * winsize / 8, scale_s = (1024 + scale_g) / (scale_g * 2);   // stereobm.cu:591-592
+    scale_g *= scale_s;
+    hipLaunchKernelGGL(k_prefilter_norm, dim3(div_up(cols, 64), div_up(div_up(rows, 32), 4)), dim3(256), 0, s, src, sstep, dst,
+                       dstep, rows, cols, cap, scale_g, scale_s, winsize);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int textureness(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, int rows, int cols,
+                int winsz, float avg_threshold, hipStream_t s)
+{
+    const float threshold = avg_threshold * (float)(winsz * winsz);   // stereobm.cu:700
+    hipLaunchKernelGGL(k_textureness, dim3(div_up(cols, 64), div_up(div_up(rows, 32), 4)), dim3(256), 0, s, img, istep, disp,
+                       dstep, rows, cols, winsz, threshold);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int dbg_wave_min(const unsigned *in_dev, unsigned *out_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dbg_wave_min, dim3(1), dim3(64), 0, s, in_dev, out_dev);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace sbm
+}  // namespace mi

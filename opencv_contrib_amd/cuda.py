@@ -179,3 +179,106 @@ def resize_linear(src, dsize=None, fx=0.0, fy=0.0, semantics=capi.MI_SEM_CPU_REF
 def round_half_even(v: float) -> int:
     import numpy as np
     return int(np.rint(v))
+
+
+# =============================================================================================
+class StereoBM:
+    """cv::cuda::StereoBM (cudastereo.hpp:72-90; StereoBMImpl cudastereo/src/stereobm.cpp:67-132).
+
+    Setters that are no-ops in the reference (minDisparity, speckle*, disp12MaxDiff, smallerBlockSize,
+    ROI1/2: stereobm.cpp:78-115) are no-ops here and their getters return the same constants."""
+
+    PREFILTER_NORMALIZED_RESPONSE, PREFILTER_XSOBEL = 0, 1  # cv::StereoBM (main repo calib3d.hpp)
+
+    def __init__(self, numDisparities=64, blockSize=19, *, emulateCudaEdge=True):
+        p = capi.StereoBMParams()
+        capi.lib().mi_stereobm_default_params(C.byref(p))
+        p.num_disparities, p.block_size, p.emulate_cuda_edge = numDisparities, blockSize, int(bool(emulateCudaEdge))
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_stereobm_create(C.byref(p), C.byref(self._h)))
+        self._p = p
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                capi.lib().mi_stereobm_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+        capi.check(capi.lib().mi_stereobm_set_params(self._h, C.byref(self._p)))
+
+    def getMinDisparity(self): return 0
+    def setMinDisparity(self, v): pass
+    def getNumDisparities(self): return self._p.num_disparities
+    def setNumDisparities(self, v): self._set(num_disparities=v)
+    def getBlockSize(self): return self._p.block_size
+    def setBlockSize(self, v): self._set(block_size=v)
+    def getSpeckleWindowSize(self): return 0
+    def setSpeckleWindowSize(self, v): pass
+    def getSpeckleRange(self): return 0
+    def setSpeckleRange(self, v): pass
+    def getDisp12MaxDiff(self): return 0
+    def setDisp12MaxDiff(self, v): pass
+    def getPreFilterType(self): return self._p.prefilter_type
+    def setPreFilterType(self, v): self._set(prefilter_type=v)
+    def getPreFilterSize(self): return self._p.prefilter_size
+    def setPreFilterSize(self, v): self._set(prefilter_size=v)
+    def getPreFilterCap(self): return self._p.prefilter_cap
+    def setPreFilterCap(self, v): self._set(prefilter_cap=v)
+    def getTextureThreshold(self): return int(self._p.texture_threshold)
+    def setTextureThreshold(self, v): self._set(texture_threshold=float(v))
+    def getUniquenessRatio(self): return self._p.uniqueness_ratio
+    def setUniquenessRatio(self, v): self._set(uniqueness_ratio=v)
+    def getSmallerBlockSize(self): return 0
+    def setSmallerBlockSize(self, v): pass
+
+    def compute(self, left, right, disparity=None, stream=None):
+        """compute(left, right, disparity[, stream]) (cudastereo.hpp:80-82).  Returns CV_8UC1 disparity."""
+        import torch
+        if disparity is None:  # _disparity.create(left.size(), CV_8UC1)  stereobm.cpp:154
+            disparity = torch.empty((left.shape[0], left.shape[1]), dtype=torch.uint8, device=left.device)
+        ml, mr, md = capi.mat_from_tensor(left), capi.mat_from_tensor(right), capi.mat_from_tensor(disparity)
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        capi.check(capi.lib().mi_stereobm_compute(self._h, C.byref(ml), C.byref(mr), C.byref(md), sp))
+        return disparity
+
+
+def createStereoBM(numDisparities=64, blockSize=19, **kw) -> StereoBM:
+    """cv::cuda::createStereoBM (cudastereo.hpp:90)."""
+    return StereoBM(numDisparities, blockSize, **kw)
+
+
+def stereobm_prefilter_xsobel(img, cap=31):
+    import torch
+    out = torch.empty_like(img)
+    capi.check(capi.lib().mi_stereobm_prefilter_xsobel(C.byref(_m(img)), C.byref(_m(out)), cap, capi.current_stream_ptr()))
+    return out
+
+
+def stereobm_prefilter_norm(img, cap=31, winsize=9):
+    import torch
+    out = torch.empty_like(img)
+    capi.check(capi.lib().mi_stereobm_prefilter_norm(C.byref(_m(img)), C.byref(_m(out)), cap, winsize, capi.current_stream_ptr()))
+    return out
+
+
+def stereobm_block_match(left, right, ndisp=64, winsz=19, uniqueness_ratio=0, emulate_cuda_edge=True):
+    """-> (disp CV_8UC1, minSSD CV_32SC1 holding uint32 bit patterns)."""
+    import torch
+    disp = torch.empty_like(left)
+    ssd = torch.empty(left.shape, dtype=torch.int32, device=left.device)
+    capi.check(capi.lib().mi_stereobm_block_match(C.byref(_m(left)), C.byref(_m(right)), C.byref(_m(disp)), C.byref(_m(ssd)),
+                                                  ndisp, winsz, uniqueness_ratio, int(bool(emulate_cuda_edge)),
+                                                  capi.current_stream_ptr()))
+    return disp, ssd
+
+
+def stereobm_textureness(img, disp, winsz=19, avg_threshold=3.0):
+    out = disp.clone()
+    capi.check(capi.lib().mi_stereobm_textureness(C.byref(_m(img)), C.byref(_m(out)), winsz, avg_threshold,
+                                                  capi.current_stream_ptr()))
+    return out

@@ -39,7 +39,14 @@ class TVL1Stats(C.Structure):
                 ("iters", (C.c_int * 64) * 32)]
 
 
+class SBMParams(C.Structure):
+    _fields_ = [("num_disparities", C.c_int), ("block_size", C.c_int), ("prefilter_type", C.c_int),
+                ("prefilter_cap", C.c_int), ("prefilter_size", C.c_int), ("texture_threshold", C.c_float),
+                ("uniqueness_ratio", C.c_int), ("emulate_edge", C.c_int)]
+
+
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 
 def lib():
@@ -67,7 +74,19 @@ def lib():
         L.orc_tvl1_warp.argtypes = [C.c_int] + [_f32p] * 6 + [C.c_int, C.c_int] + [_f32p] * 5
         L.orc_tvl1_iteration.restype = C.c_float
         L.orc_tvl1_iteration.argtypes = [C.c_int] + [_f32p] * 4 + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 4
+        _bind_stereobm(L)
     return _lib
+
+
+def _bind_stereobm(L):
+    L.orc_sbm_default_params.argtypes = [C.POINTER(SBMParams)]
+    L.orc_sbm_prefilter_xsobel.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+    L.orc_sbm_prefilter_norm.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_sbm_block_match.restype = C.c_int
+    L.orc_sbm_block_match.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_void_p]
+    L.orc_sbm_textureness.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_float, _u8p]
+    L.orc_sbm_compute.restype = C.c_int
+    L.orc_sbm_compute.argtypes = [C.POINTER(SBMParams), _u8p, _u8p, C.c_int, C.c_int, _u8p]
 
 
 def _c(a, dt=np.float32):
@@ -214,3 +233,68 @@ def tvl1_iteration(semantics, I1wx, I1wy, grad, rho_c, u1, u2, p11, p12, p21, p2
     if u3 is not None:
         out = out + (u3c, p3[0], p3[1])
     return out
+
+
+# ---------------------------------------------------------------- StereoBM (cv::cuda::StereoBM semantics)
+def sbm_params(**kw) -> SBMParams:
+    """createStereoBM defaults (cudastereo.hpp:90, stereobm.cpp:129-132), overridden by kw."""
+    p = SBMParams()
+    lib().orc_sbm_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown StereoBM parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8 or a.ndim != 2:
+        raise ValueError("CV_8UC1 image required")  # CV_Assert, stereobm.cpp:151
+    return a
+
+
+def sbm_prefilter_xsobel(img, cap=31):
+    img = _u8(img)
+    out = np.empty_like(img)
+    lib().orc_sbm_prefilter_xsobel(img, out, img.shape[0], img.shape[1], cap)
+    return out
+
+
+def sbm_prefilter_norm(img, cap=31, winsize=9):
+    img = _u8(img)
+    out = np.empty_like(img)
+    lib().orc_sbm_prefilter_norm(img, out, img.shape[0], img.shape[1], cap, winsize)
+    return out
+
+
+def sbm_block_match(left, right, ndisp=64, winsz=19, uniqueness_ratio=0, emulate_edge=True, return_ssd=False):
+    left, right = _u8(left), _u8(right)
+    if left.shape != right.shape:
+        raise ValueError("left/right size mismatch")  # stereobm.cpp:152
+    disp = np.empty_like(left)
+    ssd = np.empty(left.shape, np.uint32) if return_ssd else None
+    rc = lib().orc_sbm_block_match(left, right, left.shape[0], left.shape[1], ndisp, winsz, uniqueness_ratio,
+                                   int(emulate_edge), disp, ssd.ctypes.data if return_ssd else None)
+    if rc != 0:
+        raise ValueError(f"orc_sbm_block_match failed: {rc}")
+    return (disp, ssd) if return_ssd else disp
+
+
+def sbm_textureness(img, disp, winsz=19, avg_threshold=3.0):
+    img = _u8(img)
+    out = _u8(disp).copy()
+    lib().orc_sbm_textureness(img, img.shape[0], img.shape[1], winsz, avg_threshold, out)
+    return out
+
+
+def sbm_compute(left, right, params: SBMParams | None = None):
+    p = params or sbm_params()
+    left, right = _u8(left), _u8(right)
+    if left.shape != right.shape:
+        raise ValueError("left/right size mismatch")
+    disp = np.empty_like(left)
+    rc = lib().orc_sbm_compute(C.byref(p), left, right, left.shape[0], left.shape[1], disp)
+    if rc != 0:
+        raise ValueError(f"orc_sbm_compute failed: {rc}")
+    return disp
