@@ -1,0 +1,80 @@
+// Drop-in for modules/cudaoptflow/include/opencv2/cudaoptflow.hpp (the classes on the hot path):
+// same class names, factory signatures, defaults and getters/setters; implementation = the miflow
+// C-ABI (include/miflow/c_api.h, libmiflow.so) running hand-written gfx950 HIP kernels.
+#ifndef MIFLOW_OPENCV_CUDAOPTFLOW_HPP
+#define MIFLOW_OPENCV_CUDAOPTFLOW_HPP
+
+#include "opencv2/core/cuda.hpp"
+
+namespace cv { namespace cuda {
+
+/** cudaoptflow.hpp:70-81 */
+class DenseOpticalFlow : public Algorithm {
+public:
+    virtual void calc(InputArray I0, InputArray I1, InputOutputArray flow, Stream &stream = Stream::Null()) = 0;
+};
+
+/** cudaoptflow.hpp:305-386; implementation twin of OpticalFlowDual_TVL1_Impl, cudaoptflow/src/tvl1flow.cpp:80-168 */
+class OpticalFlowDual_TVL1 : public DenseOpticalFlow {
+public:
+    virtual double getTau() const = 0;             virtual void setTau(double tau) = 0;
+    virtual double getLambda() const = 0;          virtual void setLambda(double lambda) = 0;
+    virtual double getGamma() const = 0;           virtual void setGamma(double gamma) = 0;
+    virtual double getTheta() const = 0;           virtual void setTheta(double theta) = 0;
+    virtual int getNumScales() const = 0;          virtual void setNumScales(int nscales) = 0;
+    virtual int getNumWarps() const = 0;           virtual void setNumWarps(int warps) = 0;
+    virtual double getEpsilon() const = 0;         virtual void setEpsilon(double epsilon) = 0;
+    virtual int getNumIterations() const = 0;      virtual void setNumIterations(int iterations) = 0;
+    virtual double getScaleStep() const = 0;       virtual void setScaleStep(double scaleStep) = 0;
+    virtual bool getUseInitialFlow() const = 0;    virtual void setUseInitialFlow(bool useInitialFlow) = 0;
+
+    static Ptr<OpticalFlowDual_TVL1> create(double tau = 0.25, double lambda = 0.15, double theta = 0.3, int nscales = 5,
+                                            int warps = 5, double epsilon = 0.01, int iterations = 300,
+                                            double scaleStep = 0.8, double gamma = 0.0, bool useInitialFlow = false);
+};
+
+namespace miflow_detail {
+class TVL1Impl final : public OpticalFlowDual_TVL1 {
+public:
+    explicit TVL1Impl(const mi_tvl1_params &p) : p_(p) { miCheck(mi_tvl1_create(&p_, &h_)); }
+    ~TVL1Impl() override { mi_tvl1_destroy(h_); }
+    TVL1Impl(const TVL1Impl &) = delete;
+    TVL1Impl &operator=(const TVL1Impl &) = delete;
+    void calc(InputArray I0, InputArray I1, InputOutputArray flow, Stream &stream) override
+    {
+        // BufferPool/merge of the reference (tvl1flow.cpp:175-182): the flow matrix is (re)allocated by the callee
+        if (!p_.use_initial_flow) flow.create(I0.size(), CV_32FC2);
+        mi_mat a = miMat(I0), b = miMat(I1), f = miMat(flow);
+        miCheck(mi_tvl1_calc(h_, &a, &b, &f, stream.hipStream()));
+    }
+    String getDefaultName() const override { return "DenseOpticalFlow.OpticalFlowDual_TVL1"; }   // tvl1flow.cpp:122
+#define MIFLOW_PROP(T, Name, field) \
+    T get##Name() const override { return (T)p_.field; } \
+    void set##Name(T v) override { mi_tvl1_params q = p_; q.field = v; miCheck(mi_tvl1_set_params(h_, &q)); p_ = q; }
+    MIFLOW_PROP(double, Tau, tau) MIFLOW_PROP(double, Lambda, lambda) MIFLOW_PROP(double, Gamma, gamma)
+    MIFLOW_PROP(double, Theta, theta) MIFLOW_PROP(int, NumScales, nscales) MIFLOW_PROP(int, NumWarps, warps)
+    MIFLOW_PROP(double, Epsilon, epsilon) MIFLOW_PROP(int, NumIterations, iterations) MIFLOW_PROP(double, ScaleStep, scale_step)
+#undef MIFLOW_PROP
+    bool getUseInitialFlow() const override { return p_.use_initial_flow != 0; }
+    void setUseInitialFlow(bool v) override { mi_tvl1_params q = p_; q.use_initial_flow = v; miCheck(mi_tvl1_set_params(h_, &q)); p_ = q; }
+    // non-reference knobs of the C-ABI (semantics, exact_math, time_block): reachable through the handle
+    mi_tvl1 *handle() { return h_; }
+private:
+    mi_tvl1_params p_;
+    mi_tvl1 *h_ = nullptr;
+};
+}  // namespace miflow_detail
+
+inline Ptr<OpticalFlowDual_TVL1> OpticalFlowDual_TVL1::create(double tau, double lambda, double theta, int nscales, int warps,
+                                                              double epsilon, int iterations, double scaleStep, double gamma,
+                                                              bool useInitialFlow)
+{
+    mi_tvl1_params p;
+    mi_tvl1_default_params(&p);
+    p.tau = tau; p.lambda = lambda; p.theta = theta; p.nscales = nscales; p.warps = warps; p.epsilon = epsilon;
+    p.iterations = iterations; p.scale_step = scaleStep; p.gamma = gamma; p.use_initial_flow = useInitialFlow;
+    return makePtr<miflow_detail::TVL1Impl>(p);
+}
+
+}}  // namespace cv::cuda
+#endif

@@ -1,0 +1,93 @@
+// Drop-in for modules/cudastereo/include/opencv2/cudastereo.hpp (cuda::StereoBM + createStereoBM).
+#ifndef MIFLOW_OPENCV_CUDASTEREO_HPP
+#define MIFLOW_OPENCV_CUDASTEREO_HPP
+
+#include "opencv2/core/cuda.hpp"
+
+namespace cv {
+
+#ifndef MIFLOW_WITH_OPENCV
+/** the part of cv::StereoMatcher / cv::StereoBM (main repo calib3d.hpp) that cuda::StereoBM inherits */
+class StereoMatcher : public Algorithm {
+public:
+    virtual int getMinDisparity() const = 0;       virtual void setMinDisparity(int) = 0;
+    virtual int getNumDisparities() const = 0;     virtual void setNumDisparities(int) = 0;
+    virtual int getBlockSize() const = 0;          virtual void setBlockSize(int) = 0;
+    virtual int getSpeckleWindowSize() const = 0;  virtual void setSpeckleWindowSize(int) = 0;
+    virtual int getSpeckleRange() const = 0;       virtual void setSpeckleRange(int) = 0;
+    virtual int getDisp12MaxDiff() const = 0;      virtual void setDisp12MaxDiff(int) = 0;
+};
+class StereoBM : public StereoMatcher {
+public:
+    enum { PREFILTER_NORMALIZED_RESPONSE = 0, PREFILTER_XSOBEL = 1 };
+    virtual int getPreFilterType() const = 0;      virtual void setPreFilterType(int) = 0;
+    virtual int getPreFilterSize() const = 0;      virtual void setPreFilterSize(int) = 0;
+    virtual int getPreFilterCap() const = 0;       virtual void setPreFilterCap(int) = 0;
+    virtual int getTextureThreshold() const = 0;   virtual void setTextureThreshold(int) = 0;
+    virtual int getUniquenessRatio() const = 0;    virtual void setUniquenessRatio(int) = 0;
+    virtual int getSmallerBlockSize() const = 0;   virtual void setSmallerBlockSize(int) = 0;
+    virtual Rect getROI1() const = 0;              virtual void setROI1(Rect) = 0;
+    virtual Rect getROI2() const = 0;              virtual void setROI2(Rect) = 0;
+};
+#endif
+
+namespace cuda {
+
+/** cudastereo.hpp:72-84 */
+class StereoBM : public cv::StereoBM {
+public:
+    virtual void compute(InputArray left, InputArray right, OutputArray disparity) = 0;
+    virtual void compute(InputArray left, InputArray right, OutputArray disparity, Stream &stream) = 0;
+};
+
+namespace miflow_detail {
+/** twin of StereoBMImpl, cudastereo/src/stereobm.cpp:67-132 (no-op setters and constant getters included) */
+class StereoBMImpl final : public cuda::StereoBM {
+public:
+    StereoBMImpl(int numDisparities, int blockSize)
+    {
+        mi_stereobm_default_params(&p_);
+        p_.num_disparities = numDisparities; p_.block_size = blockSize;
+        miCheck(mi_stereobm_create(&p_, &h_));
+    }
+    ~StereoBMImpl() override { mi_stereobm_destroy(h_); }
+    StereoBMImpl(const StereoBMImpl &) = delete;
+    StereoBMImpl &operator=(const StereoBMImpl &) = delete;
+    void compute(InputArray left, InputArray right, OutputArray disparity) override { compute(left, right, disparity, Stream::Null()); }
+    void compute(InputArray left, InputArray right, OutputArray disparity, Stream &stream) override
+    {
+        disparity.create(left.size(), CV_8UC1);   // stereobm.cpp:154
+        mi_mat l = miMat(left), r = miMat(right), d = miMat(disparity);
+        miCheck(mi_stereobm_compute(h_, &l, &r, &d, stream.hipStream()));
+    }
+    int getMinDisparity() const override { return 0; }           void setMinDisparity(int) override {}
+    int getNumDisparities() const override { return p_.num_disparities; }
+    void setNumDisparities(int v) override { p_.num_disparities = v; push(); }
+    int getBlockSize() const override { return p_.block_size; }   void setBlockSize(int v) override { p_.block_size = v; push(); }
+    int getSpeckleWindowSize() const override { return 0; }      void setSpeckleWindowSize(int) override {}
+    int getSpeckleRange() const override { return 0; }           void setSpeckleRange(int) override {}
+    int getDisp12MaxDiff() const override { return 0; }          void setDisp12MaxDiff(int) override {}
+    int getPreFilterType() const override { return p_.prefilter_type; }  void setPreFilterType(int v) override { p_.prefilter_type = v; push(); }
+    int getPreFilterSize() const override { return p_.prefilter_size; }  void setPreFilterSize(int v) override { p_.prefilter_size = v; push(); }
+    int getPreFilterCap() const override { return p_.prefilter_cap; }    void setPreFilterCap(int v) override { p_.prefilter_cap = v; push(); }
+    int getTextureThreshold() const override { return (int)p_.texture_threshold; }
+    void setTextureThreshold(int v) override { p_.texture_threshold = (float)v; push(); }
+    int getUniquenessRatio() const override { return p_.uniqueness_ratio; }  void setUniquenessRatio(int v) override { p_.uniqueness_ratio = v; push(); }
+    int getSmallerBlockSize() const override { return 0; }       void setSmallerBlockSize(int) override {}
+    Rect getROI1() const override { return Rect(); }             void setROI1(Rect) override {}
+    Rect getROI2() const override { return Rect(); }             void setROI2(Rect) override {}
+private:
+    void push() { miCheck(mi_stereobm_set_params(h_, &p_)); }
+    mi_stereobm_params p_;
+    mi_stereobm *h_ = nullptr;
+};
+}  // namespace miflow_detail
+
+/** cudastereo.hpp:90 */
+inline Ptr<cuda::StereoBM> createStereoBM(int numDisparities = 64, int blockSize = 19)
+{
+    return makePtr<miflow_detail::StereoBMImpl>(numDisparities, blockSize);
+}
+
+}}  // namespace cv::cuda
+#endif

@@ -1,0 +1,52 @@
+// Source-compatibility smoke test of the C++ drop-in headers: the code below is written the way a caller of
+// the reference writes it (cudaoptflow/samples/optical_flow.cpp:184-185, cudastereo/test/test_stereo.cpp:76-80).
+// Usage: shim_smoke <in.bin> <out.bin>   (in: int32 h, w; u8 I0[h*w], I1[h*w]; out: f32 flow[h*w*2], u8 disp[h*w])
+// Without a GPU it must fail with cv::Exception (no CPU fallback) and return 3.
+#include <cstdio>
+#include <vector>
+#include "opencv2/cudaoptflow.hpp"
+#include "opencv2/cudastereo.hpp"
+
+int main(int argc, char **argv)
+{
+    using namespace cv;
+    try {
+        Ptr<cuda::OpticalFlowDual_TVL1> tvl1 = cuda::OpticalFlowDual_TVL1::create();
+        if (tvl1->getNumIterations() != 300 || tvl1->getDefaultName() != "DenseOpticalFlow.OpticalFlowDual_TVL1") return 2;
+        tvl1->setNumIterations(10);
+        tvl1->setEpsilon(0.0);
+        Ptr<cuda::StereoBM> bm = cuda::createStereoBM(32, 9);
+        if (argc < 3) return 0;
+        FILE *f = fopen(argv[1], "rb");
+        if (!f) return 4;
+        int hw[2];
+        if (fread(hw, 4, 2, f) != 2) return 4;
+        const int h = hw[0], w = hw[1];
+        std::vector<unsigned char> a((size_t)h * w), b((size_t)h * w);
+        if (fread(a.data(), 1, a.size(), f) != a.size() || fread(b.data(), 1, b.size(), f) != b.size()) return 4;
+        fclose(f);
+        cuda::GpuMat d0(h, w, CV_8UC1), d1(h, w, CV_8UC1), flow, disp;
+        d0.upload(a.data(), (size_t)w);
+        d1.upload(b.data(), (size_t)w);
+        cuda::Stream stream;
+        tvl1->calc(d0, d1, flow, stream);
+        bm->compute(d0, d1, disp, stream);
+        stream.waitForCompletion();
+        if (flow.type() != CV_32FC2 || flow.size() != d0.size() || disp.type() != CV_8UC1) return 5;
+        std::vector<float> hf((size_t)h * w * 2);
+        std::vector<unsigned char> hd((size_t)h * w);
+        flow.download(hf.data(), (size_t)w * 8);
+        disp.download(hd.data(), (size_t)w);
+        FILE *o = fopen(argv[2], "wb");
+        fwrite(hf.data(), 4, hf.size(), o);
+        fwrite(hd.data(), 1, hd.size(), o);
+        fclose(o);
+        // error mapping: CV_Assert-style failures surface as cv::Exception
+        bool threw = false;
+        try { cuda::GpuMat bad(h, w, CV_32FC1); bm->compute(bad, bad, disp); } catch (const cv::Exception &) { threw = true; }
+        return threw ? 0 : 6;
+    } catch (const cv::Exception &e) {
+        fprintf(stderr, "cv::Exception %d: %s\n", e.code, e.what());
+        return 3;
+    }
+}
