@@ -32,7 +32,8 @@ struct mi_tvl1 {
     size_t arena_floats = 0;
     std::vector<LevelBuf> L;
     // full-resolution-capacity scratch planes (re-laid-out densely per level)
-    float *scr[6] = {};    // I1x, I1y, I1wx, I1wy, grad, rho_c
+    float *scr[6] = {};    // scr[0..1] unused (kept for layout), I1wx, I1wy, grad, rho_c
+    float *pack = nullptr; // float4 {I1, I1x, I1y, 0} per pixel of the current level
     float *pbuf[2][4] = {};
     float *cubic_tab = nullptr;
     PtrTab *tab_dev = nullptr;
@@ -194,7 +195,8 @@ static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
     }
     const size_t nfull = (size_t)geo[0].ps * B;
     size_t offScr[6], offP[8];
-    for (int k = 0; k < 6; ++k) offScr[k] = take(nfull);
+    for (int k = 0; k < 6; ++k) offScr[k] = k < 2 ? 0 : take(nfull);
+    const size_t offPack = take(nfull * 4);
     for (int k = 0; k < 8; ++k) offP[k] = take(nfull);
     MI_HIP_TRY(hipMalloc((void **)&h->arena, total * sizeof(float)));
     h->arena_floats = total;
@@ -206,6 +208,7 @@ static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
         for (int k = 0; k < 4; ++k) h->L[l].u[k >> 1][k & 1] = h->arena + offU[l * 4 + k];
     }
     for (int k = 0; k < 6; ++k) h->scr[k] = h->arena + offScr[k];
+    h->pack = h->arena + offPack;
     for (int k = 0; k < 8; ++k) h->pbuf[k >> 2][k & 3] = h->arena + offP[k];
     h->capW = W; h->capH = H; h->capB = B; h->capScales = h->P.nscales; h->capStep = h->P.scale_step;
     return MI_OK;
@@ -345,8 +348,9 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         LevelBuf &Lv = h->L[s];
         Geo g = Lv.g;
         // dense per-level re-layout of the full-resolution scratch planes
-        float *I1x = h->scr[0], *I1y = h->scr[1], *I1wx = h->scr[2], *I1wy = h->scr[3], *grad = h->scr[4], *rho = h->scr[5];
-        rc = gradient(Lv.I1, I1x, I1y, g, st);
+        float *I1wx = h->scr[2], *I1wy = h->scr[3], *grad = h->scr[4], *rho = h->scr[5];
+        // pair stride of the packed plane is g.ps float4 = 4*g.ps floats: same element index as the planes
+        rc = gradient_pack(Lv.I1, h->pack, g, st);
         if (rc) return rc;
         const float *u1v[2] = {Lv.u[0][0], Lv.u[1][0]}, *u2v[2] = {Lv.u[0][1], Lv.u[1][1]};
         IterPlanes pl;
@@ -363,7 +367,7 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
             wc.q_prev = q_last;
             // at the first warp of a scale u lives in set 0 (host-known)
             const bool dev_cur = check && !first_of_scale;
-            rc = warp(sem, Lv.I0, Lv.I1, I1x, I1y, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g,
+            rc = warp(sem, Lv.I0, h->pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g,
                       dev_cur ? &wc : nullptr, cur, st);
             if (rc) return rc;
             int e0 = -1, e1 = -1;

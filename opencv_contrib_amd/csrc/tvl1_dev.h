@@ -50,10 +50,12 @@ int resize(int semantics, int nplanes, const float *const src[3][2], int src_set
            const Geo &gs, const Geo &gd, double inv_scale_x, double inv_scale_y,
            const float post_scale[3], const Ctl *ctl, int cur_host, hipStream_t s);
 int gradient(const float *src, float *dx, float *dy, const Geo &g, hipStream_t s);
-int warp(int semantics, const float *I0, const float *I1, const float *I1x, const float *I1y,
-         const float *u1[2], const float *u2[2], float *I1w, float *I1wx, float *I1wy, float *grad,
-         float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
-         hipStream_t s);
+// pk = one float4 {I1, I1x, I1y, 0} per pixel (4 * g.ps floats per pair, 16-B aligned)
+int gradient_pack(const float *src, float *pk, const Geo &g, hipStream_t s);
+int pack3(const float *a, const float *b, const float *c, float *pk, const Geo &g, hipStream_t s);
+int warp(int semantics, const float *I0, const float *pk, const float *u1[2], const float *u2[2], float *I1w,
+         float *I1wx, float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl,
+         int cur_host, hipStream_t s);
 // one fused iteration (estimateU + estimateDualVariables), set cur -> set cur^1.
 // p_zero: p_in is known to be all-zero (first iteration of a scale) and is not read.
 int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut,

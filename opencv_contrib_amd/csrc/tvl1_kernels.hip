@@ -171,9 +171,37 @@ __global__ __launch_bounds__(256) void k_gradient(const float *src, float *dxp, 
     dyp[o] = 0.5f * (d - u);
 }
 
+// Same differences, written together with the image as one float4 per pixel {I1, I1x, I1y, 0}: the warp
+// kernel then gathers ONE 16-B element per bicubic tap instead of three dwords (the gather is bound by the
+// texture-addresser rate of ~4 lanes/clk per wave-load, rocprofv3 r01a: 48 dword gathers/px = 308 us/launch).
+__global__ __launch_bounds__(256) void k_gradient_pack(const float *src, float4 *pk, Geo g)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const float *S = src + (long long)b * g.ps;
+    const long long r = (long long)y * g.ld;
+    const float c = S[r + x];
+    const float l = S[r + max(x - 1, 0)], rr = S[r + min(x + 1, g.w - 1)];
+    const float u = S[(long long)max(y - 1, 0) * g.ld + x], d = S[(long long)min(y + 1, g.h - 1) * g.ld + x];
+    pk[(long long)b * g.ps + r + x] = make_float4(c, 0.5f * (rr - l), 0.5f * (d - u), 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_pack3(const float *a, const float *b_, const float *c, float4 *pk, Geo g)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (x >= g.w || y >= g.h) return;
+    const long long o = (long long)b * g.ps + (long long)y * g.ld + x;
+    pk[o] = make_float4(a[o], b_[o], c[o], 0.f);
+}
+
 // ------------------------------------------------------------------ warp
 struct WarpArgs {
-    const float *I0, *I1, *I1x, *I1y;
+    const float *I0;
+    const float4 *pk;   // {I1, I1x, I1y, 0} per pixel
     const float *u1[2], *u2[2];
     float *I1w, *I1wx, *I1wy, *grad, *rho;
     const float *tab;  // 32x4 cubic phase table (CPU_REF)
@@ -206,7 +234,7 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host
     const long long pb = (long long)b * A.g.ps;
     const long long o = pb + (long long)y * ld + x;
     const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
-    const float *P0 = A.I1 + pb, *P1 = A.I1x + pb, *P2 = A.I1y + pb;
+    const float4 *P = A.pk + pb;
     float v0, v1, v2;
     if (SEM == MI_SEM_CPU_REF) {
         // buildFlowMap + cv::remap(INTER_CUBIC, BORDER_CONSTANT 0):
@@ -225,25 +253,23 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host
             const long long base = (long long)sy * ld + sx;
             float s0, s1, s2;
             {
-                const float *S = P0 + base;
-                s0 = S[0] * w[0] + S[1] * w[1] + S[2] * w[2] + S[3] * w[3]; S += ld;
-                s0 += S[0] * w[4] + S[1] * w[5] + S[2] * w[6] + S[3] * w[7]; S += ld;
-                s0 += S[0] * w[8] + S[1] * w[9] + S[2] * w[10] + S[3] * w[11]; S += ld;
-                s0 += S[0] * w[12] + S[1] * w[13] + S[2] * w[14] + S[3] * w[15];
-            }
-            {
-                const float *S = P1 + base;
-                s1 = S[0] * w[0] + S[1] * w[1] + S[2] * w[2] + S[3] * w[3]; S += ld;
-                s1 += S[0] * w[4] + S[1] * w[5] + S[2] * w[6] + S[3] * w[7]; S += ld;
-                s1 += S[0] * w[8] + S[1] * w[9] + S[2] * w[10] + S[3] * w[11]; S += ld;
-                s1 += S[0] * w[12] + S[1] * w[13] + S[2] * w[14] + S[3] * w[15];
-            }
-            {
-                const float *S = P2 + base;
-                s2 = S[0] * w[0] + S[1] * w[1] + S[2] * w[2] + S[3] * w[3]; S += ld;
-                s2 += S[0] * w[4] + S[1] * w[5] + S[2] * w[6] + S[3] * w[7]; S += ld;
-                s2 += S[0] * w[8] + S[1] * w[9] + S[2] * w[10] + S[3] * w[11]; S += ld;
-                s2 += S[0] * w[12] + S[1] * w[13] + S[2] * w[14] + S[3] * w[15];
+                const float4 *S = P + base;
+                float4 a = S[0], b4 = S[1], c = S[2], d = S[3];
+                s0 = a.x * w[0] + b4.x * w[1] + c.x * w[2] + d.x * w[3];
+                s1 = a.y * w[0] + b4.y * w[1] + c.y * w[2] + d.y * w[3];
+                s2 = a.z * w[0] + b4.z * w[1] + c.z * w[2] + d.z * w[3];
+                S += ld; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
+                s0 += a.x * w[4] + b4.x * w[5] + c.x * w[6] + d.x * w[7];
+                s1 += a.y * w[4] + b4.y * w[5] + c.y * w[6] + d.y * w[7];
+                s2 += a.z * w[4] + b4.z * w[5] + c.z * w[6] + d.z * w[7];
+                S += ld; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
+                s0 += a.x * w[8] + b4.x * w[9] + c.x * w[10] + d.x * w[11];
+                s1 += a.y * w[8] + b4.y * w[9] + c.y * w[10] + d.y * w[11];
+                s2 += a.z * w[8] + b4.z * w[9] + c.z * w[10] + d.z * w[11];
+                S += ld; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
+                s0 += a.x * w[12] + b4.x * w[13] + c.x * w[14] + d.x * w[15];
+                s1 += a.y * w[12] + b4.y * w[13] + c.y * w[14] + d.y * w[15];
+                s2 += a.z * w[12] + b4.z * w[13] + c.z * w[14] + d.z * w[15];
             }
             v0 = s0; v1 = s1; v2 = s2;
         } else if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
@@ -256,10 +282,10 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host
                 for (int j = 0; j < 4; ++j) {
                     const int xj = sx + j;
                     if (xj < 0 || xj >= W) continue;
-                    const long long a = (long long)yi * ld + xj;
-                    s0 += (P0[a] - 0.f) * w[i * 4 + j];
-                    s1 += (P1[a] - 0.f) * w[i * 4 + j];
-                    s2 += (P2[a] - 0.f) * w[i * 4 + j];
+                    const float4 t = P[(long long)yi * ld + xj];
+                    s0 += (t.x - 0.f) * w[i * 4 + j];
+                    s1 += (t.y - 0.f) * w[i * 4 + j];
+                    s2 += (t.z - 0.f) * w[i * 4 + j];
                 }
             }
             v0 = s0; v1 = s1; v2 = s2;
@@ -273,10 +299,10 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host
         for (int cy = ymin; cy <= ymax; ++cy)
             for (int cx = xmin; cx <= xmax; ++cx) {
                 const float wgt = bicubic_coeff_cuda(wxp - (float)cx) * bicubic_coeff_cuda(wyp - (float)cy);
-                const long long a = (long long)min(max(cy, 0), H - 1) * ld + min(max(cx, 0), W - 1);
-                sum += wgt * P0[a];
-                sumx += wgt * P1[a];
-                sumy += wgt * P2[a];
+                const float4 t = P[(long long)min(max(cy, 0), H - 1) * ld + min(max(cx, 0), W - 1)];
+                sum += wgt * t.x;
+                sumx += wgt * t.y;
+                sumy += wgt * t.z;
                 wsum += wgt;
             }
         const float coeff = 1.0f / wsum;
@@ -610,12 +636,26 @@ int gradient(const float *src, float *dx, float *dy, const Geo &g, hipStream_t s
     return MI_OK;
 }
 
-int warp(int semantics, const float *I0, const float *I1, const float *I1x, const float *I1y,
-         const float *u1[2], const float *u2[2], float *I1w, float *I1wx, float *I1wy, float *grad, float *rho,
-         const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host, hipStream_t s)
+int gradient_pack(const float *src, float *pk, const Geo &g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gradient_pack, grid2d(g, g.batch), dim3(256), 0, s, src, reinterpret_cast<float4 *>(pk), g);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int pack3(const float *a, const float *b, const float *c, float *pk, const Geo &g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack3, grid2d(g, g.batch), dim3(256), 0, s, a, b, c, reinterpret_cast<float4 *>(pk), g);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int warp(int semantics, const float *I0, const float *pk, const float *u1[2], const float *u2[2], float *I1w,
+         float *I1wx, float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl,
+         int cur_host, hipStream_t s)
 {
     WarpArgs A;
-    A.I0 = I0; A.I1 = I1; A.I1x = I1x; A.I1y = I1y;
+    A.I0 = I0; A.pk = reinterpret_cast<const float4 *>(pk);
     A.u1[0] = u1[0]; A.u1[1] = u1[1]; A.u2[0] = u2[0]; A.u2[1] = u2[1];
     A.I1w = I1w; A.I1wx = I1wx; A.I1wy = I1wy; A.grad = grad; A.rho = rho;
     A.tab = cubic_tab_dev;

@@ -97,7 +97,11 @@ int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *I1, con
     S.bufs.push_back(tabd);
     MI_HIP_TRY(hipMemcpyAsync(tabd, tabh, sizeof(tabh), hipMemcpyHostToDevice, st));
     const float *u1v[2] = {in[4], in[4]}, *u2v[2] = {in[5], in[5]};
-    TRY(warp(semantics, in[0], in[1], in[2], in[3], u1v, u2v, out[0], out[1], out[2], out[3], out[4], tabd, g, nullptr, 0, st));
+    float *pk = nullptr;   // {I1, I1x, I1y, 0} per pixel, the layout the warp kernel gathers from
+    MI_HIP_TRY(hipMalloc((void **)&pk, sizeof(float) * 4 * (size_t)g.ps));
+    S.bufs.push_back(pk);
+    TRY(pack3(in[1], in[2], in[3], pk, g, st));
+    TRY(warp(semantics, in[0], pk, u1v, u2v, out[0], out[1], out[2], out[3], out[4], tabd, g, nullptr, 0, st));
     for (int i = 0; i < 5; ++i) TRY(stage_out(out[i], g, outs[i], st));
     MI_HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
