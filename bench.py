@@ -121,9 +121,66 @@ def bench_stereobm(args):
     print(json.dumps(out))
 
 
+def bench_farneback(args):
+    """BASELINE configs[0]: calcOpticalFlowFarneback on one 640x480 synthetic pair, class defaults (the
+    reference's own CPU-runnable case) -- GPU path (mi_farneback_calc) next to the CPU restatement."""
+    import numpy as np
+    import torch
+    from opencv_contrib_amd import cuda, synth
+    dev = torch.device("cuda", 0)
+    W, H = args.width, args.height
+    I0, I1, gt = synth.flow_pair(H, W, seed=1234, dtype="u8")
+    t0_, t1_ = torch.from_numpy(I0).to(dev), torch.from_numpy(I1).to(dev)
+    flow = torch.empty((H, W, 2), dtype=torch.float32, device=dev)
+    alg = cuda.FarnebackOpticalFlow.create()
+    n = max(args.batch, 1)
+    for _ in range(args.warmup * n):
+        alg.calc(t0_, t1_, flow)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * n):
+        alg.calc(t0_, t1_, flow)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    f = flow.cpu().numpy()
+    # algorithmic bytes of the fused formulation: per level 2x polyexp 24 + updateMatrices 68 + iters*(M 20 + R0 20 + R1 20 + flow 8 + M' 20)
+    px = 0
+    w_, h_ = W, H
+    lv = []
+    scale = 1.0
+    for k in range(6):
+        if k and (W * scale < 32 or H * scale < 32):
+            break
+        lv.append(int(np.rint(W * scale)) * int(np.rint(H * scale)))
+        scale *= 0.5
+    lv = lv[:6]
+    algo = float(sum(p * (2 * 24 + 68 + 10 * 88) for p in lv))
+    out = {"metric": "frame-pairs/sec Farneback flow", "value": args.steps * n / el, "unit": "pairs/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"FarnebackOpticalFlow {W}x{H} CV_8UC1, numLevels 5, pyrScale .5, winSize 13, numIters 10, polyN 5 "
+                                  f"(BASELINE configs[0]), {n} sequential calc()/step"},
+           "epe_vs_analytic_flow_px": float(synth.epe(f[40:-40, 40:-40], gt[40:-40, 40:-40])),
+           "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo * args.steps * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "single small pair: launch-latency bound (about 70 launches of 5-50 us); bytes = fused-iteration accounting"}}
+    if not args.no_cpu:
+        from oracle import oracle as O
+        O.fb_calc(I0, I1)
+        t0 = time.perf_counter()
+        k = 0
+        while k < 3 or time.perf_counter() - t0 < 5.0:
+            O.fb_calc(I0, I1)
+            k += 1
+        ct = (time.perf_counter() - t0) / k
+        out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{k} x 1 pair {W}x{H}, {ct * 1e3:.0f} ms each, oracle/farneback_ref.c (OpenMP rows)"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["tvl1", "stereobm"], default="tvl1")
+    ap.add_argument("--workload", choices=["tvl1", "stereobm", "farneback"], default="tvl1")
     ap.add_argument("--ndisp", type=int, default=128)
     ap.add_argument("--block-size", type=int, default=15)
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +204,10 @@ def main():
         args.iterations, args.epsilon = 300, 0.01
     if args.workload == "stereobm":
         return bench_stereobm(args)
+    if args.workload == "farneback":
+        if (args.width, args.height) == (1920, 1080):
+            args.width, args.height = 640, 480
+        return bench_farneback(args)
 
     import numpy as np
     import torch

@@ -193,6 +193,55 @@ MI_API int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, f
  * out_host[64] = lane picked by the reference's tie-break rule among the minima. */
 MI_API int mi_dbg_wave_min(const unsigned *in_host, unsigned *out_host /*[65]*/);
 
+/* ====================================================================== Farneback ===== */
+
+/* cv::OPTFLOW_* flags (main repo video/tracking.hpp), as passed to FarnebackOpticalFlow::create */
+enum { MI_OPTFLOW_USE_INITIAL_FLOW = 4, MI_OPTFLOW_FARNEBACK_GAUSSIAN = 256 };
+
+/* Parameters of cv::cuda::FarnebackOpticalFlow::create (cudaoptflow.hpp:285-293) */
+typedef struct mi_farneback_params {
+    int num_levels;
+    double pyr_scale;
+    int fast_pyramids;
+    int win_size, num_iters, poly_n;
+    double poly_sigma;
+    int flags;
+} mi_farneback_params;
+
+typedef struct mi_farneback mi_farneback;
+
+MI_API void mi_farneback_default_params(mi_farneback_params *p);
+/* Replaces: cv::cuda::FarnebackOpticalFlow::create, cudaoptflow/src/farneback.cpp:485-489 */
+MI_API int mi_farneback_create(const mi_farneback_params *p, mi_farneback **out);
+MI_API int mi_farneback_set_params(mi_farneback *h, const mi_farneback_params *p);
+MI_API int mi_farneback_get_params(const mi_farneback *h, mi_farneback_params *p);
+/* Replaces: FarnebackOpticalFlowImpl::calc + calcImpl, cudaoptflow/src/farneback.cpp:167-199,314-482.
+ * I0,I1: MI_8UC1 or MI_32FC1 (convertTo(CV_32F), no scaling), same size/type; flow: MI_32FC2 of the frame size,
+ * read as the initial flow when MI_OPTFLOW_USE_INITIAL_FLOW.  One stream, no host synchronisation. */
+MI_API int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream);
+MI_API void mi_farneback_destroy(mi_farneback *h);
+
+/* Stage-level entry points == cv::cuda::device::optflow_farneback:: functions (cudaoptflow/src/farneback.cpp:60-92);
+ * 5-plane buffers are MI_32FC1 matrices of 5*rows x cols (planes stacked vertically) like the reference's.
+ * Replaces: setPolynomialExpansionConsts + polynomialExpansionGpu  farneback.cpp:262-276, cuda/farneback.cu:122-151 */
+MI_API int mi_farneback_poly_exp(const mi_mat *src, mi_mat *dst5, int poly_n, double poly_sigma, void *stream);
+/* Replaces: setUpdateMatricesConsts + updateMatricesGpu  cuda/farneback.cu:244-264 */
+MI_API int mi_farneback_update_matrices(const mi_mat *flowx, const mi_mat *flowy, const mi_mat *R0, const mi_mat *R1,
+                                        mi_mat *M5, void *stream);
+/* Replaces: boxFilter5Gpu / gaussianBlur5Gpu(BORDER_REPLICATE)  cuda/farneback.cu:415-450,598-651
+ * (gaussian != 0: kernel getGaussianKernel(ksize, ksize/2*0.3f), farneback.cpp:460-464) */
+MI_API int mi_farneback_blur5(const mi_mat *M5, mi_mat *dst5, int ksize, int gaussian, void *stream);
+/* Replaces: updateFlowGpu  cuda/farneback.cu:289-300 */
+MI_API int mi_farneback_update_flow(const mi_mat *M5, mi_mat *flowx, mi_mat *flowy, void *stream);
+/* One fused inner iteration (blur5 + updateFlow + optional updateMatrices): updateFlow_boxFilter /
+ * updateFlow_gaussianBlur, farneback.cpp:278-312.  M5out must not alias M5. */
+MI_API int mi_farneback_iterate(const mi_mat *M5, const mi_mat *R0, const mi_mat *R1, mi_mat *flowx, mi_mat *flowy,
+                                mi_mat *M5out, int ksize, int gaussian, int update_matrices, void *stream);
+/* Replaces: setGaussianBlurKernel + gaussianBlurGpu  cuda/farneback.cu:495-536; border: 1 REPLICATE, 4 REFLECT101 */
+MI_API int mi_farneback_gaussian_blur(const mi_mat *src, mi_mat *dst, int ksize, double sigma, int border, void *stream);
+/* Replaces: cv::cuda::pyrDown on CV_32FC1  cudawarping/src/pyramids.cpp:66-94 */
+MI_API int mi_pyr_down(const mi_mat *src, mi_mat *dst, void *stream);
+
 /* Hardware self-test hook: out_host[0..63] = value received from lane n-1, out_host[64..127] = from
  * lane n+1 when every lane n contributes n+100 (DPP wave shifts used by the blocked kernels). */
 MI_API int mi_dbg_lane_shift(int *out_host /*[128]*/);

@@ -76,5 +76,60 @@ inline Ptr<OpticalFlowDual_TVL1> OpticalFlowDual_TVL1::create(double tau, double
     return makePtr<miflow_detail::TVL1Impl>(p);
 }
 
+/** cudaoptflow.hpp:258-294; implementation twin of FarnebackOpticalFlowImpl, cudaoptflow/src/farneback.cpp:96-165 */
+class FarnebackOpticalFlow : public DenseOpticalFlow {
+public:
+    virtual int getNumLevels() const = 0;        virtual void setNumLevels(int numLevels) = 0;
+    virtual double getPyrScale() const = 0;      virtual void setPyrScale(double pyrScale) = 0;
+    virtual bool getFastPyramids() const = 0;    virtual void setFastPyramids(bool fastPyramids) = 0;
+    virtual int getWinSize() const = 0;          virtual void setWinSize(int winSize) = 0;
+    virtual int getNumIters() const = 0;         virtual void setNumIters(int numIters) = 0;
+    virtual int getPolyN() const = 0;            virtual void setPolyN(int polyN) = 0;
+    virtual double getPolySigma() const = 0;     virtual void setPolySigma(double polySigma) = 0;
+    virtual int getFlags() const = 0;            virtual void setFlags(int flags) = 0;
+
+    static Ptr<FarnebackOpticalFlow> create(int numLevels = 5, double pyrScale = 0.5, bool fastPyramids = false, int winSize = 13,
+                                            int numIters = 10, int polyN = 5, double polySigma = 1.1, int flags = 0);
+};
+
+namespace miflow_detail {
+class FarnebackImpl final : public FarnebackOpticalFlow {
+public:
+    explicit FarnebackImpl(const mi_farneback_params &p) : p_(p) { miCheck(mi_farneback_create(&p_, &h_)); }
+    ~FarnebackImpl() override { mi_farneback_destroy(h_); }
+    FarnebackImpl(const FarnebackImpl &) = delete;
+    FarnebackImpl &operator=(const FarnebackImpl &) = delete;
+    void calc(InputArray I0, InputArray I1, InputOutputArray flow, Stream &stream) override
+    {
+        if (!(p_.flags & MI_OPTFLOW_USE_INITIAL_FLOW)) flow.create(I0.size(), CV_32FC2);   // farneback.cpp:189-198 (create + merge)
+        mi_mat a = miMat(I0), b = miMat(I1), f = miMat(flow);
+        miCheck(mi_farneback_calc(h_, &a, &b, &f, stream.hipStream()));
+    }
+    String getDefaultName() const override { return "DenseOpticalFlow.FarnebackOpticalFlow"; }   // farneback.cpp:132
+#define MIFLOW_PROP(T, Name, field) \
+    T get##Name() const override { return (T)p_.field; } \
+    void set##Name(T v) override { p_.field = v; miCheck(mi_farneback_set_params(h_, &p_)); }
+    MIFLOW_PROP(int, NumLevels, num_levels) MIFLOW_PROP(double, PyrScale, pyr_scale) MIFLOW_PROP(int, WinSize, win_size)
+    MIFLOW_PROP(int, NumIters, num_iters) MIFLOW_PROP(int, PolyN, poly_n) MIFLOW_PROP(double, PolySigma, poly_sigma)
+    MIFLOW_PROP(int, Flags, flags)
+#undef MIFLOW_PROP
+    bool getFastPyramids() const override { return p_.fast_pyramids != 0; }
+    void setFastPyramids(bool v) override { p_.fast_pyramids = v; miCheck(mi_farneback_set_params(h_, &p_)); }
+private:
+    mi_farneback_params p_;
+    mi_farneback *h_ = nullptr;
+};
+}  // namespace miflow_detail
+
+inline Ptr<FarnebackOpticalFlow> FarnebackOpticalFlow::create(int numLevels, double pyrScale, bool fastPyramids, int winSize,
+                                                              int numIters, int polyN, double polySigma, int flags)
+{
+    mi_farneback_params p;
+    mi_farneback_default_params(&p);
+    p.num_levels = numLevels; p.pyr_scale = pyrScale; p.fast_pyramids = fastPyramids; p.win_size = winSize;
+    p.num_iters = numIters; p.poly_n = polyN; p.poly_sigma = polySigma; p.flags = flags;
+    return makePtr<miflow_detail::FarnebackImpl>(p);
+}
+
 }}  // namespace cv::cuda
 #endif

@@ -38,6 +38,11 @@ class TVL1Params(C.Structure):
                 ("time_block", C.c_int)]
 
 
+class FarnebackParams(C.Structure):
+    _fields_ = [("num_levels", C.c_int), ("pyr_scale", C.c_double), ("fast_pyramids", C.c_int), ("win_size", C.c_int),
+                ("num_iters", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
+
+
 class StereoBMParams(C.Structure):
     _fields_ = [("num_disparities", C.c_int), ("block_size", C.c_int), ("prefilter_type", C.c_int),
                 ("prefilter_cap", C.c_int), ("prefilter_size", C.c_int), ("texture_threshold", C.c_float),
@@ -104,6 +109,19 @@ def lib():
         "mi_stereobm_block_match": (i, [PM, PM, PM, PM, i, i, i, i, vp]),
         "mi_stereobm_textureness": (i, [PM, PM, i, f, vp]),
         "mi_dbg_wave_min": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "mi_farneback_default_params": (None, [C.POINTER(FarnebackParams)]),
+        "mi_farneback_create": (i, [C.POINTER(FarnebackParams), C.POINTER(vp)]),
+        "mi_farneback_set_params": (i, [vp, C.POINTER(FarnebackParams)]),
+        "mi_farneback_get_params": (i, [vp, C.POINTER(FarnebackParams)]),
+        "mi_farneback_calc": (i, [vp, PM, PM, PM, vp]),
+        "mi_farneback_destroy": (None, [vp]),
+        "mi_farneback_poly_exp": (i, [PM, PM, i, d, vp]),
+        "mi_farneback_update_matrices": (i, [PM, PM, PM, PM, PM, vp]),
+        "mi_farneback_blur5": (i, [PM, PM, i, i, vp]),
+        "mi_farneback_update_flow": (i, [PM, PM, PM, vp]),
+        "mi_farneback_iterate": (i, [PM, PM, PM, PM, PM, PM, i, i, i, vp]),
+        "mi_farneback_gaussian_blur": (i, [PM, PM, i, d, i, vp]),
+        "mi_pyr_down": (i, [PM, PM, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

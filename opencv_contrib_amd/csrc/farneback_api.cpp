@@ -1,0 +1,498 @@
+// cv::cuda::FarnebackOpticalFlow: handle, level loop and C-ABI entry points.  Host-side twin of
+// FarnebackOpticalFlowImpl (modules/cudaoptflow/src/farneback.cpp:96-492), ordered on ONE stream (the
+// reference fans out over 5 streams and blocks the host once per level, :319-324,366,456).
+#include "farneback_dev.h"
+#include "tvl1_dev.h"   // tvl1::resize == cuda::resize(INTER_LINEAR) on dense f32 planes
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+using namespace mi;
+using namespace mi::fb;
+
+namespace mi { namespace fb {
+
+// cv::getGaussianKernel(n, sigma, CV_32F) (main repo imgproc): fixed tables for n <= 7 with sigma <= 0,
+// else exp(-x^2/(2 sigma^2)) normalised to sum 1
+void gaussian_kernel(int n, double sigma, float *k)
+{
+    static const float t1[] = {1.f}, t3[] = {0.25f, 0.5f, 0.25f}, t5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                       t7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    if (sigma <= 0 && n <= 7 && (n & 1)) {
+        const float *t = n == 1 ? t1 : n == 3 ? t3 : n == 5 ? t5 : t7;
+        for (int i = 0; i < n; ++i) k[i] = t[i];
+        return;
+    }
+    const double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2 = -0.5 / (sx * sx);
+    std::vector<double> w(n);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = std::exp(scale2 * x * x); sum += w[i]; }
+    for (int i = 0; i < n; ++i) k[i] = (float)(w[i] / sum);
+}
+
+// prepareGaussian, farneback.cpp:209-260: Gaussian-weighted moments and the 4 used entries of inv(G)
+int prepare_gaussian(int n, double sigma, PolyC *C)
+{
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;   // :270-271
+    float gb[17], *g = gb + 8;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) { g[x] = (float)std::exp(-x * x / (2 * sigma * sigma)); s += g[x]; }
+    s = 1. / s;
+    memset(C, 0, sizeof(*C));
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        if (x >= 0) { C->g[x] = g[x]; C->xg[x] = (float)(x * g[x]); C->xxg[x] = (float)(x * x * g[x]); }
+    }
+    double G[6][6] = {{0}};
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0][0] += g[y] * g[x];
+            G[1][1] += g[y] * g[x] * x * x;
+            G[3][3] += g[y] * g[x] * x * x * x * x;
+            G[5][5] += g[y] * g[x] * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    // inv(G) by Cholesky (Mat::inv(DECOMP_CHOLESKY), :254)
+    double L[6][6] = {{0}}, inv[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double a = G[i][j];
+            for (int k = 0; k < j; ++k) a -= L[i][k] * L[j][k];
+            if (i == j) { if (a <= 0) { set_error("moment matrix is not positive definite"); return MI_ERR_BAD_ARG; } L[i][i] = std::sqrt(a); }
+            else L[i][j] = a / L[j][j];
+        }
+    for (int c = 0; c < 6; ++c) {
+        double yv[6], xv[6];
+        for (int i = 0; i < 6; ++i) { double a = i == c ? 1.0 : 0.0; for (int k = 0; k < i; ++k) a -= L[i][k] * yv[k]; yv[i] = a / L[i][i]; }
+        for (int i = 5; i >= 0; --i) { double a = yv[i]; for (int k = i + 1; k < 6; ++k) a -= L[k][i] * xv[k]; xv[i] = a / L[i][i]; }
+        for (int i = 0; i < 6; ++i) inv[i][c] = xv[i];
+    }
+    C->ig11 = (float)inv[1][1]; C->ig03 = (float)inv[0][3]; C->ig33 = (float)inv[3][3]; C->ig55 = (float)inv[5][5];
+    return MI_OK;
+}
+
+}}  // namespace mi::fb
+
+struct mi_farneback {
+    mi_farneback_params P;
+    float *arena = nullptr;
+    int capW = 0, capH = 0;
+    // full-size-capacity planes
+    float *frames[2] = {}, *blurred = nullptr, *lvl[2] = {}, *R[2] = {}, *M = nullptr, *bufM = nullptr;
+    float *flow[3][2] = {};   // [slot][x,y]: slot 0 = level 0 (and the initial flow), slots 1,2 alternate over the coarse levels
+    std::vector<float *> pyr[2];
+    std::vector<Plane> pyrg;
+    size_t pyr_floats = 0;
+    float *pyr_arena = nullptr;
+};
+
+static int cv_round(double v) { return (int)std::lrint(v); }
+
+extern "C" {
+
+void mi_farneback_default_params(mi_farneback_params *p)
+{
+    if (!p) return;
+    // cv::cuda::FarnebackOpticalFlow::create defaults, cudaoptflow.hpp:285-293
+    p->num_levels = 5; p->pyr_scale = 0.5; p->fast_pyramids = 0; p->win_size = 13; p->num_iters = 10;
+    p->poly_n = 5; p->poly_sigma = 1.1; p->flags = 0;
+}
+
+static int validate(const mi_farneback_params *p)
+{
+    MI_REQUIRE(p, MI_ERR_BAD_ARG, "null params");
+    MI_REQUIRE(p->poly_n == 5 || p->poly_n == 7, MI_ERR_BAD_ARG, "polyN must be 5 or 7");                                   // farneback.cpp:316
+    MI_REQUIRE(!p->fast_pyramids || std::abs(p->pyr_scale - 0.5) < 1e-6, MI_ERR_BAD_ARG, "fastPyramids requires pyrScale == 0.5");  // :317
+    MI_REQUIRE(p->num_levels >= 0 && p->num_levels <= 32, MI_ERR_BAD_ARG, "numLevels out of range");
+    MI_REQUIRE(p->pyr_scale > 0 && p->pyr_scale < 1, MI_ERR_BAD_ARG, "pyrScale must be in (0,1)");
+    MI_REQUIRE(p->win_size >= 1 && (p->win_size & 1) && p->win_size / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "winSize must be odd and <= 201");
+    MI_REQUIRE(p->num_iters >= 0, MI_ERR_BAD_ARG, "numIters must be >= 0");
+    return MI_OK;
+}
+
+int mi_farneback_create(const mi_farneback_params *p, mi_farneback **out)
+{
+    MI_REQUIRE(out, MI_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    mi_farneback_params d;
+    if (!p) { mi_farneback_default_params(&d); p = &d; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        set_error("no HIP device available: the miflow product path has no CPU fallback");
+        return MI_ERR_NO_DEVICE;
+    }
+    mi_farneback *h = new mi_farneback();
+    h->P = *p;   // validated at calc(), like the reference (CV_Assert inside calcImpl)
+    *out = h;
+    return MI_OK;
+}
+
+int mi_farneback_set_params(mi_farneback *h, const mi_farneback_params *p)
+{
+    MI_REQUIRE(h && p, MI_ERR_BAD_ARG, "null argument");
+    h->P = *p;
+    return MI_OK;
+}
+
+int mi_farneback_get_params(const mi_farneback *h, mi_farneback_params *p)
+{
+    MI_REQUIRE(h && p, MI_ERR_BAD_ARG, "null argument");
+    *p = h->P;
+    return MI_OK;
+}
+
+void mi_farneback_destroy(mi_farneback *h)
+{
+    if (!h) return;
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->pyr_arena) (void)hipFree(h->pyr_arena);
+    delete h;
+}
+
+static int ensure(mi_farneback *h, int W, int H)
+{
+    if (h->arena && h->capW == W && h->capH == H) return MI_OK;
+    if (h->arena) (void)hipFree(h->arena);
+    h->arena = nullptr;
+    const Plane g = plane_of(W, H);
+    const size_t n = (size_t)g.ld * H;
+    // frames 2, blurred 1, lvl 2, R 2x5, M 5, bufM 5, flows 6  = 31 planes
+    MI_HIP_TRY(hipMalloc((void **)&h->arena, sizeof(float) * n * 31));
+    float *p = h->arena;
+    auto take = [&](size_t k) { float *q = p; p += n * k; return q; };
+    h->frames[0] = take(1); h->frames[1] = take(1); h->blurred = take(1); h->lvl[0] = take(1); h->lvl[1] = take(1);
+    h->R[0] = take(5); h->R[1] = take(5); h->M = take(5); h->bufM = take(5);
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) h->flow[a][b] = take(1);
+    h->capW = W; h->capH = H;
+    return MI_OK;
+}
+
+static void geo_tvl1(const Plane &p, mi::tvl1::Geo &g) { g.w = p.w; g.h = p.h; g.ld = p.ld; g.ps = (long long)p.ld * p.h; g.batch = 1; }
+
+// cuda::resize(src -> dst, Size(dw,dh), INTER_LINEAR) followed by convertTo(*alpha) on up to 2 planes
+static int resize2(const float *s0, const float *s1, const Plane &gs, float *d0, float *d1, const Plane &gd, float alpha, hipStream_t st)
+{
+    if (gs.w == gd.w && gs.h == gd.h && alpha == 1.f) {   // dsize == src.size(): copy (cudawarping/src/resize.cpp:89-93)
+        MI_HIP_TRY(hipMemcpyAsync(d0, s0, sizeof(float) * (size_t)gs.ld * gs.h, hipMemcpyDeviceToDevice, st));
+        if (s1) MI_HIP_TRY(hipMemcpyAsync(d1, s1, sizeof(float) * (size_t)gs.ld * gs.h, hipMemcpyDeviceToDevice, st));
+        return MI_OK;
+    }
+    mi::tvl1::Geo a, b;
+    geo_tvl1(gs, a); geo_tvl1(gd, b);
+    const float *src[3][2] = {{s0, nullptr}, {s1, nullptr}, {nullptr, nullptr}};
+    float *dst[3] = {d0, d1, nullptr};
+    const float post[3] = {alpha, alpha, 1.f};
+    return mi::tvl1::resize(MI_SEM_CUDA_COMPAT, s1 ? 2 : 1, src, 1, dst, a, b, (double)gd.w / gs.w, (double)gd.h / gs.h, post, nullptr, 0, st);
+}
+
+int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    const mi_farneback_params &P = h->P;
+    int rc = validate(&P);
+    if (rc) return rc;
+    MI_REQUIRE(I0 && I1 && flow && I0->data && I1->data && flow->data, MI_ERR_BAD_ARG, "null matrix");
+    // CV_Assert(frame0.channels() == 1 && frame1.channels() == 1)  farneback.cpp:173; depths supported here: 8U, 32F
+    MI_REQUIRE((I0->type == MI_8UC1 || I0->type == MI_32FC1) && I1->type == I0->type, MI_ERR_BAD_TYPE, "frames must be CV_8UC1 or CV_32FC1, same type");
+    MI_REQUIRE(I0->rows == I1->rows && I0->cols == I1->cols, MI_ERR_BAD_SIZE, "frame0.size() != frame1.size()");   // :174
+    MI_REQUIRE(flow->type == MI_32FC2 && flow->rows == I0->rows && flow->cols == I0->cols, MI_ERR_BAD_SIZE, "flow must be CV_32FC2 of the frame size");  // :181-182
+    MI_REQUIRE(flow->step % 8 == 0 && ((uintptr_t)flow->data % 8) == 0, MI_ERR_BAD_ARG, "flow must be 8-byte aligned");
+    if (I0->type == MI_32FC1) MI_REQUIRE(I0->step % 4 == 0 && I1->step % 4 == 0, MI_ERR_BAD_ARG, "float frames must be 4-byte aligned");
+    const int W = I0->cols, H = I0->rows;
+    MI_REQUIRE(W >= 2 && H >= 2, MI_ERR_BAD_SIZE, "frames too small");
+    if ((rc = ensure(h, W, H))) return rc;
+    const Plane g0 = plane_of(W, H);
+    const bool use_init = (P.flags & MI_OPTFLOW_USE_INITIAL_FLOW) != 0;
+    const bool gauss = (P.flags & MI_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
+
+    if ((rc = convert(I0->data, (long long)I0->step, I1->data, (long long)I1->step, I0->type, h->frames[0], h->frames[1], g0, st))) return rc;
+    // flowx0/flowy0 (level-0 flow planes; also the caller's initial flow)
+    float *fx0 = h->flow[0][0], *fy0 = h->flow[0][1];
+    if (use_init && (rc = split_flow(flow->data, (long long)flow->step, fx0, fy0, g0, st))) return rc;
+
+    // crop unnecessary levels, farneback.cpp:330-340
+    double scale = 1;
+    int levels = 0;
+    for (; levels < P.num_levels; levels++) {
+        scale *= P.pyr_scale;
+        if (W * scale < 32 || H * scale < 32) break;   // MIN_SIZE :54
+    }
+    if (P.fast_pyramids) {   // :346-359
+        std::vector<Plane> pg(levels + 1);
+        pg[0] = g0;
+        size_t total = 0;
+        for (int i = 1; i <= levels; ++i) { pg[i] = plane_of((pg[i - 1].w + 1) / 2, (pg[i - 1].h + 1) / 2); total += (size_t)pg[i].ld * pg[i].h; }
+        if (h->pyr_floats < 2 * total) {
+            if (h->pyr_arena) (void)hipFree(h->pyr_arena);
+            h->pyr_arena = nullptr;
+            MI_HIP_TRY(hipMalloc((void **)&h->pyr_arena, sizeof(float) * (2 * total + 64)));
+            h->pyr_floats = 2 * total;
+        }
+        h->pyrg = pg;
+        for (int f = 0; f < 2; ++f) {
+            h->pyr[f].assign(levels + 1, nullptr);
+            h->pyr[f][0] = h->frames[f];
+        }
+        float *p = h->pyr_arena;
+        for (int i = 1; i <= levels; ++i)
+            for (int f = 0; f < 2; ++f) {
+                h->pyr[f][i] = p; p += (size_t)pg[i].ld * pg[i].h;
+                if ((rc = pyr_down(h->pyr[f][i - 1], pg[i - 1], h->pyr[f][i], pg[i], st))) return rc;
+            }
+    }
+    PolyC C;
+    if ((rc = prepare_gaussian(P.poly_n, P.poly_sigma, &C))) return rc;   // setPolynomialExpansionConsts :361
+    Taps wk;
+    memset(&wk, 0, sizeof(wk));
+    if (gauss) {   // :460-464
+        std::vector<float> k(P.win_size);
+        gaussian_kernel(P.win_size, (double)(P.win_size / 2 * 0.3f), k.data());
+        for (int i = 0; i <= P.win_size / 2; ++i) wk.k[i] = k[P.win_size / 2 + i];
+    }
+
+    float *prevx = nullptr, *prevy = nullptr;
+    Plane gprev = g0;
+    for (int k = levels; k >= 0; k--) {
+        scale = 1;
+        for (int i = 0; i < k; i++) scale *= P.pyr_scale;
+        const double sigma = (1. / scale - 1) * 0.5;
+        int smoothSize = cv_round(sigma * 5) | 1;
+        smoothSize = smoothSize > 3 ? smoothSize : 3;
+        int width = cv_round(W * scale), height = cv_round(H * scale);
+        if (P.fast_pyramids) { width = h->pyrg[k].w; height = h->pyrg[k].h; }
+        MI_REQUIRE(smoothSize / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "pyramid smoothing kernel too large (MAX_KSIZE_HALF)");
+        const Plane g = plane_of(width, height);
+        float *curx, *cury;
+        if (k > 0) { curx = h->flow[1 + (k & 1)][0]; cury = h->flow[1 + (k & 1)][1]; }
+        else { curx = fx0; cury = fy0; }
+        if (!prevx) {
+            if (use_init) {   // :398-404
+                if (k > 0 && (rc = resize2(fx0, fy0, g0, curx, cury, g, (float)scale, st))) return rc;
+            } else {
+                MI_HIP_TRY(hipMemsetAsync(curx, 0, sizeof(float) * (size_t)g.ld * g.h, st));
+                MI_HIP_TRY(hipMemsetAsync(cury, 0, sizeof(float) * (size_t)g.ld * g.h, st));
+            }
+        } else {              // :412-417
+            if ((rc = resize2(prevx, prevy, gprev, curx, cury, g, (float)(1. / P.pyr_scale), st))) return rc;
+        }
+        if (P.fast_pyramids) {
+            if ((rc = poly_exp(h->pyr[0][k], h->R[0], g, P.poly_n, C, st))) return rc;
+            if ((rc = poly_exp(h->pyr[1][k], h->R[1], g, P.poly_n, C, st))) return rc;
+        } else {              // :434-454
+            std::vector<float> gk(smoothSize);
+            gaussian_kernel(smoothSize, sigma, gk.data());
+            Taps K;
+            memset(&K, 0, sizeof(K));
+            for (int i = 0; i <= smoothSize / 2; ++i) K.k[i] = gk[smoothSize / 2 + i];
+            for (int i = 0; i < 2; i++) {
+                if ((rc = gaussian_blur(h->frames[i], h->blurred, g0, smoothSize / 2, K, MI_BORDER_REFLECT101, st))) return rc;
+                const float *lv = h->blurred;
+                if (!(g.w == g0.w && g.h == g0.h)) {
+                    if ((rc = resize2(h->blurred, nullptr, g0, h->lvl[i], nullptr, g, 1.f, st))) return rc;
+                    lv = h->lvl[i];
+                }
+                if ((rc = poly_exp(lv, h->R[i], g, P.poly_n, C, st))) return rc;
+            }
+        }
+        float *M = h->M, *bufM = h->bufM;
+        if ((rc = update_matrices(curx, cury, h->R[0], h->R[1], M, g, st))) return rc;   // :458
+        for (int i = 0; i < P.num_iters; i++) {   // :465-471 -> :278-312, fused
+            if ((rc = iterate(M, h->R[0], h->R[1], curx, cury, bufM, g, P.win_size, gauss ? &wk : nullptr, i < P.num_iters - 1, st))) return rc;
+            std::swap(M, bufM);
+        }
+        prevx = curx; prevy = cury; gprev = g;
+    }
+    return merge_flow(fx0, fy0, flow->data, (long long)flow->step, g0, st);   // cuda::merge :197-198
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ stage-level entry points
+namespace {
+struct Stage {
+    std::vector<float *> bufs;
+    ~Stage() { for (float *p : bufs) (void)hipFree(p); }
+    float *alloc(size_t n)
+    {
+        float *p = nullptr;
+        if (hipMalloc((void **)&p, sizeof(float) * n) != hipSuccess) return nullptr;
+        bufs.push_back(p);
+        return p;
+    }
+};
+int check_f32(const mi_mat *m, const char *name)
+{
+    MI_REQUIRE(m && m->data, MI_ERR_BAD_ARG, "%s: null matrix", name);
+    MI_REQUIRE(m->type == MI_32FC1, MI_ERR_BAD_TYPE, "%s: must be CV_32FC1", name);
+    MI_REQUIRE(m->rows > 0 && m->cols > 0, MI_ERR_BAD_SIZE, "%s: empty", name);
+    MI_REQUIRE(m->step >= (size_t)m->cols * 4 && m->step % 4 == 0, MI_ERR_BAD_ARG, "%s: bad step", name);
+    return MI_OK;
+}
+// rows x cols matrix (rows may be 5*h) -> dense plane(s) with pitch ld
+int stage_in(Stage &S, const mi_mat *m, int ld, float **out, hipStream_t st)
+{
+    float *p = S.alloc((size_t)ld * m->rows);
+    MI_REQUIRE(p, MI_ERR_OOM, "stage allocation failed");
+    MI_HIP_TRY(hipMemcpy2DAsync(p, (size_t)ld * 4, m->data, m->step, (size_t)m->cols * 4, (size_t)m->rows, hipMemcpyDeviceToDevice, st));
+    *out = p;
+    return MI_OK;
+}
+int stage_out(const float *p, int ld, mi_mat *m, hipStream_t st)
+{
+    MI_HIP_TRY(hipMemcpy2DAsync(m->data, m->step, p, (size_t)ld * 4, (size_t)m->cols * 4, (size_t)m->rows, hipMemcpyDeviceToDevice, st));
+    return MI_OK;
+}
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+int make_win_taps(int ksize, Taps *K)
+{
+    MI_REQUIRE(ksize >= 1 && (ksize & 1) && ksize / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "ksize must be odd and <= 201");
+    std::vector<float> k(ksize);
+    gaussian_kernel(ksize, (double)(ksize / 2 * 0.3f), k.data());
+    memset(K, 0, sizeof(*K));
+    for (int i = 0; i <= ksize / 2; ++i) K->k[i] = k[ksize / 2 + i];
+    return MI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_farneback_poly_exp(const mi_mat *src, mi_mat *dst5, int poly_n, double poly_sigma, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    TRY(check_f32(src, "src")); TRY(check_f32(dst5, "dst"));
+    MI_REQUIRE(dst5->rows == 5 * src->rows && dst5->cols == src->cols, MI_ERR_BAD_SIZE, "dst must be 5*rows x cols");
+    MI_REQUIRE(poly_n == 5 || poly_n == 7, MI_ERR_BAD_ARG, "polyN must be 5 or 7");
+    const Plane g = plane_of(src->cols, src->rows);
+    Stage S;
+    float *in = nullptr, *out = S.alloc((size_t)g.ld * g.h * 5);
+    MI_REQUIRE(out, MI_ERR_OOM, "stage allocation failed");
+    TRY(stage_in(S, src, g.ld, &in, st));
+    PolyC C;
+    TRY(prepare_gaussian(poly_n, poly_sigma, &C));
+    TRY(poly_exp(in, out, g, poly_n, C, st));
+    TRY(stage_out(out, g.ld, dst5, st));
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_farneback_update_matrices(const mi_mat *flowx, const mi_mat *flowy, const mi_mat *R0, const mi_mat *R1, mi_mat *M5, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    TRY(check_f32(flowx, "flowx")); TRY(check_f32(flowy, "flowy")); TRY(check_f32(R0, "R0")); TRY(check_f32(R1, "R1")); TRY(check_f32(M5, "M"));
+    const int w = flowx->cols, hh = flowx->rows;
+    MI_REQUIRE(flowy->rows == hh && flowy->cols == w && R0->rows == 5 * hh && R1->rows == 5 * hh && M5->rows == 5 * hh &&
+               R0->cols == w && R1->cols == w && M5->cols == w, MI_ERR_BAD_SIZE, "size mismatch");
+    const Plane g = plane_of(w, hh);
+    Stage S;
+    float *fx, *fy, *r0, *r1, *m = S.alloc((size_t)g.ld * hh * 5);
+    MI_REQUIRE(m, MI_ERR_OOM, "stage allocation failed");
+    TRY(stage_in(S, flowx, g.ld, &fx, st)); TRY(stage_in(S, flowy, g.ld, &fy, st));
+    TRY(stage_in(S, R0, g.ld, &r0, st)); TRY(stage_in(S, R1, g.ld, &r1, st));
+    TRY(update_matrices(fx, fy, r0, r1, m, g, st));
+    TRY(stage_out(m, g.ld, M5, st));
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_farneback_blur5(const mi_mat *M5, mi_mat *dst5, int ksize, int gaussian, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    TRY(check_f32(M5, "M")); TRY(check_f32(dst5, "dst"));
+    MI_REQUIRE(M5->rows % 5 == 0 && dst5->rows == M5->rows && dst5->cols == M5->cols, MI_ERR_BAD_SIZE, "size mismatch");
+    const Plane g = plane_of(M5->cols, M5->rows / 5);
+    Taps K;
+    TRY(make_win_taps(ksize, &K));
+    Stage S;
+    float *m, *out = S.alloc((size_t)g.ld * g.h * 5);
+    MI_REQUIRE(out, MI_ERR_OOM, "stage allocation failed");
+    TRY(stage_in(S, M5, g.ld, &m, st));
+    TRY(blur5(m, out, g, ksize, gaussian ? &K : nullptr, st));
+    TRY(stage_out(out, g.ld, dst5, st));
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_farneback_update_flow(const mi_mat *M5, mi_mat *flowx, mi_mat *flowy, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    TRY(check_f32(M5, "M")); TRY(check_f32(flowx, "flowx")); TRY(check_f32(flowy, "flowy"));
+    MI_REQUIRE(M5->rows == 5 * flowx->rows && M5->cols == flowx->cols && flowy->rows == flowx->rows && flowy->cols == flowx->cols,
+               MI_ERR_BAD_SIZE, "size mismatch");
+    const Plane g = plane_of(flowx->cols, flowx->rows);
+    Stage S;
+    float *m, *fx = S.alloc((size_t)g.ld * g.h), *fy = S.alloc((size_t)g.ld * g.h);
+    MI_REQUIRE(fx && fy, MI_ERR_OOM, "stage allocation failed");
+    TRY(stage_in(S, M5, g.ld, &m, st));
+    TRY(update_flow(m, fx, fy, g, st));
+    TRY(stage_out(fx, g.ld, flowx, st)); TRY(stage_out(fy, g.ld, flowy, st));
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_farneback_iterate(const mi_mat *M5, const mi_mat *R0, const mi_mat *R1, mi_mat *flowx, mi_mat *flowy, mi_mat *M5out,
+                         int ksize, int gaussian, int update, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    TRY(check_f32(M5, "M")); TRY(check_f32(R0, "R0")); TRY(check_f32(R1, "R1")); TRY(check_f32(flowx, "flowx")); TRY(check_f32(flowy, "flowy"));
+    TRY(check_f32(M5out, "Mout"));
+    const int w = flowx->cols, hh = flowx->rows;
+    MI_REQUIRE(flowy->rows == hh && flowy->cols == w && M5->rows == 5 * hh && R0->rows == 5 * hh && R1->rows == 5 * hh && M5out->rows == 5 * hh &&
+               M5->cols == w && R0->cols == w && R1->cols == w && M5out->cols == w, MI_ERR_BAD_SIZE, "size mismatch");
+    MI_REQUIRE(M5->data != M5out->data, MI_ERR_BAD_ARG, "Mout must not alias M");
+    const Plane g = plane_of(w, hh);
+    Taps K;
+    TRY(make_win_taps(ksize, &K));
+    Stage S;
+    float *m, *r0, *r1, *fx = S.alloc((size_t)g.ld * hh), *fy = S.alloc((size_t)g.ld * hh), *mo = S.alloc((size_t)g.ld * hh * 5);
+    MI_REQUIRE(fx && fy && mo, MI_ERR_OOM, "stage allocation failed");
+    TRY(stage_in(S, M5, g.ld, &m, st)); TRY(stage_in(S, R0, g.ld, &r0, st)); TRY(stage_in(S, R1, g.ld, &r1, st));
+    MI_HIP_TRY(hipMemsetAsync(mo, 0, sizeof(float) * (size_t)g.ld * hh * 5, st));
+    TRY(iterate(m, r0, r1, fx, fy, mo, g, ksize, gaussian ? &K : nullptr, update != 0, st));
+    TRY(stage_out(fx, g.ld, flowx, st)); TRY(stage_out(fy, g.ld, flowy, st)); TRY(stage_out(mo, g.ld, M5out, st));
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_farneback_gaussian_blur(const mi_mat *src, mi_mat *dst, int ksize, double sigma, int border, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    TRY(check_f32(src, "src")); TRY(check_f32(dst, "dst"));
+    MI_REQUIRE(dst->rows == src->rows && dst->cols == src->cols, MI_ERR_BAD_SIZE, "size mismatch");
+    MI_REQUIRE(ksize >= 1 && (ksize & 1) && ksize / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "ksize must be odd and <= 201");
+    const Plane g = plane_of(src->cols, src->rows);
+    std::vector<float> k(ksize);
+    gaussian_kernel(ksize, sigma, k.data());
+    Taps K;
+    memset(&K, 0, sizeof(K));
+    for (int i = 0; i <= ksize / 2; ++i) K.k[i] = k[ksize / 2 + i];
+    Stage S;
+    float *in, *out = S.alloc((size_t)g.ld * g.h);
+    MI_REQUIRE(out, MI_ERR_OOM, "stage allocation failed");
+    TRY(stage_in(S, src, g.ld, &in, st));
+    TRY(gaussian_blur(in, out, g, ksize / 2, K, border, st));
+    TRY(stage_out(out, g.ld, dst, st));
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_pyr_down(const mi_mat *src, mi_mat *dst, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    TRY(check_f32(src, "src")); TRY(check_f32(dst, "dst"));
+    MI_REQUIRE(dst->rows == (src->rows + 1) / 2 && dst->cols == (src->cols + 1) / 2, MI_ERR_BAD_SIZE, "dst must be ((rows+1)/2, (cols+1)/2)");
+    const Plane gs = plane_of(src->cols, src->rows), gd = plane_of(dst->cols, dst->rows);
+    Stage S;
+    float *in, *out = S.alloc((size_t)gd.ld * gd.h);
+    MI_REQUIRE(out, MI_ERR_OOM, "stage allocation failed");
+    TRY(stage_in(S, src, gs.ld, &in, st));
+    TRY(pyr_down(in, gs, out, gd, st));
+    TRY(stage_out(out, gd.ld, dst, st));
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// Internal launch API of the Farneback HIP kernels (farneback_kernels.hip).  Not part of the C-ABI.
+#pragma once
+#include "mi_common.h"
+
+#define MI_FB_MAX_KSIZE_HALF 100   /* MAX_KSIZE_HALF, cudaoptflow/src/cuda/farneback.cu:56 */
+enum { MI_BORDER_REPLICATE = 1, MI_BORDER_REFLECT101 = 4 };   /* cv::BorderTypes */
+
+namespace mi {
+namespace fb {
+
+struct Plane { int w, h, ld; };                 // dense f32 plane(s), ld floats per row
+struct Taps { float k[MI_FB_MAX_KSIZE_HALF + 1]; };   // centre + positive half of a symmetric kernel (by value)
+struct PolyC { float g[8], xg[8], xxg[8]; float ig11, ig03, ig33, ig55; };
+
+inline Plane plane_of(int w, int h) { Plane p; p.w = w; p.h = h; p.ld = align_up(w, 64); return p; }
+
+int convert(const void *a, long long sa, const void *b, long long sb, int type, float *A, float *B, const Plane &g, hipStream_t s);
+int split_flow(const void *flow, long long sf, float *fx, float *fy, const Plane &g, hipStream_t s);
+int merge_flow(const float *fx, const float *fy, void *flow, long long sf, const Plane &g, hipStream_t s);
+int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Taps &K, int border, hipStream_t s);
+int poly_exp(const float *src, float *dst5, const Plane &g, int polyN, const PolyC &C, hipStream_t s);
+int update_matrices(const float *flowx, const float *flowy, const float *R0, const float *R1, float *M, const Plane &g, hipStream_t s);
+// fused blur5 (box when gauss == nullptr) + updateFlow + (update ? updateMatrices -> Mout)
+int iterate(const float *M, const float *R0, const float *R1, float *flowx, float *flowy, float *Mout, const Plane &g, int ksize,
+            const Taps *gauss, bool update, hipStream_t s);
+int blur5(const float *M, float *dst, const Plane &g, int ksize, const Taps *gauss, hipStream_t s);
+int update_flow(const float *M, float *flowx, float *flowy, const Plane &g, hipStream_t s);
+int pyr_down(const float *src, const Plane &gs, float *dst, const Plane &gd, hipStream_t s);
+
+// host math (farneback.cpp:209-276 and the main-repo cv::getGaussianKernel)
+void gaussian_kernel(int n, double sigma, float *k);
+int prepare_gaussian(int n, double sigma, PolyC *C);
+
+}  // namespace fb
+}  // namespace mi

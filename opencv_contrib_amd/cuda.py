@@ -282,3 +282,131 @@ def stereobm_textureness(img, disp, winsz=19, avg_threshold=3.0):
     capi.check(capi.lib().mi_stereobm_textureness(C.byref(_m(img)), C.byref(_m(out)), winsz, avg_threshold,
                                                   capi.current_stream_ptr()))
     return out
+
+
+# =============================================================================================
+OPTFLOW_USE_INITIAL_FLOW, OPTFLOW_FARNEBACK_GAUSSIAN = 4, 256   # cv::OPTFLOW_* (main repo video/tracking.hpp)
+
+
+class FarnebackOpticalFlow:
+    """cv::cuda::FarnebackOpticalFlow (cudaoptflow.hpp:258-294; impl cudaoptflow/src/farneback.cpp:96-165)."""
+
+    def __init__(self, params: capi.FarnebackParams):
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_farneback_create(C.byref(params), C.byref(self._h)))
+        self._p = params
+
+    @staticmethod
+    def create(numLevels=5, pyrScale=0.5, fastPyramids=False, winSize=13, numIters=10, polyN=5, polySigma=1.1,
+               flags=0) -> "FarnebackOpticalFlow":
+        p = capi.FarnebackParams()
+        capi.lib().mi_farneback_default_params(C.byref(p))
+        p.num_levels, p.pyr_scale, p.fast_pyramids, p.win_size = numLevels, pyrScale, int(bool(fastPyramids)), winSize
+        p.num_iters, p.poly_n, p.poly_sigma, p.flags = numIters, polyN, polySigma, flags
+        return FarnebackOpticalFlow(p)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                capi.lib().mi_farneback_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def getDefaultName(self) -> str:  # farneback.cpp:132
+        return "DenseOpticalFlow.FarnebackOpticalFlow"
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+        capi.check(capi.lib().mi_farneback_set_params(self._h, C.byref(self._p)))
+
+    # getters / setters, farneback.cpp:106-128
+    def getNumLevels(self): return self._p.num_levels
+    def setNumLevels(self, v): self._set(num_levels=v)
+    def getPyrScale(self): return self._p.pyr_scale
+    def setPyrScale(self, v): self._set(pyr_scale=v)
+    def getFastPyramids(self): return bool(self._p.fast_pyramids)
+    def setFastPyramids(self, v): self._set(fast_pyramids=int(bool(v)))
+    def getWinSize(self): return self._p.win_size
+    def setWinSize(self, v): self._set(win_size=v)
+    def getNumIters(self): return self._p.num_iters
+    def setNumIters(self, v): self._set(num_iters=v)
+    def getPolyN(self): return self._p.poly_n
+    def setPolyN(self, v): self._set(poly_n=v)
+    def getPolySigma(self): return self._p.poly_sigma
+    def setPolySigma(self, v): self._set(poly_sigma=v)
+    def getFlags(self): return self._p.flags
+    def setFlags(self, v): self._set(flags=v)
+
+    def calc(self, I0, I1, flow=None, stream=None):
+        """DenseOpticalFlow::calc(I0, I1, flow, stream) (cudaoptflow.hpp:80).  Returns flow (H,W,2) f32."""
+        import torch
+        if flow is None:
+            if self._p.flags & OPTFLOW_USE_INITIAL_FLOW:
+                raise MiError(-1, "OPTFLOW_USE_INITIAL_FLOW requires a flow argument")
+            flow = torch.empty((I0.shape[0], I0.shape[1], 2), dtype=torch.float32, device=I0.device)
+        m0, m1, mf = capi.mat_from_tensor(I0), capi.mat_from_tensor(I1), capi.mat_from_tensor(flow)
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        capi.check(capi.lib().mi_farneback_calc(self._h, C.byref(m0), C.byref(m1), C.byref(mf), sp))
+        return flow
+
+
+def farneback_polyExp(src, polyN=5, polySigma=1.1):
+    import torch
+    dst = torch.empty((5 * src.shape[0], src.shape[1]), dtype=torch.float32, device=src.device)
+    capi.check(capi.lib().mi_farneback_poly_exp(C.byref(_m(src)), C.byref(_m(dst)), polyN, polySigma, capi.current_stream_ptr()))
+    return dst
+
+
+def farneback_updateMatrices(flowx, flowy, R0, R1):
+    import torch
+    M = torch.empty_like(R0)
+    capi.check(capi.lib().mi_farneback_update_matrices(C.byref(_m(flowx)), C.byref(_m(flowy)), C.byref(_m(R0)), C.byref(_m(R1)),
+                                                       C.byref(_m(M)), capi.current_stream_ptr()))
+    return M
+
+
+def farneback_blur5(M, ksize, gaussian=False):
+    import torch
+    out = torch.empty_like(M)
+    capi.check(capi.lib().mi_farneback_blur5(C.byref(_m(M)), C.byref(_m(out)), ksize, int(bool(gaussian)), capi.current_stream_ptr()))
+    return out
+
+
+def farneback_updateFlow(M):
+    import torch
+    h = M.shape[0] // 5
+    fx = torch.empty((h, M.shape[1]), dtype=torch.float32, device=M.device)
+    fy = torch.empty_like(fx)
+    capi.check(capi.lib().mi_farneback_update_flow(C.byref(_m(M)), C.byref(_m(fx)), C.byref(_m(fy)), capi.current_stream_ptr()))
+    return fx, fy
+
+
+def farneback_iterate(M, R0, R1, ksize, gaussian=False, update=True):
+    """One fused inner iteration -> (flowx, flowy, M')."""
+    import torch
+    h = M.shape[0] // 5
+    fx = torch.empty((h, M.shape[1]), dtype=torch.float32, device=M.device)
+    fy = torch.empty_like(fx)
+    Mo = torch.empty_like(M)
+    capi.check(capi.lib().mi_farneback_iterate(C.byref(_m(M)), C.byref(_m(R0)), C.byref(_m(R1)), C.byref(_m(fx)), C.byref(_m(fy)),
+                                               C.byref(_m(Mo)), ksize, int(bool(gaussian)), int(bool(update)),
+                                               capi.current_stream_ptr()))
+    return fx, fy, Mo
+
+
+def farneback_gaussianBlur(src, ksize, sigma, border=4):
+    import torch
+    dst = torch.empty_like(src)
+    capi.check(capi.lib().mi_farneback_gaussian_blur(C.byref(_m(src)), C.byref(_m(dst)), ksize, float(sigma), border,
+                                                     capi.current_stream_ptr()))
+    return dst
+
+
+def pyrDown(src):
+    """cv::cuda::pyrDown on CV_32FC1 (cudawarping/src/pyramids.cpp:66-94)."""
+    import torch
+    dst = torch.empty(((src.shape[0] + 1) // 2, (src.shape[1] + 1) // 2), dtype=torch.float32, device=src.device)
+    capi.check(capi.lib().mi_pyr_down(C.byref(_m(src)), C.byref(_m(dst)), capi.current_stream_ptr()))
+    return dst

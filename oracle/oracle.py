@@ -45,6 +45,11 @@ class SBMParams(C.Structure):
                 ("uniqueness_ratio", C.c_int), ("emulate_edge", C.c_int)]
 
 
+class FBParams(C.Structure):
+    _fields_ = [("num_levels", C.c_int), ("pyr_scale", C.c_double), ("fast_pyramids", C.c_int), ("win_size", C.c_int),
+                ("num_iters", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
+
+
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
@@ -75,6 +80,7 @@ def lib():
         L.orc_tvl1_iteration.restype = C.c_float
         L.orc_tvl1_iteration.argtypes = [C.c_int] + [_f32p] * 4 + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 4
         _bind_stereobm(L)
+        _bind_farneback(L)
     return _lib
 
 
@@ -87,6 +93,22 @@ def _bind_stereobm(L):
     L.orc_sbm_textureness.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_float, _u8p]
     L.orc_sbm_compute.restype = C.c_int
     L.orc_sbm_compute.argtypes = [C.POINTER(SBMParams), _u8p, _u8p, C.c_int, C.c_int, _u8p]
+
+
+def _bind_farneback(L):
+    i, d = C.c_int, C.c_double
+    L.orc_fb_default_params.argtypes = [C.POINTER(FBParams)]
+    L.orc_fb_gaussian_kernel.argtypes = [i, d, _f32p]
+    L.orc_fb_prepare_gaussian.restype = i
+    L.orc_fb_prepare_gaussian.argtypes = [i, d, _f32p, _f32p, _f32p, _f32p]
+    L.orc_fb_gaussian_blur.argtypes = [_f32p, _f32p, i, i, i, C.c_void_p, i]
+    L.orc_fb_poly_exp.argtypes = [_f32p, i, i, i, _f32p, _f32p, _f32p, _f32p, _f32p]
+    L.orc_fb_update_matrices.argtypes = [_f32p] * 5 + [i, i]
+    L.orc_fb_update_flow.argtypes = [_f32p, _f32p, _f32p, i, i]
+    L.orc_fb_blur5.argtypes = [_f32p, _f32p, i, i, i, C.c_void_p]
+    L.orc_fb_pyr_down.argtypes = [_f32p, i, i, _f32p, i, i]
+    L.orc_fb_calc.restype = i
+    L.orc_fb_calc.argtypes = [C.POINTER(FBParams), C.c_void_p, C.c_void_p, i, i, i, _f32p]
 
 
 def _c(a, dt=np.float32):
@@ -298,3 +320,114 @@ def sbm_compute(left, right, params: SBMParams | None = None):
     if rc != 0:
         raise ValueError(f"orc_sbm_compute failed: {rc}")
     return disp
+
+
+# ---------------------------------------------------------------- Farneback (cv::cuda::FarnebackOpticalFlow semantics)
+OPTFLOW_USE_INITIAL_FLOW, OPTFLOW_FARNEBACK_GAUSSIAN = 4, 256
+BORDER_REPLICATE, BORDER_REFLECT101 = 1, 4
+
+
+def fb_params(**kw) -> FBParams:
+    """FarnebackOpticalFlow::create defaults (cudaoptflow.hpp:285-293), overridden by kw."""
+    p = FBParams()
+    lib().orc_fb_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown Farneback parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+def fb_gaussian_kernel(n, sigma):
+    k = np.empty(n, np.float32)
+    lib().orc_fb_gaussian_kernel(n, float(sigma), k)
+    return k
+
+
+def fb_prepare_gaussian(n, sigma):
+    g, xg, xxg, ig = (np.zeros(8, np.float32) for _ in range(3)), None, None, np.zeros(4, np.float32)
+    g, xg, xxg = np.zeros(8, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32)
+    rc = lib().orc_fb_prepare_gaussian(n, float(sigma), g, xg, xxg, ig)
+    if rc:
+        raise ValueError("prepareGaussian failed")
+    return g[: n + 1], xg[: n + 1], xxg[: n + 1], ig
+
+
+def fb_gaussian_blur(src, ksize, sigma, border=BORDER_REFLECT101):
+    src = _c(src)
+    k = fb_gaussian_kernel(ksize, sigma)
+    half = np.ascontiguousarray(k[ksize // 2:])
+    dst = np.empty_like(src)
+    lib().orc_fb_gaussian_blur(src, dst, src.shape[1], src.shape[0], ksize // 2, half.ctypes.data, border)
+    return dst
+
+
+def fb_poly_exp(src, poly_n=5, poly_sigma=1.1):
+    src = _c(src)
+    h, w = src.shape
+    g, xg, xxg, ig = fb_prepare_gaussian(poly_n, poly_sigma)
+    pad = lambda a: np.ascontiguousarray(np.concatenate([a, np.zeros(8 - len(a), np.float32)]))
+    dst = np.empty((5 * h, w), np.float32)
+    lib().orc_fb_poly_exp(src, w, h, poly_n, pad(g), pad(xg), pad(xxg), ig, dst)
+    return dst
+
+
+def fb_update_matrices(flowx, flowy, R0, R1):
+    flowx, flowy, R0, R1 = map(_c, (flowx, flowy, R0, R1))
+    h, w = flowx.shape
+    M = np.empty((5 * h, w), np.float32)
+    lib().orc_fb_update_matrices(flowx, flowy, R0, R1, M, w, h)
+    return M
+
+
+def fb_update_flow(M):
+    M = _c(M)
+    h, w = M.shape[0] // 5, M.shape[1]
+    fx, fy = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    lib().orc_fb_update_flow(M, fx, fy, w, h)
+    return fx, fy
+
+
+def fb_blur5(M, ksize, gaussian_sigma=None):
+    M = _c(M)
+    h, w = M.shape[0] // 5, M.shape[1]
+    out = np.empty_like(M)
+    if gaussian_sigma is None:
+        lib().orc_fb_blur5(M, out, w, h, ksize // 2, None)
+    else:
+        k = np.ascontiguousarray(fb_gaussian_kernel(ksize, gaussian_sigma)[ksize // 2:])
+        lib().orc_fb_blur5(M, out, w, h, ksize // 2, k.ctypes.data)
+    return out
+
+
+def fb_pyr_down(src):
+    src = _c(src)
+    h, w = src.shape
+    dst = np.empty(((h + 1) // 2, (w + 1) // 2), np.float32)
+    lib().orc_fb_pyr_down(src, w, h, dst, dst.shape[1], dst.shape[0])
+    return dst
+
+
+def fb_calc(I0, I1, params: FBParams | None = None, init_flow=None):
+    p = params or fb_params()
+    I0, I1 = np.ascontiguousarray(I0), np.ascontiguousarray(I1)
+    if I0.ndim != 2 or I1.ndim != 2:
+        raise ValueError("single-channel frames required")      # farneback.cpp:173
+    if I0.shape != I1.shape or I0.dtype != I1.dtype:
+        raise ValueError("frame size/type mismatch")             # :174
+    if I0.dtype == np.uint8:
+        typ = 0
+    elif I0.dtype == np.float32:
+        typ = 1
+    else:
+        raise ValueError("uint8 or float32 frames")
+    h, w = I0.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    if p.flags & OPTFLOW_USE_INITIAL_FLOW:
+        if init_flow is None or init_flow.shape != (h, w, 2):
+            raise ValueError("initial flow of the frame size required")   # :181-182
+        flow[...] = init_flow
+    rc = lib().orc_fb_calc(C.byref(p), I0.ctypes.data, I1.ctypes.data, typ, w, h, flow.reshape(-1))
+    if rc:
+        raise ValueError(f"orc_fb_calc failed: {rc}")
+    return flow

@@ -16,6 +16,9 @@ int main(int argc, char **argv)
         tvl1->setNumIterations(10);
         tvl1->setEpsilon(0.0);
         Ptr<cuda::StereoBM> bm = cuda::createStereoBM(32, 9);
+        Ptr<cuda::FarnebackOpticalFlow> fb = cuda::FarnebackOpticalFlow::create();
+        if (fb->getWinSize() != 13 || fb->getDefaultName() != "DenseOpticalFlow.FarnebackOpticalFlow") return 2;
+        fb->setNumLevels(3);
         if (argc < 3) return 0;
         FILE *f = fopen(argv[1], "rb");
         if (!f) return 4;
@@ -31,7 +34,10 @@ int main(int argc, char **argv)
         cuda::Stream stream;
         tvl1->calc(d0, d1, flow, stream);
         bm->compute(d0, d1, disp, stream);
+        cuda::GpuMat fbflow;
+        fb->calc(d0, d1, fbflow, stream);
         stream.waitForCompletion();
+        if (fbflow.type() != CV_32FC2 || fbflow.size() != d0.size()) return 5;
         if (flow.type() != CV_32FC2 || flow.size() != d0.size() || disp.type() != CV_8UC1) return 5;
         std::vector<float> hf((size_t)h * w * 2);
         std::vector<unsigned char> hd((size_t)h * w);
@@ -40,6 +46,8 @@ int main(int argc, char **argv)
         FILE *o = fopen(argv[2], "wb");
         fwrite(hf.data(), 4, hf.size(), o);
         fwrite(hd.data(), 1, hd.size(), o);
+        fbflow.download(hf.data(), (size_t)w * 8);
+        fwrite(hf.data(), 4, hf.size(), o);
         fclose(o);
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;

@@ -63,9 +63,11 @@ def test_shim_matches_python_mirror_on_gpu(gpu, tmp_path):
     assert r.returncode == 0, (r.returncode, r.stderr)
     raw = open(fout, "rb").read()
     flow = np.frombuffer(raw[: 96 * 160 * 8], np.float32).reshape(96, 160, 2)
-    disp = np.frombuffer(raw[96 * 160 * 8:], np.uint8).reshape(96, 160)
+    disp = np.frombuffer(raw[96 * 160 * 8: 96 * 160 * 9], np.uint8).reshape(96, 160)
+    fbflow = np.frombuffer(raw[96 * 160 * 9:], np.float32).reshape(96, 160, 2)
     tl, tr = torch.from_numpy(left).to(gpu), torch.from_numpy(right).to(gpu)
     pf = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0).calc(tl, tr).cpu().numpy()
     pd = cuda.createStereoBM(32, 9).compute(tl, tr).cpu().numpy()
     np.testing.assert_array_equal(flow, pf)
     np.testing.assert_array_equal(disp, pd)
+    np.testing.assert_array_equal(fbflow, cuda.FarnebackOpticalFlow.create(numLevels=3).calc(tl, tr).cpu().numpy())

@@ -1,0 +1,241 @@
+"""Farneback: oracle self-tests (CPU) and HIP-vs-oracle parity (GPU) for cv::cuda::FarnebackOpticalFlow.
+
+Tolerances (float path, stated):
+  * stage level: same binary32 operations in the same order on both sides (-ffp-contract=off); the only
+    freedom is libm exp() in the host-side kernel tables (identical code path: both computed on the host
+    with the same formula) -> atol 1e-5 relative to plane magnitude (rtol 2e-6);
+  * full calc vs oracle: mean EPE <= 2e-3 px and |1-CCORR| <= 1e-5 -- far inside the reference's own
+    CUDA-vs-CPU acceptance |1-CCORR| <= 1e-4 (box) / 2e-2 (Gaussian), cudaoptflow/test/test_optflow.cpp:349.
+"""
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+def test_oracle_gaussian_kernel_tables_and_normalisation(oracle):
+    np.testing.assert_array_equal(oracle.fb_gaussian_kernel(3, 0), np.array([0.25, 0.5, 0.25], np.float32))
+    k = oracle.fb_gaussian_kernel(13, 13 // 2 * 0.3)
+    assert abs(k.sum() - 1) < 1e-6 and np.allclose(k, k[::-1]) and k.argmax() == 6
+    k = oracle.fb_gaussian_kernel(9, 0)      # sigma <= 0, n > 7: sigma = ((n-1)*0.5 - 1)*0.3 + 0.8
+    s = ((9 - 1) * 0.5 - 1) * 0.3 + 0.8
+    x = np.arange(9) - 4
+    ref = np.exp(-x * x / (2 * s * s)); ref /= ref.sum()
+    np.testing.assert_allclose(k, ref, rtol=1e-6)
+
+
+def test_oracle_prepare_gaussian_inverts_moment_matrix(oracle):
+    g, xg, xxg, ig = oracle.fb_prepare_gaussian(5, 1.1)
+    full = np.concatenate([g[:0:-1], g])
+    assert abs(full.sum() - 1) < 1e-6
+    # ig11 = 1 / sum(g_y g_x x^2) (the x-moment block of G is diagonal)
+    x = np.arange(-5, 6)
+    m2 = (full[:, None] * full[None, :] * (x[None, :] ** 2)).sum()
+    assert abs(ig[0] - 1 / m2) < 1e-5
+
+
+def test_oracle_polyexp_recovers_quadratic(oracle):
+    """f(x,y) = c + ax + by + (1/2)(r4 x^2... ): the expansion of an exact quadratic returns its coefficients
+    in the layout [b_y?]: plane0 = d/dy, plane1 = d/dx, plane2 = yy/..., here checked via a pure linear ramp."""
+    h, w = 40, 50
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = (3.0 + 0.5 * x - 0.25 * y).astype(np.float32)
+    R = oracle.fb_poly_exp(img, 5, 1.1).reshape(5, h, w)
+    c = (slice(8, -8), slice(8, -8))
+    np.testing.assert_allclose(R[0][c], -0.25, atol=1e-4)   # b3*ig11: linear term in y
+    np.testing.assert_allclose(R[1][c], 0.5, atol=1e-4)     # b2*ig11: linear term in x
+    for k in (2, 3, 4):
+        np.testing.assert_allclose(R[k][c], 0.0, atol=1e-4)
+
+
+def test_oracle_pyr_down_constant_and_size(oracle):
+    img = np.full((31, 45), 7.0, np.float32)
+    d = oracle.fb_pyr_down(img)
+    assert d.shape == (16, 23)
+    np.testing.assert_allclose(d, 7.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("flags", [0, 256])
+def test_oracle_recovers_analytic_flow_config1(oracle, flags):
+    """BASELINE configs[0]: 640x480 synthetic pair, class defaults."""
+    I0, I1, gt = synth.flow_pair(480, 640, seed=1234, dtype="u8")
+    f = oracle.fb_calc(I0, I1, oracle.fb_params(flags=flags))
+    assert synth.epe(f[40:-40, 40:-40], gt[40:-40, 40:-40]) < 0.08
+
+
+def test_oracle_initial_flow_and_fast_pyramids(oracle):
+    I0, I1, gt = synth.flow_pair(240, 320, seed=5, dtype="u8")
+    f = oracle.fb_calc(I0, I1, oracle.fb_params(fast_pyramids=1))
+    assert synth.epe(f[30:-30, 30:-30], gt[30:-30, 30:-30]) < 0.12
+    f2 = oracle.fb_calc(I0, I1, oracle.fb_params(flags=4, num_iters=3), init_flow=gt)
+    assert synth.epe(f2[30:-30, 30:-30], gt[30:-30, 30:-30]) < 0.12
+
+
+def test_oracle_argument_errors(oracle):
+    I = np.zeros((64, 64), np.uint8)
+    with pytest.raises(ValueError):
+        oracle.fb_calc(I, I, oracle.fb_params(poly_n=6))              # CV_Assert(polyN == 5 || 7)  farneback.cpp:316
+    with pytest.raises(ValueError):
+        oracle.fb_calc(I, I, oracle.fb_params(fast_pyramids=1, pyr_scale=0.8))   # :317
+    with pytest.raises(ValueError):
+        oracle.fb_calc(I, I[:, :32])
+    with pytest.raises(ValueError):
+        oracle.fb_calc(I, I, oracle.fb_params(flags=4))               # initial flow missing
+
+
+# ------------------------------------------------------------------ HIP vs oracle (GPU)
+gpu_mark = pytest.mark.gpu
+
+
+def _close(a, b, name=""):
+    scale = max(float(np.abs(b).max()), 1e-6)
+    np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-6 * scale, err_msg=name)
+
+
+@gpu_mark
+@pytest.mark.parametrize("shape", [(48, 70), (97, 531)])
+@pytest.mark.parametrize("polyN,sigma", [(5, 1.1), (7, 1.5)])
+def test_poly_exp_matches_oracle(gpu, oracle, shape, polyN, sigma):
+    from opencv_contrib_amd import cuda
+    img = np.random.default_rng(1).random(shape, dtype=np.float32) * 255
+    ref = oracle.fb_poly_exp(img, polyN, sigma)
+    _close(N(cuda.farneback_polyExp(T(img, gpu), polyN, sigma)), ref)
+
+
+def _fb_state(h, w, seed, amp=2.0):
+    rng = np.random.default_rng(seed)
+    I0 = synth.texture(h, w, seed, 2.0).astype(np.float32)
+    I1 = synth.texture(h, w, seed + 1, 2.0).astype(np.float32)
+    fx = ((rng.random((h, w), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+    fy = ((rng.random((h, w), dtype=np.float32) - 0.5) * 2 * amp).astype(np.float32)
+    return I0, I1, fx, fy
+
+
+@gpu_mark
+@pytest.mark.parametrize("shape,amp", [((40, 64), 1.5), ((67, 300), 30.0)])
+def test_update_matrices_matches_oracle(gpu, oracle, shape, amp):
+    from opencv_contrib_amd import cuda
+    I0, I1, fx, fy = _fb_state(*shape, seed=3, amp=amp)
+    R0, R1 = oracle.fb_poly_exp(I0), oracle.fb_poly_exp(I1)
+    ref = oracle.fb_update_matrices(fx, fy, R0, R1)
+    out = cuda.farneback_updateMatrices(T(fx, gpu), T(fy, gpu), T(R0, gpu), T(R1, gpu))
+    _close(N(out), ref)
+
+
+@gpu_mark
+@pytest.mark.parametrize("ksize,gauss", [(13, False), (13, True), (5, False), (31, True)])
+def test_blur5_update_flow_and_fused_iteration_match_oracle(gpu, oracle, ksize, gauss):
+    from opencv_contrib_amd import cuda
+    h, w = 61, 277
+    I0, I1, fx, fy = _fb_state(h, w, seed=7)
+    R0, R1 = oracle.fb_poly_exp(I0), oracle.fb_poly_exp(I1)
+    M = oracle.fb_update_matrices(fx, fy, R0, R1)
+    sig = (ksize // 2 * np.float32(0.3)) if gauss else None
+    Mb = oracle.fb_blur5(M, ksize, float(sig) if gauss else None)
+    _close(N(cuda.farneback_blur5(T(M, gpu), ksize, gauss)), Mb, "blur5")
+    rfx, rfy = oracle.fb_update_flow(Mb)
+    gfx, gfy = cuda.farneback_updateFlow(T(Mb, gpu))
+    _close(N(gfx), rfx, "flowx"); _close(N(gfy), rfy, "flowy")
+    M2 = oracle.fb_update_matrices(rfx, rfy, R0, R1)
+    ifx, ify, iM = cuda.farneback_iterate(T(M, gpu), T(R0, gpu), T(R1, gpu), ksize, gauss, True)
+    # the fused kernel divides once per pixel like updateFlow; flows agree to float rounding, M' follows
+    np.testing.assert_allclose(N(ifx), rfx, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(N(ify), rfy, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(N(iM), M2, rtol=1e-3, atol=1e-3 * np.abs(M2).max())
+
+
+@gpu_mark
+@pytest.mark.parametrize("border", [1, 4])
+@pytest.mark.parametrize("ksize,sigma", [(3, 0.0), (9, 1.5), (39, 7.5)])
+def test_gaussian_blur_and_pyr_down_match_oracle(gpu, oracle, border, ksize, sigma):
+    from opencv_contrib_amd import cuda
+    img = np.random.default_rng(2).random((53, 300), dtype=np.float32) * 255
+    _close(N(cuda.farneback_gaussianBlur(T(img, gpu), ksize, sigma, border)), oracle.fb_gaussian_blur(img, ksize, sigma, border))
+    if border == 4 and ksize == 3:
+        for shp in ((53, 300), (32, 33), (7, 9)):
+            im = np.random.default_rng(3).random(shp, dtype=np.float32)
+            np.testing.assert_array_equal(N(cuda.pyrDown(T(im, gpu))), oracle.fb_pyr_down(im))
+
+
+def _assert_flow_close(flow, ref, mean_epe=2e-3, ccorr=1e-5):
+    assert np.isfinite(flow).all()
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= mean_epe, f"mean EPE {d.mean()}"
+    assert synth.ccorr_dissimilarity(flow, ref) <= ccorr
+
+
+@gpu_mark
+@pytest.mark.parametrize("pyrScale", [0.3, 0.5, 0.8])
+@pytest.mark.parametrize("polyN,sigma", [(5, 1.1), (7, 1.5)])
+@pytest.mark.parametrize("flags", [0, 256])
+def test_calc_matches_oracle_reference_test_parameters(gpu, oracle, pyrScale, polyN, sigma, flags):
+    """Parameter grid of cudaoptflow/test/test_optflow.cpp:307-356 (pyrScale x polyN x flags), RubberWhale-size
+    synthetic pair (584x388)."""
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(388, 584, seed=31, dtype="u8")
+    p = oracle.fb_params(pyr_scale=pyrScale, poly_n=polyN, poly_sigma=sigma, flags=flags)
+    ref = oracle.fb_calc(I0, I1, p)
+    alg = cuda.FarnebackOpticalFlow.create(pyrScale=pyrScale, polyN=polyN, polySigma=sigma, flags=flags)
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    _assert_flow_close(flow, ref)
+
+
+@gpu_mark
+def test_calc_config1_defaults_640x480(gpu, oracle):
+    """BASELINE configs[0] workload on the GPU path vs the oracle, plus accuracy against the analytic flow."""
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(480, 640, seed=1234, dtype="u8")
+    ref = oracle.fb_calc(I0, I1)
+    alg = cuda.FarnebackOpticalFlow.create()
+    assert alg.getDefaultName() == "DenseOpticalFlow.FarnebackOpticalFlow" and alg.getWinSize() == 13
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    _assert_flow_close(flow, ref)
+    assert synth.epe(flow[40:-40, 40:-40], gt[40:-40, 40:-40]) < 0.08
+
+
+@gpu_mark
+def test_calc_initial_flow_fast_pyramids_f32_and_pitched(gpu, oracle):
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(240, 320, seed=5, dtype="u8")
+    # fastPyramids
+    ref = oracle.fb_calc(I0, I1, oracle.fb_params(fast_pyramids=1))
+    alg = cuda.FarnebackOpticalFlow.create(fastPyramids=True)
+    _assert_flow_close(N(alg.calc(T(I0, gpu), T(I1, gpu))), ref)
+    # initial flow (flags = USE_INITIAL_FLOW), pitched float frames and pitched flow
+    F0, F1 = I0.astype(np.float32), I1.astype(np.float32)
+    ref = oracle.fb_calc(F0, F1, oracle.fb_params(flags=4, num_iters=3, num_levels=3), init_flow=gt)
+    buf0 = torch.zeros((240, 384), dtype=torch.float32, device=gpu); buf1 = torch.zeros((240, 352), dtype=torch.float32, device=gpu)
+    fbuf = torch.zeros((240, 330, 2), dtype=torch.float32, device=gpu)
+    buf0[:, 5:325] = T(F0, gpu); buf1[:, 1:321] = T(F1, gpu); fbuf[:, 3:323] = T(gt, gpu)
+    alg = cuda.FarnebackOpticalFlow.create(numLevels=3, numIters=3, flags=cuda.OPTFLOW_USE_INITIAL_FLOW)
+    out = alg.calc(buf0[:, 5:325], buf1[:, 1:321], fbuf[:, 3:323])
+    _assert_flow_close(N(out), ref)
+
+
+@gpu_mark
+def test_calc_argument_errors_and_determinism(gpu):
+    import torch
+    from opencv_contrib_amd import cuda, capi
+    a = torch.zeros((64, 80), dtype=torch.uint8, device=gpu)
+    with pytest.raises(capi.MiError):
+        cuda.FarnebackOpticalFlow.create(polyN=6).calc(a, a)
+    with pytest.raises(capi.MiError):
+        cuda.FarnebackOpticalFlow.create(fastPyramids=True, pyrScale=0.8).calc(a, a)
+    with pytest.raises(capi.MiError):
+        cuda.FarnebackOpticalFlow.create().calc(a, a[:, :40])
+    I0, I1, _ = synth.flow_pair(200, 300, seed=9, dtype="u8")
+    alg = cuda.FarnebackOpticalFlow.create()
+    f1 = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    f2 = N(cuda.FarnebackOpticalFlow.create().calc(T(I0, gpu), T(I1, gpu)))
+    np.testing.assert_array_equal(f1, f2)
