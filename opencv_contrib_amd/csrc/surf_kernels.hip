@@ -1,0 +1,649 @@
+// SURF detect + describe (cv::cuda::SURF_CUDA) -- HIP kernels for gfx950 (MI355X, CDNA4), wave64.
+//
+// Reference: modules/xfeatures2d/src/cuda/surf.cu:122-942 driven by src/surf.cuda.cpp:134-255; texture-free
+// definitions (clamped point reads, bilinear/area patch filters, 3x3 solve) from the reference's OpenCL twin
+// src/opencl/surf.cl:55-68,413-441,873-952 (CDNA has no sampler path worth relying on).
+// MI355X formulation:
+//   * no __constant__ state (the reference loads 9 symbols per call and serialises every call behind a mutex,
+//     surf.cuda.cpp:117,371): parameters are kernel arguments, tables live in the handle;
+//   * DETERMINISTIC compaction: the reference appends maxima / features with atomicInc (surf.cu:341,476), so order
+//     and, on overflow, the surviving subset change run to run.  Here maxima are flagged per 64-sample chunk with
+//     a wave ballot, row counts are scanned, and candidates / features are written in (layer, row, column) scan
+//     order; the first maxCandidates / maxFeatures survive;
+//   * no host round trips inside the octave loop (the reference copies two counters to the host per octave,
+//     surf.cuda.cpp:193,206): every stage reads the counts from device memory and bounds itself;
+//   * integral image: band-local column prefix in registers + one wave-wide DPP scan per 64 columns;
+//   * orientation / descriptor reductions are the reference's 32-lane shfl_down trees (16,8,4,2,1), two per wave64.
+// Haar responses accumulate in double like the reference (u32 integral differences do not fit a float mantissa).
+#include "surf_dev.h"
+#include <cfloat>
+
+namespace mi {
+namespace surf {
+
+#define CV_PI_F 3.14159265f
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int rn(float v) { return __float2int_rn(v); }
+__host__ __device__ __forceinline__ int calc_size(int octave, int layer) { return (9 + 6 * layer) << octave; }   // surf.cu:161-173
+
+// ------------------------------------------------------------------ integral image
+// pass A: band-local vertical prefix V[y][x] = sum of img[y0..y][x] (u32) and band totals BT[band][x]
+__global__ __launch_bounds__(256) void k_int_cols(const unsigned char *img, long long istep, int rows, int cols, int clamp1,
+                                                  unsigned *V, int vld, unsigned *BT, int band_rows)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int band = blockIdx.y;
+    if (x >= cols) return;
+    const int y0 = band * band_rows, y1 = min(y0 + band_rows, rows);
+    unsigned acc = 0;
+    for (int y = y0; y < y1; ++y) {
+        unsigned v = img[(long long)y * istep + x];
+        if (clamp1) v = min(v, 1u);   // cuda::min(mask, 1.0), surf.cuda.cpp:167
+        acc += v;
+        V[(long long)y * vld + x] = acc;
+    }
+    BT[(long long)band * vld + x] = acc;
+}
+// pass A2: exclusive prefix of the band totals per column (in place)
+__global__ __launch_bounds__(256) void k_int_bands(unsigned *BT, int vld, int cols, int nbands)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= cols) return;
+    unsigned acc = 0;
+    for (int b = 0; b < nbands; ++b) {
+        const unsigned t = BT[(long long)b * vld + x];
+        BT[(long long)b * vld + x] = acc;
+        acc += t;
+    }
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp0(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
+{
+    v += dpp0<0x111, 0xf>(v);   // row_shr:1
+    v += dpp0<0x112, 0xf>(v);   // row_shr:2
+    v += dpp0<0x114, 0xf>(v);   // row_shr:4
+    v += dpp0<0x118, 0xf>(v);   // row_shr:8  -> inclusive scan inside each row of 16
+    v += dpp0<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3 += total of the previous row
+    v += dpp0<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3 += total of rows 0..1
+    return v;
+}
+// pass B: horizontal scan of (V + band offset) per row -> sum[(y+1)][(x+1)]; first row/column 0
+__global__ __launch_bounds__(256) void k_int_rows(const unsigned *V, const unsigned *BT, int vld, int rows, int cols, int band_rows,
+                                                  unsigned *sum, int sld)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per row; y == rows: the zero top row
+    if (y > rows) return;
+    if (y == rows) {
+        for (int x = lane; x <= cols; x += 64) sum[x] = 0;
+        return;
+    }
+    const unsigned *bt = BT + (long long)(y / band_rows) * vld;
+    unsigned carry = 0;
+    if (lane == 0) sum[(long long)(y + 1) * sld] = 0;
+    for (int x0 = 0; x0 < cols; x0 += 64) {
+        const int x = x0 + lane;
+        unsigned v = x < cols ? V[(long long)y * vld + x] + bt[x] : 0u;
+        v = wave_incl_scan(v) + carry;
+        if (x < cols) sum[(long long)(y + 1) * sld + x + 1] = v;
+        carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    }
+}
+__global__ void k_dbg_scan(const unsigned *in, unsigned *out) { out[threadIdx.x] = wave_incl_scan(in[threadIdx.x]); }
+
+// ------------------------------------------------------------------ Haar responses
+struct SumTex { const unsigned *s; int sld, rows, cols; };   // image size; the integral is (rows+1) x (cols+1)
+__device__ __forceinline__ unsigned tex(const SumTex &t, int y, int x)
+{
+    return t.s[(long long)clampi(y, 0, t.rows) * t.sld + clampi(x, 0, t.cols)];   // surf.cl:55-60 (clamp addressing)
+}
+// surf.cu:122-152
+template <int N>
+__device__ __forceinline__ float haar(const SumTex &t, const float (&src)[N][5], int oldSize, int newSize, int y, int x)
+{
+    const float ratio = (float)newSize / oldSize;
+    double d = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int dx1 = rn(ratio * src[k][0]), dy1 = rn(ratio * src[k][1]), dx2 = rn(ratio * src[k][2]), dy2 = rn(ratio * src[k][3]);
+        double tt = 0;
+        tt += tex(t, y + dy1, x + dx1);
+        tt -= tex(t, y + dy2, x + dx1);
+        tt -= tex(t, y + dy1, x + dx2);
+        tt += tex(t, y + dy2, x + dx2);
+        d += tt * src[k][4] / ((dx2 - dx1) * (dy2 - dy1));
+    }
+    return (float)d;
+}
+
+// surf.cu:175-203.  Grid covers the whole layer region; samples outside the valid window are written as 0
+// (the reference leaves them unwritten = stale memory).
+__global__ __launch_bounds__(256) void k_det_trace(SumTex t, float *det, float *trace, int dld, int octave, int nlayers2)
+{
+    const float c_DX[3][5] = {{0, 2, 3, 7, 1}, {3, 2, 6, 7, -2}, {6, 2, 9, 7, 1}};      // surf.cu:157-159
+    const float c_DY[3][5] = {{2, 0, 7, 3, 1}, {2, 3, 7, 6, -2}, {2, 6, 7, 9, 1}};
+    const float c_DXY[4][5] = {{1, 1, 4, 4, 1}, {5, 1, 8, 4, -1}, {1, 5, 4, 8, -1}, {5, 5, 8, 8, 1}};
+    const int layer_rows = t.rows >> octave, layer_cols = t.cols >> octave;
+    const int jj = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ii = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int layer = blockIdx.z;
+    if (jj >= layer_cols || ii >= layer_rows || layer >= nlayers2) return;
+    const int size = calc_size(octave, layer);
+    const int samples_i = 1 + ((t.rows - size) >> octave), samples_j = 1 + ((t.cols - size) >> octave);
+    const int margin = (size >> 1) >> octave;
+    const int i = ii - margin, j = jj - margin;
+    float d = 0.f, tr = 0.f;
+    if (size <= t.rows && size <= t.cols && i >= 0 && j >= 0 && i < samples_i && j < samples_j) {
+        const float dx = haar<3>(t, c_DX, 9, size, i << octave, j << octave);
+        const float dy = haar<3>(t, c_DY, 9, size, i << octave, j << octave);
+        const float dxy = haar<4>(t, c_DXY, 9, size, i << octave, j << octave);
+        d = dx * dy - 0.81f * dxy * dxy;
+        tr = dx + dy;
+    }
+    const long long o = (long long)(layer * layer_rows + ii) * dld + jj;
+    det[o] = d;
+    trace[o] = tr;
+}
+
+// ------------------------------------------------------------------ non-maximum suppression
+// Mask::check surf.cu:229-261
+__device__ __forceinline__ bool mask_check(const SumTex &m, int sum_i, int sum_j, int size)
+{
+    const float ratio = (float)size / 9.0f;
+    const int dx1 = rn(ratio * 0.f), dy1 = rn(ratio * 0.f), dx2 = rn(ratio * 9.f), dy2 = rn(ratio * 9.f);
+    float tt = 0, d = 0;
+    tt += (float)tex(m, sum_i + dy1, sum_j + dx1);
+    tt -= (float)tex(m, sum_i + dy2, sum_j + dx1);
+    tt -= (float)tex(m, sum_i + dy1, sum_j + dx2);
+    tt += (float)tex(m, sum_i + dy2, sum_j + dx2);
+    d += tt * 1.f / ((dx2 - dx1) * (dy2 - dy1));
+    return d >= 0.5f;
+}
+
+struct NmsArgs {
+    const float *det, *trace;
+    int dld, rows, cols, octave, nlayers;   // nlayers = nOctaveLayers
+    float thr;
+    SumTex mask;                            // mask.s == nullptr: no mask
+    unsigned long long *bits;               // [nlayers][layer_rows][chunks] ballot of the maxima
+    unsigned *rowcnt;                       // [nlayers * layer_rows (+1)]  counts, then exclusive offsets
+    int chunks;
+};
+
+// surf.cu:263-355: one wave per (layer, row); flags per 64-column chunk
+__global__ __launch_bounds__(256) void k_nms_flag(NmsArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int layer_rows = A.rows >> A.octave, layer_cols = A.cols >> A.octave;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.nlayers * layer_rows) return;
+    const int layer = r / layer_rows + 1, i = r % layer_rows;
+    const int size = calc_size(A.octave, layer);
+    const int margin = ((calc_size(A.octave, layer + 1) >> 1) >> A.octave) + 1;
+    unsigned cnt = 0;
+    const bool row_ok = i >= margin && i < layer_rows - margin;
+    for (int c = 0; c < A.chunks; ++c) {
+        const int j = c * 64 + lane;
+        bool ismax = false;
+        if (row_ok && j >= margin && j < layer_cols - margin) {
+#define DET(l, ii, jj) A.det[(long long)((l) * layer_rows + clampi(ii, 0, A.rows - 1)) * A.dld + clampi(jj, 0, A.cols - 1)]
+            const float v = DET(layer, i, j);
+            if (v > A.thr) {
+                const int sum_i = (i - ((size >> 1) >> A.octave)) << A.octave, sum_j = (j - ((size >> 1) >> A.octave)) << A.octave;
+                if (!A.mask.s || mask_check(A.mask, sum_i, sum_j, size)) {
+                    ismax = true;
+#pragma unroll
+                    for (int dl = -1; dl <= 1; ++dl)
+#pragma unroll
+                        for (int di = -1; di <= 1; ++di)
+#pragma unroll
+                            for (int dj = -1; dj <= 1; ++dj)
+                                if (dl || di || dj) ismax = ismax && (v > DET(layer + dl, i + di, j + dj));
+                }
+            }
+#undef DET
+        }
+        const unsigned long long m = __ballot(ismax);
+        if (lane == 0) A.bits[(long long)r * A.chunks + c] = m;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) A.rowcnt[r] = cnt;
+}
+
+// exclusive scan of n (<= 1024 * per) counts by ONE block; total -> cnt[n]
+__global__ __launch_bounds__(1024) void k_scan_counts(unsigned *cnt, int n)
+{
+    __shared__ unsigned part[1024];
+    const int per = (n + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, n);
+    unsigned s = 0;
+    for (int k = b; k < e; ++k) s += cnt[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+    for (int k = b; k < e; ++k) { const unsigned c = cnt[k]; cnt[k] = run; run += c; }
+    if (threadIdx.x == 1023) cnt[n] = part[1023];
+}
+
+// write candidates {j, i, layer, laplacian} in scan order; count (clamped) -> ncand
+__global__ __launch_bounds__(256) void k_nms_write(NmsArgs A, int4 *cand, int max_candidates, unsigned *ncand)
+{
+    const int lane = threadIdx.x & 63;
+    const int layer_rows = A.rows >> A.octave;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nrows = A.nlayers * layer_rows;
+    if (r == 0 && lane == 0) *ncand = min(A.rowcnt[nrows], (unsigned)max_candidates);
+    if (r >= nrows) return;
+    const int layer = r / layer_rows + 1, i = r % layer_rows;
+    unsigned base = A.rowcnt[r];
+    for (int c = 0; c < A.chunks; ++c) {
+        const unsigned long long m = A.bits[(long long)r * A.chunks + c];
+        if (!m) continue;
+        if ((m >> lane) & 1ull) {
+            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (idx < (unsigned)max_candidates) {
+                const int j = c * 64 + lane;
+                const int lap = (int)copysignf(1.0f, A.trace[(long long)(layer * layer_rows + i) * A.dld + j]);
+                cand[idx] = make_int4(j, i, layer, lap);
+            }
+        }
+        base += (unsigned)__popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------ sub-pixel interpolation
+// surf.cl:413-441
+__device__ __forceinline__ bool solve3x3(const float A[3][3], const float b[3], float x[3])
+{
+    const float det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                      A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    if (det != 0) {
+        const float invdet = 1.0f / det;
+        x[0] = invdet * (b[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (b[1] * A[2][2] - A[1][2] * b[2]) +
+                         A[0][2] * (b[1] * A[2][1] - A[1][1] * b[2]));
+        x[1] = invdet * (A[0][0] * (b[1] * A[2][2] - A[1][2] * b[2]) - b[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                         A[0][2] * (A[1][0] * b[2] - b[1] * A[2][0]));
+        x[2] = invdet * (A[0][0] * (A[1][1] * b[2] - b[1] * A[2][1]) - A[0][1] * (A[1][0] * b[2] - b[1] * A[2][0]) +
+                         b[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]));
+        return true;
+    }
+    return false;
+}
+
+// surf.cu:391-493: one thread per candidate (ONE block of 1024 threads, candidates strided) -> accepted features
+// compacted in candidate order behind the features of the previous octaves.
+__global__ __launch_bounds__(1024) void k_interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
+                                                      const unsigned *ncand_p, float *kp, int kld, int max_features,
+                                                      unsigned *nfeat_p)
+{
+    __shared__ unsigned part[1024];
+    const int layer_rows = rows >> octave;
+    const unsigned ncand = *ncand_p, nfeat0 = *nfeat_p;
+    const int per = (int)(ncand + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, (int)ncand);
+    // pass 1: count accepted candidates of this thread's contiguous range; pass 2: write
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned run = 0;
+        if (pass == 1) run = nfeat0 + (threadIdx.x ? part[threadIdx.x - 1] : 0u);
+        unsigned cnt = 0;
+        for (int c = b; c < e; ++c) {
+            const int4 mp = cand[c];
+            float N9[3][3][3];
+#pragma unroll
+            for (int z = 0; z < 3; ++z)
+#pragma unroll
+                for (int y = 0; y < 3; ++y)
+#pragma unroll
+                    for (int x = 0; x < 3; ++x)
+                        N9[z][y][x] = det[(long long)(layer_rows * (mp.z - 1 + z) + mp.y - 1 + y) * dld + mp.x - 1 + x];
+            float dD[3], H[3][3], xs[3];
+            dD[0] = -0.5f * (N9[1][1][2] - N9[1][1][0]);
+            dD[1] = -0.5f * (N9[1][2][1] - N9[1][0][1]);
+            dD[2] = -0.5f * (N9[2][1][1] - N9[0][1][1]);
+            H[0][0] = N9[1][1][0] - 2.0f * N9[1][1][1] + N9[1][1][2];
+            H[0][1] = 0.25f * (N9[1][2][2] - N9[1][2][0] - N9[1][0][2] + N9[1][0][0]);
+            H[0][2] = 0.25f * (N9[2][1][2] - N9[2][1][0] - N9[0][1][2] + N9[0][1][0]);
+            H[1][0] = H[0][1];
+            H[1][1] = N9[1][0][1] - 2.0f * N9[1][1][1] + N9[1][2][1];
+            H[1][2] = 0.25f * (N9[2][2][1] - N9[2][0][1] - N9[0][2][1] + N9[0][0][1]);
+            H[2][0] = H[0][2];
+            H[2][1] = H[1][2];
+            H[2][2] = N9[0][1][1] - 2.0f * N9[1][1][1] + N9[2][1][1];
+            bool ok = solve3x3(H, dD, xs);
+            ok = ok && fabsf(xs[0]) <= 1.f && fabsf(xs[1]) <= 1.f && fabsf(xs[2]) <= 1.f;
+            float px = 0, py = 0, psize = 0;
+            if (ok) {
+                const int size = calc_size(octave, mp.z);
+                const int sum_i = (mp.y - ((size >> 1) >> octave)) << octave, sum_j = (mp.x - ((size >> 1) >> octave)) << octave;
+                const float center_i = sum_i + (float)(size - 1) / 2, center_j = sum_j + (float)(size - 1) / 2;
+                px = center_j + xs[0] * (1 << octave);
+                py = center_i + xs[1] * (1 << octave);
+                const int ds = size - calc_size(octave, mp.z - 1);
+                psize = roundf(size + xs[2] * ds);
+                const float s = psize * 1.2f / 9.0f;
+                const int grad_wav_size = 2 * rn(2.0f * s);
+                ok = (rows + 1) >= grad_wav_size && (cols + 1) >= grad_wav_size;
+            }
+            if (ok) {
+                if (pass == 1) {
+                    const unsigned ind = run + cnt;
+                    if (ind < (unsigned)max_features) {
+                        kp[0 * kld + ind] = px;
+                        kp[1 * kld + ind] = py;
+                        reinterpret_cast<int *>(kp)[2 * kld + ind] = mp.w;     // LAPLACIAN_ROW holds int bit patterns (cuda.hpp:89-99)
+                        reinterpret_cast<int *>(kp)[3 * kld + ind] = octave;
+                        kp[4 * kld + ind] = psize;
+                        kp[6 * kld + ind] = N9[1][1][1];
+                    }
+                }
+                ++cnt;
+            }
+        }
+        if (pass == 0) {
+            part[threadIdx.x] = cnt;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                unsigned v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+                __syncthreads();
+                part[threadIdx.x] += v;
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *nfeat_p = min(nfeat0 + part[1023], (unsigned)max_features);
+}
+
+// ------------------------------------------------------------------ orientation
+__device__ __forceinline__ float reduce32(float v)   // device::reduce<32>, plus<float>: shfl_down 16,8,4,2,1 inside a 32-lane half
+{
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v = v + __shfl_down(v, off, 32);
+    return v;
+}
+
+// surf.cu:527-658: one wave per feature; the two 32-lane halves play threadIdx.y = {0,2} and {1,3}
+__global__ __launch_bounds__(256) void k_orientation(SumTex t, float *kp, int kld, const unsigned *nfeat_p, int n_fixed, const float *apt)
+{
+    __shared__ float sh[4][3][128];
+    __shared__ float best[4][4][3];
+    const float c_NX[2][5] = {{0, 0, 2, 4, -1}, {2, 0, 4, 4, 1}};   // surf.cu:524-525
+    const float c_NY[2][5] = {{0, 0, 4, 2, 1}, {0, 2, 4, 4, -1}};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = blockIdx.x * 4 + wv;
+    const int nfeat = nfeat_p ? (int)*nfeat_p : n_fixed;
+    if (f >= nfeat) return;
+    const float fx = kp[f], fy = kp[kld + f], fsz = kp[4 * kld + f];
+    const float s = fsz * 1.2f / 9.0f;
+    const int grad_wav_size = 2 * rn(2.0f * s);
+    if ((t.rows + 1) < grad_wav_size || (t.cols + 1) < grad_wav_size) return;   // the reference returns without writing
+    float *sX = sh[wv][0], *sY = sh[wv][1], *sA = sh[wv][2];
+    for (int tid = lane; tid < 128; tid += 64) {
+        float X = 0.f, Y = 0.f, angle = 0.f;
+        if (tid < 113) {
+            const float margin = (float)(grad_wav_size - 1) / 2.0f;
+            const int x = rn(fx + apt[tid] * s - margin), y = rn(fy + apt[113 + tid] * s - margin);
+            if (y >= 0 && y < (t.rows + 1) - grad_wav_size && x >= 0 && x < (t.cols + 1) - grad_wav_size) {
+                X = apt[226 + tid] * haar<2>(t, c_NX, 4, grad_wav_size, y, x);
+                Y = apt[226 + tid] * haar<2>(t, c_NY, 4, grad_wav_size, y, x);
+                angle = atan2f(Y, X);
+                if (angle < 0) angle += 2.0f * CV_PI_F;
+                angle *= 180.0f / CV_PI_F;
+            }
+        }
+        sX[tid] = X; sY[tid] = Y; sA[tid] = angle;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int tx = lane & 31, half = lane >> 5;
+    int a4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a4[q] = rn(sA[tx + 32 * q]);
+    for (int rep = 0; rep < 2; ++rep) {
+        const int ty = half + 2 * rep;
+        float bestx = 0, besty = 0, best_mod = 0;
+        for (int i = 0; i < 18; ++i) {
+            const int dir = (i * 4 + ty) * 5;
+            float sumx = 0.0f, sumy = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = abs(a4[q] - dir);
+                if (d < 30 || d > 330) {
+                    if (q == 0) { sumx = sX[tx]; sumy = sY[tx]; }
+                    else { sumx += sX[tx + 32 * q]; sumy += sY[tx + 32 * q]; }
+                }
+            }
+            sumx = reduce32(sumx);
+            sumy = reduce32(sumy);
+            const float temp_mod = sumx * sumx + sumy * sumy;   // meaningful in lane tx == 0 of each half
+            if (temp_mod > best_mod) { best_mod = temp_mod; bestx = sumx; besty = sumy; }
+        }
+        if (tx == 0) { best[wv][ty][0] = bestx; best[wv][ty][1] = besty; best[wv][ty][2] = best_mod; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        int bi = 0;
+        if (best[wv][1][2] > best[wv][bi][2]) bi = 1;
+        if (best[wv][2][2] > best[wv][bi][2]) bi = 2;
+        if (best[wv][3][2] > best[wv][bi][2]) bi = 3;
+        float kp_dir = atan2f(best[wv][bi][1], best[wv][bi][0]);
+        if (kp_dir < 0) kp_dir += 2.0f * CV_PI_F;
+        kp_dir *= 180.0f / CV_PI_F;
+        kp_dir = 360.0f - kp_dir;
+        if (fabsf(kp_dir - 360.f) < FLT_EPSILON) kp_dir = 0.f;
+        kp[5 * kld + f] = kp_dir;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_angle(float *kp, int kld, const unsigned *nfeat_p, int n_fixed, float value)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int nfeat = nfeat_p ? (int)*nfeat_p : n_fixed;
+    if (f < nfeat) kp[5 * kld + f] = value;   // upright: 360 - 90 (surf.cuda.cpp:211-212)
+}
+
+// ------------------------------------------------------------------ descriptors
+struct Win { const unsigned char *img; long long step; int rows, cols; float cx, cy, off, c, s; };
+__device__ __forceinline__ float win_get(const Win &w, int i, int j)
+{
+    // WinReader (surf.cu:709-731) + read_imgTex_ (surf.cl:62-68): nearest texel, round-to-nearest-even, clamp
+    const float px = w.cx + (w.off + j) * w.c + (w.off + i) * w.s;
+    const float py = w.cy - (w.off + j) * w.s + (w.off + i) * w.c;
+    const int x = clampi(rn(px), 0, w.cols - 1), y = clampi(rn(py), 0, w.rows - 1);
+    return (float)w.img[(long long)y * w.step + x];
+}
+__device__ float linear_filter(const Win &w, float y, float x)   // surf.cl:873-898
+{
+    float out = 0.0f;
+    const int x1 = (int)roundf(x), y1 = (int)roundf(y), x2 = x1 + 1, y2 = y1 + 1;
+    out = out + win_get(w, y1, x1) * ((x2 - x) * (y2 - y));
+    out = out + win_get(w, y1, x2) * ((x - x1) * (y2 - y));
+    out = out + win_get(w, y2, x1) * ((x2 - x) * (y - y1));
+    out = out + win_get(w, y2, x2) * ((x - x1) * (y - y1));
+    return out;
+}
+__device__ float area_filter(const Win &w, float x, float y, float s)   // surf.cl:900-952
+{
+    const float fsx1 = x * s, fsx2 = fsx1 + s;
+    const int sx1 = (int)ceilf(fsx1), sx2 = (int)floorf(fsx2);
+    const float fsy1 = y * s, fsy2 = fsy1 + s;
+    const int sy1 = (int)ceilf(fsy1), sy2 = (int)floorf(fsy2);
+    const float scale = 1.f / (s * s);
+    float out = 0.f;
+    for (int dy = sy1; dy < sy2; ++dy) {
+        for (int dx = sx1; dx < sx2; ++dx) out = out + win_get(w, dy, dx) * scale;
+        if (sx1 > fsx1) out = out + win_get(w, dy, sx1 - 1) * ((sx1 - fsx1) * scale);
+        if (sx2 < fsx2) out = out + win_get(w, dy, sx2) * ((fsx2 - sx2) * scale);
+    }
+    if (sy1 > fsy1) for (int dx = sx1; dx < sx2; ++dx) out = out + win_get(w, sy1 - 1, dx) * ((sy1 - fsy1) * scale);
+    if (sy2 < fsy2) for (int dx = sx1; dx < sx2; ++dx) out = out + win_get(w, sy2, dx) * ((fsy2 - sy2) * scale);
+    if ((sy1 > fsy1) && (sx1 > fsx1)) out = out + win_get(w, sy1 - 1, sx1 - 1) * ((sy1 - fsy1) * (sx1 - fsx1) * scale);
+    if ((sy1 > fsy1) && (sx2 < fsx2)) out = out + win_get(w, sy1 - 1, sx2) * ((sy1 - fsy1) * (fsx2 - sx2) * scale);
+    if ((sy2 < fsy2) && (sx2 < fsx2)) out = out + win_get(w, sy2, sx2) * ((fsy2 - sy2) * (fsx2 - sx2) * scale);
+    if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + win_get(w, sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
+    return out;
+}
+
+// surf.cu:733-912: one workgroup (4 waves) per feature: 21x21 patch -> 16 sub-regions of 25 weighted Haar responses,
+// 32-lane trees (two per wave) -> 64 or 128 sums -> L2 normalisation.
+template <bool EXT>
+__global__ __launch_bounds__(256) void k_descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
+                                                     int kld, int nfeat, float *desc, long long dstep /* floats */, const float *dw)
+{
+    __shared__ float P[21][21];
+    __shared__ float D[128];
+    const int f = blockIdx.x;
+    if (f >= nfeat) return;
+    Win w;
+    w.img = img; w.step = istep; w.rows = rows; w.cols = cols; w.cx = kp[f]; w.cy = kp[kld + f];
+    const float s = kp[4 * kld + f] * 1.2f / 9.0f;
+    const int win_size = (int)(21 * s);
+    w.off = -(win_size - 1.0f) / 2.0f;
+    float ddir = 360.0f - kp[5 * kld + f];
+    if (fabsf(ddir - 360.f) < FLT_EPSILON) ddir = 0.f;
+    ddir *= CV_PI_F / 180.0f;
+    sincosf(ddir, &w.s, &w.c);
+    for (int tid = threadIdx.x; tid < 441; tid += 256) {
+        const int xl = tid % 21, yl = tid / 21;
+        P[yl][xl] = s > 1 ? area_filter(w, (float)xl, (float)yl, s) : linear_filter(w, yl * s, xl * s);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tx = lane & 31, half = lane >> 5;
+    for (int rep = 0; rep < 2; ++rep) {
+        const int ty = rep * 8 + wv * 2 + half;    // sub-region 0..15 (threadIdx.y of the reference)
+        const int xb = ty % 4, yb = ty / 4;
+        float dx = 0.f, dy = 0.f;
+        const int xp = tx % 5, yp = tx / 5;
+        if (yp < 5) {
+            const int xi = xb * 5 + xp, yi = yb * 5 + yp;
+            const float wgt = dw[yi * 20 + xi];
+            dx = (P[yi][xi + 1] - P[yi][xi] + P[yi + 1][xi + 1] - P[yi + 1][xi]) * wgt;
+            dy = (P[yi + 1][xi] - P[yi][xi] + P[yi + 1][xi + 1] - P[yi][xi + 1]) * wgt;
+        }
+        if (!EXT) {
+            const float a = reduce32(dx), b = reduce32(dy), c = reduce32(fabsf(dx)), d = reduce32(fabsf(dy));
+            if (tx == 0) { D[ty * 4 + 0] = a; D[ty * 4 + 1] = b; D[ty * 4 + 2] = c; D[ty * 4 + 3] = d; }
+        } else {
+            const bool py = dy >= 0;
+            const float a = reduce32(py ? dx : 0.f), b = reduce32(py ? fabsf(dx) : 0.f), c = reduce32(py ? 0.f : dx), d = reduce32(py ? 0.f : fabsf(dx));
+            const bool pxp = dx >= 0;
+            const float e = reduce32(pxp ? dy : 0.f), g = reduce32(pxp ? fabsf(dy) : 0.f), h = reduce32(pxp ? 0.f : dy), k = reduce32(pxp ? 0.f : fabsf(dy));
+            if (tx == 0) {
+                D[ty * 8 + 0] = a; D[ty * 8 + 1] = b; D[ty * 8 + 2] = c; D[ty * 8 + 3] = d;
+                D[ty * 8 + 4] = e; D[ty * 8 + 5] = g; D[ty * 8 + 6] = h; D[ty * 8 + 7] = k;
+            }
+        }
+    }
+    __syncthreads();
+    // normalize_descriptors<N> (surf.cu:891-912): halving tree over the squares, val / sqrt(len)
+    constexpr int N = EXT ? 128 : 64;
+    __shared__ float sq[128];
+    if (threadIdx.x < N) sq[threadIdx.x] = D[threadIdx.x] * D[threadIdx.x];
+    __syncthreads();
+    for (int off = N / 2; off >= 1; off >>= 1) {
+        float v = 0.f;
+        if ((int)threadIdx.x < off) v = sq[threadIdx.x] + sq[threadIdx.x + off];
+        __syncthreads();
+        if ((int)threadIdx.x < off) sq[threadIdx.x] = v;
+        __syncthreads();
+    }
+    const float len = sqrtf(sq[0]);
+    if (threadIdx.x < N) desc[(long long)f * dstep + threadIdx.x] = D[threadIdx.x] / len;
+}
+
+// ------------------------------------------------------------------ host launchers
+int integral(const unsigned char *img, long long istep, int rows, int cols, bool clamp1, unsigned *V, unsigned *BT, int vld,
+             unsigned *sum, int sld, hipStream_t s)
+{
+    const int band_rows = 32, nbands = div_up(rows, band_rows);
+    hipLaunchKernelGGL(k_int_cols, dim3(div_up(cols, 256), nbands), dim3(256), 0, s, img, istep, rows, cols, clamp1 ? 1 : 0, V, vld, BT, band_rows);
+    hipLaunchKernelGGL(k_int_bands, dim3(div_up(cols, 256)), dim3(256), 0, s, BT, vld, cols, nbands);
+    hipLaunchKernelGGL(k_int_rows, dim3(div_up(rows + 1, 4)), dim3(256), 0, s, V, BT, vld, rows, cols, band_rows, sum, sld);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+int integral_bands(int rows) { return div_up(rows, 32); }
+
+int det_trace(const unsigned *sum, int sld, int rows, int cols, int octave, int nOctaveLayers, float *det, float *trace, int dld,
+              hipStream_t s)
+{
+    SumTex t = {sum, sld, rows, cols};
+    const int lr = rows >> octave, lc = cols >> octave;
+    hipLaunchKernelGGL(k_det_trace, dim3(div_up(lc, 64), div_up(lr, 4), nOctaveLayers + 2), dim3(256), 0, s, t, det, trace, dld, octave,
+                       nOctaveLayers + 2);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int find_maxima(const float *det, const float *trace, int dld, const unsigned *mask_sum, int sld, int rows, int cols, int octave,
+                int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, int4 *cand, int max_candidates,
+                unsigned *ncand, hipStream_t s)
+{
+    NmsArgs A;
+    A.det = det; A.trace = trace; A.dld = dld; A.rows = rows; A.cols = cols; A.octave = octave; A.nlayers = nOctaveLayers; A.thr = thr;
+    A.mask.s = mask_sum; A.mask.sld = sld; A.mask.rows = rows; A.mask.cols = cols;
+    A.bits = bits; A.rowcnt = rowcnt;
+    const int lr = rows >> octave, lc = cols >> octave;
+    A.chunks = div_up(lc, 64);
+    const int nrows = nOctaveLayers * lr;
+    hipLaunchKernelGGL(k_nms_flag, dim3(div_up(nrows, 4)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, rowcnt, nrows);
+    hipLaunchKernelGGL(k_nms_write, dim3(div_up(nrows, 4)), dim3(256), 0, s, A, cand, max_candidates, ncand);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, float *kp, int kld,
+                int max_features, unsigned *nfeat, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_interpolate, dim3(1), dim3(1024), 0, s, det, dld, rows, cols, octave, cand, ncand, kp, kld, max_features, nfeat);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int kld, const unsigned *nfeat_dev, int n_or_max,
+                bool upright, const float *apt, hipStream_t s)
+{
+    if (n_or_max <= 0) return MI_OK;
+    if (upright) {
+        hipLaunchKernelGGL(k_fill_angle, dim3(div_up(n_or_max, 256)), dim3(256), 0, s, kp, kld, nfeat_dev, n_or_max, 360.0f - 90.0f);
+    } else {
+        SumTex t = {sum, sld, rows, cols};
+        hipLaunchKernelGGL(k_orientation, dim3(div_up(n_or_max, 4)), dim3(256), 0, s, t, kp, kld, nfeat_dev, n_or_max, apt);
+    }
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp, int kld, int nfeat, bool extended,
+                float *desc, long long dstep_floats, const float *dw, hipStream_t s)
+{
+    if (nfeat <= 0) return MI_OK;
+    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(nfeat), dim3(256), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
+    else hipLaunchKernelGGL(k_descriptors<false>, dim3(nfeat), dim3(256), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int dbg_scan(const unsigned *in_dev, unsigned *out_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dbg_scan, dim3(1), dim3(64), 0, s, in_dev, out_dev);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace surf
+}  // namespace mi

@@ -363,13 +363,14 @@ static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
 #define TBV(T, PPL, WPS) {T, PPL, WPS, launch_tb<T, PPL, WPS>}
 // first entry of each T = default; the others are selectable with MIFLOW_TB_VARIANT="ppl,wps" (tuning sweeps)
 static const TbVariant g_variants[] = {
-    // defaults (first entry of each T): best of the r01b sweep (profiles/r01b/sweep_variants.jsonl), G px-iter/s:
-    //   T10 1px/lane 4 waves/SIMD 361 | T8 (1,4) 293 | T6 (1,5) 314 | T5 (2,3) 237 | T4 (2,4) 268 | T3 (1,8) 188
-    TBV(1, 2, 1), TBV(2, 2, 1), TBV(3, 1, 8), TBV(4, 2, 4), TBV(5, 2, 3), TBV(6, 1, 5), TBV(8, 1, 4), TBV(10, 1, 4),
+    // defaults (first entry of each T): best single-block timings of the r01b sweep (profiles/r01b/README.md),
+    // G px-iter/s at 1080p x 16:  T8 (1 px/lane, 4 waves/SIMD) 287 | T6 (1,5) 260 | T5 (2,3) 244 | T4 (2,1) 221 |
+    // T10 (1,4) 220 | T3 (2,4) 193 | T2 (1,8) 114
+    TBV(1, 2, 1), TBV(2, 1, 8), TBV(3, 2, 4), TBV(4, 2, 1), TBV(5, 2, 3), TBV(6, 1, 5), TBV(8, 1, 4), TBV(10, 1, 4),
     // alternatives, selectable with MIFLOW_TB_VARIANT="ppl,wps" (tuning sweeps)
-    TBV(3, 2, 1), TBV(4, 2, 1), TBV(5, 2, 1), TBV(6, 2, 1), TBV(8, 2, 1), TBV(10, 2, 1),
-    TBV(3, 2, 4), TBV(6, 2, 3),
-    TBV(2, 1, 8), TBV(4, 1, 8), TBV(5, 1, 8), TBV(5, 1, 6), TBV(6, 1, 6), TBV(8, 1, 5),
+    TBV(2, 2, 1), TBV(3, 2, 1), TBV(5, 2, 1), TBV(6, 2, 1), TBV(8, 2, 1), TBV(10, 2, 1),
+    TBV(4, 2, 4), TBV(6, 2, 3), TBV(3, 1, 8),
+    TBV(4, 1, 8), TBV(5, 1, 8), TBV(5, 1, 6), TBV(6, 1, 6), TBV(8, 1, 5),
     TBV(10, 1, 3), TBV(10, 1, 5), TBV(8, 1, 6), TBV(6, 1, 8),
 };
 
@@ -398,8 +399,18 @@ int tb_max_block() { return 10; }
 int tb_plan(int n, int cap, int *blocks, int max_blocks)
 {
     static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
-    static const double cost[11] = {0, 16.0, 9.04, 5.31, 3.73, 4.21, 3.19, 0, 3.42, 0, 2.77};
+    static const double cost[11] = {0, 16.9, 8.77, 5.18, 4.52, 4.10, 3.85, 0, 3.49, 0, 4.54};
     if (n <= 0) return 0;
+    if (getenv("MIFLOW_TB_FORCE")) {   // tuning sweeps: greedy blocks of exactly `cap` (then the largest that fit)
+        int k = 0;
+        for (int left = n; left > 0 && k < max_blocks;) {
+            int t = 1;
+            for (int c : sup) if (c <= left && c <= cap) t = c;
+            blocks[k++] = t;
+            left -= t;
+        }
+        return k;
+    }
     std::vector<double> best(n + 1, 1e300);
     std::vector<int> pick(n + 1, 1);
     best[0] = 0;

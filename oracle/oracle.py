@@ -45,6 +45,11 @@ class SBMParams(C.Structure):
                 ("uniqueness_ratio", C.c_int), ("emulate_edge", C.c_int)]
 
 
+class SURFParams(C.Structure):
+    _fields_ = [("hessian_threshold", C.c_double), ("n_octaves", C.c_int), ("n_octave_layers", C.c_int), ("extended", C.c_int),
+                ("keypoints_ratio", C.c_float), ("upright", C.c_int)]
+
+
 class FBParams(C.Structure):
     _fields_ = [("num_levels", C.c_int), ("pyr_scale", C.c_double), ("fast_pyramids", C.c_int), ("win_size", C.c_int),
                 ("num_iters", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
@@ -81,6 +86,7 @@ def lib():
         L.orc_tvl1_iteration.argtypes = [C.c_int] + [_f32p] * 4 + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 4
         _bind_stereobm(L)
         _bind_farneback(L)
+        _bind_surf(L)
     return _lib
 
 
@@ -93,6 +99,27 @@ def _bind_stereobm(L):
     L.orc_sbm_textureness.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_float, _u8p]
     L.orc_sbm_compute.restype = C.c_int
     L.orc_sbm_compute.argtypes = [C.POINTER(SBMParams), _u8p, _u8p, C.c_int, C.c_int, _u8p]
+
+
+def _bind_surf(L):
+    i, f = C.c_int, C.c_float
+    u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+    i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    L.orc_surf_default_params.argtypes = [C.POINTER(SURFParams)]
+    L.orc_surf_calc_size.restype = i
+    L.orc_surf_calc_size.argtypes = [i, i]
+    L.orc_surf_tables.argtypes = [_f32p] * 4
+    L.orc_surf_integral.argtypes = [_u8p, i, i, u32p]
+    L.orc_surf_det_trace.argtypes = [u32p, i, i, i, i, _f32p, _f32p]
+    L.orc_surf_find_maxima.restype = i
+    L.orc_surf_find_maxima.argtypes = [_f32p, _f32p, C.c_void_p, i, i, i, i, f, i, i32p]
+    L.orc_surf_interpolate.restype = i
+    L.orc_surf_interpolate.argtypes = [_f32p, i, i, i, i32p, _f32p]
+    L.orc_surf_orientation.restype = f
+    L.orc_surf_orientation.argtypes = [u32p, i, i, f, f, f, _f32p, _f32p, _f32p]
+    L.orc_surf_descriptor.argtypes = [_u8p, i, i, f, f, f, f, i, _f32p, _f32p]
+    L.orc_surf_detect_describe.restype = i
+    L.orc_surf_detect_describe.argtypes = [C.POINTER(SURFParams), _u8p, C.c_void_p, i, i, _f32p, i, C.c_void_p, i]
 
 
 def _bind_farneback(L):
@@ -431,3 +458,63 @@ def fb_calc(I0, I1, params: FBParams | None = None, init_flow=None):
     if rc:
         raise ValueError(f"orc_fb_calc failed: {rc}")
     return flow
+
+
+# ---------------------------------------------------------------- SURF (cv::cuda::SURF_CUDA semantics)
+def surf_params(**kw) -> SURFParams:
+    """SURF_CUDA::create defaults (cuda.hpp:117-118), overridden by kw."""
+    p = SURFParams()
+    lib().orc_surf_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown SURF parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+def surf_tables():
+    ax, ay, aw, dw = (np.empty(113, np.float32) for _ in range(3)), None, None, np.empty(400, np.float32)
+    ax, ay, aw = np.empty(113, np.float32), np.empty(113, np.float32), np.empty(113, np.float32)
+    lib().orc_surf_tables(ax, ay, aw, dw)
+    return ax, ay, aw, dw
+
+
+def surf_integral(img):
+    img = _u8(img)
+    s = np.empty((img.shape[0] + 1, img.shape[1] + 1), np.uint32)
+    lib().orc_surf_integral(img, img.shape[0], img.shape[1], s)
+    return s
+
+
+def surf_det_trace(sum_, octave, n_octave_layers=2):
+    sum_ = np.ascontiguousarray(sum_, np.uint32)
+    rows, cols = sum_.shape[0] - 1, sum_.shape[1] - 1
+    lr = rows >> octave
+    det = np.empty(((n_octave_layers + 2) * lr, cols), np.float32)
+    tr = np.empty_like(det)
+    lib().orc_surf_det_trace(sum_, rows, cols, octave, n_octave_layers, det, tr)
+    return det, tr
+
+
+def surf_detect_describe(img, params: SURFParams | None = None, mask=None, want_desc=True):
+    """-> dict(x, y, laplacian, octave, size, angle, hessian, descriptors) in the deterministic scan order."""
+    p = params or surf_params()
+    img = _u8(img)
+    rows, cols = img.shape
+    maxf = min(int(np.float32(rows * cols) * np.float32(p.keypoints_ratio)), 65535)
+    if maxf <= 0:
+        raise ValueError("maxFeatures <= 0")
+    kp = np.zeros((7, maxf), np.float32)
+    dsz = 128 if p.extended else 64
+    desc = np.zeros((maxf, dsz), np.float32) if want_desc else None
+    m = _u8(mask) if mask is not None else None
+    if m is not None and m.shape != img.shape:
+        raise ValueError("mask size mismatch")    # surf.cuda.cpp:140
+    n = lib().orc_surf_detect_describe(C.byref(p), img, m.ctypes.data if m is not None else None, rows, cols, kp.reshape(-1), maxf,
+                                       desc.ctypes.data if want_desc else None, int(want_desc))
+    if n < 0:
+        raise ValueError(f"orc_surf_detect_describe failed: {n}")
+    ki = kp.view(np.int32)
+    return {"n": n, "x": kp[0, :n].copy(), "y": kp[1, :n].copy(), "laplacian": ki[2, :n].copy(), "octave": ki[3, :n].copy(),
+            "size": kp[4, :n].copy(), "angle": kp[5, :n].copy(), "hessian": kp[6, :n].copy(),
+            "descriptors": desc[:n].copy() if want_desc else None}

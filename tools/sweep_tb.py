@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--tag", type=str, default="")
     ap.add_argument("--no-v1", action="store_true")
     args = ap.parse_args()
+    os.environ["MIFLOW_TB_FORCE"] = "1"   # time blocks of exactly T (no cost-model decomposition)
     import torch
     from opencv_contrib_amd import cuda
     from bench import make_inputs, level_pixels
