@@ -242,6 +242,50 @@ MI_API int mi_farneback_gaussian_blur(const mi_mat *src, mi_mat *dst, int ksize,
 /* Replaces: cv::cuda::pyrDown on CV_32FC1  cudawarping/src/pyramids.cpp:66-94 */
 MI_API int mi_pyr_down(const mi_mat *src, mi_mat *dst, void *stream);
 
+/* =========================================================================== SURF ===== */
+
+/* Public fields of cv::cuda::SURF_CUDA (xfeatures2d/cuda.hpp:182-189) */
+typedef struct mi_surf_params {
+    double hessian_threshold;
+    int n_octaves, n_octave_layers;
+    int extended;             /* 0: 64-float descriptors, 1: 128 */
+    float keypoints_ratio;    /* maxFeatures = min(int(area * ratio), 65535) */
+    int upright;
+} mi_surf_params;
+
+typedef struct mi_surf mi_surf;
+
+MI_API void mi_surf_default_params(mi_surf_params *p);
+/* Replaces: cv::cuda::SURF_CUDA::create / constructors, xfeatures2d/src/surf.cuda.cpp:257-285,444-448 */
+MI_API int mi_surf_create(const mi_surf_params *p, mi_surf **out);
+MI_API int mi_surf_set_params(mi_surf *h, const mi_surf_params *p);
+MI_API int mi_surf_get_params(const mi_surf *h, mi_surf_params *p);
+MI_API int mi_surf_descriptor_size(const mi_surf *h);                 /* SURF_CUDA::descriptorSize, surf.cuda.cpp:277-280 */
+/* maxFeatures of SURF_CUDA_Invoker (surf.cuda.cpp:153): the keypoint matrix must have at least this many columns */
+MI_API int mi_surf_max_features(const mi_surf *h, int rows, int cols, int *max_features);
+/* Replaces: SURF_CUDA::operator()(img, mask, keypoints) = SURF_CUDA_Invoker ctor + detectKeypoints,
+ * surf.cuda.cpp:137-215,369-378.  img: MI_8UC1; mask: MI_8UC1 of the same size or NULL; keypoints: MI_32FC1 with
+ * ROWS_COUNT = 7 rows {X, Y, LAPLACIAN(int bits), OCTAVE(int bits), SIZE, ANGLE, HESSIAN} (cuda.hpp:89-99) and
+ * >= max_features columns.  Features come out in a deterministic order (octave, layer, row, column).
+ * Synchronises `stream` once to return the count (the reference's keypoints.cols = featureCounter). */
+MI_API int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, int *n_features, void *stream);
+/* Replaces: SURF_CUDA_Invoker::findOrientation for provided keypoints, surf.cuda.cpp:217-225,391-393 */
+MI_API int mi_surf_compute_orientation(mi_surf *h, const mi_mat *img, mi_mat *keypoints, int n_features, void *stream);
+/* Replaces: SURF_CUDA_Invoker::computeDescriptors, surf.cuda.cpp:227-236 (+ normalize_descriptors).
+ * descriptors: MI_32FC1, n_features x descriptorSize(). */
+MI_API int mi_surf_compute_descriptors(mi_surf *h, const mi_mat *img, const mi_mat *keypoints, int n_features, mi_mat *descriptors,
+                                       void *stream);
+MI_API void mi_surf_release_memory(mi_surf *h);                       /* SURF_CUDA::releaseMemory */
+MI_API void mi_surf_destroy(mi_surf *h);
+/* Stage level.  Replaces: cv::cuda::integral (CV_8UC1 -> CV_32SC1 (rows+1)x(cols+1)), cudaarithm/src/cuda/integral.cu:62-83;
+ * clamp_to_one applies cuda::min(mask, 1.0) first (surf.cuda.cpp:167). */
+MI_API int mi_surf_integral(mi_surf *h, const mi_mat *img, int clamp_to_one, mi_mat *sum, void *stream);
+/* Replaces: icvCalcLayerDetAndTrace_gpu, xfeatures2d/src/cuda/surf.cu:205-222; det/trace: MI_32FC1,
+ * ((n_octave_layers+2) * (rows >> octave)) x cols, same step */
+MI_API int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_layers, mi_mat *det, mi_mat *trace, void *stream);
+/* Hardware self-test hook: out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan) */
+MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
+
 /* Hardware self-test hook: out_host[0..63] = value received from lane n-1, out_host[64..127] = from
  * lane n+1 when every lane n contributes n+100 (DPP wave shifts used by the blocked kernels). */
 MI_API int mi_dbg_lane_shift(int *out_host /*[128]*/);

@@ -38,6 +38,11 @@ class TVL1Params(C.Structure):
                 ("time_block", C.c_int)]
 
 
+class SURFParams(C.Structure):
+    _fields_ = [("hessian_threshold", C.c_double), ("n_octaves", C.c_int), ("n_octave_layers", C.c_int), ("extended", C.c_int),
+                ("keypoints_ratio", C.c_float), ("upright", C.c_int)]
+
+
 class FarnebackParams(C.Structure):
     _fields_ = [("num_levels", C.c_int), ("pyr_scale", C.c_double), ("fast_pyramids", C.c_int), ("win_size", C.c_int),
                 ("num_iters", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
@@ -122,6 +127,20 @@ def lib():
         "mi_farneback_iterate": (i, [PM, PM, PM, PM, PM, PM, i, i, i, vp]),
         "mi_farneback_gaussian_blur": (i, [PM, PM, i, d, i, vp]),
         "mi_pyr_down": (i, [PM, PM, vp]),
+        "mi_surf_default_params": (None, [C.POINTER(SURFParams)]),
+        "mi_surf_create": (i, [C.POINTER(SURFParams), C.POINTER(vp)]),
+        "mi_surf_set_params": (i, [vp, C.POINTER(SURFParams)]),
+        "mi_surf_get_params": (i, [vp, C.POINTER(SURFParams)]),
+        "mi_surf_descriptor_size": (i, [vp]),
+        "mi_surf_max_features": (i, [vp, i, i, C.POINTER(i)]),
+        "mi_surf_detect": (i, [vp, PM, PM, PM, C.POINTER(i), vp]),
+        "mi_surf_compute_orientation": (i, [vp, PM, PM, i, vp]),
+        "mi_surf_compute_descriptors": (i, [vp, PM, PM, i, PM, vp]),
+        "mi_surf_release_memory": (None, [vp]),
+        "mi_surf_destroy": (None, [vp]),
+        "mi_surf_integral": (i, [vp, PM, i, PM, vp]),
+        "mi_surf_det_trace": (i, [vp, PM, i, i, PM, PM, vp]),
+        "mi_dbg_wave_scan": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -1,0 +1,274 @@
+// cv::cuda::SURF_CUDA: handle + C-ABI entry points.  Host-side twin of SURF_CUDA_Invoker
+// (modules/xfeatures2d/src/surf.cuda.cpp:134-255): validation, integral(s), octave loop, orientation, descriptors.
+// One stream, no host round trip inside the octave loop; the only synchronisation is the final read-back of the
+// feature count (the reference's keypoints.cols = featureCounter, :205-209).
+#include "surf_dev.h"
+#include <cmath>
+#include <vector>
+
+using namespace mi;
+
+struct mi_surf {
+    mi_surf_params P;
+    // tables (surf.cpp:544-565 generators; see oracle/surf_ref.c for the correspondence with surf.cu:520-522,685-707)
+    float *apt = nullptr, *dw = nullptr;
+    // scratch sized for (rows, cols, layers)
+    int capR = 0, capC = 0, capL = 0, capCand = 0;
+    unsigned *sum = nullptr, *msum = nullptr, *V = nullptr, *BT = nullptr;
+    float *det = nullptr, *trace = nullptr;
+    unsigned long long *bits = nullptr;
+    unsigned *rowcnt = nullptr;
+    int4 *cand = nullptr;
+    unsigned *counters = nullptr;   // [0] = features, [1 + octave] = candidates of the octave (surf.cuda.cpp:158-159)
+    int sld = 0, vld = 0, dld = 0;
+};
+
+static int calc_size(int octave, int layer) { return (9 + 6 * layer) << octave; }
+
+static void gauss(int n, double sigma, float *k)   // cv::getGaussianKernel(n, sigma > 0, CV_32F)
+{
+    const double scale2 = -0.5 / (sigma * sigma);
+    std::vector<double> w(n);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = std::exp(scale2 * x * x); sum += w[i]; }
+    for (int i = 0; i < n; ++i) k[i] = (float)(w[i] / sum);
+}
+
+extern "C" {
+
+void mi_surf_default_params(mi_surf_params *p)
+{
+    if (!p) return;
+    // SURF_CUDA::create(thr, nOctaves=4, nOctaveLayers=2, extended=false, keypointsRatio=0.01f, upright=false), cuda.hpp:117-118
+    p->hessian_threshold = 100; p->n_octaves = 4; p->n_octave_layers = 2; p->extended = 0; p->keypoints_ratio = 0.01f; p->upright = 0;
+}
+
+int mi_surf_create(const mi_surf_params *p, mi_surf **out)
+{
+    MI_REQUIRE(out, MI_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        set_error("no HIP device available: the miflow product path has no CPU fallback");
+        return MI_ERR_NO_DEVICE;
+    }
+    mi_surf *h = new mi_surf();
+    if (p) h->P = *p; else mi_surf_default_params(&h->P);
+    // orientation samples: disc of radius 6, weights = outer product of getGaussianKernel(13, 2.5) (surf.cpp:544-556);
+    // descriptor weights: outer product of getGaussianKernel(20, 3.3) (surf.cpp:560-565)
+    float g[13], G[20], apt[3 * 113], dw[400];
+    gauss(13, 2.5, g);
+    int k = 0;
+    for (int i = -6; i <= 6; i++)
+        for (int j = -6; j <= 6; j++)
+            if (i * i + j * j <= 36) { apt[k] = (float)i; apt[113 + k] = (float)j; apt[226 + k] = g[i + 6] * g[j + 6]; ++k; }
+    gauss(20, 3.3, G);
+    for (int i = 0; i < 20; i++) for (int j = 0; j < 20; j++) dw[i * 20 + j] = G[i] * G[j];
+    MI_HIP_TRY(hipMalloc((void **)&h->apt, sizeof(apt)));
+    MI_HIP_TRY(hipMalloc((void **)&h->dw, sizeof(dw)));
+    MI_HIP_TRY(hipMemcpy(h->apt, apt, sizeof(apt), hipMemcpyHostToDevice));
+    MI_HIP_TRY(hipMemcpy(h->dw, dw, sizeof(dw), hipMemcpyHostToDevice));
+    MI_HIP_TRY(hipMalloc((void **)&h->counters, sizeof(unsigned) * 64));
+    *out = h;
+    return MI_OK;
+}
+
+int mi_surf_set_params(mi_surf *h, const mi_surf_params *p) { MI_REQUIRE(h && p, MI_ERR_BAD_ARG, "null argument"); h->P = *p; return MI_OK; }
+int mi_surf_get_params(const mi_surf *h, mi_surf_params *p) { MI_REQUIRE(h && p, MI_ERR_BAD_ARG, "null argument"); *p = h->P; return MI_OK; }
+
+static void free_scratch(mi_surf *h)
+{
+    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->rowcnt, h->cand};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->rowcnt = nullptr; h->cand = nullptr;
+    h->capR = h->capC = h->capL = h->capCand = 0;
+}
+
+void mi_surf_release_memory(mi_surf *h) { if (h) free_scratch(h); }   // SURF_CUDA::releaseMemory, surf.cuda.cpp:434-442
+
+void mi_surf_destroy(mi_surf *h)
+{
+    if (!h) return;
+    free_scratch(h);
+    if (h->apt) (void)hipFree(h->apt);
+    if (h->dw) (void)hipFree(h->dw);
+    if (h->counters) (void)hipFree(h->counters);
+    delete h;
+}
+
+int mi_surf_descriptor_size(const mi_surf *h) { return h && h->P.extended ? 128 : 64; }   // surf.cuda.cpp:277-280
+
+// limits of SURF_CUDA_Invoker's constructor, surf.cuda.cpp:137-156
+static int limits(const mi_surf_params &P, int rows, int cols, int *maxFeatures, int *maxCandidates)
+{
+    MI_REQUIRE(P.n_octaves > 0 && P.n_octave_layers > 0, MI_ERR_BAD_ARG, "nOctaves and nOctaveLayers must be > 0");          // :141
+    MI_REQUIRE(P.n_octaves <= 16 && P.n_octave_layers <= 16, MI_ERR_BAD_ARG, "nOctaves / nOctaveLayers too large");
+    const int min_size = calc_size(P.n_octaves - 1, 0);
+    MI_REQUIRE(rows - min_size >= 0 && cols - min_size >= 0, MI_ERR_BAD_SIZE, "image too small for nOctaves");               // :144-145
+    const int lr = rows >> (P.n_octaves - 1), lc = cols >> (P.n_octaves - 1);
+    const int min_margin = ((calc_size(P.n_octaves - 1, 2) >> 1) >> (P.n_octaves - 1)) + 1;
+    MI_REQUIRE(lr - 2 * min_margin > 0 && lc - 2 * min_margin > 0, MI_ERR_BAD_SIZE, "image too small for nOctaves");         // :150-151
+    int mf = (int)((float)(rows * cols) * P.keypoints_ratio);                                                               // :153
+    if (mf > 65535) mf = 65535;
+    int mc = (int)(1.5 * mf);
+    if (mc > 65535) mc = 65535;
+    MI_REQUIRE(mf > 0, MI_ERR_BAD_ARG, "maxFeatures <= 0 (keypointsRatio too small)");                                        // :156
+    *maxFeatures = mf; *maxCandidates = mc;
+    return MI_OK;
+}
+
+int mi_surf_max_features(const mi_surf *h, int rows, int cols, int *max_features)
+{
+    MI_REQUIRE(h && max_features, MI_ERR_BAD_ARG, "null argument");
+    int mc;
+    return limits(h->P, rows, cols, max_features, &mc);
+}
+
+static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool need_mask)
+{
+    if (!(h->capR == rows && h->capC == cols && h->capL >= layers && h->capCand >= maxCand)) {
+        free_scratch(h);
+        h->sld = align_up(cols + 1, 64); h->vld = align_up(cols, 64); h->dld = align_up(cols, 64);
+        MI_HIP_TRY(hipMalloc((void **)&h->sum, sizeof(unsigned) * (size_t)h->sld * (rows + 1)));
+        MI_HIP_TRY(hipMalloc((void **)&h->V, sizeof(unsigned) * (size_t)h->vld * rows));
+        MI_HIP_TRY(hipMalloc((void **)&h->BT, sizeof(unsigned) * (size_t)h->vld * surf::integral_bands(rows)));
+        MI_HIP_TRY(hipMalloc((void **)&h->det, sizeof(float) * (size_t)h->dld * rows * (layers + 2)));
+        MI_HIP_TRY(hipMalloc((void **)&h->trace, sizeof(float) * (size_t)h->dld * rows * (layers + 2)));
+        MI_HIP_TRY(hipMalloc((void **)&h->bits, sizeof(unsigned long long) * (size_t)layers * rows * div_up(cols, 64)));
+        MI_HIP_TRY(hipMalloc((void **)&h->rowcnt, sizeof(unsigned) * ((size_t)layers * rows + 1)));
+        MI_HIP_TRY(hipMalloc((void **)&h->cand, sizeof(int4) * (size_t)maxCand));
+        h->capR = rows; h->capC = cols; h->capL = layers; h->capCand = maxCand;
+    }
+    if (need_mask && !h->msum) MI_HIP_TRY(hipMalloc((void **)&h->msum, sizeof(unsigned) * (size_t)h->sld * (rows + 1)));
+    return MI_OK;
+}
+
+static int check_img(const mi_mat *m, const char *name)
+{
+    MI_REQUIRE(m && m->data, MI_ERR_BAD_ARG, "%s: empty", name);
+    MI_REQUIRE(m->type == MI_8UC1, MI_ERR_BAD_TYPE, "%s: must be CV_8UC1", name);   // surf.cuda.cpp:139
+    MI_REQUIRE(m->rows > 0 && m->cols > 0 && m->step >= (size_t)m->cols, MI_ERR_BAD_ARG, "%s: bad size/step", name);
+    return MI_OK;
+}
+static int check_kp(const mi_mat *kp, int min_cols)
+{
+    MI_REQUIRE(kp && kp->data && kp->type == MI_32FC1 && kp->rows == 7 && kp->cols >= min_cols && kp->step % 4 == 0 &&
+               kp->step >= (size_t)kp->cols * 4, MI_ERR_BAD_ARG, "keypoints must be CV_32FC1 with ROWS_COUNT = 7 rows and enough columns");
+    return MI_OK;
+}
+
+int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, int *n_features, void *stream)
+{
+    MI_REQUIRE(h && n_features, MI_ERR_BAD_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const mi_surf_params &P = h->P;
+    int rc;
+    if ((rc = check_img(img, "img"))) return rc;
+    const bool use_mask = mask && mask->data;
+    if (use_mask) {
+        if ((rc = check_img(mask, "mask"))) return rc;
+        MI_REQUIRE(mask->rows == img->rows && mask->cols == img->cols, MI_ERR_BAD_SIZE, "mask.size() != img.size()");   // :140
+    }
+    const int rows = img->rows, cols = img->cols;
+    int maxF, maxC;
+    if ((rc = limits(P, rows, cols, &maxF, &maxC))) return rc;
+    if ((rc = check_kp(keypoints, maxF))) return rc;
+    if ((rc = ensure(h, rows, cols, P.n_octave_layers, maxC, use_mask))) return rc;
+    const int kld = (int)(keypoints->step / 4);
+    float *kp = (float *)keypoints->data;
+
+    MI_HIP_TRY(hipMemsetAsync(h->counters, 0, sizeof(unsigned) * 64, st));                                           // :158-159
+    if ((rc = surf::integral((const unsigned char *)img->data, (long long)img->step, rows, cols, false, h->V, h->BT, h->vld, h->sum, h->sld, st))) return rc;   // :163
+    if (use_mask && (rc = surf::integral((const unsigned char *)mask->data, (long long)mask->step, rows, cols, true, h->V, h->BT, h->vld, h->msum, h->sld, st)))
+        return rc;                                                                                                    // :165-169
+    MI_HIP_TRY(hipMemset2DAsync(kp, keypoints->step, 0, (size_t)maxF * 4, 7, st));                                   // keypoints.setTo(0) :180
+    for (int octave = 0; octave < P.n_octaves; ++octave) {                                                           // :182-204
+        if ((rc = surf::det_trace(h->sum, h->sld, rows, cols, octave, P.n_octave_layers, h->det, h->trace, h->dld, st))) return rc;
+        if ((rc = surf::find_maxima(h->det, h->trace, h->dld, use_mask ? h->msum : nullptr, h->sld, rows, cols, octave, P.n_octave_layers,
+                                    (float)P.hessian_threshold, h->bits, h->rowcnt, h->cand, maxC, h->counters + 1 + octave, st))) return rc;
+        if ((rc = surf::interpolate(h->det, h->dld, rows, cols, octave, h->cand, h->counters + 1 + octave, kp, kld, maxF, h->counters, st))) return rc;
+    }
+    if ((rc = surf::orientation(h->sum, h->sld, rows, cols, kp, kld, h->counters, maxF, P.upright != 0, h->apt, st))) return rc;   // :211-214
+    unsigned nf = 0;
+    MI_HIP_TRY(hipMemcpyAsync(&nf, h->counters, sizeof(unsigned), hipMemcpyDeviceToHost, st));                       // :205-207
+    MI_HIP_TRY(hipStreamSynchronize(st));
+    *n_features = (int)(nf < (unsigned)maxF ? nf : (unsigned)maxF);
+    return MI_OK;
+}
+
+int mi_surf_compute_orientation(mi_surf *h, const mi_mat *img, mi_mat *keypoints, int n_features, void *stream)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = check_img(img, "img")) || (rc = check_kp(keypoints, n_features))) return rc;
+    if (n_features <= 0) return MI_OK;
+    const int rows = img->rows, cols = img->cols;
+    int maxF, maxC;
+    if ((rc = limits(h->P, rows, cols, &maxF, &maxC))) return rc;
+    if ((rc = ensure(h, rows, cols, h->P.n_octave_layers, maxC, false))) return rc;
+    if ((rc = surf::integral((const unsigned char *)img->data, (long long)img->step, rows, cols, false, h->V, h->BT, h->vld, h->sum, h->sld, st))) return rc;
+    return surf::orientation(h->sum, h->sld, rows, cols, (float *)keypoints->data, (int)(keypoints->step / 4), nullptr, n_features,
+                             h->P.upright != 0, h->apt, st);
+}
+
+int mi_surf_compute_descriptors(mi_surf *h, const mi_mat *img, const mi_mat *keypoints, int n_features, mi_mat *descriptors, void *stream)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    int rc;
+    if ((rc = check_img(img, "img")) || (rc = check_kp(keypoints, n_features))) return rc;
+    if (n_features <= 0) return MI_OK;
+    const int dsz = h->P.extended ? 128 : 64;
+    MI_REQUIRE(descriptors && descriptors->data && descriptors->type == MI_32FC1 && descriptors->rows >= n_features && descriptors->cols == dsz &&
+               descriptors->step % 4 == 0, MI_ERR_BAD_ARG, "descriptors must be CV_32FC1, nFeatures x descriptorSize()");   // :232
+    return surf::descriptors((const unsigned char *)img->data, (long long)img->step, img->rows, img->cols, (const float *)keypoints->data,
+                             (int)(keypoints->step / 4), n_features, h->P.extended != 0, (float *)descriptors->data,
+                             (long long)(descriptors->step / 4), h->dw, (hipStream_t)stream);
+}
+
+// ---- stage-level entry points (parity tests)
+int mi_surf_integral(mi_surf *h, const mi_mat *img, int clamp_to_one, mi_mat *sum, void *stream)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = check_img(img, "img"))) return rc;
+    MI_REQUIRE(sum && sum->data && sum->type == MI_32SC1 && sum->rows == img->rows + 1 && sum->cols == img->cols + 1 && sum->step % 4 == 0,
+               MI_ERR_BAD_ARG, "sum must be CV_32SC1 (rows+1) x (cols+1)");   // cuda::integral, cudaarithm/src/cuda/integral.cu:62-83
+    const int vld = align_up(img->cols, 64);
+    unsigned *V = nullptr, *BT = nullptr;
+    MI_HIP_TRY(hipMalloc((void **)&V, sizeof(unsigned) * (size_t)vld * img->rows));
+    MI_HIP_TRY(hipMalloc((void **)&BT, sizeof(unsigned) * (size_t)vld * surf::integral_bands(img->rows)));
+    rc = surf::integral((const unsigned char *)img->data, (long long)img->step, img->rows, img->cols, clamp_to_one != 0, V, BT, vld,
+                        (unsigned *)sum->data, (int)(sum->step / 4), st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(V); (void)hipFree(BT);
+    return rc;
+}
+
+int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_layers, mi_mat *det, mi_mat *trace, void *stream)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    MI_REQUIRE(sum && sum->data && sum->type == MI_32SC1 && sum->step % 4 == 0 && sum->rows > 1 && sum->cols > 1, MI_ERR_BAD_ARG, "bad sum");
+    const int rows = sum->rows - 1, cols = sum->cols - 1, lr = rows >> octave;
+    MI_REQUIRE(octave >= 0 && octave < 16 && n_octave_layers > 0 && lr > 0, MI_ERR_BAD_ARG, "bad octave / layers");
+    MI_REQUIRE(det && trace && det->data && trace->data && det->type == MI_32FC1 && trace->type == MI_32FC1 &&
+               det->rows == (n_octave_layers + 2) * lr && trace->rows == det->rows && det->cols == cols && trace->cols == cols &&
+               det->step == trace->step && det->step % 4 == 0, MI_ERR_BAD_ARG, "det/trace must be CV_32FC1 ((layers+2)*layer_rows) x cols, same step");
+    return surf::det_trace((const unsigned *)sum->data, (int)(sum->step / 4), rows, cols, octave, n_octave_layers, (float *)det->data,
+                           (float *)trace->data, (int)(det->step / 4), (hipStream_t)stream);
+}
+
+int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host)
+{
+    MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
+    unsigned *d = nullptr;
+    MI_HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned) * 128));
+    MI_HIP_TRY(hipMemcpy(d, in_host, sizeof(unsigned) * 64, hipMemcpyHostToDevice));
+    int rc = surf::dbg_scan(d, d + 64, nullptr);
+    if (!rc) { MI_HIP_TRY(hipDeviceSynchronize()); MI_HIP_TRY(hipMemcpy(out_host, d + 64, sizeof(unsigned) * 64, hipMemcpyDeviceToHost)); }
+    (void)hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

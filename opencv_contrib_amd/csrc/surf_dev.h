@@ -1,0 +1,28 @@
+// Internal launch API of the SURF HIP kernels (surf_kernels.hip).  Not part of the C-ABI.
+#pragma once
+#include "mi_common.h"
+
+namespace mi {
+namespace surf {
+
+// integral image of a CV_8UC1 image into sum ((rows+1) x sld u32); V: rows x vld scratch, BT: integral_bands(rows) x vld scratch
+int integral(const unsigned char *img, long long istep, int rows, int cols, bool clamp1, unsigned *V, unsigned *BT, int vld,
+             unsigned *sum, int sld, hipStream_t s);
+int integral_bands(int rows);
+int det_trace(const unsigned *sum, int sld, int rows, int cols, int octave, int nOctaveLayers, float *det, float *trace, int dld,
+              hipStream_t s);
+// bits: nOctaveLayers*layer_rows*ceil(layer_cols/64) u64; rowcnt: nOctaveLayers*layer_rows + 1 u32
+int find_maxima(const float *det, const float *trace, int dld, const unsigned *mask_sum, int sld, int rows, int cols, int octave,
+                int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, int4 *cand, int max_candidates,
+                unsigned *ncand, hipStream_t s);
+int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, float *kp, int kld,
+                int max_features, unsigned *nfeat, hipStream_t s);
+// nfeat_dev != nullptr: count read on the device (grid sized for n_or_max); else n_or_max features
+int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int kld, const unsigned *nfeat_dev, int n_or_max,
+                bool upright, const float *apt /* [3][113] x, y, w */, hipStream_t s);
+int descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp, int kld, int nfeat, bool extended,
+                float *desc, long long dstep_floats, const float *dw /* [400] */, hipStream_t s);
+int dbg_scan(const unsigned *in_dev, unsigned *out_dev, hipStream_t s);
+
+}  // namespace surf
+}  // namespace mi

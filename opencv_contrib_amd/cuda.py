@@ -410,3 +410,108 @@ def pyrDown(src):
     dst = torch.empty(((src.shape[0] + 1) // 2, (src.shape[1] + 1) // 2), dtype=torch.float32, device=src.device)
     capi.check(capi.lib().mi_pyr_down(C.byref(_m(src)), C.byref(_m(dst)), capi.current_stream_ptr()))
     return dst
+
+
+# =============================================================================================
+class SURF_CUDA:
+    """cv::cuda::SURF_CUDA (xfeatures2d/cuda.hpp:86-196).  Keypoints live in a 7 x N CV_32FC1 device matrix
+    (rows X, Y, LAPLACIAN, OCTAVE, SIZE, ANGLE, HESSIAN; LAPLACIAN/OCTAVE hold int bit patterns)."""
+
+    X_ROW, Y_ROW, LAPLACIAN_ROW, OCTAVE_ROW, SIZE_ROW, ANGLE_ROW, HESSIAN_ROW, ROWS_COUNT = range(8)
+
+    def __init__(self, _hessianThreshold=100.0, _nOctaves=4, _nOctaveLayers=2, _extended=True, _keypointsRatio=0.01,
+                 _upright=False):
+        # defaults of the default constructor (surf.cuda.cpp:257-265): extended = true
+        p = capi.SURFParams()
+        p.hessian_threshold, p.n_octaves, p.n_octave_layers = _hessianThreshold, _nOctaves, _nOctaveLayers
+        p.extended, p.keypoints_ratio, p.upright = int(bool(_extended)), _keypointsRatio, int(bool(_upright))
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_surf_create(C.byref(p), C.byref(self._h)))
+        self._p = p
+
+    @staticmethod
+    def create(_hessianThreshold, _nOctaves=4, _nOctaveLayers=2, _extended=False, _keypointsRatio=0.01, _upright=False):
+        """cuda.hpp:117-118 (extended defaults to false here)."""
+        return SURF_CUDA(_hessianThreshold, _nOctaves, _nOctaveLayers, _extended, _keypointsRatio, _upright)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                capi.lib().mi_surf_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _sync(self):
+        capi.check(capi.lib().mi_surf_set_params(self._h, C.byref(self._p)))
+
+    # public fields of the reference class
+    hessianThreshold = property(lambda s: s._p.hessian_threshold, lambda s, v: (setattr(s._p, "hessian_threshold", v), s._sync()))
+    nOctaves = property(lambda s: s._p.n_octaves, lambda s, v: (setattr(s._p, "n_octaves", v), s._sync()))
+    nOctaveLayers = property(lambda s: s._p.n_octave_layers, lambda s, v: (setattr(s._p, "n_octave_layers", v), s._sync()))
+    extended = property(lambda s: bool(s._p.extended), lambda s, v: (setattr(s._p, "extended", int(bool(v))), s._sync()))
+    upright = property(lambda s: bool(s._p.upright), lambda s, v: (setattr(s._p, "upright", int(bool(v))), s._sync()))
+    keypointsRatio = property(lambda s: s._p.keypoints_ratio, lambda s, v: (setattr(s._p, "keypoints_ratio", v), s._sync()))
+
+    def descriptorSize(self): return 128 if self._p.extended else 64   # surf.cuda.cpp:277-280
+    def defaultNorm(self): return 4                                    # NORM_L2, surf.cuda.cpp:282-285
+    def releaseMemory(self): capi.lib().mi_surf_release_memory(self._h)
+
+    def detect(self, img, mask=None, stream=None):
+        """operator()(img, mask, keypoints) -> keypoints (7, nFeatures) float32 device tensor."""
+        import torch
+        mf = C.c_int()
+        capi.check(capi.lib().mi_surf_max_features(self._h, img.shape[0], img.shape[1], C.byref(mf)))
+        kp = torch.empty((7, mf.value), dtype=torch.float32, device=img.device)   # ensureSizeIsEnough(ROWS_COUNT, maxFeatures)
+        n = C.c_int()
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        mm = C.byref(capi.mat_from_tensor(mask)) if mask is not None else None
+        mk = capi.mat_from_tensor(kp)
+        capi.check(capi.lib().mi_surf_detect(self._h, C.byref(capi.mat_from_tensor(img)), mm, C.byref(mk), C.byref(n), sp))
+        return kp[:, : n.value]   # keypoints.cols = featureCounter (surf.cuda.cpp:209)
+
+    def detectWithDescriptors(self, img, mask=None, keypoints=None, useProvidedKeypoints=False, stream=None):
+        """operator()(img, mask, keypoints, descriptors, useProvidedKeypoints) (surf.cuda.cpp:380-397)."""
+        import torch
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        if not useProvidedKeypoints:
+            keypoints = self.detect(img, mask, stream)
+        elif not self._p.upright:
+            capi.check(capi.lib().mi_surf_compute_orientation(self._h, C.byref(capi.mat_from_tensor(img)),
+                                                              C.byref(capi.mat_from_tensor(keypoints)), keypoints.shape[1], sp))
+        n = keypoints.shape[1]
+        desc = torch.empty((n, self.descriptorSize()), dtype=torch.float32, device=img.device)
+        if n:
+            capi.check(capi.lib().mi_surf_compute_descriptors(self._h, C.byref(capi.mat_from_tensor(img)),
+                                                              C.byref(capi.mat_from_tensor(keypoints)), n,
+                                                              C.byref(capi.mat_from_tensor(desc)), sp))
+        return keypoints, desc
+
+    @staticmethod
+    def downloadKeypoints(keypointsGPU):
+        """-> dict of host arrays (the fields of cv::KeyPoint the reference fills, surf.cuda.cpp:319-356)."""
+        import numpy as np
+        k = keypointsGPU.detach().cpu().numpy()
+        ki = k.view(np.int32)
+        return {"x": k[0].copy(), "y": k[1].copy(), "laplacian": ki[2].copy(), "octave": ki[3].copy(), "size": k[4].copy(),
+                "angle": k[5].copy(), "hessian": k[6].copy()}
+
+
+def surf_integral(img, clamp_to_one=False):
+    import torch
+    alg = SURF_CUDA(100)
+    s = torch.empty((img.shape[0] + 1, img.shape[1] + 1), dtype=torch.int32, device=img.device)
+    capi.check(capi.lib().mi_surf_integral(alg._h, C.byref(_m(img)), int(bool(clamp_to_one)), C.byref(_m(s)), capi.current_stream_ptr()))
+    return s
+
+
+def surf_detTrace(sum_, octave, nOctaveLayers=2):
+    import torch
+    alg = SURF_CUDA(100)
+    rows, cols = sum_.shape[0] - 1, sum_.shape[1] - 1
+    det = torch.empty(((nOctaveLayers + 2) * (rows >> octave), cols), dtype=torch.float32, device=sum_.device)
+    tr = torch.empty_like(det)
+    capi.check(capi.lib().mi_surf_det_trace(alg._h, C.byref(_m(sum_)), octave, nOctaveLayers, C.byref(_m(det)), C.byref(_m(tr)),
+                                            capi.current_stream_ptr()))
+    torch.cuda.synchronize()
+    return det, tr

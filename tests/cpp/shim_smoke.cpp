@@ -6,6 +6,7 @@
 #include <vector>
 #include "opencv2/cudaoptflow.hpp"
 #include "opencv2/cudastereo.hpp"
+#include "opencv2/xfeatures2d/cuda.hpp"
 
 int main(int argc, char **argv)
 {
@@ -19,6 +20,8 @@ int main(int argc, char **argv)
         Ptr<cuda::FarnebackOpticalFlow> fb = cuda::FarnebackOpticalFlow::create();
         if (fb->getWinSize() != 13 || fb->getDefaultName() != "DenseOpticalFlow.FarnebackOpticalFlow") return 2;
         fb->setNumLevels(3);
+        cuda::SURF_CUDA surf(300, 3, 2, false, 0.05f);
+        if (surf.descriptorSize() != 64 || surf.defaultNorm() != NORM_L2 || cuda::SURF_CUDA().descriptorSize() != 128) return 2;
         if (argc < 3) return 0;
         FILE *f = fopen(argv[1], "rb");
         if (!f) return 4;
@@ -48,6 +51,14 @@ int main(int argc, char **argv)
         fwrite(hd.data(), 1, hd.size(), o);
         fbflow.download(hf.data(), (size_t)w * 8);
         fwrite(hf.data(), 4, hf.size(), o);
+        std::vector<KeyPoint> kps;
+        std::vector<float> desc;
+        surf(d0, cuda::GpuMat(), kps, desc);
+        const int nk = (int)kps.size();
+        fwrite(&nk, 4, 1, o);
+        for (const KeyPoint &k : kps) { float r[5] = {k.pt.x, k.pt.y, k.size, k.angle, k.response}; fwrite(r, 4, 5, o); }
+        fwrite(desc.data(), 4, desc.size(), o);
+        if (desc.size() != (size_t)nk * 64) return 7;
         fclose(o);
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;

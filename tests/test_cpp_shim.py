@@ -64,10 +64,19 @@ def test_shim_matches_python_mirror_on_gpu(gpu, tmp_path):
     raw = open(fout, "rb").read()
     flow = np.frombuffer(raw[: 96 * 160 * 8], np.float32).reshape(96, 160, 2)
     disp = np.frombuffer(raw[96 * 160 * 8: 96 * 160 * 9], np.uint8).reshape(96, 160)
-    fbflow = np.frombuffer(raw[96 * 160 * 9:], np.float32).reshape(96, 160, 2)
+    fbflow = np.frombuffer(raw[96 * 160 * 9: 96 * 160 * 17], np.float32).reshape(96, 160, 2)
+    rest = raw[96 * 160 * 17:]
+    nk = struct.unpack("i", rest[:4])[0]
+    kps = np.frombuffer(rest[4: 4 + nk * 20], np.float32).reshape(nk, 5)
+    sdesc = np.frombuffer(rest[4 + nk * 20:], np.float32).reshape(nk, 64)
     tl, tr = torch.from_numpy(left).to(gpu), torch.from_numpy(right).to(gpu)
     pf = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0).calc(tl, tr).cpu().numpy()
     pd = cuda.createStereoBM(32, 9).compute(tl, tr).cpu().numpy()
     np.testing.assert_array_equal(flow, pf)
     np.testing.assert_array_equal(disp, pd)
     np.testing.assert_array_equal(fbflow, cuda.FarnebackOpticalFlow.create(numLevels=3).calc(tl, tr).cpu().numpy())
+    pk, pdesc = cuda.SURF_CUDA.create(300, 3, 2, False, 0.05).detectWithDescriptors(tl)
+    pk = cuda.SURF_CUDA.downloadKeypoints(pk)
+    assert nk == pk["x"].shape[0]
+    np.testing.assert_array_equal(kps, np.stack([pk["x"], pk["y"], pk["size"], pk["angle"], pk["hessian"]], 1))
+    np.testing.assert_array_equal(sdesc, pdesc.cpu().numpy())

@@ -1,0 +1,195 @@
+"""SURF: oracle self-tests (CPU) and HIP-vs-oracle parity (GPU) for cv::cuda::SURF_CUDA.
+
+Stated tolerances:
+  * integral image, candidate set, laplacian/octave/size rows: exact;
+  * det/trace and x/y/hessian rows: same double/float operations in the same order on both sides -> exact or 1 ulp
+    (assert_allclose rtol 1e-6);
+  * angle: atan2f of the device vs glibc may differ by 1 ulp, which can move a sample across a 5-degree window edge
+    -> >= 99 % of the features within 1e-2 degrees;
+  * descriptors: >= 99 % of the features with max |diff| <= 1e-4 (sincosf ulp differences can flip a
+    nearest-texel read for a few samples).
+The reference's own CUDA-vs-CPU acceptance is far looser (matched-keypoint ratio > 0.95, descriptor match ratio > 0.6,
+xfeatures2d/test/test_surf.cuda.cpp:102-107,166-173).
+"""
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+def test_oracle_tables_match_reference_literals(oracle):
+    """Generated tables vs literal entries of the reference's constant tables (xfeatures2d/src/cuda/surf.cu:520-522,
+    685-707): c_aptX[0..8], c_aptY[0..8], c_aptW[0], c_aptW[56] (centre), c_DW[0], c_DW[21], c_DW[210]."""
+    ax, ay, aw, dw = oracle.surf_tables()
+    np.testing.assert_array_equal(ax[:9], [-6, -5, -5, -5, -5, -5, -5, -5, -4])
+    np.testing.assert_array_equal(ay[:9], [0, -3, -2, -1, 0, 1, 2, 3, -4])
+    assert ax[-1] == 6 and ay[-1] == 0 and len(ax) == 113
+    np.testing.assert_allclose([aw[0], aw[56]], [0.001455130288377404, 0.02592208795249462], rtol=3e-7)
+    np.testing.assert_allclose([dw[0], dw[21], dw[210]], [3.695352233989979e-06, 1.929736572492402e-05, 0.01435048412531614], rtol=5e-7)
+
+
+def test_oracle_integral(oracle):
+    img = np.random.default_rng(0).integers(0, 256, size=(37, 53)).astype(np.uint8)
+    s = oracle.surf_integral(img)
+    ref = np.zeros((38, 54), np.uint64)
+    ref[1:, 1:] = img.astype(np.uint64).cumsum(0).cumsum(1)
+    np.testing.assert_array_equal(s, ref.astype(np.uint32))
+
+
+def test_oracle_cross_fixture(oracle):
+    """The reference's only self-contained SURF fixture (xfeatures2d/test/test_rotation_and_scale_invariance.cpp:259-285:
+    100x100 white image, two 3-px dark bars, SURF(8000, 3, 4, extended, upright=false)).  The CPU class reports 5
+    keypoints there; under the CUDA class's strict 26-neighbour maximum the centre is a plateau (det = 15376 on a 3x3
+    patch of layer 1) and only the 4 symmetric keypoints survive -- with equal responses, as that test requires."""
+    img = synth.cross_image()
+    r = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=8000, n_octaves=3, n_octave_layers=4, extended=1,
+                                                            keypoints_ratio=0.05))
+    assert r["n"] == 4
+    assert np.ptp(r["hessian"]) <= 1e-6 * r["hessian"][0]
+    c = np.stack([r["x"], r["y"]], 1)
+    np.testing.assert_allclose(np.abs(c - 50.0), np.abs(c[0] - 50.0)[None].repeat(4, 0), rtol=1e-6)   # 4-fold symmetric about (50,50)
+    assert set(map(tuple, np.sign(c - 50.0).astype(int))) == {(-1, -1), (1, -1), (-1, 1), (1, 1)}
+
+
+def test_oracle_blobs_scale_and_descriptor_norm(oracle):
+    img = synth.blob_image(240, 320, seed=7)
+    r = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=400))
+    assert r["n"] > 50 and len(np.unique(r["octave"])) >= 2
+    np.testing.assert_allclose(np.linalg.norm(r["descriptors"], axis=1), 1.0, atol=1e-5)
+    assert ((r["angle"] >= 0) & (r["angle"] < 360)).all()
+    r2 = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=400, upright=1, extended=1))
+    assert (r2["angle"] == 270).all() and r2["descriptors"].shape[1] == 128 and r2["n"] == r["n"]
+
+
+def test_oracle_mask_and_errors(oracle):
+    img = synth.blob_image(200, 260, seed=3)
+    full = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=300), want_desc=False)
+    mask = np.zeros_like(img); mask[:, :130] = 255
+    half = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=300), mask=mask, want_desc=False)
+    assert 0 < half["n"] < full["n"] and half["x"].max() < 140
+    with pytest.raises(ValueError):
+        oracle.surf_detect_describe(img[:60, :60], oracle.surf_params())          # too small for 4 octaves (surf.cuda.cpp:144-151)
+    with pytest.raises(ValueError):
+        oracle.surf_detect_describe(img, oracle.surf_params(n_octaves=0))
+
+
+# ------------------------------------------------------------------ HIP vs oracle (GPU)
+gpu_mark = pytest.mark.gpu
+
+
+@gpu_mark
+def test_wave_scan_semantics(gpu):
+    import ctypes as C
+    from opencv_contrib_amd import capi
+    v = np.random.default_rng(1).integers(0, 1000, size=64).astype(np.uint32)
+    inp = (C.c_uint * 64)(*[int(x) for x in v]); out = (C.c_uint * 64)()
+    capi.check(capi.lib().mi_dbg_wave_scan(inp, out))
+    np.testing.assert_array_equal(np.array(out[:], np.uint64), np.cumsum(v.astype(np.uint64)))
+
+
+@gpu_mark
+@pytest.mark.parametrize("shape", [(37, 53), (100, 64), (481, 1283)])
+def test_integral_bit_exact(gpu, oracle, shape):
+    from opencv_contrib_amd import cuda
+    img = np.random.default_rng(2).integers(0, 256, size=shape).astype(np.uint8)
+    np.testing.assert_array_equal(N(cuda.surf_integral(T(img, gpu))).view(np.uint32), oracle.surf_integral(img))
+    m = (img > 100).astype(np.uint8) * 255
+    np.testing.assert_array_equal(N(cuda.surf_integral(T(m, gpu), True)).view(np.uint32), oracle.surf_integral(np.minimum(m, 1)))
+
+
+@gpu_mark
+@pytest.mark.parametrize("octave", [0, 1, 2])
+def test_det_trace_matches_oracle(gpu, oracle, octave):
+    from opencv_contrib_amd import cuda
+    img = synth.blob_image(200, 264, seed=5)
+    S = oracle.surf_integral(img)
+    rd, rt = oracle.surf_det_trace(S, octave, 2)
+    gd, gt = cuda.surf_detTrace(T(S.view(np.int32), gpu), octave, 2)
+    lc = 264 >> octave
+    np.testing.assert_allclose(N(gd)[:, :lc], rd[:, :lc], rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(N(gt)[:, :lc], rt[:, :lc], rtol=1e-6, atol=1e-3)
+
+
+def _compare(kp, desc, ref, check_desc=True):
+    assert kp["x"].shape[0] == ref["n"], (kp["x"].shape[0], ref["n"])
+    for k in ("laplacian", "octave", "size"):
+        np.testing.assert_array_equal(kp[k], ref[k], err_msg=k)
+    for k in ("x", "y", "hessian"):
+        np.testing.assert_allclose(kp[k], ref[k], rtol=1e-6, atol=1e-4, err_msg=k)
+    d = np.abs(kp["angle"] - ref["angle"]); d = np.minimum(d, 360 - d)
+    assert (d <= 1e-2).mean() >= 0.99, (d > 1e-2).sum()
+    if check_desc:
+        dd = np.abs(desc - ref["descriptors"]).max(1)
+        ok = (dd <= 1e-4) | (d > 1e-2)     # a feature whose angle differs is allowed a different descriptor
+        assert ok.mean() >= 0.99, (float(dd.max()), int((~ok).sum()))
+
+
+@gpu_mark
+@pytest.mark.parametrize("thr,octaves,layers,extended,upright", [(100, 4, 2, False, False), (500, 3, 3, True, False),
+                                                                 (1000, 4, 2, False, True), (100, 3, 2, True, True)])
+def test_detect_and_describe_match_oracle(gpu, oracle, thr, octaves, layers, extended, upright):
+    """Parameter grid after xfeatures2d/test/test_surf.cuda.cpp:176-187, keypointsRatio 0.05 as there (:92)."""
+    from opencv_contrib_amd import cuda
+    img = synth.blob_image(300, 400, seed=11)
+    ref = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=thr, n_octaves=octaves, n_octave_layers=layers,
+                                                              extended=int(extended), upright=int(upright), keypoints_ratio=0.05))
+    assert ref["n"] > 20
+    alg = cuda.SURF_CUDA.create(thr, octaves, layers, extended, 0.05, upright)
+    kpg, desc = alg.detectWithDescriptors(T(img, gpu))
+    assert desc.shape == (ref["n"], alg.descriptorSize()) and alg.defaultNorm() == 4
+    _compare(cuda.SURF_CUDA.downloadKeypoints(kpg), N(desc), ref)
+
+
+@gpu_mark
+def test_detect_mask_overflow_and_provided_keypoints(gpu, oracle):
+    from opencv_contrib_amd import cuda
+    img = synth.blob_image(260, 330, seed=13)
+    mask = np.zeros_like(img); mask[40:200, 30:220] = 7
+    p = oracle.surf_params(hessian_threshold=200, keypoints_ratio=0.05)
+    ref = oracle.surf_detect_describe(img, p, mask=mask)
+    alg = cuda.SURF_CUDA.create(200, _keypointsRatio=0.05)
+    kpg = alg.detect(T(img, gpu), T(mask, gpu))
+    _compare(cuda.SURF_CUDA.downloadKeypoints(kpg), None, ref, check_desc=False)
+    # overflow: tiny keypointsRatio -> deterministic prefix of the scan-ordered feature list
+    full = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=50, keypoints_ratio=0.05), want_desc=False)
+    few = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=50, keypoints_ratio=0.0004), want_desc=False)
+    assert few["n"] == int(np.float32(260 * 330) * np.float32(0.0004)) < full["n"]
+    kpf = cuda.SURF_CUDA.downloadKeypoints(cuda.SURF_CUDA.create(50, _keypointsRatio=0.0004).detect(T(img, gpu)))
+    np.testing.assert_allclose(kpf["x"], few["x"], rtol=1e-6, atol=1e-4)
+    # useProvidedKeypoints: orientation + descriptors recomputed for the given keypoints
+    ref2 = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=200, keypoints_ratio=0.05))
+    kpg2 = alg.detect(T(img, gpu))
+    kpg2c = kpg2.clone(); kpg2c[5] = 0
+    kpo, desc = alg.detectWithDescriptors(T(img, gpu), None, kpg2c, True)
+    _compare(cuda.SURF_CUDA.downloadKeypoints(kpo), N(desc), ref2)
+
+
+@gpu_mark
+def test_cross_fixture_and_errors(gpu, oracle):
+    import torch
+    from opencv_contrib_amd import cuda, capi
+    img = synth.cross_image()
+    alg = cuda.SURF_CUDA.create(8000, 3, 4, True, 0.05, False)
+    kp = cuda.SURF_CUDA.downloadKeypoints(alg.detect(T(img, gpu)))
+    assert kp["x"].shape[0] == 4 and np.ptp(kp["hessian"]) <= 1e-6 * kp["hessian"][0]
+    with pytest.raises(capi.MiError):
+        cuda.SURF_CUDA.create(100).detect(T(img[:60, :60], gpu))                  # too small for 4 octaves
+    with pytest.raises(capi.MiError):
+        cuda.SURF_CUDA.create(100).detect(T(img.astype(np.float32), gpu))         # CV_8UC1 only (surf.cuda.cpp:139)
+    with pytest.raises(capi.MiError):
+        cuda.SURF_CUDA.create(100).detect(T(img, gpu), T(img[:50], gpu))          # mask size (:140)
+    # determinism: two runs, identical bytes
+    b = synth.blob_image(300, 400, seed=4)
+    a1 = alg2 = cuda.SURF_CUDA.create(100)
+    k1, d1 = a1.detectWithDescriptors(T(b, gpu)); k2, d2 = alg2.detectWithDescriptors(T(b, gpu))
+    assert torch.equal(k1, k2) and torch.equal(d1, d2)
