@@ -267,16 +267,10 @@ def main():
     import numpy as np
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dist = dist_
+    # one process per GPU; every rank runs its own batch of independent pairs (no data-path collective);
+    # RCCL ("nccl") only carries the barriers and the max-over-ranks timing reduction
+    from opencv_contrib_amd import parallel
+    dist, rank, world, local = parallel.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -293,12 +287,10 @@ def main():
                                                timeBlock=args.time_block)
         alg.setProfiling(profile)
         el = time_steps(alg, I0, I1, flows, steps, warmup, dist)
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = parallel.max_over_ranks(dist, el, dev)
         prof = alg.getProfile() if profile else None
         its = alg.lastIterations(0)
-        return float(t.item()), prof, its, alg
+        return float(el), prof, its, alg
 
     el, prof, its, alg = run(args.iterations, args.epsilon, args.steps, args.warmup, profile=True)
     pairs = B * world * args.steps

@@ -1,0 +1,104 @@
+"""Batched-frames mode across the GPUs of one node: the path shards ONLY across independent image
+pairs / frames -- one process per GPU, a static block partition of the batch, no data-path collective.
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests) is used for rendezvous,
+barriers, the max-over-ranks timing reduction and (optionally) gathering per-rank results to rank 0.
+"""
+from __future__ import annotations
+
+import os
+
+
+def shard_range(n_items: int, world: int, rank: int) -> range:
+    """Static block partition (pair i -> rank i // ceil(n/world)): contiguous, sizes differ by at most ... the last
+    ranks may be short or empty when n is not a multiple of world."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    per = -(-n_items // world)
+    lo = min(rank * per, n_items)
+    hi = min(lo + per, n_items)
+    return range(lo, hi)
+
+
+def init_distributed(backend: str | None = None, device=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (dist or None, rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return None, 0, 1, local
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, **kw)
+    return dist, rank, world, local
+
+
+def max_over_ranks(dist, value: float, device=None) -> float:
+    """Slowest rank's time (the job's wall time)."""
+    if dist is None:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist, value: float, device=None) -> float:
+    if dist is None:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def run_sharded(dist, rank: int, world: int, n_items: int, work, warmup: int, steps: int, sync=None, device=None):
+    """Runs `work(range_of_items)` `warmup` + `steps` times on this rank's shard, bracketed by barriers, and returns
+    (wall seconds = max over ranks, items processed by the whole job per step).  `sync` = device synchronisation."""
+    import time
+    shard = shard_range(n_items, world, rank)
+    for _ in range(warmup):
+        work(shard)
+    if sync:
+        sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        work(shard)
+    if sync:
+        sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    wall = max_over_ranks(dist, el, device)
+    total = sum_over_ranks(dist, float(len(shard)), device)
+    return wall, int(round(total))
+
+
+def gather_to_rank0(dist, rank: int, world: int, tensor):
+    """Gather per-rank result tensors (same shape except dim 0) on rank 0 -- the only data-path exchange of the
+    batched mode (flows back to the caller's GPU).  Returns the concatenation on rank 0, None elsewhere."""
+    if dist is None:
+        return tensor
+    import torch
+    sizes = [None] * world
+    dist.all_gather_object(sizes, int(tensor.shape[0]))
+    if rank == 0:
+        outs = [tensor]
+        for r in range(1, world):
+            buf = torch.empty((sizes[r],) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+            if sizes[r]:
+                dist.recv(buf, src=r)
+            outs.append(buf)
+        return torch.cat(outs, 0)
+    if tensor.shape[0]:
+        dist.send(tensor.contiguous(), dst=0)
+    return None
