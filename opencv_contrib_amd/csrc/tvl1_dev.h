@@ -34,8 +34,10 @@ struct PtrTab {          // per-pair external image pointers (device array)
 
 struct IterPlanes {
     const float *ix, *iy, *g, *rc;   // I1wx, I1wy, grad, rho_c
-    float *u[2][2];                  // [set][component]
-    float *p[2][4];                  // [set][p11,p12,p21,p22]
+    float *u[2][3];                  // [set][u1,u2,u3]   (u3 only when gamma != 0)
+    float *p[2][6];                  // [set][p11,p12,p21,p22,p31,p32]
+    float gamma;                     // illumination-change weight; 0 = the 2-channel model
+    int err_u3;                      // 1: the convergence error includes (du3)^2 (CPU class, optflow tvl1flow.cpp:1110); 0: cv::cuda
 };
 
 // type: MI_8UC1 (x1) or MI_32FC1 (x255)

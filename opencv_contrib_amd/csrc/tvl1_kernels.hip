@@ -321,20 +321,22 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host
 // Per-pixel math.  EXACT: the CPU reference's operations (optflow/src/tvl1flow.cpp:989-1041
 // estimateV, :857-899 divergence, :1096-1112 estimateU, :1140-1181 dual update with hypot in
 // double) in reference order.  !EXACT: same formulas with fmaf + v_rcp/v_sqrt approximations.
-template <bool EXACT>
+template <bool EXACT, bool GAMMA = false>
 __device__ __forceinline__ void px_update_u(float ix, float iy, float g, float rc, float u1, float u2,
                                             float div1, float div2, float l_t, float theta,
-                                            float &u1n, float &u2n, float &err)
+                                            float &u1n, float &u2n, float &err, float gamma = 0.f, float u3 = 0.f,
+                                            float div3 = 0.f, float *u3n = nullptr, bool err_u3 = false)
 {
-    float rho, d1 = 0.f, d2 = 0.f;
+    float rho, d1 = 0.f, d2 = 0.f, d3 = 0.f;
     if (EXACT) rho = rc + (ix * u1 + iy * u2);
     else rho = rc + fmaf(ix, u1, iy * u2);
+    if (GAMMA) rho = rho + gamma * u3;   // optflow tvl1flow.cpp:1011
     const float ltg = l_t * g;
-    if (rho < -ltg) { d1 = l_t * ix; d2 = l_t * iy; }
-    else if (rho > ltg) { d1 = -l_t * ix; d2 = -l_t * iy; }
+    if (rho < -ltg) { d1 = l_t * ix; d2 = l_t * iy; if (GAMMA) d3 = l_t * gamma; }
+    else if (rho > ltg) { d1 = -l_t * ix; d2 = -l_t * iy; if (GAMMA) d3 = -l_t * gamma; }
     else if (g > FLT_EPSILON) {
         const float fi = EXACT ? (-rho / g) : (-rho * __builtin_amdgcn_rcpf(g));
-        d1 = fi * ix; d2 = fi * iy;
+        d1 = fi * ix; d2 = fi * iy; if (GAMMA) d3 = fi * gamma;
     }
     if (EXACT) {
         const float v1 = u1 + d1, v2 = u2 + d2;
@@ -346,6 +348,12 @@ __device__ __forceinline__ void px_update_u(float ix, float iy, float g, float r
     }
     const float e1 = u1n - u1, e2 = u2n - u2;
     err = EXACT ? (e1 * e1 + e2 * e2) : fmaf(e1, e1, e2 * e2);
+    if (GAMMA) {
+        const float v3 = u3 + d3;
+        *u3n = v3 + theta * div3;
+        const float e3 = *u3n - u3;
+        if (err_u3) err = err + e3 * e3;   // :1110
+    }
 }
 
 template <bool EXACT>
@@ -384,14 +392,25 @@ __device__ __forceinline__ void st4(float *p, long long off, bool ok, const floa
 
 struct RowIn {
     float ix[4], iy[4], g[4], rc[4], u1[4], u2[4], p11[4], p12[4], p21[4], p22[4];
+    float u3[4], p31[4], p32[4];   // gamma != 0 only
 };
 
 #define UNPACK4(dst, v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
 
-template <bool PZ>
-__device__ __forceinline__ void load_row(RowIn &r, const IterArgs &A, const float *const u[2], const float *const p[4],
+template <bool PZ, bool GAMMA = false>
+__device__ __forceinline__ void load_row(RowIn &r, const IterArgs &A, const float *const u[3], const float *const p[6],
                                          long long off, bool ok)
 {
+    if (GAMMA) {
+        float4 t3 = ld4(u[2], off, ok); UNPACK4(r.u3, t3);
+        if (!PZ) {
+            t3 = ld4(p[4], off, ok); UNPACK4(r.p31, t3);
+            t3 = ld4(p[5], off, ok); UNPACK4(r.p32, t3);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.p31[j] = r.p32[j] = 0.f;
+        }
+    }
     float4 t;
     t = ld4(A.pl.ix, off, ok); UNPACK4(r.ix, t);
     t = ld4(A.pl.iy, off, ok); UNPACK4(r.iy, t);
@@ -412,10 +431,11 @@ __device__ __forceinline__ void load_row(RowIn &r, const IterArgs &A, const floa
 
 // u_new of one row.  up12/up22 = p12,p22 of the row above (unused when y == 0);
 // l11/l21 = p11,p21 at x-1 of this lane's first pixel.
-template <bool EXACT>
+template <bool EXACT, bool GAMMA = false>
 __device__ __forceinline__ void row_update_u(const RowIn &r, const float up12[4], const float up22[4],
                                              float l11, float l21, int xb, int y, float l_t, float theta,
-                                             float u1n[4], float u2n[4], float e[4])
+                                             float u1n[4], float u2n[4], float e[4], const float up32[4] = nullptr,
+                                             float l31 = 0.f, float gamma = 0.f, bool err_u3 = false, float u3n[4] = nullptr)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -441,8 +461,17 @@ __device__ __forceinline__ void row_update_u(const RowIn &r, const float up12[4]
                 d2 = r.p21[j] + r.p22[j];
             }
         }
-        px_update_u<EXACT>(r.ix[j], r.iy[j], r.g[j], r.rc[j], r.u1[j], r.u2[j], d1, d2, l_t, theta,
-                           u1n[j], u2n[j], e[j]);
+        if (GAMMA) {
+            const float p31l = j ? r.p31[j - 1] : l31;
+            float d3;
+            if (y > 0) d3 = x > 0 ? (r.p31[j] - p31l) + (r.p32[j] - up32[j]) : r.p31[j] + r.p32[j] - up32[j];
+            else d3 = x > 0 ? r.p31[j] - p31l + r.p32[j] : r.p31[j] + r.p32[j];
+            px_update_u<EXACT, true>(r.ix[j], r.iy[j], r.g[j], r.rc[j], r.u1[j], r.u2[j], d1, d2, l_t, theta,
+                                     u1n[j], u2n[j], e[j], gamma, r.u3[j], d3, &u3n[j], err_u3);
+        } else {
+            px_update_u<EXACT>(r.ix[j], r.iy[j], r.g[j], r.rc[j], r.u1[j], r.u2[j], d1, d2, l_t, theta,
+                               u1n[j], u2n[j], e[j]);
+        }
     }
 }
 
