@@ -15,7 +15,7 @@ namespace {
 struct LevelBuf {
     Geo g;
     float *I0 = nullptr, *I1 = nullptr;
-    float *u[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [set][component]
+    float *u[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [set][u1,u2,u3]
 };
 
 struct SlotInfo { int scale, warp; };
@@ -34,7 +34,8 @@ struct mi_tvl1 {
     // full-resolution-capacity scratch planes (re-laid-out densely per level)
     float *scr[6] = {};    // scr[0..1] unused (kept for layout), I1wx, I1wy, grad, rho_c
     float *pack = nullptr; // float4 {I1, I1x, I1y, 0} per pixel of the current level
-    float *pbuf[2][4] = {};
+    float *pbuf[2][6] = {};   // [set][p11,p12,p21,p22,p31,p32]
+    bool capGamma = false;
     float *cubic_tab = nullptr;
     PtrTab *tab_dev = nullptr;
     int tab_cap = 0;
@@ -73,7 +74,6 @@ static int validate_params(const mi_tvl1_params *p)
     MI_REQUIRE(p->scale_step > 0 && p->scale_step < 1, MI_ERR_BAD_ARG, "scale_step must be in (0,1)");
     MI_REQUIRE(p->theta != 0, MI_ERR_BAD_ARG, "theta must be non-zero");
     MI_REQUIRE(p->semantics == MI_SEM_CPU_REF || p->semantics == MI_SEM_CUDA_COMPAT, MI_ERR_BAD_ARG, "bad semantics");
-    MI_REQUIRE(p->gamma == 0.0, MI_ERR_NOT_IMPL, "gamma != 0 (u3/p3 channel) is not implemented yet");
     MI_REQUIRE(p->median_filtering <= 1, MI_ERR_NOT_IMPL, "median_filtering > 1 is not implemented yet");
     return MI_OK;
 }
@@ -179,25 +179,26 @@ static int plan_levels(const mi_tvl1_params &P, int W, int H, int B, std::vector
 
 static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
 {
+    const bool gam = h->P.gamma != 0.0;
     if (h->arena && h->capW == W && h->capH == H && h->capB >= B && h->capScales == h->P.nscales &&
-        h->capStep == h->P.scale_step)
+        h->capStep == h->P.scale_step && h->capGamma == gam)
         return MI_OK;
     free_arena(h);
     std::vector<Geo> geo;
     const int nl = plan_levels(h->P, W, H, B, geo);
     size_t total = 0;
     auto take = [&](size_t nfloats) { size_t o = total; total += (nfloats + 63) / 64 * 64; return o; };
-    std::vector<size_t> offI0(nl), offI1(nl), offU(nl * 4);
+    std::vector<size_t> offI0(nl), offI1(nl), offU(nl * 6);
     for (int l = 0; l < nl; ++l) {
         const size_t n = (size_t)geo[l].ps * B;
         offI0[l] = take(n); offI1[l] = take(n);
-        for (int k = 0; k < 4; ++k) offU[l * 4 + k] = take(n);
+        for (int k = 0; k < 6; ++k) offU[l * 6 + k] = (k % 3 == 2 && !gam) ? 0 : take(n);   // u3 planes only when gamma != 0
     }
     const size_t nfull = (size_t)geo[0].ps * B;
-    size_t offScr[6], offP[8];
+    size_t offScr[6], offP[12];
     for (int k = 0; k < 6; ++k) offScr[k] = k < 2 ? 0 : take(nfull);
     const size_t offPack = take(nfull * 4);
-    for (int k = 0; k < 8; ++k) offP[k] = take(nfull);
+    for (int k = 0; k < 12; ++k) offP[k] = (k % 6 >= 4 && !gam) ? 0 : take(nfull);
     MI_HIP_TRY(hipMalloc((void **)&h->arena, total * sizeof(float)));
     h->arena_floats = total;
     h->L.resize(nl);
@@ -205,11 +206,12 @@ static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
         h->L[l].g = geo[l];
         h->L[l].I0 = h->arena + offI0[l];
         h->L[l].I1 = h->arena + offI1[l];
-        for (int k = 0; k < 4; ++k) h->L[l].u[k >> 1][k & 1] = h->arena + offU[l * 4 + k];
+        for (int k = 0; k < 6; ++k) h->L[l].u[k / 3][k % 3] = (k % 3 == 2 && !gam) ? nullptr : h->arena + offU[l * 6 + k];
     }
     for (int k = 0; k < 6; ++k) h->scr[k] = h->arena + offScr[k];
     h->pack = h->arena + offPack;
-    for (int k = 0; k < 8; ++k) h->pbuf[k >> 2][k & 3] = h->arena + offP[k];
+    for (int k = 0; k < 12; ++k) h->pbuf[k / 6][k % 6] = (k % 6 >= 4 && !gam) ? nullptr : h->arena + offP[k];
+    h->capGamma = gam;
     h->capW = W; h->capH = H; h->capB = B; h->capScales = h->P.nscales; h->capStep = h->P.scale_step;
     return MI_OK;
 }
@@ -333,6 +335,11 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         MI_HIP_TRY(hipMemsetAsync(h->L[ns - 1].u[0][0], 0, sizeof(float) * (size_t)g.ps * B, st));
         MI_HIP_TRY(hipMemsetAsync(h->L[ns - 1].u[0][1], 0, sizeof(float) * (size_t)g.ps * B, st));
     }
+    const bool gam = P.gamma != 0.0;
+    if (gam) {   // u3 starts at 0 on the coarsest scale (tvl1flow.cpp:273-275; optflow tvl1flow.cpp:498-500)
+        const Geo &g = h->L[ns - 1].g;
+        MI_HIP_TRY(hipMemsetAsync(h->L[ns - 1].u[0][2], 0, sizeof(float) * (size_t)g.ps * B, st));
+    }
 
     const float l_t = (float)(P.lambda * P.theta);
     const float taut = (float)(P.tau / P.theta);
@@ -355,7 +362,9 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         const float *u1v[2] = {Lv.u[0][0], Lv.u[1][0]}, *u2v[2] = {Lv.u[0][1], Lv.u[1][1]};
         IterPlanes pl;
         pl.ix = I1wx; pl.iy = I1wy; pl.g = grad; pl.rc = rho;
-        for (int k = 0; k < 2; ++k) { pl.u[k][0] = Lv.u[k][0]; pl.u[k][1] = Lv.u[k][1]; for (int j = 0; j < 4; ++j) pl.p[k][j] = h->pbuf[k][j]; }
+        for (int k = 0; k < 2; ++k) { for (int j = 0; j < 3; ++j) pl.u[k][j] = Lv.u[k][j]; for (int j = 0; j < 6; ++j) pl.p[k][j] = h->pbuf[k][j]; }
+        pl.gamma = (float)P.gamma;
+        pl.err_u3 = sem == MI_SEM_CPU_REF ? 1 : 0;   // optflow tvl1flow.cpp:1110 vs cuda tvl1flow.cu:276-283
         cur = 0;
         bool first_of_scale = true;
         // scaledEpsilon: float in the CPU class (optflow tvl1flow.cpp:1315), double in cv::cuda (:310)
@@ -375,7 +384,7 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
                 rc = next_event(&e0); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(h->ev_pool[e0], st));
             }
-            const bool blocked = !check && !P.exact_math && P.time_block != 1;
+            const bool blocked = !check && !P.exact_math && P.time_block != 1 && !gam;
             long long nlaunch = 0;
             if (blocked) {
                 // T iterations per HBM pass (tvl1_tb_kernels.hip), decomposition by measured cost
@@ -421,11 +430,12 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         }
         // zoom the flow to the next finer scale and rescale it (tvl1flow.cpp:291-300)
         const Geo &gf = h->L[s - 1].g;
-        const float *us[3][2] = {{Lv.u[0][0], Lv.u[1][0]}, {Lv.u[0][1], Lv.u[1][1]}, {nullptr, nullptr}};
-        float *ud[3] = {h->L[s - 1].u[0][0], h->L[s - 1].u[0][1], nullptr};
+        // u3 is zoomed too but NOT rescaled (tvl1flow.cpp:293-300; optflow tvl1flow.cpp:524-528)
+        const float *us[3][2] = {{Lv.u[0][0], Lv.u[1][0]}, {Lv.u[0][1], Lv.u[1][1]}, {gam ? Lv.u[0][2] : nullptr, gam ? Lv.u[1][2] : nullptr}};
+        float *ud[3] = {h->L[s - 1].u[0][0], h->L[s - 1].u[0][1], gam ? h->L[s - 1].u[0][2] : nullptr};
         const float inv = (float)(1.0 / P.scale_step);
         const float post[3] = {inv, inv, 1.f};
-        rc = resize(sem, 2, us, 2, ud, g, gf, (double)gf.w / g.w, (double)gf.h / g.h, post,
+        rc = resize(sem, gam ? 3 : 2, us, 2, ud, g, gf, (double)gf.w / g.w, (double)gf.h / g.h, post,
                     dev_cur ? &ec : nullptr, cur, st);
         if (rc) return rc;
     }

@@ -475,7 +475,7 @@ __device__ __forceinline__ void row_update_u(const RowIn &r, const float up12[4]
     }
 }
 
-template <bool EXACT, bool PZ, bool CHECK>
+template <bool EXACT, bool PZ, bool CHECK, bool GAMMA = false>
 __global__ __launch_bounds__(256) void k_iterate(IterArgs A, CtlK ctl, int cur_host)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -510,67 +510,81 @@ __global__ __launch_bounds__(256) void k_iterate(IterArgs A, CtlK ctl, int cur_h
     const bool ok = xb < W;
     const long long pb = (long long)b * A.g.ps;
 
-    const float *uin[2] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb};
-    const float *pin[4] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb};
-    float *uout[2] = {A.pl.u[cur ^ 1][0] + pb, A.pl.u[cur ^ 1][1] + pb};
-    float *pout[4] = {A.pl.p[cur ^ 1][0] + pb, A.pl.p[cur ^ 1][1] + pb, A.pl.p[cur ^ 1][2] + pb, A.pl.p[cur ^ 1][3] + pb};
+    const float *uin[3] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb, GAMMA ? A.pl.u[cur][2] + pb : nullptr};
+    const float *pin[6] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb,
+                           GAMMA ? A.pl.p[cur][4] + pb : nullptr, GAMMA ? A.pl.p[cur][5] + pb : nullptr};
+    float *uout[3] = {A.pl.u[cur ^ 1][0] + pb, A.pl.u[cur ^ 1][1] + pb, GAMMA ? A.pl.u[cur ^ 1][2] + pb : nullptr};
+    float *pout[6] = {A.pl.p[cur ^ 1][0] + pb, A.pl.p[cur ^ 1][1] + pb, A.pl.p[cur ^ 1][2] + pb, A.pl.p[cur ^ 1][3] + pb,
+                      GAMMA ? A.pl.p[cur ^ 1][4] + pb : nullptr, GAMMA ? A.pl.p[cur ^ 1][5] + pb : nullptr};
+    const float gamma = A.pl.gamma;
+    const bool err_u3 = A.pl.err_u3 != 0;
     IterArgs B = A;
     B.pl.ix += pb; B.pl.iy += pb; B.pl.g += pb; B.pl.rc += pb;
 
     // p12/p22 of row y0-1
-    float up12[4] = {0, 0, 0, 0}, up22[4] = {0, 0, 0, 0};
+    float up12[4] = {0, 0, 0, 0}, up22[4] = {0, 0, 0, 0}, up32[4] = {0, 0, 0, 0};
     if (!PZ && y0 > 0) {
         const long long off = (long long)(y0 - 1) * ld + xb;
         float4 t = ld4(pin[1], off, ok); UNPACK4(up12, t);
         t = ld4(pin[3], off, ok); UNPACK4(up22, t);
+        if (GAMMA) { t = ld4(pin[5], off, ok); UNPACK4(up32, t); }
     }
 
     RowIn r;
-    float u1c[4], u2c[4], ec[4];
+    float u1c[4], u2c[4], ec[4], u3c[4] = {0, 0, 0, 0};
     {
         const long long off = (long long)y0 * ld + xb;
-        load_row<PZ>(r, B, uin, pin, off, ok);
-        float l11 = lane_prev(r.p11[3]), l21 = lane_prev(r.p21[3]);
+        load_row<PZ, GAMMA>(r, B, uin, pin, off, ok);
+        float l11 = lane_prev(r.p11[3]), l21 = lane_prev(r.p21[3]), l31 = GAMMA ? lane_prev(r.p31[3]) : 0.f;
         if (!PZ && lane == 0 && x0 > 0) {
             l11 = pin[0][(long long)y0 * ld + x0 - 1];
             l21 = pin[2][(long long)y0 * ld + x0 - 1];
+            if (GAMMA) l31 = pin[4][(long long)y0 * ld + x0 - 1];
         }
-        row_update_u<EXACT>(r, up12, up22, l11, l21, xb, y0, A.l_t, A.theta, u1c, u2c, ec);
+        row_update_u<EXACT, GAMMA>(r, up12, up22, l11, l21, xb, y0, A.l_t, A.theta, u1c, u2c, ec, up32, l31, gamma, err_u3, u3c);
     }
     float errsum = 0.f;
     const bool own = lane < 63;
 
     for (int y = y0; y < y1; ++y) {
         // current row: r (inputs), u1c/u2c (new u), ec (error terms)
-        float p11c[4], p12c[4], p21c[4], p22c[4];
+        float p11c[4], p12c[4], p21c[4], p22c[4], p31c[4], p32c[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { p11c[j] = r.p11[j]; p12c[j] = r.p12[j]; p21c[j] = r.p21[j]; p22c[j] = r.p22[j]; }
-        float u1d[4], u2d[4], ed[4];
+        for (int j = 0; j < 4; ++j) { p11c[j] = r.p11[j]; p12c[j] = r.p12[j]; p21c[j] = r.p21[j]; p22c[j] = r.p22[j];
+                                      p31c[j] = GAMMA ? r.p31[j] : 0.f; p32c[j] = GAMMA ? r.p32[j] : 0.f; }
+        float u1d[4], u2d[4], ed[4], u3d[4] = {0, 0, 0, 0};
         const bool has_next = (y + 1 < H);
         if (has_next) {
             const long long off = (long long)(y + 1) * ld + xb;
             // p12,p22 of the current row become the "row above" of the next row
-            float c12[4], c22[4];
+            float c12[4], c22[4], c32[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { c12[j] = r.p12[j]; c22[j] = r.p22[j]; }
-            load_row<PZ>(r, B, uin, pin, off, ok);
-            float l11 = lane_prev(r.p11[3]), l21 = lane_prev(r.p21[3]);
+            for (int j = 0; j < 4; ++j) { c12[j] = r.p12[j]; c22[j] = r.p22[j]; c32[j] = GAMMA ? r.p32[j] : 0.f; }
+            load_row<PZ, GAMMA>(r, B, uin, pin, off, ok);
+            float l11 = lane_prev(r.p11[3]), l21 = lane_prev(r.p21[3]), l31 = GAMMA ? lane_prev(r.p31[3]) : 0.f;
             if (!PZ && lane == 0 && x0 > 0) {
                 l11 = pin[0][(long long)(y + 1) * ld + x0 - 1];
                 l21 = pin[2][(long long)(y + 1) * ld + x0 - 1];
+                if (GAMMA) l31 = pin[4][(long long)(y + 1) * ld + x0 - 1];
             }
-            row_update_u<EXACT>(r, c12, c22, l11, l21, xb, y + 1, A.l_t, A.theta, u1d, u2d, ed);
+            row_update_u<EXACT, GAMMA>(r, c12, c22, l11, l21, xb, y + 1, A.l_t, A.theta, u1d, u2d, ed, c32, l31, gamma, err_u3, u3d);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { u1d[j] = u1c[j]; u2d[j] = u2c[j]; ed[j] = 0.f; }
+            for (int j = 0; j < 4; ++j) { u1d[j] = u1c[j]; u2d[j] = u2c[j]; u3d[j] = u3c[j]; ed[j] = 0.f; }
         }
         // forward differences (optflow/src/tvl1flow.cpp:775-840: 0 at the last row/col)
-        const float r1 = lane_next(u1c[0]), r2 = lane_next(u2c[0]);
+        const float r1 = lane_next(u1c[0]), r2 = lane_next(u2c[0]), r3 = GAMMA ? lane_next(u3c[0]) : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int x = xb + j;
             const float n1 = j < 3 ? u1c[j + 1] : r1;
             const float n2 = j < 3 ? u2c[j + 1] : r2;
+            if (GAMMA) {
+                const float n3 = j < 3 ? u3c[j + 1] : r3;
+                const float u3x = (x + 1 < W) ? n3 - u3c[j] : 0.f;
+                const float u3y = has_next ? u3d[j] - u3c[j] : 0.f;
+                px_update_p<EXACT>(u3x, u3y, A.taut, p31c[j], p32c[j]);
+            }
             const float u1x = (x + 1 < W) ? n1 - u1c[j] : 0.f;
             const float u2x = (x + 1 < W) ? n2 - u2c[j] : 0.f;
             const float u1y = has_next ? u1d[j] - u1c[j] : 0.f;
@@ -587,8 +601,13 @@ __global__ __launch_bounds__(256) void k_iterate(IterArgs A, CtlK ctl, int cur_h
         st4(pout[1], off, st, p12c);
         st4(pout[2], off, st, p21c);
         st4(pout[3], off, st, p22c);
+        if (GAMMA) {
+            st4(uout[2], off, st, u3c);
+            st4(pout[4], off, st, p31c);
+            st4(pout[5], off, st, p32c);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { u1c[j] = u1d[j]; u2c[j] = u2d[j]; ec[j] = ed[j]; }
+        for (int j = 0; j < 4; ++j) { u1c[j] = u1d[j]; u2c[j] = u2d[j]; u3c[j] = u3d[j]; ec[j] = ed[j]; }
     }
 
     if (CHECK) {
@@ -711,7 +730,13 @@ template <bool EXACT, bool PZ>
 static void launch_iter(const IterArgs &A, const dim3 grid, const Ctl *ctl, int cur_host, hipStream_t s)
 {
     const CtlK ck = make_ctlk(ctl);
-    if (ctl && ctl->S)
+    const bool check = ctl && ctl->S;
+    if (A.pl.gamma != 0.f) {   // 3-channel model (u3, p31, p32): tvl1flow.cu:233-236,266-274,336-344
+        if (check) hipLaunchKernelGGL((k_iterate<EXACT, PZ, true, true>), grid, dim3(256), 0, s, A, ck, cur_host);
+        else hipLaunchKernelGGL((k_iterate<EXACT, PZ, false, true>), grid, dim3(256), 0, s, A, ck, cur_host);
+        return;
+    }
+    if (check)
         hipLaunchKernelGGL((k_iterate<EXACT, PZ, true>), grid, dim3(256), 0, s, A, ck, cur_host);
     else
         hipLaunchKernelGGL((k_iterate<EXACT, PZ, false>), grid, dim3(256), 0, s, A, ck, cur_host);

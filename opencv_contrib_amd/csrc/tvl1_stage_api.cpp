@@ -125,6 +125,7 @@ int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1w
     float *sp[4];
     for (int i = 0; i < 4; ++i) TRY(stage_in(S, stat[i], g, &sp[i], st));
     IterPlanes pl;
+    memset(&pl, 0, sizeof(pl));
     pl.ix = sp[0]; pl.iy = sp[1]; pl.g = sp[2]; pl.rc = sp[3];
     for (int i = 0; i < 2; ++i) { TRY(stage_in(S, &u_in[i], g, &pl.u[0][i], st)); pl.u[1][i] = S.alloc(g); MI_REQUIRE(pl.u[1][i], MI_ERR_OOM, "oom"); }
     for (int i = 0; i < 4; ++i) { TRY(stage_in(S, &p_in[i], g, &pl.p[0][i], st)); pl.p[1][i] = S.alloc(g); MI_REQUIRE(pl.p[1][i], MI_ERR_OOM, "oom"); }

@@ -344,3 +344,30 @@ def test_1080p_properties(gpu):
     d = np.sqrt(((fe - gt) ** 2).sum(-1))
     assert d[40:-40, 40:-40].mean() < 0.15, d[40:-40, 40:-40].mean()
     assert np.sqrt(((fe - ff) ** 2).sum(-1)).mean() < 5e-3
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+@pytest.mark.parametrize("fast", [False, True])
+def test_calc_gamma_illumination_channel_matches_oracle(gpu, oracle, sem, fast):
+    """gamma != 0 adds the u3 / p31 / p32 channel (cudaoptflow/test/test_optflow.cpp:530-532 runs gamma in {0, 1});
+    here with a brightness change between the frames so that u3 is actually exercised."""
+    I0, I1, _ = synth.flow_pair(240, 320, seed=17)
+    I1 = np.clip(I1 * 1.08 + 0.02, 0, 1).astype(np.float32)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0, gamma=1.0, semantics=sem))
+    ref0 = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0, gamma=0.0, semantics=sem))
+    assert np.sqrt(((ref - ref0) ** 2).sum(-1)).mean() > 1e-2, "gamma has no effect on this input"
+    flow, _ = _run(gpu, I0, I1, iterations=10, epsilon=0.0, gamma=1.0, semantics=sem, exactMath=not fast)
+    if fast:
+        _assert_flow_close(flow, ref, mean_epe=5e-3, ccorr=1e-5, frac_within=(0.02, 0.99))
+    else:
+        _assert_flow_close(flow, ref)
+
+
+def test_calc_gamma_with_device_side_convergence(gpu, oracle):
+    I0, I1, _ = synth.flow_pair(200, 280, seed=19, dtype="u8")
+    p = oracle.tvl1_params(iterations=300, epsilon=0.01, gamma=0.5)
+    ref, st = oracle.tvl1_calc(I0, I1, p, return_stats=True)
+    flow, alg = _run(gpu, I0, I1, iterations=300, epsilon=0.01, gamma=0.5)
+    _assert_flow_close(flow, ref, mean_epe=5e-3)
+    its = np.array(alg.lastIterations()); rits = np.array(st["iters"])
+    assert its.shape == rits.shape and np.abs(its - rits).max() <= max(3, 0.1 * rits.max())
