@@ -192,6 +192,8 @@ MI_API int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, f
 /* Hardware self-test hook: out_host[0..63] = wave-wide min of in_host[0..63] as seen by every lane,
  * out_host[64] = lane picked by the reference's tie-break rule among the minima. */
 MI_API int mi_dbg_wave_min(const unsigned *in_host, unsigned *out_host /*[65]*/);
+/* in_host[k*64 + lane] = value k of lane `lane` (k < 16); out_host[lane] = max over all lanes of value (lane & 15) */
+MI_API int mi_dbg_tmax16(const unsigned *in_host /*[1024]*/, unsigned *out_host /*[64]*/);
 
 /* ====================================================================== Farneback ===== */
 

@@ -23,14 +23,20 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
+# files compiled WITH the SLP vectoriser (v_pk_*_f32 packed math); everything else keeps -fno-slp-vectorize
+SLP_FILES = set(filter(None, os.environ.get("MIFLOW_SLP_FILES", "").split(",")))
+VARIANT = os.environ.get("MIFLOW_BUILD_VARIANT", "")   # suffix of the object dir / library name for A/B builds
+
+
 def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJ, src + ".o")
+    obj = os.path.join(OBJ, src + (("." + VARIANT) if VARIANT else "") + ".o")
     path = os.path.join(CSRC, src)
     deps = [path] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
            [os.path.join(ROOT, "include", "miflow", "c_api.h")]
     if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+    flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and src in SLP_FILES)]
+    cmd = [HIPCC] + flags + ["-x", "hip", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -44,14 +50,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    lib = LIB if not VARIANT else LIB.replace(".so", "_" + VARIANT + ".so")
+    if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print("built", LIB)
-    return LIB
+        print("built", lib)
+    return lib
 
 
 if __name__ == "__main__":

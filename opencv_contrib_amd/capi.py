@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiflow.so")
+# MIFLOW_LIB selects an A/B build variant of the same sources (tuning experiments); default libmiflow.so
+LIB_PATH = os.path.join(_HERE, os.environ.get("MIFLOW_LIB", "libmiflow.so"))
 
 MI_8UC1, MI_32SC1, MI_32FC1, MI_32FC2, MI_32SC4 = 0, 4, 5, 13, 28
 MI_SEM_CPU_REF, MI_SEM_CUDA_COMPAT = 0, 1
@@ -114,6 +115,7 @@ def lib():
         "mi_stereobm_block_match": (i, [PM, PM, PM, PM, i, i, i, i, vp]),
         "mi_stereobm_textureness": (i, [PM, PM, i, f, vp]),
         "mi_dbg_wave_min": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "mi_dbg_tmax16": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
         "mi_farneback_default_params": (None, [C.POINTER(FarnebackParams)]),
         "mi_farneback_create": (i, [C.POINTER(FarnebackParams), C.POINTER(vp)]),
         "mi_farneback_set_params": (i, [vp, C.POINTER(FarnebackParams)]),

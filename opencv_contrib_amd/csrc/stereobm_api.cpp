@@ -188,6 +188,18 @@ int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, float av
                             (long long)disp->step, img->rows, img->cols, winsz, avg_texture_threshold, (hipStream_t)stream);
 }
 
+int mi_dbg_tmax16(const unsigned *in_host, unsigned *out_host)
+{
+    MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
+    unsigned *d = nullptr;
+    MI_HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned) * (1024 + 64)));
+    MI_HIP_TRY(hipMemcpy(d, in_host, sizeof(unsigned) * 1024, hipMemcpyHostToDevice));
+    int rc = sbm::dbg_tmax16(d, d + 1024, nullptr);
+    if (!rc) { MI_HIP_TRY(hipDeviceSynchronize()); MI_HIP_TRY(hipMemcpy(out_host, d + 1024, sizeof(unsigned) * 64, hipMemcpyDeviceToHost)); }
+    (void)hipFree(d);
+    return rc;
+}
+
 int mi_dbg_wave_min(const unsigned *in_host, unsigned *out_host)
 {
     MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");

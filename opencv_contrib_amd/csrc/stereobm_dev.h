@@ -18,6 +18,7 @@ int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst
 int textureness(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, int rows, int cols,
                 int winsz, float avg_threshold, hipStream_t s);
 int dbg_wave_min(const unsigned *in_dev, unsigned *out_dev, hipStream_t s);
+int dbg_tmax16(const unsigned *in_dev /*[16][64]*/, unsigned *out_dev /*[64]*/, hipStream_t s);
 
 }  // namespace sbm
 }  // namespace mi

@@ -71,6 +71,51 @@ __device__ __forceinline__ void wave_max_u32x4(const unsigned in[4], unsigned ou
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[k] = (unsigned)__builtin_amdgcn_readlane((int)v[k], 63);
 }
+// Transposed max-reduction: 16 per-lane values (one per tile column) -> lane j (of every 16-lane row) holds the
+// maximum over all 64 lanes of value j.  Level L pairs lanes that differ in bit L: each lane keeps the half of its
+// values selected by its own bit and receives the partner's copy of that half, so the value count halves while
+// the lanes covered double: 16+8+4+2 exchanges instead of 16 x 6 for one-at-a-time reductions.
+template <int CTRL, int BANK>
+__device__ __forceinline__ unsigned dppb(unsigned old, unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, BANK, true);
+}
+__device__ __forceinline__ unsigned tmax16(const unsigned *v, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    unsigned w[8], x[4], y[2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const unsigned keep = b0 ? v[2 * m + 1] : v[2 * m], give = b0 ? v[2 * m] : v[2 * m + 1];
+        w[m] = max(keep, dppb<0xB1, 0xf>(0u, give));          // quad_perm:[1,0,3,2]  (lane ^ 1)
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const unsigned keep = b1 ? w[2 * m + 1] : w[2 * m], give = b1 ? w[2 * m] : w[2 * m + 1];
+        x[m] = max(keep, dppb<0x4E, 0xf>(0u, give));          // quad_perm:[2,3,0,1]  (lane ^ 2)
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const unsigned keep = b2 ? x[2 * m + 1] : x[2 * m], give = b2 ? x[2 * m] : x[2 * m + 1];
+        const unsigned lo = dppb<0x104, 0x5>(0u, give);       // row_shl:4 into banks 0,2 (lanes 0-3, 8-11 <- lane + 4)
+        y[m] = max(keep, dppb<0x114, 0xa>(lo, give));         // row_shr:4 into banks 1,3 (lanes 4-7, 12-15 <- lane - 4)
+    }
+    const unsigned keep = b3 ? y[1] : y[0], give = b3 ? y[0] : y[1];
+    const unsigned lo = dppb<0x108, 0x3>(0u, give);           // row_shl:8 into banks 0,1
+    unsigned z = max(keep, dppb<0x118, 0xc>(lo, give));       // row_shr:8 into banks 2,3      (lane ^ 8)
+    z = max(z, (unsigned)__shfl_xor((int)z, 16));             // the four rows of 16 lanes
+    z = max(z, (unsigned)__shfl_xor((int)z, 32));
+    return z;
+}
+
+__global__ void k_dbg_tmax16(const unsigned *in, unsigned *out)
+{
+    unsigned v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = in[k * 64 + threadIdx.x];
+    out[threadIdx.x] = tmax16(v, threadIdx.x);
+}
+
 // Among the lanes flagged in `mask` (bit = lane = disparity - 64*set): the reference keeps the LAST
 // index inside a batch of 8 (stereobm.cu:120-125) and the FIRST batch (strict <, :349,426).
 __device__ __forceinline__ int pick_lane(unsigned long long mask)
@@ -112,7 +157,10 @@ struct BmArgs {
 template <int R>
 struct Cfg {
     static constexpr int TWr = (64 - 2 * R) & ~3;
-    static constexpr int TW = TWr < 16 ? 16 : TWr;   // output columns per tile
+    // R <= 12: max SSD (2R+1)^2 * 255^2 < 2^26, so (2^26-1 - SSD) << 6 | tie-break key fits one u32 and the winner is a
+    // single max-reduction, done 16 columns at a time (tile width 48 = 3 groups); larger windows: generic path
+    static constexpr bool PACKED = R <= 12;
+    static constexpr int TW = PACKED ? 48 : (TWr < 16 ? 16 : TWr);   // output columns per tile
     static constexpr int NC = TW + 2 * R;            // column sums per lane
     static constexpr int LS = (NC + 15) / 16 * 16;   // LDS bytes per staged left row
     static constexpr int NLW = LS / 4;               // dwords per left row
@@ -241,6 +289,46 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
         unsigned resm = UINT_MAX, resd = 0;   // lane i collects the result of tile column i
         auto row_stage = [&](auto edge_tag) {
             constexpr bool EDGE = decltype(edge_tag)::value;
+            if (MODE == 0 && C::PACKED) {
+                // ---- packed winner-take-all: score = (2^26-1 - SSD) << 6 | key, key = lane ^ 0x38 (earlier batch of 8
+                //      wins, then the LAST index inside the batch: stereobm.cu:120-125,349); inactive lanes score 0
+                const unsigned key = (unsigned)(lane ^ 0x38), amask = active ? 0xffffffffu : 0u;
+                unsigned nw = 0x3ffffffu, nh = 0x3ffffffu;
+#pragma unroll
+                for (int c = 0; c < 2 * R; ++c) nw -= cs[c];
+                if (EDGE) {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) nh -= cs[c];
+                }
+                unsigned zr[TW / 16];
+#pragma unroll
+                for (int g = 0; g < TW / 16; ++g) {
+                    unsigned pk[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = g * 16 + k;
+                        nw -= cs[i + 2 * R];
+                        unsigned val = nw;
+                        if (EDGE) {
+                            nh -= cs[i + R];
+                            const int X = X0 + i;
+                            const int t = (X - A.ndisp - R) & 127;
+                            val = (t < 128 - R && X + R >= A.cols - R) ? nh : nw;   // stereobm.cu:77-89 (see below)
+                            nh += cs[i];
+                        }
+                        nw += cs[i];
+                        pk[k] = ((val << 6) | key) & amask;
+                    }
+                    zr[g] = tmax16(pk, lane);
+                }
+                // lane i <- column i of the tile: row r of 16 lanes takes group r
+                unsigned z = zr[0];
+#pragma unroll
+                for (int g = 1; g < TW / 16; ++g) z = (lane >> 4) == g ? zr[g] : z;
+                resm = 0x3ffffffu - (z >> 6);
+                resd = (unsigned)(wset * 64) + ((z & 63u) ^ 0x38u);
+                return;
+            }
             // nwin = ~(window SSD) = UINT_MAX - SSD, slid in complemented form (same op count)
             unsigned nwin = ~bias;
 #pragma unroll
@@ -563,6 +651,13 @@ int textureness(const unsigned char *img, long long istep, unsigned char *disp, 
     const float threshold = avg_threshold * (float)(winsz * winsz);   // stereobm.cu:700
     hipLaunchKernelGGL(k_textureness, dim3(div_up(cols, 64), div_up(div_up(rows, 32), 4)), dim3(256), 0, s, img, istep, disp,
                        dstep, rows, cols, winsz, threshold);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int dbg_tmax16(const unsigned *in_dev, unsigned *out_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dbg_tmax16, dim3(1), dim3(64), 0, s, in_dev, out_dev);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

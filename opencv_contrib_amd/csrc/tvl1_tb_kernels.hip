@@ -22,7 +22,6 @@
 #include <cfloat>
 #include <vector>
 #include <cstdlib>
-#include <type_traits>
 
 namespace mi {
 namespace tvl1 {
@@ -128,10 +127,7 @@ __device__ __forceinline__ void lds_get(const float *slot, int lane, Stat<PPL> &
 // One pipeline stage (iteration level t).  `in` = level t-1 row a (u, p), `st` = static row a,
 // `S` = what this stage holds (u_t(a-1), p_(t-1)(a-1)); writes the new held state (row a) to `N`
 // and replaces `in` by level t row a-1.  a, H are wave-uniform (SGPRs).
-// INTERIOR: the wave's strip touches neither image side and its streamed rows stay strictly inside the image, so
-// none of the four border fix-ups can fire: the stage is straight-line code and the scheduler may interleave the T
-// stages of a step (the generic form has 4 scalar branches per stage, each a scheduling barrier).
-template <int PPL, bool INTERIOR = false>
+template <int PPL>
 __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const Dyn<PPL> &S, Dyn<PPL> &N, int a, int H,
                                       bool has_left, bool has_right, bool x_is_zero, const bool right_ok[PPL],
                                       float l_t, float theta, float taut)
@@ -145,7 +141,7 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
     dx2[0] = in.p21[0] - dpp_from_prev(in.p21[PPL - 1]);
 #pragma unroll
     for (int j = 1; j < PPL; ++j) { dx1[j] = in.p11[j] - in.p11[j - 1]; dx2[j] = in.p21[j] - in.p21[j - 1]; }
-    if (!INTERIOR && has_left) {  // first column: no p(x-1) term (optflow tvl1flow.cpp:893-894)
+    if (has_left) {  // first column: no p(x-1) term (optflow tvl1flow.cpp:893-894)
         asm volatile("" ::: "memory");
         if (x_is_zero) { dx1[0] = in.p11[0]; dx2[0] = in.p21[0]; }
     }
@@ -159,7 +155,7 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
         N.u2[j] = fmaf(theta, div2, fmaf(fi, st.iy[j], in.u2[j]));
         N.p11[j] = in.p11[j]; N.p12[j] = in.p12[j]; N.p21[j] = in.p21[j]; N.p22[j] = in.p22[j];
     }
-    if (!INTERIOR && a == H) {  // below the last row: forward y-difference is 0 (optflow tvl1flow.cpp:826-831)
+    if (a == H) {  // below the last row: forward y-difference is 0 (optflow tvl1flow.cpp:826-831)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < PPL; ++j) { N.u1[j] = S.u1[j]; N.u2[j] = S.u2[j]; }
@@ -175,7 +171,7 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
         u1xv[j] = n1 - S.u1[j];
         u2xv[j] = n2 - S.u2[j];
     }
-    if (!INTERIOR && has_right) {  // last column: forward x-difference is 0 (optflow tvl1flow.cpp:833-838)
+    if (has_right) {  // last column: forward x-difference is 0 (optflow tvl1flow.cpp:833-838)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < PPL; ++j) { u1xv[j] = right_ok[j] ? u1xv[j] : 0.f; u2xv[j] = right_ok[j] ? u2xv[j] : 0.f; }
@@ -196,18 +192,18 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
         in.p22[j] = fmaf(taut, u2y, S.p22[j]) * q2;
         in.u1[j] = S.u1[j]; in.u2[j] = S.u2[j];
     }
-    if (!INTERIOR && a <= 0) {  // the emitted row a-1 lies above the image: p(y-1) terms vanish at y == 0 (:889-890)
+    if (a <= 0) {  // the emitted row a-1 lies above the image: p(y-1) terms vanish at y == 0 (:889-890)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < PPL; ++j) in.p12[j] = in.p22[j] = 0.f;
     }
 }
 
-template <int PPL, bool PZ, bool INTERIOR = false>
+template <int PPL, bool PZ>
 __device__ __forceinline__ void load_input_row(Dyn<PPL> &r, Stat<PPL> &st, const TbArgs &A, const float *const u[2],
                                                const float *const p[4], int row, int H, long long xoff, bool xok)
 {
-    const bool ok = INTERIOR ? true : (xok && row >= 0 && row < H);
+    const bool ok = xok && row >= 0 && row < H;
     const long long off = (long long)row * A.g.ld + xoff;
     float g[PPL];
     ldv<PPL>(st.ix, A.pl.ix, off, ok);
@@ -231,7 +227,7 @@ __device__ __forceinline__ void load_input_row(Dyn<PPL> &r, Stat<PPL> &st, const
 }
 
 // One step of the whole pipeline: row `arow` of level 0 enters, row arow-T of level T leaves in `io`.
-template <int T, int PPL, int K, bool INTERIOR = false>
+template <int T, int PPL, int K>
 __device__ __forceinline__ void pipeline_step(Dyn<PPL> &io, const Stat<PPL> &st0, const Dyn<PPL> (&S)[T], Dyn<PPL> (&N)[T],
                                               float *ring, int slot0, int lane, int arow, int H, bool has_left,
                                               bool has_right, bool x_is_zero, const bool right_ok[PPL], float l_t,
@@ -247,7 +243,7 @@ __device__ __forceinline__ void pipeline_step(Dyn<PPL> &io, const Stat<PPL> &st0
             if (sl < 0) sl += K;
             lds_get<PPL>(ring + sl * (256 * PPL), lane, st);
         }
-        stage<PPL, INTERIOR>(io, st, S[t], N[t], arow - t, H, has_left, has_right, x_is_zero, right_ok, l_t, theta, taut);
+        stage<PPL>(io, st, S[t], N[t], arow - t, H, has_left, has_right, x_is_zero, right_ok, l_t, theta, taut);
     }
 }
 
@@ -320,29 +316,22 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
         }
     };
 
-    // rows touched by any stage or load of this wave: ystart - T .. ystart + nsteps + 1
-    const bool interior = !has_left && !has_right && (ystart - T > 0) && (ystart + nsteps + 2 < H);
-    auto run = [&](auto tag) {
-        constexpr bool IN = decltype(tag)::value;
-        for (int s = 0; s < nsteps; s += 2) {
-            // even step: state SA -> SB
-            Dyn<PPL> io = nxt;
-            Stat<PPL> st0 = nst;
-            load_input_row<PPL, PZ, IN>(nxt, nst, B, uin, pin, ystart + s + 1, H, xl, xok);
-            pipeline_step<T, PPL, K, IN>(io, st0, SA, SB, ring, slot0, lane, ystart + s, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
-            emit(io, ystart + s - T);
-            slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
-            // odd step: state SB -> SA (rows past the band end are computed but never stored)
-            io = nxt;
-            st0 = nst;
-            load_input_row<PPL, PZ, IN>(nxt, nst, B, uin, pin, ystart + s + 2, H, xl, xok);
-            pipeline_step<T, PPL, K, IN>(io, st0, SB, SA, ring, slot0, lane, ystart + s + 1, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
-            emit(io, ystart + s + 1 - T);
-            slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
-        }
-    };
-    if (interior) run(std::true_type{});
-    else run(std::false_type{});
+    for (int s = 0; s < nsteps; s += 2) {
+        // even step: state SA -> SB
+        Dyn<PPL> io = nxt;
+        Stat<PPL> st0 = nst;
+        load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart + s + 1, H, xl, xok);
+        pipeline_step<T, PPL, K>(io, st0, SA, SB, ring, slot0, lane, ystart + s, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+        emit(io, ystart + s - T);
+        slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
+        // odd step: state SB -> SA (rows past the band end are computed but never stored)
+        io = nxt;
+        st0 = nst;
+        load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart + s + 2, H, xl, xok);
+        pipeline_step<T, PPL, K>(io, st0, SB, SA, ring, slot0, lane, ystart + s + 1, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+        emit(io, ystart + s + 1 - T);
+        slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
+    }
 }
 
 // ------------------------------------------------------------------ host side

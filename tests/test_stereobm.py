@@ -139,8 +139,23 @@ def test_wave_min_and_tie_break_semantics(gpu):
 
 
 @gpu_mark
+def test_transposed_max16_semantics(gpu):
+    """16 values per lane -> lane j holds max over the 64 lanes of value (j & 15) (DPP quad_perm / row_shl+shr with
+    bank masks / cross-row permutes used by the packed winner-take-all)."""
+    import ctypes as C
+    from opencv_contrib_amd import capi
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, 2 ** 32, size=(16, 64), dtype=np.uint64).astype(np.uint32)
+    inp = (C.c_uint * 1024)(*[int(x) for x in v.reshape(-1)])
+    out = (C.c_uint * 64)()
+    capi.check(capi.lib().mi_dbg_tmax16(inp, out))
+    want = v.max(axis=1)
+    assert [int(out[l]) for l in range(64)] == [int(want[l & 15]) for l in range(64)]
+
+
+@gpu_mark
 @pytest.mark.parametrize("shape,ndisp,winsz", [((60, 200), 32, 9), ((97, 331), 64, 15), ((70, 300), 128, 19),
-                                               ((64, 420), 48, 7), ((80, 400), 256, 5), ((120, 260), 64, 51),
+                                               ((64, 420), 48, 7), ((80, 400), 256, 5), ((120, 260), 64, 51), ((90, 300), 64, 25), ((90, 300), 64, 27), ((75, 290), 128, 11),
                                                ((50, 180), 8, 3)])
 def test_block_match_bit_exact(gpu, oracle, shape, ndisp, winsz):
     h, w = shape
