@@ -35,6 +35,40 @@ def tvl1():
         print(name, "EPE vs analytic truth", synth.epe(flow, gt), st["iters"][0])
 
 
+def stereobm():
+    left, right, _ = synth.stereo_pair(96, 224, seed=42, max_disp=30)
+    for name, kw in {"sbm_96x224_nd64_bs15": dict(num_disparities=64, block_size=15),
+                     "sbm_96x224_nd64_bs9_xsobel_uniq": dict(num_disparities=64, block_size=9, prefilter_type=1, uniqueness_ratio=10),
+                     "sbm_96x224_nd32_bs11_norm_noedge": dict(num_disparities=32, block_size=11, prefilter_type=0, emulate_edge=0,
+                                                              texture_threshold=0.0)}.items():
+        disp = O.sbm_compute(left, right, O.sbm_params(**kw))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), left=left, right=right, disp=disp, params=np.array(json.dumps(kw)))
+        print(name, "nonzero", float((disp > 0).mean()))
+
+
+def farneback():
+    I0, I1, gt = synth.flow_pair(120, 160, seed=1234, dtype="u8")
+    for name, kw in {"fb_u8_120x160_defaults": dict(), "fb_u8_120x160_gauss_poly7": dict(flags=256, poly_n=7, poly_sigma=1.5),
+                     "fb_u8_120x160_fastpyr": dict(fast_pyramids=1, num_levels=3)}.items():
+        flow = O.fb_calc(I0, I1, O.fb_params(**kw))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), I0=I0, I1=I1, flow=flow.astype(np.float32), params=np.array(json.dumps(kw)))
+        print(name, "EPE vs analytic truth", synth.epe(flow[20:-20, 20:-20], gt[20:-20, 20:-20]))
+
+
+def surf():
+    img = synth.blob_image(160, 200, seed=7)
+    for name, kw in {"surf_160x200_thr300": dict(hessian_threshold=300.0, n_octaves=3, keypoints_ratio=0.05),
+                     "surf_160x200_thr300_ext_upright": dict(hessian_threshold=300.0, n_octaves=3, keypoints_ratio=0.05, extended=1, upright=1)}.items():
+        r = O.surf_detect_describe(img, O.surf_params(**kw))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), img=img, x=r["x"], y=r["y"], laplacian=r["laplacian"], octave=r["octave"],
+                            size=r["size"], angle=r["angle"], hessian=r["hessian"], descriptors=r["descriptors"].astype(np.float32),
+                            params=np.array(json.dumps(kw)))
+        print(name, "features", r["n"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     tvl1()
+    stereobm()
+    farneback()
+    surf()
