@@ -10,6 +10,7 @@ struct mi_stereobm {
     // scratch owned by the handle (stereobm.cpp:126: minSSD_, leBuf_, riBuf_)
     unsigned *minssd = nullptr;
     unsigned char *lebuf = nullptr, *ribuf = nullptr;
+    int *tex = nullptr;   // |Sobel| plane of the textureness filter (extended domain)
     int cap_rows = 0, cap_cols = 0;
     long long step = 0;   // bytes per row of lebuf/ribuf; minssd uses step elements
 };
@@ -59,6 +60,7 @@ void mi_stereobm_destroy(mi_stereobm *h)
     if (h->minssd) (void)hipFree(h->minssd);
     if (h->lebuf) (void)hipFree(h->lebuf);
     if (h->ribuf) (void)hipFree(h->ribuf);
+    if (h->tex) (void)hipFree(h->tex);
     delete h;
 }
 
@@ -90,7 +92,8 @@ static int ensure_scratch(mi_stereobm *h, int rows, int cols, bool need_bufs)
         if (h->minssd) (void)hipFree(h->minssd);
         if (h->lebuf) (void)hipFree(h->lebuf);
         if (h->ribuf) (void)hipFree(h->ribuf);
-        h->minssd = nullptr; h->lebuf = h->ribuf = nullptr;
+        if (h->tex) (void)hipFree(h->tex);
+        h->minssd = nullptr; h->lebuf = h->ribuf = nullptr; h->tex = nullptr;
         h->cap_rows = rows; h->cap_cols = cols;
         h->step = align_up(cols, 256);
     }
@@ -134,9 +137,15 @@ int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right,
     if ((rc = sbm::block_match(le, ls, ri, rs, (unsigned char *)disp->data, (long long)disp->step, h->minssd, h->step, rows, cols,
                                P.num_disparities, P.block_size, P.uniqueness_ratio, P.emulate_cuda_edge, st)))
         return rc;
-    if (P.texture_threshold > 0)                                         // stereobm.cpp:189-190
+    if (P.texture_threshold > 0) {                                       // stereobm.cpp:189-190
+        if (!h->tex) {
+            int sld, sh;
+            sbm::textureness_scratch_dims(h->cap_rows, h->cap_cols, &sld, &sh);
+            MI_HIP_TRY(hipMalloc((void **)&h->tex, sizeof(int) * (size_t)sld * sh));
+        }
         rc = sbm::textureness(le, ls, (unsigned char *)disp->data, (long long)disp->step, rows, cols, P.block_size,
-                              P.texture_threshold, st);
+                              P.texture_threshold, h->tex, st);
+    }
     return rc;
 }
 
@@ -184,8 +193,15 @@ int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, float av
     if ((rc = check_u8(img, "input")) || (rc = check_u8(disp, "disparity"))) return rc;
     MI_REQUIRE(img->rows == disp->rows && img->cols == disp->cols, MI_ERR_BAD_SIZE, "size mismatch");
     MI_REQUIRE(winsz % 2 == 1 && winsz / 2 <= 25, MI_ERR_BAD_ARG, "Unsupported window size");
-    return sbm::textureness((const unsigned char *)img->data, (long long)img->step, (unsigned char *)disp->data,
-                            (long long)disp->step, img->rows, img->cols, winsz, avg_texture_threshold, (hipStream_t)stream);
+    int sld, sh;
+    sbm::textureness_scratch_dims(img->rows, img->cols, &sld, &sh);
+    int *S = nullptr;
+    MI_HIP_TRY(hipMalloc((void **)&S, sizeof(int) * (size_t)sld * sh));
+    rc = sbm::textureness((const unsigned char *)img->data, (long long)img->step, (unsigned char *)disp->data,
+                          (long long)disp->step, img->rows, img->cols, winsz, avg_texture_threshold, S, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(S);
+    return rc;
 }
 
 int mi_dbg_tmax16(const unsigned *in_host, unsigned *out_host)

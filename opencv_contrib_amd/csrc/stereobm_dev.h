@@ -15,8 +15,10 @@ int prefilter_xsobel(const unsigned char *src, long long sstep, unsigned char *d
                      int cap, hipStream_t s);
 int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,
                    int cap, int winsize, hipStream_t s);
+// S: int scratch of textureness_scratch_dims() = sld x sh elements
+void textureness_scratch_dims(int rows, int cols, int *sld, int *sh);
 int textureness(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, int rows, int cols,
-                int winsz, float avg_threshold, hipStream_t s);
+                int winsz, float avg_threshold, int *S, hipStream_t s);
 int dbg_wave_min(const unsigned *in_dev, unsigned *out_dev, hipStream_t s);
 int dbg_tmax16(const unsigned *in_dev /*[16][64]*/, unsigned *out_dev /*[64]*/, hipStream_t s);
 

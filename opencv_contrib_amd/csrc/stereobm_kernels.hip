@@ -524,8 +524,21 @@ __device__ __forceinline__ int tex_sobel(const unsigned char *img, long long ste
     return abs(c);
 }
 
-__global__ __launch_bounds__(256) void k_textureness(const unsigned char *img, long long istep, unsigned char *disp,
-                                                     long long dstep, int rows, int cols, int winsz, float threshold)
+// pass 1: S = |x-Sobel of B| on the extended domain x in [-TEX_MX, ...), y in [-TEX_MY, rows + TEX_MY) (coordinates are
+// clamped texel-wise inside tex_box4, exactly like reading the clamp-addressed texture out of range)
+#define TEX_MX 32
+#define TEX_MY 26
+__global__ __launch_bounds__(256) void k_tex_sobel(const unsigned char *img, long long istep, int rows, int cols, int *S, int sld, int sh)
+{
+    const int xe = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ye = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xe >= sld || ye >= sh) return;
+    S[(long long)ye * sld + xe] = tex_sobel(img, istep, rows, cols, xe - TEX_MX, ye - TEX_MY);
+}
+
+// pass 2: winsz x winsz window sums of S by sliding column sums (one wave per 64 columns x 32 rows) + threshold
+__global__ __launch_bounds__(256) void k_textureness(const int *S, int sld, unsigned char *disp, long long dstep, int rows, int cols,
+                                                     int winsz, float threshold)
 {
     __shared__ int colsum[4][64 + 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -535,10 +548,11 @@ __global__ __launch_bounds__(256) void k_textureness(const unsigned char *img, l
     if (yb >= rows) return;
     const int ye = min(yb + 32, rows);
     const int xh = lane < 32 ? blockIdx.x * 64 - 32 + lane : blockIdx.x * 64 + 64 + (lane - 32);
+    const int *S0 = S + (long long)TEX_MY * sld + TEX_MX + x, *S1 = S + (long long)TEX_MY * sld + TEX_MX + xh;
     int s0 = 0, s1 = 0;
     for (int i = -W2; i <= W2; ++i) {
-        s0 += tex_sobel(img, istep, rows, cols, x, yb + i);
-        s1 += tex_sobel(img, istep, rows, cols, xh, yb + i);
+        s0 += S0[(long long)(yb + i) * sld];
+        s1 += S1[(long long)(yb + i) * sld];
     }
     int *cs = colsum[wv];
     for (int y = yb; y < ye; ++y) {
@@ -555,8 +569,8 @@ __global__ __launch_bounds__(256) void k_textureness(const unsigned char *img, l
             }
         }
         __builtin_amdgcn_wave_barrier();
-        s0 += tex_sobel(img, istep, rows, cols, x, y + 1 + W2) - tex_sobel(img, istep, rows, cols, x, y - W2);
-        s1 += tex_sobel(img, istep, rows, cols, xh, y + 1 + W2) - tex_sobel(img, istep, rows, cols, xh, y - W2);
+        s0 += S0[(long long)(y + 1 + W2) * sld] - S0[(long long)(y - W2) * sld];
+        s1 += S1[(long long)(y + 1 + W2) * sld] - S1[(long long)(y - W2) * sld];
     }
 }
 
@@ -607,11 +621,11 @@ int block_match(const unsigned char *left, long long lstep, const unsigned char 
     A.nsets = div_up(ndisp, 64);
     A.emulate_edge = emulate_edge;
     A.thresh_scale = (float)(1.0 + uniqueness_ratio / 100.0f);
-    // rows per band: enough waves for the 1024 SIMDs (target ~3 per SIMD) but keep the 2R-row start-up
+    // rows per band: enough waves for the 1024 SIMDs (target ~5 per SIMD) but keep the 2R-row start-up
     // of every band (column sums of the first window) a modest fraction of the work
     const int xt = div_up(cols - ndisp - 2 * R, tile_w_of(R));
     const int vrows = rows - 2 * R;
-    int bands = div_up(3072, xt * A.nsets);
+    int bands = div_up(5120, xt * A.nsets);   // r01f sweep: ~16 rows per band is the optimum at 1080p / 128 disparities
     int rb = div_up(vrows, bands > 0 ? bands : 1);
     rb = rb < 2 * R + 2 ? 2 * R + 2 : rb;
     rb = rb > 96 ? 96 : rb;
@@ -645,11 +659,20 @@ int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst
     return MI_OK;
 }
 
+void textureness_scratch_dims(int rows, int cols, int *sld, int *sh)
+{
+    *sld = align_up(cols, 64) + 2 * TEX_MX;
+    *sh = rows + 2 * TEX_MY;
+}
+
 int textureness(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, int rows, int cols,
-                int winsz, float avg_threshold, hipStream_t s)
+                int winsz, float avg_threshold, int *S, hipStream_t s)
 {
     const float threshold = avg_threshold * (float)(winsz * winsz);   // stereobm.cu:700
-    hipLaunchKernelGGL(k_textureness, dim3(div_up(cols, 64), div_up(div_up(rows, 32), 4)), dim3(256), 0, s, img, istep, disp,
+    int sld, sh;
+    textureness_scratch_dims(rows, cols, &sld, &sh);
+    hipLaunchKernelGGL(k_tex_sobel, dim3(div_up(sld, 64), div_up(sh, 4)), dim3(256), 0, s, img, istep, rows, cols, S, sld, sh);
+    hipLaunchKernelGGL(k_textureness, dim3(div_up(cols, 64), div_up(div_up(rows, 32), 4)), dim3(256), 0, s, (const int *)S, sld, disp,
                        dstep, rows, cols, winsz, threshold);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -15,8 +15,10 @@ int det_trace(const unsigned *sum, int sld, int rows, int cols, int octave, int 
 int find_maxima(const float *det, const float *trace, int dld, const unsigned *mask_sum, int sld, int rows, int cols, int octave,
                 int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, int4 *cand, int max_candidates,
                 unsigned *ncand, hipStream_t s);
-int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, float *kp, int kld,
-                int max_features, unsigned *nfeat, hipStream_t s);
+// tmp: interp_tmp_bytes(max_candidates) bytes of scratch
+int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, int max_candidates,
+                void *tmp, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s);
+size_t interp_tmp_bytes(int max_candidates);
 // nfeat_dev != nullptr: count read on the device (grid sized for n_or_max); else n_or_max features
 int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int kld, const unsigned *nfeat_dev, int n_or_max,
                 bool upright, const float *apt /* [3][113] x, y, w */, hipStream_t s);

@@ -281,85 +281,89 @@ __device__ __forceinline__ bool solve3x3(const float A[3][3], const float b[3], 
     return false;
 }
 
-// surf.cu:391-493: one thread per candidate (ONE block of 1024 threads, candidates strided) -> accepted features
-// compacted in candidate order behind the features of the previous octaves.
-__global__ __launch_bounds__(1024) void k_interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
-                                                      const unsigned *ncand_p, float *kp, int kld, int max_features,
-                                                      unsigned *nfeat_p)
+// surf.cu:391-493, pass 1: one thread per candidate (any number of workgroups) evaluates the 3-D quadratic refinement and
+// stores {ok, x, y, size, hessian} at the candidate's index; pass 2 (k_interp_compact, one workgroup) scans the ok flags and
+// appends the accepted features in candidate order behind the features of the previous octaves.
+struct InterpOut { float px, py, psize, hess; int lap, ok; };
+
+__global__ __launch_bounds__(256) void k_interp_eval(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
+                                                     const unsigned *ncand_p, InterpOut *tmp)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= (int)*ncand_p) return;
+    const int layer_rows = rows >> octave;
+    const int4 mp = cand[c];
+    float N9[3][3][3];
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+#pragma unroll
+        for (int y = 0; y < 3; ++y)
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+                N9[z][y][x] = det[(long long)(layer_rows * (mp.z - 1 + z) + mp.y - 1 + y) * dld + mp.x - 1 + x];
+    float dD[3], H[3][3], xs[3];
+    dD[0] = -0.5f * (N9[1][1][2] - N9[1][1][0]);
+    dD[1] = -0.5f * (N9[1][2][1] - N9[1][0][1]);
+    dD[2] = -0.5f * (N9[2][1][1] - N9[0][1][1]);
+    H[0][0] = N9[1][1][0] - 2.0f * N9[1][1][1] + N9[1][1][2];
+    H[0][1] = 0.25f * (N9[1][2][2] - N9[1][2][0] - N9[1][0][2] + N9[1][0][0]);
+    H[0][2] = 0.25f * (N9[2][1][2] - N9[2][1][0] - N9[0][1][2] + N9[0][1][0]);
+    H[1][0] = H[0][1];
+    H[1][1] = N9[1][0][1] - 2.0f * N9[1][1][1] + N9[1][2][1];
+    H[1][2] = 0.25f * (N9[2][2][1] - N9[2][0][1] - N9[0][2][1] + N9[0][0][1]);
+    H[2][0] = H[0][2];
+    H[2][1] = H[1][2];
+    H[2][2] = N9[0][1][1] - 2.0f * N9[1][1][1] + N9[2][1][1];
+    bool ok = solve3x3(H, dD, xs);
+    ok = ok && fabsf(xs[0]) <= 1.f && fabsf(xs[1]) <= 1.f && fabsf(xs[2]) <= 1.f;
+    InterpOut o;
+    o.px = o.py = o.psize = 0.f; o.hess = N9[1][1][1]; o.lap = mp.w; o.ok = 0;
+    if (ok) {
+        const int size = calc_size(octave, mp.z);
+        const int sum_i = (mp.y - ((size >> 1) >> octave)) << octave, sum_j = (mp.x - ((size >> 1) >> octave)) << octave;
+        const float center_i = sum_i + (float)(size - 1) / 2, center_j = sum_j + (float)(size - 1) / 2;
+        o.px = center_j + xs[0] * (1 << octave);
+        o.py = center_i + xs[1] * (1 << octave);
+        const int ds = size - calc_size(octave, mp.z - 1);
+        o.psize = roundf(size + xs[2] * ds);
+        const float sc = o.psize * 1.2f / 9.0f;
+        const int grad_wav_size = 2 * rn(2.0f * sc);
+        ok = (rows + 1) >= grad_wav_size && (cols + 1) >= grad_wav_size;
+    }
+    o.ok = ok ? 1 : 0;
+    tmp[c] = o;
+}
+
+__global__ __launch_bounds__(1024) void k_interp_compact(const InterpOut *tmp, const unsigned *ncand_p, int octave, float *kp, int kld,
+                                                         int max_features, unsigned *nfeat_p)
 {
     __shared__ unsigned part[1024];
-    const int layer_rows = rows >> octave;
     const unsigned ncand = *ncand_p, nfeat0 = *nfeat_p;
     const int per = (int)(ncand + 1023) / 1024;
     const int b = threadIdx.x * per, e = min(b + per, (int)ncand);
-    // pass 1: count accepted candidates of this thread's contiguous range; pass 2: write
-    for (int pass = 0; pass < 2; ++pass) {
-        unsigned run = 0;
-        if (pass == 1) run = nfeat0 + (threadIdx.x ? part[threadIdx.x - 1] : 0u);
-        unsigned cnt = 0;
-        for (int c = b; c < e; ++c) {
-            const int4 mp = cand[c];
-            float N9[3][3][3];
-#pragma unroll
-            for (int z = 0; z < 3; ++z)
-#pragma unroll
-                for (int y = 0; y < 3; ++y)
-#pragma unroll
-                    for (int x = 0; x < 3; ++x)
-                        N9[z][y][x] = det[(long long)(layer_rows * (mp.z - 1 + z) + mp.y - 1 + y) * dld + mp.x - 1 + x];
-            float dD[3], H[3][3], xs[3];
-            dD[0] = -0.5f * (N9[1][1][2] - N9[1][1][0]);
-            dD[1] = -0.5f * (N9[1][2][1] - N9[1][0][1]);
-            dD[2] = -0.5f * (N9[2][1][1] - N9[0][1][1]);
-            H[0][0] = N9[1][1][0] - 2.0f * N9[1][1][1] + N9[1][1][2];
-            H[0][1] = 0.25f * (N9[1][2][2] - N9[1][2][0] - N9[1][0][2] + N9[1][0][0]);
-            H[0][2] = 0.25f * (N9[2][1][2] - N9[2][1][0] - N9[0][1][2] + N9[0][1][0]);
-            H[1][0] = H[0][1];
-            H[1][1] = N9[1][0][1] - 2.0f * N9[1][1][1] + N9[1][2][1];
-            H[1][2] = 0.25f * (N9[2][2][1] - N9[2][0][1] - N9[0][2][1] + N9[0][0][1]);
-            H[2][0] = H[0][2];
-            H[2][1] = H[1][2];
-            H[2][2] = N9[0][1][1] - 2.0f * N9[1][1][1] + N9[2][1][1];
-            bool ok = solve3x3(H, dD, xs);
-            ok = ok && fabsf(xs[0]) <= 1.f && fabsf(xs[1]) <= 1.f && fabsf(xs[2]) <= 1.f;
-            float px = 0, py = 0, psize = 0;
-            if (ok) {
-                const int size = calc_size(octave, mp.z);
-                const int sum_i = (mp.y - ((size >> 1) >> octave)) << octave, sum_j = (mp.x - ((size >> 1) >> octave)) << octave;
-                const float center_i = sum_i + (float)(size - 1) / 2, center_j = sum_j + (float)(size - 1) / 2;
-                px = center_j + xs[0] * (1 << octave);
-                py = center_i + xs[1] * (1 << octave);
-                const int ds = size - calc_size(octave, mp.z - 1);
-                psize = roundf(size + xs[2] * ds);
-                const float s = psize * 1.2f / 9.0f;
-                const int grad_wav_size = 2 * rn(2.0f * s);
-                ok = (rows + 1) >= grad_wav_size && (cols + 1) >= grad_wav_size;
-            }
-            if (ok) {
-                if (pass == 1) {
-                    const unsigned ind = run + cnt;
-                    if (ind < (unsigned)max_features) {
-                        kp[0 * kld + ind] = px;
-                        kp[1 * kld + ind] = py;
-                        reinterpret_cast<int *>(kp)[2 * kld + ind] = mp.w;     // LAPLACIAN_ROW holds int bit patterns (cuda.hpp:89-99)
-                        reinterpret_cast<int *>(kp)[3 * kld + ind] = octave;
-                        kp[4 * kld + ind] = psize;
-                        kp[6 * kld + ind] = N9[1][1][1];
-                    }
-                }
-                ++cnt;
-            }
+    unsigned cnt = 0;
+    for (int c = b; c < e; ++c) cnt += (unsigned)tmp[c].ok;
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned ind = nfeat0 + (threadIdx.x ? part[threadIdx.x - 1] : 0u);
+    for (int c = b; c < e; ++c) {
+        const InterpOut o = tmp[c];
+        if (!o.ok) continue;
+        if (ind < (unsigned)max_features) {
+            kp[0 * kld + ind] = o.px;
+            kp[1 * kld + ind] = o.py;
+            reinterpret_cast<int *>(kp)[2 * kld + ind] = o.lap;     // LAPLACIAN_ROW holds int bit patterns (cuda.hpp:89-99)
+            reinterpret_cast<int *>(kp)[3 * kld + ind] = octave;
+            kp[4 * kld + ind] = o.psize;
+            kp[6 * kld + ind] = o.hess;
         }
-        if (pass == 0) {
-            part[threadIdx.x] = cnt;
-            __syncthreads();
-            for (int off = 1; off < 1024; off <<= 1) {
-                unsigned v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-                __syncthreads();
-                part[threadIdx.x] += v;
-                __syncthreads();
-            }
-        }
+        ++ind;
     }
     __syncthreads();
     if (threadIdx.x == 0) *nfeat_p = min(nfeat0 + part[1023], (unsigned)max_features);
@@ -474,6 +478,20 @@ __device__ float linear_filter(const Win &w, float y, float x)   // surf.cl:873-
     out = out + win_get(w, y2, x2) * ((x - x1) * (y - y1));
     return out;
 }
+// sum_{dx in [a, b)} win_get(w, dy, dx) * wgt accumulated onto `out` in ascending dx order (the reference's order);
+// the texel reads of 8 consecutive dx are issued together so their latencies overlap (the adds stay sequential)
+__device__ __forceinline__ float row_accum(const Win &w, int dy, int a, int b, float wgt, float out)
+{
+    for (int dx = a; dx < b; dx += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = win_get(w, dy, min(dx + k, b - 1));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (dx + k < b) out = out + v[k] * wgt;
+    }
+    return out;
+}
+
 __device__ float area_filter(const Win &w, float x, float y, float s)   // surf.cl:900-952
 {
     const float fsx1 = x * s, fsx2 = fsx1 + s;
@@ -483,12 +501,12 @@ __device__ float area_filter(const Win &w, float x, float y, float s)   // surf.
     const float scale = 1.f / (s * s);
     float out = 0.f;
     for (int dy = sy1; dy < sy2; ++dy) {
-        for (int dx = sx1; dx < sx2; ++dx) out = out + win_get(w, dy, dx) * scale;
+        out = row_accum(w, dy, sx1, sx2, scale, out);
         if (sx1 > fsx1) out = out + win_get(w, dy, sx1 - 1) * ((sx1 - fsx1) * scale);
         if (sx2 < fsx2) out = out + win_get(w, dy, sx2) * ((fsx2 - sx2) * scale);
     }
-    if (sy1 > fsy1) for (int dx = sx1; dx < sx2; ++dx) out = out + win_get(w, sy1 - 1, dx) * ((sy1 - fsy1) * scale);
-    if (sy2 < fsy2) for (int dx = sx1; dx < sx2; ++dx) out = out + win_get(w, sy2, dx) * ((fsy2 - sy2) * scale);
+    if (sy1 > fsy1) out = row_accum(w, sy1 - 1, sx1, sx2, (sy1 - fsy1) * scale, out);
+    if (sy2 < fsy2) out = row_accum(w, sy2, sx1, sx2, (fsy2 - sy2) * scale, out);
     if ((sy1 > fsy1) && (sx1 > fsx1)) out = out + win_get(w, sy1 - 1, sx1 - 1) * ((sy1 - fsy1) * (sx1 - fsx1) * scale);
     if ((sy1 > fsy1) && (sx2 < fsx2)) out = out + win_get(w, sy1 - 1, sx2) * ((sy1 - fsy1) * (fsx2 - sx2) * scale);
     if ((sy2 < fsy2) && (sx2 < fsx2)) out = out + win_get(w, sy2, sx2) * ((fsy2 - sy2) * (fsx2 - sx2) * scale);
@@ -606,13 +624,16 @@ int find_maxima(const float *det, const float *trace, int dld, const unsigned *m
     return MI_OK;
 }
 
-int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, float *kp, int kld,
-                int max_features, unsigned *nfeat, hipStream_t s)
+int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, int max_candidates,
+                void *tmp, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_interpolate, dim3(1), dim3(1024), 0, s, det, dld, rows, cols, octave, cand, ncand, kp, kld, max_features, nfeat);
+    hipLaunchKernelGGL(k_interp_eval, dim3(div_up(max_candidates, 256)), dim3(256), 0, s, det, dld, rows, cols, octave, cand, ncand,
+                       (InterpOut *)tmp);
+    hipLaunchKernelGGL(k_interp_compact, dim3(1), dim3(1024), 0, s, (const InterpOut *)tmp, ncand, octave, kp, kld, max_features, nfeat);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
+size_t interp_tmp_bytes(int max_candidates) { return sizeof(InterpOut) * (size_t)max_candidates; }
 
 int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int kld, const unsigned *nfeat_dev, int n_or_max,
                 bool upright, const float *apt, hipStream_t s)
