@@ -17,11 +17,21 @@
 // (modules/optflow/src/tvl1flow.cpp); fast-math variants use explicit fmaf/rcp.
 #include "tvl1_dev.h"
 #include <cfloat>
+#include <cstdlib>
 
 namespace mi {
 namespace tvl1 {
 
 // ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ float4 ld4(const float *p, long long off, bool ok)
+{
+    return ok ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void st4(float *p, long long off, bool ok, const float v[4])
+{
+    if (ok) *reinterpret_cast<float4 *>(p + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+#define UNPACK4(dst, v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
 __device__ __forceinline__ float lane_prev(float v) { return __shfl_up(v, 1); }   // lane n <- n-1
 __device__ __forceinline__ float lane_next(float v) { return __shfl_down(v, 1); } // lane n <- n+1
 
@@ -317,6 +327,127 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host
     A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
 }
 
+// ------------------------------------------------------------------ warp, 4 pixels per lane (CPU_REF semantics)
+// Same arithmetic as k_warp<CPU_REF>, reorganised for the texture-addresser: a lane owns 4 consecutive pixels; when
+// their bicubic windows are the common "rigid" case (same first row, first columns sx0, sx0+1, sx0+2, sx0+3 -- any
+// locally smooth flow) the union footprint of 7 x 4 float4 {I1, I1x, I1y} elements is loaded ONCE per row (7 gathers
+// instead of 16 per row) and every pixel takes its 4-wide sub-window from registers; u1, u2, I0 and the four outputs
+// move as dwordx4.  Pixels whose windows are not rigid, or touch the border, take the per-pixel path.
+__device__ __forceinline__ void warp_px_generic(const float4 *P, int W, int H, int ld, int sx, int sy, const float w[16],
+                                                float &v0, float &v1, float &v2)
+{
+    if ((unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0)) {
+        const float4 *S = P + (long long)sy * ld + sx;
+        float4 a = S[0], b4 = S[1], c = S[2], d = S[3];
+        float s0 = a.x * w[0] + b4.x * w[1] + c.x * w[2] + d.x * w[3];
+        float s1 = a.y * w[0] + b4.y * w[1] + c.y * w[2] + d.y * w[3];
+        float s2 = a.z * w[0] + b4.z * w[1] + c.z * w[2] + d.z * w[3];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            S += ld; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
+            s0 += a.x * w[4 * r] + b4.x * w[4 * r + 1] + c.x * w[4 * r + 2] + d.x * w[4 * r + 3];
+            s1 += a.y * w[4 * r] + b4.y * w[4 * r + 1] + c.y * w[4 * r + 2] + d.y * w[4 * r + 3];
+            s2 += a.z * w[4 * r] + b4.z * w[4 * r + 1] + c.z * w[4 * r + 2] + d.z * w[4 * r + 3];
+        }
+        v0 = s0; v1 = s1; v2 = s2;
+    } else if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
+        v0 = v1 = v2 = 0.f;
+    } else {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int yi = sy + i;
+            if (yi < 0 || yi >= H) continue;
+            for (int j = 0; j < 4; ++j) {
+                const int xj = sx + j;
+                if (xj < 0 || xj >= W) continue;
+                const float4 t = P[(long long)yi * ld + xj];
+                s0 += (t.x - 0.f) * w[i * 4 + j];
+                s1 += (t.y - 0.f) * w[i * 4 + j];
+                s2 += (t.z - 0.f) * w[i * 4 + j];
+            }
+        }
+        v0 = s0; v1 = s1; v2 = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_warp4(WarpArgs A, CtlK ctl, int cur_host)
+{
+    __shared__ float s_tab[128];
+    if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
+    __syncthreads();
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    if (x0 >= W || y >= H) return;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const long long pb = (long long)b * A.g.ps;
+    const long long o = pb + (long long)y * ld + x0;   // rows are padded to ld (multiple of 64 floats): float4 access is in bounds
+    const float4 *P = A.pk + pb;
+    float u1v[4], u2v[4], i0v[4];
+    { const float4 t = *reinterpret_cast<const float4 *>(A.u1[cur] + o); UNPACK4(u1v, t); }
+    { const float4 t = *reinterpret_cast<const float4 *>(A.u2[cur] + o); UNPACK4(u2v, t); }
+    { const float4 t = *reinterpret_cast<const float4 *>(A.I0 + o); UNPACK4(i0v, t); }
+    int sx[4], sy[4], px[4], py[4];
+    bool rigid = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // buildFlowMap + cv::remap(INTER_CUBIC): map quantised to 1/32 px (optflow/src/tvl1flow.cpp:650-666,1371-1374)
+        const bool valid = x0 + j < W;
+        const float mx = (float)(x0 + j) + (valid ? u1v[j] : 0.f), my = (float)y + (valid ? u2v[j] : 0.f);
+        const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+        sx[j] = min(max(qx >> 5, -32768), 32767) - 1;
+        sy[j] = min(max(qy >> 5, -32768), 32767) - 1;
+        px[j] = (qx & 31) * 4; py[j] = (qy & 31) * 4;
+        if (valid) rigid = rigid && sy[j] == sy[0] && sx[j] == sx[0] + j;
+    }
+    rigid = rigid && (unsigned)sx[0] < (unsigned)max(W - 6, 0) && (unsigned)sy[0] < (unsigned)max(H - 3, 0);
+    float v0[4], v1[4], v2[4];
+    if (rigid) {
+        const float4 *S = P + (long long)sy[0] * ld + sx[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 t[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) t[k] = S[k];
+            S += ld;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float wy = s_tab[py[j] + r];
+                const float w0 = wy * s_tab[px[j]], w1 = wy * s_tab[px[j] + 1], w2 = wy * s_tab[px[j] + 2], w3 = wy * s_tab[px[j] + 3];
+                const float e0 = t[j].x * w0 + t[j + 1].x * w1 + t[j + 2].x * w2 + t[j + 3].x * w3;
+                const float e1 = t[j].y * w0 + t[j + 1].y * w1 + t[j + 2].y * w2 + t[j + 3].y * w3;
+                const float e2 = t[j].z * w0 + t[j + 1].z * w1 + t[j + 2].z * w2 + t[j + 3].z * w3;
+                if (r == 0) { v0[j] = e0; v1[j] = e1; v2[j] = e2; }
+                else { v0[j] += e0; v1[j] += e1; v2[j] += e2; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w[16];
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) w[k1 * 4 + k2] = s_tab[py[j] + k1] * s_tab[px[j] + k2];
+            warp_px_generic(P, W, H, ld, sx[j], sy[j], w, v0[j], v1[j], v2[j]);
+        }
+    }
+    float g[4], rh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // calcGradRho  optflow/src/tvl1flow.cpp:918-944
+        const float Ix2 = v1[j] * v1[j], Iy2 = v2[j] * v2[j];
+        g[j] = Ix2 + Iy2;
+        rh[j] = (v0[j] - v1[j] * u1v[j] - v2[j] * u2v[j] - i0v[j]);
+    }
+    if (A.I1w) st4(A.I1w, o, true, v0);
+    st4(A.I1wx, o, true, v1);
+    st4(A.I1wy, o, true, v2);
+    st4(A.grad, o, true, g);
+    st4(A.rho, o, true, rh);
+}
+
 // ------------------------------------------------------------------ fused iteration
 // Per-pixel math.  EXACT: the CPU reference's operations (optflow/src/tvl1flow.cpp:989-1041
 // estimateV, :857-899 divergence, :1096-1112 estimateU, :1140-1181 dual update with hypot in
@@ -381,21 +512,12 @@ struct IterArgs {
 
 #define STRIP_W 252  // 63 lanes x 4 px own results; lane 63 only supplies u_new(x+1) to lane 62
 
-__device__ __forceinline__ float4 ld4(const float *p, long long off, bool ok)
-{
-    return ok ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ void st4(float *p, long long off, bool ok, const float v[4])
-{
-    if (ok) *reinterpret_cast<float4 *>(p + off) = make_float4(v[0], v[1], v[2], v[3]);
-}
 
 struct RowIn {
     float ix[4], iy[4], g[4], rc[4], u1[4], u2[4], p11[4], p12[4], p21[4], p22[4];
     float u3[4], p31[4], p32[4];   // gamma != 0 only
 };
 
-#define UNPACK4(dst, v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
 
 template <bool PZ, bool GAMMA = false>
 __device__ __forceinline__ void load_row(RowIn &r, const IterArgs &A, const float *const u[3], const float *const p[6],
@@ -709,7 +831,9 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
     A.tab = cubic_tab_dev;
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
-    if (semantics == MI_SEM_CPU_REF)
+    if (semantics == MI_SEM_CPU_REF && !getenv("MIFLOW_WARP1"))
+        hipLaunchKernelGGL(k_warp4, dim3(div_up(g.w, 256), div_up(g.h, 4), g.batch), dim3(256), 0, s, A, ck, cur_host);
+    else if (semantics == MI_SEM_CPU_REF)
         hipLaunchKernelGGL(k_warp<MI_SEM_CPU_REF>, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
     else
         hipLaunchKernelGGL(k_warp<MI_SEM_CUDA_COMPAT>, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
