@@ -482,13 +482,15 @@ __device__ float linear_filter(const Win &w, float y, float x)   // surf.cl:873-
 // the texel reads of 8 consecutive dx are issued together so their latencies overlap (the adds stay sequential)
 __device__ __forceinline__ float row_accum(const Win &w, int dy, int a, int b, float wgt, float out)
 {
-    for (int dx = a; dx < b; dx += 8) {
+    int dx = a;
+    for (; dx + 8 <= b; dx += 8) {
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = win_get(w, dy, min(dx + k, b - 1));
+        for (int k = 0; k < 8; ++k) v[k] = win_get(w, dy, dx + k);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (dx + k < b) out = out + v[k] * wgt;
+        for (int k = 0; k < 8; ++k) out = out + v[k] * wgt;
     }
+    for (; dx < b; ++dx) out = out + win_get(w, dy, dx) * wgt;
     return out;
 }
 
@@ -514,16 +516,18 @@ __device__ float area_filter(const Win &w, float x, float y, float s)   // surf.
     return out;
 }
 
-// surf.cu:733-912: one workgroup (4 waves) per feature: 21x21 patch -> 16 sub-regions of 25 weighted Haar responses,
-// 32-lane trees (two per wave) -> 64 or 128 sums -> L2 normalisation.
+// surf.cu:733-912: one workgroup (8 waves) per feature: 21x21 patch (one sample per thread) -> 16 sub-regions of 25
+// weighted Haar responses, one 32-lane tree per half-wave -> 64 or 128 sums -> L2 normalisation.
 template <bool EXT>
-__global__ __launch_bounds__(256) void k_descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
+__global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
                                                      int kld, int nfeat, float *desc, long long dstep /* floats */, const float *dw)
 {
     __shared__ float P[21][21];
     __shared__ float D[128];
-    const int f = blockIdx.x;
-    if (f >= nfeat) return;
+    // features are ordered by octave, i.e. by patch cost (441 x s^2 texel reads, s up to ~29 at 4 octaves): launch the
+    // expensive ones first so they do not form the tail of the grid
+    const int f = nfeat - 1 - (int)blockIdx.x;
+    if (f < 0) return;
     Win w;
     w.img = img; w.step = istep; w.rows = rows; w.cols = cols; w.cx = kp[f]; w.cy = kp[kld + f];
     const float s = kp[4 * kld + f] * 1.2f / 9.0f;
@@ -533,15 +537,15 @@ __global__ __launch_bounds__(256) void k_descriptors(const unsigned char *img, l
     if (fabsf(ddir - 360.f) < FLT_EPSILON) ddir = 0.f;
     ddir *= CV_PI_F / 180.0f;
     sincosf(ddir, &w.s, &w.c);
-    for (int tid = threadIdx.x; tid < 441; tid += 256) {
-        const int xl = tid % 21, yl = tid / 21;
+    if (threadIdx.x < 441) {
+        const int tid = threadIdx.x, xl = tid % 21, yl = tid / 21;
         P[yl][xl] = s > 1 ? area_filter(w, (float)xl, (float)yl, s) : linear_filter(w, yl * s, xl * s);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tx = lane & 31, half = lane >> 5;
-    for (int rep = 0; rep < 2; ++rep) {
-        const int ty = rep * 8 + wv * 2 + half;    // sub-region 0..15 (threadIdx.y of the reference)
+    {
+        const int ty = wv * 2 + half;    // sub-region 0..15 (threadIdx.y of the reference)
         const int xb = ty % 4, yb = ty / 4;
         float dx = 0.f, dy = 0.f;
         const int xp = tx % 5, yp = tx / 5;
@@ -653,8 +657,8 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
                 float *desc, long long dstep_floats, const float *dw, hipStream_t s)
 {
     if (nfeat <= 0) return MI_OK;
-    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(nfeat), dim3(256), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
-    else hipLaunchKernelGGL(k_descriptors<false>, dim3(nfeat), dim3(256), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
+    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
+    else hipLaunchKernelGGL(k_descriptors<false>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
