@@ -18,6 +18,7 @@
 #include "tvl1_dev.h"
 #include <cfloat>
 #include <cstdlib>
+#include <climits>
 
 namespace mi {
 namespace tvl1 {
@@ -448,6 +449,94 @@ __global__ __launch_bounds__(256) void k_warp4(WarpArgs A, CtlK ctl, int cur_hos
     st4(A.rho, o, true, rh);
 }
 
+// ------------------------------------------------------------------ warp through an LDS tile (CPU_REF semantics)
+// Same arithmetic as k_warp<CPU_REF>.  The 16 gathers per pixel of k_warp are bound by the texture addresser
+// (~4 lanes/clk per wave-load, r01a/r01g profiles: 269 us/launch).  Here a workgroup (4 rows x 64 px) first finds the
+// bounding box of all its bicubic windows (wave min/max + LDS), stages that box of {I1, I1x, I1y} float4 elements into
+// LDS with coalesced 16-B loads, and every pixel reads its 16 taps with ds_read_b128.  Workgroups whose box does not fit
+// the tile (large or discontinuous motion) and pixels whose window leaves the image take the per-pixel global path.
+#define WT_W 88   // tile columns  (64 px + 3 + 21 px of horizontal motion spread)
+#define WT_H 16   // tile rows     (4 rows + 3 + 9 rows of vertical motion spread)
+__global__ __launch_bounds__(256) void k_warp_lds(WarpArgs A, CtlK ctl, int cur_host)
+{
+    __shared__ float s_tab[128];
+    __shared__ int s_mm[4][4];
+    __shared__ float4 s_tile[WT_H * WT_W];
+    if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + wv;
+    const int b = blockIdx.z;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    const bool valid = x < W && y < H;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const long long pb = (long long)b * A.g.ps;
+    const long long o = pb + (long long)min(y, H - 1) * ld + min(x, W - 1);
+    const float4 *P = A.pk + pb;
+    const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
+    // buildFlowMap + cv::remap(INTER_CUBIC): map quantised to 1/32 px (optflow/src/tvl1flow.cpp:650-666,1371-1374)
+    const float mx = (float)x + u1v, my = (float)y + u2v;
+    const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+    const int sx = min(max(qx >> 5, -32768), 32767) - 1;
+    const int sy = min(max(qy >> 5, -32768), 32767) - 1;
+    const bool inside = valid && (unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0);
+    // bounding box of the windows that lie inside the image
+    int mnx = inside ? sx : INT_MAX, mxx = inside ? sx : INT_MIN, mny = inside ? sy : INT_MAX, mxy = inside ? sy : INT_MIN;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, off)); mxx = max(mxx, __shfl_xor(mxx, off));
+        mny = min(mny, __shfl_xor(mny, off)); mxy = max(mxy, __shfl_xor(mxy, off));
+    }
+    if (lane == 0) { s_mm[wv][0] = mnx; s_mm[wv][1] = mxx; s_mm[wv][2] = mny; s_mm[wv][3] = mxy; }
+    __syncthreads();
+    const int tx0 = min(min(s_mm[0][0], s_mm[1][0]), min(s_mm[2][0], s_mm[3][0]));
+    const int tx1 = max(max(s_mm[0][1], s_mm[1][1]), max(s_mm[2][1], s_mm[3][1]));
+    const int ty0 = min(min(s_mm[0][2], s_mm[1][2]), min(s_mm[2][2], s_mm[3][2]));
+    const int ty1 = max(max(s_mm[0][3], s_mm[1][3]), max(s_mm[2][3], s_mm[3][3]));
+    const bool any_inside = tx1 >= tx0;
+    const int tw = any_inside ? tx1 + 4 - tx0 : 0, th = any_inside ? ty1 + 4 - ty0 : 0;
+    const bool use_tile = any_inside && tw <= WT_W && th <= WT_H;   // workgroup-uniform
+    if (use_tile) {
+        for (int i = threadIdx.x; i < th * tw; i += 256) {
+            const int r = i / tw, c = i - r * tw;
+            s_tile[r * WT_W + c] = P[(long long)(ty0 + r) * ld + tx0 + c];   // inside the image by construction
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
+    const float *wxp = s_tab + (qx & 31) * 4, *wyp = s_tab + (qy & 31) * 4;
+    float w[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) w[k1 * 4 + k2] = wyp[k1] * wxp[k2];
+    float v0, v1, v2;
+    if (use_tile && inside) {
+        const float4 *S = s_tile + (sy - ty0) * WT_W + (sx - tx0);
+        float4 a = S[0], b4 = S[1], c = S[2], d = S[3];
+        float s0 = a.x * w[0] + b4.x * w[1] + c.x * w[2] + d.x * w[3];
+        float s1 = a.y * w[0] + b4.y * w[1] + c.y * w[2] + d.y * w[3];
+        float s2 = a.z * w[0] + b4.z * w[1] + c.z * w[2] + d.z * w[3];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            S += WT_W; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
+            s0 += a.x * w[4 * r] + b4.x * w[4 * r + 1] + c.x * w[4 * r + 2] + d.x * w[4 * r + 3];
+            s1 += a.y * w[4 * r] + b4.y * w[4 * r + 1] + c.y * w[4 * r + 2] + d.y * w[4 * r + 3];
+            s2 += a.z * w[4 * r] + b4.z * w[4 * r + 1] + c.z * w[4 * r + 2] + d.z * w[4 * r + 3];
+        }
+        v0 = s0; v1 = s1; v2 = s2;
+    } else {
+        warp_px_generic(P, W, H, ld, sx, sy, w, v0, v1, v2);
+    }
+    if (A.I1w) A.I1w[o] = v0;
+    A.I1wx[o] = v1;
+    A.I1wy[o] = v2;
+    // calcGradRho  optflow/src/tvl1flow.cpp:918-944
+    const float Ix2 = v1 * v1, Iy2 = v2 * v2;
+    A.grad[o] = Ix2 + Iy2;
+    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
+}
+
 // ------------------------------------------------------------------ fused iteration
 // Per-pixel math.  EXACT: the CPU reference's operations (optflow/src/tvl1flow.cpp:989-1041
 // estimateV, :857-899 divergence, :1096-1112 estimateU, :1140-1181 dual update with hypot in
@@ -831,8 +920,11 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
     A.tab = cubic_tab_dev;
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
-    if (semantics == MI_SEM_CPU_REF && !getenv("MIFLOW_WARP1"))
+    static const char *wsel = getenv("MIFLOW_WARP");   // tuning: "4" = 4 px/lane (measured slower, r01h), "1" = per-pixel gathers
+    if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == '4')
         hipLaunchKernelGGL(k_warp4, dim3(div_up(g.w, 256), div_up(g.h, 4), g.batch), dim3(256), 0, s, A, ck, cur_host);
+    else if (semantics == MI_SEM_CPU_REF && !(wsel && wsel[0] == '1'))
+        hipLaunchKernelGGL(k_warp_lds, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
     else if (semantics == MI_SEM_CPU_REF)
         hipLaunchKernelGGL(k_warp<MI_SEM_CPU_REF>, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
     else
