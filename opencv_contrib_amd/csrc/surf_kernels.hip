@@ -483,6 +483,13 @@ __device__ float linear_filter(const Win &w, float y, float x)   // surf.cl:873-
 __device__ __forceinline__ float row_accum(const Win &w, int dy, int a, int b, float wgt, float out)
 {
     int dx = a;
+    for (; dx + 16 <= b; dx += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = win_get(w, dy, dx + k);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out = out + v[k] * wgt;
+    }
     for (; dx + 8 <= b; dx += 8) {
         float v[8];
 #pragma unroll

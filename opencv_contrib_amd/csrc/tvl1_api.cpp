@@ -35,7 +35,7 @@ struct mi_tvl1 {
     float *scr[6] = {};    // scr[0..1] unused (kept for layout), I1wx, I1wy, grad, rho_c
     float *pack = nullptr; // float4 {I1, I1x, I1y, 0} per pixel of the current level
     float *pbuf[2][6] = {};   // [set][p11,p12,p21,p22,p31,p32]
-    bool capGamma = false;
+    bool capGamma = false, capMedian = false;
     float *cubic_tab = nullptr;
     PtrTab *tab_dev = nullptr;
     int tab_cap = 0;
@@ -74,7 +74,8 @@ static int validate_params(const mi_tvl1_params *p)
     MI_REQUIRE(p->scale_step > 0 && p->scale_step < 1, MI_ERR_BAD_ARG, "scale_step must be in (0,1)");
     MI_REQUIRE(p->theta != 0, MI_ERR_BAD_ARG, "theta must be non-zero");
     MI_REQUIRE(p->semantics == MI_SEM_CPU_REF || p->semantics == MI_SEM_CUDA_COMPAT, MI_ERR_BAD_ARG, "bad semantics");
-    MI_REQUIRE(p->median_filtering <= 1, MI_ERR_NOT_IMPL, "median_filtering > 1 is not implemented yet");
+    MI_REQUIRE(p->median_filtering <= 1 || p->median_filtering == 3 || p->median_filtering == 5, MI_ERR_BAD_ARG,
+               "medianFiltering must be 1 (off), 3 or 5 (cv::medianBlur on CV_32F)");
     return MI_OK;
 }
 
@@ -181,8 +182,9 @@ static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
 {
     const bool gam = h->P.gamma != 0.0;
     if (h->arena && h->capW == W && h->capH == H && h->capB >= B && h->capScales == h->P.nscales &&
-        h->capStep == h->P.scale_step && h->capGamma == gam)
+        h->capStep == h->P.scale_step && h->capGamma == gam && h->capMedian == (h->P.median_filtering > 1))
         return MI_OK;
+    const bool med = h->P.median_filtering > 1;
     free_arena(h);
     std::vector<Geo> geo;
     const int nl = plan_levels(h->P, W, H, B, geo);
@@ -196,7 +198,7 @@ static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
     }
     const size_t nfull = (size_t)geo[0].ps * B;
     size_t offScr[6], offP[12];
-    for (int k = 0; k < 6; ++k) offScr[k] = k < 2 ? 0 : take(nfull);
+    for (int k = 0; k < 6; ++k) offScr[k] = (k < 2 && !med) ? 0 : take(nfull);   // scr[0..1]: median-filter temporaries
     const size_t offPack = take(nfull * 4);
     for (int k = 0; k < 12; ++k) offP[k] = (k % 6 >= 4 && !gam) ? 0 : take(nfull);
     MI_HIP_TRY(hipMalloc((void **)&h->arena, total * sizeof(float)));
@@ -211,7 +213,7 @@ static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
     for (int k = 0; k < 6; ++k) h->scr[k] = h->arena + offScr[k];
     h->pack = h->arena + offPack;
     for (int k = 0; k < 12; ++k) h->pbuf[k / 6][k % 6] = (k % 6 >= 4 && !gam) ? nullptr : h->arena + offP[k];
-    h->capGamma = gam;
+    h->capGamma = gam; h->capMedian = med;
     h->capW = W; h->capH = H; h->capB = B; h->capScales = h->P.nscales; h->capStep = h->P.scale_step;
     return MI_OK;
 }
@@ -386,19 +388,31 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
             }
             const bool blocked = !check && !P.exact_math && P.time_block != 1 && !gam;
             long long nlaunch = 0;
+            const int mf = P.median_filtering > 1 ? P.median_filtering : 0;
+            float *const mu1[2] = {Lv.u[0][0], Lv.u[1][0]}, *const mu2[2] = {Lv.u[0][1], Lv.u[1][1]};
             if (blocked) {
-                // T iterations per HBM pass (tvl1_tb_kernels.hip), decomposition by measured cost
-                std::vector<int> plan(iters_per_warp + 1);
-                const int nb = tb_plan(iters_per_warp, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), iters_per_warp);
-                for (int k = 0; k < nb; ++k) {
-                    ++nlaunch;
-                    rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
-                    if (rc) return rc;
-                    cur ^= 1;
-                    first_of_scale = false;
+                // T iterations per HBM pass (tvl1_tb_kernels.hip), decomposition by measured cost; the optional median
+                // filter sits between outer iterations, so blocks never span more than inner_iterations
+                const int per = mf ? P.inner_iterations : iters_per_warp, nouter = mf ? P.iterations : 1;
+                std::vector<int> plan(per + 1);
+                const int nb = tb_plan(per, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), per);
+                for (int no = 0; no < nouter; ++no) {
+                    if (mf && (rc = median_flow(mf, mu1, mu2, h->scr[0], h->scr[1], g, nullptr, cur, st))) return rc;
+                    for (int k = 0; k < nb; ++k) {
+                        ++nlaunch;
+                        rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
+                        if (rc) return rc;
+                        cur ^= 1;
+                        first_of_scale = false;
+                    }
                 }
             } else for (int it = 0; it < iters_per_warp; ++it) {
                 ++nlaunch;
+                if (mf && it % P.inner_iterations == 0) {   // cv::medianBlur before each outer iteration (optflow tvl1flow.cpp:1381-1384)
+                    Ctl mc = ctl;
+                    mc.q_prev = q_last; mc.first_of_warp = (it == 0); mc.reset_cur = first_of_scale;
+                    if ((rc = median_flow(mf, mu1, mu2, h->scr[0], h->scr[1], g, check ? &mc : nullptr, cur, st))) return rc;
+                }
                 if (check) {
                     Ctl ic = ctl;
                     ic.q = q; ic.q_prev = q_last;

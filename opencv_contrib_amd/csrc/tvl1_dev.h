@@ -52,6 +52,9 @@ int resize(int semantics, int nplanes, const float *const src[3][2], int src_set
            const Geo &gs, const Geo &gd, double inv_scale_x, double inv_scale_y,
            const float post_scale[3], const Ctl *ctl, int cur_host, hipStream_t s);
 int gradient(const float *src, float *dx, float *dy, const Geo &g, hipStream_t s);
+// cv::medianBlur(ksize 3|5) of u1,u2 in place (through tmp planes); device-side loop control like iterate()
+int median_flow(int ksize, float *const u1[2], float *const u2[2], float *tmp1, float *tmp2, const Geo &g, const Ctl *ctl, int cur_host,
+                hipStream_t s);
 // pk = one float4 {I1, I1x, I1y, 0} per pixel (4 * g.ps floats per pair, 16-B aligned)
 int gradient_pack(const float *src, float *pk, const Geo &g, hipStream_t s);
 int pack3(const float *a, const float *b, const float *c, float *pk, const Geo &g, hipStream_t s);

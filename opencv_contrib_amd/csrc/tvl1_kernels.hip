@@ -108,6 +108,65 @@ __global__ __launch_bounds__(256) void k_pack_flow(const PtrTab *tab, const floa
     ((float2 *)((char *)t.out + (long long)y * t.step_out))[x] = make_float2(u1[o], u2[o]);
 }
 
+// ------------------------------------------------------------------ median filter of the flow (CPU class only)
+// cv::medianBlur(u, u, medianFiltering) before every outer iteration (optflow/src/tvl1flow.cpp:1381-1384): ksize 3 or 5,
+// replicate border.  Loop control: the filter runs only while the outer loop is still active, evaluated on the device
+// from the previous iteration launch's slot exactly like k_iterate does.
+__device__ __forceinline__ bool resolve_active_k(const CtlK &c, int b, int cur_host, int &cur)
+{
+    if (!c.S) { cur = cur_host; return true; }
+    if (c.q_prev < 0) { cur = 0; return true; }
+    const long long sp = (long long)b * c.Q + c.q_prev;
+    const int2 s = c.S[sp];
+    cur = c.reset_cur ? 0 : (s.x ^ s.y);
+    if (c.first_of_warp) return true;
+    const double e = (double)c.E[sp] * (1.0 / ERR_FIX_SCALE);
+    return s.y && (e > c.thr);
+}
+
+struct MedArgs { float *u[2][2]; float *tmp[2]; Geo g; };   // u[set][component]
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_median(MedArgs A, CtlK ctl, int cur_host)
+{
+    constexpr int N = KS * KS, R = KS / 2;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z >> 1, c = blockIdx.z & 1;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    int cur;
+    if (!resolve_active_k(ctl, b, cur_host, cur)) return;
+    if (x >= W || y >= H) return;
+    const float *S = A.u[cur][c] + (long long)b * A.g.ps;
+    float v[N];
+#pragma unroll
+    for (int j = -R; j <= R; ++j)
+#pragma unroll
+        for (int i = -R; i <= R; ++i)
+            v[(j + R) * KS + i + R] = S[(long long)min(max(y + j, 0), H - 1) * ld + min(max(x + i, 0), W - 1)];
+    // selection of the N/2-th smallest by partial exchange sort (exact median, same value as a full sort)
+#pragma unroll
+    for (int i = 0; i <= N / 2; ++i)
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) {
+            const float lo = fminf(v[i], v[j]), hi = fmaxf(v[i], v[j]);
+            v[i] = lo; v[j] = hi;
+        }
+    A.tmp[c][(long long)b * A.g.ps + (long long)y * ld + x] = v[N / 2];
+}
+
+__global__ __launch_bounds__(256) void k_median_copy(MedArgs A, CtlK ctl, int cur_host)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z >> 1, c = blockIdx.z & 1;
+    int cur;
+    if (!resolve_active_k(ctl, b, cur_host, cur)) return;
+    if (x >= A.g.w || y >= A.g.h) return;
+    const long long o = (long long)b * A.g.ps + (long long)y * A.g.ld + x;
+    A.u[cur][c][o] = A.tmp[c][o];
+}
+
 // ------------------------------------------------------------------ resize (pyramid / flow upsample)
 struct ResizeArgs {
     const float *src[3][2];
@@ -884,6 +943,22 @@ int resize(int semantics, int nplanes, const float *const src[3][2], int src_set
         A.scale_y = (double)(float)(1.0 / inv_scale_y);
         hipLaunchKernelGGL(k_resize<MI_SEM_CUDA_COMPAT>, grid, dim3(256), 0, s, A, ck, cur_host);
     }
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int median_flow(int ksize, float *const u1[2], float *const u2[2], float *tmp1, float *tmp2, const Geo &g, const Ctl *ctl, int cur_host,
+                hipStream_t s)
+{
+    MedArgs A;
+    A.u[0][0] = u1[0]; A.u[1][0] = u1[1]; A.u[0][1] = u2[0]; A.u[1][1] = u2[1];
+    A.tmp[0] = tmp1; A.tmp[1] = tmp2; A.g = g;
+    const CtlK ck = make_ctlk(ctl);
+    const dim3 grid(div_up(g.w, 64), div_up(g.h, 4), g.batch * 2);
+    if (ksize == 5) hipLaunchKernelGGL(k_median<5>, grid, dim3(256), 0, s, A, ck, cur_host);
+    else if (ksize == 3) hipLaunchKernelGGL(k_median<3>, grid, dim3(256), 0, s, A, ck, cur_host);
+    else { set_error("medianFiltering must be 1 (off), 3 or 5 for CV_32F (cv::medianBlur)"); return MI_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(k_median_copy, grid, dim3(256), 0, s, A, ck, cur_host);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

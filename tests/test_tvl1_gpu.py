@@ -372,3 +372,32 @@ def test_calc_gamma_with_device_side_convergence(gpu, oracle):
     _assert_flow_close(flow, ref, mean_epe=5e-3)
     its = np.array(alg.lastIterations()); rits = np.array(st["iters"])
     assert its.shape == rits.shape and np.abs(its - rits).max() <= max(3, 0.1 * rits.max())
+
+
+@pytest.mark.parametrize("median,fast", [(5, False), (3, False), (5, True)])
+def test_calc_cpu_class_knobs_median_and_inner_iterations(gpu, oracle, median, fast):
+    """The three knobs only the CPU class has (optflow.hpp:283-295): medianFiltering (cv::medianBlur of u before every outer
+    iteration, optflow/src/tvl1flow.cpp:1381-1384), innerIterations, outerIterations."""
+    I0, I1, _ = synth.flow_pair(150, 210, seed=23)
+    p = oracle.tvl1_params(outer_iterations=4, inner_iterations=6, median_filtering=median, epsilon=0.0)
+    ref = oracle.tvl1_calc(I0, I1, p)
+    ref_nomed = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(outer_iterations=4, inner_iterations=6, median_filtering=1, epsilon=0.0))
+    assert np.abs(ref - ref_nomed).max() > 1e-3, "median filtering has no effect on this input"
+    flow, _ = _run(gpu, I0, I1, iterations=4, innerIterations=6, medianFiltering=median, epsilon=0.0, exactMath=not fast)
+    if fast:
+        _assert_flow_close(flow, ref, mean_epe=5e-3, ccorr=1e-5, frac_within=(0.03, 0.985))
+    else:
+        _assert_flow_close(flow, ref)
+
+
+def test_calc_cpu_class_defaults_with_convergence_test(gpu, oracle):
+    """cv::optflow::DualTVL1OpticalFlow defaults: median 5, inner 30, outer 10, epsilon 0.01 (optflow/src/tvl1flow.cpp:386-400);
+    the median launches obey the same device-side loop control as the iterations."""
+    I0, I1, _ = synth.flow_pair(120, 168, seed=29, dtype="u8")
+    p = oracle.tvl1_params()   # CPU class defaults
+    assert (p.median_filtering, p.inner_iterations, p.outer_iterations) == (5, 30, 10)
+    ref, st = oracle.tvl1_calc(I0, I1, p, return_stats=True)
+    flow, alg = _run(gpu, I0, I1, iterations=10, innerIterations=30, medianFiltering=5, epsilon=0.01)
+    _assert_flow_close(flow, ref, mean_epe=5e-3)
+    its = np.array(alg.lastIterations()); rits = np.array(st["iters"])
+    assert its.shape == rits.shape and np.abs(its - rits).max() <= max(3, 0.1 * rits.max())
