@@ -995,10 +995,13 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
     A.tab = cubic_tab_dev;
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
-    static const char *wsel = getenv("MIFLOW_WARP");   // tuning: "4" = 4 px/lane (measured slower, r01h), "1" = per-pixel gathers
+    // default: per-pixel float4 gathers (k_warp).  Two alternatives were built and measured SLOWER at 1080p x 16
+    // (profiles/r01h, r01i: k_warp 269 us/launch, k_warp_lds 325 us, k_warp4 376 us): fewer resident waves / strided lanes
+    // cost more memory-level parallelism than the saved texture-addresser work buys.  MIFLOW_WARP=lds|4 selects them.
+    static const char *wsel = getenv("MIFLOW_WARP");
     if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == '4')
         hipLaunchKernelGGL(k_warp4, dim3(div_up(g.w, 256), div_up(g.h, 4), g.batch), dim3(256), 0, s, A, ck, cur_host);
-    else if (semantics == MI_SEM_CPU_REF && !(wsel && wsel[0] == '1'))
+    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'l')
         hipLaunchKernelGGL(k_warp_lds, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
     else if (semantics == MI_SEM_CPU_REF)
         hipLaunchKernelGGL(k_warp<MI_SEM_CPU_REF>, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);

@@ -221,9 +221,17 @@ __device__ __forceinline__ void load_input_row(Dyn<PPL> &r, Stat<PPL> &st, const
 #pragma unroll
         for (int j = 0; j < PPL; ++j) r.p11[j] = r.p12[j] = r.p21[j] = r.p22[j] = 0.f;
     }
-    // 1/grad; grad == 0 -> huge, so that clamp() yields -+l_t*sign(rho) like the reference's first two branches
+    // st.rg holds the RAW |grad|^2 until the row is consumed (finish_static): nothing here depends on a load result, so the
+    // prefetch can stay in flight for PF pipeline steps
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) st.rg[j] = __builtin_amdgcn_rcpf(fmaxf(g[j], 1e-30f));
+    for (int j = 0; j < PPL; ++j) st.rg[j] = g[j];
+}
+// 1/grad; grad == 0 -> huge, so that clamp() yields -+l_t*sign(rho) like the reference's first two branches
+template <int PPL>
+__device__ __forceinline__ void finish_static(Stat<PPL> &st)
+{
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) st.rg[j] = __builtin_amdgcn_rcpf(fmaxf(st.rg[j], 1e-30f));
 }
 
 // One step of the whole pipeline: row `arow` of level 0 enters, row arow-T of level T leaves in `io`.
@@ -247,7 +255,9 @@ __device__ __forceinline__ void pipeline_step(Dyn<PPL> &io, const Stat<PPL> &st0
     }
 }
 
-template <int T, int PPL, bool PZ, int WPS>
+// PF = prefetch depth in pipeline steps (rows): the kernel is bound by HBM bytes in flight (r01i PMC: 63 % of wave time in
+// s_waitcnt, ~4 TB/s of real traffic), and a prefetched row costs only 10*PPL VGPRs.
+template <int T, int PPL, bool PZ, int WPS, int PF>
 __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;    // validity margin per side (px)
@@ -299,9 +309,10 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
 
     const int ystart = y0 - T;
     const int nsteps = (y1 - y0) + 2 * T;
-    Dyn<PPL> nxt;
-    Stat<PPL> nst;
-    load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart, H, xl, xok);
+    Dyn<PPL> nxt[PF];
+    Stat<PPL> nst[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load_input_row<PPL, PZ>(nxt[k], nst[k], B, uin, pin, ystart + k, H, xl, xok);
     int slot0 = 0;
 
     auto emit = [&](const Dyn<PPL> &r, int orow) {
@@ -316,21 +327,24 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
         }
     };
 
-    for (int s = 0; s < nsteps; s += 2) {
-        // even step: state SA -> SB
-        Dyn<PPL> io = nxt;
-        Stat<PPL> st0 = nst;
-        load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart + s + 1, H, xl, xok);
-        pipeline_step<T, PPL, K>(io, st0, SA, SB, ring, slot0, lane, ystart + s, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
-        emit(io, ystart + s - T);
-        slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
-        // odd step: state SB -> SA (rows past the band end are computed but never stored)
-        io = nxt;
-        st0 = nst;
-        load_input_row<PPL, PZ>(nxt, nst, B, uin, pin, ystart + s + 2, H, xl, xok);
-        pipeline_step<T, PPL, K>(io, st0, SB, SA, ring, slot0, lane, ystart + s + 1, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
-        emit(io, ystart + s + 1 - T);
-        slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
+    constexpr int U = PF < 2 ? 2 : PF;   // unroll: even (state ping-pongs SA <-> SB) and a multiple of PF (static prefetch slots)
+    for (int s = 0; s < nsteps; s += U) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = k % PF;
+            Dyn<PPL> io = nxt[slot];
+            Stat<PPL> st0 = nst[slot];
+            finish_static<PPL>(st0);
+            load_input_row<PPL, PZ>(nxt[slot], nst[slot], B, uin, pin, ystart + s + k + PF, H, xl, xok);
+            // even step: state SA -> SB, odd step: SB -> SA (rows past the band end are computed but never stored)
+            if ((k & 1) == 0)
+                pipeline_step<T, PPL, K>(io, st0, SA, SB, ring, slot0, lane, ystart + s + k, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+            else
+                pipeline_step<T, PPL, K>(io, st0, SB, SA, ring, slot0, lane, ystart + s + k, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+            emit(io, ystart + s + k - T);
+            slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
+        }
     }
 }
 
@@ -339,11 +353,11 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
 // leave room for).  More waves per SIMD hide the s_waitcnt stalls (rocprofv3: 40 % of wave time at
 // 2 waves/SIMD), fewer registers per wave cap T: the table is the measured trade-off.
 struct TbVariant {
-    int T, PPL, WPS;
+    int T, PPL, WPS, PF;
     void (*launch)(const TbArgs &, bool, hipStream_t);
 };
 
-template <int T, int PPL, int WPS>
+template <int T, int PPL, int WPS, int PF>
 static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
@@ -352,41 +366,40 @@ static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
     constexpr size_t lds_bytes = (size_t)4 * (T + 1) * 256 * PPL * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, true, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, false, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, true, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_iterate_tb<T, PPL, false, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tb<T, PPL, true, WPS>), grid, dim3(256), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tb<T, PPL, false, WPS>), grid, dim3(256), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tb<T, PPL, true, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tb<T, PPL, false, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
 }
 
-#define TBV(T, PPL, WPS) {T, PPL, WPS, launch_tb<T, PPL, WPS>}
-// first entry of each T = default; the others are selectable with MIFLOW_TB_VARIANT="ppl,wps" (tuning sweeps)
+#define TBV(T, PPL, WPS, PF) {T, PPL, WPS, PF, launch_tb<T, PPL, WPS, PF>}
 static const TbVariant g_variants[] = {
-    // defaults (first entry of each T): best single-block timings of the r01b sweep (profiles/r01b/README.md),
-    // G px-iter/s at 1080p x 16:  T8 (1 px/lane, 4 waves/SIMD) 287 | T6 (1,5) 260 | T5 (2,3) 244 | T4 (2,1) 221 |
-    // T10 (1,4) 220 | T3 (2,4) 193 | T2 (1,8) 114
-    TBV(1, 2, 1), TBV(2, 1, 8), TBV(3, 2, 4), TBV(4, 2, 1), TBV(5, 2, 3), TBV(6, 1, 5), TBV(8, 1, 4), TBV(10, 1, 4),
-    // alternatives, selectable with MIFLOW_TB_VARIANT="ppl,wps" (tuning sweeps)
-    TBV(2, 2, 1), TBV(3, 2, 1), TBV(5, 2, 1), TBV(6, 2, 1), TBV(8, 2, 1), TBV(10, 2, 1),
-    TBV(4, 2, 4), TBV(6, 2, 3), TBV(3, 1, 8),
-    TBV(4, 1, 8), TBV(5, 1, 8), TBV(5, 1, 6), TBV(6, 1, 6), TBV(8, 1, 5),
-    TBV(10, 1, 3), TBV(10, 1, 5), TBV(8, 1, 6), TBV(6, 1, 8),
+    // defaults (first entry of each T); alternatives are selectable with MIFLOW_TB_VARIANT="ppl,wps,pf" (tuning sweeps)
+    TBV(1, 2, 1, 1), TBV(2, 1, 8, 1), TBV(3, 2, 4, 1), TBV(4, 2, 1, 1), TBV(5, 2, 3, 1), TBV(6, 1, 5, 1), TBV(8, 1, 4, 1), TBV(10, 1, 4, 1),
+    // deeper prefetch
+    TBV(3, 2, 3, 2), TBV(4, 2, 3, 2), TBV(5, 2, 2, 2), TBV(5, 2, 3, 2),
+    TBV(4, 1, 6, 2), TBV(5, 1, 5, 2), TBV(6, 1, 4, 2), TBV(6, 1, 5, 2), TBV(8, 1, 4, 2), TBV(8, 1, 3, 2), TBV(10, 1, 3, 2),
+    TBV(4, 1, 5, 4), TBV(5, 1, 4, 4), TBV(6, 1, 4, 4), TBV(8, 1, 3, 4), TBV(10, 1, 3, 4), TBV(3, 1, 6, 4),
+    TBV(3, 2, 3, 4), TBV(4, 2, 2, 4),
+    // PF = 1 alternatives of the r01b/r01d sweeps
+    TBV(8, 2, 1, 1), TBV(10, 2, 1, 1), TBV(5, 1, 6, 1), TBV(8, 1, 5, 1), TBV(3, 1, 8, 1),
 };
 
 static const TbVariant *pick_variant(int T)
 {
-    static int want_ppl = -1, want_wps = -1;
+    static int want_ppl = -1, want_wps = -1, want_pf = 1;
     static bool parsed = false;
     if (!parsed) {
         parsed = true;
-        if (const char *e = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(e, "%d,%d", &want_ppl, &want_wps);
+        if (const char *e = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(e, "%d,%d,%d", &want_ppl, &want_wps, &want_pf);
     }
     const TbVariant *def = nullptr;
     for (const TbVariant &v : g_variants) {
         if (v.T != T) continue;
         if (!def) def = &v;
-        if (v.PPL == want_ppl && v.WPS == want_wps) return &v;
+        if (v.PPL == want_ppl && v.WPS == want_wps && v.PF == want_pf) return &v;
     }
     return def;
 }
