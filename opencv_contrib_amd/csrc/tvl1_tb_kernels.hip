@@ -377,11 +377,13 @@ static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
 #define TBV(T, PPL, WPS, PF) {T, PPL, WPS, PF, launch_tb<T, PPL, WPS, PF>}
 static const TbVariant g_variants[] = {
     // defaults (first entry of each T); alternatives are selectable with MIFLOW_TB_VARIANT="ppl,wps,pf" (tuning sweeps)
-    TBV(1, 2, 1, 1), TBV(2, 1, 8, 1), TBV(3, 2, 4, 1), TBV(4, 2, 1, 1), TBV(5, 2, 3, 1), TBV(6, 1, 5, 1), TBV(8, 1, 4, 1), TBV(10, 1, 4, 1),
-    // deeper prefetch
-    TBV(3, 2, 3, 2), TBV(4, 2, 3, 2), TBV(5, 2, 2, 2), TBV(5, 2, 3, 2),
-    TBV(4, 1, 6, 2), TBV(5, 1, 5, 2), TBV(6, 1, 4, 2), TBV(6, 1, 5, 2), TBV(8, 1, 4, 2), TBV(8, 1, 3, 2), TBV(10, 1, 3, 2),
-    TBV(4, 1, 5, 4), TBV(5, 1, 4, 4), TBV(6, 1, 4, 4), TBV(8, 1, 3, 4), TBV(10, 1, 3, 4), TBV(3, 1, 6, 4),
+    // r01j sweep, G px-iter/s at 1080p x 16: T8 (1 px/lane, 4 waves/SIMD, 2 rows prefetched) 296 | T10 (1,3,4) 273 |
+    // T6 (1,4,2) 260 | T5 (2,3,1) 230 | T4 (2,1,1) 221 | T3 (2,4,1) 193 | T2 (1,8,1) 114
+    TBV(1, 2, 1, 1), TBV(2, 1, 8, 1), TBV(3, 2, 4, 1), TBV(4, 2, 1, 1), TBV(5, 2, 3, 1), TBV(6, 1, 4, 2), TBV(8, 1, 4, 2), TBV(10, 1, 3, 4),
+    // other prefetch depths / occupancies
+    TBV(3, 2, 3, 2), TBV(4, 2, 3, 2), TBV(5, 2, 2, 2), TBV(5, 2, 3, 2), TBV(6, 1, 5, 1), TBV(8, 1, 4, 1), TBV(10, 1, 4, 1),
+    TBV(4, 1, 6, 2), TBV(5, 1, 5, 2), TBV(6, 1, 5, 2), TBV(8, 1, 3, 2), TBV(10, 1, 3, 2),
+    TBV(4, 1, 5, 4), TBV(5, 1, 4, 4), TBV(6, 1, 4, 4), TBV(8, 1, 3, 4), TBV(3, 1, 6, 4),
     TBV(3, 2, 3, 4), TBV(4, 2, 2, 4),
     // PF = 1 alternatives of the r01b/r01d sweeps
     TBV(8, 2, 1, 1), TBV(10, 2, 1, 1), TBV(5, 1, 6, 1), TBV(8, 1, 5, 1), TBV(3, 1, 8, 1),
@@ -407,12 +409,12 @@ static const TbVariant *pick_variant(int T)
 int tb_max_block() { return 10; }
 
 // Decompose n iterations into supported time blocks minimising the modelled cost.  cost[T] = measured
-// ps per pixel-iteration of k_iterate_tb<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01b):
+// ps per pixel-iteration of k_iterate_tb<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01j):
 // deeper blocks save HBM passes but cost registers (occupancy) and halo recomputation.
 int tb_plan(int n, int cap, int *blocks, int max_blocks)
 {
     static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
-    static const double cost[11] = {0, 16.9, 8.77, 5.18, 4.52, 4.10, 3.85, 0, 3.49, 0, 4.54};
+    static const double cost[11] = {0, 16.9, 8.77, 5.18, 4.52, 4.35, 3.85, 0, 3.38, 0, 3.66};
     if (n <= 0) return 0;
     if (getenv("MIFLOW_TB_FORCE")) {   // tuning sweeps: greedy blocks of exactly `cap` (then the largest that fit)
         int k = 0;
