@@ -26,6 +26,7 @@ def _sources():
 # files compiled WITH the SLP vectoriser (v_pk_*_f32 packed math); everything else keeps -fno-slp-vectorize
 SLP_FILES = set(filter(None, os.environ.get("MIFLOW_SLP_FILES", "").split(",")))
 VARIANT = os.environ.get("MIFLOW_BUILD_VARIANT", "")   # suffix of the object dir / library name for A/B builds
+EXTRA = os.environ.get("MIFLOW_EXTRA_FLAGS", "").split()   # e.g. -DTB_EXPERIMENT=1 for an A/B variant (tuning only)
 
 
 def _compile(src: str, force: bool) -> str:
@@ -35,7 +36,7 @@ def _compile(src: str, force: bool) -> str:
            [os.path.join(ROOT, "include", "miflow", "c_api.h")]
     if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj
-    flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and src in SLP_FILES)]
+    flags = [f for f in FLAGS if not (f == "-fno-slp-vectorize" and src in SLP_FILES)] + EXTRA
     cmd = [HIPCC] + flags + ["-x", "hip", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

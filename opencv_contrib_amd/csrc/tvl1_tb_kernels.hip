@@ -60,6 +60,7 @@ struct TbArgs {
     float l_t, theta, taut;
     int rows_per_band;
     int cur;  // input set
+    int swz, nstrips;
 };
 
 template <int PPL>
@@ -127,21 +128,21 @@ __device__ __forceinline__ void lds_get(const float *slot, int lane, Stat<PPL> &
 // One pipeline stage (iteration level t).  `in` = level t-1 row a (u, p), `st` = static row a,
 // `S` = what this stage holds (u_t(a-1), p_(t-1)(a-1)); writes the new held state (row a) to `N`
 // and replaces `in` by level t row a-1.  a, H are wave-uniform (SGPRs).
-template <int PPL>
+template <int PPL, bool EDGE>
 __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const Dyn<PPL> &S, Dyn<PPL> &N, int a, int H,
                                       bool has_left, bool has_right, bool x_is_zero, const bool right_ok[PPL],
                                       float l_t, float theta, float taut)
 {
-    // has_left / has_right / a are wave-uniform: the border fix-ups are scalar branches that the
-    // interior strips and rows skip (the empty asm keeps the compiler from if-converting them
-    // into per-pixel selects).
+    // EDGE = false: interior step of an interior strip -- no image border can be touched by any stage, straight-line code.
+    // EDGE = true: has_left / has_right / a are wave-uniform, the border fix-ups are scalar branches (the empty asm keeps
+    // the compiler from if-converting them into per-pixel selects).
     // ---- u_t(a)
     float dx1[PPL], dx2[PPL];  // backward x-differences of p11, p21
     dx1[0] = in.p11[0] - dpp_from_prev(in.p11[PPL - 1]);
     dx2[0] = in.p21[0] - dpp_from_prev(in.p21[PPL - 1]);
 #pragma unroll
     for (int j = 1; j < PPL; ++j) { dx1[j] = in.p11[j] - in.p11[j - 1]; dx2[j] = in.p21[j] - in.p21[j - 1]; }
-    if (has_left) {  // first column: no p(x-1) term (optflow tvl1flow.cpp:893-894)
+    if (EDGE && has_left) {  // first column: no p(x-1) term (optflow tvl1flow.cpp:893-894)
         asm volatile("" ::: "memory");
         if (x_is_zero) { dx1[0] = in.p11[0]; dx2[0] = in.p21[0]; }
     }
@@ -155,7 +156,7 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
         N.u2[j] = fmaf(theta, div2, fmaf(fi, st.iy[j], in.u2[j]));
         N.p11[j] = in.p11[j]; N.p12[j] = in.p12[j]; N.p21[j] = in.p21[j]; N.p22[j] = in.p22[j];
     }
-    if (a == H) {  // below the last row: forward y-difference is 0 (optflow tvl1flow.cpp:826-831)
+    if (EDGE && a == H) {  // below the last row: forward y-difference is 0 (optflow tvl1flow.cpp:826-831)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < PPL; ++j) { N.u1[j] = S.u1[j]; N.u2[j] = S.u2[j]; }
@@ -171,7 +172,7 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
         u1xv[j] = n1 - S.u1[j];
         u2xv[j] = n2 - S.u2[j];
     }
-    if (has_right) {  // last column: forward x-difference is 0 (optflow tvl1flow.cpp:833-838)
+    if (EDGE && has_right) {  // last column: forward x-difference is 0 (optflow tvl1flow.cpp:833-838)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < PPL; ++j) { u1xv[j] = right_ok[j] ? u1xv[j] : 0.f; u2xv[j] = right_ok[j] ? u2xv[j] : 0.f; }
@@ -192,39 +193,87 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
         in.p22[j] = fmaf(taut, u2y, S.p22[j]) * q2;
         in.u1[j] = S.u1[j]; in.u2[j] = S.u2[j];
     }
-    if (a <= 0) {  // the emitted row a-1 lies above the image: p(y-1) terms vanish at y == 0 (:889-890)
+    if (EDGE && a <= 0) {  // the emitted row a-1 lies above the image: p(y-1) terms vanish at y == 0 (:889-890)
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < PPL; ++j) in.p12[j] = in.p22[j] = 0.f;
     }
 }
 
+// Row prefetch.  The loads are UNCONDITIONAL (clamped row / column, uniform row base + 32-bit lane offset): a load inside a
+// divergent `if` sits in its own basic block, and the waitcnt pass then has to assume vmcnt(0) at every later use, which
+// serialises the prefetch (r01k ISA).  Out-of-image rows/columns are zeroed when the row is consumed (mask_input_row).
+// Pins a wave-uniform row pointer into an SGPR pair so that the access is emitted as `global_* v, voffset, s[base:base+1]`
+// (otherwise base + lane offset is reassociated into per-plane 64-bit VGPR addresses hoisted out of the row loop: 32 VGPRs
+// and two VALU adds per access).  The integer round trip drops the inferred address space, hence the explicit global one.
+#define MI_GLOBAL __attribute__((address_space(1)))
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MI_GLOBAL char *sgpr_row(const void *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (MI_GLOBAL char *)(((unsigned long long)hi << 32) | lo);
+}
+// Row prefetch.  The loads are UNCONDITIONAL (clamped row / column): a load inside a divergent `if` sits in its own basic
+// block, and the waitcnt pass then has to assume vmcnt(0) at every later use, which serialises the prefetch (r01k ISA).
+// Out-of-image rows/columns are zeroed when the row is consumed (mask_input_row).  xb = lane offset in BYTES.
+template <int PPL>
+__device__ __forceinline__ void ldu(float dst[PPL], const float *rowp, unsigned xb)
+{
+    const MI_GLOBAL char *q = sgpr_row(rowp) + xb;
+    if (PPL == 1) {
+        dst[0] = *(const MI_GLOBAL float *)q;
+    } else if (PPL == 2) {
+        const f2v v = *(const MI_GLOBAL f2v *)q;
+        dst[0] = v.x; dst[1] = v.y;
+    } else {
+        const f4v v = *(const MI_GLOBAL f4v *)q;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+template <int PPL>
+__device__ __forceinline__ void stu(float *rowp, unsigned xb, const float v[PPL])
+{
+    MI_GLOBAL char *q = sgpr_row(rowp) + xb;
+    if (PPL == 1) *(MI_GLOBAL float *)q = v[0];
+    else if (PPL == 2) *(MI_GLOBAL f2v *)q = f2v{v[0], v[1]};
+    else *(MI_GLOBAL f4v *)q = f4v{v[0], v[1], v[2], v[3]};
+}
 template <int PPL, bool PZ>
 __device__ __forceinline__ void load_input_row(Dyn<PPL> &r, Stat<PPL> &st, const TbArgs &A, const float *const u[2],
-                                               const float *const p[4], int row, int H, long long xoff, bool xok)
+                                               const float *const p[4], int row, int H, unsigned xc)
 {
-    const bool ok = xok && row >= 0 && row < H;
-    const long long off = (long long)row * A.g.ld + xoff;
-    float g[PPL];
-    ldv<PPL>(st.ix, A.pl.ix, off, ok);
-    ldv<PPL>(st.iy, A.pl.iy, off, ok);
-    ldv<PPL>(g, A.pl.g, off, ok);
-    ldv<PPL>(st.rc, A.pl.rc, off, ok);
-    ldv<PPL>(r.u1, u[0], off, ok);
-    ldv<PPL>(r.u2, u[1], off, ok);
+    const long long ro = (long long)min(max(row, 0), H - 1) * A.g.ld;   // wave-uniform
+    ldu<PPL>(st.ix, A.pl.ix + ro, xc);
+    ldu<PPL>(st.iy, A.pl.iy + ro, xc);
+    ldu<PPL>(st.rg, A.pl.g + ro, xc);   // RAW |grad|^2 until the row is consumed (finish_static)
+    ldu<PPL>(st.rc, A.pl.rc + ro, xc);
+    ldu<PPL>(r.u1, u[0] + ro, xc);
+    ldu<PPL>(r.u2, u[1] + ro, xc);
     if (!PZ) {
-        ldv<PPL>(r.p11, p[0], off, ok);
-        ldv<PPL>(r.p12, p[1], off, ok);
-        ldv<PPL>(r.p21, p[2], off, ok);
-        ldv<PPL>(r.p22, p[3], off, ok);
+        ldu<PPL>(r.p11, p[0] + ro, xc);
+        ldu<PPL>(r.p12, p[1] + ro, xc);
+        ldu<PPL>(r.p21, p[2] + ro, xc);
+        ldu<PPL>(r.p22, p[3] + ro, xc);
     } else {
 #pragma unroll
         for (int j = 0; j < PPL; ++j) r.p11[j] = r.p12[j] = r.p21[j] = r.p22[j] = 0.f;
     }
-    // st.rg holds the RAW |grad|^2 until the row is consumed (finish_static): nothing here depends on a load result, so the
-    // prefetch can stay in flight for PF pipeline steps
+}
+template <int PPL, bool PZ>
+__device__ __forceinline__ void mask_input_row(Dyn<PPL> &r, Stat<PPL> &st, bool ok)
+{
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) st.rg[j] = g[j];
+    for (int j = 0; j < PPL; ++j) {
+        st.ix[j] = ok ? st.ix[j] : 0.f; st.iy[j] = ok ? st.iy[j] : 0.f;
+        st.rg[j] = ok ? st.rg[j] : 0.f; st.rc[j] = ok ? st.rc[j] : 0.f;
+        r.u1[j] = ok ? r.u1[j] : 0.f; r.u2[j] = ok ? r.u2[j] : 0.f;
+        if (!PZ) {
+            r.p11[j] = ok ? r.p11[j] : 0.f; r.p12[j] = ok ? r.p12[j] : 0.f;
+            r.p21[j] = ok ? r.p21[j] : 0.f; r.p22[j] = ok ? r.p22[j] : 0.f;
+        }
+    }
 }
 // 1/grad; grad == 0 -> huge, so that clamp() yields -+l_t*sign(rho) like the reference's first two branches
 template <int PPL>
@@ -234,24 +283,25 @@ __device__ __forceinline__ void finish_static(Stat<PPL> &st)
     for (int j = 0; j < PPL; ++j) st.rg[j] = __builtin_amdgcn_rcpf(fmaxf(st.rg[j], 1e-30f));
 }
 
-// One step of the whole pipeline: row `arow` of level 0 enters, row arow-T of level T leaves in `io`.
-template <int T, int PPL, int K>
+// One step of the whole pipeline: row `arow` of level 0 enters, row arow-T of level T leaves in `io`.  The static row of
+// stage t+1 is fetched from the LDS ring before stage t computes (ds_read latency hidden behind one stage of VALU work).
+template <int T, int PPL, int K, bool EDGE>
 __device__ __forceinline__ void pipeline_step(Dyn<PPL> &io, const Stat<PPL> &st0, const Dyn<PPL> (&S)[T], Dyn<PPL> (&N)[T],
                                               float *ring, int slot0, int lane, int arow, int H, bool has_left,
                                               bool has_right, bool x_is_zero, const bool right_ok[PPL], float l_t,
                                               float theta, float taut)
 {
     lds_put<PPL>(ring + slot0 * (256 * PPL), lane, st0);
+    Stat<PPL> st = st0, nx;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        Stat<PPL> st;
-        if (t == 0) st = st0;
-        else {
-            int sl = slot0 - t;
+        if (t + 1 < T) {
+            int sl = slot0 - (t + 1);
             if (sl < 0) sl += K;
-            lds_get<PPL>(ring + sl * (256 * PPL), lane, st);
+            lds_get<PPL>(ring + sl * (256 * PPL), lane, nx);
         }
-        stage<PPL>(io, st, S[t], N[t], arow - t, H, has_left, has_right, x_is_zero, right_ok, l_t, theta, taut);
+        stage<PPL, EDGE>(io, st, S[t], N[t], arow - t, H, has_left, has_right, x_is_zero, right_ok, l_t, theta, taut);
+        st = nx;
     }
 }
 
@@ -266,8 +316,22 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int strip = blockIdx.x, b = blockIdx.z;
-    const int band = blockIdx.y * 4 + wave;
+    // Block -> (strip, band group, pair) mapping.  swz 0: natural order (the dispatcher deals workgroup `id` to XCD id % 8, so
+    // neighbouring strips sit on different XCDs).  swz 1: bijective XCD remap of the whole grid (cdna_hip_programming.md T1).
+    // swz 2: remap of the strips inside one grid row only (gridDim.x padded to a multiple of 8 by the launcher).
+    int strip = blockIdx.x, bgrp = blockIdx.y, b = blockIdx.z;
+    if (A.swz == 1) {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
+        const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        strip = lid % gridDim.x; bgrp = (lid / gridDim.x) % gridDim.y; b = lid / (gridDim.x * gridDim.y);
+    } else if (A.swz == 2) {
+        strip = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        if (strip >= A.nstrips) return;
+    }
+    strip = __builtin_amdgcn_readfirstlane(strip); bgrp = __builtin_amdgcn_readfirstlane(bgrp); b = __builtin_amdgcn_readfirstlane(b);
+    const int band = bgrp * 4 + wave;
     const int W = A.g.w, H = A.g.h, ld = A.g.ld;
     const int y0 = band * A.rows_per_band;
     float *ring = lds + wave * (K * 256 * PPL);
@@ -276,6 +340,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
     const int own_lo = strip * STRIDE, own_hi = min(own_lo + STRIDE, W);
     const int xl = own_lo - M + lane * PPL;         // first pixel of this lane (may be < 0 or >= W)
     const bool xok = xl >= 0 && xl < W;
+    const unsigned xc = 4u * (unsigned)min(max(xl, 0), ld - PPL);   // clamped column of the unconditional loads, in bytes (ld >= W, multiple of 64)
     const bool x_is_zero = (xl == 0);
     bool right_ok[PPL];
 #pragma unroll
@@ -283,6 +348,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
     const bool st_ok = xl >= own_lo && xl < own_hi;  // owned group (groups never straddle own_lo)
     const bool has_left = (strip == 0);                              // wave-uniform: strip contains x == 0
     const bool has_right = (own_lo - M + 64 * PPL >= W);             // wave-uniform: strip reaches x == W-1
+    const bool edge_strip = has_left || has_right;
 
     const long long pb = (long long)b * A.g.ps;
     const int cur = A.cur;
@@ -312,18 +378,18 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
     Dyn<PPL> nxt[PF];
     Stat<PPL> nst[PF];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load_input_row<PPL, PZ>(nxt[k], nst[k], B, uin, pin, ystart + k, H, xl, xok);
+    for (int k = 0; k < PF; ++k) load_input_row<PPL, PZ>(nxt[k], nst[k], B, uin, pin, ystart + k, H, xc);
     int slot0 = 0;
 
     auto emit = [&](const Dyn<PPL> &r, int orow) {
         if (orow >= y0 && orow < y1 && st_ok) {
-            const long long off = (long long)orow * ld + xl;
-            stv<PPL>(uout[0], off, r.u1);
-            stv<PPL>(uout[1], off, r.u2);
-            stv<PPL>(pout[0], off, r.p11);
-            stv<PPL>(pout[1], off, r.p12);
-            stv<PPL>(pout[2], off, r.p21);
-            stv<PPL>(pout[3], off, r.p22);
+            const long long ro = (long long)orow * ld;   // wave-uniform; owned lanes have xc == 4 * xl
+            stu<PPL>(uout[0] + ro, xc, r.u1);
+            stu<PPL>(uout[1] + ro, xc, r.u2);
+            stu<PPL>(pout[0] + ro, xc, r.p11);
+            stu<PPL>(pout[1] + ro, xc, r.p12);
+            stu<PPL>(pout[2] + ro, xc, r.p21);
+            stu<PPL>(pout[3] + ro, xc, r.p22);
         }
     };
 
@@ -335,13 +401,24 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tb(TbArgs A)
             const int slot = k % PF;
             Dyn<PPL> io = nxt[slot];
             Stat<PPL> st0 = nst[slot];
+            const int r0 = ystart + s + k;
+            // wave-uniform: can any stage of this step touch an image border (row r0-t, t < T, or the x borders)?
+            const bool edge = edge_strip || r0 < T || r0 >= H;
+            if (edge) mask_input_row<PPL, PZ>(io, st0, xok && r0 >= 0 && r0 < H);
             finish_static<PPL>(st0);
-            load_input_row<PPL, PZ>(nxt[slot], nst[slot], B, uin, pin, ystart + s + k + PF, H, xl, xok);
+            load_input_row<PPL, PZ>(nxt[slot], nst[slot], B, uin, pin, r0 + PF, H, xc);
             // even step: state SA -> SB, odd step: SB -> SA (rows past the band end are computed but never stored)
-            if ((k & 1) == 0)
-                pipeline_step<T, PPL, K>(io, st0, SA, SB, ring, slot0, lane, ystart + s + k, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
-            else
-                pipeline_step<T, PPL, K>(io, st0, SB, SA, ring, slot0, lane, ystart + s + k, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+            if (edge) {
+                if ((k & 1) == 0)
+                    pipeline_step<T, PPL, K, true>(io, st0, SA, SB, ring, slot0, lane, r0, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+                else
+                    pipeline_step<T, PPL, K, true>(io, st0, SB, SA, ring, slot0, lane, r0, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+            } else {
+                if ((k & 1) == 0)
+                    pipeline_step<T, PPL, K, false>(io, st0, SA, SB, ring, slot0, lane, r0, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+                else
+                    pipeline_step<T, PPL, K, false>(io, st0, SB, SA, ring, slot0, lane, r0, H, has_left, has_right, x_is_zero, right_ok, A.l_t, A.theta, A.taut);
+            }
             emit(io, ystart + s + k - T);
             slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
         }
@@ -358,11 +435,16 @@ struct TbVariant {
 };
 
 template <int T, int PPL, int WPS, int PF>
-static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
+static void launch_tb(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
     constexpr int STRIDE = 64 * PPL - 2 * M;
-    const dim3 grid(div_up(A.g.w, STRIDE), div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
+    TbArgs A = A0;
+    A.nstrips = div_up(A.g.w, STRIDE);
+    static int swz = -1;
+    if (swz < 0) { const char *e = getenv("MIFLOW_TB_SWZ"); swz = e ? atoi(e) : 1; }
+    A.swz = swz;
+    const dim3 grid(swz == 2 ? div_up(A.nstrips, 8) * 8 : A.nstrips, div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
     constexpr size_t lds_bytes = (size_t)4 * (T + 1) * 256 * PPL * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -377,16 +459,13 @@ static void launch_tb(const TbArgs &A, bool pz, hipStream_t s)
 #define TBV(T, PPL, WPS, PF) {T, PPL, WPS, PF, launch_tb<T, PPL, WPS, PF>}
 static const TbVariant g_variants[] = {
     // defaults (first entry of each T); alternatives are selectable with MIFLOW_TB_VARIANT="ppl,wps,pf" (tuning sweeps)
-    // r01j sweep, G px-iter/s at 1080p x 16: T8 (1 px/lane, 4 waves/SIMD, 2 rows prefetched) 296 | T10 (1,3,4) 273 |
-    // T6 (1,4,2) 260 | T5 (2,3,1) 230 | T4 (2,1,1) 221 | T3 (2,4,1) 193 | T2 (1,8,1) 114
-    TBV(1, 2, 1, 1), TBV(2, 1, 8, 1), TBV(3, 2, 4, 1), TBV(4, 2, 1, 1), TBV(5, 2, 3, 1), TBV(6, 1, 4, 2), TBV(8, 1, 4, 2), TBV(10, 1, 3, 4),
-    // other prefetch depths / occupancies
-    TBV(3, 2, 3, 2), TBV(4, 2, 3, 2), TBV(5, 2, 2, 2), TBV(5, 2, 3, 2), TBV(6, 1, 5, 1), TBV(8, 1, 4, 1), TBV(10, 1, 4, 1),
-    TBV(4, 1, 6, 2), TBV(5, 1, 5, 2), TBV(6, 1, 5, 2), TBV(8, 1, 3, 2), TBV(10, 1, 3, 2),
-    TBV(4, 1, 5, 4), TBV(5, 1, 4, 4), TBV(6, 1, 4, 4), TBV(8, 1, 3, 4), TBV(3, 1, 6, 4),
-    TBV(3, 2, 3, 4), TBV(4, 2, 2, 4),
-    // PF = 1 alternatives of the r01b/r01d sweeps
-    TBV(8, 2, 1, 1), TBV(10, 2, 1, 1), TBV(5, 1, 6, 1), TBV(8, 1, 5, 1), TBV(3, 1, 8, 1),
+    // r01p sweep (interior/edge step specialisation, XCD remap), G px-iter/s at 1080p x 16: T8 (2 px/lane, 2 waves/SIMD) 346 |
+    // T10 (1 px/lane, 3 waves/SIMD, 2 rows prefetched) 311 | T6 (1,4,2) 274 | T5 (2,2,2) 255 | T4 (2,1,1) 227 | T3 163 | T2 111
+    TBV(1, 2, 1, 1), TBV(2, 1, 8, 1), TBV(3, 2, 4, 1), TBV(4, 2, 1, 1), TBV(5, 2, 2, 2), TBV(6, 1, 4, 2), TBV(8, 2, 1, 1), TBV(10, 1, 3, 2),
+    // alternatives (tuning sweeps)
+    TBV(3, 2, 3, 2), TBV(4, 2, 3, 2), TBV(5, 2, 3, 1), TBV(5, 2, 3, 2), TBV(6, 1, 5, 1), TBV(8, 1, 4, 1), TBV(8, 1, 4, 2), TBV(10, 1, 4, 1),
+    TBV(4, 1, 6, 2), TBV(5, 1, 5, 2), TBV(6, 1, 5, 2), TBV(8, 1, 3, 2), TBV(10, 1, 3, 4),
+    TBV(4, 1, 5, 4), TBV(5, 1, 4, 4), TBV(6, 1, 4, 4), TBV(8, 1, 3, 4), TBV(10, 2, 1, 1),
 };
 
 static const TbVariant *pick_variant(int T)
@@ -409,12 +488,12 @@ static const TbVariant *pick_variant(int T)
 int tb_max_block() { return 10; }
 
 // Decompose n iterations into supported time blocks minimising the modelled cost.  cost[T] = measured
-// ps per pixel-iteration of k_iterate_tb<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01j):
+// ps per pixel-iteration of k_iterate_tb<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01p):
 // deeper blocks save HBM passes but cost registers (occupancy) and halo recomputation.
 int tb_plan(int n, int cap, int *blocks, int max_blocks)
 {
     static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
-    static const double cost[11] = {0, 16.9, 8.77, 5.18, 4.52, 4.35, 3.85, 0, 3.38, 0, 3.66};
+    static const double cost[11] = {0, 15.5, 9.0, 6.14, 4.41, 3.92, 3.65, 0, 2.89, 0, 3.21};
     if (n <= 0) return 0;
     if (getenv("MIFLOW_TB_FORCE")) {   // tuning sweeps: greedy blocks of exactly `cap` (then the largest that fit)
         int k = 0;
