@@ -18,24 +18,15 @@
 // 857-899, 1096-1112, 1140-1181): thresholding written as fi = clamp(-rho/g, +-l_t), reciprocals
 // via v_rcp_f32, |grad u| via v_sqrt_f32, fma contraction.  Parity of this path is tested
 // against the exact-math v1 kernel and the oracle with a stated tolerance.
-#include "tvl1_dev.h"
+#include "tvl1_tb_dev.h"
 #include <cfloat>
 #include <vector>
 #include <cstdlib>
+#include <cstdio>
 
 namespace mi {
 namespace tvl1 {
 
-// lane n <- lane n-1 (wave_shr:1) / lane n <- lane n+1 (wave_shl:1); semantics verified on HW
-// by tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics through mi_dbg_lane_shift.
-__device__ __forceinline__ float dpp_from_prev(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_from_next(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
-}
 
 __global__ void k_dbg_lane_shift(int *out)
 {
@@ -44,24 +35,6 @@ __global__ void k_dbg_lane_shift(int *out)
     out[64 + l] = __float_as_int(dpp_from_next(__int_as_float(l + 100)));
 }
 
-// Dynamic state of one pipeline stage: u_t(a) and p_(t-1)(a) of the row it holds.
-template <int PPL>
-struct Dyn {
-    float u1[PPL], u2[PPL], p11[PPL], p12[PPL], p21[PPL], p22[PPL];
-};
-template <int PPL>
-struct Stat {  // static planes of one row: I1wx, I1wy, 1/grad, rho_c
-    float ix[PPL], iy[PPL], rg[PPL], rc[PPL];
-};
-
-struct TbArgs {
-    IterPlanes pl;
-    Geo g;
-    float l_t, theta, taut;
-    int rows_per_band;
-    int cur;  // input set
-    int swz, nstrips;
-};
 
 template <int PPL>
 __device__ __forceinline__ void ldv(float dst[PPL], const float *p, long long off, bool ok)
@@ -84,45 +57,6 @@ __device__ __forceinline__ void stv(float *p, long long off, const float v[PPL])
     if (PPL == 1) p[off] = v[0];
     else if (PPL == 2) *reinterpret_cast<float2 *>(p + off) = make_float2(v[0], v[1]);
     else *reinterpret_cast<float4 *>(p + off) = make_float4(v[0], v[1], v[2], v[3]);
-}
-// per-wave LDS ring of static rows: slot layout [plane 0..3][64*PPL floats]
-template <int PPL>
-__device__ __forceinline__ void lds_put(float *slot, int lane, const Stat<PPL> &s)
-{
-    float *q = slot + lane * PPL;
-    if (PPL == 1) {
-        q[0] = s.ix[0]; q[64] = s.iy[0]; q[128] = s.rg[0]; q[192] = s.rc[0];
-    } else if (PPL == 2) {
-        *reinterpret_cast<float2 *>(q) = make_float2(s.ix[0], s.ix[1]);
-        *reinterpret_cast<float2 *>(q + 128) = make_float2(s.iy[0], s.iy[1]);
-        *reinterpret_cast<float2 *>(q + 256) = make_float2(s.rg[0], s.rg[1]);
-        *reinterpret_cast<float2 *>(q + 384) = make_float2(s.rc[0], s.rc[1]);
-    } else {
-        *reinterpret_cast<float4 *>(q) = make_float4(s.ix[0], s.ix[1], s.ix[2], s.ix[3]);
-        *reinterpret_cast<float4 *>(q + 256) = make_float4(s.iy[0], s.iy[1], s.iy[2], s.iy[3]);
-        *reinterpret_cast<float4 *>(q + 512) = make_float4(s.rg[0], s.rg[1], s.rg[2], s.rg[3]);
-        *reinterpret_cast<float4 *>(q + 768) = make_float4(s.rc[0], s.rc[1], s.rc[2], s.rc[3]);
-    }
-}
-template <int PPL>
-__device__ __forceinline__ void lds_get(const float *slot, int lane, Stat<PPL> &s)
-{
-    const float *q = slot + lane * PPL;
-    if (PPL == 1) {
-        s.ix[0] = q[0]; s.iy[0] = q[64]; s.rg[0] = q[128]; s.rc[0] = q[192];
-    } else if (PPL == 2) {
-        float2 a = *reinterpret_cast<const float2 *>(q), b = *reinterpret_cast<const float2 *>(q + 128);
-        float2 c = *reinterpret_cast<const float2 *>(q + 256), d = *reinterpret_cast<const float2 *>(q + 384);
-        s.ix[0] = a.x; s.ix[1] = a.y; s.iy[0] = b.x; s.iy[1] = b.y;
-        s.rg[0] = c.x; s.rg[1] = c.y; s.rc[0] = d.x; s.rc[1] = d.y;
-    } else {
-        float4 a = *reinterpret_cast<const float4 *>(q), b = *reinterpret_cast<const float4 *>(q + 256);
-        float4 c = *reinterpret_cast<const float4 *>(q + 512), d = *reinterpret_cast<const float4 *>(q + 768);
-        s.ix[0] = a.x; s.ix[1] = a.y; s.ix[2] = a.z; s.ix[3] = a.w;
-        s.iy[0] = b.x; s.iy[1] = b.y; s.iy[2] = b.z; s.iy[3] = b.w;
-        s.rg[0] = c.x; s.rg[1] = c.y; s.rg[2] = c.z; s.rg[3] = c.w;
-        s.rc[0] = d.x; s.rc[1] = d.y; s.rc[2] = d.z; s.rc[3] = d.w;
-    }
 }
 
 // One pipeline stage (iteration level t).  `in` = level t-1 row a (u, p), `st` = static row a,
@@ -200,46 +134,6 @@ __device__ __forceinline__ void stage(Dyn<PPL> &in, const Stat<PPL> &st, const D
     }
 }
 
-// Row prefetch.  The loads are UNCONDITIONAL (clamped row / column, uniform row base + 32-bit lane offset): a load inside a
-// divergent `if` sits in its own basic block, and the waitcnt pass then has to assume vmcnt(0) at every later use, which
-// serialises the prefetch (r01k ISA).  Out-of-image rows/columns are zeroed when the row is consumed (mask_input_row).
-// Pins a wave-uniform row pointer into an SGPR pair so that the access is emitted as `global_* v, voffset, s[base:base+1]`
-// (otherwise base + lane offset is reassociated into per-plane 64-bit VGPR addresses hoisted out of the row loop: 32 VGPRs
-// and two VALU adds per access).  The integer round trip drops the inferred address space, hence the explicit global one.
-#define MI_GLOBAL __attribute__((address_space(1)))
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ MI_GLOBAL char *sgpr_row(const void *p)
-{
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (MI_GLOBAL char *)(((unsigned long long)hi << 32) | lo);
-}
-// Row prefetch.  The loads are UNCONDITIONAL (clamped row / column): a load inside a divergent `if` sits in its own basic
-// block, and the waitcnt pass then has to assume vmcnt(0) at every later use, which serialises the prefetch (r01k ISA).
-// Out-of-image rows/columns are zeroed when the row is consumed (mask_input_row).  xb = lane offset in BYTES.
-template <int PPL>
-__device__ __forceinline__ void ldu(float dst[PPL], const float *rowp, unsigned xb)
-{
-    const MI_GLOBAL char *q = sgpr_row(rowp) + xb;
-    if (PPL == 1) {
-        dst[0] = *(const MI_GLOBAL float *)q;
-    } else if (PPL == 2) {
-        const f2v v = *(const MI_GLOBAL f2v *)q;
-        dst[0] = v.x; dst[1] = v.y;
-    } else {
-        const f4v v = *(const MI_GLOBAL f4v *)q;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    }
-}
-template <int PPL>
-__device__ __forceinline__ void stu(float *rowp, unsigned xb, const float v[PPL])
-{
-    MI_GLOBAL char *q = sgpr_row(rowp) + xb;
-    if (PPL == 1) *(MI_GLOBAL float *)q = v[0];
-    else if (PPL == 2) *(MI_GLOBAL f2v *)q = f2v{v[0], v[1]};
-    else *(MI_GLOBAL f4v *)q = f4v{v[0], v[1], v[2], v[3]};
-}
 template <int PPL, bool PZ>
 __device__ __forceinline__ void load_input_row(Dyn<PPL> &r, Stat<PPL> &st, const TbArgs &A, const float *const u[2],
                                                const float *const p[4], int row, int H, unsigned xc)
@@ -274,13 +168,6 @@ __device__ __forceinline__ void mask_input_row(Dyn<PPL> &r, Stat<PPL> &st, bool 
             r.p21[j] = ok ? r.p21[j] : 0.f; r.p22[j] = ok ? r.p22[j] : 0.f;
         }
     }
-}
-// 1/grad; grad == 0 -> huge, so that clamp() yields -+l_t*sign(rho) like the reference's first two branches
-template <int PPL>
-__device__ __forceinline__ void finish_static(Stat<PPL> &st)
-{
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) st.rg[j] = __builtin_amdgcn_rcpf(fmaxf(st.rg[j], 1e-30f));
 }
 
 // One step of the whole pipeline: row `arow` of level 0 enters, row arow-T of level T leaves in `io`.  The static row of
@@ -458,14 +345,10 @@ static void launch_tb(const TbArgs &A0, bool pz, hipStream_t s)
 
 #define TBV(T, PPL, WPS, PF) {T, PPL, WPS, PF, launch_tb<T, PPL, WPS, PF>}
 static const TbVariant g_variants[] = {
-    // defaults (first entry of each T); alternatives are selectable with MIFLOW_TB_VARIANT="ppl,wps,pf" (tuning sweeps)
-    // r01p sweep (interior/edge step specialisation, XCD remap), G px-iter/s at 1080p x 16: T8 (2 px/lane, 2 waves/SIMD) 346 |
-    // T10 (1 px/lane, 3 waves/SIMD, 2 rows prefetched) 311 | T6 (1,4,2) 274 | T5 (2,2,2) 255 | T4 (2,1,1) 227 | T3 163 | T2 111
+    // ping-pong-state kernels (MIFLOW_TB_ROT=0; superseded by tvl1_tbr_kernels.hip, kept as an independent cross-check).
+    // r01p sweep, G px-iter/s at 1080p x 16: T8 (2 px/lane) 346 | T10 (1 px/lane, 3 waves/SIMD, 2 rows prefetched) 311 |
+    // T6 (1,4,2) 274 | T5 (2,2,2) 255 | T4 (2,1,1) 227 | T3 163 | T2 111
     TBV(1, 2, 1, 1), TBV(2, 1, 8, 1), TBV(3, 2, 4, 1), TBV(4, 2, 1, 1), TBV(5, 2, 2, 2), TBV(6, 1, 4, 2), TBV(8, 2, 1, 1), TBV(10, 1, 3, 2),
-    // alternatives (tuning sweeps)
-    TBV(3, 2, 3, 2), TBV(4, 2, 3, 2), TBV(5, 2, 3, 1), TBV(5, 2, 3, 2), TBV(6, 1, 5, 1), TBV(8, 1, 4, 1), TBV(8, 1, 4, 2), TBV(10, 1, 4, 1),
-    TBV(4, 1, 6, 2), TBV(5, 1, 5, 2), TBV(6, 1, 5, 2), TBV(8, 1, 3, 2), TBV(10, 1, 3, 4),
-    TBV(4, 1, 5, 4), TBV(5, 1, 4, 4), TBV(6, 1, 4, 4), TBV(8, 1, 3, 4), TBV(10, 2, 1, 1),
 };
 
 static const TbVariant *pick_variant(int T)
@@ -488,12 +371,12 @@ static const TbVariant *pick_variant(int T)
 int tb_max_block() { return 10; }
 
 // Decompose n iterations into supported time blocks minimising the modelled cost.  cost[T] = measured
-// ps per pixel-iteration of k_iterate_tb<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01p):
+// ps per pixel-iteration of k_iterate_tb<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01s, rotating-slot kernels):
 // deeper blocks save HBM passes but cost registers (occupancy) and halo recomputation.
 int tb_plan(int n, int cap, int *blocks, int max_blocks)
 {
     static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
-    static const double cost[11] = {0, 15.5, 9.0, 6.14, 4.41, 3.92, 3.65, 0, 2.89, 0, 3.21};
+    static const double cost[11] = {0, 15.6, 9.4, 6.6, 4.65, 3.9, 3.7, 0, 2.83, 0, 2.54};
     if (n <= 0) return 0;
     if (getenv("MIFLOW_TB_FORCE")) {   // tuning sweeps: greedy blocks of exactly `cap` (then the largest that fit)
         int k = 0;
@@ -523,10 +406,27 @@ int tb_plan(int n, int cap, int *blocks, int max_blocks)
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s)
 {
-    const TbVariant *v = pick_variant(T);
-    if (!v) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
+    // kernel family: 1 = rotating-slot formulation (tvl1_tbr_kernels.hip) where it has an entry for T, 0 = ping-pong state
+    static int rot = -1, want_ppl = -1, want_wps = -1, want_pf = -1;
+    if (rot < 0) {
+        const char *e = getenv("MIFLOW_TB_ROT");
+        rot = e ? atoi(e) : 1;
+        if (const char *v = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(v, "%d,%d,%d", &want_ppl, &want_wps, &want_pf);
+    }
+    int ppl = 0, wps_v = 0, pf = 0, ring_slots = T + 1, rot_P = 0;
+    TbLaunch launch = nullptr;
+    if (rot) {
+        launch = tbr_pick(T, want_ppl, want_wps, want_pf, &ppl, &wps_v, &pf);
+        ring_slots = T > 2 ? T - 1 : 1;
+        if (launch) rot_P = T + 1 + pf;
+    }
+    if (!launch) {
+        const TbVariant *v = pick_variant(T);
+        if (!v) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
+        launch = v->launch; ppl = v->PPL; wps_v = v->WPS; pf = v->PF; ring_slots = T + 1; rot_P = 0;
+    }
     TbArgs A;
-    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.swz = 0; A.nstrips = 0;
     if (rows_per_band <= 0) {
         // Band height: every wave streams rows_per_band + 2T rows.  Pick the band count that minimises
         //   rounds x (rows + 2T),  rounds = ceil(waves / resident-wave capacity),
@@ -534,27 +434,35 @@ int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta
         // band overlap stays small.  Capacity: waves/SIMD allowed by the variant's VGPR count
         // (-Rpass-analysis=kernel-resource-usage, gfx950), its LDS ring and the 8-wave hardware limit.
         static const int wps_of_T_ppl2[11] = {8, 7, 5, 4, 3, 3, 2, 2, 2, 2, 2};
-        int wps = v->WPS > 1 ? v->WPS : (v->PPL == 2 ? wps_of_T_ppl2[T] : 4);
-        const int lds_blocks = (160 * 1024) / ((T + 1) * 4 * 256 * v->PPL * 4);
+        int wps = wps_v > 1 ? wps_v : (ppl == 2 ? wps_of_T_ppl2[T] : 4);
+        const int lds_blocks = (160 * 1024) / (ring_slots * 4 * 256 * ppl * 4);
         if (wps > lds_blocks) wps = lds_blocks;
         if (const char *e = getenv("MIFLOW_TB_WPS")) wps = atoi(e) > 0 ? atoi(e) : wps;
         const long long cap = 1024LL * wps;
-        const int M = (T + v->PPL - 1) / v->PPL * v->PPL;
-        const long long per_band = (long long)div_up(g.w, 64 * v->PPL - 2 * M) * g.batch;
+        const int M = (T + ppl - 1) / ppl * ppl;
+        const long long per_band = (long long)div_up(g.w, 64 * ppl - 2 * M) * g.batch;
         long long best_cost = -1;
         int best_nb = 1;
         for (int nb = 1; nb <= g.h; ++nb) {
             const int R = div_up(g.h, nb);
             if (R < 8 && nb > 1) break;
             const long long rounds = (per_band * nb + cap - 1) / cap;
-            const long long cost = rounds * (R + 2 * T);
+            long long steps = R + 2 * T;
+            if (rot_P > 0) steps = (steps + rot_P - 1) / rot_P * rot_P;   // rotating kernels run whole blocks of P steps
+            const long long cost = rounds * steps;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_nb = nb; }
         }
         rows_per_band = div_up(g.h, best_nb);
         if (const char *e = getenv("MIFLOW_TB_ROWS")) rows_per_band = atoi(e) > 0 ? atoi(e) : rows_per_band;
     }
     A.rows_per_band = rows_per_band;
-    v->launch(A, p_zero, s);
+    if (getenv("MIFLOW_TB_VERBOSE")) {
+        static int shown = 0;
+        if (shown++ < 40)
+            fprintf(stderr, "[tb] T=%d rot=%d ppl=%d wps=%d pf=%d %dx%d batch=%d rows_per_band=%d\n", T, rot_P > 0, ppl, wps_v, pf, g.w, g.h,
+                    g.batch, rows_per_band);
+    }
+    launch(A, p_zero, s);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

@@ -1,0 +1,349 @@
+// Dual TV-L1 -- temporally blocked fused iteration, ROTATING-SLOT formulation (gfx950, wave64).
+//
+// Same pipeline as tvl1_tb_kernels.hip (T iteration levels = T pipeline stages, one image row apart, all state in VGPRs,
+// static planes on a per-wave LDS ring, x-neighbours by DPP), but the stage is written as an IN-PLACE update so that no
+// state is ever copied and no border handling needs a branch:
+//
+//   stage t sees   A = (u_(t-1), p_(t-1)) of row a      (its input)        B = (u_t, p_(t-1)) of row a-1   (its held state)
+//   and leaves     A = (u_t,     p_(t-1)) of row a      (its NEW state)    B = (u_t, p_t)     of row a-1   (its output)
+//
+// i.e. only A.u and B.p are overwritten, and the two register sets swap roles.  A stage's output set is the next stage's
+// input set, so after one pipeline step every held state has moved by one register set: with P = T + 1 + PF sets
+// (T held states + the row in flight + PF prefetched rows) and the row loop unrolled P times, set indices are compile-time
+// constants and the assignment returns to itself at the loop back-edge -- no v_mov, no ping-pong copy of the state
+// (the SA/SB scheme of tvl1_tb_kernels.hip needs 12 registers per stage and pixel, this one 6), prefetched rows land
+// directly in the set that consumes them.
+//
+// Borders without branches (profiles/r01p: the five wave-uniform border branches per stage cost 16-25 %):
+//   * left:   strip 0 starts at x = 0 in lane 0, so the zero fill of `wave_shr:1 bound_ctrl` IS the missing p(x-1) term
+//             (optflow/src/tvl1flow.cpp:893-894);
+//   * right:  forward x-difference forced to 0 by a per-lane select (:833-838);
+//   * top:    the p(y-1) term of row 0 is cut at the consumer, div = dx + fma(-m1, p12(a-1), p12(a)), m1 = (a != 0) (:889-890);
+//   * bottom: the forward y-difference of row H-1 is multiplied by m2 = (a != H) (:826-831).
+// Rows above / below the image and columns right of it are loaded from clamped addresses (finite data) and are isolated
+// from the valid region by exactly these four cuts, so loads are unconditional and nothing is masked.
+//
+// Arithmetic: the fast-math form of tvl1_tb_kernels.hip (v_rcp / v_sqrt / fma); parity against the oracle and the exact
+// kernel is tested with a stated tolerance (tests/test_tvl1_gpu.py).
+#include "tvl1_tb_dev.h"
+#include <utility>
+#include <cstdlib>
+#include <cstdio>
+
+namespace mi {
+namespace tvl1 {
+
+template <int PPL>
+struct Slot {
+    Dyn<PPL> d;
+    Stat<PPL> s;
+};
+
+// In-place stage.  negm1 = -(a != 0), m2 = (a != H), taum2 = taut * m2 are wave-uniform scalars.
+template <int PPL>
+__device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
+                                        float m2, float taum2, float l_t, float theta, float taut)
+{
+    float dx1[PPL], dx2[PPL];
+    dx1[0] = A.p11[0] - dpp_from_prev(A.p11[PPL - 1]);
+    dx2[0] = A.p21[0] - dpp_from_prev(A.p21[PPL - 1]);
+#pragma unroll
+    for (int j = 1; j < PPL; ++j) { dx1[j] = A.p11[j] - A.p11[j - 1]; dx2[j] = A.p21[j] - A.p21[j - 1]; }
+    const float r1 = dpp_from_next(B.u1[0]);
+    const float r2 = dpp_from_next(B.u2[0]);
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        // ---- u_t(a)   (optflow/src/tvl1flow.cpp:989-1041, 1096-1112; TH written as clamp(-rho/grad, +-l_t))
+        const float div1 = dx1[j] + fmaf(negm1, B.p12[j], A.p12[j]);
+        const float div2 = dx2[j] + fmaf(negm1, B.p22[j], A.p22[j]);
+        const float rho = fmaf(st.ix[j], A.u1[j], fmaf(st.iy[j], A.u2[j], st.rc[j]));
+        const float fi = __builtin_amdgcn_fmed3f(-rho * st.rg[j], -l_t, l_t);
+        const float nu1 = fmaf(theta, div1, fmaf(fi, st.ix[j], A.u1[j]));
+        const float nu2 = fmaf(theta, div2, fmaf(fi, st.iy[j], A.u2[j]));
+        // ---- p_t(a-1)  (:1140-1181)
+        const float n1 = (j + 1 < PPL) ? B.u1[j + 1 < PPL ? j + 1 : j] : r1;
+        const float n2 = (j + 1 < PPL) ? B.u2[j + 1 < PPL ? j + 1 : j] : r2;
+        const float u1x = right_ok[j] ? n1 - B.u1[j] : 0.f;
+        const float u2x = right_ok[j] ? n2 - B.u2[j] : 0.f;
+        const float d1 = nu1 - B.u1[j];
+        const float d2 = nu2 - B.u2[j];
+        const float g1 = __builtin_amdgcn_sqrtf(fmaf(d1 * d1, m2, u1x * u1x));
+        const float g2 = __builtin_amdgcn_sqrtf(fmaf(d2 * d2, m2, u2x * u2x));
+        const float q1 = __builtin_amdgcn_rcpf(fmaf(taut, g1, 1.0f));
+        const float q2 = __builtin_amdgcn_rcpf(fmaf(taut, g2, 1.0f));
+        B.p11[j] = fmaf(taut, u1x, B.p11[j]) * q1;
+        B.p12[j] = fmaf(taum2, d1, B.p12[j]) * q1;
+        B.p21[j] = fmaf(taut, u2x, B.p21[j]) * q2;
+        B.p22[j] = fmaf(taum2, d2, B.p22[j]) * q2;
+        A.u1[j] = nu1;
+        A.u2[j] = nu2;
+    }
+}
+
+// Row accesses as `global_* v, voffset, s[base]`: the row base (plane + row * ld) is wave-uniform and the lane offset is made
+// opaque per row (empty asm), otherwise LICM re-associates base + lane offset into per-plane 64-bit VGPR addresses.
+template <int PPL>
+__device__ __forceinline__ void ldr(float dst[PPL], const float *rowp, unsigned xb)
+{
+    const char *q = reinterpret_cast<const char *>(rowp) + xb;
+    if (PPL == 1) {
+        dst[0] = *reinterpret_cast<const float *>(q);
+    } else if (PPL == 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(q);
+        dst[0] = v.x; dst[1] = v.y;
+    } else {
+        const float4 v = *reinterpret_cast<const float4 *>(q);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+template <int PPL>
+__device__ __forceinline__ void str(float *rowp, unsigned xb, const float v[PPL])
+{
+    char *q = reinterpret_cast<char *>(rowp) + xb;
+    if (PPL == 1) *reinterpret_cast<float *>(q) = v[0];
+    else if (PPL == 2) *reinterpret_cast<float2 *>(q) = make_float2(v[0], v[1]);
+    else *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int PPL, bool PZ>
+__device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const float *const u[2], const float *const p[4], int row,
+                                           int H, unsigned xc)
+{
+    const long long ro = (long long)min(max(row, 0), H - 1) * A.g.ld;   // wave-uniform
+    asm volatile("" : "+v"(xc));
+    ldr<PPL>(x.s.ix, A.pl.ix + ro, xc);
+    ldr<PPL>(x.s.iy, A.pl.iy + ro, xc);
+    ldr<PPL>(x.s.rg, A.pl.g + ro, xc);   // RAW |grad|^2 until the row is consumed (finish_static)
+    ldr<PPL>(x.s.rc, A.pl.rc + ro, xc);
+    ldr<PPL>(x.d.u1, u[0] + ro, xc);
+    ldr<PPL>(x.d.u2, u[1] + ro, xc);
+    if (!PZ) {
+        ldr<PPL>(x.d.p11, p[0] + ro, xc);
+        ldr<PPL>(x.d.p12, p[1] + ro, xc);
+        ldr<PPL>(x.d.p21, p[2] + ro, xc);
+        ldr<PPL>(x.d.p22, p[3] + ro, xc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) x.d.p11[j] = x.d.p12[j] = x.d.p21[j] = x.d.p22[j] = 0.f;
+    }
+}
+
+// Wave-constant context of the row loop (all scalars after inlining).
+template <int PPL>
+struct CtxR {
+    TbArgs B;                 // plane pointers already offset to the pair
+    const float *uin[2], *pin[4];
+    float *uout[2], *pout[4];
+    float *ring;
+    int lane, H, ld, y0, y1, ystart, nsteps;
+    unsigned xc;
+    bool st_ok;
+    bool right_ok[PPL];
+    float l_t, theta, taut;
+};
+
+// Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
+// No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
+// block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
+template <int T, int PPL, bool PZ, int PF, int k>
+__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0)
+{
+    constexpr int P = T + 1 + PF;
+    constexpr int K = T > 2 ? T - 1 : 1;
+    const int n = n0 + k;
+    const int r0 = c.ystart + n;
+    finish_static<PPL>(X[k].s);
+#ifndef TBR_X_NOLOAD   // timing experiments only (wrong results): no row loads after the prologue
+    load_row_r<PPL, PZ>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
+#else
+    X[(k + PF) % P] = X[k];
+#endif
+    // static rows: stage 0 reads the registers of the entering row, stage 1 those of the previous row (still in its
+    // register set), stages t >= 2 the LDS ring (row n - t), fetched one stage early.  The entering row is written to the ring
+    // after the last read of the step has been issued: it replaces row n - (T-1), so K = T - 1 slots suffice.
+    Stat<PPL> nx;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) nx.ix[j] = nx.iy[j] = nx.rg[j] = nx.rc[j] = 0.f;
+    if (T < 3) lds_put<PPL>(c.ring + slot0 * (256 * PPL), c.lane, X[k].s);   // (unused ring: keeps the code uniform)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        Stat<PPL> st;
+        if (t == 0) st = X[k].s;
+        else if (t == 1) st = X[(k - 1 + P) % P].s;
+        else st = nx;
+#ifdef TBR_X_NOLDS
+        if (t >= 2) st = X[k].s;
+#else
+        if (t + 1 < T && t + 1 >= 2) {
+            int sl = slot0 - (t + 1);
+            if (sl < 0) sl += K;
+            lds_get<PPL>(c.ring + sl * (256 * PPL), c.lane, nx);
+            if (t + 1 == T - 1) lds_put<PPL>(c.ring + slot0 * (256 * PPL), c.lane, X[k].s);
+        }
+#endif
+        const int a = r0 - t;   // row of the stage's input
+        // wave-uniform masks, selected as INTEGERS so that they stay on the scalar unit (a float select is lowered to v_cndmask)
+        const float negm1 = __uint_as_float((a == 0) ? 0u : 0xbf800000u);
+        const float m2 = __uint_as_float((a == c.H) ? 0u : 0x3f800000u);
+        const float taum2 = __uint_as_float((a == c.H) ? 0u : __float_as_uint(c.taut));
+        stage_r<PPL>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut);
+    }
+    {   // level-T row r0 - T leaves the pipeline
+        const Dyn<PPL> &r = X[(k - T + 2 * P) % P].d;
+        const int orow = r0 - T;
+#ifdef TBR_X_NOSTORE
+        if (orow == c.y1 - 1 && c.st_ok) {
+#else
+        if (orow >= c.y0 && orow < c.y1 && c.st_ok) {
+#endif
+            const long long ro = (long long)orow * c.ld;   // wave-uniform; owned lanes have xc == 4 * xl
+            unsigned xb = c.xc;
+            asm volatile("" : "+v"(xb));
+            str<PPL>(c.uout[0] + ro, xb, r.u1);
+            str<PPL>(c.uout[1] + ro, xb, r.u2);
+            str<PPL>(c.pout[0] + ro, xb, r.p11);
+            str<PPL>(c.pout[1] + ro, xb, r.p12);
+            str<PPL>(c.pout[2] + ro, xb, r.p21);
+            str<PPL>(c.pout[3] + ro, xb, r.p22);
+        }
+    }
+    slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
+}
+template <int T, int PPL, bool PZ, int PF, int... Ks>
+__device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, std::integer_sequence<int, Ks...>)
+{
+    (step_r<T, PPL, PZ, PF, Ks>(c, X, n0, slot0), ...);
+}
+
+template <int T, int PPL, bool PZ, int WPS, int PF>
+__global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
+{
+    constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
+    constexpr int LW = 64 * PPL;                   // pixels a wave covers
+    constexpr int STRIDE = LW - 2 * M;             // owned columns of the strips >= 1 (strip 0 owns LW - M)
+    constexpr int P = T + 1 + PF;                  // register sets
+    constexpr int K = T > 2 ? T - 1 : 1;           // LDS ring slots: the row of step n is read by stages 2..T-1 at steps n+2..n+T-1
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    CtxR<PPL> c;
+    c.lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // block -> (strip, band group, pair), see k_iterate_tb
+    int strip = blockIdx.x, bgrp = blockIdx.y, b = blockIdx.z;
+    if (A.swz == 1) {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
+        const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        strip = lid % gridDim.x; bgrp = (lid / gridDim.x) % gridDim.y; b = lid / (gridDim.x * gridDim.y);
+    }
+    strip = __builtin_amdgcn_readfirstlane(strip); bgrp = __builtin_amdgcn_readfirstlane(bgrp); b = __builtin_amdgcn_readfirstlane(b);
+    const int band = bgrp * 4 + wave;
+    const int W = A.g.w;
+    c.H = A.g.h; c.ld = A.g.ld;
+    c.y0 = band * A.rows_per_band;
+    c.ring = lds + wave * (K * 256 * PPL);
+    if (c.y0 >= c.H) return;
+    c.y1 = min(c.y0 + A.rows_per_band, c.H);
+    // strip 0 starts at the image border in lane 0; strip s >= 1 starts M px left of what it owns
+    const int own_lo = strip == 0 ? 0 : (LW - M) + (strip - 1) * STRIDE;
+    const int own_hi = min(strip == 0 ? LW - M : own_lo + STRIDE, W);
+    const int xl = (strip == 0 ? 0 : own_lo - M) + c.lane * PPL;   // first pixel of this lane, >= 0
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) c.right_ok[j] = (xl + j + 1 < W);
+    c.st_ok = xl >= own_lo && xl < own_hi;
+    c.xc = 4u * (unsigned)min(xl, c.ld - PPL);   // clamped column of the unconditional loads, bytes
+
+    const long long pb = (long long)b * A.g.ps;
+    const int cur = A.cur;
+    c.uin[0] = A.pl.u[cur][0] + pb; c.uin[1] = A.pl.u[cur][1] + pb;
+    c.uout[0] = A.pl.u[cur ^ 1][0] + pb; c.uout[1] = A.pl.u[cur ^ 1][1] + pb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c.pin[i] = A.pl.p[cur][i] + pb; c.pout[i] = A.pl.p[cur ^ 1][i] + pb; }
+    c.B = A;
+    c.B.pl.ix += pb; c.B.pl.iy += pb; c.B.pl.g += pb; c.B.pl.rc += pb;
+    c.l_t = A.l_t; c.theta = A.theta; c.taut = A.taut;
+
+    Slot<PPL> X[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            X[i].d.u1[j] = X[i].d.u2[j] = X[i].d.p11[j] = X[i].d.p12[j] = X[i].d.p21[j] = X[i].d.p22[j] = 0.f;
+            X[i].s.ix[j] = X[i].s.iy[j] = X[i].s.rg[j] = X[i].s.rc[j] = 0.f;
+        }
+    for (int k = 0; k < K; ++k) lds_put<PPL>(c.ring + k * (256 * PPL), c.lane, X[0].s);
+
+    c.ystart = c.y0 - T;
+    c.nsteps = (c.y1 - c.y0) + 2 * T;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
+    int slot0 = 0;   // ring slot of the row entering at this step (= step mod K)
+    for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF>(c, X, n0, slot0, std::make_integer_sequence<int, P>{});
+}
+
+template <int T, int PPL, int WPS, int PF>
+static void launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
+{
+    constexpr int M = (T + PPL - 1) / PPL * PPL;
+    constexpr int LW = 64 * PPL;
+    constexpr int STRIDE = LW - 2 * M;
+    TbArgs A = A0;
+    A.nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
+    static int swz = -1;
+    if (swz < 0) { const char *e = getenv("MIFLOW_TB_SWZ"); swz = e ? atoi(e) : 1; }
+    A.swz = swz == 1 ? 1 : 0;
+    const dim3 grid(A.nstrips, div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
+    constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    if (getenv("MIFLOW_TB_VERBOSE")) {
+        static bool shown = false;
+        if (!shown) {
+            shown = true;
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, 256, lds_bytes);
+            fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, lds_bytes, nb);
+        }
+    }
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
+}
+
+// WPS = occupancy the register allocator is held to (launch bound); PLAN = waves/SIMD the band planner assumes.  r01s: the
+// T10 kernel is resident 4 waves/SIMD but fastest when the grid is cut for 3 (394 vs 340 G px-iter/s): with all four slots
+// full the 46 KB unrolled loop of 16 waves per CU at 16 different positions overruns the instruction cache.
+struct TbrEntry {
+    int T, PPL, WPS, PF, PLAN;
+    TbLaunch launch;
+};
+#define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF>}
+static const TbrEntry g_tbr[] = {
+    // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
+    TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
+    TBR(1, 1, 8, 2, 8),
+    // alternatives (tuning sweeps)
+    TBR(10, 1, 4, 1, 3), TBR(10, 2, 2, 2, 2), TBR(8, 1, 4, 2, 2), TBR(8, 1, 5, 1, 3), TBR(6, 1, 6, 1, 4), TBR(6, 2, 3, 2, 3), TBR(5, 1, 6, 2, 4),
+    TBR(4, 1, 7, 2, 6),
+};
+
+// First entry of time block T, or the entry matching (ppl, wps, pf) when those are >= 0.  Returns nullptr if T has none.
+// *wps receives the occupancy the band planner should assume.
+TbLaunch tbr_pick(int T, int want_ppl, int want_wps, int want_pf, int *ppl, int *wps, int *pf)
+{
+    const TbrEntry *def = nullptr;
+    for (const TbrEntry &e : g_tbr) {
+        if (e.T != T) continue;
+        if (!def) def = &e;
+        if (e.PPL == want_ppl && e.WPS == want_wps && e.PF == want_pf) { def = &e; break; }
+    }
+    if (!def) return nullptr;
+    *ppl = def->PPL; *wps = def->PLAN; *pf = def->PF;
+    return def->launch;
+}
+
+}  // namespace tvl1
+}  // namespace mi

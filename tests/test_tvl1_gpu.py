@@ -19,6 +19,7 @@ from opencv_contrib_amd import synth
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def T(a, dev):
@@ -165,13 +166,38 @@ def test_iterate_blocked_matches_exact(gpu, T, shape):
             np.testing.assert_allclose(N(b), N(a), rtol=0, atol=2e-5 * niter, err_msg=f"{nm} T={T} niter={niter}")
 
 
+def test_blocked_kernel_families_agree(gpu, tmp_path):
+    """The rotating-slot kernels (default) and the older ping-pong-state kernels (MIFLOW_TB_ROT=0) are two independent
+    implementations of the same fast-math iteration: one 10-iteration pass over a multi-strip, multi-band image must agree
+    to rounding.  The family is latched per process, hence the subprocesses."""
+    import subprocess, sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from opencv_contrib_amd import cuda\n"
+        "from test_tvl1_gpu import _iter_inputs\n"
+        "I1wx, I1wy, grad, rho, u, p = _iter_inputs(211, 467, seed=11)\n"
+        "T = lambda a: torch.from_numpy(a).cuda()\n"
+        "uo, po, _ = cuda.tvl1_iterate(T(I1wx), T(I1wy), T(grad), T(rho), [T(a) for a in u], [T(a) for a in p], 0.045, 0.3, 0.25 / 0.3,"
+        " niter=10, exact=False, time_block=10, want_err=False)\n"
+        "np.save(sys.argv[1], np.stack([a.cpu().numpy() for a in uo + po]))\n" % (ROOT, os.path.join(ROOT, "tests")))
+    outs = []
+    for rot in ("1", "0"):
+        out = str(tmp_path / f"rot{rot}.npy")
+        env = dict(os.environ, MIFLOW_TB_ROT=rot)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+        outs.append(np.load(out))
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=2e-5)
+
+
 @pytest.mark.parametrize("tb", [0, 5])
 def test_calc_fast_blocked_matches_oracle(gpu, oracle, tb):
     """Product fast path (fast math + temporal blocking) against the CPU oracle, stated tolerance."""
     I0, I1, _ = synth.flow_pair(388, 584, seed=78)
     ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0))
     flow, _ = _run(gpu, I0, I1, iterations=10, epsilon=0.0, exactMath=False, timeBlock=tb)
-    _assert_flow_close(flow, ref, mean_epe=5e-3, ccorr=1e-5, frac_within=(0.02, 0.99))
+    # CCORR bound: the top image row of this pair (flow pointing out of the image) is ill-conditioned -- the EXACT path itself
+    # moves by 3.4 px there (CCORR 5e-5) under 1e-6 input noise (profiles/r01q); the reference accepts 4e-3 for CUDA vs CPU
+    _assert_flow_close(flow, ref, mean_epe=5e-3, ccorr=1e-4, frac_within=(0.02, 0.99))
 
 
 # ------------------------------------------------------------------ full calc

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-1 GPU session R: rotating-slot kernel with a (T-1)-slot LDS ring: parity, occupancy check, sweep, bench.
+set -u
+export TMPDIR=/tmp
+O=gpurun_out/r01r
+mkdir -p $O; rm -f $O/sweep.jsonl
+export MIFLOW_TB_ROT=1
+(timeout 900 python -m pytest tests/test_tvl1_gpu.py tests/test_golden.py -m gpu -q 2>&1 | tail -8) > $O/pytest_tvl1.log
+(timeout 300 python tools/sweep_tb.py --no-v1 --tag rot-defaults 2>/dev/null | tail -1) >> $O/sweep.jsonl
+for w in 3 4; do for v in "1,4,2:10" "1,4,1:10"; do
+  var=${v%%:*}; blocks=${v##*:}
+  (MIFLOW_TB_WPS=$w MIFLOW_TB_VARIANT=$var timeout 200 python tools/sweep_tb.py --blocks $blocks --tag "rot wps=$w variant=$var" --no-v1 2>/dev/null | tail -1) >> $O/sweep.jsonl
+done; done
+for v in "1,5,1:8" "2,2,2:8,10" "2,3,2:4,5,6" "1,6,1:6"; do
+  var=${v%%:*}; blocks=${v##*:}
+  (MIFLOW_TB_VARIANT=$var timeout 200 python tools/sweep_tb.py --blocks $blocks --tag "rot variant=$var" --no-v1 2>/dev/null | tail -1) >> $O/sweep.jsonl
+done
+(timeout 300 python bench.py --no-variants --no-cpu 2>/dev/null | tail -1) > $O/bench.json
+cat $O/pytest_tvl1.log
+python - <<'PY'
+import json
+for l in open('gpurun_out/r01r/sweep.jsonl'):
+    d=json.loads(l); print(d['tag'], {k:round(v['Gpxiter_per_s'],1) for k,v in d.items() if k.startswith('T')})
+d=json.loads(open('gpurun_out/r01r/bench.json').read()); print('bench', d['value'], d['roofline']['avg_launch_us'])
+PY

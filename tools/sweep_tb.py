@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--blocks", type=str, default="1,2,3,4,5,6,8,10")
     ap.add_argument("--tag", type=str, default="")
     ap.add_argument("--no-v1", action="store_true")
@@ -37,11 +37,14 @@ def main():
         alg = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=0.0, exactMath=exact, timeBlock=tb)
         alg.calc_batch(I0, I1, flows)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
+        ts = []
+        for _ in range(args.reps):   # median of individually timed calls (the slope of two such timings amplifies noise)
+            t0 = time.perf_counter()
             alg.calc_batch(I0, I1, flows)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / args.reps
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2]
 
     res = {}
     t0 = t(0, 1)
