@@ -47,7 +47,9 @@ typedef enum mi_status {
 } mi_status;
 
 /* OpenCV type codes (CV_MAKETYPE(depth, cn)), so GpuMat::type() passes straight through. */
-enum { MI_8UC1 = 0, MI_32SC1 = 4, MI_32FC1 = 5, MI_32FC2 = 13, MI_32SC4 = 28 };
+enum { MI_8UC1 = 0, MI_32SC1 = 4, MI_32FC1 = 5, MI_32FC2 = 13, MI_32SC4 = 28,
+       /* accepted only by mi_superres_to_gray8 (OpenCV codes CV_8UC3/4, CV_16UC1/3/4, CV_32FC3/4) */
+       MI_16UC1 = 2, MI_8UC3 = 16, MI_16UC3 = 18, MI_32FC3 = 21, MI_8UC4 = 24, MI_16UC4 = 26, MI_32FC4 = 29 };
 
 /* Device-side matrix view == cv::cuda::PtrStepSz<T> {data, step, cols, rows} + type.
  * Replaces: opencv2/core/cuda_types.hpp PtrStepSz (main repo); in-tree twin
@@ -287,6 +289,17 @@ MI_API int mi_surf_integral(mi_surf *h, const mi_mat *img, int clamp_to_one, mi_
 MI_API int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_layers, mi_mat *det, mi_mat *trace, void *stream);
 /* Hardware self-test hook: out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan) */
 MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
+
+/* ================================================= superres optical-flow adapters ===== */
+
+/* Replaces: cv::superres::convertToType(GpuMat, CV_8UC1) as used by GpuOpticalFlow::calc, superres/src/optical_flow.cpp:469-470
+ * = convertToCn (cuda::cvtColor BGR2GRAY / BGRA2GRAY) then convertToDepth (GpuMat::convertTo(CV_8U, 255 / maxVal(depth))),
+ * superres/src/input_array_utility.cpp:165-234,291-314.  src: 8U / 16U / 32F with 1, 3 (BGR) or 4 (BGRA) channels;
+ * dst: MI_8UC1 of the same size.  One kernel, no intermediate image. */
+MI_API int mi_superres_to_gray8(const mi_mat *src, mi_mat *dst, void *stream);
+/* Replaces: cuda::split(flow, flows) in Farneback_CUDA::impl / DualTVL1_CUDA::impl, superres/src/optical_flow.cpp:737-741,834-838.
+ * flow: MI_32FC2; u, v: MI_32FC1 of the same size. */
+MI_API int mi_split_flow(const mi_mat *flow, mi_mat *u, mi_mat *v, void *stream);
 
 /* Hardware self-test hook: out_host[0..63] = value received from lane n-1, out_host[64..127] = from
  * lane n+1 when every lane n contributes n+100 (DPP wave shifts used by the blocked kernels). */

@@ -143,6 +143,8 @@ def lib():
         "mi_surf_integral": (i, [vp, PM, i, PM, vp]),
         "mi_surf_det_trace": (i, [vp, PM, i, i, PM, PM, vp]),
         "mi_dbg_wave_scan": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "mi_superres_to_gray8": (i, [PM, PM, vp]),
+        "mi_split_flow": (i, [PM, PM, PM, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -186,7 +188,10 @@ def mat_from_tensor(t) -> Mat:
         raise MiError(-3, "expected a 2-D or 3-D tensor")
     key = (t.dtype, cn)
     types = {(torch.uint8, 1): MI_8UC1, (torch.float32, 1): MI_32FC1, (torch.float32, 2): MI_32FC2,
-             (torch.int32, 1): MI_32SC1, (torch.int32, 4): MI_32SC4}
+             (torch.int32, 1): MI_32SC1, (torch.int32, 4): MI_32SC4,
+             # frames accepted by the superres adapters only (mi_superres_to_gray8)
+             (torch.uint8, 3): 16, (torch.uint8, 4): 24, (torch.uint16, 1): 2, (torch.uint16, 3): 18, (torch.uint16, 4): 26,
+             (torch.float32, 3): 21, (torch.float32, 4): 29}
     if key not in types:
         raise MiError(-2, f"unsupported dtype/channels {key}")
     return Mat(t.data_ptr(), t.stride(0) * t.element_size(), t.shape[0], t.shape[1], types[key])

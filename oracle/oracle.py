@@ -518,3 +518,29 @@ def surf_detect_describe(img, params: SURFParams | None = None, mask=None, want_
     return {"n": n, "x": kp[0, :n].copy(), "y": kp[1, :n].copy(), "laplacian": ki[2, :n].copy(), "octave": ki[3, :n].copy(),
             "size": kp[4, :n].copy(), "angle": kp[5, :n].copy(), "hessian": kp[6, :n].copy(),
             "descriptors": desc[:n].copy() if want_desc else None}
+
+
+# ------------------------------------------------------------------ superres adapter data formats
+def superres_to_gray8(frame):
+    """cv::superres::convertToType(frame, CV_8UC1) for GpuMat frames, restated in numpy:
+    convertToCn = cuda::cvtColor BGR2GRAY / BGRA2GRAY (integer types CV_DESCALE(b*1868 + g*9617 + r*4899, 14); float types
+    0.114 b + 0.587 g + 0.299 r in binary32, left to right), then convertToDepth = convertTo(CV_8U, 255 / maxVal(depth)) with
+    saturate_cast<uchar> (round half to even, clamp) -- superres/src/input_array_utility.cpp:165-234,291-314."""
+    f = np.asarray(frame)
+    if f.ndim == 2:
+        g = f
+    else:
+        if f.shape[2] not in (3, 4):
+            raise ValueError("scn == 1 || scn == 3 || scn == 4")
+        b, gch, r = f[..., 0], f[..., 1], f[..., 2]
+        if f.dtype == np.float32:
+            g = (b * np.float32(0.114) + gch * np.float32(0.587)).astype(np.float32) + r * np.float32(0.299)
+            g = g.astype(np.float32)
+        else:
+            acc = b.astype(np.uint64) * 1868 + gch.astype(np.uint64) * 9617 + r.astype(np.uint64) * 4899 + (1 << 13)
+            g = (acc >> 14).astype(f.dtype)
+    if g.dtype == np.uint8:
+        return np.ascontiguousarray(g)
+    scale = np.float32(255.0 / 65535.0) if g.dtype == np.uint16 else np.float32(255.0)
+    v = scale * g.astype(np.float32)
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)

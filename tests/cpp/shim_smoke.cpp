@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include "opencv2/cudaoptflow.hpp"
+#include "opencv2/superres/optical_flow.hpp"
 #include "opencv2/cudastereo.hpp"
 #include "opencv2/xfeatures2d/cuda.hpp"
 
@@ -60,6 +61,32 @@ int main(int argc, char **argv)
         fwrite(desc.data(), 4, desc.size(), o);
         if (desc.size() != (size_t)nk * 64) return 7;
         fclose(o);
+        // superres adapters (the in-tree caller of the flow classes): planar flow == split of the class's own result
+        if (argc > 3) {
+            Ptr<superres::DualTVL1OpticalFlow> sr = superres::createOptFlow_DualTVL1_CUDA();
+            if (sr->getIterations() != 300 || sr->getScalesNumber() != 5) return 8;
+            sr->setIterations(10);
+            sr->setEpsilon(0.0);
+            cuda::GpuMat u, v;
+            sr->calc(d0, d1, u, &v);
+            if (u.type() != CV_32FC1 || v.type() != CV_32FC1 || u.size() != d0.size()) return 8;
+            std::vector<float> hu((size_t)h * w), hv((size_t)h * w);
+            u.download(hu.data(), (size_t)w * 4);
+            v.download(hv.data(), (size_t)w * 4);
+            FILE *o2 = fopen(argv[3], "wb");
+            fwrite(hu.data(), 4, hu.size(), o2);
+            fwrite(hv.data(), 4, hv.size(), o2);
+            Ptr<superres::FarnebackOpticalFlow> sf = superres::createOptFlow_Farneback_CUDA();
+            if (sf->getWindowSize() != 13) return 8;
+            sf->setLevelsNumber(3);
+            cuda::GpuMat merged;
+            sf->calc(d0, d1, merged);
+            if (merged.type() != CV_32FC2) return 8;
+            merged.download(hf.data(), (size_t)w * 8);
+            fwrite(hf.data(), 4, hf.size(), o2);
+            fclose(o2);
+            sr->collectGarbage();
+        }
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;
         try { cuda::GpuMat bad(h, w, CV_32FC1); bm->compute(bad, bad, disp); } catch (const cv::Exception &) { threw = true; }

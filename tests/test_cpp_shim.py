@@ -59,7 +59,8 @@ def test_shim_matches_python_mirror_on_gpu(gpu, tmp_path):
         f.write(struct.pack("ii", 96, 160))
         f.write(left.tobytes())
         f.write(right.tobytes())
-    r = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True)
+    fsr = tmp_path / "sr.bin"
+    r = subprocess.run([exe, str(fin), str(fout), str(fsr)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
     raw = open(fout, "rb").read()
     flow = np.frombuffer(raw[: 96 * 160 * 8], np.float32).reshape(96, 160, 2)
@@ -80,3 +81,8 @@ def test_shim_matches_python_mirror_on_gpu(gpu, tmp_path):
     assert nk == pk["x"].shape[0]
     np.testing.assert_array_equal(kps, np.stack([pk["x"], pk["y"], pk["size"], pk["angle"], pk["hessian"]], 1))
     np.testing.assert_array_equal(sdesc, pdesc.cpu().numpy())
+    # superres adapters: (u, v) planes of DualTVL1_CUDA == the class's own flow; Farneback_CUDA merged == the class's flow
+    sr = np.frombuffer(open(fsr, "rb").read(), np.float32)
+    np.testing.assert_array_equal(sr[: 96 * 160].reshape(96, 160), pf[..., 0])
+    np.testing.assert_array_equal(sr[96 * 160: 2 * 96 * 160].reshape(96, 160), pf[..., 1])
+    np.testing.assert_array_equal(sr[2 * 96 * 160:].reshape(96, 160, 2), fbflow)

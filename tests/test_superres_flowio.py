@@ -1,0 +1,150 @@
+"""SURVEY 8f "next" rows N1 (superres optical-flow adapters, the in-tree caller of the hot path) and N2 (.flo flow files and
+the reference's flow acceptance check)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from opencv_contrib_amd import flowio  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------ N2: .flo (CPU)
+def test_flo_roundtrip_and_layout(tmp_path):
+    rng = np.random.default_rng(3)
+    flow = rng.standard_normal((5, 7, 2)).astype(np.float32)
+    path = str(tmp_path / "a.flo")
+    flowio.writeOpticalFlow(path, flow)
+    raw = open(path, "rb").read()
+    # "PIEH", width, height (little endian), then interleaved (u, v) rows: test_tvl1optflow.cpp:55-75
+    assert raw[:4] == b"PIEH" and np.frombuffer(raw[:4], "<f4")[0] == np.float32(202021.25)
+    assert list(np.frombuffer(raw[4:12], "<i4")) == [7, 5] and len(raw) == 12 + 5 * 7 * 8
+    assert np.frombuffer(raw[12:20], "<f4").tolist() == flow[0, 0].tolist()
+    np.testing.assert_array_equal(flowio.readOpticalFlow(path), flow)
+
+
+def test_flo_rejects_bad_tag_and_truncation(tmp_path):
+    p = str(tmp_path / "bad.flo")
+    open(p, "wb").write(b"PIEX" + np.array([2, 2], "<i4").tobytes() + bytes(32))
+    with pytest.raises(ValueError):
+        flowio.readOpticalFlow(p)
+    open(p, "wb").write(b"PIEH" + np.array([4, 4], "<i4").tobytes() + bytes(32))
+    with pytest.raises(ValueError):
+        flowio.readOpticalFlow(p)
+
+
+def test_flow_acceptance_check_semantics():
+    """check() of test_tvl1optflow.cpp:114-141: invalid gold pixels are not counted, invalid result pixels count as misses."""
+    gold = np.zeros((4, 5, 2), np.float32)
+    flow = gold.copy()
+    gold[0, 0] = np.nan            # not counted
+    gold[0, 1] = 2e9               # not counted (|u| >= 1e9)
+    flow[1, 0] = np.nan            # miss
+    flow[1, 1] = (0.08, 0.05)      # err^2 = 0.0089 <= 0.01: hit
+    flow[1, 2] = (0.09, 0.05)      # err^2 = 0.0106 > 0.01: miss
+    assert flowio.accuracy(gold, flow) == pytest.approx(16 / 18)
+    assert flowio.isFlowCorrect(gold).sum() == 18
+    assert flowio.calcRMSE(gold, gold) == 0.0
+
+
+def test_golden_flo_fixture_matches_npz():
+    """tests/golden/tvl1_f32_96x128_it10.flo is the .flo image of a committed oracle golden (tools/make_golden.py)."""
+    flo = os.path.join(GOLD, "tvl1_f32_96x128_it10.flo")
+    ref = np.load(os.path.join(GOLD, "tvl1_f32_96x128_it10.npz"))["flow"]
+    np.testing.assert_array_equal(flowio.readOpticalFlow(flo), ref)
+
+
+# ------------------------------------------------------------------ N1: superres adapters
+def test_gray8_oracle_known_values(oracle):
+    """Pins the restatement on hand-computed values: BGR (255, 0, 0) -> (255*1868 + 8192) >> 14 = 29, (0, 255, 0) -> 150,
+    (0, 0, 255) -> 76 (the familiar 0.114 / 0.587 / 0.299 weights), 16-bit full scale -> 255, float 0.5 -> 128 (127.5 rounds to even)."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]]], np.uint8)
+    assert oracle.superres_to_gray8(px).tolist() == [[29, 150, 76, 255]]
+    assert oracle.superres_to_gray8(np.array([[65535, 32768, 0]], np.uint16)).tolist() == [[255, 128, 0]]
+    assert oracle.superres_to_gray8(np.array([[0.5, 1.5, -0.2, 0.002]], np.float32)).tolist() == [[128, 255, 0, 1]]
+
+
+def _frames(rng, h, w, dtype, cn):
+    shape = (h, w) if cn == 1 else (h, w, cn)
+    if dtype == np.float32:
+        return rng.random(shape, dtype=np.float32) * 1.2 - 0.1   # exercises saturation at both ends
+    hi = 256 if dtype == np.uint8 else 65536
+    return rng.integers(0, hi, size=shape).astype(dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+def test_to_gray8_bit_exact(gpu, oracle, dtype, cn):
+    import torch
+    from opencv_contrib_amd import superres
+    if dtype == np.uint8 and cn == 1:
+        pytest.skip("same type: returned as is")
+    f = _frames(np.random.default_rng(5), 67, 131, dtype, cn)
+    out = superres.convertToGray8(torch.from_numpy(f).to(gpu)).cpu().numpy()
+    np.testing.assert_array_equal(out, oracle.superres_to_gray8(f))
+
+
+@pytest.mark.gpu
+def test_split_flow_and_pitched_rows(gpu):
+    import torch
+    from opencv_contrib_amd import superres
+    flow = torch.randn(37, 80, 2, device=gpu)[:, 7:70]      # ROI view: pitched rows
+    u, v = superres.splitFlow(flow)
+    assert torch.equal(u, flow[..., 0]) and torch.equal(v, flow[..., 1])
+
+
+@pytest.mark.gpu
+def test_dualtvl1_adapter_equals_class_on_converted_frames(gpu):
+    """DualTVL1_CUDA::impl (optical_flow.cpp:817-838): the adapter's planes are the split of the class's flow on the
+    CV_8UC1 conversion of the frames; parameters set on the adapter reach the class."""
+    import torch
+    from opencv_contrib_amd import cuda, superres, synth
+    I0, I1, _ = synth.flow_pair(96, 128, seed=21)
+    bgr0 = np.stack([I0, I0, I0], -1).astype(np.float32)     # float BGR frames in [0, 1]
+    bgr1 = np.stack([I1, I1, I1], -1).astype(np.float32)
+    sr = superres.createOptFlow_DualTVL1_CUDA()
+    assert (sr.getIterations(), sr.getScalesNumber(), sr.getWarpingsNumber()) == (300, 5, 5)
+    sr.setIterations(10); sr.setEpsilon(0.0); sr.setScalesNumber(3)
+    u, v = sr.calc(torch.from_numpy(bgr0).to(gpu), torch.from_numpy(bgr1).to(gpu))
+    g0, g1 = (superres.convertToGray8(torch.from_numpy(b).to(gpu)) for b in (bgr0, bgr1))
+    ref = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0, nscales=3).calc(g0, g1)
+    assert torch.equal(u, ref[..., 0]) and torch.equal(v, ref[..., 1])
+    merged = sr.calc(torch.from_numpy(bgr0).to(gpu), torch.from_numpy(bgr1).to(gpu), want_flow2=False)
+    assert torch.equal(merged, ref)
+    sr.collectGarbage()
+    with pytest.raises(Exception):
+        sr.calc(torch.from_numpy(bgr0).to(gpu), torch.from_numpy(I1).to(gpu))     # frame types differ
+
+
+@pytest.mark.gpu
+def test_farneback_adapter_equals_class(gpu):
+    import torch
+    from opencv_contrib_amd import cuda, superres, synth
+    I0, I1, _ = synth.flow_pair(120, 160, seed=22)
+    f0, f1 = (torch.from_numpy((x * 65535).astype(np.uint16)).to(gpu) for x in (I0, I1))
+    sr = superres.createOptFlow_Farneback_CUDA()
+    assert (sr.getWindowSize(), sr.getLevelsNumber(), sr.getPolyN()) == (13, 5, 5)
+    sr.setLevelsNumber(3)
+    u, v = sr.calc(f0, f1)
+    ref = cuda.FarnebackOpticalFlow.create(numLevels=3).calc(superres.convertToGray8(f0), superres.convertToGray8(f1))
+    assert torch.equal(u, ref[..., 0]) and torch.equal(v, ref[..., 1])
+
+
+@pytest.mark.gpu
+def test_gpu_flow_passes_reference_acceptance_against_flo_golden(gpu):
+    """The reference's TV-L1 regression check (test_tvl1optflow.cpp:143-171: >= 95 % of pixels within 0.1 px of the .flo golden),
+    here against the committed oracle golden stored as .flo."""
+    import torch
+    from opencv_contrib_amd import cuda
+    import json
+    z = np.load(os.path.join(GOLD, "tvl1_f32_96x128_it10.npz"))
+    gold = flowio.readOpticalFlow(os.path.join(GOLD, "tvl1_f32_96x128_it10.flo"))
+    alg = cuda.OpticalFlowDual_TVL1.create(**json.loads(str(z["params"])))
+    flow = alg.calc(torch.from_numpy(z["I0"]).to(gpu), torch.from_numpy(z["I1"]).to(gpu)).cpu().numpy()
+    assert flowio.accuracy(gold, flow, threshold=0.1) >= 0.95
+    assert flowio.calcRMSE(gold, flow) < 0.05

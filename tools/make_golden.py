@@ -33,6 +33,9 @@ def tvl1():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), I0=I0, I1=I1, flow=flow.astype(np.float32),
                             iters=np.array(st["iters"], np.int32), params=np.array(json.dumps(kw)))
         print(name, "EPE vs analytic truth", synth.epe(flow, gt), st["iters"][0])
+        if name == "tvl1_f32_96x128_it10":   # the same field in the reference's on-disk golden format (optflow/test/test_tvl1optflow.cpp:49-107)
+            from opencv_contrib_amd import flowio
+            flowio.writeOpticalFlow(os.path.join(OUT, name + ".flo"), flow.astype(np.float32))
 
 
 def stereobm():
