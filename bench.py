@@ -111,13 +111,30 @@ def bench_stereobm(args):
                         "frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "not HBM-bound (SURVEY 8d config 3): 6.2 MB/pair of compulsory traffic; the limiter is "
                                 "integer VALU issue: see pixel_disparities_per_s and DESIGN.md"}}
+    # post-filter of the stereo pipeline: DisparityBilateralFilter(ndisp, radius 3, 1 iteration) on the maps above
+    dbf = cuda.createDisparityBilateralFilter(nd, 3, 1)
+    F = [torch.empty_like(D[0]) for _ in range(B)]
+    for i in range(B):
+        dbf.apply(D[i], L[i], F[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for i in range(B):
+            dbf.apply(D[i], L[i], F[i])
+    torch.cuda.synchronize()
+    eld = time.perf_counter() - t0
+    out["disparity_bilateral_filter_maps_per_s"] = n / eld
+    out["disparity_bilateral_filter_refined_fraction"] = float((F[0] != D[0]).float().mean())
     if not args.no_cpu:
         from oracle import oracle as O
         t0 = time.perf_counter()
-        O.sbm_compute(left, right, O.sbm_params(num_disparities=nd, block_size=bs))
+        dref = O.sbm_compute(left, right, O.sbm_params(num_disparities=nd, block_size=bs))
         ct = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"1 pair {W}x{H}, {ct:.1f} s wall, oracle/stereobm_ref.c (OpenMP rows)"}
+        t0 = time.perf_counter()
+        O.dbf_apply(dref, left, O.dbf_params(ndisp=nd, radius=3, iters=1))
+        out["cpu_baseline"]["disparity_bilateral_filter_maps_per_s"] = 1.0 / (time.perf_counter() - t0)
     print(json.dumps(out))
 
 

@@ -49,7 +49,7 @@ typedef enum mi_status {
 /* OpenCV type codes (CV_MAKETYPE(depth, cn)), so GpuMat::type() passes straight through. */
 enum { MI_8UC1 = 0, MI_32SC1 = 4, MI_32FC1 = 5, MI_32FC2 = 13, MI_32SC4 = 28,
        /* accepted only by mi_superres_to_gray8 (OpenCV codes CV_8UC3/4, CV_16UC1/3/4, CV_32FC3/4) */
-       MI_16UC1 = 2, MI_8UC3 = 16, MI_16UC3 = 18, MI_32FC3 = 21, MI_8UC4 = 24, MI_16UC4 = 26, MI_32FC4 = 29 };
+       MI_16UC1 = 2, MI_16SC1 = 3 /* disparity maps of mi_disp_bilateral_apply */, MI_8UC3 = 16, MI_16UC3 = 18, MI_32FC3 = 21, MI_8UC4 = 24, MI_16UC4 = 26, MI_32FC4 = 29 };
 
 /* Device-side matrix view == cv::cuda::PtrStepSz<T> {data, step, cols, rows} + type.
  * Replaces: opencv2/core/cuda_types.hpp PtrStepSz (main repo); in-tree twin
@@ -289,6 +289,26 @@ MI_API int mi_surf_integral(mi_surf *h, const mi_mat *img, int clamp_to_one, mi_
 MI_API int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_layers, mi_mat *det, mi_mat *trace, void *stream);
 /* Hardware self-test hook: out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan) */
 MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
+
+/* ========================================== DisparityBilateralFilter (first part) ===== */
+
+/* cv::cuda::createDisparityBilateralFilter(ndisp = 64, radius = 3, iters = 1), cudastereo.hpp + defaults of
+ * cudastereo/src/disparity_bilateral_filter.cpp:125-136 (edge threshold 0.1, max disc threshold 0.2, sigma range 10). */
+typedef struct mi_disp_bilateral_params {
+    int ndisp, radius, iters;
+    float edge_threshold, max_disc_threshold, sigma_range;
+} mi_disp_bilateral_params;
+typedef struct mi_disp_bilateral mi_disp_bilateral;
+MI_API void mi_disp_bilateral_default_params(mi_disp_bilateral_params *p);
+MI_API int mi_disp_bilateral_create(const mi_disp_bilateral_params *p, mi_disp_bilateral **out);
+MI_API int mi_disp_bilateral_set_params(mi_disp_bilateral *h, const mi_disp_bilateral_params *p);   /* setRadius / setSigmaRange rebuild the tables, .cpp:138-148 */
+MI_API int mi_disp_bilateral_get_params(const mi_disp_bilateral *h, mi_disp_bilateral_params *p);
+/* Replaces: DispBilateralFilterImpl::apply + device::disp_bilateral_filter<T>, disparity_bilateral_filter.cpp:150-190,
+ * cuda/disparity_bilateral_filter.cu:76-199.  disp: MI_8UC1 or MI_16SC1; img: MI_8UC1 or MI_8UC3 of the same size; dst: type and
+ * size of disp (may be disp itself).  Every red/black pass reads the map as it was when the pass started (the reference's
+ * in-place passes race on same-colour pixels inside the window; see oracle/dbf_ref.c). */
+MI_API int mi_disp_bilateral_apply(mi_disp_bilateral *h, const mi_mat *disp, const mi_mat *img, mi_mat *dst, void *stream);
+MI_API void mi_disp_bilateral_destroy(mi_disp_bilateral *h);
 
 /* ================================================= superres optical-flow adapters ===== */
 

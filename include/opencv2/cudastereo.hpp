@@ -89,5 +89,55 @@ inline Ptr<cuda::StereoBM> createStereoBM(int numDisparities = 64, int blockSize
     return makePtr<miflow_detail::StereoBMImpl>(numDisparities, blockSize);
 }
 
+/** cudastereo.hpp:298-330 */
+class CV_EXPORTS_W DisparityBilateralFilter : public cv::Algorithm {
+public:
+    virtual void apply(InputArray disparity, InputArray image, OutputArray dst, Stream &stream = Stream::Null()) = 0;
+    virtual int getNumDisparities() const = 0;        virtual void setNumDisparities(int numDisparities) = 0;
+    virtual int getRadius() const = 0;                virtual void setRadius(int radius) = 0;
+    virtual int getNumIters() const = 0;              virtual void setNumIters(int iters) = 0;
+    virtual double getEdgeThreshold() const = 0;      virtual void setEdgeThreshold(double edge_threshold) = 0;
+    virtual double getMaxDiscThreshold() const = 0;   virtual void setMaxDiscThreshold(double max_disc_threshold) = 0;
+    virtual double getSigmaRange() const = 0;         virtual void setSigmaRange(double sigma_range) = 0;
+};
+
+namespace miflow_detail {
+/** twin of DispBilateralFilterImpl, cudastereo/src/disparity_bilateral_filter.cpp:58-190 */
+class DispBilateralFilterImpl final : public cuda::DisparityBilateralFilter {
+public:
+    DispBilateralFilterImpl(int ndisp, int radius, int iters)
+    {
+        mi_disp_bilateral_default_params(&p_);
+        p_.ndisp = ndisp; p_.radius = radius; p_.iters = iters;
+        miCheck(mi_disp_bilateral_create(&p_, &h_));
+    }
+    ~DispBilateralFilterImpl() override { mi_disp_bilateral_destroy(h_); }
+    DispBilateralFilterImpl(const DispBilateralFilterImpl &) = delete;
+    DispBilateralFilterImpl &operator=(const DispBilateralFilterImpl &) = delete;
+    void apply(InputArray disparity, InputArray image, OutputArray dst, Stream &stream) override
+    {
+        if (dst.data != disparity.data) dst.create(disparity.size(), disparity.type());   // disparity_bilateral_filter.cpp:152
+        mi_mat d = miMat(disparity), i = miMat(image), o = miMat(dst);
+        miCheck(mi_disp_bilateral_apply(h_, &d, &i, &o, stream.hipStream()));
+    }
+    int getNumDisparities() const override { return p_.ndisp; }                  void setNumDisparities(int v) override { p_.ndisp = v; push(); }
+    int getRadius() const override { return p_.radius; }                         void setRadius(int v) override { p_.radius = v; push(); }
+    int getNumIters() const override { return p_.iters; }                        void setNumIters(int v) override { p_.iters = v; push(); }
+    double getEdgeThreshold() const override { return p_.edge_threshold; }       void setEdgeThreshold(double v) override { p_.edge_threshold = (float)v; push(); }
+    double getMaxDiscThreshold() const override { return p_.max_disc_threshold; } void setMaxDiscThreshold(double v) override { p_.max_disc_threshold = (float)v; push(); }
+    double getSigmaRange() const override { return p_.sigma_range; }             void setSigmaRange(double v) override { p_.sigma_range = (float)v; push(); }
+private:
+    void push() { miCheck(mi_disp_bilateral_set_params(h_, &p_)); }
+    mi_disp_bilateral_params p_;
+    mi_disp_bilateral *h_ = nullptr;
+};
+}  // namespace miflow_detail
+
+/** cudastereo.hpp:338-339 */
+inline Ptr<cuda::DisparityBilateralFilter> createDisparityBilateralFilter(int ndisp = 64, int radius = 3, int iters = 1)
+{
+    return makePtr<miflow_detail::DispBilateralFilterImpl>(ndisp, radius, iters);
+}
+
 }}  // namespace cv::cuda
 #endif

@@ -49,6 +49,11 @@ class FarnebackParams(C.Structure):
                 ("num_iters", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
 
 
+class DispBilateralParams(C.Structure):
+    _fields_ = [("ndisp", C.c_int), ("radius", C.c_int), ("iters", C.c_int), ("edge_threshold", C.c_float),
+                ("max_disc_threshold", C.c_float), ("sigma_range", C.c_float)]
+
+
 class StereoBMParams(C.Structure):
     _fields_ = [("num_disparities", C.c_int), ("block_size", C.c_int), ("prefilter_type", C.c_int),
                 ("prefilter_cap", C.c_int), ("prefilter_size", C.c_int), ("texture_threshold", C.c_float),
@@ -143,6 +148,12 @@ def lib():
         "mi_surf_integral": (i, [vp, PM, i, PM, vp]),
         "mi_surf_det_trace": (i, [vp, PM, i, i, PM, PM, vp]),
         "mi_dbg_wave_scan": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "mi_disp_bilateral_default_params": (None, [C.POINTER(DispBilateralParams)]),
+        "mi_disp_bilateral_create": (i, [C.POINTER(DispBilateralParams), C.POINTER(vp)]),
+        "mi_disp_bilateral_set_params": (i, [vp, C.POINTER(DispBilateralParams)]),
+        "mi_disp_bilateral_get_params": (i, [vp, C.POINTER(DispBilateralParams)]),
+        "mi_disp_bilateral_apply": (i, [vp, PM, PM, PM, vp]),
+        "mi_disp_bilateral_destroy": (None, [vp]),
         "mi_superres_to_gray8": (i, [PM, PM, vp]),
         "mi_split_flow": (i, [PM, PM, PM, vp]),
     }
@@ -190,6 +201,7 @@ def mat_from_tensor(t) -> Mat:
     types = {(torch.uint8, 1): MI_8UC1, (torch.float32, 1): MI_32FC1, (torch.float32, 2): MI_32FC2,
              (torch.int32, 1): MI_32SC1, (torch.int32, 4): MI_32SC4,
              # frames accepted by the superres adapters only (mi_superres_to_gray8)
+             (torch.int16, 1): 3,   # CV_16SC1 disparity maps (DisparityBilateralFilter)
              (torch.uint8, 3): 16, (torch.uint8, 4): 24, (torch.uint16, 1): 2, (torch.uint16, 3): 18, (torch.uint16, 4): 26,
              (torch.float32, 3): 21, (torch.float32, 4): 29}
     if key not in types:

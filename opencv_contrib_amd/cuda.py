@@ -252,6 +252,55 @@ def createStereoBM(numDisparities=64, blockSize=19, **kw) -> StereoBM:
     return StereoBM(numDisparities, blockSize, **kw)
 
 
+class DisparityBilateralFilter:
+    """cv::cuda::DisparityBilateralFilter (cudastereo.hpp:298-330; cudastereo/src/disparity_bilateral_filter.cpp:58-190):
+    joint bilateral refinement of a disparity map at its discontinuities, guided by the image."""
+
+    def __init__(self, ndisp=64, radius=3, iters=1):
+        self._p = capi.DispBilateralParams()
+        capi.lib().mi_disp_bilateral_default_params(C.byref(self._p))
+        self._p.ndisp, self._p.radius, self._p.iters = ndisp, radius, iters
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_disp_bilateral_create(C.byref(self._p), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.lib().mi_disp_bilateral_destroy(self._h)
+            self._h = None
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+        capi.check(capi.lib().mi_disp_bilateral_set_params(self._h, C.byref(self._p)))
+
+    def getNumDisparities(self): return self._p.ndisp
+    def setNumDisparities(self, v): self._set(ndisp=v)
+    def getRadius(self): return self._p.radius
+    def setRadius(self, v): self._set(radius=v)
+    def getNumIters(self): return self._p.iters
+    def setNumIters(self, v): self._set(iters=v)
+    def getEdgeThreshold(self): return float(self._p.edge_threshold)
+    def setEdgeThreshold(self, v): self._set(edge_threshold=float(v))
+    def getMaxDiscThreshold(self): return float(self._p.max_disc_threshold)
+    def setMaxDiscThreshold(self, v): self._set(max_disc_threshold=float(v))
+    def getSigmaRange(self): return float(self._p.sigma_range)
+    def setSigmaRange(self, v): self._set(sigma_range=float(v))
+
+    def apply(self, disparity, image, dst=None):
+        """disparity: uint8 or int16 (H, W); image: uint8 (H, W) or (H, W, 3); returns dst (same type as disparity)."""
+        import torch
+        if dst is None:
+            dst = torch.empty_like(disparity)
+        capi.check(capi.lib().mi_disp_bilateral_apply(self._h, C.byref(_m(disparity)), C.byref(_m(image)), C.byref(_m(dst)),
+                                                      capi.current_stream_ptr()))
+        return dst
+
+
+def createDisparityBilateralFilter(ndisp=64, radius=3, iters=1) -> DisparityBilateralFilter:
+    """cv::cuda::createDisparityBilateralFilter (cudastereo.hpp:338-339)."""
+    return DisparityBilateralFilter(ndisp, radius, iters)
+
+
 def stereobm_prefilter_xsobel(img, cap=31):
     import torch
     out = torch.empty_like(img)

@@ -544,3 +544,33 @@ def superres_to_gray8(frame):
     scale = np.float32(255.0 / 65535.0) if g.dtype == np.uint16 else np.float32(255.0)
     v = scale * g.astype(np.float32)
     return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ DisparityBilateralFilter (part)
+class DBFParams(C.Structure):
+    _fields_ = [("ndisp", C.c_int), ("radius", C.c_int), ("iters", C.c_int), ("edge_threshold", C.c_float),
+                ("max_disc_threshold", C.c_float), ("sigma_range", C.c_float)]
+
+
+def dbf_params(ndisp=64, radius=3, iters=1, edge_threshold=0.1, max_disc_threshold=0.2, sigma_range=10.0):
+    """createDisparityBilateralFilter defaults: cudastereo.hpp + disparity_bilateral_filter.cpp:125-136."""
+    return DBFParams(ndisp, radius, iters, edge_threshold, max_disc_threshold, sigma_range)
+
+
+def dbf_apply(disp, img, params: DBFParams | None = None):
+    """cv::cuda::DisparityBilateralFilter::apply restated on the CPU.  disp: uint8 or int16 (H, W); img: uint8 (H, W) or (H, W, 3)."""
+    p = params or dbf_params()
+    d = np.ascontiguousarray(disp).copy()
+    im = np.ascontiguousarray(img, dtype=np.uint8)
+    if d.dtype not in (np.uint8, np.int16):
+        raise ValueError("disp.type() == CV_8U || disp.type() == CV_16S")
+    cn = 1 if im.ndim == 2 else im.shape[2]
+    if im.shape[:2] != d.shape:
+        raise ValueError("disp.size() == img.size()")
+    L = lib()
+    L.orc_dbf_apply.restype = C.c_int
+    L.orc_dbf_apply.argtypes = [C.POINTER(DBFParams), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rc = L.orc_dbf_apply(C.byref(p), d.ctypes.data, d.itemsize, im.ctypes.data, cn, d.shape[0], d.shape[1])
+    if rc:
+        raise ValueError(f"orc_dbf_apply failed: {rc}")
+    return d
