@@ -236,6 +236,17 @@ def bench_surf(args):
                         "frac": algo * args.steps * n / el_det / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "detector stage only; the Haar box sums are gather/latency bound (40 integral taps per sample per "
                                 "layer from a 33 MB L2/MALL-resident table), not HBM-bound (SURVEY 8d config 4)"}}
+    # the step after detect/describe: brute-force 2-NN matching of the frame's descriptors against themselves
+    bfm = cuda.createBFMatcher()
+    bfm.knnMatch(desc, desc, k=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        bfm.knnMatch(desc, desc, k=2)
+    torch.cuda.synchronize()
+    elm = (time.perf_counter() - t0) / 3
+    out["bf_knn2_match_ms"] = 1e3 * elm
+    out["bf_descriptor_pairs_per_s"] = float(desc.shape[0]) ** 2 / elm
     if not args.no_cpu:
         from oracle import oracle as O
         t0 = time.perf_counter()

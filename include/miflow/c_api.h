@@ -47,7 +47,7 @@ typedef enum mi_status {
 } mi_status;
 
 /* OpenCV type codes (CV_MAKETYPE(depth, cn)), so GpuMat::type() passes straight through. */
-enum { MI_8UC1 = 0, MI_32SC1 = 4, MI_32FC1 = 5, MI_32FC2 = 13, MI_32SC4 = 28,
+enum { MI_8UC1 = 0, MI_32SC1 = 4, MI_32FC1 = 5, MI_32SC2 = 12 /* knn match indices */, MI_32FC2 = 13, MI_32SC4 = 28,
        /* accepted only by mi_superres_to_gray8 (OpenCV codes CV_8UC3/4, CV_16UC1/3/4, CV_32FC3/4) */
        MI_16UC1 = 2, MI_16SC1 = 3 /* disparity maps of mi_disp_bilateral_apply */, MI_8UC3 = 16, MI_16UC3 = 18, MI_32FC3 = 21, MI_8UC4 = 24, MI_16UC4 = 26, MI_32FC4 = 29 };
 
@@ -289,6 +289,25 @@ MI_API int mi_surf_integral(mi_surf *h, const mi_mat *img, int clamp_to_one, mi_
 MI_API int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_layers, mi_mat *det, mi_mat *trace, void *stream);
 /* Hardware self-test hook: out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan) */
 MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
+
+/* ================================== brute-force descriptor matcher for SURF output (first part) ===== */
+
+/* cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L2) for CV_32F descriptors of up to 128 elements (SURF: 64 / 128),
+ * cudafeatures2d/src/brute_force_matcher.cpp + cuda/bf_match.cu:92-183,559-587, cuda/bf_knnmatch.cu (k = 2).
+ * Distance = sqrtf of the k-ascending chain sum = fma(d, d, sum), d = q[k] - t[k] (the order of loopUnrolledCached, bf_match.cu:
+ * 100-121, with nvcc's default mul+add contraction); best = first strict minimum in train order (exact ties: lowest train
+ * index, the CPU BFMatcher's rule; the reference's cross-thread reduction prefers the lowest train index modulo 16 first). */
+typedef struct mi_bfmatcher mi_bfmatcher;
+enum { MI_NORM_L2 = 4 };                                   /* cv::NORM_L2 */
+MI_API int mi_bf_create(int norm_type, mi_bfmatcher **out);
+MI_API void mi_bf_destroy(mi_bfmatcher *h);
+/* matchSingle: query n_q x D, train n_t x D (MI_32FC1), mask NULL or MI_8UC1 n_q x n_t (non-zero = allowed);
+ * train_idx MI_32SC1 1 x n_q (-1 = none), distance MI_32FC1 1 x n_q (FLT_MAX = none). */
+MI_API int mi_bf_match(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train, const mi_mat *mask, mi_mat *train_idx,
+                       mi_mat *distance, void *stream);
+/* knnMatch with k = 2 (bf_knnmatch.cu match2): train_idx MI_32SC2 1 x n_q, distance MI_32FC2 1 x n_q. */
+MI_API int mi_bf_knn_match2(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train, const mi_mat *mask, mi_mat *train_idx,
+                            mi_mat *distance, void *stream);
 
 /* ========================================== DisparityBilateralFilter (first part) ===== */
 

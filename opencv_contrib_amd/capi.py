@@ -154,6 +154,10 @@ def lib():
         "mi_disp_bilateral_get_params": (i, [vp, C.POINTER(DispBilateralParams)]),
         "mi_disp_bilateral_apply": (i, [vp, PM, PM, PM, vp]),
         "mi_disp_bilateral_destroy": (None, [vp]),
+        "mi_bf_create": (i, [i, C.POINTER(vp)]),
+        "mi_bf_destroy": (None, [vp]),
+        "mi_bf_match": (i, [vp, PM, PM, PM, PM, PM, vp]),
+        "mi_bf_knn_match2": (i, [vp, PM, PM, PM, PM, PM, vp]),
         "mi_superres_to_gray8": (i, [PM, PM, vp]),
         "mi_split_flow": (i, [PM, PM, PM, vp]),
     }
@@ -199,7 +203,7 @@ def mat_from_tensor(t) -> Mat:
         raise MiError(-3, "expected a 2-D or 3-D tensor")
     key = (t.dtype, cn)
     types = {(torch.uint8, 1): MI_8UC1, (torch.float32, 1): MI_32FC1, (torch.float32, 2): MI_32FC2,
-             (torch.int32, 1): MI_32SC1, (torch.int32, 4): MI_32SC4,
+             (torch.int32, 1): MI_32SC1, (torch.int32, 4): MI_32SC4, (torch.int32, 2): 12,
              # frames accepted by the superres adapters only (mi_superres_to_gray8)
              (torch.int16, 1): 3,   # CV_16SC1 disparity maps (DisparityBilateralFilter)
              (torch.uint8, 3): 16, (torch.uint8, 4): 24, (torch.uint16, 1): 2, (torch.uint16, 3): 18, (torch.uint16, 4): 26,

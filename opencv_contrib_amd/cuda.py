@@ -252,6 +252,48 @@ def createStereoBM(numDisparities=64, blockSize=19, **kw) -> StereoBM:
     return StereoBM(numDisparities, blockSize, **kw)
 
 
+class BFMatcher:
+    """cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L2) for float descriptors (SURF: 64 / 128 elements):
+    match() and knnMatch(k = 2) in the device-matrix form of the reference's matchAsync / knnMatchAsync
+    (cudafeatures2d/src/brute_force_matcher.cpp; kernels cuda/bf_match.cu, cuda/bf_knnmatch.cu)."""
+
+    NORM_L2 = 4
+
+    def __init__(self, normType=4):
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_bf_create(int(normType), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.lib().mi_bf_destroy(self._h)
+            self._h = None
+
+    def _run(self, fn, query, train, mask, cn):
+        import torch
+        nq = query.shape[0]
+        shape = (1, nq) if cn == 1 else (1, nq, 2)
+        idx = torch.empty(shape, dtype=torch.int32, device=query.device)
+        dist = torch.empty(shape, dtype=torch.float32, device=query.device)
+        pm = C.byref(_m(mask)) if mask is not None else None
+        capi.check(fn(self._h, C.byref(_m(query)), C.byref(_m(train)), pm, C.byref(_m(idx)), C.byref(_m(dist)), capi.current_stream_ptr()))
+        return idx[0], dist[0]
+
+    def match(self, queryDescriptors, trainDescriptors, mask=None):
+        """-> (trainIdx (nq,) int32, distance (nq,) float32); -1 / FLT_MAX where the mask leaves no candidate."""
+        return self._run(capi.lib().mi_bf_match, queryDescriptors, trainDescriptors, mask, 1)
+
+    def knnMatch(self, queryDescriptors, trainDescriptors, k=2, mask=None):
+        """k = 2 only (the ratio-test form): -> (trainIdx (nq, 2), distance (nq, 2))."""
+        if k != 2:
+            raise capi.MiError(-1, "only k = 2 is built")
+        return self._run(capi.lib().mi_bf_knn_match2, queryDescriptors, trainDescriptors, mask, 2)
+
+
+def createBFMatcher(normType=4) -> BFMatcher:
+    """cv::cuda::DescriptorMatcher::createBFMatcher (cudafeatures2d.hpp)."""
+    return BFMatcher(normType)
+
+
 class DisparityBilateralFilter:
     """cv::cuda::DisparityBilateralFilter (cudastereo.hpp:298-330; cudastereo/src/disparity_bilateral_filter.cpp:58-190):
     joint bilateral refinement of a disparity map at its discontinuities, guided by the image."""

@@ -574,3 +574,27 @@ def dbf_apply(disp, img, params: DBFParams | None = None):
     if rc:
         raise ValueError(f"orc_dbf_apply failed: {rc}")
     return d
+
+
+# ------------------------------------------------------------------ brute-force L2 matcher (part)
+def bf_knn_match2(query, train, mask=None):
+    """-> (train_idx (nq, 2) int32, distance (nq, 2) float32); column 0 is what match() returns."""
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    t = np.ascontiguousarray(train, dtype=np.float32)
+    if q.ndim != 2 or t.ndim != 2 or q.shape[1] != t.shape[1]:
+        raise ValueError("query.cols == train.cols")
+    m = None
+    if mask is not None:
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if m.shape != (q.shape[0], t.shape[0]):
+            raise ValueError("mask must be query.rows x train.rows")
+    idx = np.empty((q.shape[0], 2), np.int32)
+    dist = np.empty((q.shape[0], 2), np.float32)
+    L = lib()
+    L.orc_bf_knn2.restype = C.c_int
+    L.orc_bf_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_bf_knn2(q.ctypes.data, q.shape[0], t.ctypes.data, t.shape[0], q.shape[1], m.ctypes.data if m is not None else None,
+                       idx.ctypes.data, dist.ctypes.data)
+    if rc:
+        raise ValueError(f"orc_bf_knn2 failed: {rc}")
+    return idx, dist

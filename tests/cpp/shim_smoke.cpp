@@ -7,6 +7,7 @@
 #include "opencv2/cudaoptflow.hpp"
 #include "opencv2/superres/optical_flow.hpp"
 #include "opencv2/cudastereo.hpp"
+#include "opencv2/cudafeatures2d.hpp"
 #include "opencv2/xfeatures2d/cuda.hpp"
 
 int main(int argc, char **argv)
@@ -87,6 +88,24 @@ int main(int argc, char **argv)
             fclose(o2);
             sr->collectGarbage();
         }
+        // descriptor matching + disparity post-filter (the steps after the hot path's SURF and StereoBM)
+        if (nk > 0) {
+            cuda::GpuMat ddesc(nk, 64, CV_32FC1);
+            ddesc.upload(desc.data(), 64 * sizeof(float));
+            Ptr<cuda::DescriptorMatcher> bf = cuda::DescriptorMatcher::createBFMatcher(NORM_L2);
+            std::vector<DMatch> mm;
+            bf->match(ddesc, ddesc, mm);
+            if ((int)mm.size() != nk) return 9;
+            for (int k = 0; k < nk; ++k) if (mm[k].trainIdx != k || mm[k].distance != 0.f) return 9;
+            std::vector<std::vector<DMatch> > knn;
+            bf->knnMatch(ddesc, ddesc, knn, 2);
+            if ((int)knn.size() != nk || (nk > 1 && knn[0].size() != 2)) return 9;
+        }
+        Ptr<cuda::DisparityBilateralFilter> dbf = cuda::createDisparityBilateralFilter(32, 3, 1);
+        if (dbf->getRadius() != 3 || dbf->getSigmaRange() != 10.0) return 9;
+        cuda::GpuMat refined;
+        dbf->apply(disp, d0, refined);
+        if (refined.type() != CV_8UC1 || refined.size() != disp.size()) return 9;
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;
         try { cuda::GpuMat bad(h, w, CV_32FC1); bm->compute(bad, bad, disp); } catch (const cv::Exception &) { threw = true; }
