@@ -600,6 +600,104 @@ __global__ __launch_bounds__(256) void k_warp_lds(WarpArgs A, CtlK ctl, int cur_
     A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
 }
 
+// ------------------------------------------------------------------ warp through PER-WAVE LDS tiles (CPU_REF semantics)
+// Same arithmetic and summation order as k_warp<CPU_REF> (bit-identical output).  A wave owns a TX x (64/TX) pixel patch; when
+// all its bicubic windows lie inside the image it takes the bounding box of the windows (four DPP max-reductions), stages
+// that box -- typically (TX+3+s) x (64/TX+3+s) elements for a flow spread s -- into its private LDS tile with a few
+// coalesced 16-B loads, and every lane reads its 16 taps with ds_read_b128.  The texture-addresser cost drops from 16 scattered
+// wave-loads per pixel to 3-6 coalesced ones per wave; there is no workgroup barrier (the workgroup-tile variant k_warp_lds
+// lost more to its two barriers than it saved).  Waves touching the image border or with a box larger than the tile take
+// the per-pixel path.
+#define WWT_CAP 448   // tile capacity in float4 elements (7 wave-loads, 7 KB per wave)
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    unsigned u = (unsigned)v ^ 0x80000000u;   // order-preserving map to unsigned
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x111, 0xf, 0xf, true));
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x112, 0xf, 0xf, true));
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x114, 0xf, 0xf, true));
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x118, 0xf, 0xf, true));
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x142, 0xa, 0xf, true));
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x143, 0xc, 0xf, true));
+    return (int)((unsigned)__builtin_amdgcn_readlane((int)u, 63) ^ 0x80000000u);
+}
+template <int TX>
+__global__ __launch_bounds__(256) void k_warp_wt(WarpArgs A, CtlK ctl, int cur_host)
+{
+    __shared__ float s_tab[128];
+    __shared__ float4 s_tile[4][WWT_CAP];
+    if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
+    __syncthreads();
+    constexpr int TY = 64 / TX;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * TX + (lane % TX);
+    const int y = blockIdx.y * (4 * TY) + wv * TY + lane / TX;
+    const int b = blockIdx.z;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    const bool valid = x < W && y < H;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const long long pb = (long long)b * A.g.ps;
+    const long long o = pb + (long long)min(y, H - 1) * ld + min(x, W - 1);
+    const float4 *P = A.pk + pb;
+    const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
+    // buildFlowMap + cv::remap(INTER_CUBIC): map quantised to 1/32 px (optflow/src/tvl1flow.cpp:650-666,1371-1374)
+    const float mx = (float)x + u1v, my = (float)y + u2v;
+    const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+    const int sx = min(max(qx >> 5, -32768), 32767) - 1;
+    const int sy = min(max(qy >> 5, -32768), 32767) - 1;
+    const bool inside = (unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0);
+    // wave-uniform: every valid pixel's window inside the image?  (invalid lanes repeat a clamped valid pixel: harmless)
+    const bool all_inside = __ballot(inside) == ~0ull;
+    bool use_tile = false;
+    int tx0 = 0, ty0 = 0, tw = 1;
+    if (all_inside) {
+        tx0 = -wave_max_i32(-sx); ty0 = -wave_max_i32(-sy);
+        const int tx1 = wave_max_i32(sx), ty1 = wave_max_i32(sy);
+        tw = tx1 + 4 - tx0;
+        const int th = ty1 + 4 - ty0;
+        use_tile = tw * th <= WWT_CAP;   // wave-uniform
+        if (use_tile) {
+            float4 *T = s_tile[wv];
+            const int n = tw * th;
+            for (int i = lane; i < n; i += 64) {
+                const int r = i / tw, c = i - r * tw;
+                T[i] = P[(long long)(ty0 + r) * ld + tx0 + c];   // inside the image by construction
+            }
+        }
+    }
+    if (!valid) return;
+    const float *wxp = s_tab + (qx & 31) * 4, *wyp = s_tab + (qy & 31) * 4;
+    float w[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) w[k1 * 4 + k2] = wyp[k1] * wxp[k2];
+    float v0, v1, v2;
+    if (use_tile) {
+        const float4 *S = s_tile[wv] + (sy - ty0) * tw + (sx - tx0);
+        float4 a = S[0], b4 = S[1], c = S[2], d = S[3];
+        float s0 = a.x * w[0] + b4.x * w[1] + c.x * w[2] + d.x * w[3];
+        float s1 = a.y * w[0] + b4.y * w[1] + c.y * w[2] + d.y * w[3];
+        float s2 = a.z * w[0] + b4.z * w[1] + c.z * w[2] + d.z * w[3];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            S += tw; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
+            s0 += a.x * w[4 * r] + b4.x * w[4 * r + 1] + c.x * w[4 * r + 2] + d.x * w[4 * r + 3];
+            s1 += a.y * w[4 * r] + b4.y * w[4 * r + 1] + c.y * w[4 * r + 2] + d.y * w[4 * r + 3];
+            s2 += a.z * w[4 * r] + b4.z * w[4 * r + 1] + c.z * w[4 * r + 2] + d.z * w[4 * r + 3];
+        }
+        v0 = s0; v1 = s1; v2 = s2;
+    } else {
+        warp_px_generic(P, W, H, ld, sx, sy, w, v0, v1, v2);
+    }
+    if (A.I1w) A.I1w[o] = v0;
+    A.I1wx[o] = v1;
+    A.I1wy[o] = v2;
+    // calcGradRho  optflow/src/tvl1flow.cpp:918-944
+    const float Ix2 = v1 * v1, Iy2 = v2 * v2;
+    A.grad[o] = Ix2 + Iy2;
+    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
+}
+
 // ------------------------------------------------------------------ fused iteration
 // Per-pixel math.  EXACT: the CPU reference's operations (optflow/src/tvl1flow.cpp:989-1041
 // estimateV, :857-899 divergence, :1096-1112 estimateU, :1140-1181 dual update with hypot in
@@ -1007,6 +1105,12 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
         hipLaunchKernelGGL(k_warp4, dim3(div_up(g.w, 256), div_up(g.h, 4), g.batch), dim3(256), 0, s, A, ck, cur_host);
     else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'l')
         hipLaunchKernelGGL(k_warp_lds, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
+    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'w' && wsel[1] == '3')    // per-wave tiles, 32 x 2 patches
+        hipLaunchKernelGGL((k_warp_wt<32>), dim3(div_up(g.w, 32), div_up(g.h, 8), g.batch), dim3(256), 0, s, A, ck, cur_host);
+    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'w' && wsel[1] == '8')    // 8 x 8 patches
+        hipLaunchKernelGGL((k_warp_wt<8>), dim3(div_up(g.w, 8), div_up(g.h, 32), g.batch), dim3(256), 0, s, A, ck, cur_host);
+    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'w')                      // 16 x 4 patches
+        hipLaunchKernelGGL((k_warp_wt<16>), dim3(div_up(g.w, 16), div_up(g.h, 16), g.batch), dim3(256), 0, s, A, ck, cur_host);
     else if (semantics == MI_SEM_CPU_REF) {
         static int tile = -1;
         if (tile < 0) { const char *e = getenv("MIFLOW_WARP_TILE"); tile = e ? atoi(e) : 32; }   // r01u: 32 x 2 patch per wave +2 % on the bench (64: 881, 32: 902, 16: 878, 8: 784 pairs/s)
