@@ -125,6 +125,19 @@ def bench_stereobm(args):
     eld = time.perf_counter() - t0
     out["disparity_bilateral_filter_maps_per_s"] = n / eld
     out["disparity_bilateral_filter_refined_fraction"] = float((F[0] != D[0]).float().mean())
+    # semi-global matching on the same pairs: StereoSGM(0, ndisp, 10, 120, 5, MODE_HH4), CV_16SC1 output
+    sgm = cuda.createStereoSGM(0, nd, 10, 120, 5, cuda.StereoSGM.MODE_HH4)
+    S = torch.empty((H, W), dtype=torch.int16, device=dev)
+    sgm.compute(L[0], Rr[0], S)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nsg = max(2, min(B, 4)) * args.steps
+    for k in range(nsg):
+        sgm.compute(L[k % B], Rr[k % B], S)
+    torch.cuda.synchronize()
+    els = time.perf_counter() - t0
+    out["stereosgm_hh4_pairs_per_s"] = nsg / els
+    out["stereosgm_valid_fraction"] = float((S >= 0).float().mean())
     if not args.no_cpu:
         from oracle import oracle as O
         t0 = time.perf_counter()
@@ -135,6 +148,9 @@ def bench_stereobm(args):
         t0 = time.perf_counter()
         O.dbf_apply(dref, left, O.dbf_params(ndisp=nd, radius=3, iters=1))
         out["cpu_baseline"]["disparity_bilateral_filter_maps_per_s"] = 1.0 / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        O.sgm_compute(left, right, O.sgm_params(num_disparities=nd))
+        out["cpu_baseline"]["stereosgm_hh4_pairs_per_s"] = 1.0 / (time.perf_counter() - t0)
     print(json.dumps(out))
 
 

@@ -309,6 +309,35 @@ MI_API int mi_bf_match(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train
 MI_API int mi_bf_knn_match2(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train, const mi_mat *mask, mi_mat *train_idx,
                             mi_mat *distance, void *stream);
 
+/* ======================================================== StereoSGM ===== */
+
+enum { MI_SGM_MODE_HH = 1, MI_SGM_MODE_HH4 = 3 };   /* cv::StereoSGBM::MODE_HH (8 paths), MODE_HH4 (4 paths) */
+/* cv::cuda::createStereoSGM(minDisparity = 0, numDisparities = 128, P1 = 10, P2 = 120, uniquenessRatio = 5, mode = MODE_HH4),
+ * cudastereo.hpp; numDisparities in {64, 128, 256}.  emulate_cuda_quirks (default 1): the 8-bit sorting of the 16-bit median's
+ * scalar columns (stereosgm.cu:1871-1896) and the width/16 x height/16 launch of the consistency check (:1985); 0 = clean. */
+typedef struct mi_stereosgm_params {
+    int min_disparity, num_disparities, P1, P2, uniqueness_ratio, mode, emulate_cuda_quirks;
+} mi_stereosgm_params;
+typedef struct mi_stereosgm mi_stereosgm;
+MI_API void mi_stereosgm_default_params(mi_stereosgm_params *p);
+MI_API int mi_stereosgm_create(const mi_stereosgm_params *p, mi_stereosgm **out);
+MI_API int mi_stereosgm_set_params(mi_stereosgm *h, const mi_stereosgm_params *p);
+MI_API int mi_stereosgm_get_params(const mi_stereosgm *h, mi_stereosgm_params *p);
+/* Replaces: StereoSGMImpl::compute, cudastereo/src/stereosgm.cpp:96-144.  left, right: MI_8UC1 or MI_16UC1; disparity: MI_16SC1
+ * of the image size, fixed point with 4 fractional bits, (minDisparity - 1) * 16 where invalid. */
+MI_API int mi_stereosgm_compute(mi_stereosgm *h, const mi_mat *left, const mi_mat *right, mi_mat *disparity, void *stream);
+MI_API void mi_stereosgm_destroy(mi_stereosgm *h);
+/* Stage level = the functions the reference unit-tests against CPU twins (cudastereo/test/test_sgm_funcs.cpp):
+ * census_transform::censusTransform (cuda/stereosgm.cu:460-480): src MI_8UC1 | MI_16UC1 -> dst MI_32SC1, 0 on the border */
+MI_API int mi_sgm_census(const mi_mat *src, mi_mat *dst, void *stream);
+/* path_aggregation::{horizontal,vertical,oblique}::aggregate*Path (cuda/stereosgm.cu:483-1330): dense MI_32SC1 census images ->
+ * dst MI_8UC1 1 x (width * height * num_disparities), layout [pixel][disparity]; (dx, dy) = the step of the path */
+MI_API int mi_sgm_aggregate_path(const mi_mat *left_census, const mi_mat *right_census, mi_mat *dst, int num_disparities,
+                                 int min_disparity, int p1, int p2, int dx, int dy, void *stream);
+/* winner_takes_all::winnerTakesAll (cuda/stereosgm.cu:1433-1616): src MI_8UC1 1 x (w * h * D * num_paths) -> left, right MI_16SC1 */
+MI_API int mi_sgm_winner_takes_all(const mi_mat *src, mi_mat *left, mi_mat *right, int num_disparities, int num_paths, float uniqueness,
+                                   int subpixel, void *stream);
+
 /* ========================================== DisparityBilateralFilter (first part) ===== */
 
 /* cv::cuda::createDisparityBilateralFilter(ndisp = 64, radius = 3, iters = 1), cudastereo.hpp + defaults of

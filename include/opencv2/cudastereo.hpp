@@ -89,6 +89,65 @@ inline Ptr<cuda::StereoBM> createStereoBM(int numDisparities = 64, int blockSize
     return makePtr<miflow_detail::StereoBMImpl>(numDisparities, blockSize);
 }
 
+/** cudastereo.hpp: class StereoSGM (cv::StereoSGBM interface subset used by the CUDA class, cudastereo/src/stereosgm.cpp:20-80) */
+class CV_EXPORTS_W StereoSGM : public cv::StereoMatcher {
+public:
+    enum { MODE_SGBM = 0, MODE_HH = 1, MODE_SGBM_3WAY = 2, MODE_HH4 = 3 };
+    virtual void compute(InputArray left, InputArray right, OutputArray disparity) = 0;
+    virtual void compute(InputArray left, InputArray right, OutputArray disparity, Stream &stream) = 0;
+    virtual int getPreFilterCap() const = 0;      virtual void setPreFilterCap(int) = 0;
+    virtual int getUniquenessRatio() const = 0;   virtual void setUniquenessRatio(int) = 0;
+    virtual int getP1() const = 0;                virtual void setP1(int) = 0;
+    virtual int getP2() const = 0;                virtual void setP2(int) = 0;
+    virtual int getMode() const = 0;              virtual void setMode(int) = 0;
+};
+
+namespace miflow_detail {
+/** twin of StereoSGMImpl, cudastereo/src/stereosgm.cpp:20-146 */
+class StereoSGMImpl final : public cuda::StereoSGM {
+public:
+    StereoSGMImpl(int minDisparity, int numDisparities, int P1, int P2, int uniquenessRatio, int mode)
+    {
+        mi_stereosgm_default_params(&p_);
+        p_.min_disparity = minDisparity; p_.num_disparities = numDisparities; p_.P1 = P1; p_.P2 = P2;
+        p_.uniqueness_ratio = uniquenessRatio; p_.mode = mode;
+        miCheck(mi_stereosgm_create(&p_, &h_));
+    }
+    ~StereoSGMImpl() override { mi_stereosgm_destroy(h_); }
+    StereoSGMImpl(const StereoSGMImpl &) = delete;
+    StereoSGMImpl &operator=(const StereoSGMImpl &) = delete;
+    void compute(InputArray left, InputArray right, OutputArray disparity) override { compute(left, right, disparity, Stream::Null()); }
+    void compute(InputArray left, InputArray right, OutputArray disparity, Stream &stream) override
+    {
+        disparity.create(left.size(), CV_MAKETYPE(3 /* CV_16S */, 1));   // stereosgm.cpp:110
+        mi_mat l = miMat(left), r = miMat(right), d = miMat(disparity);
+        miCheck(mi_stereosgm_compute(h_, &l, &r, &d, stream.hipStream()));
+    }
+    int getBlockSize() const override { return -1; }             void setBlockSize(int) override {}
+    int getDisp12MaxDiff() const override { return 1; }          void setDisp12MaxDiff(int) override {}
+    int getMinDisparity() const override { return p_.min_disparity; }       void setMinDisparity(int v) override { p_.min_disparity = v; push(); }
+    int getNumDisparities() const override { return p_.num_disparities; }   void setNumDisparities(int v) override { p_.num_disparities = v; push(); }
+    int getSpeckleWindowSize() const override { return 0; }      void setSpeckleWindowSize(int) override {}
+    int getSpeckleRange() const override { return 0; }           void setSpeckleRange(int) override {}
+    int getP1() const override { return p_.P1; }                 void setP1(int v) override { p_.P1 = v; push(); }
+    int getP2() const override { return p_.P2; }                 void setP2(int v) override { p_.P2 = v; push(); }
+    int getUniquenessRatio() const override { return p_.uniqueness_ratio; } void setUniquenessRatio(int v) override { p_.uniqueness_ratio = v; push(); }
+    int getMode() const override { return p_.mode; }             void setMode(int v) override { p_.mode = v; push(); }
+    int getPreFilterCap() const override { return -1; }          void setPreFilterCap(int) override {}
+private:
+    void push() { miCheck(mi_stereosgm_set_params(h_, &p_)); }
+    mi_stereosgm_params p_;
+    mi_stereosgm *h_ = nullptr;
+};
+}  // namespace miflow_detail
+
+/** cudastereo.hpp: createStereoSGM */
+inline Ptr<cuda::StereoSGM> createStereoSGM(int minDisparity = 0, int numDisparities = 128, int P1 = 10, int P2 = 120, int uniquenessRatio = 5,
+                                            int mode = cuda::StereoSGM::MODE_HH4)
+{
+    return makePtr<miflow_detail::StereoSGMImpl>(minDisparity, numDisparities, P1, P2, uniquenessRatio, mode);
+}
+
 /** cudastereo.hpp:298-330 */
 class CV_EXPORTS_W DisparityBilateralFilter : public cv::Algorithm {
 public:

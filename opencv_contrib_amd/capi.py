@@ -49,6 +49,11 @@ class FarnebackParams(C.Structure):
                 ("num_iters", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
 
 
+class StereoSGMParams(C.Structure):
+    _fields_ = [("min_disparity", C.c_int), ("num_disparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),
+                ("uniqueness_ratio", C.c_int), ("mode", C.c_int), ("emulate_cuda_quirks", C.c_int)]
+
+
 class DispBilateralParams(C.Structure):
     _fields_ = [("ndisp", C.c_int), ("radius", C.c_int), ("iters", C.c_int), ("edge_threshold", C.c_float),
                 ("max_disc_threshold", C.c_float), ("sigma_range", C.c_float)]
@@ -148,6 +153,15 @@ def lib():
         "mi_surf_integral": (i, [vp, PM, i, PM, vp]),
         "mi_surf_det_trace": (i, [vp, PM, i, i, PM, PM, vp]),
         "mi_dbg_wave_scan": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "mi_stereosgm_default_params": (None, [C.POINTER(StereoSGMParams)]),
+        "mi_stereosgm_create": (i, [C.POINTER(StereoSGMParams), C.POINTER(vp)]),
+        "mi_stereosgm_set_params": (i, [vp, C.POINTER(StereoSGMParams)]),
+        "mi_stereosgm_get_params": (i, [vp, C.POINTER(StereoSGMParams)]),
+        "mi_stereosgm_compute": (i, [vp, PM, PM, PM, vp]),
+        "mi_stereosgm_destroy": (None, [vp]),
+        "mi_sgm_census": (i, [PM, PM, vp]),
+        "mi_sgm_aggregate_path": (i, [PM, PM, PM, i, i, i, i, i, i, vp]),
+        "mi_sgm_winner_takes_all": (i, [PM, PM, PM, i, i, C.c_float, i, vp]),
         "mi_disp_bilateral_default_params": (None, [C.POINTER(DispBilateralParams)]),
         "mi_disp_bilateral_create": (i, [C.POINTER(DispBilateralParams), C.POINTER(vp)]),
         "mi_disp_bilateral_set_params": (i, [vp, C.POINTER(DispBilateralParams)]),

@@ -252,6 +252,93 @@ def createStereoBM(numDisparities=64, blockSize=19, **kw) -> StereoBM:
     return StereoBM(numDisparities, blockSize, **kw)
 
 
+class StereoSGM:
+    """cv::cuda::StereoSGM (cudastereo.hpp; cudastereo/src/stereosgm.cpp:20-153): semi-global matching on census costs,
+    4 (MODE_HH4) or 8 (MODE_HH) paths, CV_16SC1 output with 4 fractional bits."""
+
+    MODE_HH, MODE_HH4 = 1, 3
+
+    def __init__(self, minDisparity=0, numDisparities=128, P1=10, P2=120, uniquenessRatio=5, mode=3, emulateCudaQuirks=True):
+        self._p = capi.StereoSGMParams()
+        capi.lib().mi_stereosgm_default_params(C.byref(self._p))
+        self._p.min_disparity, self._p.num_disparities, self._p.P1, self._p.P2 = minDisparity, numDisparities, P1, P2
+        self._p.uniqueness_ratio, self._p.mode, self._p.emulate_cuda_quirks = uniquenessRatio, mode, int(bool(emulateCudaQuirks))
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_stereosgm_create(C.byref(self._p), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.lib().mi_stereosgm_destroy(self._h)
+            self._h = None
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+        capi.check(capi.lib().mi_stereosgm_set_params(self._h, C.byref(self._p)))
+
+    # stereosgm.cpp:38-72 (the fixed getters of the reference included)
+    def getBlockSize(self): return -1
+    def setBlockSize(self, v): pass
+    def getDisp12MaxDiff(self): return 1
+    def setDisp12MaxDiff(self, v): pass
+    def getMinDisparity(self): return self._p.min_disparity
+    def setMinDisparity(self, v): self._set(min_disparity=v)
+    def getNumDisparities(self): return self._p.num_disparities
+    def setNumDisparities(self, v): self._set(num_disparities=v)
+    def getSpeckleWindowSize(self): return 0
+    def setSpeckleWindowSize(self, v): pass
+    def getSpeckleRange(self): return 0
+    def setSpeckleRange(self, v): pass
+    def getP1(self): return self._p.P1
+    def setP1(self, v): self._set(P1=v)
+    def getP2(self): return self._p.P2
+    def setP2(self, v): self._set(P2=v)
+    def getUniquenessRatio(self): return self._p.uniqueness_ratio
+    def setUniquenessRatio(self, v): self._set(uniqueness_ratio=v)
+    def getMode(self): return self._p.mode
+    def setMode(self, v): self._set(mode=v)
+    def getPreFilterCap(self): return -1
+    def setPreFilterCap(self, v): pass
+
+    def compute(self, left, right, disparity=None):
+        import torch
+        if disparity is None:
+            disparity = torch.empty(left.shape[:2], dtype=torch.int16, device=left.device)
+        capi.check(capi.lib().mi_stereosgm_compute(self._h, C.byref(_m(left)), C.byref(_m(right)), C.byref(_m(disparity)),
+                                                   capi.current_stream_ptr()))
+        return disparity
+
+
+def createStereoSGM(minDisparity=0, numDisparities=128, P1=10, P2=120, uniquenessRatio=5, mode=3, **kw) -> StereoSGM:
+    """cv::cuda::createStereoSGM (cudastereo.hpp)."""
+    return StereoSGM(minDisparity, numDisparities, P1, P2, uniquenessRatio, mode, **kw)
+
+
+def sgm_census(img):
+    import torch
+    out = torch.empty(img.shape, dtype=torch.int32, device=img.device)
+    capi.check(capi.lib().mi_sgm_census(C.byref(_m(img)), C.byref(_m(out)), capi.current_stream_ptr()))
+    return out
+
+
+def sgm_aggregate_path(left_census, right_census, num_disparities, min_disparity, p1, p2, dx, dy):
+    import torch
+    h, w = left_census.shape
+    out = torch.empty((1, h * w * num_disparities), dtype=torch.uint8, device=left_census.device)
+    capi.check(capi.lib().mi_sgm_aggregate_path(C.byref(_m(left_census)), C.byref(_m(right_census)), C.byref(_m(out)), num_disparities,
+                                                min_disparity, p1, p2, dx, dy, capi.current_stream_ptr()))
+    return out
+
+
+def sgm_winner_takes_all(aggregated, width, height, num_disparities, num_paths, uniqueness, subpixel):
+    import torch
+    left = torch.empty((height, width), dtype=torch.int16, device=aggregated.device)
+    right = torch.empty_like(left)
+    capi.check(capi.lib().mi_sgm_winner_takes_all(C.byref(_m(aggregated)), C.byref(_m(left)), C.byref(_m(right)), num_disparities, num_paths,
+                                                  C.c_float(uniqueness), int(subpixel), capi.current_stream_ptr()))
+    return left, right
+
+
 class BFMatcher:
     """cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L2) for float descriptors (SURF: 64 / 128 elements):
     match() and knnMatch(k = 2) in the device-matrix form of the reference's matchAsync / knnMatchAsync

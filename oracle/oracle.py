@@ -598,3 +598,63 @@ def bf_knn_match2(query, train, mask=None):
     if rc:
         raise ValueError(f"orc_bf_knn2 failed: {rc}")
     return idx, dist
+
+
+# ------------------------------------------------------------------ StereoSGM
+class SGMParams(C.Structure):
+    _fields_ = [("min_disparity", C.c_int), ("num_disparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),
+                ("uniqueness_ratio", C.c_int), ("mode", C.c_int), ("emulate_quirks", C.c_int)]
+
+
+def sgm_params(min_disparity=0, num_disparities=128, P1=10, P2=120, uniqueness_ratio=5, mode=3, emulate_quirks=1):
+    """createStereoSGM defaults (cudastereo.hpp); mode 1 = MODE_HH (8 paths), 3 = MODE_HH4 (4 paths)."""
+    return SGMParams(min_disparity, num_disparities, P1, P2, uniqueness_ratio, mode, emulate_quirks)
+
+
+def _img816(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype not in (np.uint8, np.uint16) or a.ndim != 2:
+        raise ValueError("left.type() == CV_8UC1 || left.type() == CV_16UC1")
+    return a
+
+
+def sgm_census(img):
+    a = _img816(img)
+    out = np.empty(a.shape, np.int32)
+    lib().orc_sgm_census(C.c_void_p(a.ctypes.data), C.c_int(a.itemsize), C.c_int(a.shape[0]), C.c_int(a.shape[1]), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def sgm_path(left_census, right_census, num_disparities, min_disparity, p1, p2, dx, dy):
+    l = np.ascontiguousarray(left_census, dtype=np.int32)
+    r = np.ascontiguousarray(right_census, dtype=np.int32)
+    h, w = l.shape
+    out = np.zeros(h * w * num_disparities, np.uint8)
+    lib().orc_sgm_path(C.c_void_p(l.ctypes.data), C.c_void_p(r.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int(w), C.c_int(h),
+                       C.c_int(num_disparities), C.c_int(min_disparity), C.c_int(p1), C.c_int(p2), C.c_int(dx), C.c_int(dy))
+    return out
+
+
+def sgm_wta(aggregated, width, height, num_disparities, num_paths, uniqueness, subpixel):
+    a = np.ascontiguousarray(aggregated, dtype=np.uint8).reshape(-1)
+    assert a.size == width * height * num_disparities * num_paths
+    left = np.empty((height, width), np.int16)
+    right = np.empty((height, width), np.int16)
+    lib().orc_sgm_wta(C.c_void_p(a.ctypes.data), C.c_void_p(left.ctypes.data), C.c_void_p(right.ctypes.data), C.c_int(width), C.c_int(height),
+                      C.c_int(num_disparities), C.c_int(num_paths), C.c_float(uniqueness), C.c_int(int(subpixel)))
+    return left, right
+
+
+def sgm_compute(left, right, params: SGMParams | None = None):
+    p = params or sgm_params()
+    l, r = _img816(left), _img816(right)
+    if l.shape != r.shape or l.dtype != r.dtype:
+        raise ValueError("size == right.size() && left.type() == right.type()")
+    disp = np.empty(l.shape, np.int16)
+    L = lib()
+    L.orc_sgm_compute.restype = C.c_int
+    rc = L.orc_sgm_compute(C.byref(p), C.c_void_p(l.ctypes.data), C.c_void_p(r.ctypes.data), C.c_int(l.itemsize), C.c_int(l.shape[0]),
+                           C.c_int(l.shape[1]), C.c_void_p(disp.ctypes.data))
+    if rc:
+        raise ValueError(f"orc_sgm_compute failed: {rc} (unsupported mode / number of disparities)")
+    return disp

@@ -101,6 +101,11 @@ int main(int argc, char **argv)
             bf->knnMatch(ddesc, ddesc, knn, 2);
             if ((int)knn.size() != nk || (nk > 1 && knn[0].size() != 2)) return 9;
         }
+        Ptr<cuda::StereoSGM> sgm = cuda::createStereoSGM(0, 64);
+        if (sgm->getP1() != 10 || sgm->getP2() != 120 || sgm->getMode() != cuda::StereoSGM::MODE_HH4 || sgm->getBlockSize() != -1) return 9;
+        cuda::GpuMat sdisp;
+        sgm->compute(d0, d1, sdisp);
+        if (sdisp.depth() != 3 /* CV_16S */ || sdisp.size() != d0.size()) return 9;
         Ptr<cuda::DisparityBilateralFilter> dbf = cuda::createDisparityBilateralFilter(32, 3, 1);
         if (dbf->getRadius() != 3 || dbf->getSigmaRange() != 10.0) return 9;
         cuda::GpuMat refined;
