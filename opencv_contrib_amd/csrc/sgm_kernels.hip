@@ -84,9 +84,29 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A)
 #pragma unroll
     for (int v = 0; v < V; ++v) prev[v] = 0;
     const int BIG = 1 << 20;
+    // census values of a pixel do not depend on the recurrence: they are fetched one pixel ahead (the loop is otherwise a chain of
+    // dependent load -> min -> store steps with nothing to overlap the load latency inside a wave)
+    auto fetch = [&](int ii, int jj, unsigned &l_, unsigned (&r_)[V]) {
+        const bool in = ii >= 0 && ii < H && jj >= 0 && jj < W;
+        const int ic = min(max(ii, 0), H - 1), jc = min(max(jj, 0), W - 1);
+        l_ = in ? (unsigned)A.left[(size_t)ic * W + jc] : 0u;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int k = lane * V + v;
+            const int jr = jj - k - A.min_disp;
+            const bool ok = in && !(k + A.min_disp > jj) && jr < W;   // (jr >= W: negative minDisparity)
+            r_[v] = ok ? (unsigned)A.right[(size_t)ic * W + min(max(jr, 0), W - 1)] : 0u;
+        }
+    };
+    unsigned l_nx, r_nx[V];
+    fetch(i, j, l_nx, r_nx);
     while (i >= 0 && i < H && j >= 0 && j < W) {
         const size_t pix = (size_t)i * W + j;
-        const unsigned l = (unsigned)A.left[pix];
+        const unsigned l = l_nx;
+        unsigned rr[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) rr[v] = r_nx[v];
+        fetch(i + dy, j + dx, l_nx, r_nx);
         unsigned mn = (unsigned)prev[0];
 #pragma unroll
         for (int v = 1; v < V; ++v) mn = min(mn, (unsigned)prev[v]);
@@ -99,9 +119,7 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A)
         int cur[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const int k = lane * V + v;
-            const int jr = j - k - A.min_disp;
-            const unsigned r = (k + A.min_disp > j || jr >= W) ? 0u : (unsigned)A.right[(size_t)i * W + jr];   // (jr >= W: negative minDisparity)
+            const unsigned r = rr[v];
             const int left_n = v > 0 ? prev[v > 0 ? v - 1 : 0] : lo;
             const int right_n = v + 1 < V ? prev[v + 1 < V ? v + 1 : v] : hi;
             int cost = min(prev[v] - m, A.p2);
@@ -136,6 +154,20 @@ __global__ __launch_bounds__(256) void k_wta(const unsigned char *src, short *le
     unsigned rb[V];
 #pragma unroll
     for (int s = 0; s < V; ++s) rb[s] = 0xffffffffu;
+    auto load_sums = [&](int xx, unsigned (&sm)[V]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) sm[v] = 0;
+        const unsigned char *p0 = src + ((size_t)y * width + xx) * D + lane * V;
+        for (int q = 0; q < npaths; ++q) {
+            const unsigned char *pp = p0 + (size_t)q * cost_step;
+            if (V == 1) sm[0] += pp[0];
+            else if (V == 2) { const unsigned t = *reinterpret_cast<const unsigned short *>(pp); sm[0] += t & 0xff; sm[V > 1 ? 1 : 0] += t >> 8; }
+            else { const unsigned t = *reinterpret_cast<const unsigned *>(pp);
+                   sm[0] += t & 0xff; sm[V > 1 ? 1 : 0] += (t >> 8) & 0xff; sm[V > 2 ? 2 : 0] += (t >> 16) & 0xff; sm[V > 3 ? 3 : 0] += t >> 24; }
+        }
+    };
+    unsigned nsum[V];
+    load_sums(0, nsum);
     for (int x0 = 0; x0 < width; x0 += V) {
 #pragma unroll
         for (int x1 = 0; x1 < V; ++x1) {
@@ -143,15 +175,8 @@ __global__ __launch_bounds__(256) void k_wta(const unsigned char *src, short *le
             if (x >= width) break;   // wave-uniform
             unsigned sum[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) sum[v] = 0;
-            const unsigned char *p0 = src + ((size_t)y * width + x) * D + lane * V;
-            for (int q = 0; q < npaths; ++q) {
-                const unsigned char *pp = p0 + (size_t)q * cost_step;
-                if (V == 1) sum[0] += pp[0];
-                else if (V == 2) { const unsigned t = *reinterpret_cast<const unsigned short *>(pp); sum[0] += t & 0xff; sum[V > 1 ? 1 : 0] += t >> 8; }
-                else { const unsigned t = *reinterpret_cast<const unsigned *>(pp);
-                       sum[0] += t & 0xff; sum[V > 1 ? 1 : 0] += (t >> 8) & 0xff; sum[V > 2 ? 2 : 0] += (t >> 16) & 0xff; sum[V > 3 ? 3 : 0] += t >> 24; }
-            }
+            for (int v = 0; v < V; ++v) sum[v] = nsum[v];
+            load_sums(min(x + 1, width - 1), nsum);   // one pixel ahead (independent of this pixel's reductions)
             unsigned packed[V];
             unsigned bl = 0xffffffffu;
 #pragma unroll
