@@ -50,7 +50,57 @@ def test_surf_oracle_matches_golden(oracle, path):
     np.testing.assert_allclose(r["descriptors"], z["descriptors"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("path", _files("sgm"))
+def test_stereosgm_oracle_matches_golden(oracle, path):
+    z = np.load(path)
+    np.testing.assert_array_equal(oracle.sgm_compute(z["left"], z["right"], oracle.sgm_params(**json.loads(str(z["params"])))), z["disp"])
+
+
+@pytest.mark.parametrize("path", _files("dbf"))
+def test_disp_bilateral_oracle_matches_golden(oracle, path):
+    z = np.load(path)
+    np.testing.assert_array_equal(oracle.dbf_apply(z["disp"], z["img"], oracle.dbf_params(**json.loads(str(z["params"])))), z["out"])
+
+
+@pytest.mark.parametrize("path", _files("bf"))
+def test_bfmatch_oracle_matches_golden(oracle, path):
+    z = np.load(path)
+    idx, dist = oracle.bf_knn_match2(z["query"], z["train"])
+    np.testing.assert_array_equal(idx, z["idx"]); np.testing.assert_array_equal(dist, z["dist"])
+
+
 # ------------------------------------------------------------------ HIP vs golden (GPU)
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", _files("sgm"))
+def test_stereosgm_hip_matches_golden(gpu, path):
+    from opencv_contrib_amd import cuda
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    sgm = cuda.createStereoSGM(kw.get("min_disparity", 0), kw["num_disparities"], 10, 120, 5, kw["mode"],
+                               emulateCudaQuirks=bool(kw.get("emulate_quirks", 1)))
+    np.testing.assert_array_equal(sgm.compute(T(z["left"], gpu), T(z["right"], gpu)).cpu().numpy(), z["disp"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", _files("dbf"))
+def test_disp_bilateral_hip_matches_golden(gpu, path):
+    from opencv_contrib_amd import cuda
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    f = cuda.createDisparityBilateralFilter(kw["ndisp"], kw["radius"], kw["iters"])
+    np.testing.assert_array_equal(f.apply(T(z["disp"], gpu), T(z["img"], gpu)).cpu().numpy(), z["out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", _files("bf"))
+def test_bfmatch_hip_matches_golden(gpu, path):
+    from opencv_contrib_amd import cuda
+    z = np.load(path)
+    idx, dist = cuda.createBFMatcher().knnMatch(T(z["query"], gpu), T(z["train"], gpu), k=2)
+    np.testing.assert_array_equal(idx.cpu().numpy(), z["idx"]); np.testing.assert_array_equal(dist.cpu().numpy(), z["dist"])
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", _files("sbm"))
 def test_stereobm_hip_matches_golden(gpu, path):

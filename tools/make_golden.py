@@ -69,8 +69,33 @@ def surf():
         print(name, "features", r["n"])
 
 
+def stereo_next():
+    """StereoSGM and DisparityBilateralFilter goldens on the StereoBM pair."""
+    left, right, _ = synth.stereo_pair(96, 224, seed=42, max_disp=30)
+    for name, kw in {"sgm_96x224_nd64_hh4": dict(num_disparities=64, mode=3),
+                     "sgm_96x224_nd128_hh_min2_clean": dict(num_disparities=128, mode=1, min_disparity=2, emulate_quirks=0)}.items():
+        disp = O.sgm_compute(left, right, O.sgm_params(**kw))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), left=left, right=right, disp=disp, params=np.array(json.dumps(kw)))
+        print(name, "valid", float((disp >= 0).mean()))
+    d = O.sbm_compute(left, right, O.sbm_params(num_disparities=64, block_size=15))
+    kw = dict(ndisp=64, radius=4, iters=2)
+    out = O.dbf_apply(d, left, O.dbf_params(**kw))
+    np.savez_compressed(os.path.join(OUT, "dbf_96x224_nd64_r4_it2.npz"), disp=d, img=left, out=out, params=np.array(json.dumps(kw)))
+    print("dbf refined", int((out != d).sum()))
+
+
+def bfmatch():
+    rng = np.random.default_rng(99)
+    q = rng.standard_normal((60, 64)).astype(np.float32); t = rng.standard_normal((90, 64)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    idx, dist = O.bf_knn_match2(q, t)
+    np.savez_compressed(os.path.join(OUT, "bf_60x90x64.npz"), query=q, train=t, idx=idx, dist=dist, params=np.array(json.dumps({})))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    stereo_next()
+    bfmatch()
     tvl1()
     stereobm()
     farneback()
