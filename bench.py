@@ -197,8 +197,21 @@ def bench_farneback(args):
            "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo * args.steps * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "single small pair: launch-latency bound (about 70 launches of 5-50 us); bytes = fused-iteration accounting"}}
+    # the third dense flow class of the module on the same pair: DensePyrLKOpticalFlow((13, 13), 3, 30)
+    lk = cuda.DensePyrLKOpticalFlow.create()
+    lk.calc(t0_, t1_, flow)
+    torch.cuda.synchronize()
+    tq = time.perf_counter()
+    for _ in range(10):
+        lk.calc(t0_, t1_, flow)
+    torch.cuda.synchronize()
+    out["dense_pyrlk_pairs_per_s"] = 10 / (time.perf_counter() - tq)
+    out["dense_pyrlk_epe_vs_analytic_flow_px"] = float(synth.epe(flow.cpu().numpy()[40:-40, 40:-40], gt[40:-40, 40:-40]))
     if not args.no_cpu:
         from oracle import oracle as O
+        tq = time.perf_counter()
+        O.pyrlk_dense(I0, I1)
+        lk_cpu = 1.0 / (time.perf_counter() - tq)
         O.fb_calc(I0, I1)
         t0 = time.perf_counter()
         k = 0
@@ -207,7 +220,8 @@ def bench_farneback(args):
             k += 1
         ct = (time.perf_counter() - t0) / k
         out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": f"{k} x 1 pair {W}x{H}, {ct * 1e3:.0f} ms each, oracle/farneback_ref.c (OpenMP rows)"}
+                               "sample": f"{k} x 1 pair {W}x{H}, {ct * 1e3:.0f} ms each, oracle/farneback_ref.c (OpenMP rows)",
+                               "dense_pyrlk_pairs_per_s": lk_cpu}
     print(json.dumps(out))
 
 

@@ -309,6 +309,25 @@ MI_API int mi_bf_match(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train
 MI_API int mi_bf_knn_match2(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train, const mi_mat *mask, mi_mat *train_idx,
                             mi_mat *distance, void *stream);
 
+/* ======================================================== dense PyrLK ===== */
+
+/* cv::cuda::DensePyrLKOpticalFlow::create(winSize = (13, 13), maxLevel = 3, iters = 30, useInitialFlow = false), cudaoptflow.hpp;
+ * use_initial_flow is stored but, like the reference's dense path (pyrlk.cpp:238-299), not used. */
+typedef struct mi_densepyrlk_params {
+    int win_width, win_height, max_level, iters, use_initial_flow;
+} mi_densepyrlk_params;
+typedef struct mi_densepyrlk mi_densepyrlk;
+MI_API void mi_densepyrlk_default_params(mi_densepyrlk_params *p);
+MI_API int mi_densepyrlk_create(const mi_densepyrlk_params *p, mi_densepyrlk **out);
+MI_API int mi_densepyrlk_set_params(mi_densepyrlk *h, const mi_densepyrlk_params *p);
+MI_API int mi_densepyrlk_get_params(const mi_densepyrlk *h, mi_densepyrlk_params *p);
+/* Replaces: DensePyrLKOpticalFlowImpl::calc + PyrLKOpticalFlowBase::dense + pyrlk::denseKernel, cudaoptflow/src/pyrlk.cpp:238-299,
+ * 379-392, cuda/pyrlk.cu:709-847.  prev, next: MI_8UC1 of the same size; flow: MI_32FC2 of the image size.  Pixels whose
+ * structure tensor is singular or whose track leaves the image keep the value their (u, v) buffer held (the reference returns
+ * without writing; buffers start at zero). */
+MI_API int mi_densepyrlk_calc(mi_densepyrlk *h, const mi_mat *prev, const mi_mat *next, mi_mat *flow, void *stream);
+MI_API void mi_densepyrlk_destroy(mi_densepyrlk *h);
+
 /* ======================================================== StereoSGM ===== */
 
 enum { MI_SGM_MODE_HH = 1, MI_SGM_MODE_HH4 = 3 };   /* cv::StereoSGBM::MODE_HH (8 paths), MODE_HH4 (4 paths) */

@@ -131,5 +131,50 @@ inline Ptr<FarnebackOpticalFlow> FarnebackOpticalFlow::create(int numLevels, dou
     return makePtr<miflow_detail::FarnebackImpl>(p);
 }
 
+/** cudaoptflow.hpp: class DensePyrLKOpticalFlow; implementation twin of DensePyrLKOpticalFlowImpl, cudaoptflow/src/pyrlk.cpp:354-406 */
+class DensePyrLKOpticalFlow : public DenseOpticalFlow {
+public:
+    virtual Size getWinSize() const = 0;          virtual void setWinSize(Size winSize) = 0;
+    virtual int getMaxLevel() const = 0;          virtual void setMaxLevel(int maxLevel) = 0;
+    virtual int getNumIters() const = 0;          virtual void setNumIters(int iters) = 0;
+    virtual bool getUseInitialFlow() const = 0;   virtual void setUseInitialFlow(bool useInitialFlow) = 0;
+    static Ptr<DensePyrLKOpticalFlow> create(Size winSize = Size(13, 13), int maxLevel = 3, int iters = 30, bool useInitialFlow = false);
+};
+
+namespace miflow_detail {
+class DensePyrLKImpl final : public DensePyrLKOpticalFlow {
+public:
+    explicit DensePyrLKImpl(const mi_densepyrlk_params &p) : p_(p) { miCheck(mi_densepyrlk_create(&p_, &h_)); }
+    ~DensePyrLKImpl() override { mi_densepyrlk_destroy(h_); }
+    DensePyrLKImpl(const DensePyrLKImpl &) = delete;
+    DensePyrLKImpl &operator=(const DensePyrLKImpl &) = delete;
+    void calc(InputArray prevImg, InputArray nextImg, InputOutputArray flow, Stream &stream) override
+    {
+        flow.create(prevImg.size(), CV_32FC2);   // cuda::merge into _flow, pyrlk.cpp:390-391
+        mi_mat a = miMat(prevImg), b = miMat(nextImg), f = miMat(flow);
+        miCheck(mi_densepyrlk_calc(h_, &a, &b, &f, stream.hipStream()));
+    }
+    String getDefaultName() const override { return "DenseOpticalFlow.DensePyrLKOpticalFlow"; }   // pyrlk.cpp:394
+    Size getWinSize() const override { return Size(p_.win_width, p_.win_height); }
+    void setWinSize(Size v) override { p_.win_width = v.width; p_.win_height = v.height; push(); }
+    int getMaxLevel() const override { return p_.max_level; }           void setMaxLevel(int v) override { p_.max_level = v; push(); }
+    int getNumIters() const override { return p_.iters; }               void setNumIters(int v) override { p_.iters = v; push(); }
+    bool getUseInitialFlow() const override { return p_.use_initial_flow != 0; }
+    void setUseInitialFlow(bool v) override { p_.use_initial_flow = v; push(); }
+private:
+    void push() { miCheck(mi_densepyrlk_set_params(h_, &p_)); }
+    mi_densepyrlk_params p_;
+    mi_densepyrlk *h_ = nullptr;
+};
+}  // namespace miflow_detail
+
+inline Ptr<DensePyrLKOpticalFlow> DensePyrLKOpticalFlow::create(Size winSize, int maxLevel, int iters, bool useInitialFlow)
+{
+    mi_densepyrlk_params p;
+    mi_densepyrlk_default_params(&p);
+    p.win_width = winSize.width; p.win_height = winSize.height; p.max_level = maxLevel; p.iters = iters; p.use_initial_flow = useInitialFlow;
+    return makePtr<miflow_detail::DensePyrLKImpl>(p);
+}
+
 }}  // namespace cv::cuda
 #endif

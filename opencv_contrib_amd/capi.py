@@ -49,6 +49,10 @@ class FarnebackParams(C.Structure):
                 ("num_iters", C.c_int), ("poly_n", C.c_int), ("poly_sigma", C.c_double), ("flags", C.c_int)]
 
 
+class DensePyrLKParams(C.Structure):
+    _fields_ = [("win_width", C.c_int), ("win_height", C.c_int), ("max_level", C.c_int), ("iters", C.c_int), ("use_initial_flow", C.c_int)]
+
+
 class StereoSGMParams(C.Structure):
     _fields_ = [("min_disparity", C.c_int), ("num_disparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),
                 ("uniqueness_ratio", C.c_int), ("mode", C.c_int), ("emulate_cuda_quirks", C.c_int)]
@@ -153,6 +157,12 @@ def lib():
         "mi_surf_integral": (i, [vp, PM, i, PM, vp]),
         "mi_surf_det_trace": (i, [vp, PM, i, i, PM, PM, vp]),
         "mi_dbg_wave_scan": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "mi_densepyrlk_default_params": (None, [C.POINTER(DensePyrLKParams)]),
+        "mi_densepyrlk_create": (i, [C.POINTER(DensePyrLKParams), C.POINTER(vp)]),
+        "mi_densepyrlk_set_params": (i, [vp, C.POINTER(DensePyrLKParams)]),
+        "mi_densepyrlk_get_params": (i, [vp, C.POINTER(DensePyrLKParams)]),
+        "mi_densepyrlk_calc": (i, [vp, PM, PM, PM, vp]),
+        "mi_densepyrlk_destroy": (None, [vp]),
         "mi_stereosgm_default_params": (None, [C.POINTER(StereoSGMParams)]),
         "mi_stereosgm_create": (i, [C.POINTER(StereoSGMParams), C.POINTER(vp)]),
         "mi_stereosgm_set_params": (i, [vp, C.POINTER(StereoSGMParams)]),

@@ -252,6 +252,50 @@ def createStereoBM(numDisparities=64, blockSize=19, **kw) -> StereoBM:
     return StereoBM(numDisparities, blockSize, **kw)
 
 
+class DensePyrLKOpticalFlow:
+    """cv::cuda::DensePyrLKOpticalFlow (cudaoptflow.hpp; cudaoptflow/src/pyrlk.cpp:238-299,354-406)."""
+
+    def __init__(self, winSize=(13, 13), maxLevel=3, iters=30, useInitialFlow=False):
+        self._p = capi.DensePyrLKParams()
+        capi.lib().mi_densepyrlk_default_params(C.byref(self._p))
+        self._p.win_width, self._p.win_height, self._p.max_level, self._p.iters = winSize[0], winSize[1], maxLevel, iters
+        self._p.use_initial_flow = int(bool(useInitialFlow))
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_densepyrlk_create(C.byref(self._p), C.byref(self._h)))
+
+    @classmethod
+    def create(cls, winSize=(13, 13), maxLevel=3, iters=30, useInitialFlow=False):
+        return cls(winSize, maxLevel, iters, useInitialFlow)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.lib().mi_densepyrlk_destroy(self._h)
+            self._h = None
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+        capi.check(capi.lib().mi_densepyrlk_set_params(self._h, C.byref(self._p)))
+
+    def getDefaultName(self): return "DenseOpticalFlow.DensePyrLKOpticalFlow"   # pyrlk.cpp:394
+    def getWinSize(self): return (self._p.win_width, self._p.win_height)
+    def setWinSize(self, v): self._set(win_width=v[0], win_height=v[1])
+    def getMaxLevel(self): return self._p.max_level
+    def setMaxLevel(self, v): self._set(max_level=v)
+    def getNumIters(self): return self._p.iters
+    def setNumIters(self, v): self._set(iters=v)
+    def getUseInitialFlow(self): return bool(self._p.use_initial_flow)
+    def setUseInitialFlow(self, v): self._set(use_initial_flow=int(bool(v)))
+
+    def calc(self, prevImg, nextImg, flow=None):
+        import torch
+        if flow is None:
+            flow = torch.empty((prevImg.shape[0], prevImg.shape[1], 2), dtype=torch.float32, device=prevImg.device)
+        capi.check(capi.lib().mi_densepyrlk_calc(self._h, C.byref(_m(prevImg)), C.byref(_m(nextImg)), C.byref(_m(flow)),
+                                                 capi.current_stream_ptr()))
+        return flow
+
+
 class StereoSGM:
     """cv::cuda::StereoSGM (cudastereo.hpp; cudastereo/src/stereosgm.cpp:20-153): semi-global matching on census costs,
     4 (MODE_HH4) or 8 (MODE_HH) paths, CV_16SC1 output with 4 fractional bits."""

@@ -658,3 +658,19 @@ def sgm_compute(left, right, params: SGMParams | None = None):
     if rc:
         raise ValueError(f"orc_sgm_compute failed: {rc} (unsupported mode / number of disparities)")
     return disp
+
+
+# ------------------------------------------------------------------ dense PyrLK
+def pyrlk_dense(prev, nxt, win_size=(13, 13), max_level=3, iters=30):
+    """cv::cuda::DensePyrLKOpticalFlow::create(winSize = (13, 13), maxLevel = 3, iters = 30)->calc restated on the CPU."""
+    a, b = _u8(prev), _u8(nxt)
+    if a.shape != b.shape:
+        raise ValueError("prevImg.size() == nextImg.size()")
+    flow = np.empty(a.shape + (2,), np.float32)
+    L = lib()
+    L.orc_pyrlk_dense.restype = C.c_int
+    rc = L.orc_pyrlk_dense(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_int(a.shape[0]), C.c_int(a.shape[1]),
+                           C.c_int(win_size[0]), C.c_int(win_size[1]), C.c_int(max_level), C.c_int(iters), C.c_void_p(flow.ctypes.data))
+    if rc:
+        raise ValueError("maxLevel >= 0 && winSize > 2")
+    return flow

@@ -101,6 +101,13 @@ int main(int argc, char **argv)
             bf->knnMatch(ddesc, ddesc, knn, 2);
             if ((int)knn.size() != nk || (nk > 1 && knn[0].size() != 2)) return 9;
         }
+        Ptr<cuda::DensePyrLKOpticalFlow> lk = cuda::DensePyrLKOpticalFlow::create();
+        if (lk->getWinSize().width != 13 || lk->getMaxLevel() != 3 || lk->getNumIters() != 30 ||
+            lk->getDefaultName() != "DenseOpticalFlow.DensePyrLKOpticalFlow") return 9;
+        cuda::GpuMat lkflow;
+        lk->calc(d0, d1, lkflow, stream);
+        stream.waitForCompletion();
+        if (lkflow.type() != CV_32FC2 || lkflow.size() != d0.size()) return 9;
         Ptr<cuda::StereoSGM> sgm = cuda::createStereoSGM(0, 64);
         if (sgm->getP1() != 10 || sgm->getP2() != 120 || sgm->getMode() != cuda::StereoSGM::MODE_HH4 || sgm->getBlockSize() != -1) return 9;
         cuda::GpuMat sdisp;
