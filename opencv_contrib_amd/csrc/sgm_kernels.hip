@@ -142,12 +142,16 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A)
 // ------------------------------------------------------------------ winner takes all (test_sgm_funcs.cpp:354-403; stereosgm.cu:1524-1568)
 template <int D>
 __global__ __launch_bounds__(256) void k_wta(const unsigned char *src, short *left, size_t lstep, short *right, size_t rstep, int width,
-                                             int height, int npaths, float uniqueness, int subpixel)
+                                             int height, int npaths, float uniqueness, int subpixel, int seg)
 {
     constexpr int V = D / 64;
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (y >= height) return;
+    // A row is cut into segments of `seg` pixels (one wave each; a single wave per row leaves the chip at one wave per SIMD
+    // with every load latency exposed).  The left disparity is per pixel; a right pixel p needs the left pixels p .. p + D - 1,
+    // so a segment also walks the D - 1 pixels after its end, for the right minima only.
+    const int xs = blockIdx.y * seg, xe = min(xs + seg, width), x_end = min(xe + D - 1, width);
     const size_t cost_step = (size_t)D * width * height;
     short *lrow = reinterpret_cast<short *>(reinterpret_cast<unsigned char *>(left) + (size_t)y * lstep);
     short *rrow = reinterpret_cast<short *>(reinterpret_cast<unsigned char *>(right) + (size_t)y * rstep);
@@ -167,12 +171,12 @@ __global__ __launch_bounds__(256) void k_wta(const unsigned char *src, short *le
         }
     };
     unsigned nsum[V];
-    load_sums(0, nsum);
-    for (int x0 = 0; x0 < width; x0 += V) {
+    load_sums(xs, nsum);
+    for (int x0 = xs; x0 < x_end; x0 += V) {
 #pragma unroll
         for (int x1 = 0; x1 < V; ++x1) {
             const int x = x0 + x1;
-            if (x >= width) break;   // wave-uniform
+            if (x >= x_end) break;   // wave-uniform
             unsigned sum[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) sum[v] = nsum[v];
@@ -191,10 +195,11 @@ __global__ __launch_bounds__(256) void k_wta(const unsigned char *src, short *le
                 rb[s] = min(rb[s], recv);
                 if (k == D - 1) {
                     const int p = x - k;
-                    if (p >= 0) rrow[p] = (short)(rb[s] & 0xffffu);
+                    if (p >= xs) rrow[p] = (short)(rb[s] & 0xffffu);   // (p < xe by construction; p < xs: started mid-way, other segment's)
                     rb[s] = 0xffffffffu;
                 }
             }
+            if (x >= xe) continue;   // wave-uniform: the overlap pixels feed the right minima only
             // left image: uniqueness + sub-pixel
             const unsigned best_cost = best >> 16;
             const int best_disp = (int)(best & 0xffffu);
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void k_wta(const unsigned char *src, short *le
     for (int s = 0; s < V; ++s) {   // flush: right pixels in (width - D, width)
         const unsigned k0 = (unsigned)(lane * V + s);
         const int p = (int)((((unsigned)width - k0) & ~(unsigned)(D - 1)) + k0);
-        if (p >= 0 && p < width) rrow[p] = (short)(rb[s] & 0xffffu);
+        if (p >= xs && p < xe && p < width) rrow[p] = (short)(rb[s] & 0xffffu);
     }
 }
 
@@ -325,10 +330,11 @@ static int launch_paths(const PathArgs &A, int D, hipStream_t st)
 static int launch_wta(const unsigned char *src, short *l, size_t ls, short *r, size_t rs, int w, int h, int D, int np, float uniq, int subpixel,
                       hipStream_t st)
 {
-    const dim3 grid(div_up(h, 4));
-    if (D == 64) hipLaunchKernelGGL((k_wta<64>), grid, dim3(256), 0, st, src, l, ls, r, rs, w, h, np, uniq, subpixel);
-    else if (D == 128) hipLaunchKernelGGL((k_wta<128>), grid, dim3(256), 0, st, src, l, ls, r, rs, w, h, np, uniq, subpixel);
-    else hipLaunchKernelGGL((k_wta<256>), grid, dim3(256), 0, st, src, l, ls, r, rs, w, h, np, uniq, subpixel);
+    const int seg = D <= 128 ? 256 : 512;   // multiple of V; (seg + D - 1) / seg = 1.25 .. 1.5 of redundant walking buys 4 - 8 waves per SIMD
+    const dim3 grid(div_up(h, 4), div_up(w, seg));
+    if (D == 64) hipLaunchKernelGGL((k_wta<64>), grid, dim3(256), 0, st, src, l, ls, r, rs, w, h, np, uniq, subpixel, seg);
+    else if (D == 128) hipLaunchKernelGGL((k_wta<128>), grid, dim3(256), 0, st, src, l, ls, r, rs, w, h, np, uniq, subpixel, seg);
+    else hipLaunchKernelGGL((k_wta<256>), grid, dim3(256), 0, st, src, l, ls, r, rs, w, h, np, uniq, subpixel, seg);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

@@ -119,6 +119,21 @@ def test_winner_takes_all_random(gpu, oracle, subpixel, npaths, D):
     np.testing.assert_array_equal(right.cpu().numpy(), rr)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,w", [(64, 600), (128, 777), (256, 1100)])
+def test_winner_takes_all_wide_rows_are_segmented(gpu, oracle, D, w):
+    """Rows wider than one segment (256 / 512 px): segments walk D - 1 pixels past their end for the right minima."""
+    import torch
+    from opencv_contrib_amd import cuda
+    rng = np.random.default_rng(D + w)
+    h = 5
+    agg = rng.integers(0, 32, (1, w * h * D * 4)).astype(np.uint8)
+    left, right = cuda.sgm_winner_takes_all(torch.from_numpy(agg).to(gpu), w, h, D, 4, 0.95, True)
+    rl, rr = oracle.sgm_wta(agg, w, h, D, 4, 0.95, True)
+    np.testing.assert_array_equal(left.cpu().numpy(), rl)
+    np.testing.assert_array_equal(right.cpu().numpy(), rr)
+
+
 # ------------------------------------------------------------------ full pipeline
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [1, 3])
