@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A)
 {
     constexpr int V = D / 64;
     const int lane = threadIdx.x & 63;
-    const int gl = blockIdx.x * 4 + (threadIdx.x >> 6);   // global line index
+    const int gl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // global line index, pinned wave-uniform (scalar loop control)
     if (gl >= A.line0[A.npaths]) return;
     int q = 0;
     while (gl >= A.line0[q + 1]) ++q;
@@ -84,12 +84,16 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A)
 #pragma unroll
     for (int v = 0; v < V; ++v) prev[v] = 0;
     const int BIG = 1 << 20;
-    // census values of a pixel do not depend on the recurrence: they are fetched one pixel ahead (the loop is otherwise a chain of
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    // census values of a pixel do not depend on the recurrence: they are fetched ahead of it (the loop is otherwise a chain of
     // dependent load -> min -> store steps with nothing to overlap the load latency inside a wave)
     auto fetch = [&](int ii, int jj, unsigned &l_, unsigned (&r_)[V]) {
         const bool in = ii >= 0 && ii < H && jj >= 0 && jj < W;
         const int ic = min(max(ii, 0), H - 1), jc = min(max(jj, 0), W - 1);
-        l_ = in ? (unsigned)A.left[(size_t)ic * W + jc] : 0u;
+        // read through the VECTOR memory path (vz is an opaque zero VGPR): as a scalar load the compiler must wait lgkmcnt(0) at its
+        // use, which also waits for the scalar loads just issued for later steps and defeats the prefetch
+        l_ = in ? (unsigned)A.left[(size_t)ic * W + jc + vz] : 0u;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             const int k = lane * V + v;
@@ -98,44 +102,51 @@ __global__ __launch_bounds__(256) void k_paths(PathArgs A)
             r_[v] = ok ? (unsigned)A.right[(size_t)ic * W + min(max(jr, 0), W - 1)] : 0u;
         }
     };
-    unsigned l_nx, r_nx[V];
-    fetch(i, j, l_nx, r_nx);
+    // PD steps ahead: a vertical or diagonal step touches a new image row (new cache lines), whose latency is several step times
+    constexpr int PD = 4;
+    unsigned lq[PD], rq[PD][V];
+#pragma unroll
+    for (int s = 0; s < PD; ++s) fetch(i + s * dy, j + s * dx, lq[s], rq[s]);
     while (i >= 0 && i < H && j >= 0 && j < W) {
-        const size_t pix = (size_t)i * W + j;
-        const unsigned l = l_nx;
-        unsigned rr[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) rr[v] = r_nx[v];
-        fetch(i + dy, j + dx, l_nx, r_nx);
-        unsigned mn = (unsigned)prev[0];
+        for (int s = 0; s < PD; ++s) {
+            if (!(i >= 0 && i < H && j >= 0 && j < W)) break;   // wave-uniform
+            const size_t pix = (size_t)i * W + j;
+            const unsigned l = lq[s];
+            unsigned rr[V];
 #pragma unroll
-        for (int v = 1; v < V; ++v) mn = min(mn, (unsigned)prev[v]);
-        const int m = (int)wave_min_u32(mn);
-        // d - 1 / d + 1 neighbours across the lane boundary
-        int lo = __builtin_amdgcn_update_dpp(0, prev[V - 1], 0x138, 0xf, 0xf, true);   // wave_shr:1  (lane n <- lane n-1)
-        int hi = __builtin_amdgcn_update_dpp(0, prev[0], 0x130, 0xf, 0xf, true);       // wave_shl:1  (lane n <- lane n+1)
-        if (lane == 0) lo = BIG;
-        if (lane == 63) hi = BIG;
-        int cur[V];
+            for (int v = 0; v < V; ++v) rr[v] = rq[s][v];
+            fetch(i + PD * dy, j + PD * dx, lq[s], rq[s]);
+            unsigned mn = (unsigned)prev[0];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const unsigned r = rr[v];
-            const int left_n = v > 0 ? prev[v > 0 ? v - 1 : 0] : lo;
-            const int right_n = v + 1 < V ? prev[v + 1 < V ? v + 1 : v] : hi;
-            int cost = min(prev[v] - m, A.p2);
-            cost = min(cost, left_n - m + A.p1);
-            cost = min(cost, right_n - m + A.p1);
-            cost += __popc(l ^ r);
-            cur[v] = cost & 0xff;   // static_cast<uint8_t>(cost)
+            for (int v = 1; v < V; ++v) mn = min(mn, (unsigned)prev[v]);
+            const int m = (int)wave_min_u32(mn);
+            // d - 1 / d + 1 neighbours across the lane boundary
+            int lo = __builtin_amdgcn_update_dpp(0, prev[V - 1], 0x138, 0xf, 0xf, true);   // wave_shr:1  (lane n <- lane n-1)
+            int hi = __builtin_amdgcn_update_dpp(0, prev[0], 0x130, 0xf, 0xf, true);       // wave_shl:1  (lane n <- lane n+1)
+            if (lane == 0) lo = BIG;
+            if (lane == 63) hi = BIG;
+            int cur[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const unsigned r = rr[v];
+                const int left_n = v > 0 ? prev[v > 0 ? v - 1 : 0] : lo;
+                const int right_n = v + 1 < V ? prev[v + 1 < V ? v + 1 : v] : hi;
+                int cost = min(prev[v] - m, A.p2);
+                cost = min(cost, left_n - m + A.p1);
+                cost = min(cost, right_n - m + A.p1);
+                cost += __popc(l ^ r);
+                cur[v] = cost & 0xff;   // static_cast<uint8_t>(cost)
+            }
+            unsigned char *o = out + pix * D + lane * V;
+            if (V == 1) o[0] = (unsigned char)cur[0];
+            else if (V == 2) *reinterpret_cast<unsigned short *>(o) = (unsigned short)(cur[0] | (cur[V > 1 ? 1 : 0] << 8));
+            else *reinterpret_cast<unsigned *>(o) = (unsigned)cur[0] | ((unsigned)cur[V > 1 ? 1 : 0] << 8) | ((unsigned)cur[V > 2 ? 2 : 0] << 16) |
+                                                     ((unsigned)cur[V > 3 ? 3 : 0] << 24);
+#pragma unroll
+            for (int v = 0; v < V; ++v) prev[v] = cur[v];
+            i += dy; j += dx;
         }
-        unsigned char *o = out + pix * D + lane * V;
-        if (V == 1) o[0] = (unsigned char)cur[0];
-        else if (V == 2) *reinterpret_cast<unsigned short *>(o) = (unsigned short)(cur[0] | (cur[V > 1 ? 1 : 0] << 8));
-        else *reinterpret_cast<unsigned *>(o) = (unsigned)cur[0] | ((unsigned)cur[V > 1 ? 1 : 0] << 8) | ((unsigned)cur[V > 2 ? 2 : 0] << 16) |
-                                                 ((unsigned)cur[V > 3 ? 3 : 0] << 24);
-#pragma unroll
-        for (int v = 0; v < V; ++v) prev[v] = cur[v];
-        i += dy; j += dx;
     }
 }
 
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256) void k_wta(const unsigned char *src, short *le
 {
     constexpr int V = D / 64;
     const int lane = threadIdx.x & 63;
-    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int y = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
     if (y >= height) return;
     // A row is cut into segments of `seg` pixels (one wave each; a single wave per row leaves the chip at one wave per SIMD
     // with every load latency exposed).  The left disparity is per pixel; a right pixel p needs the left pixels p .. p + D - 1,
