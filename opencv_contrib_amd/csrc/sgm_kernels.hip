@@ -435,7 +435,7 @@ int mi_stereosgm_compute(mi_stereosgm *h, const mi_mat *left, const mi_mat *righ
     const int rows = left->rows, cols = left->cols, D = P.num_disparities, np = P.mode == MI_SGM_MODE_HH4 ? 4 : 8;
     const size_t n = (size_t)rows * cols;
     // scratch: census L/R (int32), aggregated costs [path][pixel][d] (u8), three int16 maps
-    const size_t off_cr = align_up(1, 1) * n * 4, off_agg = off_cr + n * 4, off_lt = off_agg + n * D * np;
+    const size_t off_cr = n * 4, off_agg = off_cr + n * 4, off_lt = off_agg + n * D * np;
     const size_t off_rt = off_lt + ((n * 2 + 255) / 256) * 256, off_rm = off_rt + ((n * 2 + 255) / 256) * 256;
     const size_t need = off_rm + ((n * 2 + 255) / 256) * 256;
     if (h->buf_bytes < need) {

@@ -42,6 +42,7 @@ struct mi_tvl1 {
     // device loop control
     int2 *S = nullptr;
     unsigned long long *E = nullptr;
+    double *Pd = nullptr;   // per slot prevError (cv::cuda check schedule)
     int Q = 0, ctlB = 0;
     std::vector<SlotInfo> slots;
     int last_nscales = 0, last_batch = 0;
@@ -155,6 +156,7 @@ void mi_tvl1_destroy(mi_tvl1 *h)
     if (h->tab_dev) (void)hipFree(h->tab_dev);
     if (h->S) (void)hipFree(h->S);
     if (h->E) (void)hipFree(h->E);
+    if (h->Pd) (void)hipFree(h->Pd);
     delete h;
 }
 
@@ -283,9 +285,11 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         if (h->Q < Q || h->ctlB < B) {
             if (h->S) (void)hipFree(h->S);
             if (h->E) (void)hipFree(h->E);
-            h->S = nullptr; h->E = nullptr;
+            if (h->Pd) (void)hipFree(h->Pd);
+            h->S = nullptr; h->E = nullptr; h->Pd = nullptr;
             MI_HIP_TRY(hipMalloc((void **)&h->S, sizeof(int2) * (size_t)Q * B));
             MI_HIP_TRY(hipMalloc((void **)&h->E, sizeof(unsigned long long) * (size_t)Q * B));
+            MI_HIP_TRY(hipMalloc((void **)&h->Pd, sizeof(double) * (size_t)Q * B));
             h->Q = Q; h->ctlB = B;
         }
         MI_HIP_TRY(hipMemsetAsync(h->E, 0, sizeof(unsigned long long) * (size_t)h->Q * B, st));
@@ -352,6 +356,7 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
     Ctl ctl;
     memset(&ctl, 0, sizeof(ctl));
     ctl.S = h->S; ctl.E = h->E; ctl.Q = h->Q;
+    ctl.P = h->Pd; ctl.sched = (P.semantics == MI_SEM_CUDA_COMPAT) ? 1 : 0;   // cv::cuda's check schedule vs the CPU class's every-iteration check
 
     for (int s = ns - 1; s >= 0; --s) {
         LevelBuf &Lv = h->L[s];
@@ -418,6 +423,7 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
                     ic.q = q; ic.q_prev = q_last;
                     ic.first_of_warp = (it == 0);
                     ic.reset_cur = first_of_scale;
+                    ic.n = it;
                     rc = iterate(P.exact_math != 0, pl, g, l_t, theta, taut, first_of_scale, &ic, 0, st);
                     h->slots.push_back({s, wp});
                     q_last = q++;
@@ -478,6 +484,6 @@ int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int *iters,
     MI_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     MI_HIP_TRY(hipMemcpy(S.data(), h->S + (size_t)pair * h->Q, sizeof(int2) * nq, hipMemcpyDeviceToHost));
     for (int i = 0; i < nq; ++i)
-        if (S[i].y) iters[h->slots[i].scale * nw + h->slots[i].warp] += 1;
+        if (S[i].y & 1) iters[h->slots[i].scale * nw + h->slots[i].warp] += 1;
     return MI_OK;
 }

@@ -24,6 +24,11 @@ struct Ctl {
     int first_of_warp;   // error := max  => always active
     int reset_cur;       // first launch of a scale: cur_in := 0
     double thr;      // scaledEpsilon (already rounded through float for CPU_REF)
+    // cv::cuda's check schedule (cudaoptflow/src/tvl1flow.cpp:357-377): the error is summed only at odd iterations n and only
+    // while prevError < scaledEpsilon; after a failed or skipped check prevError shrinks by scaledEpsilon per iteration.
+    double *P;       // per slot: prevError as seen by that launch (sched only)
+    int sched;       // 0: check every iteration (CPU class), 1: the schedule above (MI_SEM_CUDA_COMPAT)
+    int n;           // iteration index inside the warp
 };
 
 struct PtrTab {          // per-pair external image pointers (device array)

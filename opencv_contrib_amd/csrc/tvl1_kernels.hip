@@ -37,10 +37,12 @@ __device__ __forceinline__ float lane_prev(float v) { return __shfl_up(v, 1); } 
 __device__ __forceinline__ float lane_next(float v) { return __shfl_down(v, 1); } // lane n <- n+1
 
 struct CtlK {  // by-value copy for kernels (Ctl may be absent)
-    int2 *S;
+    int2 *S;         // per slot {cur_in, flags}: flags bit 0 = the launch was active, bit 1 = it summed the error
     unsigned long long *E;
     int Q, q, q_prev, first_of_warp, reset_cur;
     double thr;
+    double *P;
+    int sched, n;
 };
 static CtlK make_ctlk(const Ctl *c)
 {
@@ -48,7 +50,8 @@ static CtlK make_ctlk(const Ctl *c)
     memset(&k, 0, sizeof(k));
     k.q_prev = -1;
     if (c) { k.S = c->S; k.E = c->E; k.Q = c->Q; k.q = c->q; k.q_prev = c->q_prev;
-             k.first_of_warp = c->first_of_warp; k.reset_cur = c->reset_cur; k.thr = c->thr; }
+             k.first_of_warp = c->first_of_warp; k.reset_cur = c->reset_cur; k.thr = c->thr;
+             k.P = c->P; k.sched = c->sched; k.n = c->n; }
     return k;
 }
 __device__ __forceinline__ int resolve_cur_k(const CtlK &c, int b, int cur_host)
@@ -56,7 +59,7 @@ __device__ __forceinline__ int resolve_cur_k(const CtlK &c, int b, int cur_host)
     if (!c.S) return cur_host;
     if (c.q_prev < 0) return 0;
     const int2 s = c.S[(long long)b * c.Q + c.q_prev];
-    return s.x ^ s.y;
+    return s.x ^ (s.y & 1);
 }
 
 #define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */
@@ -118,10 +121,10 @@ __device__ __forceinline__ bool resolve_active_k(const CtlK &c, int b, int cur_h
     if (c.q_prev < 0) { cur = 0; return true; }
     const long long sp = (long long)b * c.Q + c.q_prev;
     const int2 s = c.S[sp];
-    cur = c.reset_cur ? 0 : (s.x ^ s.y);
+    cur = c.reset_cur ? 0 : (s.x ^ (s.y & 1));
     if (c.first_of_warp) return true;
     const double e = (double)c.E[sp] * (1.0 / ERR_FIX_SCALE);
-    return s.y && (e > c.thr);
+    return (s.y & 1) && (!(s.y & 2) || e > c.thr);   // an unchecked iteration never ends the loop (error = max)
 }
 
 struct MedArgs { float *u[2][2]; float *tmp[2]; Geo g; };   // u[set][component]
@@ -856,20 +859,28 @@ __global__ __launch_bounds__(256) void k_iterate(IterArgs A, CtlK ctl, int cur_h
     const int W = A.g.w, H = A.g.h, ld = A.g.ld;
 
     int cur = cur_host;
+    bool calc_err = true;
     if (CHECK) {
         // loop control of procOneScale (optflow/src/tvl1flow.cpp:1376-1390), evaluated per launch
+        // (cv::cuda schedule, cudaoptflow/src/tvl1flow.cpp:357-377, when ctl.sched)
         int cur_in = 0, active = 1;
+        double prev_in = 0.0;   // prevError as this iteration sees it
         if (ctl.q_prev >= 0) {
             const long long sp = (long long)b * ctl.Q + ctl.q_prev;
             const int2 s = ctl.S[sp];
-            cur_in = ctl.reset_cur ? 0 : (s.x ^ s.y);
+            cur_in = ctl.reset_cur ? 0 : (s.x ^ (s.y & 1));
             if (!ctl.first_of_warp) {
                 const double e = (double)ctl.E[sp] * (1.0 / ERR_FIX_SCALE);
-                active = s.y && (e > ctl.thr);
+                const bool checked = (s.y & 2) != 0;
+                active = (s.y & 1) && (!checked || e > ctl.thr);
+                if (ctl.sched) prev_in = checked ? e : ctl.P[sp] - ctl.thr;
             }
         }
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-            ctl.S[(long long)b * ctl.Q + ctl.q] = make_int2(cur_in, active);
+        calc_err = !ctl.sched || ((ctl.n & 1) && prev_in < ctl.thr);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            ctl.S[(long long)b * ctl.Q + ctl.q] = make_int2(cur_in, active | (calc_err ? 2 : 0));
+            if (ctl.sched) ctl.P[(long long)b * ctl.Q + ctl.q] = prev_in;
+        }
         if (!active) return;
         cur = cur_in;
     }
@@ -982,7 +993,7 @@ __global__ __launch_bounds__(256) void k_iterate(IterArgs A, CtlK ctl, int cur_h
         for (int j = 0; j < 4; ++j) { u1c[j] = u1d[j]; u2c[j] = u2d[j]; u3c[j] = u3d[j]; ec[j] = ed[j]; }
     }
 
-    if (CHECK) {
+    if (CHECK && calc_err) {
         double s = (double)errsum;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
