@@ -268,11 +268,11 @@ def bench_surf(args):
                                 "layer from a 33 MB L2/MALL-resident table), not HBM-bound (SURVEY 8d config 4)"}}
     # the step after detect/describe: brute-force 2-NN matching of the frame's descriptors against themselves
     bfm = cuda.createBFMatcher()
-    bfm.knnMatch(desc, desc, k=2)
+    bfm.knnMatchDevice(desc, desc, k=2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
-        bfm.knnMatch(desc, desc, k=2)
+        bfm.knnMatchDevice(desc, desc, k=2)
     torch.cuda.synchronize()
     elm = (time.perf_counter() - t0) / 3
     out["bf_knn2_match_ms"] = 1e3 * elm

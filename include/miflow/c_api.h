@@ -292,13 +292,16 @@ MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/
 
 /* ================================== brute-force descriptor matcher for SURF output (first part) ===== */
 
-/* cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L2) for CV_32F descriptors of up to 128 elements (SURF: 64 / 128),
- * cudafeatures2d/src/brute_force_matcher.cpp + cuda/bf_match.cu:92-183,559-587, cuda/bf_knnmatch.cu (k = 2).
- * Distance = sqrtf of the k-ascending chain sum = fma(d, d, sum), d = q[k] - t[k] (the order of loopUnrolledCached, bf_match.cu:
- * 100-121, with nvcc's default mul+add contraction); best = first strict minimum in train order (exact ties: lowest train
- * index, the CPU BFMatcher's rule; the reference's cross-thread reduction prefers the lowest train index modulo 16 first). */
+/* cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L1 | NORM_L2) for CV_32F descriptors of up to 512 elements (SURF: 64 / 128),
+ * cudafeatures2d/src/brute_force_matcher.cpp:296-1070 + cuda/bf_match.cu:92-183,559-587, cuda/bf_knnmatch.cu, cuda/bf_radius_match.cu.
+ * Distance: k-ascending chain over the descriptor elements -- L2: sum = fma(d, d, sum), d = q[k] - t[k], result sqrtf(sum) (the
+ * order of loopUnrolledCached, bf_match.cu:100-121, with nvcc's default mul+add contraction); L1: sum += fabsf(q[k] - t[k]).
+ * Best lists are ordered by (distance, image index, train index): the first strict minimum in scan order, exact ties to the
+ * lowest index (cv::BFMatcher's CPU rule; the reference's cross-thread reductions make its tie order scheduling dependent).
+ * Other depths / NORM_HAMMING (the reference's u8 / u16 / s16 / s32 tables, brute_force_matcher.cpp:336-356) are not built:
+ * MI_ERR_BAD_ARG / MI_ERR_BAD_TYPE. */
 typedef struct mi_bfmatcher mi_bfmatcher;
-enum { MI_NORM_L2 = 4 };                                   /* cv::NORM_L2 */
+enum { MI_NORM_L1 = 2, MI_NORM_L2 = 4 };                   /* cv::NORM_L1, cv::NORM_L2 */
 MI_API int mi_bf_create(int norm_type, mi_bfmatcher **out);
 MI_API void mi_bf_destroy(mi_bfmatcher *h);
 /* matchSingle: query n_q x D, train n_t x D (MI_32FC1), mask NULL or MI_8UC1 n_q x n_t (non-zero = allowed);
@@ -308,6 +311,21 @@ MI_API int mi_bf_match(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train
 /* knnMatch with k = 2 (bf_knnmatch.cu match2): train_idx MI_32SC2 1 x n_q, distance MI_32FC2 1 x n_q. */
 MI_API int mi_bf_knn_match2(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train, const mi_mat *mask, mi_mat *train_idx,
                             mi_mat *distance, void *stream);
+/* knnMatchAsync for any k >= 1 over a collection of n_trains train sets (brute_force_matcher.cpp:574-725; n_trains = 1 is the
+ * (query, train) form).  trains: n_trains mi_mat, MI_32FC1 n_t[m] x D; masks: NULL, or n_trains mi_mat each with data == NULL
+ * (none) or MI_8UC1 n_q x n_t[m].  train_idx / img_idx MI_32SC1 n_q x k, distance MI_32FC1 n_q x k (img_idx may be NULL);
+ * entries past the number of candidates: -1 / -1 / FLT_MAX.  The reference's distance matrix + k extraction rounds (k != 2) and
+ * its per-image host merge (:512-571) are replaced by per-lane sorted lists; the result is the same list. */
+MI_API int mi_bf_knn_match(mi_bfmatcher *h, const mi_mat *query, const mi_mat *trains, const mi_mat *masks, int n_trains, int k,
+                           mi_mat *train_idx, mi_mat *img_idx, mi_mat *distance, void *stream);
+/* radiusMatchAsync (brute_force_matcher.cpp:841-980, bf_radius_match.cu:58-118): every train descriptor with mask != 0 and
+ * distance < max_distance.  train_idx / img_idx MI_32SC1 and distance MI_32FC1 are n_q x cols (the reference sizes cols =
+ * max(n_t / 100, n_q), resp. n_q for collections; img_idx may be NULL), n_matches MI_32SC1 1 x n_q counts every hit (it may
+ * exceed cols); the first min(n_matches, cols) entries of a row are the hits in ascending (image, train) order -- the reference
+ * stores them in atomicInc order (scheduling dependent) and sorts on the host; entries past them are left untouched. */
+MI_API int mi_bf_radius_match(mi_bfmatcher *h, const mi_mat *query, const mi_mat *trains, const mi_mat *masks, int n_trains,
+                              float max_distance, mi_mat *train_idx, mi_mat *img_idx, mi_mat *distance, mi_mat *n_matches,
+                              void *stream);
 
 /* ======================================================== dense PyrLK ===== */
 

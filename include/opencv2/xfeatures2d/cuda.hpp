@@ -11,7 +11,10 @@ namespace cv {
 #ifndef MIFLOW_WITH_OPENCV
 struct Point2f { float x = 0, y = 0; };
 struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };
-enum { NORM_L2 = 4 };
+#ifndef MIFLOW_HAVE_NORM_TYPES
+#define MIFLOW_HAVE_NORM_TYPES
+enum NormTypes { NORM_INF = 1, NORM_L1 = 2, NORM_L2 = 4, NORM_HAMMING = 6 };   // opencv2/core/base.hpp
+#endif
 #endif
 
 namespace cuda {

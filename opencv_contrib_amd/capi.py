@@ -182,6 +182,8 @@ def lib():
         "mi_bf_destroy": (None, [vp]),
         "mi_bf_match": (i, [vp, PM, PM, PM, PM, PM, vp]),
         "mi_bf_knn_match2": (i, [vp, PM, PM, PM, PM, PM, vp]),
+        "mi_bf_knn_match": (i, [vp, PM, PM, PM, i, i, PM, PM, PM, vp]),
+        "mi_bf_radius_match": (i, [vp, PM, PM, PM, i, C.c_float, PM, PM, PM, PM, vp]),
         "mi_superres_to_gray8": (i, [PM, PM, vp]),
         "mi_split_flow": (i, [PM, PM, PM, vp]),
     }

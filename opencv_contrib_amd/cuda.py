@@ -383,41 +383,215 @@ def sgm_winner_takes_all(aggregated, width, height, num_disparities, num_paths, 
     return left, right
 
 
-class BFMatcher:
-    """cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L2) for float descriptors (SURF: 64 / 128 elements):
-    match() and knnMatch(k = 2) in the device-matrix form of the reference's matchAsync / knnMatchAsync
-    (cudafeatures2d/src/brute_force_matcher.cpp; kernels cuda/bf_match.cu, cuda/bf_knnmatch.cu)."""
+class DMatch:
+    """cv::DMatch (queryIdx, trainIdx, imgIdx, distance); ordered by distance like the reference's operator<."""
+    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
 
+    def __init__(self, queryIdx=-1, trainIdx=-1, imgIdx=-1, distance=float("inf")):
+        self.queryIdx, self.trainIdx, self.imgIdx, self.distance = int(queryIdx), int(trainIdx), int(imgIdx), float(distance)
+
+    def __lt__(self, other):
+        return self.distance < other.distance
+
+    def __repr__(self):
+        return f"DMatch(queryIdx={self.queryIdx}, trainIdx={self.trainIdx}, imgIdx={self.imgIdx}, distance={self.distance:.6g})"
+
+
+class BFMatcher:
+    """cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L1 | NORM_L2) for float descriptors (cudafeatures2d.hpp;
+    cudafeatures2d/src/brute_force_matcher.cpp:143-1070; kernels cuda/bf_match.cu, bf_knnmatch.cu, bf_radius_match.cu).
+
+    Three forms of every query, like the reference: `match / knnMatch / radiusMatch` return DMatch lists (host),
+    `*Async` return the reference's packed device matrix and `*Convert` unpack it; `*Device` return the separate device tensors
+    the C-ABI fills (no host transfer).  With `trainDescriptors=None` the collection added with add() is searched."""
+
+    NORM_L1 = 2
     NORM_L2 = 4
 
     def __init__(self, normType=4):
         self._h = C.c_void_p()
         capi.check(capi.lib().mi_bf_create(int(normType), C.byref(self._h)))
+        self._train = []
 
     def __del__(self):
         if getattr(self, "_h", None):
             capi.lib().mi_bf_destroy(self._h)
             self._h = None
 
-    def _run(self, fn, query, train, mask, cn):
+    # ---- train collection (brute_force_matcher.cpp:187-211)
+    def isMaskSupported(self): return True
+    def add(self, descriptors): self._train.extend(descriptors)
+    def getTrainDescriptors(self): return self._train
+    def clear(self): self._train = []
+    def empty(self): return not self._train
+    def train(self): pass
+
+    def _collection(self, train, mask, masks):
+        """-> (trains list, masks list or None, is_collection)"""
+        if train is not None:
+            return [train], ([mask] if mask is not None else None), False
+        if masks is not None and len(masks) and len(masks) != len(self._train):
+            raise capi.MiError(-1, "masks.size() == trainDescCollection.size()")          # makeGpuCollection, :156
+        return list(self._train), (list(masks) if masks else None), True
+
+    @staticmethod
+    def _mats(tensors):
+        arr = (capi.Mat * len(tensors))()
+        for j, t in enumerate(tensors):
+            arr[j] = _m(t) if t is not None and t.numel() else capi.Mat(None, 0, 0, 0, 0)
+        return arr
+
+    # ---- device forms
+    def knnMatchDevice(self, queryDescriptors, trainDescriptors=None, k=2, mask=None, masks=None):
+        """-> (trainIdx (nq, k) int32, imgIdx (nq, k) int32, distance (nq, k) float32); entries past the candidates -1 / -1 / FLT_MAX."""
         import torch
-        nq = query.shape[0]
-        shape = (1, nq) if cn == 1 else (1, nq, 2)
-        idx = torch.empty(shape, dtype=torch.int32, device=query.device)
-        dist = torch.empty(shape, dtype=torch.float32, device=query.device)
-        pm = C.byref(_m(mask)) if mask is not None else None
-        capi.check(fn(self._h, C.byref(_m(query)), C.byref(_m(train)), pm, C.byref(_m(idx)), C.byref(_m(dist)), capi.current_stream_ptr()))
-        return idx[0], dist[0]
+        trains, ms, _ = self._collection(trainDescriptors, mask, masks)
+        q = queryDescriptors
+        if q.numel() == 0 or not trains:
+            e = torch.empty((0, k), dtype=torch.int32, device=q.device)
+            return e, e.clone(), torch.empty((0, k), dtype=torch.float32, device=q.device)
+        nq = q.shape[0]
+        idx = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+        img = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+        dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        capi.check(capi.lib().mi_bf_knn_match(self._h, C.byref(_m(q)), self._mats(trains), self._mats(ms) if ms else None, len(trains), int(k),
+                                              C.byref(_m(idx)), C.byref(_m(img)), C.byref(_m(dist)), capi.current_stream_ptr()))
+        return idx, img, dist
 
-    def match(self, queryDescriptors, trainDescriptors, mask=None):
-        """-> (trainIdx (nq,) int32, distance (nq,) float32); -1 / FLT_MAX where the mask leaves no candidate."""
-        return self._run(capi.lib().mi_bf_match, queryDescriptors, trainDescriptors, mask, 1)
+    def matchDevice(self, queryDescriptors, trainDescriptors=None, mask=None, masks=None):
+        """-> (trainIdx (nq,), imgIdx (nq,), distance (nq,))"""
+        idx, img, dist = self.knnMatchDevice(queryDescriptors, trainDescriptors, 1, mask, masks)
+        return idx[:, 0], img[:, 0], dist[:, 0]
 
-    def knnMatch(self, queryDescriptors, trainDescriptors, k=2, mask=None):
-        """k = 2 only (the ratio-test form): -> (trainIdx (nq, 2), distance (nq, 2))."""
-        if k != 2:
-            raise capi.MiError(-1, "only k = 2 is built")
-        return self._run(capi.lib().mi_bf_knn_match2, queryDescriptors, trainDescriptors, mask, 2)
+    def radiusMatchDevice(self, queryDescriptors, trainDescriptors=None, maxDistance=0.0, mask=None, masks=None):
+        """-> (trainIdx, imgIdx, distance) (nq, cols) and nMatches (nq,); cols as the reference sizes it (max(nTrain / 100, nQuery),
+        nQuery for a collection: brute_force_matcher.cpp:897,969).  Row q holds its first min(nMatches[q], cols) hits in ascending
+        (image, train) order."""
+        import torch
+        trains, ms, coll = self._collection(trainDescriptors, mask, masks)
+        q = queryDescriptors
+        if q.numel() == 0 or not trains:
+            e = torch.empty((0, 0), dtype=torch.int32, device=q.device)
+            return e, e.clone(), torch.empty((0, 0), dtype=torch.float32, device=q.device), torch.empty((0,), dtype=torch.int32, device=q.device)
+        nq = q.shape[0]
+        cols = nq if coll else max(trains[0].shape[0] // 100, nq)
+        idx = torch.full((nq, cols), -1, dtype=torch.int32, device=q.device)
+        img = torch.full((nq, cols), -1, dtype=torch.int32, device=q.device)
+        dist = torch.zeros((nq, cols), dtype=torch.float32, device=q.device)
+        n = torch.empty((1, nq), dtype=torch.int32, device=q.device)
+        capi.check(capi.lib().mi_bf_radius_match(self._h, C.byref(_m(q)), self._mats(trains), self._mats(ms) if ms else None, len(trains),
+                                                 float(maxDistance), C.byref(_m(idx)), C.byref(_m(img)), C.byref(_m(dist)), C.byref(_m(n)),
+                                                 capi.current_stream_ptr()))
+        return idx, img, dist, n[0]
+
+    # ---- the reference's packed device matrices (matchAsync / knnMatchAsync / radiusMatchAsync)
+    def matchAsync(self, queryDescriptors, trainDescriptors=None, mask=None, masks=None):
+        """CV_32SC1 2 x nq {trainIdx; distance bits} (:367-374), 3 x nq {trainIdx; imgIdx; distance bits} for the collection (:429-437)."""
+        import torch
+        idx, img, dist = self.matchDevice(queryDescriptors, trainDescriptors, mask, masks)
+        rows = [idx, dist.view(torch.int32)] if trainDescriptors is not None else [idx, img, dist.view(torch.int32)]
+        return torch.stack(rows, 0)
+
+    @staticmethod
+    def matchConvert(gpu_matches):
+        """brute_force_matcher.cpp:440-495: unmatched queries (trainIdx -1) are dropped."""
+        import numpy as np
+        g = gpu_matches.cpu().numpy()
+        if g.size == 0:
+            return []
+        assert g.dtype == np.int32 and g.shape[0] in (2, 3)
+        idx, dist = g[0], g[-1].view(np.float32)
+        img = g[1] if g.shape[0] == 3 else np.zeros_like(idx)
+        return [DMatch(q, idx[q], img[q], dist[q]) for q in range(g.shape[1]) if idx[q] != -1]
+
+    def match(self, queryDescriptors, trainDescriptors=None, mask=None, masks=None):
+        return self.matchConvert(self.matchAsync(queryDescriptors, trainDescriptors, mask, masks))
+
+    def knnMatchAsync(self, queryDescriptors, trainDescriptors=None, k=2, mask=None, masks=None):
+        """k = 2: CV_32SC2 2 x nq (3 x nq with imgIdx for the collection); other k (single train set only, like the reference:
+        :662-665): CV_32SC1 2 nq x k, trainIdx rows then distance rows (:634-642)."""
+        import torch
+        if trainDescriptors is None and k != 2:
+            raise capi.MiError(-1, "only k=2 mode is supported for now (knnMatchAsync over the collection); use knnMatch")
+        idx, img, dist = self.knnMatchDevice(queryDescriptors, trainDescriptors, k, mask, masks)
+        bits = dist.view(torch.int32)
+        if k == 2:
+            return torch.stack([idx, bits] if trainDescriptors is not None else [idx, img, bits], 0)
+        return torch.cat([idx, bits], 0)
+
+    @staticmethod
+    def knnMatchConvert(gpu_matches, compactResult=False):
+        """brute_force_matcher.cpp:727-812"""
+        import numpy as np
+        g = gpu_matches.cpu().numpy()
+        if g.size == 0:
+            return []
+        if g.ndim == 3:
+            idx, dist = g[0], g[-1].view(np.float32)
+            img = g[1] if g.shape[0] == 3 else np.zeros_like(idx)
+        else:
+            nq = g.shape[0] // 2
+            idx, dist = g[:nq], g[nq:].view(np.float32)
+            img = np.zeros_like(idx)
+        out = []
+        for q in range(idx.shape[0]):
+            cur = [DMatch(q, idx[q, j], img[q, j], dist[q, j]) for j in range(idx.shape[1]) if idx[q, j] != -1]
+            if cur or not compactResult:
+                out.append(cur)
+        return out
+
+    def knnMatch(self, queryDescriptors, trainDescriptors=None, k=2, mask=None, masks=None, compactResult=False):
+        """The reference merges per-image k-lists on the host for k != 2 over a collection (:512-571); here one device pass."""
+        import numpy as np
+        if trainDescriptors is not None or k == 2:
+            return self.knnMatchConvert(self.knnMatchAsync(queryDescriptors, trainDescriptors, k, mask, masks), compactResult)
+        idx, img, dist = (t.cpu().numpy() for t in self.knnMatchDevice(queryDescriptors, None, k, None, masks))
+        out = []
+        for q in range(idx.shape[0]):
+            cur = [DMatch(q, idx[q, j], img[q, j], dist[q, j]) for j in range(k) if idx[q, j] != -1]
+            if cur or not compactResult:
+                out.append(cur)
+        return out
+
+    def radiusMatchAsync(self, queryDescriptors, trainDescriptors=None, maxDistance=0.0, mask=None, masks=None):
+        """CV_32SC1 (2 nq + 1) x cols {trainIdx rows; distance rows; nMatches} (:897-905); collection: (3 nq + 1) x nq with imgIdx rows
+        (the reference types that one CV_32FC1, :969-975; the bits are the same)."""
+        import torch
+        idx, img, dist, n = self.radiusMatchDevice(queryDescriptors, trainDescriptors, maxDistance, mask, masks)
+        if idx.numel() == 0:
+            return idx
+        last = torch.zeros((1, idx.shape[1]), dtype=torch.int32, device=idx.device)
+        last[0, :n.shape[0]] = n
+        parts = [idx, dist.view(torch.int32), last] if trainDescriptors is not None else [idx, img, dist.view(torch.int32), last]
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def radiusMatchConvert(gpu_matches, compactResult=False, collection=False):
+        """brute_force_matcher.cpp:982-1063: min(nMatches, cols) entries per query, sorted by distance (stable here: ties keep the
+        ascending (image, train) order)."""
+        import numpy as np
+        g = gpu_matches.cpu().numpy()
+        if g.size == 0:
+            return []
+        per = 3 if collection else 2
+        nq = (g.shape[0] - 1) // per
+        idx, dist, n = g[:nq], g[(per - 1) * nq:per * nq].view(np.float32), g[per * nq]
+        img = g[nq:2 * nq] if collection else np.zeros_like(idx)
+        out = []
+        for q in range(nq):
+            m = min(int(n[q]), g.shape[1])
+            if m == 0:
+                if not compactResult:
+                    out.append([])
+                continue
+            cur = [DMatch(q, idx[q, j], img[q, j], dist[q, j]) for j in range(m)]
+            cur.sort(key=lambda d: d.distance)
+            out.append(cur)
+        return out
+
+    def radiusMatch(self, queryDescriptors, trainDescriptors=None, maxDistance=0.0, mask=None, masks=None, compactResult=False):
+        g = self.radiusMatchAsync(queryDescriptors, trainDescriptors, maxDistance, mask, masks)
+        return self.radiusMatchConvert(g, compactResult, collection=trainDescriptors is None)
 
 
 def createBFMatcher(normType=4) -> BFMatcher:

@@ -1,40 +1,104 @@
-/* CPU restatement of the brute-force L2 descriptor matcher -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+/* CPU restatement of the brute-force descriptor matcher (float descriptors, L1 / L2) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * Follows modules/cudafeatures2d/src/cuda/bf_match.cu:92-136 (loopUnrolledCached: for every (query, train) pair the distance is
- * accumulated over k ascending, descriptors zero-padded to 64 / 128 elements; L2Dist of the main repository's
- * opencv2/core/cuda/vec_distance.hpp -- un-vendored, restated: reduceIter: reg = a - b; sum += reg * reg (one fma under nvcc's
- * default contraction); result sqrtf(sum)), the strict-< best update in ascending train order (:127-133) and
- * cuda/bf_knnmatch.cu's two-best update for k = 2.  Exact ties go to the lowest train index (cv::BFMatcher's CPU rule; the
- * reference's cross-thread reduction prefers the lowest index modulo 16 first).  parity unpinned (no fixture in the reference's
- * tests: test_features2d.cpp generates random descriptors at run time).
+ * accumulated over k ascending, descriptors zero-padded; L1Dist / L2Dist of the main repository's
+ * opencv2/core/cuda/vec_distance.hpp -- un-vendored, restated: L1 reduceIter: sum += fabs(a - b); L2: reg = a - b;
+ * sum += reg * reg (one fma under nvcc's default contraction), result sqrtf(sum)), the strict-< best update in ascending train
+ * order (:127-133), cuda/bf_knnmatch.cu's two-best update for k = 2 (:61-102, 353-371) and, for any other k, its distance
+ * matrix + k rounds of minimum extraction (:918-1110: masked pairs become FLT_MAX, a round that finds no value < FLT_MAX writes
+ * nothing, so short lists end in trainIdx -1), cuda/bf_radius_match.cu:58-118 (mask && dist < maxDistance; count every hit,
+ * store the first `cols`) and src/brute_force_matcher.cpp:296-1070 for the collection forms (images scanned in order).
+ * Exact ties go to the lowest (image, train) index -- cv::BFMatcher's CPU rule; the reference's cross-thread reductions /
+ * atomicInc make the tie order and the stored subset of an overflowing radius list scheduling dependent, and this is one of
+ * its possible outcomes.
+ * Pinned on the reference's own known-answer test: tests/test_bfmatch.py restates the generator of
+ * cudafeatures2d/test/test_features2d.cpp:274-330 and asserts the expectations of its Match / KnnMatch_2 / KnnMatch_3 /
+ * RadiusMatch cases (single image and collection) on this oracle.
  */
 #include <float.h>
 #include <math.h>
 #include <stddef.h>
 
+enum { ORC_NORM_L1 = 2, ORC_NORM_L2 = 4 };   /* cv::NormTypes */
+
+static float bf_distance(const float *qr, const float *tr, int d, int norm)
+{
+    float sum = 0.f;
+    if (norm == ORC_NORM_L1) {
+        for (int k = 0; k < d; ++k) sum += fabsf(qr[k] - tr[k]);
+        return sum;
+    }
+    for (int k = 0; k < d; ++k) {
+        const float reg = qr[k] - tr[k];
+        sum = fmaf(reg, reg, sum);
+    }
+    return sqrtf(sum);
+}
+
+/* k nearest train descriptors of every query over a collection of n_img train sets (n_img = 1: plain match / knnMatch).
+ * trains[m]: nts[m] x d dense rows; masks NULL, or masks[m] NULL / nq x nts[m] bytes.
+ * idx / img / dist: nq x k; missing entries: idx = img = -1, dist = FLT_MAX.  img may be NULL. */
+int orc_bf_knn(const float *query, int nq, const float *const *trains, const int *nts, const unsigned char *const *masks, int n_img,
+               int d, int norm, int k, int *idx, int *img, float *dist)
+{
+    if (nq <= 0 || n_img <= 0 || d <= 0 || k <= 0 || (norm != ORC_NORM_L1 && norm != ORC_NORM_L2)) return -1;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nq; ++q) {
+        int *bi = idx + (size_t)q * k;
+        float *bd = dist + (size_t)q * k;
+        int *bm = img ? img + (size_t)q * k : NULL;
+        for (int j = 0; j < k; ++j) { bi[j] = -1; bd[j] = FLT_MAX; if (bm) bm[j] = -1; }
+        const float *qr = query + (size_t)q * d;
+        for (int m = 0; m < n_img; ++m) {
+            const unsigned char *mk = masks ? masks[m] : NULL;
+            for (int t = 0; t < nts[m]; ++t) {
+                if (mk && !mk[(size_t)q * nts[m] + t]) continue;
+                const float dv = bf_distance(qr, trains[m] + (size_t)t * d, d, norm);
+                /* strict < against the current list, scanned in ascending (image, train) order: "if (d < best1) {...} else if
+                 * (d < best2) {...}" generalised to k entries */
+                int pos = k;
+                while (pos > 0 && dv < bd[pos - 1]) --pos;
+                if (pos == k) continue;
+                for (int j = k - 1; j > pos; --j) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; if (bm) bm[j] = bm[j - 1]; }
+                bd[pos] = dv; bi[pos] = t; if (bm) bm[pos] = m;
+            }
+        }
+    }
+    return 0;
+}
+
 /* query nq x d, train nt x d (dense rows); mask NULL or nq x nt bytes.  idx/dist: nq x 2 ({best, second}). */
 int orc_bf_knn2(const float *query, int nq, const float *train, int nt, int d, const unsigned char *mask, int *idx, float *dist)
 {
-    if (nq <= 0 || nt <= 0 || d <= 0 || d > 128) return -1;
+    if (nt <= 0 || d > 128) return -1;
+    return orc_bf_knn(query, nq, &train, &nt, mask ? &mask : NULL, 1, d, ORC_NORM_L2, 2, idx, NULL, dist);
+}
+
+/* All train descriptors closer than max_dist, in ascending (image, train) order; n[q] counts every hit, the first `cols` are stored
+ * (idx / img / dist: nq x cols, entries past min(n[q], cols) are left untouched). */
+int orc_bf_radius(const float *query, int nq, const float *const *trains, const int *nts, const unsigned char *const *masks, int n_img,
+                  int d, int norm, float max_dist, int cols, int *idx, int *img, float *dist, int *n)
+{
+    if (nq <= 0 || n_img <= 0 || d <= 0 || cols <= 0 || (norm != ORC_NORM_L1 && norm != ORC_NORM_L2)) return -1;
 #pragma omp parallel for schedule(static)
     for (int q = 0; q < nq; ++q) {
-        float b1 = FLT_MAX, b2 = FLT_MAX;
-        int i1 = -1, i2 = -1;
         const float *qr = query + (size_t)q * d;
-        for (int t = 0; t < nt; ++t) {
-            if (mask && !mask[(size_t)q * nt + t]) continue;
-            const float *tr = train + (size_t)t * d;
-            float sum = 0.f;
-            for (int k = 0; k < d; ++k) {
-                const float reg = qr[k] - tr[k];
-                sum = fmaf(reg, reg, sum);
+        int cnt = 0;
+        for (int m = 0; m < n_img; ++m) {
+            const unsigned char *mk = masks ? masks[m] : NULL;
+            for (int t = 0; t < nts[m]; ++t) {
+                if (mk && !mk[(size_t)q * nts[m] + t]) continue;
+                const float dv = bf_distance(qr, trains[m] + (size_t)t * d, d, norm);
+                if (!(dv < max_dist)) continue;
+                if (cnt < cols) {
+                    idx[(size_t)q * cols + cnt] = t;
+                    dist[(size_t)q * cols + cnt] = dv;
+                    if (img) img[(size_t)q * cols + cnt] = m;
+                }
+                ++cnt;
             }
-            const float dv = sqrtf(sum);
-            if (dv < b1) { b2 = b1; i2 = i1; b1 = dv; i1 = t; }
-            else if (dv < b2) { b2 = dv; i2 = t; }
         }
-        idx[2 * q] = i1; idx[2 * q + 1] = i2;
-        dist[2 * q] = b1; dist[2 * q + 1] = b2;
+        n[q] = cnt;
     }
     return 0;
 }

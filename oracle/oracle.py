@@ -600,6 +600,65 @@ def bf_knn_match2(query, train, mask=None):
     return idx, dist
 
 
+NORM_L1, NORM_L2 = 2, 4   # cv::NormTypes
+
+
+def _bf_collection(query, trains, masks):
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    single = isinstance(trains, np.ndarray)
+    ts = [np.ascontiguousarray(t, dtype=np.float32) for t in ([trains] if single else trains)]
+    if q.ndim != 2 or not ts or any(t.ndim != 2 or t.shape[1] != q.shape[1] for t in ts):
+        raise ValueError("query.cols == train.cols")
+    if masks is None:
+        ms = None
+    else:
+        ms = [None if m is None else np.ascontiguousarray(m, dtype=np.uint8) for m in ([masks] if single else masks)]
+        if len(ms) != len(ts) or any(m is not None and m.shape != (q.shape[0], t.shape[0]) for m, t in zip(ms, ts)):
+            raise ValueError("masks must be query.rows x train.rows, one per train image")
+    n = len(ts)
+    tp = (C.c_void_p * n)(*[t.ctypes.data for t in ts])
+    nts = (C.c_int * n)(*[t.shape[0] for t in ts])
+    mp = None if ms is None else (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in ms])
+    return q, ts, ms, n, tp, nts, mp
+
+
+def bf_knn_match(query, trains, k, norm=NORM_L2, masks=None):
+    """trains: one (nt, d) array or a list of them (collection).  -> (train_idx, img_idx, distance), each (nq, k); missing
+    entries are (-1, -1, FLT_MAX)."""
+    q, ts, ms, n, tp, nts, mp = _bf_collection(query, trains, masks)
+    idx = np.empty((q.shape[0], k), np.int32)
+    img = np.empty((q.shape[0], k), np.int32)
+    dist = np.empty((q.shape[0], k), np.float32)
+    L = lib()
+    L.orc_bf_knn.restype = C.c_int
+    L.orc_bf_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_bf_knn(q.ctypes.data, q.shape[0], tp, nts, mp, n, q.shape[1], norm, k, idx.ctypes.data, img.ctypes.data,
+                      dist.ctypes.data)
+    if rc:
+        raise ValueError(f"orc_bf_knn failed: {rc}")
+    return idx, img, dist
+
+
+def bf_radius_match(query, trains, max_distance, cols, norm=NORM_L2, masks=None):
+    """-> (train_idx, img_idx, distance) each (nq, cols) (entries past min(n, cols) are -1 / -1 / 0) and n (nq,), the number of
+    train descriptors closer than max_distance; stored in ascending (image, train) order."""
+    q, ts, ms, n, tp, nts, mp = _bf_collection(query, trains, masks)
+    idx = np.full((q.shape[0], cols), -1, np.int32)
+    img = np.full((q.shape[0], cols), -1, np.int32)
+    dist = np.zeros((q.shape[0], cols), np.float32)
+    cnt = np.zeros(q.shape[0], np.int32)
+    L = lib()
+    L.orc_bf_radius.restype = C.c_int
+    L.orc_bf_radius.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_bf_radius(q.ctypes.data, q.shape[0], tp, nts, mp, n, q.shape[1], norm, max_distance, cols, idx.ctypes.data,
+                         img.ctypes.data, dist.ctypes.data, cnt.ctypes.data)
+    if rc:
+        raise ValueError(f"orc_bf_radius failed: {rc}")
+    return idx, img, dist, cnt
+
+
 # ------------------------------------------------------------------ StereoSGM (SURVEY 8f N3)
 class SGMParams(C.Structure):
     _fields_ = [("min_disparity", C.c_int), ("num_disparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),

@@ -2,6 +2,7 @@
 // the reference writes it (cudaoptflow/samples/optical_flow.cpp:184-185, cudastereo/test/test_stereo.cpp:76-80).
 // Usage: shim_smoke <in.bin> <out.bin>   (in: int32 h, w; u8 I0[h*w], I1[h*w]; out: f32 flow[h*w*2], u8 disp[h*w])
 // Without a GPU it must fail with cv::Exception (no CPU fallback) and return 3.
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 #include "opencv2/cudaoptflow.hpp"
@@ -100,6 +101,32 @@ int main(int argc, char **argv)
             std::vector<std::vector<DMatch> > knn;
             bf->knnMatch(ddesc, ddesc, knn, 2);
             if ((int)knn.size() != nk || (nk > 1 && knn[0].size() != 2)) return 9;
+            // any k, NORM_L1, radius and the train collection (add() twice, like the reference's *_Collection tests)
+            Ptr<cuda::DescriptorMatcher> b1 = cuda::DescriptorMatcher::createBFMatcher(NORM_L1);
+            b1->knnMatch(ddesc, ddesc, knn, 3);
+            if ((int)knn.size() != nk || (int)knn[0].size() != std::min(3, nk) || knn[0][0].trainIdx != 0 || knn[0][0].distance != 0.f) return 10;
+            for (size_t j = 1; j < knn[0].size(); ++j) if (knn[0][j].distance < knn[0][j - 1].distance) return 10;
+            const int h0 = nk / 2;
+            if (h0 > 0) {
+                bf->add(std::vector<cuda::GpuMat>(1, ddesc(Rect(0, 0, 64, h0))));
+                bf->add(std::vector<cuda::GpuMat>(1, ddesc(Rect(0, h0, 64, nk - h0))));
+                if (bf->empty() || bf->getTrainDescriptors().size() != 2) return 10;
+                bf->match(ddesc, mm);
+                if ((int)mm.size() != nk) return 10;
+                for (int k = 0; k < nk; ++k)
+                    if (mm[k].distance != 0.f || mm[k].imgIdx != (k < h0 ? 0 : 1) || mm[k].trainIdx != (k < h0 ? k : k - h0)) return 10;
+                bf->knnMatch(ddesc, knn, 3);
+                if ((int)knn.size() != nk || knn[nk - 1][0].imgIdx != 1 || knn[nk - 1][0].trainIdx != nk - 1 - h0) return 10;
+                std::vector<std::vector<DMatch> > rad;
+                bf->radiusMatch(ddesc, rad, 1e-6f);            // only the descriptor itself (and exact duplicates) is that close
+                if ((int)rad.size() != nk || rad[0].empty() || rad[0][0].distance != 0.f) return 10;
+                bf->clear();
+                if (!bf->empty()) return 10;
+            }
+            std::vector<std::vector<DMatch> > rad;
+            bf->radiusMatch(ddesc, ddesc, rad, 10.f);          // unit-norm descriptors: everything is within 10
+            if ((int)rad.size() != nk || (int)rad[0].size() != nk || rad[0][0].trainIdx != 0) return 10;
+            for (size_t j = 1; j < rad[0].size(); ++j) if (rad[0][j].distance < rad[0][j - 1].distance) return 10;
         }
         Ptr<cuda::DensePyrLKOpticalFlow> lk = cuda::DensePyrLKOpticalFlow::create();
         if (lk->getWinSize().width != 13 || lk->getMaxLevel() != 3 || lk->getNumIters() != 30 ||

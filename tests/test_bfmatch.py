@@ -1,5 +1,11 @@
-"""Brute-force L2 matcher for SURF descriptors (first part): HIP vs the CPU restatement, bit-exact distances
-(same fma chain order) and identical indices."""
+"""Brute-force matcher for float descriptors: NORM_L1 / NORM_L2, match / knnMatch (any k) / radiusMatch, single
+train set and collections.
+
+* The oracle (oracle/bfmatch_ref.c) is PINNED on the reference's own known-answer test: `_reference_case` restates the generator
+  and every expectation of cudafeatures2d/test/test_features2d.cpp:274-751 (BruteForceMatcher: Match_Single / _Collection,
+  KnnMatch_2 / _3 _Single / _Collection, RadiusMatch_Single / _Collection over NORM_L1 / NORM_L2, 7 descriptor sizes, mask on/off)
+  and runs it on the oracle (CPU) and on the HIP matcher (GPU).
+* HIP vs oracle: bit-exact distances (same accumulation chain) and identical indices."""
 import os
 import sys
 
@@ -9,13 +15,178 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+NORM_L1, NORM_L2 = 2, 4
+FLT_MAX = np.finfo(np.float32).max
+REF_DIMS = [57, 64, 83, 128, 179, 256, 304]            # test_features2d.cpp:756
+
 
 def _desc(rng, n, d):
     x = rng.standard_normal((n, d)).astype(np.float32)
     return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)     # unit norm like SURF descriptors
 
 
+# ------------------------------------------------------------------ the reference's test, restated
+def _reference_data(dim, seed, query_count=300, count_factor=4):
+    """test_features2d.cpp:284-329: integer-valued queries in {0, 1, 2}; every query is copied count_factor times into the train
+    set and one element of copy c is raised by a value in [c / count_factor, (c + 1) / count_factor)."""
+    rng = np.random.default_rng(seed)
+    query = rng.integers(0, 3, (query_count, dim)).astype(np.float32)
+    train = np.repeat(query, count_factor, axis=0)
+    step = 1.0 / count_factor
+    for q in range(query_count):
+        for c in range(count_factor):
+            train[q * count_factor + c, rng.integers(dim)] += np.float32(rng.uniform(step * c, step * (c + 1)))
+    return query, train
+
+
+class _OracleMatcher:
+    """The oracle behind the DescriptorMatcher interface (DMatch tuples (queryIdx, trainIdx, imgIdx, distance))."""
+
+    def __init__(self, O, norm):
+        self.O, self.norm, self.coll = O, norm, []
+
+    def add(self, descs):
+        self.coll.extend(descs)
+
+    def _lists(self, idx, img, dist, n=None):
+        out = []
+        for q in range(idx.shape[0]):
+            m = idx.shape[1] if n is None else min(int(n[q]), idx.shape[1])
+            cur = [(q, int(idx[q, j]), int(img[q, j]), float(dist[q, j])) for j in range(m) if idx[q, j] != -1]
+            if n is not None:
+                cur.sort(key=lambda t: t[3])
+            out.append(cur)
+        return out
+
+    def knnMatch(self, query, train=None, k=2, mask=None, masks=None):
+        idx, img, dist = self.O.bf_knn_match(query, train if train is not None else self.coll, k, self.norm,
+                                             mask if train is not None else masks)
+        return self._lists(idx, img, dist)
+
+    def match(self, query, train=None, mask=None, masks=None):
+        return [m[0] for m in self.knnMatch(query, train, 1, mask, masks) if m]
+
+    def radiusMatch(self, query, train=None, maxDistance=0.0, mask=None, masks=None):
+        trains = train if train is not None else self.coll
+        cols = max(train.shape[0] // 100, query.shape[0]) if train is not None else query.shape[0]
+        idx, img, dist, n = self.O.bf_radius_match(query, trains, maxDistance, cols, self.norm, mask if train is not None else masks)
+        return self._lists(idx, img, dist, n)
+
+
+class _HipMatcher:
+    """opencv_contrib_amd.cuda.BFMatcher behind the same tuple interface (host numpy in, DMatch tuples out)."""
+
+    def __init__(self, gpu, norm, matcher=None):
+        from opencv_contrib_amd import cuda
+        self.m, self.gpu = matcher if matcher is not None else cuda.createBFMatcher(norm), gpu
+
+    def _t(self, a):
+        import torch
+        return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(self.gpu)
+
+    def add(self, descs):
+        self.m.add([self._t(d) for d in descs])
+
+    @staticmethod
+    def _tup(ms):
+        return [[(d.queryIdx, d.trainIdx, d.imgIdx, d.distance) for d in row] for row in ms]
+
+    def knnMatch(self, query, train=None, k=2, mask=None, masks=None):
+        return self._tup(self.m.knnMatch(self._t(query), self._t(train), k, self._t(mask), None if masks is None else [self._t(x) for x in masks]))
+
+    def match(self, query, train=None, mask=None, masks=None):
+        return self._tup([self.m.match(self._t(query), self._t(train), self._t(mask), None if masks is None else [self._t(x) for x in masks])])[0]
+
+    def radiusMatch(self, query, train=None, maxDistance=0.0, mask=None, masks=None):
+        return self._tup(self.m.radiusMatch(self._t(query), self._t(train), maxDistance, self._t(mask),
+                                            None if masks is None else [self._t(x) for x in masks]))
+
+
+def _reference_case(make, dim, use_mask, seed):
+    """Every BruteForceMatcher case of test_features2d.cpp on one (norm, dim, mask) parameter set; `make()` -> a fresh matcher."""
+    QC, CF = 300, 4
+    query, train = _reference_data(dim, seed, QC, CF)
+    full = np.ones((QC, train.shape[0]), np.uint8) if use_mask else None
+    # Match_Single (:334-360)
+    ms = make().match(query, train, mask=full)
+    assert [(m[0], m[1], m[2]) for m in ms] == [(i, i * CF, 0) for i in range(QC)]
+    # KnnMatch_2_Single / KnnMatch_3_Single (:417-495)
+    for knn in (2, 3):
+        ms = make().knnMatch(query, train, k=knn, mask=full)
+        assert [[(m[0], m[1], m[2]) for m in row] for row in ms] == [[(i, i * CF + k, 0) for k in range(knn)] for i in range(QC)]
+    # RadiusMatch_Single (:623-671): radius 1 / countFactor admits only copy 0
+    ms = make().radiusMatch(query, train, maxDistance=1.0 / CF, mask=full)
+    assert [[(m[0], m[1], m[2]) for m in row] for row in ms] == [[(i, i * CF, 0)] for i in range(QC)]
+    # the collection cases: add() twice, masks make the first nearest match illegal (:362-415, 497-621, 673-751)
+    half = train.shape[0] // 2
+    masks = None
+    if use_mask:
+        mk = np.ones((QC, half), np.uint8)
+        mk[:, np.arange(QC // 2) * CF] = 0
+        masks = [mk, mk.copy()]
+    shift = 1 if use_mask else 0
+
+    def coll():
+        m = make()
+        m.add([train[:half]])
+        m.add([train[half:]])
+        return m
+
+    def expect(i, k):
+        return (i, i * CF + k + shift, 0) if i < QC // 2 else (i, (i - QC // 2) * CF + k + shift, 1)
+
+    ms = coll().match(query, masks=masks)
+    assert [(m[0], m[1], m[2]) for m in ms] == [expect(i, 0) for i in range(QC)]
+    for knn in (2, 3):
+        ms = coll().knnMatch(query, k=knn, masks=masks)
+        assert [[(m[0], m[1], m[2]) for m in row] for row in ms] == [[expect(i, k) for k in range(knn)] for i in range(QC)]
+    n = 3
+    ms = coll().radiusMatch(query, maxDistance=1.0 / CF * n, masks=masks)
+    need = n - 1 if use_mask else n
+    assert [[(m[0], m[1], m[2]) for m in row] for row in ms] == [[expect(i, k) for k in range(need)] for i in range(QC)]
+
+
 # ------------------------------------------------------------------ oracle (CPU)
+@pytest.mark.parametrize("norm", [NORM_L1, NORM_L2])
+@pytest.mark.parametrize("dim", REF_DIMS)
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_oracle_passes_the_reference_test(oracle, norm, dim, use_mask):
+    _reference_case(lambda: _OracleMatcher(oracle, norm), dim, use_mask, seed=dim * 4 + norm + use_mask)
+
+
+def _oracle_backed_mirror(oracle, norm):
+    """cuda.BFMatcher with the two C-ABI calls replaced by the oracle on CPU tensors: exercises the collection bookkeeping, the
+    packed *Async matrices and the *Convert unpackers of the Python mirror without a GPU."""
+    import torch
+    from opencv_contrib_amd import cuda
+
+    class M(cuda.BFMatcher):
+        def __init__(self):
+            self._h, self._train = None, []
+
+        def knnMatchDevice(self, q, train=None, k=2, mask=None, masks=None):
+            trains, ms, _ = self._collection(train, mask, masks)
+            if q.numel() == 0 or not trains:
+                return torch.empty((0, k), dtype=torch.int32), torch.empty((0, k), dtype=torch.int32), torch.empty((0, k))
+            r = oracle.bf_knn_match(q.numpy(), [t.numpy() for t in trains], k, norm,
+                                    None if ms is None else [None if x is None else x.numpy() for x in ms])
+            return tuple(torch.from_numpy(a) for a in r)
+
+        def radiusMatchDevice(self, q, train=None, maxDistance=0.0, mask=None, masks=None):
+            trains, ms, coll = self._collection(train, mask, masks)
+            cols = q.shape[0] if coll else max(trains[0].shape[0] // 100, q.shape[0])
+            r = oracle.bf_radius_match(q.numpy(), [t.numpy() for t in trains], maxDistance, cols, norm,
+                                       None if ms is None else [None if x is None else x.numpy() for x in ms])
+            return tuple(torch.from_numpy(a) for a in r)
+
+    return M()
+
+
+@pytest.mark.parametrize("norm,dim,use_mask", [(NORM_L2, 64, False), (NORM_L1, 83, True)])
+def test_python_mirror_host_logic_on_the_reference_test(oracle, norm, dim, use_mask):
+    _reference_case(lambda: _HipMatcher("cpu", norm, _oracle_backed_mirror(oracle, norm)), dim, use_mask, seed=7)
+
+
 def test_oracle_against_numpy_and_tie_rule(oracle):
     rng = np.random.default_rng(0)
     q, t = _desc(rng, 37, 64), _desc(rng, 91, 64)
@@ -24,11 +195,20 @@ def test_oracle_against_numpy_and_tie_rule(oracle):
     order = np.argsort(d, axis=1, kind="stable")
     np.testing.assert_array_equal(idx, order[:, :2])
     np.testing.assert_allclose(dist, np.take_along_axis(d, order[:, :2], 1), rtol=1e-6)
+    # any k, L1
+    i5, _, d5 = oracle.bf_knn_match(q, t, 5, NORM_L1)
+    d1 = np.abs(q[:, None, :].astype(np.float64) - t[None].astype(np.float64)).sum(-1)
+    o1 = np.argsort(d1, axis=1, kind="stable")
+    np.testing.assert_array_equal(i5, o1[:, :5])
+    np.testing.assert_allclose(d5, np.take_along_axis(d1, o1[:, :5], 1), rtol=1e-6)
     # exact ties: the lowest train index wins, the duplicate becomes the second best
     t2 = np.concatenate([t[:5], t[:5], t[5:]])
     idx2, dist2 = oracle.bf_knn_match2(t[:5], t2)
     np.testing.assert_array_equal(idx2, np.stack([np.arange(5), np.arange(5) + 5], 1))
     assert (dist2 == 0).all()
+    # k larger than the train set: the tail is (-1, -1, FLT_MAX)
+    i9, m9, d9 = oracle.bf_knn_match(q[:3], t[:4], 9)
+    assert (i9[:, 4:] == -1).all() and (m9[:, 4:] == -1).all() and (d9[:, 4:] == FLT_MAX).all() and (i9[:, :4] >= 0).all()
 
 
 def test_oracle_mask_and_no_candidate(oracle):
@@ -36,33 +216,121 @@ def test_oracle_mask_and_no_candidate(oracle):
     q, t = _desc(rng, 4, 64), _desc(rng, 6, 64)
     mask = np.ones((4, 6), np.uint8); mask[0] = 0; mask[1, 1:] = 0
     idx, dist = oracle.bf_knn_match2(q, t, mask)
-    assert idx[0].tolist() == [-1, -1] and (dist[0] == np.finfo(np.float32).max).all()      # bf_match.cu:150-151 initial values
+    assert idx[0].tolist() == [-1, -1] and (dist[0] == FLT_MAX).all()      # bf_match.cu:150-151 initial values
     assert idx[1].tolist() == [0, -1]
+
+
+def test_oracle_radius_counts_every_hit_and_keeps_the_first(oracle):
+    rng = np.random.default_rng(2)
+    q, t = _desc(rng, 5, 32), _desc(rng, 200, 32)
+    ki, _, kd = oracle.bf_knn_match(q, t, 200)                      # the oracle's own distances, as a dense matrix
+    dall = np.empty((5, 200), np.float32)
+    np.put_along_axis(dall, ki, kd, 1)
+    idx, img, dist, n = oracle.bf_radius_match(q, t, 1.4, 7)
+    for i in range(5):
+        hits = np.nonzero(dall[i] < np.float32(1.4))[0]
+        assert n[i] == len(hits) and n[i] > 7                       # counts every hit, stores the first 7 in train order
+        np.testing.assert_array_equal(idx[i], hits[:7])
+        np.testing.assert_array_equal(dist[i], dall[i, hits[:7]])
+        assert (img[i] == 0).all()
+    # a collection concatenates the images; masked pairs never count
+    mk = np.ones((5, 200), np.uint8); mk[:, ::2] = 0
+    idx2, img2, _, n2 = oracle.bf_radius_match(q, [t[:120], t[120:]], 1.4, 200, masks=[None, mk[:, 120:]])
+    for i in range(5):
+        hits = [h for h in np.nonzero(dall[i] < np.float32(1.4))[0] if h < 120 or mk[i, h]]
+        assert n2[i] == len(hits)
+        assert [(int(a), int(b)) for a, b in zip(img2[i, :n2[i]], idx2[i, :n2[i]])] == [(int(h >= 120), int(h - 120 * (h >= 120))) for h in hits]
 
 
 # ------------------------------------------------------------------ HIP vs oracle (GPU)
 @pytest.mark.gpu
-@pytest.mark.parametrize("nq,nt,d", [(1, 1, 64), (70, 33, 64), (300, 1000, 64), (257, 519, 128), (64, 200, 17), (129, 40, 100)])
-def test_match_and_knn_bit_exact(gpu, oracle, nq, nt, d):
+@pytest.mark.parametrize("norm", [NORM_L1, NORM_L2])
+@pytest.mark.parametrize("dim", REF_DIMS)
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_hip_passes_the_reference_test(gpu, norm, dim, use_mask):
+    _reference_case(lambda: _HipMatcher(gpu, norm), dim, use_mask, seed=dim * 4 + norm + use_mask)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nt,d", [(1, 1, 64), (70, 33, 64), (300, 1000, 64), (257, 519, 128), (64, 200, 17), (129, 40, 100),
+                                     (100, 333, 200), (65, 90, 304), (40, 70, 512)])
+@pytest.mark.parametrize("norm", [NORM_L2, NORM_L1])
+def test_match_and_knn_bit_exact(gpu, oracle, nq, nt, d, norm):
     import torch
     from opencv_contrib_amd import cuda
     rng = np.random.default_rng(nq * 7 + nt)
     q, t = _desc(rng, nq, d), _desc(rng, nt, d)
     if nt > 4:
         t[3] = t[1]                                  # a duplicate train descriptor: exercises the tie rule
-    m = cuda.createBFMatcher(cuda.BFMatcher.NORM_L2)
+    m = cuda.createBFMatcher(norm)
     tq, tt = torch.from_numpy(q).to(gpu), torch.from_numpy(t).to(gpu)
-    ridx, rdist = oracle.bf_knn_match2(q, t)
-    i1, d1 = m.match(tq, tt)
+    for k in (1, 2, 3, 8, 11, 20):
+        ridx, rimg, rdist = oracle.bf_knn_match(q, t, k, norm)
+        idx, img, dist = m.knnMatchDevice(tq, tt, k=k)
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+        np.testing.assert_array_equal(img.cpu().numpy(), rimg)
+        np.testing.assert_array_equal(dist.cpu().numpy(), rdist)
+    i1, m1, d1 = m.matchDevice(tq, tt)
     np.testing.assert_array_equal(i1.cpu().numpy(), ridx[:, 0])
     np.testing.assert_array_equal(d1.cpu().numpy(), rdist[:, 0])
-    i2, d2 = m.knnMatch(tq, tt, k=2)
-    np.testing.assert_array_equal(i2.cpu().numpy(), ridx)
-    np.testing.assert_array_equal(d2.cpu().numpy(), rdist)
 
 
 @pytest.mark.gpu
-def test_mask_pitched_inputs_and_errors(gpu, oracle):
+@pytest.mark.parametrize("norm", [NORM_L2, NORM_L1])
+def test_collection_radius_and_packed_forms_bit_exact(gpu, oracle, norm):
+    import torch
+    from opencv_contrib_amd import cuda
+    rng = np.random.default_rng(11)
+    q = _desc(rng, 150, 64)
+    trains = [_desc(rng, n, 64) for n in (700, 33, 1, 260)]
+    trains[1][5] = trains[0][9]                       # the same descriptor in two images: the lower image index wins
+    masks = [(rng.random((150, t.shape[0])) < 0.8).astype(np.uint8) for t in trains]
+    masks[2] = None
+    T = lambda a: None if a is None else torch.from_numpy(a).to(gpu)
+    m = cuda.createBFMatcher(norm)
+    m.add([T(t) for t in trains[:2]]); m.add([T(t) for t in trains[2:]])
+    assert not m.empty() and len(m.getTrainDescriptors()) == 4
+    for ms in (None, masks):
+        tm = None if ms is None else [T(x) for x in ms]
+        for k in (1, 2, 5, 13):
+            ridx, rimg, rdist = oracle.bf_knn_match(q, trains, k, norm, ms)
+            idx, img, dist = m.knnMatchDevice(T(q), None, k=k, masks=tm)
+            np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+            np.testing.assert_array_equal(img.cpu().numpy(), rimg)
+            np.testing.assert_array_equal(dist.cpu().numpy(), rdist)
+        radius = 1.33 if norm == NORM_L2 else 8.45
+        ridx, rimg, rdist, rn = oracle.bf_radius_match(q, trains, radius, 150, norm, ms)
+        idx, img, dist, n = m.radiusMatchDevice(T(q), None, radius, masks=tm)
+        np.testing.assert_array_equal(n.cpu().numpy(), rn)
+        assert rn.max() > 150 and rn.min() < 150                       # overflowing and short rows are both covered
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+        np.testing.assert_array_equal(img.cpu().numpy(), rimg)
+        np.testing.assert_array_equal(dist.cpu().numpy(), rdist)
+    # single train set: cols = max(nTrain / 100, nQuery), packed matrices and their converters
+    ridx, _, rdist, rn = oracle.bf_radius_match(q[:5], trains[0], radius, 7, norm)
+    g = m.radiusMatchAsync(T(q[:5]), T(trains[0]), radius)
+    assert tuple(g.shape) == (11, 7)
+    lists = m.radiusMatchConvert(g)
+    for i in range(5):
+        order = np.argsort(rdist[i, :min(rn[i], 7)], kind="stable")
+        assert [d.trainIdx for d in lists[i]] == ridx[i, :min(rn[i], 7)][order].tolist()
+    g2 = m.knnMatchAsync(T(q), T(trains[0]), k=2)
+    assert tuple(g2.shape) == (2, 150, 2) and g2.dtype == torch.int32
+    g3 = m.knnMatchAsync(T(q), T(trains[0]), k=3)
+    assert tuple(g3.shape) == (300, 3)
+    r3 = oracle.bf_knn_match(q, trains[0], 3, norm)
+    assert [[d.trainIdx for d in row] for row in m.knnMatchConvert(g3)] == r3[0].tolist()
+    g1 = m.matchAsync(T(q))
+    assert tuple(g1.shape) == (3, 150)
+    r1 = oracle.bf_knn_match(q, trains, 1, norm)
+    assert [(d.trainIdx, d.imgIdx) for d in m.matchConvert(g1)] == list(zip(r1[0][:, 0].tolist(), r1[1][:, 0].tolist()))
+    m.clear()
+    assert m.empty() and m.match(T(q)) == []
+
+
+@pytest.mark.gpu
+def test_mask_pitched_inputs_legacy_entry_points_and_errors(gpu, oracle):
+    import ctypes as C
     import torch
     from opencv_contrib_amd import capi, cuda
     rng = np.random.default_rng(5)
@@ -70,17 +338,50 @@ def test_mask_pitched_inputs_and_errors(gpu, oracle):
     mask = (rng.random((90, 150)) < 0.3).astype(np.uint8); mask[7] = 0
     m = cuda.createBFMatcher()
     big = torch.zeros((100, 80), device=gpu); big[5:95, 8:72] = torch.from_numpy(q).to(gpu)
-    i2, d2 = m.knnMatch(big[5:95, 8:72], torch.from_numpy(t).to(gpu), k=2, mask=torch.from_numpy(mask).to(gpu))   # pitched query rows
+    tt, tm = torch.from_numpy(t).to(gpu), torch.from_numpy(mask).to(gpu)
+    i2, _, d2 = m.knnMatchDevice(big[5:95, 8:72], tt, k=2, mask=tm)   # pitched query rows
     ridx, rdist = oracle.bf_knn_match2(q, t, mask)
     np.testing.assert_array_equal(i2.cpu().numpy(), ridx)
     np.testing.assert_array_equal(d2.cpu().numpy(), rdist)
     assert i2[7].tolist() == [-1, -1]
+    assert len(m.match(big[5:95, 8:72], tt, mask=tm)) == int((ridx[:, 0] != -1).sum())        # matchConvert drops unmatched queries
+    # the fixed-shape C entry points the C++ shim binds (1 x nq outputs)
+    _m = capi.mat_from_tensor
+    qc = torch.from_numpy(q).to(gpu)
+    i1 = torch.empty((1, 90), dtype=torch.int32, device=gpu); d1 = torch.empty((1, 90), dtype=torch.float32, device=gpu)
+    capi.check(capi.lib().mi_bf_match(m._h, C.byref(_m(qc)), C.byref(_m(tt)), C.byref(_m(tm)), C.byref(_m(i1)), C.byref(_m(d1)), None))
+    ik = torch.empty((1, 90, 2), dtype=torch.int32, device=gpu); dk = torch.empty((1, 90, 2), dtype=torch.float32, device=gpu)
+    capi.check(capi.lib().mi_bf_knn_match2(m._h, C.byref(_m(qc)), C.byref(_m(tt)), C.byref(_m(tm)), C.byref(_m(ik)), C.byref(_m(dk)), None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(i1[0].cpu().numpy(), ridx[:, 0]); np.testing.assert_array_equal(d1[0].cpu().numpy(), rdist[:, 0])
+    np.testing.assert_array_equal(ik[0].cpu().numpy(), ridx); np.testing.assert_array_equal(dk[0].cpu().numpy(), rdist)
     with pytest.raises(capi.MiError):
-        m.match(torch.from_numpy(q).to(gpu), torch.from_numpy(_desc(rng, 10, 32)).to(gpu))     # query.cols != train.cols
+        m.matchDevice(qc, torch.from_numpy(_desc(rng, 10, 32)).to(gpu))                         # query.cols != train.cols
     with pytest.raises(capi.MiError):
-        m.match(torch.zeros((4, 200), device=gpu), torch.zeros((4, 200), device=gpu))           # longer than 128
+        m.matchDevice(torch.zeros((4, 600), device=gpu), torch.zeros((4, 600), device=gpu))     # longer than 512
+    with pytest.raises(capi.MiError):
+        m.knnMatchDevice(qc, tt, k=2, mask=tm[:, :100].contiguous())                            # mask size
+    with pytest.raises(capi.MiError):
+        m.knnMatchAsync(qc, None, k=3)                                                          # reference: only k = 2 over a collection
     with pytest.raises(capi.MiError):
         cuda.createBFMatcher(6)                                                                 # NORM_HAMMING: not built
+
+
+@pytest.mark.gpu
+def test_wave_shared_tiles_agree(gpu, oracle, monkeypatch):
+    """The 4-waves-per-workgroup shape used for long descriptors, forced onto 64 / 128-element ones (MIFLOW_BF_W is read on
+    every call)."""
+    import torch
+    from opencv_contrib_amd import cuda
+    monkeypatch.setenv("MIFLOW_BF_W", "4")
+    rng = np.random.default_rng(3)
+    for d in (64, 128):
+        q = rng.standard_normal((200, d)).astype(np.float32); t = rng.standard_normal((777, d)).astype(np.float32)
+        for norm in (NORM_L2, NORM_L1):
+            for k in (2, 5):
+                r = oracle.bf_knn_match(q, t, k, norm)
+                g = cuda.createBFMatcher(norm).knnMatchDevice(torch.from_numpy(q).to(gpu), torch.from_numpy(t).to(gpu), k=k)
+                np.testing.assert_array_equal(g[0].cpu().numpy(), r[0]); np.testing.assert_array_equal(g[2].cpu().numpy(), r[2])
 
 
 @pytest.mark.gpu
@@ -93,5 +394,5 @@ def test_surf_descriptors_match_themselves_and_a_shifted_view(gpu):
     surf = cuda.SURF_CUDA.create(300, 3, 2, False, 0.05)
     _, desc = surf.detectWithDescriptors(torch.from_numpy(img).to(gpu))
     assert desc.shape[0] > 20
-    idx, dist = cuda.createBFMatcher().match(desc, desc)
+    idx, _, dist = cuda.createBFMatcher().matchDevice(desc, desc)
     assert torch.equal(idx.cpu(), torch.arange(desc.shape[0], dtype=torch.int32)) and float(dist.max()) == 0.0

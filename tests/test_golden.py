@@ -96,7 +96,7 @@ def test_disp_bilateral_hip_matches_golden(gpu, path):
 def test_bfmatch_hip_matches_golden(gpu, path):
     from opencv_contrib_amd import cuda
     z = np.load(path)
-    idx, dist = cuda.createBFMatcher().knnMatch(T(z["query"], gpu), T(z["train"], gpu), k=2)
+    idx, _, dist = cuda.createBFMatcher().knnMatchDevice(T(z["query"], gpu), T(z["train"], gpu), k=2)
     np.testing.assert_array_equal(idx.cpu().numpy(), z["idx"]); np.testing.assert_array_equal(dist.cpu().numpy(), z["dist"])
 
 
