@@ -368,12 +368,12 @@ def test_mask_pitched_inputs_legacy_entry_points_and_errors(gpu, oracle):
 
 
 @pytest.mark.gpu
-def test_wave_shared_tiles_agree(gpu, oracle, monkeypatch):
-    """The 4-waves-per-workgroup shape used for long descriptors, forced onto 64 / 128-element ones (MIFLOW_BF_W is read on
-    every call)."""
+def test_single_wave_shape_agrees(gpu, oracle, monkeypatch):
+    """The one-wave-per-workgroup shape (MIFLOW_BF_W=1, read on every call) against the oracle; every other test runs the
+    default four-wave shape for 64 / 128-element descriptors."""
     import torch
     from opencv_contrib_amd import cuda
-    monkeypatch.setenv("MIFLOW_BF_W", "4")
+    monkeypatch.setenv("MIFLOW_BF_W", "1")
     rng = np.random.default_rng(3)
     for d in (64, 128):
         q = rng.standard_normal((200, d)).astype(np.float32); t = rng.standard_normal((777, d)).astype(np.float32)

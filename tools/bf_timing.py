@@ -34,7 +34,7 @@ def main():
             for norm, nn in ((4, "L2"), (2, "L1")):
                 m = cuda.createBFMatcher(norm)
                 out[f"knn2_{nn}_d{d}_w{w}_ms"] = timed(lambda: m.knnMatchDevice(x, x, k=2))
-        os.environ["MIFLOW_BF_W"] = "1"
+        os.environ.pop("MIFLOW_BF_W", None)
         m = cuda.createBFMatcher(4)
         out[f"knn8_L2_d{d}_ms"] = timed(lambda: m.knnMatchDevice(x, x, k=8))
         out[f"radius_L2_d{d}_ms"] = timed(lambda: m.radiusMatchDevice(x, x, 0.5), reps=2)
