@@ -65,11 +65,15 @@ int mi_surf_create(const mi_surf_params *p, mi_surf **out)
             if (i * i + j * j <= 36) { apt[k] = (float)i; apt[113 + k] = (float)j; apt[226 + k] = g[i + 6] * g[j + 6]; ++k; }
     gauss(20, 3.3, G);
     for (int i = 0; i < 20; i++) for (int j = 0; j < 20; j++) dw[i * 20 + j] = G[i] * G[j];
-    MI_HIP_TRY(hipMalloc((void **)&h->apt, sizeof(apt)));
-    MI_HIP_TRY(hipMalloc((void **)&h->dw, sizeof(dw)));
-    MI_HIP_TRY(hipMemcpy(h->apt, apt, sizeof(apt), hipMemcpyHostToDevice));
-    MI_HIP_TRY(hipMemcpy(h->dw, dw, sizeof(dw), hipMemcpyHostToDevice));
-    MI_HIP_TRY(hipMalloc((void **)&h->counters, sizeof(unsigned) * 64));
+    auto upload = [&]() -> int {
+        MI_HIP_TRY(hipMalloc((void **)&h->apt, sizeof(apt)));
+        MI_HIP_TRY(hipMalloc((void **)&h->dw, sizeof(dw)));
+        MI_HIP_TRY(hipMemcpy(h->apt, apt, sizeof(apt), hipMemcpyHostToDevice));
+        MI_HIP_TRY(hipMemcpy(h->dw, dw, sizeof(dw), hipMemcpyHostToDevice));
+        MI_HIP_TRY(hipMalloc((void **)&h->counters, sizeof(unsigned) * 64));
+        return MI_OK;
+    };
+    if (const int rc = upload()) { mi_surf_destroy(h); return rc; }
     *out = h;
     return MI_OK;
 }

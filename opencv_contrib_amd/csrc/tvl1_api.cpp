@@ -39,6 +39,7 @@ struct mi_tvl1 {
     float *cubic_tab = nullptr;
     PtrTab *tab_dev = nullptr;
     int tab_cap = 0;
+    std::vector<PtrTab> tab_host;   // source of the asynchronous upload: must outlive the call
     // device loop control
     int2 *S = nullptr;
     unsigned long long *E = nullptr;
@@ -95,11 +96,15 @@ int mi_tvl1_create(const mi_tvl1_params *p, mi_tvl1 **out)
     }
     mi_tvl1 *h = new mi_tvl1();
     h->P = *p;
-    MI_HIP_TRY(hipGetDevice(&h->device));
     float tab[128];
     host_cubic_table(tab);
-    MI_HIP_TRY(hipMalloc((void **)&h->cubic_tab, sizeof(tab)));
-    MI_HIP_TRY(hipMemcpy(h->cubic_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    auto upload = [&]() -> int {
+        MI_HIP_TRY(hipGetDevice(&h->device));
+        MI_HIP_TRY(hipMalloc((void **)&h->cubic_tab, sizeof(tab)));
+        MI_HIP_TRY(hipMemcpy(h->cubic_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+        return MI_OK;
+    };
+    if (const int rc = upload()) { mi_tvl1_destroy(h); return rc; }
     *out = h;
     return MI_OK;
 }
@@ -268,13 +273,14 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         h->tab_cap = B;
     }
     {
-        std::vector<PtrTab> tab(B);
+        std::vector<PtrTab> &tab = h->tab_host;
+        tab.resize(B);
         for (int i = 0; i < B; ++i) {
             tab[i].a = I0s[i].data; tab[i].b = I1s[i].data; tab[i].out = flows[i].data;
             tab[i].step_a = (long long)I0s[i].step; tab[i].step_b = (long long)I1s[i].step;
             tab[i].step_out = (long long)flows[i].step;
         }
-        // pageable source: staged by the runtime before the call returns
+        // pageable source: a few KB, staged by the runtime before the call returns; kept in the handle anyway
         MI_HIP_TRY(hipMemcpyAsync(h->tab_dev, tab.data(), sizeof(PtrTab) * B, hipMemcpyHostToDevice, st));
     }
 
