@@ -4,7 +4,9 @@
 A "step" is one pass of the hot path (mi_tvl1_calc_batch through the C-ABI) over one batch of
 `--batch` synthetic 1920x1080 CV_32FC1 pairs already resident in HBM.  Workload at N=1 is
 BASELINE.json configs[1] ("DualTVL1 dense flow, 1920x1080, 1xMI355X"); with --gpus N every rank
-processes its own batch (independent pairs, no data-path collective: weak scaling, configs[4]).
+processes its own batch (independent pairs, no data-path collective: weak scaling, configs[4]); the same job
+with the pairs resident on GPU 0 only (RCCL scatter / gather inside the timed region, overlapped with compute) is
+reported next to it as "with_scatter_gather" (MIFLOW_BENCH_EXCHANGE=0 skips that leg).
 
 Primary parameter set: the reference accuracy-test setting iterations=10 with epsilon=0
 (fixed work: cudaoptflow/test/test_optflow.cpp:450; CPU equivalent median=1, inner=1, outer=10)
@@ -68,6 +70,40 @@ def time_steps(alg, I0, I1, flows, steps, warmup, dist):
     if dist is not None:
         dist.barrier()
     return time.perf_counter() - t0
+
+
+def bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows_ref):
+    """Batched-frames mode with the pairs resident on GPU 0 only (BASELINE north_star / SURVEY 8e): every step scatters the
+    batches over RCCL, computes, and gathers the flows back to GPU 0; scatter of step k+1 and gather of step k-1 overlap the
+    compute of step k (opencv_contrib_amd/parallel.py).  Reported next to `value`, never as `value` (which is measured with the
+    inputs already resident on every GPU)."""
+    import torch
+    from opencv_contrib_amd import cuda
+    x = torch.stack([I0, I1], 1)                                   # (B, 2, H, W): rank 0's batch is what every rank receives
+    parts = [x] * world if rank == 0 else None
+    local_in = [torch.empty_like(x) for _ in range(2)]
+    local_out = [torch.empty_like(flows_ref) for _ in range(2)]
+    root_out = [[torch.empty_like(flows_ref) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
+                                           timeBlock=args.time_block)
+
+    def compute(inp, out):
+        alg.calc_batch(inp[:, 0], inp[:, 1], out)
+
+    sync = torch.cuda.synchronize
+    parallel.run_exchange_pipeline(dist, rank, world, parts, local_in, local_out, root_out, compute, max(1, args.warmup), sync)
+    el = parallel.run_exchange_pipeline(dist, rank, world, parts, local_in, local_out, root_out, compute, args.steps, sync)
+    el = parallel.max_over_ranks(dist, el, dev)
+    B = x.shape[0]
+    res = {"value": B * world * args.steps / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / args.steps,
+           "exchange_GB_per_step": (world - 1) * (x.numel() + flows_ref.numel()) * 4 / 1e9,
+           "note": "inputs on GPU 0 only: scatter (grouped RCCL send/recv) -> calc_batch -> gather of the flows to GPU 0 inside "
+                   "the timed region, double buffered"}
+    if rank == 0:
+        last = root_out[(args.steps - 1) & 1]
+        # every rank received rank 0's batch and the kernels are deterministic: all gathered flows equal the resident run's
+        res["gathered_flows_identical"] = bool(all(torch.equal(o, flows_ref) for o in last))
+    return res
 
 
 def bench_stereobm(args):
@@ -403,6 +439,12 @@ def main():
            "whole_job_frac_of_hbm_peak": ab_pair * fps / 1e9 / HBM_PEAK_GBS,
            "epe_vs_analytic_flow_px": epe_gt,
            "roofline": roof}
+
+    if world > 1 and os.environ.get("MIFLOW_BENCH_EXCHANGE", "1") != "0":
+        try:
+            out["with_scatter_gather"] = bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows)
+        except Exception as e:   # the headline number above does not depend on this leg
+            out["with_scatter_gather"] = {"error": repr(e)[:300]}
 
     if not args.no_variants and world == 1:
         var = {}

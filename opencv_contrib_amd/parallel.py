@@ -102,3 +102,68 @@ def gather_to_rank0(dist, rank: int, world: int, tensor):
     if tensor.shape[0]:
         dist.send(tensor.contiguous(), dst=0)
     return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Batched-frames mode with the inputs on ONE GPU (BASELINE north_star: "RCCL over xGMI for the scatter/gather only";
+# scatter of the image pairs from GPU 0, gather of the flows back).  torch.distributed's scatter / gather on
+# the "nccl" backend are grouped point-to-point sends / receives (ncclGroupStart ... ncclGroupEnd), which is what a
+# point-to-point fabric wants: the root's 7 xGMI links run concurrently.  Both are issued asynchronously on the
+# collective stream so that the exchange of step k+1 overlaps the compute of step k.
+
+def scatter_from_rank0(dist, rank: int, world: int, out, parts=None, async_op: bool = False):
+    """Every rank receives its part into `out`; `parts` (rank 0 only): `world` tensors shaped like `out`.
+    Returns the Work handle when async_op (None in a single-process run)."""
+    if dist is None:
+        out.copy_(parts[0])
+        return None
+    return dist.scatter(out, scatter_list=list(parts) if rank == 0 else None, src=0, async_op=async_op)
+
+
+def gather_on_rank0(dist, rank: int, world: int, tensor, outs=None, async_op: bool = False):
+    """Rank 0 receives every rank's `tensor` into `outs[r]` (`world` tensors shaped like `tensor`)."""
+    if dist is None:
+        outs[0].copy_(tensor)
+        return None
+    return dist.gather(tensor, gather_list=list(outs) if rank == 0 else None, dst=0, async_op=async_op)
+
+
+def run_exchange_pipeline(dist, rank: int, world: int, parts, local_in, local_out, root_out, compute, steps: int, sync=None):
+    """`steps` rounds of scatter -> compute -> gather, double buffered: the scatter of round k+1 and the gather of round k-1
+    run on the collective stream while round k computes.
+
+    parts:     rank 0: `world` input tensors (one per rank), else None
+    local_in:  two input buffers of this rank, local_out: two output buffers
+    root_out:  rank 0: two lists of `world` output tensors, else None
+    compute(inp, out): this rank's work for one round, enqueued on the current stream
+    Returns the wall seconds of this rank (bracket with barriers and reduce with max_over_ranks at the call site)."""
+    import time
+
+    def wait(w):
+        if w is not None:
+            w.wait()      # nccl: the current stream waits for the collective; gloo: the host does
+
+    sc = [None, None]
+    ga = [None, None]
+    if sync:
+        sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    sc[0] = scatter_from_rank0(dist, rank, world, local_in[0], parts, async_op=True)
+    for k in range(steps):
+        b = k & 1
+        wait(sc[b])
+        if k + 1 < steps:                       # next round's inputs travel while this round computes
+            sc[b ^ 1] = scatter_from_rank0(dist, rank, world, local_in[b ^ 1], parts, async_op=True)
+        wait(ga[b])                             # round k-2's gather has drained local_out[b]
+        compute(local_in[b], local_out[b])
+        ga[b] = gather_on_rank0(dist, rank, world, local_out[b], root_out[b] if rank == 0 else None, async_op=True)
+    wait(ga[0])
+    wait(ga[1])
+    if sync:
+        sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    return el

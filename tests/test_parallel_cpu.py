@@ -64,3 +64,71 @@ def test_two_rank_gloo_job(tmp_path):
     assert abs(res[0]["wall"] - res[1]["wall"]) < 1e-9 and res[0]["wall"] >= 0.055      # 3 steps x 20 ms of the slow rank
     assert res[1]["gathered"] is None
     assert res[0]["gathered"] == [[0.0, 0.0]] * 4 + [[1.0, 1.0]] * 3
+
+
+EXCHANGE_WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+import torch
+from opencv_contrib_amd import parallel
+dist, rank, world, local = parallel.init_distributed("gloo")
+B, H, W = 3, 4, 5
+parts = [torch.arange(B * 2 * H * W, dtype=torch.float32).reshape(B, 2, H, W) + 1000 * r for r in range(world)] if rank == 0 else None
+local_in = [torch.zeros(B, 2, H, W) for _ in range(2)]
+local_out = [torch.zeros(B, H, W, 2) for _ in range(2)]
+root_out = [[torch.zeros(B, H, W, 2) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+seen = []
+def compute(inp, out):                      # stand-in for calc_batch: a per-rank function of both frames
+    seen.append(float(inp[0, 0, 0, 0]))
+    time.sleep(0.005 * (rank + 1))
+    out[..., 0] = inp[:, 0] * 2 + rank
+    out[..., 1] = inp[:, 1] - inp[:, 0]
+el = parallel.run_exchange_pipeline(dist, rank, world, parts, local_in, local_out, root_out, compute, steps=5)
+wall = parallel.max_over_ranks(dist, el)
+ok = None
+if rank == 0:
+    ok = True
+    for b in range(2):
+        for r in range(world):
+            exp0 = parts[r][:, 0] * 2 + r
+            exp1 = parts[r][:, 1] - parts[r][:, 0]
+            ok = ok and bool(torch.equal(root_out[b][r][..., 0], exp0)) and bool(torch.equal(root_out[b][r][..., 1], exp1))
+print("RESULT " + json.dumps({"rank": rank, "wall": wall, "rounds": len(seen), "first": seen[0], "ok": ok}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_scatter_compute_gather_pipeline(tmp_path):
+    """The exchange of the batched-frames mode (inputs on rank 0, flows back to rank 0) with a stand-in compute: every rank gets
+    ITS part in every round, both output buffers of the double-buffered pipeline arrive intact on rank 0."""
+    import json
+    script = tmp_path / "exchange_worker.py"
+    script.write_text(EXCHANGE_WORKER % {"root": ROOT})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = sorted((json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l), key=lambda d: d["rank"])
+    assert len(res) == 2 and res[0]["ok"] is True
+    assert res[0]["rounds"] == res[1]["rounds"] == 5
+    assert res[0]["first"] == 0.0 and res[1]["first"] == 1000.0            # each rank computed on its own part
+    assert abs(res[0]["wall"] - res[1]["wall"]) < 1e-9 and res[0]["wall"] >= 0.05
+
+
+def test_exchange_pipeline_single_process():
+    import torch
+    parts = [torch.arange(12, dtype=torch.float32).reshape(1, 2, 2, 3)]
+    lin = [torch.zeros(1, 2, 2, 3) for _ in range(2)]
+    lout = [torch.zeros(1, 2, 3, 2) for _ in range(2)]
+    rout = [[torch.zeros(1, 2, 3, 2)] for _ in range(2)]
+
+    def compute(inp, out):
+        out[..., 0] = inp[:, 0]
+        out[..., 1] = inp[:, 1]
+
+    parallel.run_exchange_pipeline(None, 0, 1, parts, lin, lout, rout, compute, steps=3)
+    for b in range(2):
+        assert torch.equal(rout[b][0][..., 0], parts[0][:, 0]) and torch.equal(rout[b][0][..., 1], parts[0][:, 1])
