@@ -32,6 +32,14 @@ def test_shim_compiles_and_fails_loudly_without_gpu(tmp_path):
     assert r.returncode == 3 and "no CPU fallback" in r.stderr
 
 
+def test_public_signatures_match_the_reference_headers():
+    """tests/cpp/api_conformance.cpp: member-function pointer types, factory defaults and public fields of every class of the
+    drop-in headers, transcribed from the reference's headers (cited there), checked at compile time."""
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "api_conformance.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_gpumat_layout_matches_reference_struct(tmp_path):
     """SURVEY 8b: {int flags; int rows, cols; size_t step; uchar* data; int* refcount; uchar* datastart;
     const uchar* dataend; Allocator* allocator;} -- offsets on LP64."""
