@@ -520,6 +520,48 @@ def surf_detect_describe(img, params: SURFParams | None = None, mask=None, want_
             "descriptors": desc[:n].copy() if want_desc else None}
 
 
+# ------------------------------------------------------------------ the reference's CPU SURF class (oracle/surfcpu_ref.c)
+def surfcpu_detect(img, hessian_threshold=100.0, n_octaves=4, n_octave_layers=3, mask=None, cap=65536):
+    """xfeatures2d::SURF::detect without the orientation pass -> (n, 7) float32 rows {x, y, size, angle = -1, response, octave,
+    class_id}, sorted like the reference (response descending)."""
+    img = _u8(img)
+    m = _u8(mask) if mask is not None else None
+    kp = np.zeros((cap, 7), np.float32)
+    L = lib()
+    L.orc_surfcpu_detect.restype = C.c_int
+    L.orc_surfcpu_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.orc_surfcpu_detect(img.ctypes.data, m.ctypes.data if m is not None else None, img.shape[0], img.shape[1],
+                             hessian_threshold, n_octaves, n_octave_layers, kp.ctypes.data, cap)
+    if n < 0:
+        raise ValueError(f"orc_surfcpu_detect failed: {n}")
+    return kp[:min(n, cap)].copy()
+
+
+def surfcpu_compute(img, keypoints, extended=False, upright=False, want_desc=True):
+    """SURFInvoker over the given keypoints: -> (keypoints with their angle, descriptors) with the keypoints the reference erases
+    (no orientation sample inside the image) removed."""
+    img = _u8(img)
+    kp = np.ascontiguousarray(keypoints, np.float32).copy()
+    n = kp.shape[0]
+    desc = np.zeros((n, 128 if extended else 64), np.float32) if want_desc else None
+    L = lib()
+    L.orc_surfcpu_compute.restype = C.c_int
+    L.orc_surfcpu_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.orc_surfcpu_compute(img.ctypes.data, img.shape[0], img.shape[1], kp.ctypes.data, n, int(extended), int(upright),
+                               desc.ctypes.data if want_desc else None)
+    if rc:
+        raise ValueError(f"orc_surfcpu_compute failed: {rc}")
+    keep = kp[:, 2] > 0
+    return kp[keep], (desc[keep] if want_desc else None)
+
+
+def surfcpu_detect_and_compute(img, hessian_threshold=100.0, n_octaves=4, n_octave_layers=3, extended=False, upright=False, mask=None,
+                               want_desc=True):
+    """SURF_Impl::detectAndCompute (surf.cpp:881-1015)."""
+    kp = surfcpu_detect(img, hessian_threshold, n_octaves, n_octave_layers, mask)
+    return surfcpu_compute(img, kp, extended, upright, want_desc)
+
+
 # ------------------------------------------------------------------ superres adapter data formats (SURVEY 8f N1)
 def superres_to_gray8(frame):
     """cv::superres::convertToType(frame, CV_8UC1) for GpuMat frames, restated in numpy:

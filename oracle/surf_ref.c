@@ -19,8 +19,12 @@
  * run-dependent): candidates in (layer, row, column) scan order per octave, octaves ascending; the first
  * maxCandidates / maxFeatures are kept.  det/trace cells the reference leaves unwritten (stale memory) are 0.
  * Warp reductions (device::reduce<32>) are restated as the shfl_down tree 16,8,4,2,1.
- * PARITY UNPINNED: aloe.png (opencv_extra) is absent; the only self-contained fixture of the reference is the
- * synthetic cross of xfeatures2d/test/test_rotation_and_scale_invariance.cpp:259-285 (written for the CPU class).
+ * Pinning: aloe.png (opencv_extra), which the reference's CUDA test reads, is absent.  The reference's known-answer vectors are
+ * for its CPU class (misc/java/test/SURFFeatureDetectorTest.java:52-57, SURFDescriptorExtractorTest.java:43-66); oracle/surfcpu_ref.c
+ * restates that class and reproduces them to the last digit, and this restatement is held to it the way the reference's own test
+ * holds the CUDA class to the CPU class (test_surf.cuda.cpp:81-170) -- tests/test_zz_surf_cpu_class.py: on the golden cross the same
+ * four keypoints (position, size, response, octave within 1e-3; orientation up to an exact two-way tie the two classes break
+ * differently), on textured images matched-keypoint ratio 1.00 (> 0.95 required) and descriptor match ratio >= 0.98 (> 0.6 required).
  */
 #include "surf_ref.h"
 
