@@ -47,7 +47,8 @@ def test_oracle_integral(oracle):
 
 
 def test_oracle_cross_fixture(oracle):
-    """The reference's only self-contained SURF fixture (xfeatures2d/test/test_rotation_and_scale_invariance.cpp:259-285:
+    """A self-contained SURF fixture of the reference (xfeatures2d/test/test_rotation_and_scale_invariance.cpp:259-285; the one
+    with known answers, the Java tests' cross, is in tests/test_zz_surf_cpu_class.py:
     100x100 white image, two 3-px dark bars, SURF(8000, 3, 4, extended, upright=false)).  The CPU class reports 5
     keypoints there; under the CUDA class's strict 26-neighbour maximum the centre is a plateau (det = 15376 on a 3x3
     patch of layer 1) and only the 4 symmetric keypoints survive -- with equal responses, as that test requires."""
