@@ -4,7 +4,6 @@ bytes as the Python mirror (both are thin bindings of the same C-ABI)."""
 import os
 import struct
 import subprocess
-import sys
 
 import numpy as np
 import pytest
