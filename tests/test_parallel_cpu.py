@@ -132,3 +132,52 @@ def test_exchange_pipeline_single_process():
     parallel.run_exchange_pipeline(None, 0, 1, parts, lin, lout, rout, compute, steps=3)
     for b in range(2):
         assert torch.equal(rout[b][0][..., 0], parts[0][:, 0]) and torch.equal(rout[b][0][..., 1], parts[0][:, 1])
+
+
+BENCH_EXCHANGE_WORKER = r'''
+import json, os, sys, types
+sys.path.insert(0, %(root)r)
+sys.argv = ["bench.py"]
+import torch
+import bench
+from opencv_contrib_amd import parallel, cuda
+
+class FakeAlg:                               # stand-in for the HIP TV-L1 object: deterministic function of the two frames
+    def calc_batch(self, a, b, out):
+        out[..., 0] = a * 2 + 1
+        out[..., 1] = b - a
+
+cuda.OpticalFlowDual_TVL1 = types.SimpleNamespace(create=lambda **kw: FakeAlg())
+torch.cuda.synchronize = lambda: None
+dist, rank, world, local = parallel.init_distributed("gloo")
+args = types.SimpleNamespace(iterations=10, epsilon=0.0, exact_math=False, time_block=0, warmup=1, steps=4)
+g = torch.Generator().manual_seed(5)          # rank 0's batch is what every rank receives
+I0 = torch.rand(3, 6, 8, generator=g) + rank   # other ranks hold different data of their own: it must not matter
+I1 = torch.rand(3, 6, 8, generator=g) + rank
+ref = torch.empty(3, 6, 8, 2)
+if rank == 0:
+    FakeAlg().calc_batch(I0, I1, ref)
+res = bench.bench_exchange(args, parallel, dist, rank, world, "cpu", I0, I1, ref)
+print("RESULT " + json.dumps({"rank": rank, "res": res}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_bench_exchange_leg_two_ranks_with_a_stand_in_algorithm(tmp_path):
+    """bench.py's "with_scatter_gather" leg end to end on 2 gloo ranks (the TV-L1 object replaced by a stand-in): rank 0's batch reaches
+    both ranks, both flows come back identical to the resident result, one throughput figure for the job."""
+    import json
+    script = tmp_path / "bench_exchange_worker.py"
+    script.write_text(BENCH_EXCHANGE_WORKER % {"root": ROOT})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = sorted((json.loads(l.split("RESULT ", 1)[1]) for l in r.stdout.splitlines() if "RESULT " in l), key=lambda d: d["rank"])
+    assert len(res) == 2
+    assert res[0]["res"]["gathered_flows_identical"] is True and "gathered_flows_identical" not in res[1]["res"]
+    assert res[0]["res"]["value"] == res[1]["res"]["value"] > 0
+    assert abs(res[0]["res"]["exchange_GB_per_step"] - (3 * 2 * 6 * 8 + 3 * 6 * 8 * 2) * 4 / 1e9) < 1e-15
