@@ -290,6 +290,18 @@ MI_API int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_oc
 /* Hardware self-test hook: out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan) */
 MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
 
+/* ---- the CPU SURF class's orientation and descriptor for given keypoints (xfeatures2d::SURF_Impl, surf.cpp:568-866) ----
+ * cv::cuda::SURF_CUDA samples its descriptor patch differently from cv::xfeatures2d::SURF (the reference's own test only asks for a
+ * 60 % nearest-neighbour agreement, test_surf.cuda.cpp:166-169).  These two entry points run the CPU class's arithmetic -- Haar
+ * responses on the integral image, fastAtan2 polynomial, sequential 60-degree window search; bilinear window, INTER_AREA patch,
+ * 4 x 4 x (4 | 8) bins -- for callers that need its numbers (the reference's known-answer vectors, misc/java/test/SURF*Test.java,
+ * are reproduced).  keypoints: the CV_32FC1 7 x nFeatures matrix of SURF_CUDA (cuda.hpp:89-99); sum: CV_32SC1 (rows + 1) x (cols + 1)
+ * from mi_surf_integral.  Orientation writes the ANGLE row (270 when upright) and sets SIZE to -1 for keypoints the CPU class erases
+ * (no sample inside the image, surf.cpp:604-611,631-638); descriptors of erased keypoints are zero rows. */
+MI_API int mi_surfcpu_orientation(const mi_mat *sum, mi_mat *keypoints, int n, int upright, void *stream);
+MI_API int mi_surfcpu_descriptors(const mi_mat *img, const mi_mat *keypoints, int n, int extended, int upright, mi_mat *descriptors,
+                                  void *stream);
+
 /* ================================== brute-force descriptor matcher for SURF output (first part) ===== */
 
 /* cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L1 | NORM_L2) for CV_32F descriptors of up to 512 elements (SURF: 64 / 128),

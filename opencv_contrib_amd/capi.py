@@ -178,6 +178,8 @@ def lib():
         "mi_disp_bilateral_get_params": (i, [vp, C.POINTER(DispBilateralParams)]),
         "mi_disp_bilateral_apply": (i, [vp, PM, PM, PM, vp]),
         "mi_disp_bilateral_destroy": (None, [vp]),
+        "mi_surfcpu_orientation": (i, [PM, PM, i, i, vp]),
+        "mi_surfcpu_descriptors": (i, [PM, PM, i, i, i, PM, vp]),
         "mi_bf_create": (i, [i, C.POINTER(vp)]),
         "mi_bf_destroy": (None, [vp]),
         "mi_bf_match": (i, [vp, PM, PM, PM, PM, PM, vp]),

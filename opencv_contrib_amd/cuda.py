@@ -883,6 +883,38 @@ class SURF_CUDA:
                                                               C.byref(capi.mat_from_tensor(desc)), sp))
         return keypoints, desc
 
+    # ---- the CPU class's orientation / descriptor arithmetic (xfeatures2d::SURF_Impl, surf.cpp:568-866) on the same keypoint matrix
+    def cpuClassOrientation(self, img, keypoints, stream=None):
+        """Writes the ANGLE row of `keypoints` (7, n) in place as SURFInvoker does (270 when upright) and sets SIZE to -1 for the
+        keypoints the CPU class erases."""
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        s = surf_integral(img)
+        capi.check(capi.lib().mi_surfcpu_orientation(C.byref(capi.mat_from_tensor(s)), C.byref(capi.mat_from_tensor(keypoints)),
+                                                     keypoints.shape[1], int(self._p.upright), sp))
+        return keypoints
+
+    def cpuClassDescriptors(self, img, keypoints, stream=None):
+        import torch
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        n = keypoints.shape[1]
+        desc = torch.empty((n, self.descriptorSize()), dtype=torch.float32, device=img.device)
+        if n:
+            capi.check(capi.lib().mi_surfcpu_descriptors(C.byref(capi.mat_from_tensor(img)), C.byref(capi.mat_from_tensor(keypoints)), n,
+                                                         int(self._p.extended), int(self._p.upright), C.byref(capi.mat_from_tensor(desc)), sp))
+        return desc
+
+    def detectAndComputeCpuClass(self, img, mask=None, keypoints=None, useProvidedKeypoints=False):
+        """cv::xfeatures2d::SURF::detectAndCompute (surf.cpp:881-1015) on the GPU: this class's detector (the same fast-Hessian
+        responses: tests/test_zz_surf_cpu_class.py), then the CPU class's orientation and descriptor; keypoints it erases are
+        removed.  -> (keypoints (7, n), descriptors (n, 64 | 128))."""
+        if not useProvidedKeypoints:
+            keypoints = self.detect(img, mask)
+        keypoints = keypoints.contiguous().clone()
+        self.cpuClassOrientation(img, keypoints)
+        desc = self.cpuClassDescriptors(img, keypoints)
+        keep = keypoints[4] > 0
+        return keypoints[:, keep], desc[keep]
+
     @staticmethod
     def downloadKeypoints(keypointsGPU):
         """-> dict of host arrays (the fields of cv::KeyPoint the reference fills, surf.cuda.cpp:319-356)."""
