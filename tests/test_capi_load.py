@@ -65,3 +65,30 @@ def test_bad_params_rejected_before_device():
     p.nscales = 0  # CV_Assert( nscales_ > 0 ), cudaoptflow/src/tvl1flow.cpp:191
     h = C.c_void_p()
     assert L.mi_tvl1_create(C.byref(p), C.byref(h)) == -1
+
+
+def test_every_entry_point_survives_null_and_zero_arguments():
+    """Robustness of the C boundary: every MI_API function called with NULL pointers and zero scalars returns (an error code, or
+    nothing for the void ones) instead of crashing.  Runs in a child process so that a crash is a test failure, not a dead runner."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C\n"
+        "from opencv_contrib_amd import capi\n"
+        "L = capi.lib()\n"
+        "n = 0\n"
+        "for name in capi.declared_symbols():\n"
+        "    fn = getattr(L, name)\n"
+        "    vals = []\n"
+        "    for a in (fn.argtypes or []):\n"
+        "        if a in (C.c_int, C.c_longlong, C.c_size_t, C.c_uint): vals.append(0)\n"
+        "        elif a in (C.c_float, C.c_double): vals.append(0.0)\n"
+        "        else: vals.append(None)\n"
+        "    r = fn(*vals)\n"
+        "    if fn.restype is C.c_int and name not in ('mi_device_count', 'mi_surf_descriptor_size'):\n"
+        "        assert r != 0 or name in ('mi_stream_synchronize', 'mi_set_device'), (name, r)\n"
+        "    n += 1\n"
+        "print('CALLED', n)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0 and "CALLED" in r.stdout, (r.returncode, r.stderr[-1500:])
