@@ -263,6 +263,27 @@ def bench_farneback(args):
            "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo * args.steps * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "single small pair: launch-latency bound (about 70 launches of 5-50 us); bytes = fused-iteration accounting"}}
+    # four independent objects on four streams (distinct handles share nothing: the reference's constant-memory race does not exist
+    # here): a 640 x 480 pair alone cannot fill 256 CUs, concurrent pairs can
+    try:
+        ns = 4
+        streams = [torch.cuda.Stream() for _ in range(ns)]
+        algs = [cuda.FarnebackOpticalFlow.create() for _ in range(ns)]
+        flows = [torch.empty_like(flow) for _ in range(ns)]
+        torch.cuda.synchronize()
+        for rep in range(2):                       # first round warms the handles up
+            tq = time.perf_counter()
+            for _ in range(max(1, args.steps * n // ns)):
+                for k in range(ns):
+                    with torch.cuda.stream(streams[k]):
+                        algs[k].calc(t0_, t1_, flows[k])
+            torch.cuda.synchronize()
+            el4 = time.perf_counter() - tq
+        if not all(torch.equal(fk, flow) for fk in flows):
+            raise RuntimeError("concurrent objects disagree with the sequential result")
+        out["four_streams_pairs_per_s"] = max(1, args.steps * n // ns) * ns / el4
+    except Exception as e:   # never at the expense of the line above
+        out["four_streams_pairs_per_s"] = {"error": repr(e)[:200]}
     # the third dense flow class of the module on the same pair: DensePyrLKOpticalFlow((13, 13), 3, 30)
     lk = cuda.DensePyrLKOpticalFlow.create()
     lk.calc(t0_, t1_, flow)

@@ -11,6 +11,7 @@ mkdir -p $O
 (timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4) > $O/smoke.log
 (timeout 300 python bench.py 2>$O/bench.err | tail -1) > $O/bench.json
 (timeout 60 python tools/bf_timing.py 2>&1 | tail -3) > $O/bf_timing.log
+(timeout 120 python bench.py --workload farneback --no-cpu 2>/dev/null | tail -1) > $O/farneback_bench.json
 R=$PWD
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace -- python $R/bench.py --no-variants --no-cpu > $R/$O/trace_bench.log 2>&1
