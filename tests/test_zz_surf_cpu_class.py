@@ -176,6 +176,20 @@ def test_cuda_class_oracle_descriptors_accepted_against_cpu_class(oracle, thr, o
     _descriptor_case(_oracle_describe(oracle), oracle, thr, octaves, layers, extended, upright)
 
 
+def _binding_test_case(cuda_detect, cuda_describe, oracle):
+    """xfeatures2d/misc/python/test/test_cuda_xfeatures2d.py:26-49 (its image, aloe.png, is in opencv_extra: a synthetic one here):
+    SURF_CUDA and SURF find the same NUMBER of keypoints, and descriptors computed for provided keypoints have the CPU class's shape."""
+    img = synth.blob_image(420, 560, seed=31)
+    gold, dgold = oracle.surfcpu_detect_and_compute(img, 100.0, 3, 2, extended=False, upright=False)
+    act = cuda_detect(img, 100.0, 3, 2, False, None)
+    assert len(act) == len(gold) > 100
+    assert cuda_describe(img, gold, 100.0, 3, 2, False, False).shape == dgold.shape
+
+
+def test_cuda_class_oracle_passes_the_reference_python_binding_test(oracle):
+    _binding_test_case(_oracle_detect(oracle), _oracle_describe(oracle), oracle)
+
+
 # ------------------------------------------------------------------ the same acceptance on the HIP kernels (GPU)
 def _hip_detect(gpu):
     import torch
@@ -222,3 +236,8 @@ def test_hip_masked_detector_accepted_against_cpu_class(gpu, oracle):
                                                                  (100.0, 4, 3, True, True)])
 def test_hip_descriptors_accepted_against_cpu_class(gpu, oracle, thr, octaves, layers, extended, upright):
     _descriptor_case(_hip_describe(gpu), oracle, thr, octaves, layers, extended, upright)
+
+
+@pytest.mark.gpu
+def test_hip_passes_the_reference_python_binding_test(gpu, oracle):
+    _binding_test_case(_hip_detect(gpu), _hip_describe(gpu), oracle)
