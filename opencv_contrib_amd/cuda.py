@@ -599,6 +599,14 @@ def createBFMatcher(normType=4) -> BFMatcher:
     return BFMatcher(normType)
 
 
+class DescriptorMatcher:
+    """Name parity with cv2.cuda_DescriptorMatcher: `cuda.DescriptorMatcher.createBFMatcher(cuda.NORM_L2)`."""
+    createBFMatcher = staticmethod(createBFMatcher)
+
+
+NORM_L1, NORM_L2 = 2, 4
+
+
 class DisparityBilateralFilter:
     """cv::cuda::DisparityBilateralFilter (cudastereo.hpp:298-330; cudastereo/src/disparity_bilateral_filter.cpp:58-190):
     joint bilateral refinement of a disparity map at its discontinuities, guided by the image."""
