@@ -364,6 +364,11 @@ def bench_surf(args):
     elm = (time.perf_counter() - t0) / 3
     out["bf_knn2_match_ms"] = 1e3 * elm
     out["bf_descriptor_pairs_per_s"] = float(desc.shape[0]) ** 2 / elm
+    # the matcher is VALU work, not HBM work: one subtract and one fma per descriptor element and pair, against the f32 issue peak
+    # of 256 CUs x 64 lanes x 2.4 GHz (MI355X_MICROARCH.md)
+    valu_peak = 256 * 64 * 2.4e9
+    out["bf_roofline"] = {"bound": "valu", "achieved": float(desc.shape[0]) ** 2 * desc.shape[1] * 2 / elm / 1e12, "peak": valu_peak / 1e12,
+                          "unit": "T lane-op/s", "frac": float(desc.shape[0]) ** 2 * desc.shape[1] * 2 / elm / valu_peak}
     if not args.no_cpu:
         from oracle import oracle as O
         t0 = time.perf_counter()
