@@ -531,11 +531,20 @@ def main():
         cit = args.cpu_iterations or (args.iterations if args.epsilon == 0 else 300)
         p = O.tvl1_params(iterations=cit, epsilon=args.epsilon)
         npairs, t0 = 0, time.perf_counter()
+        ref0 = None
         while npairs < len(base) * 4 and (npairs == 0 or time.perf_counter() - t0 < 10.0):
             b_ = base[npairs % len(base)]
-            O.tvl1_calc(b_[0], b_[1], p)
+            r_ = O.tvl1_calc(b_[0], b_[1], p)
+            if npairs == 0:
+                ref0 = r_
             npairs += 1
         ct = time.perf_counter() - t0
+        if ref0 is not None and cit == args.iterations:
+            # BASELINE.json metric: "... EPE vs CPU ref" -- pair 0 of the timed batch against the CPU restatement with the same
+            # parameters; |1 - CCORR| is the reference's own comparator (cudaoptflow/test/test_optflow.cpp:465, 4e-3 there)
+            out["epe_vs_cpu_ref_px"] = float(synth.epe(f0, ref0))
+            out["ccorr_dissimilarity_vs_cpu_ref"] = float(max(synth.ccorr_dissimilarity(f0[..., 0], ref0[..., 0]),
+                                                              synth.ccorr_dissimilarity(f0[..., 1], ref0[..., 1])))
         out["cpu_baseline"] = {"value": npairs / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"{npairs} pair(s) {W}x{H} CV_32FC1, iterations={cit}, epsilon={args.epsilon}, "
                                          f"{ct:.1f} s wall, oracle/tvl1_ref.c (OpenMP rows, all host cores)"}
