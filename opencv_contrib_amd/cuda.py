@@ -896,6 +896,8 @@ class SURF_CUDA:
         """Writes the ANGLE row of `keypoints` (7, n) in place as SURFInvoker does (270 when upright) and sets SIZE to -1 for the
         keypoints the CPU class erases."""
         sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        if keypoints.shape[1] == 0:
+            return keypoints
         s = surf_integral(img)
         capi.check(capi.lib().mi_surfcpu_orientation(C.byref(capi.mat_from_tensor(s)), C.byref(capi.mat_from_tensor(keypoints)),
                                                      keypoints.shape[1], int(self._p.upright), sp))
