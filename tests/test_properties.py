@@ -114,3 +114,19 @@ def test_superres_gray8_oracle_properties(oracle, seed, h, w, cn, dtype):
             np.testing.assert_array_equal(oracle.superres_to_gray8(rep), oracle.superres_to_gray8(grey))
     if dtype == "uint8" and cn == 1:
         np.testing.assert_array_equal(g, x)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_identical_frames_give_exactly_zero_flow(oracle, dtype):
+    """Zero motion is a fixed point of the iterations: rho vanishes identically for TV-L1 (both semantics), the residual for PyrLK.
+    Farneback is NOT exactly zero there: its matrix update drops the second frame's polynomial at the last row / column
+    (farneback.cu:186-208: `x1 < width - 1`), an asymmetry of the reference that leaks a sub-pixel flow inwards from the border."""
+    from opencv_contrib_amd import synth
+    I0, _, _ = synth.flow_pair(72, 96, seed=3, dtype=dtype)
+    for sem in (0, 1):
+        f = oracle.tvl1_calc(I0, I0, oracle.tvl1_params(iterations=8, epsilon=0.0, semantics=sem))
+        assert np.abs(f).max() == 0.0
+    if dtype == "u8":
+        assert np.abs(oracle.pyrlk_dense(I0, I0)).max() == 0.0
+        fb = np.abs(oracle.fb_calc(I0, I0)).max(-1)
+        assert fb[12:-12, 12:-12].max() < 1e-3 and 0 < fb.max() < 0.5
