@@ -120,7 +120,7 @@ def test_superres_gray8_oracle_properties(oracle, seed, h, w, cn, dtype):
 def test_identical_frames_give_exactly_zero_flow(oracle, dtype):
     """Zero motion is a fixed point of the iterations: rho vanishes identically for TV-L1 (both semantics), the residual for PyrLK.
     Farneback is NOT exactly zero there: its matrix update drops the second frame's polynomial at the last row / column
-    (farneback.cu:186-208: `x1 < width - 1`), an asymmetry of the reference that leaks a sub-pixel flow inwards from the border."""
+    (farneback.cu:176: `x1 < width - 1 && y1 < height - 1`), an asymmetry of the reference that leaks a sub-pixel flow inwards from the border."""
     from opencv_contrib_amd import synth
     I0, _, _ = synth.flow_pair(72, 96, seed=3, dtype=dtype)
     for sem in (0, 1):
