@@ -522,6 +522,20 @@ def main():
                 var["two_streams_half_batches"] = {"pairs_per_s": two_stream_rate(args, I0, I1, flows, max(2, args.steps // 2))}
             except Exception as e:   # never at the expense of the headline line
                 var["two_streams_half_batches"] = {"error": repr(e)[:200]}
+        # the reference's own calling pattern: one pair per calc() (no batching), back to back on one stream
+        try:
+            a1 = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
+                                                  timeBlock=args.time_block)
+            one = torch.empty((H, W, 2), dtype=torch.float32, device=dev)
+            a1.calc(I0[0], I1[0], one)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(8):
+                a1.calc(I0[i % B], I1[i % B], one)
+            torch.cuda.synchronize()
+            var["single_pair_calc_sequential"] = {"pairs_per_s": 8 / (time.perf_counter() - t1)}
+        except Exception as e:
+            var["single_pair_calc_sequential"] = {"error": repr(e)[:200]}
         out["variants"] = var
 
     if rank == 0 and world == 1 and not args.no_cpu:
