@@ -522,6 +522,16 @@ def main():
                 var["two_streams_half_batches"] = {"pairs_per_s": two_stream_rate(args, I0, I1, flows, max(2, args.steps // 2))}
             except Exception as e:   # never at the expense of the headline line
                 var["two_streams_half_batches"] = {"error": repr(e)[:200]}
+        # SURVEY 8d config 2 "also run CV_8UC1": the same batch as 8-bit frames (the class converts them to f32 once per calc)
+        try:
+            a8 = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
+                                                  timeBlock=args.time_block)
+            J0, J1 = (I0 * 255).round().clamp(0, 255).to(torch.uint8), (I1 * 255).round().clamp(0, 255).to(torch.uint8)
+            e8 = time_steps(a8, J0, J1, flows, max(1, args.steps // 2), 1, None)
+            var["u8_input"] = {"pairs_per_s": B * max(1, args.steps // 2) / e8}
+            del J0, J1, a8
+        except Exception as e:
+            var["u8_input"] = {"error": repr(e)[:200]}
         # the reference's own calling pattern: one pair per calc() (no batching), back to back on one stream
         try:
             a1 = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
