@@ -290,6 +290,24 @@ MI_API int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_oc
 /* Hardware self-test hook: out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan) */
 MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
 
+/* ======================================================== sparse PyrLK ===== */
+
+/* cv::cuda::SparsePyrLKOpticalFlow::create(winSize = (21, 21), maxLevel = 3, iters = 30, useInitialFlow = false), cudaoptflow.hpp:203-223,
+ * for CV_8UC1 frames; calc = PyrLKOpticalFlowBase::sparse (cudaoptflow/src/pyrlk.cpp:149-231) + sparseKernel (cuda/pyrlk.cu:148-340).
+ * prev_pts / next_pts: 1 x N CV_32FC2 (next_pts is read when use_initial_flow), status: 1 x N CV_8UC1 (1 = tracked), err: NULL or
+ * 1 x N CV_32FC1 (mean |J - I| over the window at level 0, in 8-bit units).  Windows of up to 1024 pixels. */
+typedef struct mi_sparsepyrlk_params {
+    int win_width, win_height, max_level, iters, use_initial_flow;
+} mi_sparsepyrlk_params;
+typedef struct mi_sparsepyrlk mi_sparsepyrlk;
+MI_API void mi_sparsepyrlk_default_params(mi_sparsepyrlk_params *p);
+MI_API int mi_sparsepyrlk_create(const mi_sparsepyrlk_params *p, mi_sparsepyrlk **out);
+MI_API int mi_sparsepyrlk_set_params(mi_sparsepyrlk *h, const mi_sparsepyrlk_params *p);
+MI_API int mi_sparsepyrlk_get_params(const mi_sparsepyrlk *h, mi_sparsepyrlk_params *p);
+MI_API int mi_sparsepyrlk_calc(mi_sparsepyrlk *h, const mi_mat *prev_img, const mi_mat *next_img, const mi_mat *prev_pts, mi_mat *next_pts,
+                               mi_mat *status, mi_mat *err, void *stream);
+MI_API void mi_sparsepyrlk_destroy(mi_sparsepyrlk *h);
+
 /* ---- the CPU SURF class's orientation and descriptor for given keypoints (xfeatures2d::SURF_Impl, surf.cpp:568-866) ----
  * cv::cuda::SURF_CUDA samples its descriptor patch differently from cv::xfeatures2d::SURF (the reference's own test only asks for a
  * 60 % nearest-neighbour agreement, test_surf.cuda.cpp:166-169).  These two entry points run the CPU class's arithmetic -- Haar

@@ -176,5 +176,69 @@ inline Ptr<DensePyrLKOpticalFlow> DensePyrLKOpticalFlow::create(Size winSize, in
     return makePtr<miflow_detail::DensePyrLKImpl>(p);
 }
 
+/** cudaoptflow.hpp:85-104 SparseOpticalFlow, :203-223 SparsePyrLKOpticalFlow; implementation twin of SparsePyrLKOpticalFlowImpl,
+ *  cudaoptflow/src/pyrlk.cpp:308-352.  CV_8UC1 frames.  `err` defaults to cuda::noArray() (a shared empty GpuMat): not computed. */
+inline GpuMat &noArray() { static thread_local GpuMat none; none.release(); return none; }
+
+class SparseOpticalFlow : public Algorithm {
+public:
+    virtual void calc(InputArray prevImg, InputArray nextImg, InputArray prevPts, InputOutputArray nextPts, OutputArray status,
+                      OutputArray err = noArray(), Stream &stream = Stream::Null()) = 0;
+};
+
+class SparsePyrLKOpticalFlow : public SparseOpticalFlow {
+public:
+    virtual Size getWinSize() const = 0;          virtual void setWinSize(Size winSize) = 0;
+    virtual int getMaxLevel() const = 0;          virtual void setMaxLevel(int maxLevel) = 0;
+    virtual int getNumIters() const = 0;          virtual void setNumIters(int iters) = 0;
+    virtual bool getUseInitialFlow() const = 0;   virtual void setUseInitialFlow(bool useInitialFlow) = 0;
+    static Ptr<SparsePyrLKOpticalFlow> create(Size winSize = Size(21, 21), int maxLevel = 3, int iters = 30, bool useInitialFlow = false);
+};
+
+namespace miflow_detail {
+class SparsePyrLKImpl final : public SparsePyrLKOpticalFlow {
+public:
+    explicit SparsePyrLKImpl(const mi_sparsepyrlk_params &p) : p_(p) { miCheck(mi_sparsepyrlk_create(&p_, &h_)); }
+    ~SparsePyrLKImpl() override { mi_sparsepyrlk_destroy(h_); }
+    SparsePyrLKImpl(const SparsePyrLKImpl &) = delete;
+    SparsePyrLKImpl &operator=(const SparsePyrLKImpl &) = delete;
+    void calc(InputArray prevImg, InputArray nextImg, InputArray prevPts, InputOutputArray nextPts, OutputArray status, OutputArray err,
+              Stream &stream) override
+    {
+        const bool wantErr = &err != &noArray();
+        if (prevPts.empty()) {                                    // pyrlk.cpp:209-215
+            nextPts.release(); status.release();
+            if (wantErr) err.release();
+            return;
+        }
+        if (p_.use_initial_flow) CV_Assert(nextPts.size() == prevPts.size() && nextPts.type() == prevPts.type());   // :159-160
+        else nextPts.create(1, prevPts.cols, prevPts.type());
+        status.create(1, prevPts.cols, CV_8UC1);
+        if (wantErr) err.create(1, prevPts.cols, CV_32FC1);
+        mi_mat a = miMat(prevImg), b = miMat(nextImg), pp = miMat(prevPts), np = miMat(nextPts), st = miMat(status), er = miMat(err);
+        miCheck(mi_sparsepyrlk_calc(h_, &a, &b, &pp, &np, &st, wantErr ? &er : nullptr, stream.hipStream()));
+    }
+    String getDefaultName() const override { return "SparseOpticalFlow.SparsePyrLKOpticalFlow"; }   // pyrlk.cpp:351
+    Size getWinSize() const override { return Size(p_.win_width, p_.win_height); }
+    void setWinSize(Size v) override { p_.win_width = v.width; p_.win_height = v.height; push(); }
+    int getMaxLevel() const override { return p_.max_level; }           void setMaxLevel(int v) override { p_.max_level = v; push(); }
+    int getNumIters() const override { return p_.iters; }               void setNumIters(int v) override { p_.iters = v; push(); }
+    bool getUseInitialFlow() const override { return p_.use_initial_flow != 0; }
+    void setUseInitialFlow(bool v) override { p_.use_initial_flow = v; push(); }
+private:
+    void push() { miCheck(mi_sparsepyrlk_set_params(h_, &p_)); }
+    mi_sparsepyrlk_params p_;
+    mi_sparsepyrlk *h_ = nullptr;
+};
+}  // namespace miflow_detail
+
+inline Ptr<SparsePyrLKOpticalFlow> SparsePyrLKOpticalFlow::create(Size winSize, int maxLevel, int iters, bool useInitialFlow)
+{
+    mi_sparsepyrlk_params p;
+    mi_sparsepyrlk_default_params(&p);
+    p.win_width = winSize.width; p.win_height = winSize.height; p.max_level = maxLevel; p.iters = iters; p.use_initial_flow = useInitialFlow;
+    return makePtr<miflow_detail::SparsePyrLKImpl>(p);
+}
+
 }}  // namespace cv::cuda
 #endif

@@ -53,6 +53,10 @@ class DensePyrLKParams(C.Structure):
     _fields_ = [("win_width", C.c_int), ("win_height", C.c_int), ("max_level", C.c_int), ("iters", C.c_int), ("use_initial_flow", C.c_int)]
 
 
+class SparsePyrLKParams(C.Structure):
+    _fields_ = [("win_width", C.c_int), ("win_height", C.c_int), ("max_level", C.c_int), ("iters", C.c_int), ("use_initial_flow", C.c_int)]
+
+
 class StereoSGMParams(C.Structure):
     _fields_ = [("min_disparity", C.c_int), ("num_disparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),
                 ("uniqueness_ratio", C.c_int), ("mode", C.c_int), ("emulate_cuda_quirks", C.c_int)]
@@ -178,6 +182,12 @@ def lib():
         "mi_disp_bilateral_get_params": (i, [vp, C.POINTER(DispBilateralParams)]),
         "mi_disp_bilateral_apply": (i, [vp, PM, PM, PM, vp]),
         "mi_disp_bilateral_destroy": (None, [vp]),
+        "mi_sparsepyrlk_default_params": (None, [C.POINTER(SparsePyrLKParams)]),
+        "mi_sparsepyrlk_create": (i, [C.POINTER(SparsePyrLKParams), C.POINTER(vp)]),
+        "mi_sparsepyrlk_set_params": (i, [vp, C.POINTER(SparsePyrLKParams)]),
+        "mi_sparsepyrlk_get_params": (i, [vp, C.POINTER(SparsePyrLKParams)]),
+        "mi_sparsepyrlk_calc": (i, [vp, PM, PM, PM, PM, PM, PM, vp]),
+        "mi_sparsepyrlk_destroy": (None, [vp]),
         "mi_surfcpu_orientation": (i, [PM, PM, i, i, vp]),
         "mi_surfcpu_descriptors": (i, [PM, PM, i, i, i, PM, vp]),
         "mi_bf_create": (i, [i, C.POINTER(vp)]),

@@ -296,6 +296,62 @@ class DensePyrLKOpticalFlow:
         return flow
 
 
+class SparsePyrLKOpticalFlow:
+    """cv::cuda::SparsePyrLKOpticalFlow for CV_8UC1 frames (cudaoptflow.hpp:85-104,203-223; cudaoptflow/src/pyrlk.cpp:149-231,308-352).
+    calc(prevImg, nextImg, prevPts (1, N, 2) or (N, 2) float32[, nextPts]) -> (nextPts (1, N, 2), status (1, N) uint8, err (1, N))."""
+
+    def __init__(self, winSize=(21, 21), maxLevel=3, iters=30, useInitialFlow=False):
+        self._p = capi.SparsePyrLKParams()
+        capi.lib().mi_sparsepyrlk_default_params(C.byref(self._p))
+        self._p.win_width, self._p.win_height, self._p.max_level, self._p.iters = winSize[0], winSize[1], maxLevel, iters
+        self._p.use_initial_flow = int(bool(useInitialFlow))
+        self._h = C.c_void_p()
+        capi.check(capi.lib().mi_sparsepyrlk_create(C.byref(self._p), C.byref(self._h)))
+
+    @classmethod
+    def create(cls, winSize=(21, 21), maxLevel=3, iters=30, useInitialFlow=False):
+        return cls(winSize, maxLevel, iters, useInitialFlow)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.lib().mi_sparsepyrlk_destroy(self._h)
+            self._h = None
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self._p, k, v)
+        capi.check(capi.lib().mi_sparsepyrlk_set_params(self._h, C.byref(self._p)))
+
+    def getDefaultName(self): return "SparseOpticalFlow.SparsePyrLKOpticalFlow"   # pyrlk.cpp:350
+    def getWinSize(self): return (self._p.win_width, self._p.win_height)
+    def setWinSize(self, v): self._set(win_width=v[0], win_height=v[1])
+    def getMaxLevel(self): return self._p.max_level
+    def setMaxLevel(self, v): self._set(max_level=v)
+    def getNumIters(self): return self._p.iters
+    def setNumIters(self, v): self._set(iters=v)
+    def getUseInitialFlow(self): return bool(self._p.use_initial_flow)
+    def setUseInitialFlow(self, v): self._set(use_initial_flow=int(bool(v)))
+
+    def calc(self, prevImg, nextImg, prevPts, nextPts=None, wantErr=True):
+        import torch
+        pp = prevPts.reshape(1, -1, 2).contiguous()
+        n = pp.shape[1]
+        if n == 0:      # pyrlk.cpp:209-215: empty input releases the outputs
+            e = torch.empty((1, 0), device=prevImg.device)
+            return torch.empty((1, 0, 2), device=prevImg.device), e.to(torch.uint8), (e if wantErr else None)
+        if self._p.use_initial_flow:
+            if nextPts is None or nextPts.numel() != pp.numel():
+                raise capi.MiError(-1, "nextPts.size() == prevPts.size() (useInitialFlow)")   # :160
+            npts = nextPts.reshape(1, -1, 2).contiguous().clone()
+        else:
+            npts = torch.empty_like(pp)
+        status = torch.empty((1, n), dtype=torch.uint8, device=prevImg.device)
+        err = torch.empty((1, n), dtype=torch.float32, device=prevImg.device) if wantErr else None
+        capi.check(capi.lib().mi_sparsepyrlk_calc(self._h, C.byref(_m(prevImg)), C.byref(_m(nextImg)), C.byref(_m(pp)), C.byref(_m(npts)),
+                                                  C.byref(_m(status)), C.byref(_m(err)) if wantErr else None, capi.current_stream_ptr()))
+        return npts, status, err
+
+
 class StereoSGM:
     """cv::cuda::StereoSGM (cudastereo.hpp; cudastereo/src/stereosgm.cpp:20-153): semi-global matching on census costs,
     4 (MODE_HH4) or 8 (MODE_HH) paths, CV_16SC1 output with 4 fractional bits."""

@@ -520,6 +520,31 @@ def surf_detect_describe(img, params: SURFParams | None = None, mask=None, want_
             "descriptors": desc[:n].copy() if want_desc else None}
 
 
+def pyrlk_sparse(prev, nxt, prev_pts, win_size=(21, 21), max_level=3, iters=30, next_pts=None):
+    """cv::cuda::SparsePyrLKOpticalFlow on CV_8UC1 frames (oracle/pyrlk_ref.c).  prev_pts (N, 2) float32; next_pts given = useInitialFlow.
+    -> (next_pts (N, 2), status (N,) uint8, err (N,) float32)."""
+    prev, nxt = _u8(prev), _u8(nxt)
+    if prev.shape != nxt.shape:
+        raise ValueError("prevImg.size() == nextImg.size()")
+    pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+    n = pp.shape[0]
+    use_init = next_pts is not None
+    out = np.ascontiguousarray(next_pts, np.float32).reshape(-1, 2).copy() if use_init else np.zeros_like(pp)
+    if out.shape != pp.shape:
+        raise ValueError("nextPts.size() == prevPts.size()")
+    st = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    L = lib()
+    L.orc_pyrlk_sparse.restype = C.c_int
+    L.orc_pyrlk_sparse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rc = L.orc_pyrlk_sparse(prev.ctypes.data, nxt.ctypes.data, prev.shape[0], prev.shape[1], pp.ctypes.data, out.ctypes.data, n,
+                            win_size[0], win_size[1], max_level, iters, int(use_init), st.ctypes.data, err.ctypes.data)
+    if rc:
+        raise ValueError(f"orc_pyrlk_sparse failed: {rc}")
+    return out, st, err
+
+
 # ------------------------------------------------------------------ the reference's CPU SURF class (oracle/surfcpu_ref.c)
 def surfcpu_detect(img, hessian_threshold=100.0, n_octaves=4, n_octave_layers=3, mask=None, cap=65536):
     """xfeatures2d::SURF::detect without the orientation pass -> (n, 7) float32 rows {x, y, size, angle = -1, response, octave,

@@ -52,6 +52,15 @@ PROP(cuda::DensePyrLKOpticalFlow, int, NumIters);
 PROP(cuda::DensePyrLKOpticalFlow, bool, UseInitialFlow);
 SAME(&cuda::DensePyrLKOpticalFlow::create, Ptr<cuda::DensePyrLKOpticalFlow> (*)(Size, int, int, bool));
 
+// ---- cudaoptflow.hpp:85-104 SparseOpticalFlow::calc, :203-223 SparsePyrLKOpticalFlow
+SAME(&cuda::SparseOpticalFlow::calc, void (cuda::SparseOpticalFlow::*)(cuda::InputArray, cuda::InputArray, cuda::InputArray, cuda::InputOutputArray,
+                                                                        cuda::OutputArray, cuda::OutputArray, Stream &));
+PROP(cuda::SparsePyrLKOpticalFlow, Size, WinSize);
+PROP(cuda::SparsePyrLKOpticalFlow, int, MaxLevel);
+PROP(cuda::SparsePyrLKOpticalFlow, int, NumIters);
+PROP(cuda::SparsePyrLKOpticalFlow, bool, UseInitialFlow);
+SAME(&cuda::SparsePyrLKOpticalFlow::create, Ptr<cuda::SparsePyrLKOpticalFlow> (*)(Size, int, int, bool));
+
 // ---- cudastereo.hpp:72-90 StereoBM + createStereoBM, :246-286 StereoSGM + createStereoSGM, :298-341 DisparityBilateralFilter
 SAME(static_cast<void (cuda::StereoBM::*)(cuda::InputArray, cuda::InputArray, cuda::OutputArray, Stream &)>(&cuda::StereoBM::compute),
      void (cuda::StereoBM::*)(cuda::InputArray, cuda::InputArray, cuda::OutputArray, Stream &));
@@ -129,6 +138,7 @@ void defaults_compile_only()
     (void)sizeof(cuda::OpticalFlowDual_TVL1::create());
     (void)sizeof(cuda::FarnebackOpticalFlow::create());
     (void)sizeof(cuda::DensePyrLKOpticalFlow::create());
+    (void)sizeof(cuda::SparsePyrLKOpticalFlow::create());
     (void)sizeof(cuda::createStereoBM());
     (void)sizeof(cuda::createStereoSGM());
     (void)sizeof(cuda::createDisparityBilateralFilter());

@@ -51,7 +51,7 @@ def test_no_cpu_fallback_without_device():
     # every other class of the library refuses just as loudly (there is no CPU path anywhere behind the C-ABI)
     for make in (lambda: cuda.createStereoBM(64, 15), lambda: cuda.FarnebackOpticalFlow.create(), lambda: cuda.SURF_CUDA.create(400),
                  lambda: cuda.createStereoSGM(), lambda: cuda.createDisparityBilateralFilter(), lambda: cuda.createBFMatcher(),
-                 lambda: cuda.DensePyrLKOpticalFlow.create()):
+                 lambda: cuda.DensePyrLKOpticalFlow.create(), lambda: cuda.SparsePyrLKOpticalFlow.create()):
         with pytest.raises(capi.MiError) as ei:
             make()
         assert "no CPU fallback" in str(ei.value) or ei.value.args[0] == -7
