@@ -294,6 +294,20 @@ def bench_farneback(args):
     torch.cuda.synchronize()
     out["dense_pyrlk_pairs_per_s"] = 10 / (time.perf_counter() - tq)
     out["dense_pyrlk_epe_vs_analytic_flow_px"] = float(synth.epe(flow.cpu().numpy()[40:-40, 40:-40], gt[40:-40, 40:-40]))
+    # and the sparse sibling: 10 000 points on the same pair, SparsePyrLKOpticalFlow((21, 21), 3, 30)
+    try:
+        rng = np.random.default_rng(0)
+        pts = torch.from_numpy(np.stack([rng.uniform(0, W, 10000), rng.uniform(0, H, 10000)], 1).astype(np.float32)).to(dev)
+        slk = cuda.SparsePyrLKOpticalFlow.create()
+        slk.calc(t0_, t1_, pts)
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for _ in range(10):
+            slk.calc(t0_, t1_, pts)
+        torch.cuda.synchronize()
+        out["sparse_pyrlk_points_per_s"] = 10 * 10000 / (time.perf_counter() - tq)
+    except Exception as e:
+        out["sparse_pyrlk_points_per_s"] = {"error": repr(e)[:200]}
     if not args.no_cpu:
         from oracle import oracle as O
         tq = time.perf_counter()
