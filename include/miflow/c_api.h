@@ -328,10 +328,12 @@ MI_API int mi_surfcpu_descriptors(const mi_mat *img, const mi_mat *keypoints, in
  * order of loopUnrolledCached, bf_match.cu:100-121, with nvcc's default mul+add contraction); L1: sum += fabsf(q[k] - t[k]).
  * Best lists are ordered by (distance, image index, train index): the first strict minimum in scan order, exact ties to the
  * lowest index (cv::BFMatcher's CPU rule; the reference's cross-thread reductions make its tie order scheduling dependent).
- * Other depths / NORM_HAMMING (the reference's u8 / u16 / s16 / s32 tables, brute_force_matcher.cpp:336-356) are not built:
- * MI_ERR_BAD_ARG / MI_ERR_BAD_TYPE. */
+ * Integer descriptors -- the other rows of the reference's (depth, norm) table, brute_force_matcher.cpp:336-356: NORM_L1 on
+ * MI_8UC1 / MI_16UC1 / MI_16SC1 / MI_32SC1, NORM_HAMMING on MI_8UC1 / MI_16UC1 / MI_32SC1 -- go through the same entry points
+ * (descriptors of up to 128 elements, k <= 16; exact integer distances returned as float).  Any other (depth, norm) pair fails
+ * with MI_ERR_BAD_TYPE like the reference's StsUnsupportedFormat. */
 typedef struct mi_bfmatcher mi_bfmatcher;
-enum { MI_NORM_L1 = 2, MI_NORM_L2 = 4 };                   /* cv::NORM_L1, cv::NORM_L2 */
+enum { MI_NORM_L1 = 2, MI_NORM_L2 = 4, MI_NORM_HAMMING = 6 };   /* cv::NORM_L1, cv::NORM_L2, cv::NORM_HAMMING */
 MI_API int mi_bf_create(int norm_type, mi_bfmatcher **out);
 MI_API void mi_bf_destroy(mi_bfmatcher *h);
 /* matchSingle: query n_q x D, train n_t x D (MI_32FC1), mask NULL or MI_8UC1 n_q x n_t (non-zero = allowed);

@@ -11,6 +11,7 @@
 // reference's summation order exactly (k ascending; L2: sum = fma(d, d, sum) then sqrtf; L1: sum += |d|), so the HIP result is
 // bit-identical to oracle/bfmatch_ref.c.
 #include "mi_common.h"
+#include "bf_dispatch.h"
 #include <cfloat>
 #include <climits>
 #include <cstdlib>
@@ -400,6 +401,9 @@ static int run_knn(mi_bfmatcher *h, const mi_mat *query, const mi_mat *trains, c
 {
     MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
     MI_REQUIRE(k >= 1, MI_ERR_BAD_ARG, "k >= 1");
+    if (query && query->type != MI_32FC1)          // integer descriptors: the other rows of the reference's (depth, norm) table
+        return bfint::knn(h->norm, query, trains, masks, n_trains, k, o.idx, o.istep, o.img, o.mstep, o.dist, o.dstep, st);
+    MI_REQUIRE(h->norm == MI_NORM_L1 || h->norm == MI_NORM_L2, MI_ERR_BAD_TYPE, "unsupported combination of query.depth() and norm");
     MI_REQUIRE(n_trains == 1 || o.img, MI_ERR_BAD_ARG, "a collection needs img_idx");
     const int K = k <= 2 ? 2 : 8;
     const Shape sh = knn_shape(query ? query->cols : 0, h->norm, K);
@@ -444,8 +448,8 @@ int mi_bf_create(int norm_type, mi_bfmatcher **out)
 {
     MI_REQUIRE(out, MI_ERR_BAD_ARG, "null out");
     *out = nullptr;
-    MI_REQUIRE(norm_type == MI_NORM_L2 || norm_type == MI_NORM_L1, MI_ERR_BAD_ARG,
-               "only NORM_L1 / NORM_L2 (float descriptors) are built");
+    MI_REQUIRE(norm_type == MI_NORM_L2 || norm_type == MI_NORM_L1 || norm_type == MI_NORM_HAMMING, MI_ERR_BAD_ARG,
+               "norm == NORM_L1 || norm == NORM_L2 || norm == NORM_HAMMING");      // BFMatcher_Impl constructor
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
         set_error("no HIP device available: the miflow product path has no CPU fallback");
@@ -509,6 +513,11 @@ int mi_bf_radius_match(mi_bfmatcher *h, const mi_mat *query, const mi_mat *train
     MI_REQUIRE(cols > 0 && bf::is_rows(train_idx, MI_32SC1, query->rows, cols) && bf::is_rows(distance, MI_32FC1, query->rows, cols) &&
                    (!img_idx || bf::is_rows(img_idx, MI_32SC1, query->rows, cols)) && bf::is_rows(n_matches, MI_32SC1, 1, query->rows),
                MI_ERR_BAD_SIZE, "train_idx / img_idx CV_32SC1, distance CV_32FC1: query.rows x cols; n_matches CV_32SC1 1 x query.rows");
+    if (query->type != MI_32FC1)
+        return bfint::radius(h->norm, query, trains, masks, n_trains, max_distance, cols, (int *)train_idx->data, train_idx->step / 4,
+                             img_idx ? (int *)img_idx->data : nullptr, img_idx ? img_idx->step / 4 : 0, (float *)distance->data,
+                             distance->step / 4, (int *)n_matches->data, st);
+    MI_REQUIRE(h->norm == MI_NORM_L1 || h->norm == MI_NORM_L2, MI_ERR_BAD_TYPE, "unsupported combination of query.depth() and norm");
     const bf::Shape sh = bf::radius_shape(query->cols, h->norm);
     std::vector<bf::Seg> segs;
     int nseg = 0;

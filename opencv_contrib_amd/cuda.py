@@ -454,7 +454,8 @@ class DMatch:
 
 
 class BFMatcher:
-    """cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L1 | NORM_L2) for float descriptors (cudafeatures2d.hpp;
+    """cv::cuda::DescriptorMatcher::createBFMatcher(NORM_L1 | NORM_L2 | NORM_HAMMING): float descriptors (L1 / L2) and integer ones
+    (L1 / Hamming: the reference's (depth, norm) table) (cudafeatures2d.hpp;
     cudafeatures2d/src/brute_force_matcher.cpp:143-1070; kernels cuda/bf_match.cu, bf_knnmatch.cu, bf_radius_match.cu).
 
     Three forms of every query, like the reference: `match / knnMatch / radiusMatch` return DMatch lists (host),
@@ -463,6 +464,7 @@ class BFMatcher:
 
     NORM_L1 = 2
     NORM_L2 = 4
+    NORM_HAMMING = 6      # integer descriptors (uint8 / uint16 / int32); NORM_L1 also takes uint8 / uint16 / int16 / int32
 
     def __init__(self, normType=4):
         self._h = C.c_void_p()
@@ -660,7 +662,7 @@ class DescriptorMatcher:
     createBFMatcher = staticmethod(createBFMatcher)
 
 
-NORM_L1, NORM_L2 = 2, 4
+NORM_L1, NORM_L2, NORM_HAMMING = 2, 4, 6
 
 
 class DisparityBilateralFilter:

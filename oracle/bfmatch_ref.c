@@ -102,3 +102,65 @@ int orc_bf_radius(const float *query, int nq, const float *const *trains, const 
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Integer descriptors (the reference's other (depth, norm) pairs, brute_force_matcher.cpp:336-356: NORM_L1 on CV_8U / 16U / 16S / 32S,
+ * NORM_HAMMING on CV_8U / 16U / 32S).  Elements arrive widened to int32 (zero extension for the unsigned depths, which leaves the
+ * bits Hamming counts unchanged); L1Dist<int types> accumulates |a - b| in an integer (__sad), HammingDist adds __popc(a ^ b), both
+ * are returned as float (vec_distance.hpp of the main repository, restated).  Same list order and radius rule as above. */
+enum { ORC_NORM_HAMMING = 6 };
+
+static float bf_distance_int(const int *qr, const int *tr, int d, int norm)
+{
+    unsigned sum = 0;
+    if (norm == ORC_NORM_HAMMING) for (int k = 0; k < d; ++k) sum += (unsigned)__builtin_popcount((unsigned)(qr[k] ^ tr[k]));
+    else for (int k = 0; k < d; ++k) { const long long v = (long long)qr[k] - tr[k]; sum += (unsigned)(v < 0 ? -v : v); }
+    return (float)sum;
+}
+
+int orc_bf_knn_int(const int *query, int nq, const int *const *trains, const int *nts, const unsigned char *const *masks, int n_img,
+                   int d, int norm, int k, int *idx, int *img, float *dist)
+{
+    if (nq <= 0 || n_img <= 0 || d <= 0 || k <= 0 || (norm != ORC_NORM_L1 && norm != ORC_NORM_HAMMING)) return -1;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nq; ++q) {
+        int *bi = idx + (size_t)q * k, *bm = img + (size_t)q * k;
+        float *bd = dist + (size_t)q * k;
+        for (int j = 0; j < k; ++j) { bi[j] = -1; bd[j] = FLT_MAX; bm[j] = -1; }
+        for (int m = 0; m < n_img; ++m) {
+            const unsigned char *mk = masks ? masks[m] : NULL;
+            for (int t = 0; t < nts[m]; ++t) {
+                if (mk && !mk[(size_t)q * nts[m] + t]) continue;
+                const float dv = bf_distance_int(query + (size_t)q * d, trains[m] + (size_t)t * d, d, norm);
+                int pos = k;
+                while (pos > 0 && dv < bd[pos - 1]) --pos;
+                if (pos == k) continue;
+                for (int j = k - 1; j > pos; --j) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; bm[j] = bm[j - 1]; }
+                bd[pos] = dv; bi[pos] = t; bm[pos] = m;
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_bf_radius_int(const int *query, int nq, const int *const *trains, const int *nts, const unsigned char *const *masks, int n_img,
+                      int d, int norm, float max_dist, int cols, int *idx, int *img, float *dist, int *n)
+{
+    if (nq <= 0 || n_img <= 0 || d <= 0 || cols <= 0 || (norm != ORC_NORM_L1 && norm != ORC_NORM_HAMMING)) return -1;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nq; ++q) {
+        int cnt = 0;
+        for (int m = 0; m < n_img; ++m) {
+            const unsigned char *mk = masks ? masks[m] : NULL;
+            for (int t = 0; t < nts[m]; ++t) {
+                if (mk && !mk[(size_t)q * nts[m] + t]) continue;
+                const float dv = bf_distance_int(query + (size_t)q * d, trains[m] + (size_t)t * d, d, norm);
+                if (!(dv < max_dist)) continue;
+                if (cnt < cols) { idx[(size_t)q * cols + cnt] = t; dist[(size_t)q * cols + cnt] = dv; img[(size_t)q * cols + cnt] = m; }
+                ++cnt;
+            }
+        }
+        n[q] = cnt;
+    }
+    return 0;
+}

@@ -670,10 +670,26 @@ def bf_knn_match2(query, train, mask=None):
 NORM_L1, NORM_L2 = 2, 4   # cv::NormTypes
 
 
-def _bf_collection(query, trains, masks):
-    q = np.ascontiguousarray(query, dtype=np.float32)
+NORM_HAMMING = 6
+_BF_INT_DEPTHS = {"uint8": (NORM_L1, NORM_HAMMING), "uint16": (NORM_L1, NORM_HAMMING), "int16": (NORM_L1,), "int32": (NORM_L1, NORM_HAMMING)}
+
+
+def _bf_is_int(query, norm):
+    """(depth, norm) table of the reference (brute_force_matcher.cpp:336-356): float32 -> L1 / L2; integer depths -> the int path."""
+    dt = np.asarray(query).dtype
+    if dt == np.float32 or dt == np.float64:
+        if norm not in (NORM_L1, NORM_L2):
+            raise ValueError("unsupported combination of query.depth() and norm")
+        return False
+    if dt.name not in _BF_INT_DEPTHS or norm not in _BF_INT_DEPTHS[dt.name]:
+        raise ValueError("unsupported combination of query.depth() and norm")
+    return True
+
+
+def _bf_collection(query, trains, masks, dtype=np.float32):
+    q = np.ascontiguousarray(query, dtype=dtype)
     single = isinstance(trains, np.ndarray)
-    ts = [np.ascontiguousarray(t, dtype=np.float32) for t in ([trains] if single else trains)]
+    ts = [np.ascontiguousarray(t, dtype=dtype) for t in ([trains] if single else trains)]
     if q.ndim != 2 or not ts or any(t.ndim != 2 or t.shape[1] != q.shape[1] for t in ts):
         raise ValueError("query.cols == train.cols")
     if masks is None:
@@ -692,16 +708,17 @@ def _bf_collection(query, trains, masks):
 def bf_knn_match(query, trains, k, norm=NORM_L2, masks=None):
     """trains: one (nt, d) array or a list of them (collection).  -> (train_idx, img_idx, distance), each (nq, k); missing
     entries are (-1, -1, FLT_MAX)."""
-    q, ts, ms, n, tp, nts, mp = _bf_collection(query, trains, masks)
+    is_int = _bf_is_int(query, norm)
+    q, ts, ms, n, tp, nts, mp = _bf_collection(query, trains, masks, np.int32 if is_int else np.float32)
     idx = np.empty((q.shape[0], k), np.int32)
     img = np.empty((q.shape[0], k), np.int32)
     dist = np.empty((q.shape[0], k), np.float32)
     L = lib()
-    L.orc_bf_knn.restype = C.c_int
-    L.orc_bf_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                             C.c_void_p, C.c_void_p, C.c_void_p]
-    rc = L.orc_bf_knn(q.ctypes.data, q.shape[0], tp, nts, mp, n, q.shape[1], norm, k, idx.ctypes.data, img.ctypes.data,
-                      dist.ctypes.data)
+    fn = L.orc_bf_knn_int if is_int else L.orc_bf_knn
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = fn(q.ctypes.data, q.shape[0], tp, nts, mp, n, q.shape[1], norm, k, idx.ctypes.data, img.ctypes.data, dist.ctypes.data)
     if rc:
         raise ValueError(f"orc_bf_knn failed: {rc}")
     return idx, img, dist
@@ -710,17 +727,19 @@ def bf_knn_match(query, trains, k, norm=NORM_L2, masks=None):
 def bf_radius_match(query, trains, max_distance, cols, norm=NORM_L2, masks=None):
     """-> (train_idx, img_idx, distance) each (nq, cols) (entries past min(n, cols) are -1 / -1 / 0) and n (nq,), the number of
     train descriptors closer than max_distance; stored in ascending (image, train) order."""
-    q, ts, ms, n, tp, nts, mp = _bf_collection(query, trains, masks)
+    is_int = _bf_is_int(query, norm)
+    q, ts, ms, n, tp, nts, mp = _bf_collection(query, trains, masks, np.int32 if is_int else np.float32)
     idx = np.full((q.shape[0], cols), -1, np.int32)
     img = np.full((q.shape[0], cols), -1, np.int32)
     dist = np.zeros((q.shape[0], cols), np.float32)
     cnt = np.zeros(q.shape[0], np.int32)
     L = lib()
-    L.orc_bf_radius.restype = C.c_int
-    L.orc_bf_radius.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
-                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    rc = L.orc_bf_radius(q.ctypes.data, q.shape[0], tp, nts, mp, n, q.shape[1], norm, max_distance, cols, idx.ctypes.data,
-                         img.ctypes.data, dist.ctypes.data, cnt.ctypes.data)
+    fn = L.orc_bf_radius_int if is_int else L.orc_bf_radius
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = fn(q.ctypes.data, q.shape[0], tp, nts, mp, n, q.shape[1], norm, max_distance, cols, idx.ctypes.data,
+            img.ctypes.data, dist.ctypes.data, cnt.ctypes.data)
     if rc:
         raise ValueError(f"orc_bf_radius failed: {rc}")
     return idx, img, dist, cnt

@@ -364,7 +364,9 @@ def test_mask_pitched_inputs_legacy_entry_points_and_errors(gpu, oracle):
     with pytest.raises(capi.MiError):
         m.knnMatchAsync(qc, None, k=3)                                                          # reference: only k = 2 over a collection
     with pytest.raises(capi.MiError):
-        cuda.createBFMatcher(6)                                                                 # NORM_HAMMING: not built
+        cuda.createBFMatcher(7)                                                                 # NORM_HAMMING2: norm == L1 || L2 || HAMMING
+    with pytest.raises(capi.MiError):
+        cuda.createBFMatcher(cuda.BFMatcher.NORM_HAMMING).matchDevice(qc, tt)                   # Hamming on CV_32F: unsupported combination
 
 
 @pytest.mark.gpu

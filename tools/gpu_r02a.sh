@@ -6,7 +6,7 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/r02a
 mkdir -p $O
-(timeout 120 python -m pytest tests/test_zz_surf_cpu_class.py tests/test_zzz_surf_cpu_class_hip.py tests/test_zzz_sparse_pyrlk_hip.py -m gpu -q -p no:cacheprovider 2>&1 | tail -25) > $O/pytest_new.log
+(timeout 120 python -m pytest tests/test_zz_surf_cpu_class.py tests/test_zzz_surf_cpu_class_hip.py tests/test_zzz_sparse_pyrlk_hip.py tests/test_zzz_bfmatch_int_hip.py -m gpu -q -p no:cacheprovider 2>&1 | tail -25) > $O/pytest_new.log
 (timeout 200 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -12) > $O/pytest_gpu.log
 (timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4) > $O/smoke.log
 (timeout 300 python bench.py 2>$O/bench.err | tail -1) > $O/bench.json
