@@ -70,6 +70,32 @@ def test_bfmatch_oracle_matches_golden(oracle, path):
 
 
 # ------------------------------------------------------------------ HIP vs golden (GPU)
+@pytest.mark.parametrize("path", _files("surfcpu"))
+def test_cpu_class_surf_oracle_matches_golden(oracle, path):
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    kp = oracle.surfcpu_detect(z["img"], kw["hessian_threshold"], kw["n_octaves"], kw["n_octave_layers"])
+    np.testing.assert_array_equal(kp, z["detected"])
+    k2, d2 = oracle.surfcpu_compute(z["img"], kp, kw["extended"], kw["upright"])
+    np.testing.assert_array_equal(k2, z["keypoints"]); np.testing.assert_array_equal(d2, z["descriptors"])
+
+
+@pytest.mark.parametrize("path", _files("sparselk"))
+def test_sparse_pyrlk_oracle_matches_golden(oracle, path):
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    nxt, st, err = oracle.pyrlk_sparse(z["I0"], z["I1"], z["prev_pts"], tuple(kw["win_size"]), kw["max_level"], kw["iters"])
+    np.testing.assert_array_equal(nxt, z["next_pts"]); np.testing.assert_array_equal(st, z["status"]); np.testing.assert_array_equal(err, z["err"])
+
+
+@pytest.mark.parametrize("path", _files("bfint"))
+def test_integer_matcher_oracle_matches_golden(oracle, path):
+    z = np.load(path)
+    kw = json.loads(str(z["params"]))
+    idx, img, dist = oracle.bf_knn_match(z["query"], [z["train0"], z["train1"]], kw["k"], kw["norm"])
+    np.testing.assert_array_equal(idx, z["idx"]); np.testing.assert_array_equal(img, z["img"]); np.testing.assert_array_equal(dist, z["dist"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", _files("sgm"))
 def test_stereosgm_hip_matches_golden(gpu, path):

@@ -92,8 +92,31 @@ def bfmatch():
     np.savez_compressed(os.path.join(OUT, "bf_60x90x64.npz"), query=q, train=t, idx=idx, dist=dist, params=np.array(json.dumps({})))
 
 
+def late_additions():
+    """CPU-class SURF, sparse PyrLK, integer-descriptor matcher (written at the end of round 1)."""
+    img = synth.blob_image(160, 200, seed=7)
+    kp = O.surfcpu_detect(img, 300.0, 3, 2)
+    k2, d2 = O.surfcpu_compute(img, kp, True, False)
+    np.savez_compressed(os.path.join(OUT, "surfcpu_160x200_thr300_ext.npz"), img=img, detected=kp, keypoints=k2, descriptors=d2,
+                        params=np.array(json.dumps(dict(hessian_threshold=300.0, n_octaves=3, n_octave_layers=2, extended=True, upright=False))))
+    I0, I1, _ = synth.flow_pair(120, 160, seed=1234, dtype="u8")
+    pts = np.stack([np.random.default_rng(5).uniform(-5, 165, 200), np.random.default_rng(6).uniform(-5, 125, 200)], 1).astype(np.float32)
+    nxt, st, err = O.pyrlk_sparse(I0, I1, pts, (21, 21), 3, 30)
+    np.savez_compressed(os.path.join(OUT, "sparselk_u8_120x160_w21_l3.npz"), I0=I0, I1=I1, prev_pts=pts, next_pts=nxt, status=st, err=err,
+                        params=np.array(json.dumps(dict(win_size=[21, 21], max_level=3, iters=30))))
+    rng = np.random.default_rng(77)
+    q = rng.integers(0, 256, (70, 32)).astype(np.uint8)
+    trains = [rng.integers(0, 256, (n, 32)).astype(np.uint8) for n in (90, 40)]
+    idx, img_, dist = O.bf_knn_match(q, trains, 3, O.NORM_HAMMING)
+    np.savez_compressed(os.path.join(OUT, "bfint_u8_hamming_70x130x32.npz"), query=q, train0=trains[0], train1=trains[1], idx=idx, img=img_,
+                        dist=dist, params=np.array(json.dumps(dict(norm=6, k=3))))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--late" in sys.argv:
+        late_additions()
+        sys.exit(0)
     stereo_next()
     bfmatch()
     tvl1()
