@@ -72,19 +72,19 @@ def time_steps(alg, I0, I1, flows, steps, warmup, dist):
     return time.perf_counter() - t0
 
 
-def two_stream_rate(args, I0, I1, flows_like, steps):
-    """pairs/s of the resident batch processed as two half batches by two algorithm objects on two HIP streams."""
+def two_stream_rate(args, I0, I1, flows_like, steps, ns=2):
+    """pairs/s of the resident batch processed as `ns` equal parts by `ns` algorithm objects on `ns` HIP streams."""
     import torch
     from opencv_contrib_amd import cuda
     B = I0.shape[0]
-    h = B // 2
+    h = B // ns
     out = torch.empty_like(flows_like)
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream() for _ in range(ns)]
     algs = [cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
-                                             timeBlock=args.time_block) for _ in range(2)]
+                                             timeBlock=args.time_block) for _ in range(ns)]
 
     def step():
-        for k in range(2):
+        for k in range(ns):
             with torch.cuda.stream(streams[k]):
                 algs[k].calc_batch(I0[k * h:(k + 1) * h], I1[k * h:(k + 1) * h], out[k * h:(k + 1) * h])
 
@@ -536,6 +536,11 @@ def main():
                 var["two_streams_half_batches"] = {"pairs_per_s": two_stream_rate(args, I0, I1, flows, max(2, args.steps // 2))}
             except Exception as e:   # never at the expense of the headline line
                 var["two_streams_half_batches"] = {"error": repr(e)[:200]}
+            if B % 4 == 0:
+                try:
+                    var["four_streams_quarter_batches"] = {"pairs_per_s": two_stream_rate(args, I0, I1, flows, max(2, args.steps // 2), ns=4)}
+                except Exception as e:
+                    var["four_streams_quarter_batches"] = {"error": repr(e)[:200]}
         # SURVEY 8d config 2 "also run CV_8UC1": the same batch as 8-bit frames (the class converts them to f32 once per calc)
         try:
             a8 = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
