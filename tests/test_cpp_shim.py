@@ -93,3 +93,18 @@ def test_shim_matches_python_mirror_on_gpu(gpu, tmp_path):
     np.testing.assert_array_equal(sr[: 96 * 160].reshape(96, 160), pf[..., 0])
     np.testing.assert_array_equal(sr[96 * 160: 2 * 96 * 160].reshape(96, 160), pf[..., 1])
     np.testing.assert_array_equal(sr[2 * 96 * 160:].reshape(96, 160, 2), fbflow)
+
+
+def test_samples_compile_against_the_drop_in_headers(tmp_path):
+    """samples/optical_flow.cpp follows the reference's sample (cudaoptflow/samples/optical_flow.cpp); it must build with nothing but
+    the headers of this repository and fail loudly without a GPU."""
+    import torch
+    exe = str(tmp_path / "optical_flow")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "samples", "optical_flow.cpp"),
+                        "-o", exe, "-L" + LIBDIR, "-lmiflow", "-Wl,-rpath," + LIBDIR], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if not torch.cuda.is_available():
+        run = subprocess.run([exe], capture_output=True, text=True)
+        assert run.returncode == 3 and "error" in run.stderr
+    import ast
+    ast.parse(open(os.path.join(ROOT, "samples", "optical_flow.py")).read())
