@@ -82,6 +82,8 @@ def lib():
                                     C.c_int, C.c_long, _f32p, C.POINTER(TVL1Stats)]
         L.orc_tvl1_centered_gradient.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
         L.orc_tvl1_warp.argtypes = [C.c_int] + [_f32p] * 6 + [C.c_int, C.c_int] + [_f32p] * 5
+        L.orc_tvl1_proc_one_scale.argtypes = [C.POINTER(TVL1Params), _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p]
         L.orc_tvl1_iteration.restype = C.c_float
         L.orc_tvl1_iteration.argtypes = [C.c_int] + [_f32p] * 4 + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 4
         _bind_stereobm(L)
@@ -282,6 +284,16 @@ def tvl1_iteration(semantics, I1wx, I1wy, grad, rho_c, u1, u2, p11, p12, p21, p2
     if u3 is not None:
         out = out + (u3c, p3[0], p3[1])
     return out
+
+
+def tvl1_proc_one_scale(I0, I1, u1, u2, params: TVL1Params):
+    """One pyramid level (gamma == 0): returns (u1, u2, iterations executed per warp)."""
+    I0, I1 = _c(I0), _c(I1)
+    u1, u2 = _c(u1).copy(), _c(u2).copy()
+    h, w = I0.shape
+    iters = np.zeros(64, np.int32)
+    lib().orc_tvl1_proc_one_scale(C.byref(params), I0, I1, u1, u2, None, w, h, iters.ctypes.data)
+    return u1, u2, iters[:params.warps].copy()
 
 
 # ---------------------------------------------------------------- StereoBM (cv::cuda::StereoBM semantics)

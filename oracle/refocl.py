@@ -1,0 +1,104 @@
+"""ctypes front-end of oracle/_ref/libref_ocl*.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+oracle/_ref holds the reference's OWN OpenCL kernel sources (modules/optflow/src/opencl/optical_flow_tvl1.cl,
+modules/xfeatures2d/src/opencl/surf.cl), compiled verbatim for x86-64 by `make -f oracle/Makefile.ref` and run on
+the CPU through the execution shim in oracle/refshim/.  It is what the restated oracles are pinned against
+(tests/test_ref_pin.py).  /root/reference exists only in the build container: the .so files are built there and
+travel with the repository snapshot; nothing here reads /root/reference at run time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DIR = os.path.join(_HERE, "_ref")
+REF_ROOT = os.environ.get("MIFLOW_REFERENCE", "/root/reference")
+_libs = {}
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+def lib_path(fma: bool = False) -> str:
+    return os.path.join(_DIR, "libref_ocl_fma.so" if fma else "libref_ocl.so")
+
+
+def can_build() -> bool:
+    return os.path.isdir(os.path.join(REF_ROOT, "modules", "optflow", "src", "opencl"))
+
+
+def build(force: bool = False) -> bool:
+    """Builds oracle/_ref when the reference tree is present (build container); True if the libraries exist."""
+    if can_build():
+        cmd = ["make", "-s", "-C", _HERE, "-f", "Makefile.ref", "REF=" + REF_ROOT] + (["-B"] if force else [])
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    return available()
+
+
+def available() -> bool:
+    return os.path.exists(lib_path(False)) and os.path.exists(lib_path(True))
+
+
+def lib(fma: bool = False):
+    key = bool(fma)
+    if key not in _libs:
+        if not available():
+            build()
+        L = C.CDLL(lib_path(fma))
+        i, f, d = C.c_int, C.c_float, C.c_double
+        L.ref_ocl_tvl1_centered_gradient.argtypes = [_f32p, i, i, _f32p, _f32p]
+        L.ref_ocl_tvl1_warp.argtypes = [_f32p] * 6 + [i, i] + [_f32p] * 5
+        L.ref_ocl_tvl1_estimate_u.argtypes = [_f32p] * 11 + [i, i, f, f, i]
+        L.ref_ocl_tvl1_estimate_dual.argtypes = [_f32p] * 6 + [i, i, f]
+        L.ref_ocl_tvl1_proc_one_scale.argtypes = [_f32p] * 4 + [i, i, d, d, d, d, i, i, i, C.c_void_p]
+        _libs[key] = L
+    return _libs[key]
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def tvl1_centered_gradient(src, fma=False):
+    src = _c(src)
+    h, w = src.shape
+    dx, dy = np.empty_like(src), np.empty_like(src)
+    lib(fma).ref_ocl_tvl1_centered_gradient(src, w, h, dx, dy)
+    return dx, dy
+
+
+def tvl1_warp(I0, I1, I1x, I1y, u1, u2, fma=False):
+    a = [_c(x) for x in (I0, I1, I1x, I1y, u1, u2)]
+    h, w = a[0].shape
+    out = [np.empty((h, w), np.float32) for _ in range(5)]
+    lib(fma).ref_ocl_tvl1_warp(*a, w, h, *out)
+    return tuple(out)   # I1w, I1wx, I1wy, grad, rho_c
+
+
+def tvl1_iteration(I1wx, I1wy, grad, rho_c, u1, u2, p11, p12, p21, p22, l_t, theta, taut, fma=False):
+    """estimateUKernel (with the error plane) then estimateDualVariablesKernel, on copies.
+    Returns (error plane, u1, u2, p11, p12, p21, p22)."""
+    st = [_c(x) for x in (I1wx, I1wy, grad, rho_c)]
+    u = [_c(x).copy() for x in (u1, u2)]
+    p = [_c(x).copy() for x in (p11, p12, p21, p22)]
+    h, w = st[0].shape
+    err = np.zeros((h, w), np.float32)
+    L = lib(fma)
+    L.ref_ocl_tvl1_estimate_u(*st, *p, u[0], u[1], err, w, h, l_t, theta, 1)
+    L.ref_ocl_tvl1_estimate_dual(u[0], u[1], *p, w, h, taut)
+    return (err, u[0], u[1], *p)
+
+
+def tvl1_proc_one_scale(I0, I1, u1, u2, tau=0.25, lambda_=0.15, theta=0.3, epsilon=0.01, warps=5, inner_iterations=1,
+                        outer_iterations=300, fma=False):
+    """OpticalFlowDual_TVL1::procOneScale_ocl on the reference kernels; returns (u1, u2, iterations per warp)."""
+    I0, I1 = _c(I0), _c(I1)
+    u1, u2 = _c(u1).copy(), _c(u2).copy()
+    h, w = I0.shape
+    iters = np.zeros(max(warps, 1), np.int32)
+    lib(fma).ref_ocl_tvl1_proc_one_scale(I0, I1, u1, u2, w, h, tau, lambda_, theta, epsilon, warps, inner_iterations,
+                                         outer_iterations, iters.ctypes.data)
+    return u1, u2, iters[:warps]

@@ -305,6 +305,14 @@ static void proc_one_scale(const orc_tvl1_params *P, const level_t *L, int *iter
     free(p11); free(p12); free(p21); free(p22); free(p31); free(p32); free(tmp);
 }
 
+void orc_tvl1_proc_one_scale(const orc_tvl1_params *P, const float *I0, const float *I1, float *u1, float *u2,
+                             float *u3, int w, int h, int *iters_out)
+{
+    level_t L;
+    L.w = w; L.h = h; L.I0 = (float *)I0; L.I1 = (float *)I1; L.u1 = u1; L.u2 = u2; L.u3 = u3;
+    proc_one_scale(P, &L, iters_out);
+}
+
 int orc_tvl1_calc(const orc_tvl1_params *P, const void *I0, const void *I1, int type, int w, int h,
                   long src_step, float *flow, orc_tvl1_stats *stats)
 {

@@ -55,6 +55,11 @@ float orc_tvl1_iteration(int semantics, const float *I1wx, const float *I1wy, co
                          float *p12, float *p21, float *p22, float *p31, float *p32, int w, int h,
                          float l_t, float theta, float taut, float gamma);
 
+/* one pyramid level: gradient, `warps` x (warp + iteration loop with the class's convergence rule), in place on
+ * u1, u2 (u3 when gamma != 0).  iters_out[warp] = executed inner iterations (may be NULL). */
+void orc_tvl1_proc_one_scale(const orc_tvl1_params *p, const float *I0, const float *I1, float *u1, float *u2,
+                             float *u3, int w, int h, int *iters_out);
+
 #ifdef __cplusplus
 }
 #endif

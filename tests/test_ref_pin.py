@@ -1,0 +1,146 @@
+"""PINNING: the restated oracle against REFERENCE CODE EXECUTED HERE.
+
+oracle/_ref/libref_ocl.so is the reference's own OpenCL kernel source
+(modules/optflow/src/opencl/optical_flow_tvl1.cl:46-378), compiled verbatim for x86-64 by clang's OpenCL C front end
+(oracle/Makefile.ref) and run on the CPU through the NDRange shim of oracle/refshim/.  These kernels are the OpenCL
+twins of cudaoptflow/src/cuda/tvl1flow.cu:59-348, i.e. the arithmetic the `MI_SEM_CUDA_COMPAT` oracle restates.
+
+What is asserted, on the same seeded inputs:
+  * every stage of oracle/tvl1_ref.c (semantics CUDA_COMPAT) equals the reference kernel BIT FOR BIT when both are
+    compiled with separately rounded operations (-ffp-contract=off);
+  * the whole per-scale loop (gradient, warps x (warp + estimateU / estimateDualVariables with the sparse convergence
+    check of procOneScale_ocl, optflow/src/tvl1flow.cpp:1224-1310 == cudaoptflow/src/tvl1flow.cpp:304-382)) yields the
+    same flow bit for bit and the same iteration counts;
+  * the freedom a device compiler has (OpenCL C's default FP_CONTRACT ON, nvcc -fmad=true: a*b+c may be fused) is
+    bounded: a second build of the same reference source with contraction allowed stays within a stated distance.
+The `-m gpu` leg holds the HIP kernels to the reference kernels directly.
+"""
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+from oracle import refocl
+
+pytestmark = pytest.mark.skipif(not (refocl.available() or refocl.can_build()),
+                                reason="oracle/_ref not built and /root/reference absent")
+
+SIZES = [(77, 101, 3), (96, 128, 5), (64, 64, 11), (33, 250, 7)]
+
+
+def _pair(h, w, seed):
+    I0, I1, _ = synth.flow_pair(h, w, seed=seed)
+    return (I0 * np.float32(255)).astype(np.float32), (I1 * np.float32(255)).astype(np.float32)
+
+
+def _flow(h, w, seed, amp):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((h, w)) * amp).astype(np.float32), (rng.standard_normal((h, w)) * amp).astype(np.float32)
+
+
+@pytest.mark.parametrize("h,w,seed", SIZES)
+def test_centered_gradient_equals_reference_kernel(oracle, h, w, seed):
+    _, I1 = _pair(h, w, seed)
+    rx, ry = refocl.tvl1_centered_gradient(I1)
+    ox, oy = oracle.tvl1_centered_gradient(I1)
+    np.testing.assert_array_equal(ox, rx)
+    np.testing.assert_array_equal(oy, ry)
+
+
+@pytest.mark.parametrize("amp", [0.0, 1.5, 8.0, 400.0])   # 400 px: every tap clamped far outside the image
+@pytest.mark.parametrize("h,w,seed", SIZES)
+def test_warp_equals_reference_kernel(oracle, h, w, seed, amp):
+    I0, I1 = _pair(h, w, seed)
+    I1x, I1y = refocl.tvl1_centered_gradient(I1)
+    u1, u2 = _flow(h, w, seed + 100, amp)
+    if amp == 0.0:
+        u1[::3, ::5] = 0.5   # exact half-pixel phases: the 5-tap rows of the [ceil(w-2), floor(w+2)] window
+        u2[1::4, ::2] = -1.0
+    ref = refocl.tvl1_warp(I0, I1, I1x, I1y, u1, u2)
+    got = oracle.tvl1_warp(1, I0, I1, I1x, I1y, u1, u2)
+    for name, r, g in zip(("I1w", "I1wx", "I1wy", "grad", "rho_c"), ref, got):
+        np.testing.assert_array_equal(g, r, err_msg=name)
+
+
+@pytest.mark.parametrize("h,w,seed", SIZES)
+def test_iteration_equals_reference_kernels(oracle, h, w, seed):
+    I0, I1 = _pair(h, w, seed)
+    I1x, I1y = refocl.tvl1_centered_gradient(I1)
+    u1, u2 = _flow(h, w, seed + 1, 2.0)
+    _, I1wx, I1wy, grad, rho_c = refocl.tvl1_warp(I0, I1, I1x, I1y, u1, u2)
+    grad[::7, ::3] = 0   # the gradVal <= FLT_EPSILON branch of the thresholding step
+    p = [x for pair in (_flow(h, w, seed + 2, 0.4), _flow(h, w, seed + 3, 0.4)) for x in pair]
+    l_t, theta, taut = np.float32(0.15 * 0.3), np.float32(0.3), np.float32(0.25 / 0.3)
+    u1r, u2r, pr = u1, u2, p
+    u1o, u2o, po = u1, u2, p
+    for it in range(3):
+        r = refocl.tvl1_iteration(I1wx, I1wy, grad, rho_c, u1r, u2r, *pr, l_t, theta, taut)
+        o = oracle.tvl1_iteration(1, I1wx, I1wy, grad, rho_c, u1o, u2o, *po, l_t, theta, taut)
+        for k, name in enumerate(("u1", "u2", "p11", "p12", "p21", "p22")):
+            np.testing.assert_array_equal(o[1 + k], r[1 + k], err_msg=f"{name} after iteration {it + 1}")
+        # cv::sum(diff)[0] of the reference's error plane (double accumulator) == the oracle's error
+        assert np.float32(r[0].astype(np.float64).sum()) == np.float32(o[0])
+        u1r, u2r, pr = r[1], r[2], list(r[3:])
+        u1o, u2o, po = o[1], o[2], list(o[3:])
+
+
+@pytest.mark.parametrize("eps,iters", [(0.0, 10), (0.01, 300), (0.05, 40)])
+@pytest.mark.parametrize("h,w,seed", SIZES[:2])
+def test_proc_one_scale_equals_reference_loop(oracle, h, w, seed, eps, iters):
+    """The per-scale loop on the reference kernels vs oracle.tvl1 (CUDA_COMPAT): flow bit for bit, iteration counts equal."""
+    I0, I1 = _pair(h, w, seed)
+    u1, u2 = _flow(h, w, seed + 9, 0.5)
+    P = oracle.tvl1_params(semantics=1, epsilon=eps, outer_iterations=iters, inner_iterations=1, median_filtering=1)
+    o1, o2, oit = oracle.tvl1_proc_one_scale(I0, I1, u1, u2, P)
+    r1, r2, rit = refocl.tvl1_proc_one_scale(I0, I1, u1, u2, epsilon=eps, outer_iterations=iters)
+    np.testing.assert_array_equal(oit, rit)
+    if eps > 0:
+        assert 2 <= rit.min() < iters, "the convergence rule must be what stops some of these warps"
+    np.testing.assert_array_equal(o1, r1)
+    np.testing.assert_array_equal(o2, r2)
+
+
+def test_contraction_freedom_is_bounded(oracle):
+    """Same reference source, built with a*b+c fusion allowed (what a device compiler may do): stage outputs move by a few
+    ulp of the plane's scale, and a 10-iteration scale by < 1e-4 px -- two orders below the parity bounds used on the GPU."""
+    h, w, seed = 96, 128, 5
+    I0, I1 = _pair(h, w, seed)
+    I1x, I1y = refocl.tvl1_centered_gradient(I1)
+    u1, u2 = _flow(h, w, seed + 100, 1.5)
+    a = refocl.tvl1_warp(I0, I1, I1x, I1y, u1, u2)
+    b = refocl.tvl1_warp(I0, I1, I1x, I1y, u1, u2, fma=True)
+    assert any(not np.array_equal(x, y) for x, y in zip(a, b)), "the contracted build must really differ"
+    for name, x, y in zip(("I1w", "I1wx", "I1wy"), a, b):
+        assert np.abs(x - y).max() <= 4e-6 * max(1.0, np.abs(x).max()), name
+    z = np.zeros((h, w), np.float32)
+    r1, r2, _ = refocl.tvl1_proc_one_scale(I0, I1, z, z, epsilon=0.0, outer_iterations=10)
+    f1, f2, _ = refocl.tvl1_proc_one_scale(I0, I1, z, z, epsilon=0.0, outer_iterations=10, fma=True)
+    assert synth.epe(np.stack([r1, r2], -1), np.stack([f1, f2], -1)) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- HIP vs the reference kernels
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,seed", SIZES[:2])
+def test_hip_stages_against_reference_kernels(gpu, h, w, seed):
+    import torch
+    from opencv_contrib_amd import capi, cuda
+    I0, I1 = _pair(h, w, seed)
+    rx, ry = refocl.tvl1_centered_gradient(I1)
+    dx, dy = cuda.tvl1_centeredGradient(torch.from_numpy(I1).to(gpu))
+    np.testing.assert_array_equal(dx.cpu().numpy(), rx)
+    np.testing.assert_array_equal(dy.cpu().numpy(), ry)
+    u1, u2 = _flow(h, w, seed + 100, 1.5)
+    ref = refocl.tvl1_warp(I0, I1, rx, ry, u1, u2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    got = cuda.tvl1_warpBackward(capi.MI_SEM_CUDA_COMPAT, t(I0), t(I1), t(rx), t(ry), t(u1), t(u2))
+    for name, r, g in zip(("I1w", "I1wx", "I1wy", "grad", "rho_c"), ref, got):
+        g = g.cpu().numpy()
+        scale = max(1.0, float(np.abs(r).max()))
+        assert np.abs(g - r).max() <= 2e-5 * scale, name
+    # one exact-math iteration on the reference's warp planes
+    p = [x for pair in (_flow(h, w, seed + 2, 0.4), _flow(h, w, seed + 3, 0.4)) for x in pair]
+    l_t, theta, taut = np.float32(0.15 * 0.3), np.float32(0.3), np.float32(0.25 / 0.3)
+    r = refocl.tvl1_iteration(ref[1], ref[2], ref[3], ref[4], u1, u2, *p, l_t, theta, taut)
+    uo, po, _ = cuda.tvl1_iterate(t(ref[1]), t(ref[2]), t(ref[3]), t(ref[4]), [t(u1), t(u2)], [t(x) for x in p],
+                                  float(l_t), float(theta), float(taut), niter=1, exact=True)
+    for k, (name, g) in enumerate(zip(("u1", "u2", "p11", "p12", "p21", "p22"), uo + po)):
+        assert np.abs(g.cpu().numpy() - r[1 + k]).max() <= 2e-6 * max(1.0, float(np.abs(r[1 + k]).max())), name
