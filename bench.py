@@ -411,6 +411,8 @@ def main():
                     help="IEEE divide + f64 hypot, one iteration per HBM pass (oracle-faithful to ~1e-6 px); default is "
                          "the product fast path: v_rcp/v_sqrt math + temporal blocking, parity-tested at mean EPE <= 5e-3 px")
     ap.add_argument("--time-block", type=int, default=0, help="iterations fused per HBM pass (fast math; 0 = auto, 1 = off)")
+    ap.add_argument("--lanes", type=int, default=0, help="internal streams a batch is split over (0 = library default: 2 from 4 pairs on)")
+    ap.add_argument("--semantics", type=int, default=0, help="0 = CPU class arithmetic (library default), 1 = cv::cuda's kernels")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=None)
@@ -448,7 +450,7 @@ def main():
     def run(iterations, epsilon, steps, warmup, profile=False, exact=None):
         alg = cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon,
                                                exactMath=args.exact_math if exact is None else exact,
-                                               timeBlock=args.time_block)
+                                               timeBlock=args.time_block, lanes=args.lanes, semantics=args.semantics)
         alg.setProfiling(profile)
         el = time_steps(alg, I0, I1, flows, steps, warmup, dist)
         el = parallel.max_over_ranks(dist, el, dev)

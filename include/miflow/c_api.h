@@ -95,9 +95,15 @@ typedef struct mi_tvl1_params {
     int use_initial_flow;
     int inner_iterations;
     int median_filtering;
-    int semantics;       /* MI_SEM_* ; default CPU_REF (acceptance is against the CPU path) */
-    int exact_math;      /* 1: IEEE divide + f64 hypot (oracle-faithful); 0: fast reciprocal math */
-    int time_block;      /* inner iterations fused per HBM pass when epsilon == 0 (0 = auto) */
+    int semantics;       /* MI_SEM_CPU_REF (default) = the arithmetic of cv::optflow::DualTVL1OpticalFlow, the acceptance reference
+                          * ("EPE vs CPU ref"): cv::remap warp, cv::resize pyramid, convergence test every iteration;
+                          * MI_SEM_CUDA_COMPAT = the arithmetic of cv::cuda's own kernels (normalised a = -0.5 bicubic, clamp
+                          * addressing, cuda::resize, sparse check schedule), for callers validated against cv::cuda: the two
+                          * differ by ~0.1 px mean EPE, mostly at image borders (see mi_tvl1_default_params) */
+    int exact_math;      /* 0 (default): fast device math (v_rcp / v_sqrt / fma), held to the oracle with a stated tolerance;
+                          * 1: IEEE divide + f64 hypot, separately rounded operations in the reference's order */
+    int time_block;      /* inner iterations fused per HBM pass (0 = auto, 1 = one iteration per launch) */
+    int lanes;           /* internal streams a batch is split over: 0 = automatic (2 from 4 pairs on), 1, 2 */
 } mi_tvl1_params;
 
 typedef struct mi_tvl1 mi_tvl1;
@@ -191,11 +197,6 @@ MI_API int mi_stereobm_block_match(const mi_mat *left, const mi_mat *right, mi_m
                                    int winsz, int uniqueness_ratio, int emulate_cuda_edge, void *stream);
 /* Replaces: postfilter_textureness  stereobm.cu:698-711 (exact-integer definition, see oracle/stereobm_ref.c) */
 MI_API int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, float avg_texture_threshold, void *stream);
-/* Hardware self-test hook: out_host[0..63] = wave-wide min of in_host[0..63] as seen by every lane,
- * out_host[64] = lane picked by the reference's tie-break rule among the minima. */
-MI_API int mi_dbg_wave_min(const unsigned *in_host, unsigned *out_host /*[65]*/);
-/* in_host[k*64 + lane] = value k of lane `lane` (k < 16); out_host[lane] = max over all lanes of value (lane & 15) */
-MI_API int mi_dbg_tmax16(const unsigned *in_host /*[1024]*/, unsigned *out_host /*[64]*/);
 
 /* ====================================================================== Farneback ===== */
 
@@ -287,8 +288,6 @@ MI_API int mi_surf_integral(mi_surf *h, const mi_mat *img, int clamp_to_one, mi_
 /* Replaces: icvCalcLayerDetAndTrace_gpu, xfeatures2d/src/cuda/surf.cu:205-222; det/trace: MI_32FC1,
  * ((n_octave_layers+2) * (rows >> octave)) x cols, same step */
 MI_API int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_layers, mi_mat *det, mi_mat *trace, void *stream);
-/* Hardware self-test hook: out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan) */
-MI_API int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
 
 /* ======================================================== sparse PyrLK ===== */
 
@@ -437,10 +436,6 @@ MI_API int mi_superres_to_gray8(const mi_mat *src, mi_mat *dst, void *stream);
 /* Replaces: cuda::split(flow, flows) in Farneback_CUDA::impl / DualTVL1_CUDA::impl, superres/src/optical_flow.cpp:737-741,834-838.
  * flow: MI_32FC2; u, v: MI_32FC1 of the same size. */
 MI_API int mi_split_flow(const mi_mat *flow, mi_mat *u, mi_mat *v, void *stream);
-
-/* Hardware self-test hook: out_host[0..63] = value received from lane n-1, out_host[64..127] = from
- * lane n+1 when every lane n contributes n+100 (DPP wave shifts used by the blocked kernels). */
-MI_API int mi_dbg_lane_shift(int *out_host /*[128]*/);
 
 #ifdef __cplusplus
 }

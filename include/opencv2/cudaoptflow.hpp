@@ -46,7 +46,32 @@ public:
         if (!p_.use_initial_flow) flow.create(I0.size(), CV_32FC2);
         mi_mat a = miMat(I0), b = miMat(I1), f = miMat(flow);
         miCheck(mi_tvl1_calc(h_, &a, &b, &f, stream.hipStream()));
+        // the reference shrinks nscales_ for good when a pyramid level falls below 16 px (tvl1flow.cpp:243-247)
+        miCheck(mi_tvl1_get_params(h_, &p_));
     }
+    // Batched-frames mode (miflow extension; reached through cv::cuda::miflow::calcBatch): n independent pairs of one size and
+    // type per launch sequence, blockIdx.z = pair.  flows[i] is (re)allocated like calc() does.
+    void calcBatch(const std::vector<GpuMat> &I0s, const std::vector<GpuMat> &I1s, std::vector<GpuMat> &flows, Stream &stream)
+    {
+        CV_Assert(!I0s.empty() && I0s.size() == I1s.size());
+        if (!p_.use_initial_flow) flows.resize(I0s.size());
+        CV_Assert(flows.size() == I0s.size());
+        std::vector<mi_mat> a(I0s.size()), b(I0s.size()), f(I0s.size());
+        for (size_t i = 0; i < I0s.size(); ++i) {
+            if (!p_.use_initial_flow) flows[i].create(I0s[i].size(), CV_32FC2);
+            a[i] = miMat(I0s[i]); b[i] = miMat(I1s[i]); f[i] = miMat(flows[i]);
+        }
+        miCheck(mi_tvl1_calc_batch(h_, (int)a.size(), a.data(), b.data(), f.data(), stream.hipStream()));
+        miCheck(mi_tvl1_get_params(h_, &p_));
+    }
+    void setExtra(int semantics, int exact_math, int time_block, int lanes)
+    {
+        mi_tvl1_params q = p_;
+        q.semantics = semantics; q.exact_math = exact_math; q.time_block = time_block; q.lanes = lanes;
+        miCheck(mi_tvl1_set_params(h_, &q));
+        p_ = q;
+    }
+    const mi_tvl1_params &params() const { return p_; }
     String getDefaultName() const override { return "DenseOpticalFlow.OpticalFlowDual_TVL1"; }   // tvl1flow.cpp:122
 #define MIFLOW_PROP(T, Name, field) \
     T get##Name() const override { return (T)p_.field; } \
@@ -57,7 +82,6 @@ public:
 #undef MIFLOW_PROP
     bool getUseInitialFlow() const override { return p_.use_initial_flow != 0; }
     void setUseInitialFlow(bool v) override { mi_tvl1_params q = p_; q.use_initial_flow = v; miCheck(mi_tvl1_set_params(h_, &q)); p_ = q; }
-    // non-reference knobs of the C-ABI (semantics, exact_math, time_block): reachable through the handle
     mi_tvl1 *handle() { return h_; }
 private:
     mi_tvl1_params p_;
@@ -75,6 +99,39 @@ inline Ptr<OpticalFlowDual_TVL1> OpticalFlowDual_TVL1::create(double tau, double
     p.iterations = iterations; p.scale_step = scaleStep; p.gamma = gamma; p.use_initial_flow = useInitialFlow;
     return makePtr<miflow_detail::TVL1Impl>(p);
 }
+
+/** miflow extensions to OpticalFlowDual_TVL1 -- everything the reference class does not have lives in this namespace, the class
+ *  declaration above is the reference's.  NOTE ON NUMERICS: a default-constructed object computes with the arithmetic of the
+ *  CPU class cv::optflow::DualTVL1OpticalFlow (MI_SEM_CPU_REF: the acceptance reference of this path, "EPE vs CPU ref") in fast
+ *  device math, iterations fused per HBM pass; cv::cuda's own kernels differ from the CPU class by ~0.1 px mean EPE (border
+ *  addressing, resize convention, check schedule) and are selected with setSemantics(alg, MI_SEM_CUDA_COMPAT). */
+namespace miflow {
+/** MI_SEM_CPU_REF (default) = the arithmetic of cv::optflow::DualTVL1OpticalFlow (cv::remap warp, cv::resize pyramid,
+ *  convergence test after every iteration); MI_SEM_CUDA_COMPAT = cv::cuda's kernels (normalised a = -0.5 bicubic with clamp
+ *  addressing, cuda::resize, sparse check schedule), bit-pinned on the reference's OpenCL twins. */
+inline void setSemantics(const Ptr<OpticalFlowDual_TVL1> &alg, int semantics)
+{
+    auto *impl = dynamic_cast<miflow_detail::TVL1Impl *>(alg.get());
+    CV_Assert(impl);
+    impl->setExtra(semantics, impl->params().exact_math, impl->params().time_block, impl->params().lanes);
+}
+/** true: IEEE divide, f64 hypot, separately rounded operations in the reference's order, one iteration per launch
+ *  (bit-comparable with the CPU restatement); false (default): v_rcp / v_sqrt / fma, temporally blocked. */
+inline void setExactMath(const Ptr<OpticalFlowDual_TVL1> &alg, bool exact)
+{
+    auto *impl = dynamic_cast<miflow_detail::TVL1Impl *>(alg.get());
+    CV_Assert(impl);
+    impl->setExtra(impl->params().semantics, exact ? 1 : 0, impl->params().time_block, impl->params().lanes);
+}
+/** n independent image pairs of identical size and type in one pass (the batched-frames mode of BASELINE configs[4]). */
+inline void calcBatch(const Ptr<OpticalFlowDual_TVL1> &alg, const std::vector<GpuMat> &I0s, const std::vector<GpuMat> &I1s,
+                      std::vector<GpuMat> &flows, Stream &stream = Stream::Null())
+{
+    auto *impl = dynamic_cast<miflow_detail::TVL1Impl *>(alg.get());
+    CV_Assert(impl);
+    impl->calcBatch(I0s, I1s, flows, stream);
+}
+}  // namespace miflow
 
 /** cudaoptflow.hpp:258-294; implementation twin of FarnebackOpticalFlowImpl, cudaoptflow/src/farneback.cpp:96-165 */
 class FarnebackOpticalFlow : public DenseOpticalFlow {
@@ -108,13 +165,13 @@ public:
     String getDefaultName() const override { return "DenseOpticalFlow.FarnebackOpticalFlow"; }   // farneback.cpp:132
 #define MIFLOW_PROP(T, Name, field) \
     T get##Name() const override { return (T)p_.field; } \
-    void set##Name(T v) override { p_.field = v; miCheck(mi_farneback_set_params(h_, &p_)); }
+    void set##Name(T v) override { mi_farneback_params q = p_; q.field = v; miCheck(mi_farneback_set_params(h_, &q)); p_ = q; }
     MIFLOW_PROP(int, NumLevels, num_levels) MIFLOW_PROP(double, PyrScale, pyr_scale) MIFLOW_PROP(int, WinSize, win_size)
     MIFLOW_PROP(int, NumIters, num_iters) MIFLOW_PROP(int, PolyN, poly_n) MIFLOW_PROP(double, PolySigma, poly_sigma)
     MIFLOW_PROP(int, Flags, flags)
 #undef MIFLOW_PROP
     bool getFastPyramids() const override { return p_.fast_pyramids != 0; }
-    void setFastPyramids(bool v) override { p_.fast_pyramids = v; miCheck(mi_farneback_set_params(h_, &p_)); }
+    void setFastPyramids(bool v) override { mi_farneback_params q = p_; q.fast_pyramids = v; miCheck(mi_farneback_set_params(h_, &q)); p_ = q; }
 private:
     mi_farneback_params p_;
     mi_farneback *h_ = nullptr;
@@ -162,8 +219,9 @@ public:
     bool getUseInitialFlow() const override { return p_.use_initial_flow != 0; }
     void setUseInitialFlow(bool v) override { p_.use_initial_flow = v; push(); }
 private:
-    void push() { miCheck(mi_densepyrlk_set_params(h_, &p_)); }
+    void push() { const int rc = mi_densepyrlk_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_densepyrlk_params p_;
+    mi_densepyrlk_params ok_ = p_;   // last parameters the library accepted
     mi_densepyrlk *h_ = nullptr;
 };
 }  // namespace miflow_detail
@@ -226,8 +284,9 @@ public:
     bool getUseInitialFlow() const override { return p_.use_initial_flow != 0; }
     void setUseInitialFlow(bool v) override { p_.use_initial_flow = v; push(); }
 private:
-    void push() { miCheck(mi_sparsepyrlk_set_params(h_, &p_)); }
+    void push() { const int rc = mi_sparsepyrlk_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_sparsepyrlk_params p_;
+    mi_sparsepyrlk_params ok_ = p_;   // last parameters the library accepted
     mi_sparsepyrlk *h_ = nullptr;
 };
 }  // namespace miflow_detail

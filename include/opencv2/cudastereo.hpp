@@ -77,8 +77,9 @@ public:
     Rect getROI1() const override { return Rect(); }             void setROI1(Rect) override {}
     Rect getROI2() const override { return Rect(); }             void setROI2(Rect) override {}
 private:
-    void push() { miCheck(mi_stereobm_set_params(h_, &p_)); }
+    void push() { const int rc = mi_stereobm_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_stereobm_params p_;
+    mi_stereobm_params ok_ = p_;   // last parameters the library accepted
     mi_stereobm *h_ = nullptr;
 };
 }  // namespace miflow_detail
@@ -135,8 +136,9 @@ public:
     int getMode() const override { return p_.mode; }             void setMode(int v) override { p_.mode = v; push(); }
     int getPreFilterCap() const override { return -1; }          void setPreFilterCap(int) override {}
 private:
-    void push() { miCheck(mi_stereosgm_set_params(h_, &p_)); }
+    void push() { const int rc = mi_stereosgm_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_stereosgm_params p_;
+    mi_stereosgm_params ok_ = p_;   // last parameters the library accepted
     mi_stereosgm *h_ = nullptr;
 };
 }  // namespace miflow_detail
@@ -186,8 +188,9 @@ public:
     double getMaxDiscThreshold() const override { return p_.max_disc_threshold; } void setMaxDiscThreshold(double v) override { p_.max_disc_threshold = (float)v; push(); }
     double getSigmaRange() const override { return p_.sigma_range; }             void setSigmaRange(double v) override { p_.sigma_range = (float)v; push(); }
 private:
-    void push() { miCheck(mi_disp_bilateral_set_params(h_, &p_)); }
+    void push() { const int rc = mi_disp_bilateral_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_disp_bilateral_params p_;
+    mi_disp_bilateral_params ok_ = p_;   // last parameters the library accepted
     mi_disp_bilateral *h_ = nullptr;
 };
 }  // namespace miflow_detail

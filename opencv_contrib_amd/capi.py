@@ -36,7 +36,7 @@ class TVL1Params(C.Structure):
                 ("scale_step", C.c_double), ("gamma", C.c_double), ("nscales", C.c_int), ("warps", C.c_int),
                 ("iterations", C.c_int), ("use_initial_flow", C.c_int), ("inner_iterations", C.c_int),
                 ("median_filtering", C.c_int), ("semantics", C.c_int), ("exact_math", C.c_int),
-                ("time_block", C.c_int)]
+                ("time_block", C.c_int), ("lanes", C.c_int)]
 
 
 class SURFParams(C.Structure):
@@ -121,7 +121,7 @@ def lib():
         "mi_tvl1_warp_backward": (i, [i] + [PM] * 11),
         "mi_tvl1_iterate": (i, [i, i, i, PM, PM, PM, PM, PM, PM, PM, PM, f, f, f, C.POINTER(d), vp]),
         "mi_resize_linear": (i, [i, PM, PM, d, d, i, f, vp]),
-        "mi_dbg_lane_shift": (i, [C.POINTER(i)]),
+        "miflow_selftest_lane_shift": (i, [C.POINTER(i)]),
         "mi_stereobm_default_params": (None, [C.POINTER(StereoBMParams)]),
         "mi_stereobm_create": (i, [C.POINTER(StereoBMParams), C.POINTER(vp)]),
         "mi_stereobm_set_params": (i, [vp, C.POINTER(StereoBMParams)]),
@@ -132,8 +132,8 @@ def lib():
         "mi_stereobm_prefilter_norm": (i, [PM, PM, i, i, vp]),
         "mi_stereobm_block_match": (i, [PM, PM, PM, PM, i, i, i, i, vp]),
         "mi_stereobm_textureness": (i, [PM, PM, i, f, vp]),
-        "mi_dbg_wave_min": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
-        "mi_dbg_tmax16": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "miflow_selftest_wave_min": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "miflow_selftest_tmax16": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
         "mi_farneback_default_params": (None, [C.POINTER(FarnebackParams)]),
         "mi_farneback_create": (i, [C.POINTER(FarnebackParams), C.POINTER(vp)]),
         "mi_farneback_set_params": (i, [vp, C.POINTER(FarnebackParams)]),
@@ -160,7 +160,7 @@ def lib():
         "mi_surf_destroy": (None, [vp]),
         "mi_surf_integral": (i, [vp, PM, i, PM, vp]),
         "mi_surf_det_trace": (i, [vp, PM, i, i, PM, PM, vp]),
-        "mi_dbg_wave_scan": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+        "miflow_selftest_wave_scan": (i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
         "mi_densepyrlk_default_params": (None, [C.POINTER(DensePyrLKParams)]),
         "mi_densepyrlk_create": (i, [C.POINTER(DensePyrLKParams), C.POINTER(vp)]),
         "mi_densepyrlk_set_params": (i, [vp, C.POINTER(DensePyrLKParams)]),

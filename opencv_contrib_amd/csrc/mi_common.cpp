@@ -1,7 +1,52 @@
 // Error channel, device selection and device-memory helpers of the C-ABI.
 #include "mi_common.h"
+#include <cstdlib>
+#include <mutex>
 
 namespace mi {
+static Tuning g_tuning;
+static std::once_flag g_tuning_once;
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+const Tuning &tuning()
+{
+    std::call_once(g_tuning_once, [] {
+        Tuning &t = g_tuning;
+        const char *w = getenv("MIFLOW_WARP");
+        t.warp_legacy = (w && w[0] == 'p') ? 1 : 0;
+        t.warp_tile = env_int("MIFLOW_WARP_TILE", 32);
+        if (t.warp_tile != 64 && t.warp_tile != 32 && t.warp_tile != 16) t.warp_tile = 32;
+        t.tb_swz = env_int("MIFLOW_TB_SWZ", 1);
+        t.tb_ppl = t.tb_wps = t.tb_pf = -1;
+        if (const char *v = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(v, "%d,%d,%d", &t.tb_ppl, &t.tb_wps, &t.tb_pf);
+        t.tb_force = getenv("MIFLOW_TB_FORCE") != nullptr;
+        t.tb_plan_wps = env_int("MIFLOW_TB_WPS", 0);
+        t.tb_rows = env_int("MIFLOW_TB_ROWS", 0);
+        t.tb_verbose = getenv("MIFLOW_TB_VERBOSE") != nullptr;
+        t.lanes = env_int("MIFLOW_LANES", 0);
+        t.spec = env_int("MIFLOW_SPEC", 1);
+    });
+    return g_tuning;
+}
+
+int device_simds()
+{
+    static std::mutex mu;
+    static int cache[64];   // 0 = not queried yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cache[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cache[dev] = 4 * cus;
+    }
+    return cache[dev];
+}
+
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...)
 {

@@ -27,6 +27,25 @@ void set_error(const char *fmt, ...);
         }                                  \
     } while (0)
 
+// Tuning switches (environment, read ONCE for the process under std::call_once; DESIGN.md lists them).  None is needed
+// in production: every default is the measured best.
+struct Tuning {
+    int warp_legacy;         // MIFLOW_WARP=pk: packed-float4 gather warp (the round-1 kernel) instead of the fused-gradient one
+    int warp_tile;           // MIFLOW_WARP_TILE: pixels of a wave along x in the warp kernels (64 | 32 | 16)
+    int tb_swz;              // MIFLOW_TB_SWZ: XCD-aware workgroup remap of the blocked iteration kernels
+    int tb_ppl, tb_wps, tb_pf;   // MIFLOW_TB_VARIANT=ppl,wps,pf (-1: table default)
+    int tb_force;            // MIFLOW_TB_FORCE: greedy blocks of exactly the cap (tuning sweeps)
+    int tb_plan_wps;         // MIFLOW_TB_WPS: waves/SIMD the band planner assumes (0: table)
+    int tb_rows;             // MIFLOW_TB_ROWS: band height (0: planner)
+    int tb_verbose;          // MIFLOW_TB_VERBOSE
+    int lanes;               // MIFLOW_LANES: internal streams a TV-L1 batch is split over (0: automatic)
+    int spec;                // MIFLOW_SPEC: speculative blocked convergence path (1) or one launch per iteration (0)
+};
+const Tuning &tuning();
+
+// SIMDs of the current device (4 per CU; 1024 on MI355X), queried once per device
+int device_simds();
+
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 static inline int align_up(int a, int b) { return div_up(a, b) * b; }
 

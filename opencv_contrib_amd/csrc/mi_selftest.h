@@ -1,0 +1,22 @@
+// Hardware self-test hooks: NOT part of the public C-ABI (include/miflow/c_api.h does not declare them).  They run the
+// cross-lane primitives the kernels rely on (DPP wave shifts / scans / reductions, ballot tie-break) on known inputs so
+// that tests/ can check their semantics on the real device.  Exported under their own prefix for the ctypes tests only.
+#pragma once
+#include "miflow/c_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* out_host[0..63] = wave-wide min of in_host[0..63] as seen by every lane, out_host[64] = lane picked by the reference's
+ * tie-break rule among the minima (StereoBM winner-take-all) */
+MI_API int miflow_selftest_wave_min(const unsigned *in_host, unsigned *out_host /*[65]*/);
+/* in_host[k*64 + lane] = value k of lane `lane` (k < 16); out_host[lane] = max over all lanes of value (lane & 15) */
+MI_API int miflow_selftest_tmax16(const unsigned *in_host /*[1024]*/, unsigned *out_host /*[64]*/);
+/* out_host[i] = inclusive prefix sum of in_host[0..i] over the 64 lanes (DPP scan of the SURF integral) */
+MI_API int miflow_selftest_wave_scan(const unsigned *in_host, unsigned *out_host /*[64]*/);
+/* out_host[0..63] = value received from lane n-1, out_host[64..127] = from lane n+1 when every lane n contributes n+100
+ * (DPP wave shifts of the blocked TV-L1 kernels) */
+MI_API int miflow_selftest_lane_shift(int *out_host /*[128]*/);
+#ifdef __cplusplus
+}
+#endif

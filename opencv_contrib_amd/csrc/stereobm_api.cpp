@@ -2,6 +2,7 @@
 // (modules/cudastereo/src/stereobm.cpp:67-197): validation, optional prefilter of both images,
 // block matching, textureness post-filter -- all stream-ordered on the caller's stream.
 #include "stereobm_dev.h"
+#include "mi_selftest.h"
 
 using namespace mi;
 
@@ -204,7 +205,7 @@ int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, float av
     return rc;
 }
 
-int mi_dbg_tmax16(const unsigned *in_host, unsigned *out_host)
+int miflow_selftest_tmax16(const unsigned *in_host, unsigned *out_host)
 {
     MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
     unsigned *d = nullptr;
@@ -216,7 +217,7 @@ int mi_dbg_tmax16(const unsigned *in_host, unsigned *out_host)
     return rc;
 }
 
-int mi_dbg_wave_min(const unsigned *in_host, unsigned *out_host)
+int miflow_selftest_wave_min(const unsigned *in_host, unsigned *out_host)
 {
     MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
     unsigned *d = nullptr;

@@ -3,6 +3,7 @@
 // One stream, no host round trip inside the octave loop; the only synchronisation is the final read-back of the
 // feature count (the reference's keypoints.cols = featureCounter, :205-209).
 #include "surf_dev.h"
+#include "mi_selftest.h"
 #include <cmath>
 #include <vector>
 
@@ -265,7 +266,7 @@ int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_la
                            (float *)trace->data, (int)(det->step / 4), (hipStream_t)stream);
 }
 
-int mi_dbg_wave_scan(const unsigned *in_host, unsigned *out_host)
+int miflow_selftest_wave_scan(const unsigned *in_host, unsigned *out_host)
 {
     MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
     unsigned *d = nullptr;

@@ -22,21 +22,21 @@ struct SlotInfo { int scale, warp; };
 
 }  // namespace
 
-struct mi_tvl1 {
-    mi_tvl1_params P;
-    int device = 0;
+// Everything one sub-batch needs: its own arena, pointer table, control slots and profiling events, so that two lanes can
+// run concurrently on two internal streams (the warp kernel is bound by the vector-memory path, the blocked iteration
+// kernel by VALU issue: they overlap, profiles/r02*).
+struct Lane {
     // capacity the arena was built for
     int capW = 0, capH = 0, capB = 0, capScales = 0;
     double capStep = 0;
+    bool capGamma = false, capMedian = false, capPack = false;
     float *arena = nullptr;
     size_t arena_floats = 0;
     std::vector<LevelBuf> L;
     // full-resolution-capacity scratch planes (re-laid-out densely per level)
-    float *scr[6] = {};    // scr[0..1] unused (kept for layout), I1wx, I1wy, grad, rho_c
-    float *pack = nullptr; // float4 {I1, I1x, I1y, 0} per pixel of the current level
+    float *scr[6] = {};    // scr[0..1]: median-filter temporaries; I1wx, I1wy, grad, rho_c
+    float *pack = nullptr; // MIFLOW_WARP=pk only: float4 {I1, I1x, I1y, 0} per pixel of the current level
     float *pbuf[2][6] = {};   // [set][p11,p12,p21,p22,p31,p32]
-    bool capGamma = false, capMedian = false;
-    float *cubic_tab = nullptr;
     PtrTab *tab_dev = nullptr;
     int tab_cap = 0;
     std::vector<PtrTab> tab_host;   // source of the asynchronous upload: must outlive the call
@@ -44,15 +44,28 @@ struct mi_tvl1 {
     int2 *S = nullptr;
     unsigned long long *E = nullptr;
     double *Pd = nullptr;   // per slot prevError (cv::cuda check schedule)
-    int Q = 0, ctlB = 0;
+    long long Q = 0;
+    int ctlB = 0;
     std::vector<SlotInfo> slots;
-    int last_nscales = 0, last_batch = 0;
-    bool last_check = false;
+    int batch = 0;          // pairs of the last calc
     // profiling (mi_tvl1_set_profiling)
-    bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     struct Region { int e0, e1; long long launches; double bytes; };
     std::vector<Region> regions;
+    // internal stream of a concurrent lane + its completion event
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+
+struct mi_tvl1 {
+    mi_tvl1_params P;
+    int device = 0;
+    float *cubic_tab = nullptr;
+    Lane lane[2];
+    hipEvent_t fork = nullptr;
+    int last_nscales = 0, last_batch = 0, last_lanes = 1, last_split = 0;
+    bool last_check = false;
+    bool profiling = false;
 };
 
 static int round_half_even(double v) { return (int)std::lrint(v); }
@@ -64,8 +77,22 @@ void mi_tvl1_default_params(mi_tvl1_params *p)
     p->tau = 0.25; p->lambda = 0.15; p->theta = 0.3; p->epsilon = 0.01; p->scale_step = 0.8; p->gamma = 0.0;
     p->nscales = 5; p->warps = 5; p->iterations = 300; p->use_initial_flow = 0;
     p->inner_iterations = 1; p->median_filtering = 1;
-    p->semantics = MI_SEM_CPU_REF; p->exact_math = 1; p->time_block = 0;
+    // SEMANTICS OF A DEFAULT-CONSTRUCTED OBJECT (read this before dropping the class in).  The acceptance reference of this
+    // path is the CPU class cv::optflow::DualTVL1OpticalFlow ("EPE vs CPU ref", BASELINE.json), so the default arithmetic is
+    // the CPU class's: cv::remap(INTER_CUBIC, a = -0.75, 1/32-px phases, constant-0 border) warp, cv::resize pyramid
+    // (half-pixel centres), convergence test after every iteration with a float threshold.  cv::cuda's own kernels differ from
+    // that -- normalised a = -0.5 bicubic with clamp addressing, cuda::resize without the half-pixel shift, a sparse check
+    // schedule -- by 0.07-0.14 px mean EPE on the synthetic pairs used here (mostly at image borders the flow leaves);
+    // semantics = MI_SEM_CUDA_COMPAT selects exactly that arithmetic (pinned bit for bit on the reference's OpenCL twins of the
+    // CUDA kernels, tests/test_ref_pin.py) for callers validated against cv::cuda.  Math: fast device math (v_rcp / v_sqrt /
+    // fma, iterations fused per HBM pass) by default, which the reference's own test tolerates (CUDA vs CPU |1 - CCORR| <= 4e-3,
+    // test_optflow.cpp:465; here <= 1e-4 and mean EPE <= 5e-3 px against the oracle); exact_math = 1 performs the separately
+    // rounded IEEE operations of the reference in its order.
+    p->semantics = MI_SEM_CPU_REF; p->exact_math = 0; p->time_block = 0; p->lanes = 0;
 }
+
+// upper bound of control slots per pair (scales x warps x iterations) a convergence-checked calc may enqueue
+static const long long kMaxSlots = 4000000;
 
 static int validate_params(const mi_tvl1_params *p)
 {
@@ -73,11 +100,14 @@ static int validate_params(const mi_tvl1_params *p)
     MI_REQUIRE(p->nscales > 0 && p->nscales <= 32, MI_ERR_BAD_ARG, "nscales must be in [1,32] (CV_Assert nscales_ > 0)");
     MI_REQUIRE(p->warps >= 0 && p->warps <= 64, MI_ERR_BAD_ARG, "warps must be in [0,64]");
     MI_REQUIRE(p->iterations >= 0 && p->inner_iterations >= 0, MI_ERR_BAD_ARG, "negative iteration count");
+    MI_REQUIRE((long long)p->iterations * p->inner_iterations <= kMaxSlots, MI_ERR_BAD_ARG,
+               "iterations x inner_iterations must not exceed %lld", kMaxSlots);
     MI_REQUIRE(p->scale_step > 0 && p->scale_step < 1, MI_ERR_BAD_ARG, "scale_step must be in (0,1)");
     MI_REQUIRE(p->theta != 0, MI_ERR_BAD_ARG, "theta must be non-zero");
     MI_REQUIRE(p->semantics == MI_SEM_CPU_REF || p->semantics == MI_SEM_CUDA_COMPAT, MI_ERR_BAD_ARG, "bad semantics");
     MI_REQUIRE(p->median_filtering <= 1 || p->median_filtering == 3 || p->median_filtering == 5, MI_ERR_BAD_ARG,
                "medianFiltering must be 1 (off), 3 or 5 (cv::medianBlur on CV_32F)");
+    MI_REQUIRE(p->lanes >= 0 && p->lanes <= 2, MI_ERR_BAD_ARG, "lanes must be 0 (automatic), 1 or 2");
     return MI_OK;
 }
 
@@ -125,11 +155,11 @@ int mi_tvl1_get_params(const mi_tvl1 *h, mi_tvl1_params *p)
     return MI_OK;
 }
 
-static void free_arena(mi_tvl1 *h)
+static void free_arena(Lane &ln)
 {
-    if (h->arena) (void)hipFree(h->arena);
-    h->arena = nullptr;
-    h->L.clear();
+    if (ln.arena) (void)hipFree(ln.arena);
+    ln.arena = nullptr;
+    ln.L.clear();
 }
 
 int mi_tvl1_set_profiling(mi_tvl1 *h, int enable)
@@ -143,11 +173,14 @@ int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, doubl
 {
     MI_REQUIRE(h && ms_total && launches && algo_bytes, MI_ERR_BAD_ARG, "null argument");
     *ms_total = 0; *launches = 0; *algo_bytes = 0;
-    for (const auto &r : h->regions) {
-        MI_HIP_TRY(hipEventSynchronize(h->ev_pool[r.e1]));
-        float ms = 0.f;
-        MI_HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[r.e0], h->ev_pool[r.e1]));
-        *ms_total += ms; *launches += r.launches; *algo_bytes += r.bytes;
+    for (int li = 0; li < h->last_lanes; ++li) {
+        Lane &ln = h->lane[li];
+        for (const auto &r : ln.regions) {
+            MI_HIP_TRY(hipEventSynchronize(ln.ev_pool[r.e1]));
+            float ms = 0.f;
+            MI_HIP_TRY(hipEventElapsedTime(&ms, ln.ev_pool[r.e0], ln.ev_pool[r.e1]));
+            *ms_total += ms; *launches += r.launches; *algo_bytes += r.bytes;
+        }
     }
     return MI_OK;
 }
@@ -155,13 +188,18 @@ int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, doubl
 void mi_tvl1_destroy(mi_tvl1 *h)
 {
     if (!h) return;
-    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    free_arena(h);
+    for (Lane &ln : h->lane) {
+        for (hipEvent_t e : ln.ev_pool) (void)hipEventDestroy(e);
+        free_arena(ln);
+        if (ln.tab_dev) (void)hipFree(ln.tab_dev);
+        if (ln.S) (void)hipFree(ln.S);
+        if (ln.E) (void)hipFree(ln.E);
+        if (ln.Pd) (void)hipFree(ln.Pd);
+        if (ln.done) (void)hipEventDestroy(ln.done);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
+    if (h->fork) (void)hipEventDestroy(h->fork);
     if (h->cubic_tab) (void)hipFree(h->cubic_tab);
-    if (h->tab_dev) (void)hipFree(h->tab_dev);
-    if (h->S) (void)hipFree(h->S);
-    if (h->E) (void)hipFree(h->E);
-    if (h->Pd) (void)hipFree(h->Pd);
     delete h;
 }
 
@@ -185,16 +223,17 @@ static int plan_levels(const mi_tvl1_params &P, int W, int H, int B, std::vector
     return (int)geo.size();
 }
 
-static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
+static int ensure_arena(const mi_tvl1_params &P, Lane &ln, int W, int H, int B)
 {
-    const bool gam = h->P.gamma != 0.0;
-    if (h->arena && h->capW == W && h->capH == H && h->capB >= B && h->capScales == h->P.nscales &&
-        h->capStep == h->P.scale_step && h->capGamma == gam && h->capMedian == (h->P.median_filtering > 1))
+    const bool gam = P.gamma != 0.0;
+    const bool med = P.median_filtering > 1;
+    const bool pk = tuning().warp_legacy != 0;
+    if (ln.arena && ln.capW == W && ln.capH == H && ln.capB >= B && ln.capScales == P.nscales && ln.capStep == P.scale_step &&
+        ln.capGamma == gam && ln.capMedian == med && ln.capPack == pk)
         return MI_OK;
-    const bool med = h->P.median_filtering > 1;
-    free_arena(h);
+    free_arena(ln);
     std::vector<Geo> geo;
-    const int nl = plan_levels(h->P, W, H, B, geo);
+    const int nl = plan_levels(P, W, H, B, geo);
     size_t total = 0;
     auto take = [&](size_t nfloats) { size_t o = total; total += (nfloats + 63) / 64 * 64; return o; };
     std::vector<size_t> offI0(nl), offI1(nl), offU(nl * 6);
@@ -206,22 +245,22 @@ static int ensure_arena(mi_tvl1 *h, int W, int H, int B)
     const size_t nfull = (size_t)geo[0].ps * B;
     size_t offScr[6], offP[12];
     for (int k = 0; k < 6; ++k) offScr[k] = (k < 2 && !med) ? 0 : take(nfull);   // scr[0..1]: median-filter temporaries
-    const size_t offPack = take(nfull * 4);
+    const size_t offPack = pk ? take(nfull * 4) : 0;
     for (int k = 0; k < 12; ++k) offP[k] = (k % 6 >= 4 && !gam) ? 0 : take(nfull);
-    MI_HIP_TRY(hipMalloc((void **)&h->arena, total * sizeof(float)));
-    h->arena_floats = total;
-    h->L.resize(nl);
+    MI_HIP_TRY(hipMalloc((void **)&ln.arena, total * sizeof(float)));
+    ln.arena_floats = total;
+    ln.L.resize(nl);
     for (int l = 0; l < nl; ++l) {
-        h->L[l].g = geo[l];
-        h->L[l].I0 = h->arena + offI0[l];
-        h->L[l].I1 = h->arena + offI1[l];
-        for (int k = 0; k < 6; ++k) h->L[l].u[k / 3][k % 3] = (k % 3 == 2 && !gam) ? nullptr : h->arena + offU[l * 6 + k];
+        ln.L[l].g = geo[l];
+        ln.L[l].I0 = ln.arena + offI0[l];
+        ln.L[l].I1 = ln.arena + offI1[l];
+        for (int k = 0; k < 6; ++k) ln.L[l].u[k / 3][k % 3] = (k % 3 == 2 && !gam) ? nullptr : ln.arena + offU[l * 6 + k];
     }
-    for (int k = 0; k < 6; ++k) h->scr[k] = h->arena + offScr[k];
-    h->pack = h->arena + offPack;
-    for (int k = 0; k < 12; ++k) h->pbuf[k / 6][k % 6] = (k % 6 >= 4 && !gam) ? nullptr : h->arena + offP[k];
-    h->capGamma = gam; h->capMedian = med;
-    h->capW = W; h->capH = H; h->capB = B; h->capScales = h->P.nscales; h->capStep = h->P.scale_step;
+    for (int k = 0; k < 6; ++k) ln.scr[k] = ln.arena + offScr[k];
+    ln.pack = pk ? ln.arena + offPack : nullptr;
+    for (int k = 0; k < 12; ++k) ln.pbuf[k / 6][k % 6] = (k % 6 >= 4 && !gam) ? nullptr : ln.arena + offP[k];
+    ln.capGamma = gam; ln.capMedian = med; ln.capPack = pk;
+    ln.capW = W; ln.capH = H; ln.capB = B; ln.capScales = P.nscales; ln.capStep = P.scale_step;
     return MI_OK;
 }
 
@@ -247,110 +286,108 @@ static int check_pair(const mi_mat *I0, const mi_mat *I1, const mi_mat *flow, co
     return MI_OK;
 }
 
-int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream_)
+// The whole coarse-to-fine computation of n pairs on one stream (OpticalFlowDual_TVL1_Impl::calcImpl + procOneScale).
+static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, hipStream_t st, int *ns_out)
 {
-    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
-    MI_REQUIRE(n > 0 && I0s && I1s && flows, MI_ERR_BAD_ARG, "empty batch");
-    hipStream_t st = (hipStream_t)stream_;
     const mi_tvl1_params &P = h->P;
-    for (int i = 0; i < n; ++i) {
-        int rc = check_pair(&I0s[i], &I1s[i], &flows[i], &I0s[0]);
-        if (rc) return rc;
-    }
     const int W = I0s[0].cols, H = I0s[0].rows, B = n;
-    int rc = ensure_arena(h, W, H, B);
+    int rc = ensure_arena(P, ln, W, H, B);
     if (rc) return rc;
-    const int nl_built = (int)h->L.size();
+    ln.batch = B;
+    const int nl_built = (int)ln.L.size();
     // number of usable scales (tvl1flow.cpp:243-247)
     int ns = nl_built;
-    if (ns > 1 && (h->L[ns - 1].g.w < 16 || h->L[ns - 1].g.h < 16)) ns -= 1;
-    for (int l = 0; l < nl_built; ++l) h->L[l].g.batch = B;
+    if (ns > 1 && (ln.L[ns - 1].g.w < 16 || ln.L[ns - 1].g.h < 16)) ns -= 1;
+    *ns_out = ns;
+    for (int l = 0; l < nl_built; ++l) ln.L[l].g.batch = B;
 
     // external pointer table
-    if (h->tab_cap < B) {
-        if (h->tab_dev) (void)hipFree(h->tab_dev);
-        MI_HIP_TRY(hipMalloc((void **)&h->tab_dev, sizeof(PtrTab) * B));
-        h->tab_cap = B;
+    if (ln.tab_cap < B) {
+        if (ln.tab_dev) (void)hipFree(ln.tab_dev);
+        ln.tab_dev = nullptr; ln.tab_cap = 0;
+        MI_HIP_TRY(hipMalloc((void **)&ln.tab_dev, sizeof(PtrTab) * B));
+        ln.tab_cap = B;
     }
     {
-        std::vector<PtrTab> &tab = h->tab_host;
+        std::vector<PtrTab> &tab = ln.tab_host;
         tab.resize(B);
         for (int i = 0; i < B; ++i) {
             tab[i].a = I0s[i].data; tab[i].b = I1s[i].data; tab[i].out = flows[i].data;
             tab[i].step_a = (long long)I0s[i].step; tab[i].step_b = (long long)I1s[i].step;
             tab[i].step_out = (long long)flows[i].step;
         }
-        // pageable source: a few KB, staged by the runtime before the call returns; kept in the handle anyway
-        MI_HIP_TRY(hipMemcpyAsync(h->tab_dev, tab.data(), sizeof(PtrTab) * B, hipMemcpyHostToDevice, st));
+        // pageable source: a few KB, staged by the runtime before the call returns; kept in the lane anyway
+        MI_HIP_TRY(hipMemcpyAsync(ln.tab_dev, tab.data(), sizeof(PtrTab) * B, hipMemcpyHostToDevice, st));
     }
 
     const int iters_per_warp = P.iterations * P.inner_iterations;
     const bool check = P.epsilon > 0.0 && iters_per_warp > 0;
-    const int Q = ns * P.warps * iters_per_warp;
+    const long long Q = (long long)ns * P.warps * iters_per_warp;
     if (check) {
-        if (h->Q < Q || h->ctlB < B) {
-            if (h->S) (void)hipFree(h->S);
-            if (h->E) (void)hipFree(h->E);
-            if (h->Pd) (void)hipFree(h->Pd);
-            h->S = nullptr; h->E = nullptr; h->Pd = nullptr;
-            MI_HIP_TRY(hipMalloc((void **)&h->S, sizeof(int2) * (size_t)Q * B));
-            MI_HIP_TRY(hipMalloc((void **)&h->E, sizeof(unsigned long long) * (size_t)Q * B));
-            MI_HIP_TRY(hipMalloc((void **)&h->Pd, sizeof(double) * (size_t)Q * B));
-            h->Q = Q; h->ctlB = B;
+        MI_REQUIRE(Q <= kMaxSlots, MI_ERR_BAD_ARG, "scales x warps x iterations = %lld control slots exceed the limit of %lld", Q, kMaxSlots);
+        if (ln.Q < Q || ln.ctlB < B) {
+            if (ln.S) (void)hipFree(ln.S);
+            if (ln.E) (void)hipFree(ln.E);
+            if (ln.Pd) (void)hipFree(ln.Pd);
+            ln.S = nullptr; ln.E = nullptr; ln.Pd = nullptr; ln.Q = 0; ln.ctlB = 0;
+            MI_HIP_TRY(hipMalloc((void **)&ln.S, sizeof(int2) * (size_t)Q * B));
+            MI_HIP_TRY(hipMalloc((void **)&ln.E, sizeof(unsigned long long) * (size_t)Q * B));
+            MI_HIP_TRY(hipMalloc((void **)&ln.Pd, sizeof(double) * (size_t)Q * B));
+            ln.Q = Q; ln.ctlB = B;
         }
-        MI_HIP_TRY(hipMemsetAsync(h->E, 0, sizeof(unsigned long long) * (size_t)h->Q * B, st));
-        MI_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(int2) * (size_t)h->Q * B, st));
+        MI_HIP_TRY(hipMemsetAsync(ln.E, 0, sizeof(unsigned long long) * (size_t)ln.Q * B, st));
+        MI_HIP_TRY(hipMemsetAsync(ln.S, 0, sizeof(int2) * (size_t)ln.Q * B, st));
     }
-    h->slots.clear();
-    h->regions.clear();
+    ln.slots.clear();
+    ln.regions.clear();
     size_t ev_used = 0;
     auto next_event = [&](int *idx) -> int {
-        if (ev_used == h->ev_pool.size()) {
+        if (ev_used == ln.ev_pool.size()) {
             hipEvent_t e;
             MI_HIP_TRY(hipEventCreate(&e));
-            h->ev_pool.push_back(e);
+            ln.ev_pool.push_back(e);
         }
         *idx = (int)ev_used++;
         return MI_OK;
     };
-    h->last_nscales = ns; h->last_batch = B; h->last_check = check;
 
     const int sem = P.semantics;
+    const bool legacy_warp = tuning().warp_legacy != 0;
     // level 0: convertTo(CV_32F, 8U ? 1 : 255)  tvl1flow.cpp:200-201
-    rc = convert(h->tab_dev, I0s[0].type, h->L[0].I0, h->L[0].I1, h->L[0].g, st);
+    rc = convert(ln.tab_dev, I0s[0].type, ln.L[0].I0, ln.L[0].I1, ln.L[0].g, st);
     if (rc) return rc;
     if (P.use_initial_flow) {
         // CPU behaviour (optflow/src/tvl1flow.cpp:435-439); the CUDA calc() never splits the
         // caller's flow (latent reference bug).
-        rc = unpack_flow(h->tab_dev, h->L[0].u[0][0], h->L[0].u[0][1], h->L[0].g, st);
+        rc = unpack_flow(ln.tab_dev, ln.L[0].u[0][0], ln.L[0].u[0][1], ln.L[0].g, st);
         if (rc) return rc;
     }
     const float one3[3] = {1.f, 1.f, 1.f};
     // create the scales (tvl1flow.cpp:238-266)
     for (int s = 1; s < nl_built; ++s) {
-        const float *src[3][2] = {{h->L[s - 1].I0, nullptr}, {h->L[s - 1].I1, nullptr}, {nullptr, nullptr}};
-        float *dst[3] = {h->L[s].I0, h->L[s].I1, nullptr};
-        rc = resize(sem, 2, src, 1, dst, h->L[s - 1].g, h->L[s].g, P.scale_step, P.scale_step, one3, nullptr, 0, st);
+        const float *src[3][2] = {{ln.L[s - 1].I0, nullptr}, {ln.L[s - 1].I1, nullptr}, {nullptr, nullptr}};
+        float *dst[3] = {ln.L[s].I0, ln.L[s].I1, nullptr};
+        rc = resize(sem, 2, src, 1, dst, ln.L[s - 1].g, ln.L[s].g, P.scale_step, P.scale_step, one3, nullptr, 0, st);
         if (rc) return rc;
         if (s >= ns) break;
         if (P.use_initial_flow) {
-            const float *us[3][2] = {{h->L[s - 1].u[0][0], nullptr}, {h->L[s - 1].u[0][1], nullptr}, {nullptr, nullptr}};
-            float *ud[3] = {h->L[s].u[0][0], h->L[s].u[0][1], nullptr};
+            const float *us[3][2] = {{ln.L[s - 1].u[0][0], nullptr}, {ln.L[s - 1].u[0][1], nullptr}, {nullptr, nullptr}};
+            float *ud[3] = {ln.L[s].u[0][0], ln.L[s].u[0][1], nullptr};
             const float sc = (float)P.scale_step;
             const float post[3] = {sc, sc, 1.f};
-            rc = resize(sem, 2, us, 1, ud, h->L[s - 1].g, h->L[s].g, P.scale_step, P.scale_step, post, nullptr, 0, st);
+            rc = resize(sem, 2, us, 1, ud, ln.L[s - 1].g, ln.L[s].g, P.scale_step, P.scale_step, post, nullptr, 0, st);
             if (rc) return rc;
         }
     }
     if (!P.use_initial_flow) {
-        const Geo &g = h->L[ns - 1].g;
-        MI_HIP_TRY(hipMemsetAsync(h->L[ns - 1].u[0][0], 0, sizeof(float) * (size_t)g.ps * B, st));
-        MI_HIP_TRY(hipMemsetAsync(h->L[ns - 1].u[0][1], 0, sizeof(float) * (size_t)g.ps * B, st));
+        const Geo &g = ln.L[ns - 1].g;
+        MI_HIP_TRY(hipMemsetAsync(ln.L[ns - 1].u[0][0], 0, sizeof(float) * (size_t)g.ps * B, st));
+        MI_HIP_TRY(hipMemsetAsync(ln.L[ns - 1].u[0][1], 0, sizeof(float) * (size_t)g.ps * B, st));
     }
     const bool gam = P.gamma != 0.0;
     if (gam) {   // u3 starts at 0 on the coarsest scale (tvl1flow.cpp:273-275; optflow tvl1flow.cpp:498-500)
-        const Geo &g = h->L[ns - 1].g;
-        MI_HIP_TRY(hipMemsetAsync(h->L[ns - 1].u[0][2], 0, sizeof(float) * (size_t)g.ps * B, st));
+        const Geo &g = ln.L[ns - 1].g;
+        MI_HIP_TRY(hipMemsetAsync(ln.L[ns - 1].u[0][2], 0, sizeof(float) * (size_t)g.ps * B, st));
     }
 
     const float l_t = (float)(P.lambda * P.theta);
@@ -361,21 +398,22 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
     int cur = 0;              // host-known buffer set (fixed-work mode)
     Ctl ctl;
     memset(&ctl, 0, sizeof(ctl));
-    ctl.S = h->S; ctl.E = h->E; ctl.Q = h->Q;
-    ctl.P = h->Pd; ctl.sched = (P.semantics == MI_SEM_CUDA_COMPAT) ? 1 : 0;   // cv::cuda's check schedule vs the CPU class's every-iteration check
+    ctl.S = ln.S; ctl.E = ln.E; ctl.Q = (int)ln.Q;
+    ctl.P = ln.Pd; ctl.sched = (P.semantics == MI_SEM_CUDA_COMPAT) ? 1 : 0;   // cv::cuda's check schedule vs the CPU class's every-iteration check
 
     for (int s = ns - 1; s >= 0; --s) {
-        LevelBuf &Lv = h->L[s];
+        LevelBuf &Lv = ln.L[s];
         Geo g = Lv.g;
         // dense per-level re-layout of the full-resolution scratch planes
-        float *I1wx = h->scr[2], *I1wy = h->scr[3], *grad = h->scr[4], *rho = h->scr[5];
-        // pair stride of the packed plane is g.ps float4 = 4*g.ps floats: same element index as the planes
-        rc = gradient_pack(Lv.I1, h->pack, g, st);
-        if (rc) return rc;
+        float *I1wx = ln.scr[2], *I1wy = ln.scr[3], *grad = ln.scr[4], *rho = ln.scr[5];
+        if (legacy_warp) {   // pair stride of the packed plane is g.ps float4 = 4*g.ps floats: same element index as the planes
+            rc = gradient_pack(Lv.I1, ln.pack, g, st);
+            if (rc) return rc;
+        }
         const float *u1v[2] = {Lv.u[0][0], Lv.u[1][0]}, *u2v[2] = {Lv.u[0][1], Lv.u[1][1]};
         IterPlanes pl;
         pl.ix = I1wx; pl.iy = I1wy; pl.g = grad; pl.rc = rho;
-        for (int k = 0; k < 2; ++k) { for (int j = 0; j < 3; ++j) pl.u[k][j] = Lv.u[k][j]; for (int j = 0; j < 6; ++j) pl.p[k][j] = h->pbuf[k][j]; }
+        for (int k = 0; k < 2; ++k) { for (int j = 0; j < 3; ++j) pl.u[k][j] = Lv.u[k][j]; for (int j = 0; j < 6; ++j) pl.p[k][j] = ln.pbuf[k][j]; }
         pl.gamma = (float)P.gamma;
         pl.err_u3 = sem == MI_SEM_CPU_REF ? 1 : 0;   // optflow tvl1flow.cpp:1110 vs cuda tvl1flow.cu:276-283
         cur = 0;
@@ -389,26 +427,28 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
             wc.q_prev = q_last;
             // at the first warp of a scale u lives in set 0 (host-known)
             const bool dev_cur = check && !first_of_scale;
-            rc = warp(sem, Lv.I0, h->pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g,
-                      dev_cur ? &wc : nullptr, cur, st);
+            if (legacy_warp)
+                rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
+            else
+                rc = warp_fused(sem, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             if (rc) return rc;
             int e0 = -1, e1 = -1;
             if (h->profiling && iters_per_warp > 0) {
                 rc = next_event(&e0); if (rc) return rc;
-                MI_HIP_TRY(hipEventRecord(h->ev_pool[e0], st));
+                MI_HIP_TRY(hipEventRecord(ln.ev_pool[e0], st));
             }
             const bool blocked = !check && !P.exact_math && P.time_block != 1 && !gam;
             long long nlaunch = 0;
             const int mf = P.median_filtering > 1 ? P.median_filtering : 0;
             float *const mu1[2] = {Lv.u[0][0], Lv.u[1][0]}, *const mu2[2] = {Lv.u[0][1], Lv.u[1][1]};
             if (blocked) {
-                // T iterations per HBM pass (tvl1_tb_kernels.hip), decomposition by measured cost; the optional median
+                // T iterations per HBM pass (tvl1_tbr_kernels.hip), decomposition by measured cost; the optional median
                 // filter sits between outer iterations, so blocks never span more than inner_iterations
                 const int per = mf ? P.inner_iterations : iters_per_warp, nouter = mf ? P.iterations : 1;
                 std::vector<int> plan(per + 1);
                 const int nb = tb_plan(per, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), per);
                 for (int no = 0; no < nouter; ++no) {
-                    if (mf && (rc = median_flow(mf, mu1, mu2, h->scr[0], h->scr[1], g, nullptr, cur, st))) return rc;
+                    if (mf && (rc = median_flow(mf, mu1, mu2, ln.scr[0], ln.scr[1], g, nullptr, cur, st))) return rc;
                     for (int k = 0; k < nb; ++k) {
                         ++nlaunch;
                         rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
@@ -422,7 +462,7 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
                 if (mf && it % P.inner_iterations == 0) {   // cv::medianBlur before each outer iteration (optflow tvl1flow.cpp:1381-1384)
                     Ctl mc = ctl;
                     mc.q_prev = q_last; mc.first_of_warp = (it == 0); mc.reset_cur = first_of_scale;
-                    if ((rc = median_flow(mf, mu1, mu2, h->scr[0], h->scr[1], g, check ? &mc : nullptr, cur, st))) return rc;
+                    if ((rc = median_flow(mf, mu1, mu2, ln.scr[0], ln.scr[1], g, check ? &mc : nullptr, cur, st))) return rc;
                 }
                 if (check) {
                     Ctl ic = ctl;
@@ -431,7 +471,7 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
                     ic.reset_cur = first_of_scale;
                     ic.n = it;
                     rc = iterate(P.exact_math != 0, pl, g, l_t, theta, taut, first_of_scale, &ic, 0, st);
-                    h->slots.push_back({s, wp});
+                    ln.slots.push_back({s, wp});
                     q_last = q++;
                 } else {
                     rc = iterate(P.exact_math != 0, pl, g, l_t, theta, taut, first_of_scale, nullptr, cur, st);
@@ -442,29 +482,77 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
             }
             if (e0 >= 0) {
                 rc = next_event(&e1); if (rc) return rc;
-                MI_HIP_TRY(hipEventRecord(h->ev_pool[e1], st));
-                h->regions.push_back({e0, e1, nlaunch, 64.0 * g.w * g.h * B * iters_per_warp});
+                MI_HIP_TRY(hipEventRecord(ln.ev_pool[e1], st));
+                ln.regions.push_back({e0, e1, nlaunch, 64.0 * g.w * g.h * B * iters_per_warp});
             }
         }
         Ctl ec = ctl;
         ec.q_prev = q_last;
         const bool dev_cur = check && !first_of_scale;
         if (s == 0) {
-            rc = pack_flow(h->tab_dev, u1v, u2v, g, dev_cur ? &ec : nullptr, cur, st);
+            rc = pack_flow(ln.tab_dev, u1v, u2v, g, dev_cur ? &ec : nullptr, cur, st);
             if (rc) return rc;
             break;
         }
         // zoom the flow to the next finer scale and rescale it (tvl1flow.cpp:291-300)
-        const Geo &gf = h->L[s - 1].g;
+        const Geo &gf = ln.L[s - 1].g;
         // u3 is zoomed too but NOT rescaled (tvl1flow.cpp:293-300; optflow tvl1flow.cpp:524-528)
         const float *us[3][2] = {{Lv.u[0][0], Lv.u[1][0]}, {Lv.u[0][1], Lv.u[1][1]}, {gam ? Lv.u[0][2] : nullptr, gam ? Lv.u[1][2] : nullptr}};
-        float *ud[3] = {h->L[s - 1].u[0][0], h->L[s - 1].u[0][1], gam ? h->L[s - 1].u[0][2] : nullptr};
+        float *ud[3] = {ln.L[s - 1].u[0][0], ln.L[s - 1].u[0][1], gam ? ln.L[s - 1].u[0][2] : nullptr};
         const float inv = (float)(1.0 / P.scale_step);
         const float post[3] = {inv, inv, 1.f};
         rc = resize(sem, gam ? 3 : 2, us, 2, ud, g, gf, (double)gf.w / g.w, (double)gf.h / g.h, post,
                     dev_cur ? &ec : nullptr, cur, st);
         if (rc) return rc;
     }
+    return MI_OK;
+}
+
+int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream_)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    MI_REQUIRE(n > 0 && I0s && I1s && flows, MI_ERR_BAD_ARG, "empty batch");
+    hipStream_t st = (hipStream_t)stream_;
+    for (int i = 0; i < n; ++i) {
+        int rc = check_pair(&I0s[i], &I1s[i], &flows[i], &I0s[0]);
+        if (rc) return rc;
+    }
+    // Lanes: a batch of >= 4 pairs is split into two halves that run concurrently on two internal streams, forked from and
+    // joined to the caller's stream with events (stream-ordered for the caller exactly like the single-stream form).  The pairs
+    // are independent, so the result is bit-identical to running them in one lane.
+    int lanes = h->P.lanes > 0 ? h->P.lanes : (tuning().lanes > 0 ? tuning().lanes : (n >= 4 ? 2 : 1));
+    if (lanes > 2) lanes = 2;
+    if (lanes > n) lanes = n;
+    const int n0 = lanes == 2 ? (n + 1) / 2 : n;
+    int ns = 0;
+    h->last_check = h->P.epsilon > 0.0 && h->P.iterations * h->P.inner_iterations > 0;
+    h->last_batch = n; h->last_lanes = lanes; h->last_split = n0;
+    if (lanes == 1) {
+        int rc = lane_calc(h, h->lane[0], n, I0s, I1s, flows, st, &ns);
+        if (rc) return rc;
+    } else {
+        if (!h->fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
+        for (Lane &ln : h->lane) {
+            if (!ln.stream) MI_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            if (!ln.done) MI_HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        }
+        MI_HIP_TRY(hipEventRecord(h->fork, st));
+        int rc_first = MI_OK;
+        for (int li = 0; li < 2; ++li) {
+            Lane &ln = h->lane[li];
+            const int off = li == 0 ? 0 : n0, cnt = li == 0 ? n0 : n - n0;
+            MI_HIP_TRY(hipStreamWaitEvent(ln.stream, h->fork, 0));
+            const int rc = lane_calc(h, ln, cnt, I0s + off, I1s + off, flows + off, ln.stream, &ns);
+            if (rc && !rc_first) rc_first = rc;
+            // always join, also after an error: the caller's stream must not run ahead of work already enqueued
+            MI_HIP_TRY(hipEventRecord(ln.done, ln.stream));
+            MI_HIP_TRY(hipStreamWaitEvent(st, ln.done, 0));
+        }
+        if (rc_first) return rc_first;
+    }
+    h->last_nscales = ns;
+    // the reference shrinks nscales_ for good when a level falls below 16 px (tvl1flow.cpp:243-247: `nscales_ = s; break;`)
+    if (ns < h->P.nscales) h->P.nscales = ns;
     return MI_OK;
 }
 
@@ -485,11 +573,13 @@ int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int *iters,
         for (int i = 0; i < ns * nw; ++i) iters[i] = h->P.iterations * h->P.inner_iterations;
         return MI_OK;
     }
-    const int nq = (int)h->slots.size();
+    Lane &ln = h->lane[(h->last_lanes == 2 && pair >= h->last_split) ? 1 : 0];
+    const int lp = (h->last_lanes == 2 && pair >= h->last_split) ? pair - h->last_split : pair;
+    const int nq = (int)ln.slots.size();
     std::vector<int2> S(nq);
     MI_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    MI_HIP_TRY(hipMemcpy(S.data(), h->S + (size_t)pair * h->Q, sizeof(int2) * nq, hipMemcpyDeviceToHost));
+    MI_HIP_TRY(hipMemcpy(S.data(), ln.S + (size_t)lp * ln.Q, sizeof(int2) * nq, hipMemcpyDeviceToHost));
     for (int i = 0; i < nq; ++i)
-        if (S[i].y & 1) iters[h->slots[i].scale * nw + h->slots[i].warp] += 1;
+        if (S[i].y & 1) iters[ln.slots[i].scale * nw + ln.slots[i].warp] += 1;
     return MI_OK;
 }

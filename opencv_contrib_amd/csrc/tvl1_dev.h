@@ -66,12 +66,17 @@ int pack3(const float *a, const float *b, const float *c, float *pk, const Geo &
 int warp(int semantics, const float *I0, const float *pk, const float *u1[2], const float *u2[2], float *I1w,
          float *I1wx, float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl,
          int cur_host, hipStream_t s);
+// the same with the centred gradient of I1 derived inside the kernel from a 6 x 6 window of I1 (tvl1_warp_kernels.hip): no packed
+// plane, half the gathered bytes, bit-identical results
+int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
+               float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
+               hipStream_t s);
 // one fused iteration (estimateU + estimateDualVariables), set cur -> set cur^1.
 // p_zero: p_in is known to be all-zero (first iteration of a scale) and is not read.
 int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut,
             bool p_zero, const Ctl *ctl, int cur_host, hipStream_t s);
 
-// Temporally blocked fast-math iteration (tvl1_tb_kernels.hip): T fused iterations in one HBM pass,
+// Temporally blocked fast-math iteration (tvl1_tbr_kernels.hip): T fused iterations in one HBM pass,
 // set cur -> cur^1.  Supported T: 1,2,3,4,5,6,8,10.  rows_per_band <= 0: auto.
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s);

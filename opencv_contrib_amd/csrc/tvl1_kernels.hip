@@ -16,6 +16,7 @@
 // rounded binary32 operations, in the same order, as the CPU reference
 // (modules/optflow/src/tvl1flow.cpp); fast-math variants use explicit fmaf/rcp.
 #include "tvl1_dev.h"
+#include "tvl1_warp_dev.h"
 #include <cfloat>
 #include <cstdlib>
 #include <climits>
@@ -35,32 +36,6 @@ __device__ __forceinline__ void st4(float *p, long long off, bool ok, const floa
 #define UNPACK4(dst, v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
 __device__ __forceinline__ float lane_prev(float v) { return __shfl_up(v, 1); }   // lane n <- n-1
 __device__ __forceinline__ float lane_next(float v) { return __shfl_down(v, 1); } // lane n <- n+1
-
-struct CtlK {  // by-value copy for kernels (Ctl may be absent)
-    int2 *S;         // per slot {cur_in, flags}: flags bit 0 = the launch was active, bit 1 = it summed the error
-    unsigned long long *E;
-    int Q, q, q_prev, first_of_warp, reset_cur;
-    double thr;
-    double *P;
-    int sched, n;
-};
-static CtlK make_ctlk(const Ctl *c)
-{
-    CtlK k;
-    memset(&k, 0, sizeof(k));
-    k.q_prev = -1;
-    if (c) { k.S = c->S; k.E = c->E; k.Q = c->Q; k.q = c->q; k.q_prev = c->q_prev;
-             k.first_of_warp = c->first_of_warp; k.reset_cur = c->reset_cur; k.thr = c->thr;
-             k.P = c->P; k.sched = c->sched; k.n = c->n; }
-    return k;
-}
-__device__ __forceinline__ int resolve_cur_k(const CtlK &c, int b, int cur_host)
-{
-    if (!c.S) return cur_host;
-    if (c.q_prev < 0) return 0;
-    const int2 s = c.S[(long long)b * c.Q + c.q_prev];
-    return s.x ^ (s.y & 1);
-}
 
 #define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */
 
@@ -389,313 +364,6 @@ __global__ __launch_bounds__(256) void k_warp(WarpArgs A, CtlK ctl, int cur_host
     A.I1wx[o] = v1;
     A.I1wy[o] = v2;
     // calcGradRho  optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163
-    const float Ix2 = v1 * v1, Iy2 = v2 * v2;
-    A.grad[o] = Ix2 + Iy2;
-    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
-}
-
-// ------------------------------------------------------------------ warp, 4 pixels per lane (CPU_REF semantics)
-// Same arithmetic as k_warp<CPU_REF>, reorganised for the texture-addresser: a lane owns 4 consecutive pixels; when
-// their bicubic windows are the common "rigid" case (same first row, first columns sx0, sx0+1, sx0+2, sx0+3 -- any
-// locally smooth flow) the union footprint of 7 x 4 float4 {I1, I1x, I1y} elements is loaded ONCE per row (7 gathers
-// instead of 16 per row) and every pixel takes its 4-wide sub-window from registers; u1, u2, I0 and the four outputs
-// move as dwordx4.  Pixels whose windows are not rigid, or touch the border, take the per-pixel path.
-__device__ __forceinline__ void warp_px_generic(const float4 *P, int W, int H, int ld, int sx, int sy, const float w[16],
-                                                float &v0, float &v1, float &v2)
-{
-    if ((unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0)) {
-        const float4 *S = P + (long long)sy * ld + sx;
-        float4 a = S[0], b4 = S[1], c = S[2], d = S[3];
-        float s0 = a.x * w[0] + b4.x * w[1] + c.x * w[2] + d.x * w[3];
-        float s1 = a.y * w[0] + b4.y * w[1] + c.y * w[2] + d.y * w[3];
-        float s2 = a.z * w[0] + b4.z * w[1] + c.z * w[2] + d.z * w[3];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-            S += ld; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
-            s0 += a.x * w[4 * r] + b4.x * w[4 * r + 1] + c.x * w[4 * r + 2] + d.x * w[4 * r + 3];
-            s1 += a.y * w[4 * r] + b4.y * w[4 * r + 1] + c.y * w[4 * r + 2] + d.y * w[4 * r + 3];
-            s2 += a.z * w[4 * r] + b4.z * w[4 * r + 1] + c.z * w[4 * r + 2] + d.z * w[4 * r + 3];
-        }
-        v0 = s0; v1 = s1; v2 = s2;
-    } else if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
-        v0 = v1 = v2 = 0.f;
-    } else {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int i = 0; i < 4; ++i) {
-            const int yi = sy + i;
-            if (yi < 0 || yi >= H) continue;
-            for (int j = 0; j < 4; ++j) {
-                const int xj = sx + j;
-                if (xj < 0 || xj >= W) continue;
-                const float4 t = P[(long long)yi * ld + xj];
-                s0 += (t.x - 0.f) * w[i * 4 + j];
-                s1 += (t.y - 0.f) * w[i * 4 + j];
-                s2 += (t.z - 0.f) * w[i * 4 + j];
-            }
-        }
-        v0 = s0; v1 = s1; v2 = s2;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_warp4(WarpArgs A, CtlK ctl, int cur_host)
-{
-    __shared__ float s_tab[128];
-    if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
-    __syncthreads();
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.z;
-    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
-    if (x0 >= W || y >= H) return;
-    const int cur = resolve_cur_k(ctl, b, cur_host);
-    const long long pb = (long long)b * A.g.ps;
-    const long long o = pb + (long long)y * ld + x0;   // rows are padded to ld (multiple of 64 floats): float4 access is in bounds
-    const float4 *P = A.pk + pb;
-    float u1v[4], u2v[4], i0v[4];
-    { const float4 t = *reinterpret_cast<const float4 *>(A.u1[cur] + o); UNPACK4(u1v, t); }
-    { const float4 t = *reinterpret_cast<const float4 *>(A.u2[cur] + o); UNPACK4(u2v, t); }
-    { const float4 t = *reinterpret_cast<const float4 *>(A.I0 + o); UNPACK4(i0v, t); }
-    int sx[4], sy[4], px[4], py[4];
-    bool rigid = true;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // buildFlowMap + cv::remap(INTER_CUBIC): map quantised to 1/32 px (optflow/src/tvl1flow.cpp:650-666,1371-1374)
-        const bool valid = x0 + j < W;
-        const float mx = (float)(x0 + j) + (valid ? u1v[j] : 0.f), my = (float)y + (valid ? u2v[j] : 0.f);
-        const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
-        sx[j] = min(max(qx >> 5, -32768), 32767) - 1;
-        sy[j] = min(max(qy >> 5, -32768), 32767) - 1;
-        px[j] = (qx & 31) * 4; py[j] = (qy & 31) * 4;
-        if (valid) rigid = rigid && sy[j] == sy[0] && sx[j] == sx[0] + j;
-    }
-    rigid = rigid && (unsigned)sx[0] < (unsigned)max(W - 6, 0) && (unsigned)sy[0] < (unsigned)max(H - 3, 0);
-    float v0[4], v1[4], v2[4];
-    if (rigid) {
-        const float4 *S = P + (long long)sy[0] * ld + sx[0];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float4 t[7];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) t[k] = S[k];
-            S += ld;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float wy = s_tab[py[j] + r];
-                const float w0 = wy * s_tab[px[j]], w1 = wy * s_tab[px[j] + 1], w2 = wy * s_tab[px[j] + 2], w3 = wy * s_tab[px[j] + 3];
-                const float e0 = t[j].x * w0 + t[j + 1].x * w1 + t[j + 2].x * w2 + t[j + 3].x * w3;
-                const float e1 = t[j].y * w0 + t[j + 1].y * w1 + t[j + 2].y * w2 + t[j + 3].y * w3;
-                const float e2 = t[j].z * w0 + t[j + 1].z * w1 + t[j + 2].z * w2 + t[j + 3].z * w3;
-                if (r == 0) { v0[j] = e0; v1[j] = e1; v2[j] = e2; }
-                else { v0[j] += e0; v1[j] += e1; v2[j] += e2; }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float w[16];
-#pragma unroll
-            for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2) w[k1 * 4 + k2] = s_tab[py[j] + k1] * s_tab[px[j] + k2];
-            warp_px_generic(P, W, H, ld, sx[j], sy[j], w, v0[j], v1[j], v2[j]);
-        }
-    }
-    float g[4], rh[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // calcGradRho  optflow/src/tvl1flow.cpp:918-944
-        const float Ix2 = v1[j] * v1[j], Iy2 = v2[j] * v2[j];
-        g[j] = Ix2 + Iy2;
-        rh[j] = (v0[j] - v1[j] * u1v[j] - v2[j] * u2v[j] - i0v[j]);
-    }
-    if (A.I1w) st4(A.I1w, o, true, v0);
-    st4(A.I1wx, o, true, v1);
-    st4(A.I1wy, o, true, v2);
-    st4(A.grad, o, true, g);
-    st4(A.rho, o, true, rh);
-}
-
-// ------------------------------------------------------------------ warp through an LDS tile (CPU_REF semantics)
-// Same arithmetic as k_warp<CPU_REF>.  The 16 gathers per pixel of k_warp are bound by the texture addresser
-// (~4 lanes/clk per wave-load, r01a/r01g profiles: 269 us/launch).  Here a workgroup (4 rows x 64 px) first finds the
-// bounding box of all its bicubic windows (wave min/max + LDS), stages that box of {I1, I1x, I1y} float4 elements into
-// LDS with coalesced 16-B loads, and every pixel reads its 16 taps with ds_read_b128.  Workgroups whose box does not fit
-// the tile (large or discontinuous motion) and pixels whose window leaves the image take the per-pixel global path.
-#define WT_W 88   // tile columns  (64 px + 3 + 21 px of horizontal motion spread)
-#define WT_H 16   // tile rows     (4 rows + 3 + 9 rows of vertical motion spread)
-__global__ __launch_bounds__(256) void k_warp_lds(WarpArgs A, CtlK ctl, int cur_host)
-{
-    __shared__ float s_tab[128];
-    __shared__ int s_mm[4][4];
-    __shared__ float4 s_tile[WT_H * WT_W];
-    if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + wv;
-    const int b = blockIdx.z;
-    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
-    const bool valid = x < W && y < H;
-    const int cur = resolve_cur_k(ctl, b, cur_host);
-    const long long pb = (long long)b * A.g.ps;
-    const long long o = pb + (long long)min(y, H - 1) * ld + min(x, W - 1);
-    const float4 *P = A.pk + pb;
-    const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
-    // buildFlowMap + cv::remap(INTER_CUBIC): map quantised to 1/32 px (optflow/src/tvl1flow.cpp:650-666,1371-1374)
-    const float mx = (float)x + u1v, my = (float)y + u2v;
-    const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
-    const int sx = min(max(qx >> 5, -32768), 32767) - 1;
-    const int sy = min(max(qy >> 5, -32768), 32767) - 1;
-    const bool inside = valid && (unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0);
-    // bounding box of the windows that lie inside the image
-    int mnx = inside ? sx : INT_MAX, mxx = inside ? sx : INT_MIN, mny = inside ? sy : INT_MAX, mxy = inside ? sy : INT_MIN;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, off)); mxx = max(mxx, __shfl_xor(mxx, off));
-        mny = min(mny, __shfl_xor(mny, off)); mxy = max(mxy, __shfl_xor(mxy, off));
-    }
-    if (lane == 0) { s_mm[wv][0] = mnx; s_mm[wv][1] = mxx; s_mm[wv][2] = mny; s_mm[wv][3] = mxy; }
-    __syncthreads();
-    const int tx0 = min(min(s_mm[0][0], s_mm[1][0]), min(s_mm[2][0], s_mm[3][0]));
-    const int tx1 = max(max(s_mm[0][1], s_mm[1][1]), max(s_mm[2][1], s_mm[3][1]));
-    const int ty0 = min(min(s_mm[0][2], s_mm[1][2]), min(s_mm[2][2], s_mm[3][2]));
-    const int ty1 = max(max(s_mm[0][3], s_mm[1][3]), max(s_mm[2][3], s_mm[3][3]));
-    const bool any_inside = tx1 >= tx0;
-    const int tw = any_inside ? tx1 + 4 - tx0 : 0, th = any_inside ? ty1 + 4 - ty0 : 0;
-    const bool use_tile = any_inside && tw <= WT_W && th <= WT_H;   // workgroup-uniform
-    if (use_tile) {
-        for (int i = threadIdx.x; i < th * tw; i += 256) {
-            const int r = i / tw, c = i - r * tw;
-            s_tile[r * WT_W + c] = P[(long long)(ty0 + r) * ld + tx0 + c];   // inside the image by construction
-        }
-    }
-    __syncthreads();
-    if (!valid) return;
-    const float *wxp = s_tab + (qx & 31) * 4, *wyp = s_tab + (qy & 31) * 4;
-    float w[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) w[k1 * 4 + k2] = wyp[k1] * wxp[k2];
-    float v0, v1, v2;
-    if (use_tile && inside) {
-        const float4 *S = s_tile + (sy - ty0) * WT_W + (sx - tx0);
-        float4 a = S[0], b4 = S[1], c = S[2], d = S[3];
-        float s0 = a.x * w[0] + b4.x * w[1] + c.x * w[2] + d.x * w[3];
-        float s1 = a.y * w[0] + b4.y * w[1] + c.y * w[2] + d.y * w[3];
-        float s2 = a.z * w[0] + b4.z * w[1] + c.z * w[2] + d.z * w[3];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-            S += WT_W; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
-            s0 += a.x * w[4 * r] + b4.x * w[4 * r + 1] + c.x * w[4 * r + 2] + d.x * w[4 * r + 3];
-            s1 += a.y * w[4 * r] + b4.y * w[4 * r + 1] + c.y * w[4 * r + 2] + d.y * w[4 * r + 3];
-            s2 += a.z * w[4 * r] + b4.z * w[4 * r + 1] + c.z * w[4 * r + 2] + d.z * w[4 * r + 3];
-        }
-        v0 = s0; v1 = s1; v2 = s2;
-    } else {
-        warp_px_generic(P, W, H, ld, sx, sy, w, v0, v1, v2);
-    }
-    if (A.I1w) A.I1w[o] = v0;
-    A.I1wx[o] = v1;
-    A.I1wy[o] = v2;
-    // calcGradRho  optflow/src/tvl1flow.cpp:918-944
-    const float Ix2 = v1 * v1, Iy2 = v2 * v2;
-    A.grad[o] = Ix2 + Iy2;
-    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
-}
-
-// ------------------------------------------------------------------ warp through PER-WAVE LDS tiles (CPU_REF semantics)
-// Same arithmetic and summation order as k_warp<CPU_REF> (bit-identical output).  A wave owns a TX x (64/TX) pixel patch; when
-// all its bicubic windows lie inside the image it takes the bounding box of the windows (four DPP max-reductions), stages
-// that box -- typically (TX+3+s) x (64/TX+3+s) elements for a flow spread s -- into its private LDS tile with a few
-// coalesced 16-B loads, and every lane reads its 16 taps with ds_read_b128.  The texture-addresser cost drops from 16 scattered
-// wave-loads per pixel to 3-6 coalesced ones per wave; there is no workgroup barrier (the workgroup-tile variant k_warp_lds
-// lost more to its two barriers than it saved).  Waves touching the image border or with a box larger than the tile take
-// the per-pixel path.
-#define WWT_CAP 448   // tile capacity in float4 elements (7 wave-loads, 7 KB per wave)
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-    unsigned u = (unsigned)v ^ 0x80000000u;   // order-preserving map to unsigned
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x111, 0xf, 0xf, true));
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x112, 0xf, 0xf, true));
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x114, 0xf, 0xf, true));
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x118, 0xf, 0xf, true));
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x142, 0xa, 0xf, true));
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x143, 0xc, 0xf, true));
-    return (int)((unsigned)__builtin_amdgcn_readlane((int)u, 63) ^ 0x80000000u);
-}
-template <int TX>
-__global__ __launch_bounds__(256) void k_warp_wt(WarpArgs A, CtlK ctl, int cur_host)
-{
-    __shared__ float s_tab[128];
-    __shared__ float4 s_tile[4][WWT_CAP];
-    if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
-    __syncthreads();
-    constexpr int TY = 64 / TX;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = blockIdx.x * TX + (lane % TX);
-    const int y = blockIdx.y * (4 * TY) + wv * TY + lane / TX;
-    const int b = blockIdx.z;
-    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
-    const bool valid = x < W && y < H;
-    const int cur = resolve_cur_k(ctl, b, cur_host);
-    const long long pb = (long long)b * A.g.ps;
-    const long long o = pb + (long long)min(y, H - 1) * ld + min(x, W - 1);
-    const float4 *P = A.pk + pb;
-    const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
-    // buildFlowMap + cv::remap(INTER_CUBIC): map quantised to 1/32 px (optflow/src/tvl1flow.cpp:650-666,1371-1374)
-    const float mx = (float)x + u1v, my = (float)y + u2v;
-    const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
-    const int sx = min(max(qx >> 5, -32768), 32767) - 1;
-    const int sy = min(max(qy >> 5, -32768), 32767) - 1;
-    const bool inside = (unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0);
-    // wave-uniform: every valid pixel's window inside the image?  (invalid lanes repeat a clamped valid pixel: harmless)
-    const bool all_inside = __ballot(inside) == ~0ull;
-    bool use_tile = false;
-    int tx0 = 0, ty0 = 0, tw = 1;
-    if (all_inside) {
-        tx0 = -wave_max_i32(-sx); ty0 = -wave_max_i32(-sy);
-        const int tx1 = wave_max_i32(sx), ty1 = wave_max_i32(sy);
-        tw = tx1 + 4 - tx0;
-        const int th = ty1 + 4 - ty0;
-        use_tile = tw * th <= WWT_CAP;   // wave-uniform
-        if (use_tile) {
-            float4 *T = s_tile[wv];
-            const int n = tw * th;
-            for (int i = lane; i < n; i += 64) {
-                const int r = i / tw, c = i - r * tw;
-                T[i] = P[(long long)(ty0 + r) * ld + tx0 + c];   // inside the image by construction
-            }
-        }
-    }
-    if (!valid) return;
-    const float *wxp = s_tab + (qx & 31) * 4, *wyp = s_tab + (qy & 31) * 4;
-    float w[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) w[k1 * 4 + k2] = wyp[k1] * wxp[k2];
-    float v0, v1, v2;
-    if (use_tile) {
-        const float4 *S = s_tile[wv] + (sy - ty0) * tw + (sx - tx0);
-        float4 a = S[0], b4 = S[1], c = S[2], d = S[3];
-        float s0 = a.x * w[0] + b4.x * w[1] + c.x * w[2] + d.x * w[3];
-        float s1 = a.y * w[0] + b4.y * w[1] + c.y * w[2] + d.y * w[3];
-        float s2 = a.z * w[0] + b4.z * w[1] + c.z * w[2] + d.z * w[3];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-            S += tw; a = S[0]; b4 = S[1]; c = S[2]; d = S[3];
-            s0 += a.x * w[4 * r] + b4.x * w[4 * r + 1] + c.x * w[4 * r + 2] + d.x * w[4 * r + 3];
-            s1 += a.y * w[4 * r] + b4.y * w[4 * r + 1] + c.y * w[4 * r + 2] + d.y * w[4 * r + 3];
-            s2 += a.z * w[4 * r] + b4.z * w[4 * r + 1] + c.z * w[4 * r + 2] + d.z * w[4 * r + 3];
-        }
-        v0 = s0; v1 = s1; v2 = s2;
-    } else {
-        warp_px_generic(P, W, H, ld, sx, sy, w, v0, v1, v2);
-    }
-    if (A.I1w) A.I1w[o] = v0;
-    A.I1wx[o] = v1;
-    A.I1wy[o] = v2;
-    // calcGradRho  optflow/src/tvl1flow.cpp:918-944
     const float Ix2 = v1 * v1, Iy2 = v2 * v2;
     A.grad[o] = Ix2 + Iy2;
     A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
@@ -1101,6 +769,9 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
          float *I1wx, float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl,
          int cur_host, hipStream_t s)
 {
+    // Packed-plane gather: one float4 {I1, I1x, I1y, 0} per bicubic tap.  Used by the stage-level entry point when the caller
+    // supplies its own derivative planes, and by calc() under MIFLOW_WARP=pk (the round-1 kernel, kept for A/B runs); calc()
+    // otherwise runs warp_fused (tvl1_warp_kernels.hip), which needs half the gathered bytes.
     WarpArgs A;
     A.I0 = I0; A.pk = reinterpret_cast<const float4 *>(pk);
     A.u1[0] = u1[0]; A.u1[1] = u1[1]; A.u2[0] = u2[0]; A.u2[1] = u2[1];
@@ -1108,27 +779,10 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
     A.tab = cubic_tab_dev;
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
-    // default: per-pixel float4 gathers (k_warp).  Two alternatives were built and measured SLOWER at 1080p x 16
-    // (profiles/r01h, r01i: k_warp 269 us/launch, k_warp_lds 325 us, k_warp4 376 us): fewer resident waves / strided lanes
-    // cost more memory-level parallelism than the saved texture-addresser work buys.  MIFLOW_WARP=lds|4 selects them.
-    static const char *wsel = getenv("MIFLOW_WARP");
-    if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == '4')
-        hipLaunchKernelGGL(k_warp4, dim3(div_up(g.w, 256), div_up(g.h, 4), g.batch), dim3(256), 0, s, A, ck, cur_host);
-    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'l')
-        hipLaunchKernelGGL(k_warp_lds, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
-    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'w' && wsel[1] == '3')    // per-wave tiles, 32 x 2 patches
-        hipLaunchKernelGGL((k_warp_wt<32>), dim3(div_up(g.w, 32), div_up(g.h, 8), g.batch), dim3(256), 0, s, A, ck, cur_host);
-    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'w' && wsel[1] == '8')    // 8 x 8 patches
-        hipLaunchKernelGGL((k_warp_wt<8>), dim3(div_up(g.w, 8), div_up(g.h, 32), g.batch), dim3(256), 0, s, A, ck, cur_host);
-    else if (semantics == MI_SEM_CPU_REF && wsel && wsel[0] == 'w')                      // 16 x 4 patches
-        hipLaunchKernelGGL((k_warp_wt<16>), dim3(div_up(g.w, 16), div_up(g.h, 16), g.batch), dim3(256), 0, s, A, ck, cur_host);
-    else if (semantics == MI_SEM_CPU_REF) {
-        static int tile = -1;
-        if (tile < 0) { const char *e = getenv("MIFLOW_WARP_TILE"); tile = e ? atoi(e) : 32; }   // r01u: 32 x 2 patch per wave +2 % on the bench (64: 881, 32: 902, 16: 878, 8: 784 pairs/s)
+    if (semantics == MI_SEM_CPU_REF) {
+        const int tile = warp_tile();   // r01u: 32 x 2 patch per wave +2 % on the bench (64: 881, 32: 902, 16: 878 pairs/s)
         if (tile == 16)
             hipLaunchKernelGGL((k_warp<MI_SEM_CPU_REF, 16>), dim3(div_up(g.w, 16), div_up(g.h, 16), g.batch), dim3(256), 0, s, A, ck, cur_host);
-        else if (tile == 8)
-            hipLaunchKernelGGL((k_warp<MI_SEM_CPU_REF, 8>), dim3(div_up(g.w, 8), div_up(g.h, 32), g.batch), dim3(256), 0, s, A, ck, cur_host);
         else if (tile == 32)
             hipLaunchKernelGGL((k_warp<MI_SEM_CPU_REF, 32>), dim3(div_up(g.w, 32), div_up(g.h, 8), g.batch), dim3(256), 0, s, A, ck, cur_host);
         else

@@ -3,6 +3,7 @@
 // modules/cudaoptflow/src/tvl1flow.cpp:58-76, and cuda::resize).  Caller planes may be
 // arbitrarily pitched; they are staged through dense 256-B-aligned scratch planes.
 #include "tvl1_dev.h"
+#include "mi_selftest.h"
 #include <vector>
 
 using namespace mi;
@@ -82,7 +83,12 @@ int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *I1, con
 {
     hipStream_t st = nullptr;
     MI_REQUIRE(semantics == MI_SEM_CPU_REF || semantics == MI_SEM_CUDA_COMPAT, MI_ERR_BAD_ARG, "bad semantics");
-    const mi_mat *ins[6] = {I0, I1, I1x, I1y, u1, u2};
+    // I1x == I1y == NULL: the derivative planes are the centred differences of I1, formed inside the warp kernel (the
+    // kernel calc() runs, tvl1_warp_kernels.hip); otherwise the caller's planes are gathered (any planes, k_warp)
+    const bool fused = !I1x && !I1y;
+    MI_REQUIRE(fused || (I1x && I1y), MI_ERR_BAD_ARG, "I1x and I1y must be both given or both NULL");
+    MI_REQUIRE(I0 && I1, MI_ERR_BAD_ARG, "null matrix");
+    const mi_mat *ins[6] = {I0, I1, fused ? I1 : I1x, fused ? I1 : I1y, u1, u2};
     mi_mat *outs[5] = {I1w, I1wx, I1wy, grad, rho};
     for (int i = 0; i < 6; ++i) { TRY(check_f32(ins[i], "input")); MI_REQUIRE(ins[i]->rows == I0->rows && ins[i]->cols == I0->cols, MI_ERR_BAD_SIZE, "input size mismatch"); }
     for (int i = 0; i < 5; ++i) { TRY(check_f32(outs[i], "output")); MI_REQUIRE(outs[i]->rows == I0->rows && outs[i]->cols == I0->cols, MI_ERR_BAD_SIZE, "output size mismatch"); }
@@ -97,11 +103,15 @@ int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *I1, con
     S.bufs.push_back(tabd);
     MI_HIP_TRY(hipMemcpyAsync(tabd, tabh, sizeof(tabh), hipMemcpyHostToDevice, st));
     const float *u1v[2] = {in[4], in[4]}, *u2v[2] = {in[5], in[5]};
-    float *pk = nullptr;   // {I1, I1x, I1y, 0} per pixel, the layout the warp kernel gathers from
-    MI_HIP_TRY(hipMalloc((void **)&pk, sizeof(float) * 4 * (size_t)g.ps));
-    S.bufs.push_back(pk);
-    TRY(pack3(in[1], in[2], in[3], pk, g, st));
-    TRY(warp(semantics, in[0], pk, u1v, u2v, out[0], out[1], out[2], out[3], out[4], tabd, g, nullptr, 0, st));
+    if (fused) {
+        TRY(warp_fused(semantics, in[0], in[1], u1v, u2v, out[0], out[1], out[2], out[3], out[4], tabd, g, nullptr, 0, st));
+    } else {
+        float *pk = nullptr;   // {I1, I1x, I1y, 0} per pixel, the layout the gather kernel reads
+        MI_HIP_TRY(hipMalloc((void **)&pk, sizeof(float) * 4 * (size_t)g.ps));
+        S.bufs.push_back(pk);
+        TRY(pack3(in[1], in[2], in[3], pk, g, st));
+        TRY(warp(semantics, in[0], pk, u1v, u2v, out[0], out[1], out[2], out[3], out[4], tabd, g, nullptr, 0, st));
+    }
     for (int i = 0; i < 5; ++i) TRY(stage_out(out[i], g, outs[i], st));
     MI_HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
@@ -199,7 +209,7 @@ int mi_resize_linear(int semantics, const mi_mat *src, mi_mat *dst, double fx, d
     return MI_OK;
 }
 
-int mi_dbg_lane_shift(int *out_host)
+int miflow_selftest_lane_shift(int *out_host)
 {
     MI_REQUIRE(out_host, MI_ERR_BAD_ARG, "null out");
     int *d = nullptr;

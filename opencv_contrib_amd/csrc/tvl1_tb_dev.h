@@ -1,4 +1,4 @@
-// Shared device helpers of the temporally blocked TV-L1 kernels (tvl1_tb_kernels.hip, tvl1_tbr_kernels.hip).
+// Device helpers of the temporally blocked TV-L1 kernels (tvl1_tbr_kernels.hip).
 #pragma once
 #include "tvl1_dev.h"
 
@@ -6,7 +6,7 @@ namespace mi {
 namespace tvl1 {
 
 // lane n <- lane n-1 (wave_shr:1) / lane n <- lane n+1 (wave_shl:1); semantics verified on HW
-// by tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics through mi_dbg_lane_shift.
+// by tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics through miflow_selftest_lane_shift.
 __device__ __forceinline__ float dpp_from_prev(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
@@ -75,47 +75,6 @@ __device__ __forceinline__ void lds_get(const float *slot, int lane, Stat<PPL> &
     }
 }
 
-// Row prefetch.  The loads are UNCONDITIONAL (clamped row / column, uniform row base + 32-bit lane offset): a load inside a
-// divergent `if` sits in its own basic block, and the waitcnt pass then has to assume vmcnt(0) at every later use, which
-// serialises the prefetch (r01k ISA).  Out-of-image rows/columns are zeroed when the row is consumed (mask_input_row).
-// Pins a wave-uniform row pointer into an SGPR pair so that the access is emitted as `global_* v, voffset, s[base:base+1]`
-// (otherwise base + lane offset is reassociated into per-plane 64-bit VGPR addresses hoisted out of the row loop: 32 VGPRs
-// and two VALU adds per access).  The integer round trip drops the inferred address space, hence the explicit global one.
-#define MI_GLOBAL __attribute__((address_space(1)))
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ MI_GLOBAL char *sgpr_row(const void *p)
-{
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (MI_GLOBAL char *)(((unsigned long long)hi << 32) | lo);
-}
-// Row prefetch.  The loads are UNCONDITIONAL (clamped row / column): a load inside a divergent `if` sits in its own basic
-// block, and the waitcnt pass then has to assume vmcnt(0) at every later use, which serialises the prefetch (r01k ISA).
-// Out-of-image rows/columns are zeroed when the row is consumed (mask_input_row).  xb = lane offset in BYTES.
-template <int PPL>
-__device__ __forceinline__ void ldu(float dst[PPL], const float *rowp, unsigned xb)
-{
-    const MI_GLOBAL char *q = sgpr_row(rowp) + xb;
-    if (PPL == 1) {
-        dst[0] = *(const MI_GLOBAL float *)q;
-    } else if (PPL == 2) {
-        const f2v v = *(const MI_GLOBAL f2v *)q;
-        dst[0] = v.x; dst[1] = v.y;
-    } else {
-        const f4v v = *(const MI_GLOBAL f4v *)q;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    }
-}
-template <int PPL>
-__device__ __forceinline__ void stu(float *rowp, unsigned xb, const float v[PPL])
-{
-    MI_GLOBAL char *q = sgpr_row(rowp) + xb;
-    if (PPL == 1) *(MI_GLOBAL float *)q = v[0];
-    else if (PPL == 2) *(MI_GLOBAL f2v *)q = f2v{v[0], v[1]};
-    else *(MI_GLOBAL f4v *)q = f4v{v[0], v[1], v[2], v[3]};
-}
-
 // 1/grad; grad == 0 -> huge, so that clamp() yields -+l_t*sign(rho) like the reference's first two branches
 template <int PPL>
 __device__ __forceinline__ void finish_static(Stat<PPL> &st)
@@ -123,10 +82,6 @@ __device__ __forceinline__ void finish_static(Stat<PPL> &st)
 #pragma unroll
     for (int j = 0; j < PPL; ++j) st.rg[j] = __builtin_amdgcn_rcpf(fmaxf(st.rg[j], 1e-30f));
 }
-
-// rotating-slot kernels (tvl1_tbr_kernels.hip): first entry of time block T, or the one matching (ppl, wps, pf) when >= 0
-typedef void (*TbLaunch)(const TbArgs &, bool, hipStream_t);
-TbLaunch tbr_pick(int T, int want_ppl, int want_wps, int want_pf, int *ppl, int *wps, int *pf);
 
 }  // namespace tvl1
 }  // namespace mi

@@ -1,7 +1,7 @@
 // Dual TV-L1 -- temporally blocked fused iteration, ROTATING-SLOT formulation (gfx950, wave64).
 //
-// Same pipeline as tvl1_tb_kernels.hip (T iteration levels = T pipeline stages, one image row apart, all state in VGPRs,
-// static planes on a per-wave LDS ring, x-neighbours by DPP), but the stage is written as an IN-PLACE update so that no
+// T iteration levels = T pipeline stages, one image row apart (dependency cone +-1 px per iteration), all state in VGPRs,
+// static planes on a per-wave LDS ring, x-neighbours by DPP.  The stage is written as an IN-PLACE update so that no
 // state is ever copied and no border handling needs a branch:
 //
 //   stage t sees   A = (u_(t-1), p_(t-1)) of row a      (its input)        B = (u_t, p_(t-1)) of row a-1   (its held state)
@@ -11,8 +11,7 @@
 // input set, so after one pipeline step every held state has moved by one register set: with P = T + 1 + PF sets
 // (T held states + the row in flight + PF prefetched rows) and the row loop unrolled P times, set indices are compile-time
 // constants and the assignment returns to itself at the loop back-edge -- no v_mov, no ping-pong copy of the state
-// (the SA/SB scheme of tvl1_tb_kernels.hip needs 12 registers per stage and pixel, this one 6), prefetched rows land
-// directly in the set that consumes them.
+// (6 registers per stage and pixel), prefetched rows land directly in the set that consumes them.
 //
 // Borders without branches (profiles/r01p: the five wave-uniform border branches per stage cost 16-25 %):
 //   * left:   strip 0 starts at x = 0 in lane 0, so the zero fill of `wave_shr:1 bound_ctrl` IS the missing p(x-1) term
@@ -23,12 +22,13 @@
 // Rows above / below the image and columns right of it are loaded from clamped addresses (finite data) and are isolated
 // from the valid region by exactly these four cuts, so loads are unconditional and nothing is masked.
 //
-// Arithmetic: the fast-math form of tvl1_tb_kernels.hip (v_rcp / v_sqrt / fma); parity against the oracle and the exact
+// Arithmetic: fast-math form (v_rcp / v_sqrt / fma; TH written as a clamp); parity against the oracle and the exact
 // kernel is tested with a stated tolerance (tests/test_tvl1_gpu.py).
 #include "tvl1_tb_dev.h"
 #include <utility>
 #include <cstdlib>
 #include <cstdio>
+#include <vector>
 
 namespace mi {
 namespace tvl1 {
@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     CtxR<PPL> c;
     c.lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // block -> (strip, band group, pair), see k_iterate_tb
+    // block -> (strip, band group, pair); with swz the linear workgroup id is remapped so that each XCD (id % 8) owns a
+    // contiguous run of strips: neighbouring strips share their halo columns through ONE L2
     int strip = blockIdx.x, bgrp = blockIdx.y, b = blockIdx.z;
     if (A.swz == 1) {
         const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
@@ -282,35 +283,37 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 }
 
 template <int T, int PPL, int WPS, int PF>
-static void launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
+static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
     constexpr int LW = 64 * PPL;
     constexpr int STRIDE = LW - 2 * M;
     TbArgs A = A0;
     A.nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
-    static int swz = -1;
-    if (swz < 0) { const char *e = getenv("MIFLOW_TB_SWZ"); swz = e ? atoi(e) : 1; }
-    A.swz = swz == 1 ? 1 : 0;
+    A.swz = tuning().tb_swz == 1 ? 1 : 0;
     const dim3 grid(A.nstrips, div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
     constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
-    }
-    if (getenv("MIFLOW_TB_VERBOSE")) {
-        static bool shown = false;
-        if (!shown) {
-            shown = true;
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, 256, lds_bytes);
-            fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, lds_bytes, nb);
-        }
+    // once per instantiation (thread-safe function-local static), result checked on every launch
+    static const hipError_t attr_rc = [] {
+        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        return e;
+    }();
+    MI_HIP_TRY(attr_rc);
+    if (tuning().tb_verbose) {
+        static const int nb = [] {
+            int n = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, 256, lds_bytes);
+            fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, lds_bytes, n);
+            return n;
+        }();
+        (void)nb;
     }
     if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
     else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
 }
 
 // WPS = occupancy the register allocator is held to (launch bound); PLAN = waves/SIMD the band planner assumes.  r01s: the
@@ -318,7 +321,7 @@ static void launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 // full the 46 KB unrolled loop of 16 waves per CU at 16 different positions overruns the instruction cache.
 struct TbrEntry {
     int T, PPL, WPS, PF, PLAN;
-    TbLaunch launch;
+    int (*launch)(const TbArgs &, bool, hipStream_t);
 };
 #define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF>}
 static const TbrEntry g_tbr[] = {
@@ -330,19 +333,114 @@ static const TbrEntry g_tbr[] = {
     TBR(4, 1, 7, 2, 6),
 };
 
-// First entry of time block T, or the entry matching (ppl, wps, pf) when those are >= 0.  Returns nullptr if T has none.
-// *wps receives the occupancy the band planner should assume.
-TbLaunch tbr_pick(int T, int want_ppl, int want_wps, int want_pf, int *ppl, int *wps, int *pf)
+// First entry of time block T, or the entry matching MIFLOW_TB_VARIANT=ppl,wps,pf.  Returns nullptr if T has none.
+static const TbrEntry *tbr_pick(int T)
 {
+    const Tuning &tn = tuning();
     const TbrEntry *def = nullptr;
     for (const TbrEntry &e : g_tbr) {
         if (e.T != T) continue;
         if (!def) def = &e;
-        if (e.PPL == want_ppl && e.WPS == want_wps && e.PF == want_pf) { def = &e; break; }
+        if (e.PPL == tn.tb_ppl && e.WPS == tn.tb_wps && e.PF == tn.tb_pf) { def = &e; break; }
     }
-    if (!def) return nullptr;
-    *ppl = def->PPL; *wps = def->PLAN; *pf = def->PF;
-    return def->launch;
+    return def;
+}
+
+int tb_max_block() { return 10; }
+
+// Decompose n iterations into supported time blocks minimising the modelled cost.  cost[T] = measured
+// ps per pixel-iteration of k_iterate_tbr<T> at 1080p x 16 pairs (tools/sweep_tb.py, profiles/r01s):
+// deeper blocks save HBM passes but cost registers (occupancy) and halo recomputation.
+int tb_plan(int n, int cap, int *blocks, int max_blocks)
+{
+    static const int sup[] = {1, 2, 3, 4, 5, 6, 8, 10};
+    static const double cost[11] = {0, 15.6, 9.4, 6.6, 4.65, 3.9, 3.7, 0, 2.83, 0, 2.54};
+    if (n <= 0) return 0;
+    if (tuning().tb_force) {   // tuning sweeps: greedy blocks of exactly `cap` (then the largest that fit)
+        int k = 0;
+        for (int left = n; left > 0 && k < max_blocks;) {
+            int t = 1;
+            for (int c : sup) if (c <= left && c <= cap) t = c;
+            blocks[k++] = t;
+            left -= t;
+        }
+        return k;
+    }
+    std::vector<double> best(n + 1, 1e300);
+    std::vector<int> pick(n + 1, 1);
+    best[0] = 0;
+    for (int i = 1; i <= n; ++i)
+        for (int t : sup) {
+            if (t > i || t > cap) continue;
+            const double c = best[i - t] + t * cost[t];
+            if (c < best[i]) { best[i] = c; pick[i] = t; }
+        }
+    int k = 0;
+    for (int i = n; i > 0 && k < max_blocks; i -= pick[i]) blocks[k++] = pick[i];
+    return k;
+}
+
+// Band height: every wave streams rows_per_band + 2T rows, in whole blocks of P = T + 1 + PF steps.  Pick the band count
+// that minimises rounds x steps, rounds = ceil(waves / resident-wave capacity), so that the grid fills the SIMDs of the
+// device in whole rounds (no half-empty tail round) while the 2T-row band overlap stays small.
+static int plan_band_rows(const TbrEntry &e, const Geo &g)
+{
+    const Tuning &tn = tuning();
+    if (tn.tb_rows > 0) return tn.tb_rows;
+    const int T = e.T, ppl = e.PPL, P = T + 1 + e.PF;
+    int wps = e.PLAN;
+    const int ring_slots = T > 2 ? T - 1 : 1;
+    const int lds_blocks = (160 * 1024) / (ring_slots * 4 * 256 * ppl * 4);
+    if (wps > lds_blocks) wps = lds_blocks;
+    if (tn.tb_plan_wps > 0) wps = tn.tb_plan_wps;
+    const long long cap = (long long)device_simds() * wps;
+    const int M = (T + ppl - 1) / ppl * ppl;
+    const int LW = 64 * ppl;
+    const long long strips = g.w <= LW - M ? 1 : 1 + div_up(g.w - (LW - M), LW - 2 * M);
+    const long long per_band = strips * g.batch;
+    long long best_cost = -1;
+    int best_nb = 1;
+    for (int nb = 1; nb <= g.h; ++nb) {
+        const int R = div_up(g.h, nb);
+        if (R < 8 && nb > 1) break;
+        const long long rounds = (per_band * nb + cap - 1) / cap;
+        const long long steps = (long long)div_up(R + 2 * T, P) * P;
+        const long long cost = rounds * steps;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_nb = nb; }
+    }
+    return div_up(g.h, best_nb);
+}
+
+// T fused iterations, set cur -> cur^1.  Returns MI_ERR_BAD_ARG for unsupported T.
+int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
+               int cur, int rows_per_band, hipStream_t s)
+{
+    const TbrEntry *e = tbr_pick(T);
+    if (!e) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
+    TbArgs A;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.swz = 0; A.nstrips = 0;
+    A.rows_per_band = rows_per_band > 0 ? rows_per_band : plan_band_rows(*e, g);
+    if (tuning().tb_verbose) {
+        static int shown = 0;
+        if (shown++ < 40)
+            fprintf(stderr, "[tb] T=%d ppl=%d wps=%d pf=%d %dx%d batch=%d rows_per_band=%d\n", T, e->PPL, e->WPS, e->PF, g.w, g.h, g.batch,
+                    A.rows_per_band);
+    }
+    return e->launch(A, p_zero, s);
+}
+
+// self-test of the DPP wave-shift semantics the kernels rely on (tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics)
+__global__ void k_dbg_lane_shift(int *out)
+{
+    const int l = threadIdx.x;
+    out[l] = __float_as_int(dpp_from_prev(__int_as_float(l + 100)));
+    out[64 + l] = __float_as_int(dpp_from_next(__int_as_float(l + 100)));
+}
+int dbg_lane_shift(int *out_dev, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dbg_lane_shift, dim3(1), dim3(64), 0, s, out_dev);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
 }
 
 }  // namespace tvl1

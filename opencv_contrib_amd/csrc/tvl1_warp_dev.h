@@ -1,0 +1,47 @@
+// Device-side loop-control view and the argument block of the fused-gradient warp kernel; shared by tvl1_kernels.hip and
+// tvl1_warp_kernels.hip.  Not part of the C-ABI.
+#pragma once
+#include "tvl1_dev.h"
+
+namespace mi {
+namespace tvl1 {
+
+struct CtlK {  // by-value copy for kernels (Ctl may be absent)
+    int2 *S;         // per slot {cur_in, flags}: flags bit 0 = the launch was active, bit 1 = it summed the error
+    unsigned long long *E;
+    int Q, q, q_prev, first_of_warp, reset_cur;
+    double thr;
+    double *P;
+    int sched, n;
+};
+static inline CtlK make_ctlk(const Ctl *c)
+{
+    CtlK k;
+    memset(&k, 0, sizeof(k));
+    k.q_prev = -1;
+    if (c) { k.S = c->S; k.E = c->E; k.Q = c->Q; k.q = c->q; k.q_prev = c->q_prev;
+             k.first_of_warp = c->first_of_warp; k.reset_cur = c->reset_cur; k.thr = c->thr;
+             k.P = c->P; k.sched = c->sched; k.n = c->n; }
+    return k;
+}
+__device__ __forceinline__ int resolve_cur_k(const CtlK &c, int b, int cur_host)
+{
+    if (!c.S) return cur_host;
+    if (c.q_prev < 0) return 0;
+    const int2 s = c.S[(long long)b * c.Q + c.q_prev];
+    return s.x ^ (s.y & 1);
+}
+
+struct Warp6Args {
+    const float *I0, *I1;
+    const float *u1[2], *u2[2];
+    float *I1w, *I1wx, *I1wy, *grad, *rho;
+    const float *tab;  // 32x4 cubic phase table (CPU_REF)
+    Geo g;
+};
+
+// pixels of a wave along x in the warp kernels (a 32 x 2 patch per wave measured best, profiles/r01u)
+static inline int warp_tile() { return tuning().warp_tile; }
+
+}  // namespace tvl1
+}  // namespace mi

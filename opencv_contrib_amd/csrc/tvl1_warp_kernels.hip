@@ -1,0 +1,223 @@
+// Dual TV-L1 -- warpBackward with the centred gradient of I1 derived IN the kernel (gfx950, wave64).
+//
+// The reference gathers three planes per bicubic tap: I1 and its centred differences I1x, I1y
+// (cudaoptflow/src/cuda/tvl1flow.cu:106-164; CPU class: 3 x cv::remap, optflow/src/tvl1flow.cpp:1371-1374).
+// The earlier kernel here (k_warp, tvl1_kernels.hip) packed {I1, I1x, I1y, 0} into one float4 per pixel and
+// gathered 16 x 16 B per output pixel; it ran at the rate of the vector-memory data path (64 B/clk/CU), i.e. it was
+// bound by the BYTES gathered.  I1x / I1y are 0.5f * (I1[x+1] - I1[x-1]) and 0.5f * (I1[y+1] - I1[y-1])
+// (tvl1flow.cu:59-69 == optflow/src/tvl1flow.cpp:688-770), so every tap value of all three planes follows from a
+// 6 x 6 window of I1 without its corners: four rows of six consecutive floats and two rows of four -- 128 B per
+// pixel, read as 4-byte-aligned dwordx4 / dwordx2 loads (gfx950 allows them), instead of 256 B, and no packed
+// plane to build per level.  The differences are the same single rounded subtraction and multiplication that
+// centeredGradient performs, so the tap values -- and with the same accumulation order, the results -- are
+// bit-identical to gathering stored gradient planes.
+//
+// Lanes whose window touches the image border take the per-tap path, where the neighbours of a tap are clamped
+// exactly like centeredGradient clamps them (and, for MI_SEM_CUDA_COMPAT, the tap itself like the clamp-addressed
+// texture, cudev/ptr2d/texture.hpp:228-232).
+#include "tvl1_dev.h"
+#include "tvl1_warp_dev.h"
+
+namespace mi {
+namespace tvl1 {
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ float bicubic_coeff_cuda6(float x_)
+{
+    // tvl1flow.cu:89-104 (Keys a = -0.5)
+    const float x = fabsf(x_);
+    if (x <= 1.0f) return x * x * (1.5f * x - 2.5f) + 1.0f;
+    else if (x < 2.0f) return x * (x * (-0.5f * x + 2.5f) - 4.0f) + 2.0f;
+    return 0.0f;
+}
+
+// {I1, I1x, I1y} at pixel (cx, cy) of the image, neighbours clamped as centeredGradient does
+__device__ __forceinline__ void fetch3(const float *P, int W, int H, int ld, int cx, int cy, float &v, float &vx, float &vy)
+{
+    const float *row = P + (long long)cy * ld;
+    v = row[cx];
+    vx = 0.5f * (row[min(cx + 1, W - 1)] - row[max(cx - 1, 0)]);
+    vy = 0.5f * (P[(long long)min(cy + 1, H - 1) * ld + cx] - P[(long long)max(cy - 1, 0) * ld + cx]);
+}
+
+template <int SEM, int TX>
+__global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_host)
+{
+    __shared__ float s_tab[128];
+    if (SEM == MI_SEM_CPU_REF) {
+        if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
+        __syncthreads();
+    }
+    constexpr int TY = 64 / TX;   // rows per wave: a TX x TY patch per wave keeps the gather footprint compact
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const int x = blockIdx.x * TX + (lane_ % TX);
+    const int y = blockIdx.y * (4 * TY) + wave_ * TY + lane_ / TX;
+    const int b = blockIdx.z;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    if (x >= W || y >= H) return;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const long long pb = (long long)b * A.g.ps;
+    const long long o = pb + (long long)y * ld + x;
+    const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
+    const float *P = A.I1 + pb;
+
+    int sx, sy;          // first tap column / row of the 4 x 4 window
+    float wxv[4], wyv[4];
+    float wxp = 0.f, wyp = 0.f;
+    if (SEM == MI_SEM_CPU_REF) {
+        // buildFlowMap + cv::remap(INTER_CUBIC, BORDER_CONSTANT 0): optflow/src/tvl1flow.cpp:650-666,1371-1374;
+        // map quantised to 1/32 px, weights from the 32-phase table (a = -0.75)
+        const float mx = (float)x + u1v, my = (float)y + u2v;
+        const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+        sx = min(max(qx >> 5, -32768), 32767) - 1;
+        sy = min(max(qy >> 5, -32768), 32767) - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wxv[k] = s_tab[(qx & 31) * 4 + k]; wyv[k] = s_tab[(qy & 31) * 4 + k]; }
+    } else {
+        // tvl1flow.cu:106-149.  The reference visits cx = ceil(wx - 2) .. floor(wx + 2): the four taps
+        // floor(wx) - 1 .. floor(wx) + 2 plus, when a bound lands on an integer, taps at distance >= 2 whose weight
+        // is exactly 0 and which therefore add +0 to every sum -- the fixed 4-tap window gives the same bits.
+        wxp = (float)x + u1v; wyp = (float)y + u2v;
+        sx = (int)fminf(fmaxf(floorf(wxp), -1.0e9f), 1.0e9f) - 1;
+        sy = (int)fminf(fmaxf(floorf(wyp), -1.0e9f), 1.0e9f) - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wxv[k] = bicubic_coeff_cuda6(wxp - (float)(sx + k));
+            wyv[k] = bicubic_coeff_cuda6(wyp - (float)(sy + k));
+        }
+    }
+
+    float v0, v1, v2;
+    const bool interior = (unsigned)(sx - 1) < (unsigned)max(W - 5, 0) && (unsigned)(sy - 1) < (unsigned)max(H - 5, 0);
+    if (interior) {
+        // rows sy-1 .. sy+4; R[r][c] = I1(sy - 1 + r, sx - 1 + c); rows 0 and 5 are needed at columns 1..4 only
+        float R[6][6];
+        const float *q = P + (long long)(sy - 1) * ld + (sx - 1);
+        {
+            const f4u a = *reinterpret_cast<const f4u *>(q + 1);
+            R[0][1] = a.x; R[0][2] = a.y; R[0][3] = a.z; R[0][4] = a.w;
+        }
+#pragma unroll
+        for (int r = 1; r < 5; ++r) {
+            const float *qr = q + (long long)r * ld;
+            const f4u a = *reinterpret_cast<const f4u *>(qr);
+            const f2u c = *reinterpret_cast<const f2u *>(qr + 4);
+            R[r][0] = a.x; R[r][1] = a.y; R[r][2] = a.z; R[r][3] = a.w; R[r][4] = c.x; R[r][5] = c.y;
+        }
+        {
+            const f4u a = *reinterpret_cast<const f4u *>(q + (long long)5 * ld + 1);
+            R[5][1] = a.x; R[5][2] = a.y; R[5][3] = a.z; R[5][4] = a.w;
+        }
+        if (SEM == MI_SEM_CPU_REF) {
+            // cv::remap bicubic interior: sum += S[0]*w[0] + S[1]*w[1] + S[2]*w[2] + S[3]*w[3] per row, w = wy[j]*wx[i]
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t0[4], t1[4], t2[4], w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w[i] = wyv[j] * wxv[i];
+                    t0[i] = R[j + 1][i + 1];
+                    t1[i] = 0.5f * (R[j + 1][i + 2] - R[j + 1][i]);
+                    t2[i] = 0.5f * (R[j + 2][i + 1] - R[j][i + 1]);
+                }
+                const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
+                const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
+                const float r2 = t2[0] * w[0] + t2[1] * w[1] + t2[2] * w[2] + t2[3] * w[3];
+                if (j == 0) { s0 = r0; s1 = r1; s2 = r2; } else { s0 += r0; s1 += r1; s2 += r2; }
+            }
+            v0 = s0; v1 = s1; v2 = s2;
+        } else {
+            float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float wgt = wxv[i] * wyv[j];
+                    sum += wgt * R[j + 1][i + 1];
+                    sumx += wgt * (0.5f * (R[j + 1][i + 2] - R[j + 1][i]));
+                    sumy += wgt * (0.5f * (R[j + 2][i + 1] - R[j][i + 1]));
+                    wsum += wgt;
+                }
+            const float coeff = 1.0f / wsum;
+            v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
+        }
+    } else if (SEM == MI_SEM_CPU_REF) {
+        if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
+            v0 = v1 = v2 = 0.f;
+        } else {
+            // cv::remap border path: taps outside the image contribute the border value 0, one tap at a time
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int yj = sy + j;
+                if (yj < 0 || yj >= H) continue;
+                for (int i = 0; i < 4; ++i) {
+                    const int xi = sx + i;
+                    if (xi < 0 || xi >= W) continue;
+                    float t0, t1, t2;
+                    fetch3(P, W, H, ld, xi, yj, t0, t1, t2);
+                    const float w = wyv[j] * wxv[i];
+                    s0 += (t0 - 0.f) * w;
+                    s1 += (t1 - 0.f) * w;
+                    s2 += (t2 - 0.f) * w;
+                }
+            }
+            v0 = s0; v1 = s1; v2 = s2;
+        }
+    } else {
+        // the reference's own loop bounds (zero-weight taps included: they read finite clamped data)
+        const int xmin = (int)ceilf(wxp - 2.0f), xmax = (int)floorf(wxp + 2.0f);
+        const int ymin = (int)ceilf(wyp - 2.0f), ymax = (int)floorf(wyp + 2.0f);
+        float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
+        for (int cy = ymin; cy <= ymax; ++cy)
+            for (int cx = xmin; cx <= xmax; ++cx) {
+                const float wgt = bicubic_coeff_cuda6(wxp - (float)cx) * bicubic_coeff_cuda6(wyp - (float)cy);
+                float t0, t1, t2;
+                fetch3(P, W, H, ld, min(max(cx, 0), W - 1), min(max(cy, 0), H - 1), t0, t1, t2);
+                sum += wgt * t0;
+                sumx += wgt * t1;
+                sumy += wgt * t2;
+                wsum += wgt;
+            }
+        const float coeff = 1.0f / wsum;
+        v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
+    }
+    if (A.I1w) A.I1w[o] = v0;
+    A.I1wx[o] = v1;
+    A.I1wy[o] = v2;
+    // calcGradRho  optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163
+    const float Ix2 = v1 * v1, Iy2 = v2 * v2;
+    A.grad[o] = Ix2 + Iy2;
+    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
+}
+
+int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
+               float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
+               hipStream_t s)
+{
+    Warp6Args A;
+    A.I0 = I0; A.I1 = I1;
+    A.u1[0] = u1[0]; A.u1[1] = u1[1]; A.u2[0] = u2[0]; A.u2[1] = u2[1];
+    A.I1w = I1w; A.I1wx = I1wx; A.I1wy = I1wy; A.grad = grad; A.rho = rho;
+    A.tab = cubic_tab_dev;
+    A.g = g;
+    const CtlK ck = make_ctlk(ctl);
+    const int tile = warp_tile();
+    const dim3 grid(div_up(g.w, tile), div_up(g.h, 4 * (64 / tile)), g.batch);
+#define LAUNCH_W6(SEM)                                                                                                   \
+    do {                                                                                                                 \
+        if (tile == 16) hipLaunchKernelGGL((k_warp6<SEM, 16>), grid, dim3(256), 0, s, A, ck, cur_host);                  \
+        else if (tile == 32) hipLaunchKernelGGL((k_warp6<SEM, 32>), grid, dim3(256), 0, s, A, ck, cur_host);             \
+        else hipLaunchKernelGGL((k_warp6<SEM, 64>), grid, dim3(256), 0, s, A, ck, cur_host);                             \
+    } while (0)
+    if (semantics == MI_SEM_CPU_REF) LAUNCH_W6(MI_SEM_CPU_REF);
+    else LAUNCH_W6(MI_SEM_CUDA_COMPAT);
+#undef LAUNCH_W6
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace tvl1
+}  // namespace mi

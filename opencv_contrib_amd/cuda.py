@@ -17,8 +17,9 @@ class OpticalFlowDual_TVL1:
     """cv::cuda::OpticalFlowDual_TVL1 (cudaoptflow.hpp:305-386).
 
     Extra, non-reference knobs (C-ABI extensions): `semantics` (0 = arithmetic of the CPU class
-    cv::optflow::DualTVL1OpticalFlow, the acceptance reference; 1 = arithmetic of the CUDA kernels),
-    `exactMath`, `innerIterations`/`medianFiltering` (CPU-class parameters).
+    cv::optflow::DualTVL1OpticalFlow, the acceptance reference and the DEFAULT; 1 = arithmetic of cv::cuda's kernels),
+    `exactMath` (default False: fast device math, fused iterations), `innerIterations`/`medianFiltering` (CPU-class
+    parameters), `lanes` (internal streams a batch is split over).
     """
 
     def __init__(self, params: capi.TVL1Params):
@@ -29,15 +30,22 @@ class OpticalFlowDual_TVL1:
     # -- factory with the reference's signature and defaults (cudaoptflow.hpp:375-385)
     @staticmethod
     def create(tau=0.25, lambda_=0.15, theta=0.3, nscales=5, warps=5, epsilon=0.01, iterations=300,
-               scaleStep=0.8, gamma=0.0, useInitialFlow=False, *, semantics=capi.MI_SEM_CPU_REF,
-               exactMath=True, innerIterations=1, medianFiltering=1, timeBlock=0) -> "OpticalFlowDual_TVL1":
+               scaleStep=0.8, gamma=0.0, useInitialFlow=False, *, semantics=None, exactMath=None, innerIterations=1,
+               medianFiltering=1, timeBlock=0, lanes=0) -> "OpticalFlowDual_TVL1":
+        """The keyword-only arguments are miflow extensions; None = the library default (mi_tvl1_default_params):
+        semantics MI_SEM_CPU_REF (the arithmetic of the CPU class, the acceptance reference; MI_SEM_CUDA_COMPAT = cv::cuda's
+        own kernels, ~0.1 px mean EPE away, mostly at borders), fast device math (exactMath=True: IEEE operations in the
+        reference's order, one iteration per launch)."""
         p = capi.TVL1Params()
         capi.lib().mi_tvl1_default_params(C.byref(p))
         p.tau, p.lambda_, p.theta, p.nscales, p.warps = tau, lambda_, theta, nscales, warps
         p.epsilon, p.iterations, p.scale_step, p.gamma = epsilon, iterations, scaleStep, gamma
         p.use_initial_flow = int(bool(useInitialFlow))
-        p.semantics, p.exact_math = semantics, int(bool(exactMath))
-        p.inner_iterations, p.median_filtering, p.time_block = innerIterations, medianFiltering, timeBlock
+        if semantics is not None:
+            p.semantics = semantics
+        if exactMath is not None:
+            p.exact_math = int(bool(exactMath))
+        p.inner_iterations, p.median_filtering, p.time_block, p.lanes = innerIterations, medianFiltering, timeBlock, lanes
         return OpticalFlowDual_TVL1(p)
 
     def __del__(self):
@@ -88,6 +96,7 @@ class OpticalFlowDual_TVL1:
         m0, m1, mf = capi.mat_from_tensor(I0), capi.mat_from_tensor(I1), capi.mat_from_tensor(flow)
         sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
         capi.check(capi.lib().mi_tvl1_calc(self._h, C.byref(m0), C.byref(m1), C.byref(mf), sp))
+        capi.check(capi.lib().mi_tvl1_get_params(self._h, C.byref(self._p)))   # nscales shrinks like the reference's nscales_
         return flow
 
     def calc_batch(self, I0s, I1s, flows=None, stream=None):
@@ -102,6 +111,7 @@ class OpticalFlowDual_TVL1:
         AF = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in flows])
         sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
         capi.check(capi.lib().mi_tvl1_calc_batch(self._h, n, A0, A1, AF, sp))
+        capi.check(capi.lib().mi_tvl1_get_params(self._h, C.byref(self._p)))
         return flows
 
     def setProfiling(self, on=True):
@@ -137,10 +147,11 @@ def tvl1_centeredGradient(src):
 
 
 def tvl1_warpBackward(semantics, I0, I1, I1x, I1y, u1, u2):
+    """I1x = I1y = None: the derivative planes are formed from I1 inside the kernel (the kernel calc() runs)."""
     import torch
     torch.cuda.synchronize()
     outs = [torch.empty_like(I0) for _ in range(5)]
-    args = [C.byref(_m(t)) for t in (I0, I1, I1x, I1y, u1, u2, *outs)]
+    args = [C.byref(_m(t)) if t is not None else None for t in (I0, I1, I1x, I1y, u1, u2, *outs)]
     capi.check(capi.lib().mi_tvl1_warp_backward(semantics, *args))
     return tuple(outs)
 

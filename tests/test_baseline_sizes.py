@@ -1,0 +1,194 @@
+"""Parity at the sizes BASELINE.json quotes: HIP through the C-ABI against the oracle on the same seeded inputs.
+
+  configs[1]  TV-L1 1920x1080, CV_32FC1 and CV_8UC1, iterations = 10 (the reference's accuracy-test setting,
+              cudaoptflow/test/test_optflow.cpp:450): what a default-constructed object runs (fast math, fused iterations)
+              and exact math against oracle.tvl1_calc; tolerance stated per test (the reference's own is |1 - CCORR| <= 4e-3,
+              test_optflow.cpp:465);
+  configs[2]  StereoBM 1920x1080, 128 disparities, block 15: bit-exact;
+  configs[3]  SURF 3840x2160, threshold 400: keypoint count, keypoints, >= 99 % of orientations / descriptors;
+  configs[4]  a 64-pair calc_batch (one GPU's share of the 512 pairs) equals 64 single calcs bit for bit.
+Also here: the kernels a default calc() is made of that round 2 added (fused-gradient warp, two-lane batches).
+"""
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, gpu):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def N(t):
+    return t.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ TV-L1, configs[1]
+@pytest.fixture(scope="module")
+def pair1080(oracle):
+    out = {}
+    for dt in ("f32", "u8"):
+        I0, I1, gt = synth.flow_pair(1080, 1920, seed=1234, dtype=dt)
+        ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0))
+        out[dt] = (I0, I1, gt, ref)
+    return out
+
+
+def test_default_object_runs_cpu_class_arithmetic_in_fast_math(gpu):
+    from opencv_contrib_amd import capi, cuda
+    alg = cuda.OpticalFlowDual_TVL1.create()
+    assert (alg._p.semantics, alg._p.exact_math, alg._p.time_block, alg._p.lanes) == (capi.MI_SEM_CPU_REF, 0, 0, 0)
+    assert (alg.getNumIterations(), alg.getEpsilon(), alg.getNumScales(), alg.getNumWarps()) == (300, 0.01, 5, 5)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+@pytest.mark.parametrize("exact", [False, True], ids=["default_fast_fused", "exact_math"])
+def test_tvl1_1080p_against_oracle(gpu, pair1080, dtype, exact):
+    from opencv_contrib_amd import cuda
+    I0, I1, gt, ref = pair1080[dtype]
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0, exactMath=exact)
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    assert np.isfinite(flow).all()
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    # exact math: the same separately rounded operations as the oracle (order of the error-free parts only);
+    # default: v_rcp / v_sqrt / fma and 10 iterations per HBM pass
+    assert d.mean() <= (2e-3 if exact else 5e-3), d.mean()
+    assert synth.ccorr_dissimilarity(flow, ref) <= 1e-4       # the reference accepts 4e-3 (test_optflow.cpp:465)
+    assert (d <= 0.02).mean() >= 0.99
+    assert synth.epe(flow, gt) < 0.15                          # and it is a flow: analytic field of the generator
+
+
+def test_tvl1_1080p_cuda_semantics_against_its_oracle(gpu, oracle):
+    """MI_SEM_CUDA_COMPAT at the BASELINE size against the oracle of the same semantics -- the one pinned bit for bit on
+    the reference's own OpenCL kernels (tests/test_ref_pin.py)."""
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(1080, 1920, seed=1234)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0, semantics=1))
+    flow = N(cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0, semantics=1).calc(T(I0, gpu), T(I1, gpu)))
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= 5e-3, d.mean()
+    assert synth.ccorr_dissimilarity(flow, ref) <= 1e-4
+
+
+def test_tvl1_batch_of_64_equals_64_single_calcs(gpu):
+    """configs[4]: one GPU's share of the 512-pair batch.  64 distinct 1080p pairs (4 generated pairs under flips and rolls)
+    through ONE calc_batch (two internal lanes of 32) against 64 calc() calls of another object: bit-identical flows."""
+    import torch
+    from opencv_contrib_amd import cuda
+    base = [synth.flow_pair(1080, 1920, seed=1000 + k)[:2] for k in range(4)]
+    I0s, I1s = [], []
+    for k in range(64):
+        a, b = (T(x, gpu) for x in base[k % 4])
+        v = k // 4
+        if v & 1: a, b = a.flip(0), b.flip(0)
+        if v & 2: a, b = a.flip(1), b.flip(1)
+        s = (v >> 2) * 37
+        I0s.append(torch.roll(a, s, 1).contiguous()); I1s.append(torch.roll(b, s, 1).contiguous())
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0)
+    flows = alg.calc_batch(I0s, I1s)
+    torch.cuda.synchronize()
+    single = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0)
+    for k in range(64):
+        f = single.calc(I0s[k], I1s[k])
+        assert torch.equal(f, flows[k]), f"pair {k}"
+    assert not torch.equal(flows[0], flows[4])
+
+
+@pytest.mark.parametrize("eps,iters", [(0.0, 10), (0.01, 60)])
+def test_two_lanes_equal_one_lane(gpu, eps, iters):
+    """A batch split over two internal streams (lanes = 2, the default from 4 pairs on) is bit-identical to the same
+    batch on the caller's stream (lanes = 1), for fixed work and for the device-decided convergence path, whose
+    per-pair iteration counts must come back from the right lane."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(150, 210, seed=40 + k)[:2] for k in range(5)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    a1 = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps, lanes=1)
+    a2 = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps, lanes=2)
+    f1, f2 = a1.calc_batch(I0s, I1s), a2.calc_batch(I0s, I1s)
+    torch.cuda.synchronize()
+    assert torch.equal(f1, f2)
+    for k in range(5):
+        assert a1.lastIterations(k) == a2.lastIterations(k)
+    if eps > 0:
+        assert a1.lastIterations(0) != a1.lastIterations(3) or a1.lastIterations(1) != a1.lastIterations(4)
+
+
+# ------------------------------------------------------------------------------------------------ fused-gradient warp
+@pytest.mark.parametrize("amp", [0.0, 1.5, 8.0, 400.0])
+@pytest.mark.parametrize("shape", [(77, 101), (6, 9), (5, 300), (211, 467)])
+def test_fused_warp_bit_exact_against_oracle_cpu_semantics(gpu, oracle, shape, amp):
+    """k_warp6<CPU_REF> (gradient of I1 formed in the kernel from a 6 x 6 window) against oracle.tvl1_warp: bit for bit,
+    interior and border lanes, flows up to far outside the image, images too small for any interior window."""
+    from opencv_contrib_amd import capi, cuda
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    I0 = (rng.random((h, w)) * 255).astype(np.float32)
+    I1 = (rng.random((h, w)) * 255).astype(np.float32)
+    u1 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    u2 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    if amp == 0.0:
+        u1[::3, ::5] = 0.5; u2[1::4, ::2] = -1.0; u1[::2, 1::3] = 1.0 / 64   # phase ties of the 1/32-px quantisation
+    ox, oy = oracle.tvl1_centered_gradient(I1)
+    ref = oracle.tvl1_warp(0, I0, I1, ox, oy, u1, u2)
+    got = cuda.tvl1_warpBackward(capi.MI_SEM_CPU_REF, T(I0, gpu), T(I1, gpu), None, None, T(u1, gpu), T(u2, gpu))
+    for name, r, g in zip(("I1w", "I1wx", "I1wy", "grad", "rho_c"), ref, got):
+        np.testing.assert_array_equal(N(g), r, err_msg=name)
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+@pytest.mark.parametrize("amp", [0.0, 2.5, 400.0])
+def test_fused_warp_equals_gather_warp(gpu, oracle, sem, amp):
+    """The fused-gradient kernel and the packed-plane gather kernel (the round-1 kernel, still the stage-level path for
+    caller-supplied derivative planes) are two implementations of one function: bit-identical for both semantics."""
+    from opencv_contrib_amd import cuda
+    h, w = 130, 203
+    rng = np.random.default_rng(sem * 7 + int(amp))
+    I0 = (rng.random((h, w)) * 255).astype(np.float32)
+    I1 = (rng.random((h, w)) * 255).astype(np.float32)
+    u1 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    u2 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    if amp == 0.0:
+        u1[::3, ::5] = 1.0; u2[1::4, ::2] = -2.0   # integer positions: the 5-tap windows of the reference's loop bounds
+    ox, oy = oracle.tvl1_centered_gradient(I1)
+    a = cuda.tvl1_warpBackward(sem, T(I0, gpu), T(I1, gpu), T(ox, gpu), T(oy, gpu), T(u1, gpu), T(u2, gpu))
+    b = cuda.tvl1_warpBackward(sem, T(I0, gpu), T(I1, gpu), None, None, T(u1, gpu), T(u2, gpu))
+    for name, x, y in zip(("I1w", "I1wx", "I1wy", "grad", "rho_c"), a, b):
+        np.testing.assert_array_equal(N(x), N(y), err_msg=name)
+
+
+# ------------------------------------------------------------------------------------------------ StereoBM, configs[2]
+def test_stereobm_1080p_128_15_bit_exact(gpu, oracle):
+    from opencv_contrib_amd import cuda
+    left, right, _ = synth.stereo_pair(1080, 1920, seed=42, max_disp=70)
+    ref = oracle.sbm_compute(left, right, oracle.sbm_params(num_disparities=128, block_size=15))
+    got = N(cuda.createStereoBM(128, 15).compute(T(left, gpu), T(right, gpu)))
+    np.testing.assert_array_equal(got, ref)
+    assert (ref > 0).mean() > 0.5   # a real disparity map, not the all-rejected corner case
+
+
+# ------------------------------------------------------------------------------------------------ SURF, configs[3]
+def test_surf_4k_threshold_400_against_oracle(gpu, oracle):
+    """3840 x 2160, hessianThreshold 400, 4 octaves x 2 layers, keypointsRatio 0.01: maxFeatures clamps at 65 535 and the
+    u32 integral image runs close to 2^31."""
+    from opencv_contrib_amd import cuda
+    img = synth.blob_image(2160, 3840, seed=7)
+    ref = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=400.0))
+    assert ref["n"] > 2000
+    np.testing.assert_array_equal(N(cuda.surf_integral(T(img, gpu))).view(np.uint32), oracle.surf_integral(img))
+    alg = cuda.SURF_CUDA.create(400.0)
+    kpg, desc = alg.detectWithDescriptors(T(img, gpu))
+    kp = cuda.SURF_CUDA.downloadKeypoints(kpg)
+    desc = N(desc)
+    assert kp["x"].shape[0] == ref["n"]
+    for k in ("laplacian", "octave", "size"):
+        np.testing.assert_array_equal(kp[k], ref[k], err_msg=k)
+    for k in ("x", "y", "hessian"):
+        np.testing.assert_allclose(kp[k], ref[k], rtol=1e-6, atol=1e-3, err_msg=k)
+    d = np.abs(kp["angle"] - ref["angle"]); d = np.minimum(d, 360 - d)
+    assert (d <= 1e-2).mean() >= 0.99
+    dd = np.abs(desc - ref["descriptors"]).max(1)
+    assert ((dd <= 1e-4) | (d > 1e-2)).mean() >= 0.99

@@ -129,7 +129,7 @@ def test_wave_min_and_tie_break_semantics(gpu):
             v[63] = 0
         inp = (C.c_uint * 64)(*[int(x) for x in v])
         out = (C.c_uint * 65)()
-        capi.check(capi.lib().mi_dbg_wave_min(inp, out))
+        capi.check(capi.lib().miflow_selftest_wave_min(inp, out))
         m = int(v.min())
         assert all(out[i] == m for i in range(64)), (trial, list(out[:64]))
         idx = np.flatnonzero(v == m)
@@ -148,7 +148,7 @@ def test_transposed_max16_semantics(gpu):
     v = rng.integers(0, 2 ** 32, size=(16, 64), dtype=np.uint64).astype(np.uint32)
     inp = (C.c_uint * 1024)(*[int(x) for x in v.reshape(-1)])
     out = (C.c_uint * 64)()
-    capi.check(capi.lib().mi_dbg_tmax16(inp, out))
+    capi.check(capi.lib().miflow_selftest_tmax16(inp, out))
     want = v.max(axis=1)
     assert [int(out[l]) for l in range(64)] == [int(want[l & 15]) for l in range(64)]
 

@@ -136,15 +136,17 @@ def test_farneback_adapter_equals_class(gpu):
 
 
 @pytest.mark.gpu
-def test_gpu_flow_passes_reference_acceptance_against_flo_golden(gpu):
+@pytest.mark.parametrize("extra", [dict(semantics=0, exactMath=True), dict()], ids=["cpu_class_exact", "library_defaults"])
+def test_gpu_flow_passes_reference_acceptance_against_flo_golden(gpu, extra):
     """The reference's TV-L1 regression check (test_tvl1optflow.cpp:143-171: >= 95 % of pixels within 0.1 px of the .flo golden),
-    here against the committed oracle golden stored as .flo."""
+    here against the committed golden of the CPU-class oracle stored as .flo -- in exact math and for what a
+    default-constructed object runs (fast math, fused iterations)."""
     import torch
     from opencv_contrib_amd import cuda
     import json
     z = np.load(os.path.join(GOLD, "tvl1_f32_96x128_it10.npz"))
     gold = flowio.readOpticalFlow(os.path.join(GOLD, "tvl1_f32_96x128_it10.flo"))
-    alg = cuda.OpticalFlowDual_TVL1.create(**json.loads(str(z["params"])))
+    alg = cuda.OpticalFlowDual_TVL1.create(**json.loads(str(z["params"])), **extra)
     flow = alg.calc(torch.from_numpy(z["I0"]).to(gpu), torch.from_numpy(z["I1"]).to(gpu)).cpu().numpy()
     assert flowio.accuracy(gold, flow, threshold=0.1) >= 0.95
     assert flowio.calcRMSE(gold, flow) < 0.05

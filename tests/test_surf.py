@@ -94,7 +94,7 @@ def test_wave_scan_semantics(gpu):
     from opencv_contrib_amd import capi
     v = np.random.default_rng(1).integers(0, 1000, size=64).astype(np.uint32)
     inp = (C.c_uint * 64)(*[int(x) for x in v]); out = (C.c_uint * 64)()
-    capi.check(capi.lib().mi_dbg_wave_scan(inp, out))
+    capi.check(capi.lib().miflow_selftest_wave_scan(inp, out))
     np.testing.assert_array_equal(np.array(out[:], np.uint64), np.cumsum(v.astype(np.uint64)))
 
 

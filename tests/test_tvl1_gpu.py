@@ -144,7 +144,7 @@ def test_dpp_wave_shift_semantics(gpu):
     import ctypes as C
     from opencv_contrib_amd import capi
     out = (C.c_int * 128)()
-    capi.check(capi.lib().mi_dbg_lane_shift(out))
+    capi.check(capi.lib().miflow_selftest_lane_shift(out))
     prev, nxt = list(out[:64]), list(out[64:])
     assert prev[1:] == [100 + i for i in range(63)], prev      # lane n receives lane n-1
     assert nxt[:63] == [101 + i for i in range(63)], nxt       # lane n receives lane n+1
@@ -166,29 +166,6 @@ def test_iterate_blocked_matches_exact(gpu, T, shape):
             np.testing.assert_allclose(N(b), N(a), rtol=0, atol=2e-5 * niter, err_msg=f"{nm} T={T} niter={niter}")
 
 
-def test_blocked_kernel_families_agree(gpu, tmp_path):
-    """The rotating-slot kernels (default) and the older ping-pong-state kernels (MIFLOW_TB_ROT=0) are two independent
-    implementations of the same fast-math iteration: one 10-iteration pass over a multi-strip, multi-band image must agree
-    to rounding.  The family is latched per process, hence the subprocesses."""
-    import subprocess, sys
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from opencv_contrib_amd import cuda\n"
-        "from test_tvl1_gpu import _iter_inputs\n"
-        "I1wx, I1wy, grad, rho, u, p = _iter_inputs(211, 467, seed=11)\n"
-        "T = lambda a: torch.from_numpy(a).cuda()\n"
-        "uo, po, _ = cuda.tvl1_iterate(T(I1wx), T(I1wy), T(grad), T(rho), [T(a) for a in u], [T(a) for a in p], 0.045, 0.3, 0.25 / 0.3,"
-        " niter=10, exact=False, time_block=10, want_err=False)\n"
-        "np.save(sys.argv[1], np.stack([a.cpu().numpy() for a in uo + po]))\n" % (ROOT, os.path.join(ROOT, "tests")))
-    outs = []
-    for rot in ("1", "0"):
-        out = str(tmp_path / f"rot{rot}.npy")
-        env = dict(os.environ, MIFLOW_TB_ROT=rot)
-        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
-        outs.append(np.load(out))
-    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=2e-5)
-
-
 @pytest.mark.parametrize("tb", [0, 5])
 def test_calc_fast_blocked_matches_oracle(gpu, oracle, tb):
     """Product fast path (fast math + temporal blocking) against the CPU oracle, stated tolerance."""
@@ -201,9 +178,17 @@ def test_calc_fast_blocked_matches_oracle(gpu, oracle, tb):
 
 
 # ------------------------------------------------------------------ full calc
-def _run(gpu, I0, I1, **kw):
+def _create(**kw):
+    """The tests of this file hold the kernels to the oracle in EXACT math unless they say otherwise (exactMath=False);
+    what a default-constructed object runs (fast math, fused iterations) is covered by tests/test_tvl1_baseline.py."""
     from opencv_contrib_amd import cuda
-    alg = cuda.OpticalFlowDual_TVL1.create(**kw)
+    kw.setdefault("semantics", 0)
+    kw.setdefault("exactMath", True)
+    return cuda.OpticalFlowDual_TVL1.create(**kw)
+
+
+def _run(gpu, I0, I1, **kw):
+    alg = _create(**kw)
     flow = alg.calc(T(I0, gpu), T(I1, gpu))
     import torch
     torch.cuda.synchronize()
@@ -282,7 +267,7 @@ def test_calc_initial_flow(gpu, oracle):
     I0, I1, gt = synth.flow_pair(96, 128, seed=21)
     init = (gt + 0.3).astype(np.float32)
     ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=5, epsilon=0.0, use_initial_flow=1), init_flow=init)
-    alg = cuda.OpticalFlowDual_TVL1.create(iterations=5, epsilon=0.0, useInitialFlow=True)
+    alg = _create(iterations=5, epsilon=0.0, useInitialFlow=True)
     flow = T(init, gpu)
     alg.calc(T(I0, gpu), T(I1, gpu), flow)
     torch.cuda.synchronize()
@@ -297,7 +282,7 @@ def test_calc_pitched_inputs_and_output(gpu, oracle):
     big0 = torch.zeros((70, 128), dtype=torch.uint8, device=gpu); big0[:, :90] = T(I0, gpu)
     big1 = torch.zeros((70, 256), dtype=torch.uint8, device=gpu); big1[:, 3:93] = T(I1, gpu)
     bigf = torch.full((70, 100, 2), -7.0, dtype=torch.float32, device=gpu)
-    alg = cuda.OpticalFlowDual_TVL1.create(iterations=4, epsilon=0.0)
+    alg = _create(iterations=4, epsilon=0.0)
     alg.calc(big0[:, :90], big1[:, 3:93], bigf[:, :90])
     torch.cuda.synchronize()
     ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=4, epsilon=0.0))
@@ -309,13 +294,13 @@ def test_batch_equals_single_and_is_deterministic(gpu):
     import torch
     from opencv_contrib_amd import cuda
     pairs = [synth.flow_pair(100, 140, seed=s)[:2] for s in (1, 2, 3)]
-    alg = cuda.OpticalFlowDual_TVL1.create(iterations=6, epsilon=0.0)
+    alg = _create(iterations=6, epsilon=0.0)
     singles = [N(alg.calc(T(a, gpu), T(b, gpu))) for a, b in pairs]
     batch = N(alg.calc_batch([T(a, gpu) for a, _ in pairs], [T(b, gpu) for _, b in pairs]))
     for i in range(3):
         np.testing.assert_array_equal(batch[i], singles[i])
     # default parameters (device-side convergence) are reproducible too
-    alg2 = cuda.OpticalFlowDual_TVL1.create()
+    alg2 = _create()
     a = N(alg2.calc(T(pairs[0][0], gpu), T(pairs[0][1], gpu)))
     b = N(alg2.calc(T(pairs[0][0], gpu), T(pairs[0][1], gpu)))
     np.testing.assert_array_equal(a, b)
@@ -330,13 +315,13 @@ def test_concurrent_handles_on_streams_bit_identical(gpu):
     from opencv_contrib_amd import cuda
     I0, I1, _ = synth.flow_pair(120, 160, seed=41)
     t0, t1 = T(I0, gpu), T(I1, gpu)
-    gold = N(cuda.OpticalFlowDual_TVL1.create(iterations=10).calc(t0, t1))
+    gold = N(_create(iterations=10).calc(t0, t1))
     outs = [None] * 8
 
     def work(i):
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            alg = cuda.OpticalFlowDual_TVL1.create(iterations=10)
+            alg = _create(iterations=10)
             f = alg.calc(t0, t1)
             s.synchronize()
             outs[i] = N(f)
@@ -352,7 +337,7 @@ def test_calc_argument_errors(gpu):
     import torch
     from opencv_contrib_amd import cuda
     from opencv_contrib_amd.capi import MiError
-    alg = cuda.OpticalFlowDual_TVL1.create(iterations=1)
+    alg = _create(iterations=1)
     a = torch.zeros((32, 32), dtype=torch.float32, device=gpu)
     with pytest.raises(MiError) as e:  # CV_Assert(I0.size() == I1.size())
         alg.calc(a, torch.zeros((32, 33), dtype=torch.float32, device=gpu))
@@ -383,8 +368,8 @@ def test_1080p_properties(gpu):
     from opencv_contrib_amd import cuda
     I0, I1, gt = synth.flow_pair(1080, 1920, seed=1234)
     t0, t1 = T(I0, gpu), T(I1, gpu)
-    fe = N(cuda.OpticalFlowDual_TVL1.create(iterations=30, epsilon=0.0, exactMath=True).calc(t0, t1))
-    ff = N(cuda.OpticalFlowDual_TVL1.create(iterations=30, epsilon=0.0, exactMath=False).calc(t0, t1))
+    fe = N(_create(iterations=30, epsilon=0.0, exactMath=True).calc(t0, t1))
+    ff = N(_create(iterations=30, epsilon=0.0, exactMath=False).calc(t0, t1))
     d = np.sqrt(((fe - gt) ** 2).sum(-1))
     assert d[40:-40, 40:-40].mean() < 0.15, d[40:-40, 40:-40].mean()
     assert np.sqrt(((fe - ff) ** 2).sum(-1)).mean() < 5e-3

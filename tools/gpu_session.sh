@@ -1,0 +1,47 @@
+#!/bin/bash
+# One GPU session: `gpurun --timeout N -- 'bash tools/gpu_session.sh <name> <steps...>'`; results under gpurun_out/<name>/.
+# Steps: tests_new | tests_all | smoke | ab_warp | bench | trace | pmc | secondary
+set -u
+export TMPDIR=/tmp
+NAME=$1; shift
+O=gpurun_out/$NAME
+mkdir -p $O
+R=$PWD
+for step in "$@"; do
+case $step in
+tests_new)
+  (timeout 900 python -m pytest tests/test_baseline_sizes.py tests/test_ref_pin.py tests/test_tvl1_gpu.py tests/test_superres_flowio.py tests/test_cpp_shim.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -30) > $O/pytest_new.log; cat $O/pytest_new.log ;;
+tests_all)
+  (timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -30) > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
+smoke)
+  (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6) > $O/smoke.log; cat $O/smoke.log ;;
+ab_warp)
+  for cfg in "pk 1" "pk 2" "fused 1" "fused 2"; do
+    set -- $cfg
+    (MIFLOW_WARP=$1 timeout 300 python bench.py --no-variants --no-cpu --lanes $2 --steps 10 --warmup 3 2>$O/ab_$1_$2.err | tail -1) > $O/ab_$1_$2.json
+    python - <<PY
+import json
+try:
+    d = json.loads(open('$O/ab_$1_$2.json').read()); print('ab warp=$1 lanes=$2', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step', 'iter-launch us', round(d['roofline']['avg_launch_us'], 1))
+except Exception as e: print('ab $1 $2 failed', e); print(open('$O/ab_$1_$2.err').read()[-2000:])
+PY
+  done ;;
+bench)
+  (timeout 900 python bench.py 2>$O/bench.err | tail -1) > $O/bench.json; tail -c 3000 $O/bench.json; tail -5 $O/bench.err ;;
+trace)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace -- python $R/bench.py --no-variants --no-cpu --steps 5 --warmup 2 > $R/$O/trace_bench.log 2>&1
+  cd $R
+  find $O/trace -name "*kernel_stats.csv" | head -3
+  for f in $(find $O/trace -name "*kernel_stats.csv" | head -1); do cp $f $O/kernel_stats.csv; head -12 $f; done
+  find $O -type f -size +4M -delete ;;
+pmc)
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c -f csv -d $R/$O/pmc_$c -- python $R/bench.py --no-variants --no-cpu --steps 2 --warmup 1 > $R/$O/pmc_$c.log 2>&1
+  done
+  cd $R
+  python tools/pmc_summary.py $O > $O/pmc_summary.md 2>&1; head -40 $O/pmc_summary.md
+  find $O -type f -size +4M -delete ;;
+esac
+done
