@@ -28,6 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# MI355X_MICROARCH.md: 157.3 TFLOP/s f32 vector peak = 256 CUs x 4 SIMD-32 x 2.4 GHz x 2 flop per fma lane-instruction
+VALU_PEAK_TLIPS = 157.3 / 2
+# vector-memory data path: 64 B/clk per CU (MI355X_MICROARCH.md: a dwordx4 wave load = 16 clk) x 256 CUs x 2.4 GHz
+VMEM_PATH_PEAK_GBS = 64 * 256 * 2.4
+SBM_VALU_PER_PXD = 10.0   # ~10 integer operations per (pixel, disparity)
 
 
 def level_pixels(w, h, nscales=5, step=0.8):
@@ -72,36 +77,6 @@ def time_steps(alg, I0, I1, flows, steps, warmup, dist):
     return time.perf_counter() - t0
 
 
-def two_stream_rate(args, I0, I1, flows_like, steps, ns=2):
-    """pairs/s of the resident batch processed as `ns` equal parts by `ns` algorithm objects on `ns` HIP streams."""
-    import torch
-    from opencv_contrib_amd import cuda
-    B = I0.shape[0]
-    h = B // ns
-    out = torch.empty_like(flows_like)
-    streams = [torch.cuda.Stream() for _ in range(ns)]
-    algs = [cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
-                                             timeBlock=args.time_block) for _ in range(ns)]
-
-    def step():
-        for k in range(ns):
-            with torch.cuda.stream(streams[k]):
-                algs[k].calc_batch(I0[k * h:(k + 1) * h], I1[k * h:(k + 1) * h], out[k * h:(k + 1) * h])
-
-    ref = algs[0].calc_batch(I0, I1)            # the whole batch on the current stream, same parameters
-    torch.cuda.synchronize()
-    step()
-    torch.cuda.synchronize()
-    if not torch.equal(out, ref):
-        raise RuntimeError("two-stream result differs from the single-stream batch")
-    del ref
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return B * steps / (time.perf_counter() - t0)
-
-
 def bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows_ref):
     """Batched-frames mode with the pairs resident on GPU 0 only (BASELINE north_star / SURVEY 8e): every step scatters the
     batches over RCCL, computes, and gathers the flows back to GPU 0; scatter of step k+1 and gather of step k-1 overlap the
@@ -114,8 +89,8 @@ def bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows_ref):
     local_in = [torch.empty_like(x) for _ in range(2)]
     local_out = [torch.empty_like(flows_ref) for _ in range(2)]
     root_out = [[torch.empty_like(flows_ref) for _ in range(world)] for _ in range(2)] if rank == 0 else None
-    alg = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
-                                           timeBlock=args.time_block)
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon,
+                                           exactMath=True if args.exact_math else None, timeBlock=args.time_block)
 
     def compute(inp, out):
         alg.calc_batch(inp[:, 0], inp[:, 1], out)
@@ -173,10 +148,14 @@ def bench_stereobm(args):
            "config": {"workload": f"StereoBM {W}x{H} numDisparities={nd} blockSize={bs} (BASELINE configs[2]), {B} pairs/step",
                       "texture_threshold": 3, "uniqueness_ratio": 0},
            "pixel_disparities_per_s": pxd * n / el,
-           "roofline": {"bound": "hbm", "achieved": algo_bytes * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "not HBM-bound (SURVEY 8d config 3): 6.2 MB/pair of compulsory traffic; the limiter is "
-                                "integer VALU issue: see pixel_disparities_per_s and DESIGN.md"}}
+           # not HBM-bound (6.2 MB/pair); the work is (pixel, disparity) cost updates on the integer VALU.
+           # k_block_match spends SBM_VALU_PER_PXD lane-instructions per (pixel, disparity) in its row loop (column-sum slide
+           # v_sub_u32_sdwa + v_mad_i32_i24, window sum add/sub, packed compare/select of the running minimum: static count of the
+           # R = 7 instantiation), against the lane-instruction issue peak of the chip
+           "roofline": {"bound": "valu_issue", "achieved": pxd * n / el * SBM_VALU_PER_PXD / 1e12, "peak": VALU_PEAK_TLIPS,
+                        "unit": "T lane-instr/s", "frac": pxd * n / el * SBM_VALU_PER_PXD / 1e12 / VALU_PEAK_TLIPS,
+                        "hbm_algorithmic_GBps": algo_bytes * n / el / 1e9, "hbm_frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None}}
     # post-filter of the stereo pipeline: DisparityBilateralFilter(ndisp, radius 3, 1 iteration) on the maps above
     dbf = cuda.createDisparityBilateralFilter(nd, 3, 1)
     F = [torch.empty_like(D[0]) for _ in range(B)]
@@ -217,7 +196,7 @@ def bench_stereobm(args):
         t0 = time.perf_counter()
         O.sgm_compute(left, right, O.sgm_params(num_disparities=nd))
         out["cpu_baseline"]["stereosgm_hh4_pairs_per_s"] = 1.0 / (time.perf_counter() - t0)
-    print(json.dumps(out))
+    return out
 
 
 def bench_farneback(args):
@@ -323,7 +302,7 @@ def bench_farneback(args):
         out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"{k} x 1 pair {W}x{H}, {ct * 1e3:.0f} ms each, oracle/farneback_ref.c (OpenMP rows)",
                                "dense_pyrlk_pairs_per_s": lk_cpu}
-    print(json.dumps(out))
+    return out
 
 
 def bench_surf(args):
@@ -390,7 +369,44 @@ def bench_surf(args):
         ct = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"1 frame {W}x{H}, {r['n']} features, {ct:.1f} s wall, oracle/surf_ref.c (OpenMP in det/trace and descriptors)"}
-    print(json.dumps(out))
+    return out
+
+
+def static_mix():
+    """Per pipeline stage and pixel row of k_iterate_tbr<10, 1, ., 4, 2>: tools/static_mix.py -> profiles/static_mix_tbr.json."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "static_mix_tbr.json")))["per_stage_and_pixel"]
+    except Exception:
+        return {"valu_plain": 31.662, "transcendental": 4.069, "dpp": 4.0, "cndmask": 2.223}
+
+
+def pmc_traffic(key):
+    """Measured HBM bytes per launch (separate rocprofv3 --pmc passes of this command, tools/pmc_summary.py), or None."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return tj[key]["hbm_bytes_per_launch"], tj[key].get("source")
+    except Exception:
+        return None, None
+
+
+def secondary(args):
+    """The other BASELINE configs in the same driver-run line (reduced step counts): configs[0] Farneback 640x480,
+    configs[2] StereoBM 1080p/128/15, configs[3] SURF 4K; each with its bound, fraction and CPU baseline."""
+    import copy
+    out = {}
+    for name, fn, kw in (("stereobm_1080p_nd128_bs15", bench_stereobm, dict(width=1920, height=1080, batch=8, steps=3, warmup=1)),
+                         ("farneback_640x480", bench_farneback, dict(width=640, height=480, batch=16, steps=3, warmup=1)),
+                         ("surf_4k_thr400", bench_surf, dict(width=3840, height=2160, batch=2, steps=3, warmup=1))):
+        a = copy.copy(args)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        try:
+            r = fn(a)
+            keep = {k: r[k] for k in r if k not in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "warmup", "steps")}
+            out[name] = keep
+        except Exception as e:   # never at the expense of the headline
+            out[name] = {"error": repr(e)[:300]}
+    return out
 
 
 def main():
@@ -408,27 +424,28 @@ def main():
     ap.add_argument("--epsilon", type=float, default=0.0)
     ap.add_argument("--defaults", action="store_true", help="class defaults: 300 iterations, epsilon 0.01")
     ap.add_argument("--exact-math", action="store_true",
-                    help="IEEE divide + f64 hypot, one iteration per HBM pass (oracle-faithful to ~1e-6 px); default is "
-                         "the product fast path: v_rcp/v_sqrt math + temporal blocking, parity-tested at mean EPE <= 5e-3 px")
+                    help="IEEE divide + f64 hypot, one iteration per HBM pass (oracle-faithful to ~1e-6 px); the library default is "
+                         "fast math: v_rcp/v_sqrt + temporal blocking, parity-tested at mean EPE <= 5e-3 px")
     ap.add_argument("--time-block", type=int, default=0, help="iterations fused per HBM pass (fast math; 0 = auto, 1 = off)")
     ap.add_argument("--lanes", type=int, default=0, help="internal streams a batch is split over (0 = library default: 2 from 4 pairs on)")
-    ap.add_argument("--semantics", type=int, default=0, help="0 = CPU class arithmetic (library default), 1 = cv::cuda's kernels")
+    ap.add_argument("--semantics", type=int, default=None, help="0 = CPU class arithmetic (library default), 1 = cv::cuda's kernels")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iterations", type=int, default=None)
     args = ap.parse_args()
     if args.defaults:
         args.iterations, args.epsilon = 300, 0.01
     if args.workload == "stereobm":
-        return bench_stereobm(args)
+        return print(json.dumps(bench_stereobm(args)))
     if args.workload == "surf":
         if (args.width, args.height) == (1920, 1080):
             args.width, args.height = 3840, 2160
-        return bench_surf(args)
+        return print(json.dumps(bench_surf(args)))
     if args.workload == "farneback":
         if (args.width, args.height) == (1920, 1080):
             args.width, args.height = 640, 480
-        return bench_farneback(args)
+        return print(json.dumps(bench_farneback(args)))
 
     import numpy as np
     import torch
@@ -439,26 +456,33 @@ def main():
     dist, rank, world, local = parallel.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-
-    from opencv_contrib_amd import cuda, synth
+    from opencv_contrib_amd import capi, cuda, synth
 
     W, H, B = args.width, args.height, args.batch
     I0, I1, base = make_inputs(B, H, W, dev)
     flows = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
     warps = 5
 
-    def run(iterations, epsilon, steps, warmup, profile=False, exact=None):
-        alg = cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon,
-                                               exactMath=args.exact_math if exact is None else exact,
-                                               timeBlock=args.time_block, lanes=args.lanes, semantics=args.semantics)
+    def create(iterations, epsilon, **kw):
+        # A DEFAULT-CONSTRUCTED object with the reference test's two setter calls (setNumIterations / setEpsilon); the miflow
+        # extensions stay at the library defaults (CPU-class arithmetic, fast math, automatic fusing and lanes) unless a variant
+        # or a command-line flag names them
+        ext = dict(exactMath=True if args.exact_math else None, timeBlock=args.time_block, lanes=args.lanes, semantics=args.semantics)
+        ext.update(kw)
+        return cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon, **ext)
+
+    def run(iterations, epsilon, steps, warmup, profile=False, inputs=None, out=None, **kw):
+        alg = create(iterations, epsilon, **kw)
         alg.setProfiling(profile)
-        el = time_steps(alg, I0, I1, flows, steps, warmup, dist)
+        a0, a1 = inputs if inputs is not None else (I0, I1)
+        el = time_steps(alg, a0, a1, flows if out is None else out, steps, warmup, dist)
         el = parallel.max_over_ranks(dist, el, dev)
-        prof = alg.getProfile() if profile else None
+        prof = (alg.getProfile(0), alg.getProfile(1)) if profile else None
         its = alg.lastIterations(0)
         return float(el), prof, its, alg
 
     el, prof, its, alg = run(args.iterations, args.epsilon, args.steps, args.warmup, profile=True)
+    P = alg._p
     pairs = B * world * args.steps
     fps = pairs / el
     # accuracy of what was just computed: EPE vs the analytic flow of pair 0
@@ -468,44 +492,73 @@ def main():
 
     mean_it = float(np.mean(its))
     ab_pair = algo_bytes_per_pair(W, H, warps, mean_it)
-    # dominant kernel: fused iteration; events bracket each warp's run of launches (last step's calc)
-    ms_total, launches, abytes = prof
-    if args.epsilon > 0:  # only executed launches move bytes; the no-op launches still cost their dispatch
-        exec_frac = mean_it / args.iterations
-        abytes *= exec_frac
-    blocked = (not args.exact_math) and args.epsilon == 0 and args.time_block != 1
-    kname = ("k_iterate_tb (T fused estimateU+estimateDualVariables iterations per HBM pass)" if blocked
-             else "k_iterate (fused estimateU+estimateDualVariables)")
-    roof = {"bound": "hbm", "kernel": kname,
-            "achieved": abytes / (ms_total * 1e-3) / 1e9 if ms_total > 0 else None, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "traffic": None,
-            "avg_launch_us": 1e3 * ms_total / max(launches, 1), "launches_timed": launches,
-            "iterations_per_launch_mean": mean_it * warps * len(its) / max(launches, 1),
-            "algorithmic_bytes_per_launch_mean": abytes / max(launches, 1),
-            "note": "achieved = algorithmic bytes (64 B x px x iterations executed by the launch, SURVEY 8d) / launch time; "
-                    "with temporal blocking one launch executes T iterations per HBM pass, so achieved may exceed the "
-                    "HBM peak -- `traffic` is the measured HBM bytes per launch"}
-    roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
-    # measured HBM traffic per launch of the dominant kernel: collected in separate rocprofv3 --pmc passes
-    # (FETCH_SIZE, WRITE_SIZE) of this same command and committed under profiles/ (tools/pmc_summary.py)
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = "tb" if blocked else "v1"
-            if key in tj:
-                roof["traffic"] = tj[key]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = tj[key].get("source")
-        except Exception:
-            pass
+    blocked = (not P.exact_math) and P.time_block != 1
+    (ms_it, n_it, bytes_it), (ms_w, n_w, bytes_w) = prof
+    px_levels = float(sum(level_pixels(W, H)))
+    px_iter_timed = px_levels * B * warps * mean_it            # pixel-iterations inside the timed iteration regions of one calc
+    if args.epsilon > 0:
+        bytes_it *= mean_it / args.iterations
+    hbm_it = {"algorithmic_bytes_per_launch_mean": bytes_it / max(n_it, 1),
+              "algorithmic_GBps": bytes_it / (ms_it * 1e-3) / 1e9 if ms_it > 0 else None,
+              "note": "64 B x px x iterations executed by the launch (SURVEY 8d) / launch time; with T iterations per HBM pass this "
+                      "exceeds the HBM peak by construction -- the kernel is not under the HBM roofline, see `traffic`"}
+    traffic, tsrc = pmc_traffic("tbr" if blocked else "v1")
+    if traffic:
+        hbm_it.update({"traffic_bytes_per_launch": traffic, "traffic_GBps": traffic / (ms_it * 1e-3 / max(n_it, 1)) / 1e9,
+                       "traffic_frac_of_hbm_peak": traffic / (ms_it * 1e-3 / max(n_it, 1)) / 1e9 / HBM_PEAK_GBS, "traffic_source": tsrc})
+    if blocked and args.epsilon == 0:
+        # VALU issue: lane-instruction slots the kernel executes per second against the chip's issue peak.  Slots per pixel-iteration
+        # = static mix of the main loop (full-rate VALU + DPP + v_cndmask count 1, the quarter-rate v_rcp / v_sqrt count 4); lanes
+        # executed per owned pixel = 64 / 44 (T = 10, 1 px/lane: 10 halo columns per side); rows streamed per owned row =
+        # (R + 2T) / R with R the band height the planner chose (about 1.15-1.25 at 1080p x 16: reported by MIFLOW_TB_VERBOSE)
+        mix = static_mix()
+        slots = mix["valu_plain"] + mix["dpp"] + mix["cndmask"] + 4.0 * mix["transcendental"]
+        lanes_per_px = 64.0 / 44.0
+        ach = px_iter_timed / (ms_it * 1e-3) * slots * lanes_per_px / 1e12
+        roof = {"bound": "valu_issue", "kernel": "k_iterate_tbr<10,1,.,4,2,0> (10 fused estimateU+estimateDualVariables iterations per HBM pass)",
+                "achieved": ach, "peak": VALU_PEAK_TLIPS, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLIPS,
+                "pixel_iterations_per_s": px_iter_timed / (ms_it * 1e-3),
+                "issue_slots_per_pixel_iteration": slots, "lanes_executed_per_owned_pixel": lanes_per_px,
+                "band_halo_rows_not_counted": True,
+                "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it,
+                "iterations_per_launch_mean": mean_it * warps * len(its) / max(n_it, 1),
+                "traffic": traffic, "hbm": hbm_it,
+                "note": "HIP events on the launch streams around each warp's iteration launch; with lanes = 2 the other half batch's "
+                        "kernels share the GPU during these intervals (the rocprofv3 kernel trace shows the same durations)"}
+    else:
+        kname = "k_iterate (fused estimateU+estimateDualVariables, one iteration per launch)" if not blocked else \
+            "k_iterate_tbr MODE 1/2 (speculative blocks of the convergence-checked path)"
+        roof = {"bound": "hbm", "kernel": kname, "achieved": hbm_it["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (hbm_it["algorithmic_GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it, "hbm": hbm_it}
+    # second kernel: the fused-gradient warp.  Bound: bytes through the vector-memory path (128 B gathered per pixel as 4-byte-aligned
+    # dwordx4 / dwordx2 + 12 B coalesced in + 16 B out), 64 B/clk per CU
+    warp_bytes_px = 128.0 + 12.0 + 16.0
+    roof_warp = {"bound": "vector_memory_path", "kernel": "k_warp6 (bicubic warp, centred gradient of I1 formed from a 6x6 window)",
+                 "achieved": px_levels * B * warps * warp_bytes_px / (ms_w * 1e-3) / 1e9 if ms_w > 0 else None,
+                 "peak": VMEM_PATH_PEAK_GBS, "unit": "GB/s", "avg_launch_us": 1e3 * ms_w / max(n_w, 1), "launches_timed": n_w,
+                 "hbm_algorithmic_GBps": bytes_w / (ms_w * 1e-3) / 1e9 if ms_w > 0 else None}
+    if roof_warp["achieved"]:
+        roof_warp["frac"] = roof_warp["achieved"] / VMEM_PATH_PEAK_GBS
+        roof_warp["hbm_algorithmic_frac"] = roof_warp["hbm_algorithmic_GBps"] / HBM_PEAK_GBS
+    wtraffic, wsrc = pmc_traffic("warp6")
+    if wtraffic:
+        roof_warp.update({"traffic": wtraffic, "traffic_source": wsrc})
+    roof["second_kernel"] = roof_warp
+    roof["time_share"] = {"iterate_ms_per_calc": ms_it, "warp_ms_per_calc": ms_w, "calc_ms": 1e3 * el / args.steps,
+                          "note": "event intervals of the two lanes add up; they overlap in wall time"}
 
     out = {"metric": "frame-pairs/sec dense TV-L1 flow @1080p", "value": fps, "unit": "pairs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"DualTVL1 dense flow, {W}x{H} CV_32FC1, {B} pairs/GPU/step (BASELINE configs[1])",
+                      "object": "default-constructed OpticalFlowDual_TVL1 + setNumIterations / setEpsilon (as cudaoptflow/test/"
+                                "test_optflow.cpp:448-451 does); miflow extensions at the library defaults unless listed",
                       "iterations": args.iterations, "epsilon": args.epsilon, "warps": warps, "nscales": 5,
-                      "executed_iterations_per_warp_mean": mean_it, "semantics": "CPU_REF",
-                      "math": "exact" if args.exact_math else "fast", "time_block": args.time_block,
+                      "executed_iterations_per_warp_mean": mean_it,
+                      "semantics": "CPU_REF" if P.semantics == capi.MI_SEM_CPU_REF else "CUDA_COMPAT",
+                      "math": "exact" if P.exact_math else "fast", "time_block": P.time_block,
+                      "lanes": alg.calc_lanes() if hasattr(alg, "calc_lanes") else (2 if (P.lanes == 0 and B >= 4) or P.lanes == 2 else 1),
                       "algorithmic_GB_per_pair": ab_pair / 1e9},
            "whole_job_algorithmic_GBps": ab_pair * fps / 1e9,
            "whole_job_frac_of_hbm_peak": ab_pair * fps / 1e9 / HBM_PEAK_GBS,
@@ -520,43 +573,35 @@ def main():
 
     if not args.no_variants and world == 1:
         var = {}
-        for name, (it, eps, ex) in {"iterations2_eps0": (2, 0.0, args.exact_math), "iterations30_eps0": (30, 0.0, args.exact_math),
-                                    "defaults_300_eps0.01": (300, 0.01, args.exact_math),
-                                    "iterations10_eps0_exact_math": (10, 0.0, True)}.items():
-            if (it, eps, ex) == (args.iterations, args.epsilon, args.exact_math):
-                continue
-            e2, _, its2, _ = run(it, eps, max(1, args.steps // 2), 1, exact=ex)
-            n2 = B * max(1, args.steps // 2)
-            m2 = float(np.mean(its2))
-            var[name] = {"pairs_per_s": n2 / e2, "executed_iterations_per_warp_mean": m2,
-                         "algorithmic_GB_per_pair": algo_bytes_per_pair(W, H, warps, m2) / 1e9,
-                         "frac_of_hbm_peak": algo_bytes_per_pair(W, H, warps, m2) * (n2 / e2) / 1e9 / HBM_PEAK_GBS}
-        # the same batch as two half batches on two streams / two algorithm objects: the gather-bound warp kernel of one half can
-        # run beside the issue-bound iteration kernel of the other (distinct handles are independent: tests/test_tvl1_gpu.py)
-        if B >= 2 and B % 2 == 0 and args.epsilon == 0:
+        hs = max(1, args.steps // 2)
+
+        def vrun(name, it, eps, **kw):
             try:
-                var["two_streams_half_batches"] = {"pairs_per_s": two_stream_rate(args, I0, I1, flows, max(2, args.steps // 2))}
+                e2, _, its2, _ = run(it, eps, hs, 1, **kw)
+                m2 = float(np.mean(its2))
+                ab = algo_bytes_per_pair(W, H, warps, m2)
+                var[name] = {"pairs_per_s": B * hs / e2, "executed_iterations_per_warp_mean": m2, "algorithmic_GB_per_pair": ab / 1e9,
+                             "frac_of_hbm_peak": ab * (B * hs / e2) / 1e9 / HBM_PEAK_GBS}
             except Exception as e:   # never at the expense of the headline line
-                var["two_streams_half_batches"] = {"error": repr(e)[:200]}
-            if B % 4 == 0:
-                try:
-                    var["four_streams_quarter_batches"] = {"pairs_per_s": two_stream_rate(args, I0, I1, flows, max(2, args.steps // 2), ns=4)}
-                except Exception as e:
-                    var["four_streams_quarter_batches"] = {"error": repr(e)[:200]}
+                var[name] = {"error": repr(e)[:200]}
+
+        vrun("iterations2_eps0", 2, 0.0)
+        vrun("iterations30_eps0", 30, 0.0)
+        vrun("class_defaults_300_eps0.01", 300, 0.01)                      # speculative blocks, device-decided stop
+        vrun("iterations10_eps0_exact_math", 10, 0.0, exactMath=True)
+        vrun("iterations10_eps0_cuda_compat_semantics", 10, 0.0, semantics=1)
+        vrun("iterations10_eps0_one_lane", 10, 0.0, lanes=1)
         # SURVEY 8d config 2 "also run CV_8UC1": the same batch as 8-bit frames (the class converts them to f32 once per calc)
         try:
-            a8 = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
-                                                  timeBlock=args.time_block)
             J0, J1 = (I0 * 255).round().clamp(0, 255).to(torch.uint8), (I1 * 255).round().clamp(0, 255).to(torch.uint8)
-            e8 = time_steps(a8, J0, J1, flows, max(1, args.steps // 2), 1, None)
-            var["u8_input"] = {"pairs_per_s": B * max(1, args.steps // 2) / e8}
-            del J0, J1, a8
+            e8, _, _, _ = run(args.iterations, args.epsilon, hs, 1, inputs=(J0, J1))
+            var["u8_input"] = {"pairs_per_s": B * hs / e8}
+            del J0, J1
         except Exception as e:
             var["u8_input"] = {"error": repr(e)[:200]}
         # the reference's own calling pattern: one pair per calc() (no batching), back to back on one stream
         try:
-            a1 = cuda.OpticalFlowDual_TVL1.create(iterations=args.iterations, epsilon=args.epsilon, exactMath=args.exact_math,
-                                                  timeBlock=args.time_block)
+            a1 = create(args.iterations, args.epsilon)
             one = torch.empty((H, W, 2), dtype=torch.float32, device=dev)
             a1.calc(I0[0], I1[0], one)
             torch.cuda.synchronize()
@@ -565,16 +610,30 @@ def main():
                 a1.calc(I0[i % B], I1[i % B], one)
             torch.cuda.synchronize()
             var["single_pair_calc_sequential"] = {"pairs_per_s": 8 / (time.perf_counter() - t1)}
+            del a1, one
         except Exception as e:
             var["single_pair_calc_sequential"] = {"error": repr(e)[:200]}
+        # north_star "1080p/4K pairs": the same object on 3840x2160 pairs (4 pairs per step = the pixels of 16 1080p pairs)
+        try:
+            K0, K1, base4k = make_inputs(4, 2160, 3840, dev, distinct=1)
+            F4 = torch.empty((4, 2160, 3840, 2), dtype=torch.float32, device=dev)
+            e4, _, _, _ = run(args.iterations, args.epsilon, hs, 1, inputs=(K0, K1), out=F4)
+            ab4 = algo_bytes_per_pair(3840, 2160, warps, args.iterations)
+            var["tvl1_4k_3840x2160"] = {"pairs_per_s": 4 * hs / e4, "batch": 4, "algorithmic_GB_per_pair": ab4 / 1e9,
+                                        "megapixels_per_s": 4 * hs / e4 * 3840 * 2160 / 1e6,
+                                        "epe_vs_analytic_flow_px": float(synth.epe(F4[0].cpu().numpy()[80:-80, 80:-80], base4k[0][2][80:-80, 80:-80]))}
+            del K0, K1, F4
+        except Exception as e:
+            var["tvl1_4k_3840x2160"] = {"error": repr(e)[:200]}
         out["variants"] = var
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        # CPU baseline: the oracle (a port of the reference CPU path; the reference itself cannot be
-        # built here) on ONE pair of the same workload, all host cores (OpenMP rows).
+        # CPU baseline: the oracle (a port of the reference CPU class; the class itself cannot be built here: it needs opencv core /
+        # imgproc) on pairs of the same workload, all host cores (OpenMP rows).  kind "port": its per-pixel loops are the reference's,
+        # including the serial float error sum -- the ratio to `value` says nothing about kernel quality (roofline.frac does).
         from oracle import oracle as O
         cit = args.cpu_iterations or (args.iterations if args.epsilon == 0 else 300)
-        p = O.tvl1_params(iterations=cit, epsilon=args.epsilon)
+        p = O.tvl1_params(iterations=cit, epsilon=args.epsilon, semantics=int(P.semantics))
         npairs, t0 = 0, time.perf_counter()
         ref0 = None
         while npairs < len(base) * 4 and (npairs == 0 or time.perf_counter() - t0 < 10.0):
@@ -592,7 +651,12 @@ def main():
                                                               synth.ccorr_dissimilarity(f0[..., 1], ref0[..., 1])))
         out["cpu_baseline"] = {"value": npairs / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"{npairs} pair(s) {W}x{H} CV_32FC1, iterations={cit}, epsilon={args.epsilon}, "
-                                         f"{ct:.1f} s wall, oracle/tvl1_ref.c (OpenMP rows, all host cores)"}
+                                         f"{ct:.1f} s wall, oracle/tvl1_ref.c (OpenMP rows, all host cores; serial float error sum "
+                                         f"like the reference)"}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del I0, I1, flows
+        torch.cuda.empty_cache()
+        out["secondary"] = secondary(args)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

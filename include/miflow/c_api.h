@@ -130,6 +130,8 @@ MI_API int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int 
  * them, and their algorithmic bytes (64 B x level pixels x batch per launch). */
 MI_API int mi_tvl1_set_profiling(mi_tvl1 *h, int enable);
 MI_API int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, double *algo_bytes);
+/* The same for kind 0 (iteration launches, as above) or kind 1 (the warp launches; algorithmic bytes 44 B x level pixels x batch). */
+MI_API int mi_tvl1_get_profile_kind(mi_tvl1 *h, int kind, double *ms_total, long long *launches, double *algo_bytes);
 MI_API void mi_tvl1_destroy(mi_tvl1 *h);
 
 /* Stage-level entry points (dense or pitched MI_32FC1 planes) == the reference's internal

@@ -4,6 +4,7 @@
 // 1313-1408) -- but fully stream-ordered: no host read-back inside the iteration loop.
 #include "tvl1_dev.h"
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -50,7 +51,7 @@ struct Lane {
     int batch = 0;          // pairs of the last calc
     // profiling (mi_tvl1_set_profiling)
     std::vector<hipEvent_t> ev_pool;
-    struct Region { int e0, e1; long long launches; double bytes; };
+    struct Region { int e0, e1; long long launches; double bytes; int kind; };   // kind 0: iteration launches, 1: warp launch
     std::vector<Region> regions;
     // internal stream of a concurrent lane + its completion event
     hipStream_t stream = nullptr;
@@ -171,11 +172,18 @@ int mi_tvl1_set_profiling(mi_tvl1 *h, int enable)
 
 int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, double *algo_bytes)
 {
+    return mi_tvl1_get_profile_kind(h, 0, ms_total, launches, algo_bytes);
+}
+
+int mi_tvl1_get_profile_kind(mi_tvl1 *h, int kind, double *ms_total, long long *launches, double *algo_bytes)
+{
     MI_REQUIRE(h && ms_total && launches && algo_bytes, MI_ERR_BAD_ARG, "null argument");
+    MI_REQUIRE(kind == 0 || kind == 1, MI_ERR_BAD_ARG, "kind must be 0 (iteration launches) or 1 (warp launches)");
     *ms_total = 0; *launches = 0; *algo_bytes = 0;
     for (int li = 0; li < h->last_lanes; ++li) {
         Lane &ln = h->lane[li];
         for (const auto &r : ln.regions) {
+            if (r.kind != kind) continue;
             MI_HIP_TRY(hipEventSynchronize(ln.ev_pool[r.e1]));
             float ms = 0.f;
             MI_HIP_TRY(hipEventElapsedTime(&ms, ln.ev_pool[r.e0], ln.ev_pool[r.e1]));
@@ -322,7 +330,16 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
 
     const int iters_per_warp = P.iterations * P.inner_iterations;
     const bool check = P.epsilon > 0.0 && iters_per_warp > 0;
-    const long long Q = (long long)ns * P.warps * iters_per_warp;
+    // convergence-checked path in fast math: speculative blocks (k_iterate_tbr MODE 1 / 2) instead of one launch per iteration
+    const bool spec = check && !P.exact_math && P.time_block != 1 && P.gamma == 0.0 && P.median_filtering <= 1 && tuning().spec != 0;
+    std::vector<int> spec_plan;
+    if (spec) {
+        spec_plan.resize(iters_per_warp);
+        spec_plan.resize(tb_spec_plan(iters_per_warp, spec_plan.data(), iters_per_warp));
+    }
+    // control slots per pair: one per launch (S, P) and one error sum per iteration (E); both index spaces fit max(.,.)
+    long long Q = (long long)ns * P.warps * iters_per_warp;
+    if (spec) Q = std::max(Q, 2LL * ns * P.warps * (long long)spec_plan.size());
     if (check) {
         MI_REQUIRE(Q <= kMaxSlots, MI_ERR_BAD_ARG, "scales x warps x iterations = %lld control slots exceed the limit of %lld", Q, kMaxSlots);
         if (ln.Q < Q || ln.ctlB < B) {
@@ -395,6 +412,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     const float theta = (float)P.theta;
 
     int q = 0, q_last = -1;   // device-control slot counters
+    int e_next = 0;           // next per-iteration error-sum index (speculative path)
     int cur = 0;              // host-known buffer set (fixed-work mode)
     Ctl ctl;
     memset(&ctl, 0, sizeof(ctl));
@@ -427,11 +445,21 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             wc.q_prev = q_last;
             // at the first warp of a scale u lives in set 0 (host-known)
             const bool dev_cur = check && !first_of_scale;
+            int w0 = -1, w1 = -1;
+            if (h->profiling) {
+                rc = next_event(&w0); if (rc) return rc;
+                MI_HIP_TRY(hipEventRecord(ln.ev_pool[w0], st));
+            }
             if (legacy_warp)
                 rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             else
                 rc = warp_fused(sem, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             if (rc) return rc;
+            if (w0 >= 0) {
+                rc = next_event(&w1); if (rc) return rc;
+                MI_HIP_TRY(hipEventRecord(ln.ev_pool[w1], st));
+                ln.regions.push_back({w0, w1, 1, 44.0 * g.w * g.h * B, 1});   // 44 B/px per warp
+            }
             int e0 = -1, e1 = -1;
             if (h->profiling && iters_per_warp > 0) {
                 rc = next_event(&e0); if (rc) return rc;
@@ -456,6 +484,29 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                         cur ^= 1;
                         first_of_scale = false;
                     }
+                }
+            } else if (spec) {
+                // Per block of T iterations two launches: A runs the block speculatively and records the T error sums, B applies
+                // the reference's stopping rule to them and, if the loop would have stopped inside the block, replays exactly that
+                // many iterations from the block's input.  After convergence the remaining launches of the warp end at once.
+                int n0 = 0;
+                for (size_t k = 0; k < spec_plan.size(); ++k) {
+                    const int T = spec_plan[k];
+                    Ctl a = ctl;
+                    a.q = q; a.q_prev = q_last; a.first_of_warp = (k == 0); a.reset_cur = first_of_scale; a.n = n0;
+                    rc = iterate_tb_spec(T, 1, pl, g, l_t, theta, taut, first_of_scale, a, e_next, st);
+                    if (rc) return rc;
+                    ln.slots.push_back({s, wp});
+                    q_last = q++;
+                    Ctl b = ctl;
+                    b.q = q; b.q_prev = q_last; b.first_of_warp = 0; b.reset_cur = 0; b.n = n0;
+                    rc = iterate_tb_spec(T, 2, pl, g, l_t, theta, taut, first_of_scale, b, e_next, st);
+                    if (rc) return rc;
+                    ln.slots.push_back({s, wp});
+                    q_last = q++;
+                    nlaunch += 2;
+                    e_next += T; n0 += T;
+                    first_of_scale = false;
                 }
             } else for (int it = 0; it < iters_per_warp; ++it) {
                 ++nlaunch;
@@ -483,7 +534,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             if (e0 >= 0) {
                 rc = next_event(&e1); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[e1], st));
-                ln.regions.push_back({e0, e1, nlaunch, 64.0 * g.w * g.h * B * iters_per_warp});
+                ln.regions.push_back({e0, e1, nlaunch, 64.0 * g.w * g.h * B * iters_per_warp, 0});
             }
         }
         Ctl ec = ctl;
@@ -579,7 +630,10 @@ int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int *iters,
     std::vector<int2> S(nq);
     MI_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     MI_HIP_TRY(hipMemcpy(S.data(), ln.S + (size_t)lp * ln.Q, sizeof(int2) * nq, hipMemcpyDeviceToHost));
-    for (int i = 0; i < nq; ++i)
-        if (S[i].y & 1) iters[ln.slots[i].scale * nw + ln.slots[i].warp] += 1;
+    for (int i = 0; i < nq; ++i) {
+        // one-iteration launches: bit 0 = the iteration was executed; speculative launches: bits 8..15 = iterations kept
+        const int k = (S[i].y >> 8) & 0xff;
+        iters[ln.slots[i].scale * nw + ln.slots[i].warp] += k ? k : (S[i].y & 1);
+    }
     return MI_OK;
 }

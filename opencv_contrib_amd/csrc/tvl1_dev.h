@@ -81,6 +81,10 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s);
 int tb_max_block();
+// speculative blocks of the convergence-checked path (epsilon > 0, fast math): see k_iterate_tbr
+int tb_spec_plan(int n, int *blocks, int max_blocks);
+int iterate_tb_spec(int T, int mode, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, const Ctl &ctl,
+                    int e0, hipStream_t s);
 // cost-model decomposition of n iterations into supported blocks (largest first); returns the count
 int tb_plan(int n, int cap, int *blocks, int max_blocks);
 // largest supported block <= n (n >= 1)

@@ -17,6 +17,7 @@
 // (modules/optflow/src/tvl1flow.cpp); fast-math variants use explicit fmaf/rcp.
 #include "tvl1_dev.h"
 #include "tvl1_warp_dev.h"
+#include "tvl1_tb_dev.h"
 #include <cfloat>
 #include <cstdlib>
 #include <climits>
@@ -37,7 +38,6 @@ __device__ __forceinline__ void st4(float *p, long long off, bool ok, const floa
 __device__ __forceinline__ float lane_prev(float v) { return __shfl_up(v, 1); }   // lane n <- n-1
 __device__ __forceinline__ float lane_next(float v) { return __shfl_down(v, 1); } // lane n <- n+1
 
-#define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */
 
 // ------------------------------------------------------------------ convert / pack
 __global__ __launch_bounds__(256) void k_convert(const PtrTab *tab, int type, float *I0, float *I1, Geo g)

@@ -1,6 +1,7 @@
 // Device helpers of the temporally blocked TV-L1 kernels (tvl1_tbr_kernels.hip).
 #pragma once
 #include "tvl1_dev.h"
+#include "tvl1_warp_dev.h"
 
 namespace mi {
 namespace tvl1 {
@@ -33,7 +34,17 @@ struct TbArgs {
     int rows_per_band;
     int cur;  // input set
     int swz, nstrips;
+    CtlK ctl;   // speculative convergence path only (MODE != 0): slot protocol of Ctl, e0 = first error-sum index of the block
+    int e0;
 };
+
+// flags of a control slot (S[..].y): bit 0 = the launch moved the state to the other buffer set, bit 1 = it summed the
+// error (one-iteration launches), bit 2 = the warp has converged, bits 8..15 = iterations this launch contributed
+#define MI_SLOT_FLIP 1
+#define MI_SLOT_CHECKED 2
+#define MI_SLOT_DONE 4
+#define MI_SLOT_ITERS(y) (((y) >> 8) & 0xff)
+#define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */
 
 // per-wave LDS ring of static rows: slot layout [plane 0..3][64*PPL floats]
 template <int PPL>

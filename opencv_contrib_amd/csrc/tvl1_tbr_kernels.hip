@@ -40,9 +40,11 @@ struct Slot {
 };
 
 // In-place stage.  negm1 = -(a != 0), m2 = (a != H), taum2 = taut * m2 are wave-uniform scalars.
-template <int PPL>
+// ERR: also accumulate this iteration level's convergence error sum(du1^2 + du2^2) (optflow/src/tvl1flow.cpp:1096-1112 ==
+// cuda tvl1flow.cu:276-283) of the pixels this lane OWNS: ew = (lane owns the column) x (row inside the wave's band).
+template <int PPL, bool ERR>
 __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
-                                        float m2, float taum2, float l_t, float theta, float taut)
+                                        float m2, float taum2, float l_t, float theta, float taut, float &acc, float ew)
 {
     float dx1[PPL], dx2[PPL];
     dx1[0] = A.p11[0] - dpp_from_prev(A.p11[PPL - 1]);
@@ -75,8 +77,15 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
         B.p12[j] = fmaf(taum2, d1, B.p12[j]) * q1;
         B.p21[j] = fmaf(taut, u2x, B.p21[j]) * q2;
         B.p22[j] = fmaf(taum2, d2, B.p22[j]) * q2;
+        if (ERR) {
+            const float e1 = nu1 - A.u1[j], e2 = nu2 - A.u2[j];
+            acc = fmaf(fmaf(e1, e1, e2 * e2), ew, acc);
+        }
         A.u1[j] = nu1;
         A.u2[j] = nu2;
+        // tie the accumulator update into the stage's dependency chain: left free, the scheduler defers the 130 low-priority
+        // accumulations of the unrolled block to its end and keeps their inputs alive (240 spilled registers measured)
+        if (ERR) asm volatile("" : "+v"(acc), "+v"(A.u1[j]));
     }
 }
 
@@ -140,13 +149,15 @@ struct CtxR {
     bool st_ok;
     bool right_ok[PPL];
     float l_t, theta, taut;
+    int nit;        // active stages (MODE 2: the replayed iteration count, < T; otherwise T)
+    float own_f;    // 1.0f where the lane owns its column(s), else 0 (MODE 1 error sums)
 };
 
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
-template <int T, int PPL, bool PZ, int PF, int k>
-__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0)
+template <int T, int PPL, bool PZ, int PF, int MODE, int k>
+__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, float (&acc)[T])
 {
     constexpr int P = T + 1 + PF;
     constexpr int K = T > 2 ? T - 1 : 1;
@@ -186,7 +197,23 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         const float negm1 = __uint_as_float((a == 0) ? 0u : 0xbf800000u);
         const float m2 = __uint_as_float((a == c.H) ? 0u : 0x3f800000u);
         const float taum2 = __uint_as_float((a == c.H) ? 0u : __float_as_uint(c.taut));
-        stage_r<PPL>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut);
+        if (MODE == 1) {
+            // speculative block: every level's error sum, over the rows of this wave's band only (halo rows belong to a neighbour)
+            const float ew = __uint_as_float((a >= c.y0 && a < c.y1) ? __float_as_uint(c.own_f) : 0u);
+            stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
+                               c.taut, acc[t], ew);
+        } else if (MODE == 2) {
+            // replay of nit < T iterations: a skipped stage writes nothing, which IS the identity of the rotating scheme
+            // (its output set still holds the unmodified input row of the previous step)
+            float dummy = 0.f;
+            if (t < c.nit)
+                stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
+                                    c.taut, dummy, 0.f);
+        } else {
+            float dummy = 0.f;
+            stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
+                                c.taut, dummy, 0.f);
+        }
     }
     {   // level-T row r0 - T leaves the pipeline
         const Dyn<PPL> &r = X[(k - T + 2 * P) % P].d;
@@ -209,13 +236,21 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     }
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
-template <int T, int PPL, bool PZ, int PF, int... Ks>
-__device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, std::integer_sequence<int, Ks...>)
+template <int T, int PPL, bool PZ, int PF, int MODE, int... Ks>
+__device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, float (&acc)[T],
+                                        std::integer_sequence<int, Ks...>)
 {
-    (step_r<T, PPL, PZ, PF, Ks>(c, X, n0, slot0), ...);
+    (step_r<T, PPL, PZ, PF, MODE, Ks>(c, X, n0, slot0, acc), ...);
 }
 
-template <int T, int PPL, bool PZ, int WPS, int PF>
+// MODE 0: T iterations, fixed work.  The convergence-checked path (epsilon > 0) runs blocks SPECULATIVELY:
+// MODE 1 = launch A of a block: T iterations from set cur into set cur^1 while recording the T per-iteration error sums;
+// MODE 2 = launch B: every workgroup evaluates the reference's stopping rule on those sums (CPU class: after every iteration,
+//          optflow/src/tvl1flow.cpp:1376-1390; cv::cuda: the sparse schedule of cudaoptflow/src/tvl1flow.cpp:357-377); if the
+//          loop would have stopped after k < T iterations the block is REPLAYED with exactly k iterations from the block's
+//          input (still intact in set cur), otherwise the speculative result stands and the launch ends at once.
+// Control travels through the per-launch slots of Ctl, so the whole calc stays stream-ordered.
+template <int T, int PPL, bool PZ, int WPS, int PF, int MODE>
 __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
@@ -255,7 +290,49 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     c.xc = 4u * (unsigned)min(xl, c.ld - PPL);   // clamped column of the unconditional loads, bytes
 
     const long long pb = (long long)b * A.g.ps;
-    const int cur = A.cur;
+    int cur = A.cur;
+    c.nit = T;
+    c.own_f = c.st_ok ? 1.0f : 0.0f;
+    if (MODE != 0) {
+        const CtlK &ck = A.ctl;
+        int cur_in = 0, done = 0;
+        double prev = 0.0;   // cv::cuda's prevError as the block's first iteration sees it
+        if (ck.q_prev >= 0) {
+            const long long sp = (long long)b * ck.Q + ck.q_prev;
+            const int2 sl = ck.S[sp];
+            cur_in = ck.reset_cur ? 0 : (sl.x ^ (sl.y & MI_SLOT_FLIP));
+            if (!ck.first_of_warp) { done = (sl.y & MI_SLOT_DONE) != 0; prev = ck.P[sp]; }
+        }
+        const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+        const long long sq = (long long)b * ck.Q + ck.q;
+        if (MODE == 1) {
+            if (writer) { ck.S[sq] = make_int2(cur_in, done ? MI_SLOT_DONE : 0); ck.P[sq] = prev; }
+            if (done) return;
+        } else {
+            int kk = 0, conv = 0;
+            if (!done) {
+                for (int t = 0; t < T; ++t) {
+                    const int n = ck.n + t;
+                    const bool calc = !ck.sched || ((n & 1) && prev < ck.thr);
+                    if (calc) {
+                        const double e = (double)ck.E[(long long)b * ck.Q + A.e0 + t] * (1.0 / ERR_FIX_SCALE);
+                        prev = e;
+                        if (!(e > ck.thr)) { kk = t + 1; conv = 1; break; }
+                    } else {
+                        prev -= ck.thr;
+                    }
+                }
+                if (!conv) kk = T;
+            }
+            if (writer) {
+                ck.S[sq] = make_int2(cur_in, (kk > 0 ? MI_SLOT_FLIP : 0) | ((conv || done) ? MI_SLOT_DONE : 0) | (kk << 8));
+                ck.P[sq] = prev;
+            }
+            if (done || kk == T) return;   // nothing to do / the speculative block stands
+            c.nit = __builtin_amdgcn_readfirstlane(kk);
+        }
+        cur = cur_in;
+    }
     c.uin[0] = A.pl.u[cur][0] + pb; c.uin[1] = A.pl.u[cur][1] + pb;
     c.uout[0] = A.pl.u[cur ^ 1][0] + pb; c.uout[1] = A.pl.u[cur ^ 1][1] + pb;
 #pragma unroll
@@ -279,10 +356,23 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 #pragma unroll
     for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
     int slot0 = 0;   // ring slot of the row entering at this step (= step mod K)
-    for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF>(c, X, n0, slot0, std::make_integer_sequence<int, P>{});
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE>(c, X, n0, slot0, acc, std::make_integer_sequence<int, P>{});
+    if (MODE == 1) {
+        // deterministic error sums: per-wave double reduction, 2^-24 fixed-point device-scope adds (as k_iterate does)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            double sacc = (double)acc[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+            if (c.lane == 0) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + t], (unsigned long long)(sacc * ERR_FIX_SCALE + 0.5));
+        }
+    }
 }
 
-template <int T, int PPL, int WPS, int PF>
+template <int T, int PPL, int WPS, int PF, int MODE>
 static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
@@ -295,43 +385,46 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         return e;
     }();
     MI_HIP_TRY(attr_rc);
     if (tuning().tb_verbose) {
         static const int nb = [] {
             int n = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF>, 256, lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE>, 256, lds_bytes);
             fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, lds_bytes, n);
             return n;
         }();
         (void)nb;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF>), grid, dim3(256), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE>), grid, dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE>), grid, dim3(256), lds_bytes, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
 // WPS = occupancy the register allocator is held to (launch bound); PLAN = waves/SIMD the band planner assumes.  r01s: the
-// T10 kernel is resident 4 waves/SIMD but fastest when the grid is cut for 3 (394 vs 340 G px-iter/s): with all four slots
-// full the 46 KB unrolled loop of 16 waves per CU at 16 different positions overruns the instruction cache.
+// T10 kernel is resident 4 waves/SIMD but fastest when the grid is cut for 3 (394 vs 340 G px-iter/s).
+typedef int (*TbLaunchFn)(const TbArgs &, bool, hipStream_t);
 struct TbrEntry {
     int T, PPL, WPS, PF, PLAN;
-    int (*launch)(const TbArgs &, bool, hipStream_t);
+    TbLaunchFn launch, spec_a, spec_b;
 };
-#define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF>}
+#define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr, nullptr}
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
     TBR(1, 1, 8, 2, 8),
-    // alternatives (tuning sweeps)
-    TBR(10, 1, 4, 1, 3), TBR(10, 2, 2, 2, 2), TBR(8, 1, 4, 2, 2), TBR(8, 1, 5, 1, 3), TBR(6, 1, 6, 1, 4), TBR(6, 2, 3, 2, 3), TBR(5, 1, 6, 2, 4),
-    TBR(4, 1, 7, 2, 6),
+    // alternatives (tuning sweeps, MIFLOW_TB_VARIANT)
+    TBR(10, 2, 2, 2, 2), TBR(8, 1, 4, 2, 2), TBR(6, 2, 3, 2, 3),
 };
+// The speculative launches A (MODE 1: T accumulator registers more, hence one wave/SIMD less at T = 10) and B (MODE 2) of the
+// convergence-checked path, for the block sizes its plan uses.
+#define TBRS(T, PPL, WPS, PF, PLAN, WPSA) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPSA, PF, 1>, launch_tbr<T, PPL, WPS, PF, 2>}
+static const TbrEntry g_spec[] = {TBRS(10, 1, 4, 2, 3, 3), TBRS(5, 1, 6, 2, 4, 5), TBRS(2, 1, 8, 2, 8, 8), TBRS(1, 1, 8, 2, 8, 8)};
 
 // First entry of time block T, or the entry matching MIFLOW_TB_VARIANT=ppl,wps,pf.  Returns nullptr if T has none.
 static const TbrEntry *tbr_pick(int T)
@@ -427,6 +520,36 @@ int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta
                     A.rows_per_band);
     }
     return e->launch(A, p_zero, s);
+}
+
+// Block sizes the speculative path may use (those with MODE 1 / 2 instantiations)
+int tb_spec_plan(int n, int *blocks, int max_blocks)
+{
+    static const int sup[] = {10, 5, 2, 1};
+    int k = 0;
+    for (int left = n; left > 0 && k < max_blocks;) {
+        int t = 1;
+        for (int c : sup) if (c <= left) { t = c; break; }
+        blocks[k++] = t;
+        left -= t;
+    }
+    return k;
+}
+
+// Launch A (mode 1) or B (mode 2) of a speculative block of T iterations; ctl carries the slot protocol, e0 the index of the
+// block's first per-iteration error sum.
+int iterate_tb_spec(int T, int mode, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, const Ctl &ctl,
+                    int e0, hipStream_t s)
+{
+    const TbrEntry *e = nullptr;
+    for (const TbrEntry &c : g_spec) if (c.T == T) e = &c;
+    if (!e) { set_error("no speculative kernel for time block %d", T); return MI_ERR_BAD_ARG; }
+    TbArgs A;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.swz = 0; A.nstrips = 0;
+    A.rows_per_band = plan_band_rows(*e, g);
+    A.ctl = make_ctlk(&ctl);
+    A.e0 = e0;
+    return (mode == 1 ? e->spec_a : e->spec_b)(A, p_zero, s);
 }
 
 // self-test of the DPP wave-shift semantics the kernels rely on (tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics)

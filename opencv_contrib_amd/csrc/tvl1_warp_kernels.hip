@@ -145,7 +145,25 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
             v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
         }
     } else if (SEM == MI_SEM_CPU_REF) {
-        if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
+        if ((unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0)) {
+            // the 4 x 4 window is inside the image (cv::remap's interior formula, row sums added row by row) but the 6 x 6
+            // window of the derivative taps is not: same association, tap values with clamped neighbours
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t0[4], t1[4], t2[4], w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w[i] = wyv[j] * wxv[i];
+                    fetch3(P, W, H, ld, sx + i, sy + j, t0[i], t1[i], t2[i]);
+                }
+                const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
+                const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
+                const float r2 = t2[0] * w[0] + t2[1] * w[1] + t2[2] * w[2] + t2[3] * w[3];
+                if (j == 0) { s0 = r0; s1 = r1; s2 = r2; } else { s0 += r0; s1 += r1; s2 += r2; }
+            }
+            v0 = s0; v1 = s1; v2 = s2;
+        } else if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
             v0 = v1 = v2 = 0.f;
         } else {
             // cv::remap border path: taps outside the image contribute the border value 0, one tap at a time

@@ -117,6 +117,47 @@ def test_two_lanes_equal_one_lane(gpu, eps, iters):
         assert a1.lastIterations(0) != a1.lastIterations(3) or a1.lastIterations(1) != a1.lastIterations(4)
 
 
+@pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class_rule", "cv_cuda_schedule"])
+@pytest.mark.parametrize("shape,seed", [((120, 160), 11), ((388, 584), 78)])
+def test_class_defaults_speculative_convergence(gpu, oracle, sem, shape, seed):
+    """Class defaults (300 iterations, epsilon 0.01) in fast math: blocks of 10 iterations run speculatively with their
+    per-iteration error sums recorded, the stopping rule of the reference (CPU class: after every iteration,
+    optflow/src/tvl1flow.cpp:1376-1390; cv::cuda: odd iterations while prevError < scaledEpsilon,
+    cudaoptflow/src/tvl1flow.cpp:357-377) is applied on the device and a block the loop stops in is replayed with exactly
+    that many iterations.  Iteration counts per (scale, warp) within 2 of the oracle's (fast-math error sums), flow within
+    the change of the last converged iterations."""
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(*shape, seed=seed)
+    ref, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=300, semantics=sem), return_stats=True)
+    alg = cuda.OpticalFlowDual_TVL1.create(semantics=sem)
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    it = np.array(alg.lastIterations())
+    rit = np.array(st["iters"])[:it.shape[0], :it.shape[1]]
+    assert it.min() >= 1 and it.max() <= 300
+    assert (it < 300).any(), "nothing converged: the stopping rule never fired"
+    assert np.abs(it - rit).max() <= 2, (it.tolist(), rit.tolist())
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= 2e-2, d.mean()
+    assert synth.ccorr_dissimilarity(flow, ref) <= 4e-3
+    # the same object, same inputs: deterministic (fixed-point error sums), and a batch gives every pair its own counts
+    flow2 = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    np.testing.assert_array_equal(flow, flow2)
+
+
+def test_speculative_equals_fixed_work_when_nothing_converges(gpu):
+    """With an unreachable threshold every speculative block is accepted: the result must be bit-identical to the fixed-work
+    run of the same iteration count (same kernels, MODE 1 vs MODE 0), for a count that is not a multiple of the block size."""
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(150, 210, seed=5)
+    a = cuda.OpticalFlowDual_TVL1.create(iterations=27, epsilon=1e-9)
+    b = cuda.OpticalFlowDual_TVL1.create(iterations=27, epsilon=0.0, timeBlock=0)
+    fa, fb = a.calc(T(I0, gpu), T(I1, gpu)), b.calc(T(I0, gpu), T(I1, gpu))
+    assert np.array(a.lastIterations()).min() == 27
+    # the fixed-work plan fuses 27 = 10 + 10 + 5 + 2 differently (cost model): compare with a tolerance of rounding only
+    assert float((fa - fb).abs().max()) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ fused-gradient warp
 @pytest.mark.parametrize("amp", [0.0, 1.5, 8.0, 400.0])
 @pytest.mark.parametrize("shape", [(77, 101), (6, 9), (5, 300), (211, 467)])

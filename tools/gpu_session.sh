@@ -12,7 +12,7 @@ case $step in
 tests_new)
   (timeout 900 python -m pytest tests/test_baseline_sizes.py tests/test_ref_pin.py tests/test_tvl1_gpu.py tests/test_superres_flowio.py tests/test_cpp_shim.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -30) > $O/pytest_new.log; cat $O/pytest_new.log ;;
 tests_all)
-  (timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -30) > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
+  (timeout 1500 python -m pytest tests -m gpu -q -rf -p no:cacheprovider 2>&1 | tail -60) > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
 smoke)
   (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6) > $O/smoke.log; cat $O/smoke.log ;;
 ab_warp)

@@ -1,0 +1,66 @@
+"""Static instruction mix of the main loop of a blocked TV-L1 kernel (k_iterate_tbr<T, PPL, PZ, WPS, PF, MODE>), per pipeline
+stage and pixel row: compiles tvl1_tbr_kernels.hip to gfx950 assembly, finds the largest loop of the instantiation and counts its
+instructions by class.  bench.py's `roofline` (bound "valu_issue") uses these figures; the output of record is
+profiles/static_mix_tbr.json.  Usage: python tools/static_mix.py [T PPL PZ WPS PF MODE]  (default 10 1 0 4 2 0)"""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0):
+    src = os.path.join(ROOT, "opencv_contrib_amd", "csrc", "tvl1_tbr_kernels.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-x", "hip", "-S", "--cuda-device-only", src,
+                        "-o", out], check=True, stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    pat = f"k_iterate_tbrILi{T}ELi{PPL}ELb{PZ}ELi{WPS}ELi{PF}ELi{MODE}E"
+    for f in re.split(r"\n\s*\.globl\s+", txt):
+        if pat not in f.split("\n", 1)[0]:
+            continue
+        lines = f.split("\n")
+        labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        best = None
+        for i, l in enumerate(lines):
+            m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+            if m and labels.get(m.group(1), i) < i and (best is None or i - labels[m.group(1)] > best[1] - best[0]):
+                best = (labels[m.group(1)], i)
+        cnt = collections.Counter()
+        for l in lines[best[0]:best[1] + 1]:
+            l = l.strip()
+            if l and not l.startswith((".", ";", "//")) and not l.endswith(":"):
+                cnt[l.split()[0]] += 1
+        cls = collections.Counter()
+        for op, n in cnt.items():
+            if op.startswith("v_"):
+                if re.match(r"v_(rcp|sqrt|rsq|exp|log|sin|cos)", op):
+                    cls["transcendental"] += n
+                elif "dpp" in op:
+                    cls["dpp"] += n
+                elif op.startswith("v_cndmask"):
+                    cls["cndmask"] += n
+                else:
+                    cls["valu_plain"] += n
+            elif op.startswith("s_"):
+                cls["salu"] += n
+            elif op.startswith("ds_"):
+                cls["lds"] += n
+            elif op.startswith(("global_", "buffer_")):
+                cls["vmem"] += n
+            else:
+                cls["other"] += n
+        stages = (T + 1 + PF) * T * PPL   # the loop body is unrolled P = T + 1 + PF steps of T stages
+        return {"kernel": pat, "loop_instructions": sum(cnt.values()), "per_stage_and_pixel": {k: round(v / stages, 3) for k, v in cls.items()}}
+    raise SystemExit("instantiation not found: " + pat)
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:7]] or [10, 1, 0, 4, 2, 0]
+    print(json.dumps(mix(*a), indent=1))
