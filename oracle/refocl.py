@@ -54,6 +54,17 @@ def lib(fma: bool = False):
         L.ref_ocl_tvl1_estimate_u.argtypes = [_f32p] * 11 + [i, i, f, f, i]
         L.ref_ocl_tvl1_estimate_dual.argtypes = [_f32p] * 6 + [i, i, f]
         L.ref_ocl_tvl1_proc_one_scale.argtypes = [_f32p] * 4 + [i, i, d, d, d, d, i, i, i, C.c_void_p]
+        u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+        i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        L.ref_ocl_surf_det_trace.argtypes = [u32p, i, i, i, i, _f32p, _f32p]
+        L.ref_ocl_surf_find_maxima.restype = i
+        L.ref_ocl_surf_find_maxima.argtypes = [_f32p, _f32p, i, i, i, i, f, i, i32p]
+        L.ref_ocl_surf_interpolate.argtypes = [_f32p, i, i, i, i32p, i, _f32p, i, i, C.POINTER(i)]
+        L.ref_ocl_surf_orientation.argtypes = [u32p, i, i, _f32p, i, i]
+        L.ref_ocl_surf_descriptors.argtypes = [u8p, i, i, _f32p, i, i, i, _f32p]
+        L.ref_ocl_surf_detect.restype = i
+        L.ref_ocl_surf_detect.argtypes = [u32p, i, i, i, i, f, f, _f32p, i]
         _libs[key] = L
     return _libs[key]
 
@@ -102,3 +113,52 @@ def tvl1_proc_one_scale(I0, I1, u1, u2, tau=0.25, lambda_=0.15, theta=0.3, epsil
     lib(fma).ref_ocl_tvl1_proc_one_scale(I0, I1, u1, u2, w, h, tau, lambda_, theta, epsilon, warps, inner_iterations,
                                          outer_iterations, iters.ctypes.data)
     return u1, u2, iters[:warps]
+
+
+# ---------------------------------------------------------------------------------------------------- SURF (surf.cl)
+def surf_det_trace(sum_, octave, n_octave_layers=2, fma=False):
+    """SURF_calcLayerDetAndTrace; planes of ((layers + 2) * (rows >> octave)) x cols like oracle.surf_det_trace."""
+    sum_ = np.ascontiguousarray(sum_, np.uint32)
+    rows, cols = sum_.shape[0] - 1, sum_.shape[1] - 1
+    lr = rows >> octave
+    det = np.zeros(((n_octave_layers + 2) * lr, cols), np.float32)
+    tr = np.zeros_like(det)
+    lib(fma).ref_ocl_surf_det_trace(sum_, rows, cols, octave, n_octave_layers, det, tr)
+    return det, tr
+
+
+def surf_find_maxima(det, trace, rows, cols, octave, n_octave_layers, hessian_threshold, max_candidates=65535, fma=False):
+    """SURF_findMaximaInLayer -> (n, candidates[n, 4] = x, y, layer, laplacian) in launch order."""
+    cand = np.zeros((max_candidates + 1, 4), np.int32)
+    n = lib(fma).ref_ocl_surf_find_maxima(_c(det), _c(trace), rows, cols, octave, n_octave_layers, hessian_threshold, max_candidates,
+                                          cand.reshape(-1))
+    return n, cand[:min(n, max_candidates)].copy()
+
+
+def surf_detect(sum_, n_octaves=4, n_octave_layers=2, hessian_threshold=100.0, keypoints_ratio=0.01, fma=False):
+    """SURF_OCL::detectKeypoints without the orientation step -> keypoint matrix (7, n), rows as cuda.hpp:89-99."""
+    sum_ = np.ascontiguousarray(sum_, np.uint32)
+    rows, cols = sum_.shape[0] - 1, sum_.shape[1] - 1
+    pitch = max(1, min(int(np.float32(rows * cols) * np.float32(keypoints_ratio)), 65535))
+    kp = np.zeros((7, pitch), np.float32)
+    n = lib(fma).ref_ocl_surf_detect(sum_, rows, cols, n_octaves, n_octave_layers, hessian_threshold, keypoints_ratio, kp.reshape(-1), pitch)
+    return kp[:, :n].copy()
+
+
+def surf_orientation(sum_, kp, fma=False):
+    """SURF_calcOrientation on a (7, n) keypoint matrix; returns the ANGLE row."""
+    sum_ = np.ascontiguousarray(sum_, np.uint32)
+    rows, cols = sum_.shape[0] - 1, sum_.shape[1] - 1
+    k = np.ascontiguousarray(kp, np.float32).copy()
+    lib(fma).ref_ocl_surf_orientation(sum_, rows, cols, k.reshape(-1), k.shape[1], k.shape[1])
+    return k[5].copy()
+
+
+def surf_descriptors(img, kp, extended=False, fma=False):
+    """SURF_computeDescriptors64/128 + SURF_normalizeDescriptors64/128 for a (7, n) keypoint matrix."""
+    img = np.ascontiguousarray(img, np.uint8)
+    k = np.ascontiguousarray(kp, np.float32)
+    dsz = 128 if extended else 64
+    desc = np.zeros((k.shape[1], dsz), np.float32)
+    lib(fma).ref_ocl_surf_descriptors(img, img.shape[0], img.shape[1], k.reshape(-1), k.shape[1], k.shape[1], dsz, desc.reshape(-1))
+    return desc

@@ -1,9 +1,10 @@
-"""PINNING: the restated oracle against REFERENCE CODE EXECUTED HERE.
+"""PINNING: the restated oracles against REFERENCE CODE EXECUTED HERE.
 
-oracle/_ref/libref_ocl.so is the reference's own OpenCL kernel source
-(modules/optflow/src/opencl/optical_flow_tvl1.cl:46-378), compiled verbatim for x86-64 by clang's OpenCL C front end
-(oracle/Makefile.ref) and run on the CPU through the NDRange shim of oracle/refshim/.  These kernels are the OpenCL
-twins of cudaoptflow/src/cuda/tvl1flow.cu:59-348, i.e. the arithmetic the `MI_SEM_CUDA_COMPAT` oracle restates.
+oracle/_ref/libref_ocl.so is the reference's own OpenCL kernel source -- modules/optflow/src/opencl/optical_flow_tvl1.cl:46-378
+and modules/xfeatures2d/src/opencl/surf.cl -- compiled verbatim for x86-64 by clang's OpenCL C front end (oracle/Makefile.ref)
+and run on the CPU through the NDRange shim of oracle/refshim/.  The TV-L1 kernels are the OpenCL twins of
+cudaoptflow/src/cuda/tvl1flow.cu:59-348, i.e. the arithmetic the `MI_SEM_CUDA_COMPAT` oracle restates; the SURF kernels are the
+twins of xfeatures2d/src/cuda/surf.cu:122-942, which oracle/surf_ref.c restates (second half of this file).
 
 What is asserted, on the same seeded inputs:
   * every stage of oracle/tvl1_ref.c (semantics CUDA_COMPAT) equals the reference kernel BIT FOR BIT when both are
@@ -115,6 +116,79 @@ def test_contraction_freedom_is_bounded(oracle):
     r1, r2, _ = refocl.tvl1_proc_one_scale(I0, I1, z, z, epsilon=0.0, outer_iterations=10)
     f1, f2, _ = refocl.tvl1_proc_one_scale(I0, I1, z, z, epsilon=0.0, outer_iterations=10, fma=True)
     assert synth.epe(np.stack([r1, r2], -1), np.stack([f1, f2], -1)) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- SURF: oracle vs surf.cl
+SURF_CASES = [(300, 400, 11, 100.0, 4, 2), (200, 264, 5, 300.0, 3, 3), (481, 640, 7, 400.0, 4, 2)]
+
+
+def _kp_matrix(ro):
+    K = np.zeros((7, ro["n"]), np.float32)
+    K[0], K[1], K[4], K[5], K[6] = ro["x"], ro["y"], ro["size"], ro["angle"], ro["hessian"]
+    K[2:3].view(np.int32)[0] = ro["laplacian"]
+    K[3:4].view(np.int32)[0] = ro["octave"]
+    return K
+
+
+@pytest.mark.parametrize("h,w,seed,thr,octaves,layers", SURF_CASES)
+def test_surf_det_trace_and_maxima_equal_reference_kernels(oracle, h, w, seed, thr, octaves, layers):
+    """SURF_calcLayerDetAndTrace (built with DOUBLE_SUPPORT, as on a device with doubles) and SURF_findMaximaInLayer against
+    oracle.surf_det_trace / orc_surf_find_maxima: determinant and trace planes bit for bit wherever the kernel writes, the same
+    set of (x, y, layer, laplacian) candidates in every octave."""
+    img = synth.blob_image(h, w, seed=seed)
+    S = oracle.surf_integral(img)
+    L = oracle.lib()
+    for octave in range(octaves):
+        rd, rt = refocl.surf_det_trace(S, octave, layers)
+        od, ot = oracle.surf_det_trace(S, octave, layers)
+        m = (rd != 0) | (rt != 0)
+        assert m.mean() > 0.02
+        np.testing.assert_array_equal(od[m], rd[m])
+        np.testing.assert_array_equal(ot[m], rt[m])
+        n, cand = refocl.surf_find_maxima(od, ot, h, w, octave, layers, thr)
+        oc = np.zeros((65536, 4), np.int32)
+        no = L.orc_surf_find_maxima(od, ot, None, h, w, octave, layers, thr, 65535, oc.reshape(-1))
+        assert n == no
+        assert set(map(tuple, cand.tolist())) == set(map(tuple, oc[:no].tolist()))
+
+
+@pytest.mark.parametrize("h,w,seed,thr,octaves,layers", SURF_CASES)
+def test_surf_keypoints_equal_reference_detector(oracle, h, w, seed, thr, octaves, layers):
+    """SURF_OCL::detectKeypoints on the reference kernels (det/trace -> maxima -> SURF_interpolateKeypoint, the octave loop of
+    surf.ocl.cpp:152-200) against oracle.surf_detect_describe: the same set of keypoints, x / y / size / response / laplacian /
+    octave bit for bit (the reference appends with atomic_inc, so order is not compared)."""
+    img = synth.blob_image(h, w, seed=seed)
+    S = oracle.surf_integral(img)
+    ro = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=thr, n_octaves=octaves, n_octave_layers=layers,
+                                                             keypoints_ratio=0.05), want_desc=False)
+    kp = refocl.surf_detect(S, octaves, layers, thr, 0.05)
+    assert kp.shape[1] == ro["n"] > 10
+    ko = _kp_matrix(ro)
+    order = lambda K: np.lexsort((K[6], K[4], K[1], K[0]))
+    a, b = kp[:, order(kp)], ko[:, order(ko)]
+    for row in (0, 1, 4, 6):
+        np.testing.assert_array_equal(a[row], b[row])
+    np.testing.assert_array_equal(a[2:4].view(np.int32), b[2:4].view(np.int32))
+
+
+@pytest.mark.parametrize("extended", [False, True])
+@pytest.mark.parametrize("h,w,seed,thr,octaves,layers", SURF_CASES[:2])
+def test_surf_orientation_and_descriptors_against_reference_kernels(oracle, h, w, seed, thr, octaves, layers, extended):
+    """SURF_calcOrientation and SURF_computeDescriptors64/128 + normalize on the oracle's keypoints.  The OpenCL twins read the
+    integral image as float and reduce in another order than surf.cu, so these two stages are held to a tolerance: every
+    orientation within 1e-3 degrees, every descriptor element within 1e-6."""
+    img = synth.blob_image(h, w, seed=seed)
+    S = oracle.surf_integral(img)
+    ro = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=thr, n_octaves=octaves, n_octave_layers=layers,
+                                                             extended=int(extended), keypoints_ratio=0.05))
+    K = _kp_matrix(ro)
+    ang = refocl.surf_orientation(S, K)
+    d = np.abs(ang - ro["angle"]); d = np.minimum(d, 360 - d)
+    assert d.max() <= 1e-3, d.max()
+    desc = refocl.surf_descriptors(img, K, extended)
+    assert desc.shape == ro["descriptors"].shape
+    assert np.abs(desc - ro["descriptors"]).max() <= 1e-6
+    np.testing.assert_allclose(np.linalg.norm(desc, axis=1), 1.0, atol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------- HIP vs the reference kernels
