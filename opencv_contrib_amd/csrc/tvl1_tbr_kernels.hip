@@ -41,10 +41,13 @@ struct Slot {
 
 // In-place stage.  negm1 = -(a != 0), m2 = (a != H), taum2 = taut * m2 are wave-uniform scalars.
 // ERR: also accumulate this iteration level's convergence error sum(du1^2 + du2^2) (optflow/src/tvl1flow.cpp:1096-1112 ==
-// cuda tvl1flow.cu:276-283) of the pixels this lane OWNS: ew = (lane owns the column) x (row inside the wave's band).
+// cuda tvl1flow.cu:276-283) as INTEGERS: every pixel's term is rounded to 2^-24 px^2 and added into a 64-bit per-lane
+// accumulator, so the sum does not depend on how rows are split into bands or pairs into batches and lanes -- a pair stops
+// after the same iteration whatever batch it is computed in.  es = 2^24 for rows inside the wave's band, 0 for its halo rows
+// (the scale doubles as the row mask); ownership of the column is applied once, when the accumulators are reduced.
 template <int PPL, bool ERR>
 __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
-                                        float m2, float taum2, float l_t, float theta, float taut, float &acc, float ew)
+                                        float m2, float taum2, float l_t, float theta, float taut, unsigned long long &acc, float es)
 {
     float dx1[PPL], dx2[PPL];
     dx1[0] = A.p11[0] - dpp_from_prev(A.p11[PPL - 1]);
@@ -79,13 +82,17 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
         B.p22[j] = fmaf(taum2, d2, B.p22[j]) * q2;
         if (ERR) {
             const float e1 = nu1 - A.u1[j], e2 = nu2 - A.u2[j];
-            acc = fmaf(fmaf(e1, e1, e2 * e2), ew, acc);
+            acc += (unsigned long long)__float2uint_rn(fmaf(e1, e1, e2 * e2) * es);   // v_cvt_u32_f32 saturates: a term >= 256 px^2 only under-counts
         }
         A.u1[j] = nu1;
         A.u2[j] = nu2;
         // tie the accumulator update into the stage's dependency chain: left free, the scheduler defers the 130 low-priority
         // accumulations of the unrolled block to its end and keeps their inputs alive (240 spilled registers measured)
-        if (ERR) asm volatile("" : "+v"(acc), "+v"(A.u1[j]));
+        if (ERR) {
+            unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
+            asm volatile("" : "+v"(lo), "+v"(hi), "+v"(A.u1[j]));
+            acc = ((unsigned long long)hi << 32) | lo;
+        }
     }
 }
 
@@ -150,14 +157,13 @@ struct CtxR {
     bool right_ok[PPL];
     float l_t, theta, taut;
     int nit;        // active stages (MODE 2: the replayed iteration count, < T; otherwise T)
-    float own_f;    // 1.0f where the lane owns its column(s), else 0 (MODE 1 error sums)
 };
 
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
 template <int T, int PPL, bool PZ, int PF, int MODE, int k>
-__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, float (&acc)[T])
+__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T])
 {
     constexpr int P = T + 1 + PF;
     constexpr int K = T > 2 ? T - 1 : 1;
@@ -199,18 +205,18 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         const float taum2 = __uint_as_float((a == c.H) ? 0u : __float_as_uint(c.taut));
         if (MODE == 1) {
             // speculative block: every level's error sum, over the rows of this wave's band only (halo rows belong to a neighbour)
-            const float ew = __uint_as_float((a >= c.y0 && a < c.y1) ? __float_as_uint(c.own_f) : 0u);
+            const float es = __uint_as_float((a >= c.y0 && a < c.y1) ? 0x4b800000u : 0u);   // 2^24 or 0, kept on the scalar unit
             stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
-                               c.taut, acc[t], ew);
+                               c.taut, acc[t], es);
         } else if (MODE == 2) {
             // replay of nit < T iterations: a skipped stage writes nothing, which IS the identity of the rotating scheme
             // (its output set still holds the unmodified input row of the previous step)
-            float dummy = 0.f;
+            unsigned long long dummy = 0;
             if (t < c.nit)
                 stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
                                     c.taut, dummy, 0.f);
         } else {
-            float dummy = 0.f;
+            unsigned long long dummy = 0;
             stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
                                 c.taut, dummy, 0.f);
         }
@@ -237,7 +243,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
 template <int T, int PPL, bool PZ, int PF, int MODE, int... Ks>
-__device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, float (&acc)[T],
+__device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
                                         std::integer_sequence<int, Ks...>)
 {
     (step_r<T, PPL, PZ, PF, MODE, Ks>(c, X, n0, slot0, acc), ...);
@@ -292,7 +298,6 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     const long long pb = (long long)b * A.g.ps;
     int cur = A.cur;
     c.nit = T;
-    c.own_f = c.st_ok ? 1.0f : 0.0f;
     if (MODE != 0) {
         const CtlK &ck = A.ctl;
         int cur_in = 0, done = 0;
@@ -356,18 +361,18 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 #pragma unroll
     for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
     int slot0 = 0;   // ring slot of the row entering at this step (= step mod K)
-    float acc[T];
+    unsigned long long acc[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    for (int t = 0; t < T; ++t) acc[t] = 0;
     for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE>(c, X, n0, slot0, acc, std::make_integer_sequence<int, P>{});
     if (MODE == 1) {
-        // deterministic error sums: per-wave double reduction, 2^-24 fixed-point device-scope adds (as k_iterate does)
+        // integer error sums: exact wave reduction of the owned lanes, one device-scope add per wave and level
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            double sacc = (double)acc[t];
+            unsigned long long sacc = c.st_ok ? acc[t] : 0ull;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-            if (c.lane == 0) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + t], (unsigned long long)(sacc * ERR_FIX_SCALE + 0.5));
+            if (c.lane == 0) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + t], sacc);
         }
     }
 }
@@ -424,7 +429,7 @@ static const TbrEntry g_tbr[] = {
 // The speculative launches A (MODE 1: T accumulator registers more, hence one wave/SIMD less at T = 10) and B (MODE 2) of the
 // convergence-checked path, for the block sizes its plan uses.
 #define TBRS(T, PPL, WPS, PF, PLAN, WPSA) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPSA, PF, 1>, launch_tbr<T, PPL, WPS, PF, 2>}
-static const TbrEntry g_spec[] = {TBRS(10, 1, 4, 2, 3, 3), TBRS(5, 1, 6, 2, 4, 5), TBRS(2, 1, 8, 2, 8, 8), TBRS(1, 1, 8, 2, 8, 8)};
+static const TbrEntry g_spec[] = {TBRS(10, 1, 4, 2, 3, 3), TBRS(5, 1, 6, 2, 4, 4), TBRS(2, 1, 8, 2, 8, 8), TBRS(1, 1, 8, 2, 8, 8)};
 
 // First entry of time block T, or the entry matching MIFLOW_TB_VARIANT=ppl,wps,pf.  Returns nullptr if T has none.
 static const TbrEntry *tbr_pick(int T)

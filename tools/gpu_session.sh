@@ -18,7 +18,7 @@ smoke)
 ab_warp)
   for cfg in "pk 1" "pk 2" "fused 1" "fused 2"; do
     set -- $cfg
-    (MIFLOW_WARP=$1 timeout 300 python bench.py --no-variants --no-cpu --lanes $2 --steps 10 --warmup 3 2>$O/ab_$1_$2.err | tail -1) > $O/ab_$1_$2.json
+    (MIFLOW_WARP=$1 timeout 300 python bench.py --no-variants --no-cpu --no-secondary --lanes $2 --steps 10 --warmup 3 2>$O/ab_$1_$2.err | tail -1) > $O/ab_$1_$2.json
     python - <<PY
 import json
 try:
@@ -30,7 +30,7 @@ bench)
   (timeout 900 python bench.py 2>$O/bench.err | tail -1) > $O/bench.json; tail -c 3000 $O/bench.json; tail -5 $O/bench.err ;;
 trace)
   cd /tmp
-  timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace -- python $R/bench.py --no-variants --no-cpu --steps 5 --warmup 2 > $R/$O/trace_bench.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace -- python $R/bench.py --no-variants --no-cpu --no-secondary --steps 5 --warmup 2 > $R/$O/trace_bench.log 2>&1
   cd $R
   find $O/trace -name "*kernel_stats.csv" | head -3
   for f in $(find $O/trace -name "*kernel_stats.csv" | head -1); do cp $f $O/kernel_stats.csv; head -12 $f; done
@@ -38,10 +38,19 @@ trace)
 pmc)
   cd /tmp
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 400 rocprofv3 --kernel-trace --pmc $c -f csv -d $R/$O/pmc_$c -- python $R/bench.py --no-variants --no-cpu --steps 2 --warmup 1 > $R/$O/pmc_$c.log 2>&1
+    timeout 400 rocprofv3 --kernel-trace --pmc $c -f csv -d $R/$O/pmc_$c -- python $R/bench.py --no-variants --no-cpu --no-secondary --steps 2 --warmup 1 > $R/$O/pmc_$c.log 2>&1
   done
   cd $R
   python tools/pmc_summary.py $O > $O/pmc_summary.md 2>&1; head -40 $O/pmc_summary.md
   find $O -type f -size +4M -delete ;;
+trace_defaults)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace_defaults -- python $R/bench.py --defaults --no-variants --no-cpu --no-secondary --steps 2 --warmup 1 > $R/$O/trace_defaults_bench.log 2>&1
+  cd $R
+  tail -1 $O/trace_defaults_bench.log | cut -c1-600
+  for f in $(find $O/trace_defaults -name "*kernel_stats.csv" | head -1); do cp $f $O/kernel_stats_defaults.csv; head -12 $f; done
+  find $O -type f -size +4M -delete ;;
+test_one)
+  (timeout 600 python -m pytest "tests/test_baseline_sizes.py" -m gpu -q -x -p no:cacheprovider -k "two_lanes or speculative" 2>&1 | tail -30) > $O/pytest_one.log; cat $O/pytest_one.log ;;
 esac
 done
