@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
             cur_in = ck.reset_cur ? 0 : (sl.x ^ (sl.y & MI_SLOT_FLIP));
             if (!ck.first_of_warp) { done = (sl.y & MI_SLOT_DONE) != 0; prev = ck.P[sp]; }
         }
-        const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+        const bool writer = strip == 0 && bgrp == 0 && threadIdx.x == 0;   // the REMAPPED indices: one writer per pair b
         const long long sq = (long long)b * ck.Q + ck.q;
         if (MODE == 1) {
             if (writer) { ck.S[sq] = make_int2(cur_in, done ? MI_SLOT_DONE : 0); ck.P[sq] = prev; }

@@ -115,6 +115,11 @@ def test_two_lanes_equal_one_lane(gpu, eps, iters):
         assert a1.lastIterations(k) == a2.lastIterations(k)
     if eps > 0:
         assert a1.lastIterations(0) != a1.lastIterations(3) or a1.lastIterations(1) != a1.lastIterations(4)
+    # ... and to five single calcs: the stopping decisions use integer error sums, so they do not depend on the batch either
+    single = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps)
+    for k in range(5):
+        assert torch.equal(single.calc(I0s[k], I1s[k]), f1[k]), f"pair {k}"
+        assert single.lastIterations(0) == a1.lastIterations(k)
 
 
 @pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class_rule", "cv_cuda_schedule"])
