@@ -32,6 +32,7 @@ void set_error(const char *fmt, ...);
 struct Tuning {
     int warp_legacy;         // MIFLOW_WARP=pk: packed-float4 gather warp (the round-1 kernel) instead of the fused-gradient one
     int warp_tile;           // MIFLOW_WARP_TILE: pixels of a wave along x in the warp kernels (64 | 32 | 16)
+    int warp_np;             // MIFLOW_WARP_NP: patches a wave of the fused-gradient warp kernel walks (1 | 2 | 4)
     int tb_swz;              // MIFLOW_TB_SWZ: XCD-aware workgroup remap of the blocked iteration kernels
     int tb_ppl, tb_wps, tb_pf;   // MIFLOW_TB_VARIANT=ppl,wps,pf (-1: table default)
     int tb_force;            // MIFLOW_TB_FORCE: greedy blocks of exactly the cap (tuning sweeps)

@@ -42,27 +42,12 @@ __device__ __forceinline__ void fetch3(const float *P, int W, int H, int ld, int
     vy = 0.5f * (P[(long long)min(cy + 1, H - 1) * ld + cx] - P[(long long)max(cy - 1, 0) * ld + cx]);
 }
 
-template <int SEM, int TX>
-__global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_host)
+// One output pixel (x, y) of pair plane P: u1v, u2v = the flow at the pixel, i0 = I0 there; writes the five planes at o.
+template <int SEM>
+__device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, const float *P, int x, int y, long long o, float u1v,
+                                        float u2v, float i0)
 {
-    __shared__ float s_tab[128];
-    if (SEM == MI_SEM_CPU_REF) {
-        if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
-        __syncthreads();
-    }
-    constexpr int TY = 64 / TX;   // rows per wave: a TX x TY patch per wave keeps the gather footprint compact
-    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-    const int x = blockIdx.x * TX + (lane_ % TX);
-    const int y = blockIdx.y * (4 * TY) + wave_ * TY + lane_ / TX;
-    const int b = blockIdx.z;
     const int W = A.g.w, H = A.g.h, ld = A.g.ld;
-    if (x >= W || y >= H) return;
-    const int cur = resolve_cur_k(ctl, b, cur_host);
-    const long long pb = (long long)b * A.g.ps;
-    const long long o = pb + (long long)y * ld + x;
-    const float u1v = A.u1[cur][o], u2v = A.u2[cur][o];
-    const float *P = A.I1 + pb;
-
     int sx, sy;          // first tap column / row of the 4 x 4 window
     float wxv[4], wyv[4];
     float wxp = 0.f, wyp = 0.f;
@@ -208,7 +193,44 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
     // calcGradRho  optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163
     const float Ix2 = v1 * v1, Iy2 = v2 * v2;
     A.grad[o] = Ix2 + Iy2;
-    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - A.I0[o]);
+    A.rho[o] = (v0 - v1 * u1v - v2 * u2v - i0);
+}
+
+// A wave owns NP consecutive TX x TY patches of a row band.  The flow and I0 of patch i + 1 are requested BEFORE the window
+// gathers of patch i are issued, so the two dependent memory phases of a pixel (flow -> addresses -> window) overlap across
+// patches: with one patch per wave the kernel ran at the latency bound of 2 phases x 2048 pixels in flight per CU (r02b).
+template <int SEM, int TX, int NP>
+__global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_host)
+{
+    __shared__ float s_tab[128];
+    if (SEM == MI_SEM_CPU_REF) {
+        if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
+        __syncthreads();
+    }
+    constexpr int TY = 64 / TX;   // rows per wave: a TX x TY patch per wave keeps the gather footprint compact
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * (TX * NP) + (lane_ % TX);
+    const int y = blockIdx.y * (4 * TY) + wave_ * TY + lane_ / TX;
+    const int b = blockIdx.z;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    if (x0 >= W || y >= H) return;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const long long pb = (long long)b * A.g.ps;
+    const long long orow = pb + (long long)y * ld;
+    const float *U1 = A.u1[cur] + orow, *U2 = A.u2[cur] + orow, *I0r = A.I0 + orow;
+    const float *P = A.I1 + pb;
+    float u1n = U1[x0], u2n = U2[x0], i0n = I0r[x0];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int x = x0 + i * TX;
+        if (x >= W) break;
+        const float u1v = u1n, u2v = u2n, i0 = i0n;
+        if (i + 1 < NP) {
+            const int xn = min(x + TX, W - 1);   // clamped: the value of a patch past the right edge is never used
+            u1n = U1[xn]; u2n = U2[xn]; i0n = I0r[xn];
+        }
+        warp_px<SEM>(A, s_tab, P, x, y, orow + x, u1v, u2v, i0);
+    }
 }
 
 int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
@@ -223,15 +245,21 @@ int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
     const int tile = warp_tile();
-    const dim3 grid(div_up(g.w, tile), div_up(g.h, 4 * (64 / tile)), g.batch);
+    const int np = tuning().warp_np;   // patches per wave (MIFLOW_WARP_NP = 1 | 2 | 4, default 4)
+    const dim3 grid(div_up(g.w, tile * np), div_up(g.h, 4 * (64 / tile)), g.batch);
+#define LAUNCH_W6N(SEM, NP)                                                                                              \
+    do {                                                                                                                 \
+        if (tile == 16) hipLaunchKernelGGL((k_warp6<SEM, 16, NP>), grid, dim3(256), 0, s, A, ck, cur_host);              \
+        else if (tile == 32) hipLaunchKernelGGL((k_warp6<SEM, 32, NP>), grid, dim3(256), 0, s, A, ck, cur_host);         \
+        else hipLaunchKernelGGL((k_warp6<SEM, 64, NP>), grid, dim3(256), 0, s, A, ck, cur_host);                         \
+    } while (0)
 #define LAUNCH_W6(SEM)                                                                                                   \
     do {                                                                                                                 \
-        if (tile == 16) hipLaunchKernelGGL((k_warp6<SEM, 16>), grid, dim3(256), 0, s, A, ck, cur_host);                  \
-        else if (tile == 32) hipLaunchKernelGGL((k_warp6<SEM, 32>), grid, dim3(256), 0, s, A, ck, cur_host);             \
-        else hipLaunchKernelGGL((k_warp6<SEM, 64>), grid, dim3(256), 0, s, A, ck, cur_host);                             \
+        if (np == 1) LAUNCH_W6N(SEM, 1); else if (np == 2) LAUNCH_W6N(SEM, 2); else LAUNCH_W6N(SEM, 4);                  \
     } while (0)
     if (semantics == MI_SEM_CPU_REF) LAUNCH_W6(MI_SEM_CPU_REF);
     else LAUNCH_W6(MI_SEM_CUDA_COMPAT);
+#undef LAUNCH_W6N
 #undef LAUNCH_W6
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -16,14 +16,15 @@ tests_all)
 smoke)
   (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6) > $O/smoke.log; cat $O/smoke.log ;;
 ab_warp)
-  for cfg in "pk 1" "pk 2" "fused 1" "fused 2"; do
+  for cfg in "1 2" "2 2" "4 2" "4 1"; do
     set -- $cfg
-    (MIFLOW_WARP=$1 timeout 300 python bench.py --no-variants --no-cpu --no-secondary --lanes $2 --steps 10 --warmup 3 2>$O/ab_$1_$2.err | tail -1) > $O/ab_$1_$2.json
+    (MIFLOW_WARP_NP=$1 timeout 300 python bench.py --no-variants --no-cpu --no-secondary --lanes $2 --steps 12 --warmup 3 2>$O/ab_np$1_l$2.err | tail -1) > $O/ab_np$1_l$2.json
     python - <<PY
 import json
 try:
-    d = json.loads(open('$O/ab_$1_$2.json').read()); print('ab warp=$1 lanes=$2', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step', 'iter-launch us', round(d['roofline']['avg_launch_us'], 1))
-except Exception as e: print('ab $1 $2 failed', e); print(open('$O/ab_$1_$2.err').read()[-2000:])
+    d = json.loads(open('$O/ab_np$1_l$2.json').read()); r = d['roofline']
+    print('ab np=$1 lanes=$2', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step | iterate us', round(r['avg_launch_us'], 1), 'warp us', round(r['second_kernel']['avg_launch_us'], 1))
+except Exception as e: print('ab $1 $2 failed', e); print(open('$O/ab_np$1_l$2.err').read()[-2000:])
 PY
   done ;;
 bench)
