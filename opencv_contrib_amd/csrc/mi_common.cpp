@@ -19,8 +19,8 @@ const Tuning &tuning()
         t.warp_legacy = (w && w[0] == 'p') ? 1 : 0;
         t.warp_tile = env_int("MIFLOW_WARP_TILE", 32);
         if (t.warp_tile != 64 && t.warp_tile != 32 && t.warp_tile != 16) t.warp_tile = 32;
-        t.warp_np = env_int("MIFLOW_WARP_NP", 4);
-        if (t.warp_np != 1 && t.warp_np != 2) t.warp_np = 4;
+        t.warp_np = env_int("MIFLOW_WARP_NP", 2);   // r02e at 1080p x 16: np 1 | 2 | 4 = 904 | 1042 | 1034 pairs/s
+        if (t.warp_np != 1 && t.warp_np != 4) t.warp_np = 2;
         t.tb_swz = env_int("MIFLOW_TB_SWZ", 1);
         t.tb_ppl = t.tb_wps = t.tb_pf = -1;
         if (const char *v = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(v, "%d,%d,%d", &t.tb_ppl, &t.tb_wps, &t.tb_pf);

@@ -245,7 +245,7 @@ int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
     const int tile = warp_tile();
-    const int np = tuning().warp_np;   // patches per wave (MIFLOW_WARP_NP = 1 | 2 | 4, default 4)
+    const int np = tuning().warp_np;   // patches per wave (MIFLOW_WARP_NP = 1 | 2 | 4, default 2)
     const dim3 grid(div_up(g.w, tile * np), div_up(g.h, 4 * (64 / tile)), g.batch);
 #define LAUNCH_W6N(SEM, NP)                                                                                              \
     do {                                                                                                                 \
@@ -255,7 +255,7 @@ int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[
     } while (0)
 #define LAUNCH_W6(SEM)                                                                                                   \
     do {                                                                                                                 \
-        if (np == 1) LAUNCH_W6N(SEM, 1); else if (np == 2) LAUNCH_W6N(SEM, 2); else LAUNCH_W6N(SEM, 4);                  \
+        if (np == 1) LAUNCH_W6N(SEM, 1); else if (np == 4) LAUNCH_W6N(SEM, 4); else LAUNCH_W6N(SEM, 2);                    \
     } while (0)
     if (semantics == MI_SEM_CPU_REF) LAUNCH_W6(MI_SEM_CPU_REF);
     else LAUNCH_W6(MI_SEM_CUDA_COMPAT);

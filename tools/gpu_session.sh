@@ -42,7 +42,8 @@ pmc)
     timeout 400 rocprofv3 --kernel-trace --pmc $c -f csv -d $R/$O/pmc_$c -- python $R/bench.py --no-variants --no-cpu --no-secondary --steps 2 --warmup 1 > $R/$O/pmc_$c.log 2>&1
   done
   cd $R
-  python tools/pmc_summary.py $O > $O/pmc_summary.md 2>&1; head -40 $O/pmc_summary.md
+  python tools/pmc_summary.py $O > $O/pmc_summary.md 2>&1; head -30 $O/pmc_summary.md
+  python tools/pmc_to_traffic.py $O "profiles/$NAME/pmc_summary.md" > $O/pmc_traffic.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; tail -40 $O/pmc_traffic.log
   find $O -type f -size +4M -delete ;;
 trace_defaults)
   cd /tmp
