@@ -52,10 +52,10 @@ def algo_bytes_per_pair(w, h, warps, iters_per_warp, nscales=5, step=0.8):
     return float(sum(p * (12 + warps * (44 + 64 * iters_per_warp)) for p in level_pixels(w, h, nscales, step)))
 
 
-def make_inputs(n, h, w, dev, distinct=4):
+def make_inputs(n, h, w, dev, distinct=4, **kw):
     import torch
     from opencv_contrib_amd import synth
-    base = [synth.flow_pair(h, w, seed=1234 + i) for i in range(min(n, distinct))]
+    base = [synth.flow_pair(h, w, seed=1234 + i, **kw) for i in range(min(n, distinct))]
     I0 = torch.stack([torch.from_numpy(base[i % len(base)][0]) for i in range(n)]).to(dev)
     I1 = torch.stack([torch.from_numpy(base[i % len(base)][1]) for i in range(n)]).to(dev)
     return I0, I1, base
@@ -221,6 +221,26 @@ def bench_farneback(args):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     f = flow.cpu().numpy()
+    # batched-frames mode: nb distinct-buffer copies of the pair per mi_farneback_calc_batch (blockIdx.z = pair in every kernel):
+    # a 640 x 480 pair alone is ~70 launches of 5-50 us, the batch shares them
+    batched = None
+    try:
+        nb = 32
+        b0, b1 = [t0_.clone() for _ in range(nb)], [t1_.clone() for _ in range(nb)]
+        bflows = torch.empty((nb, H, W, 2), dtype=torch.float32, device=dev)
+        balg = cuda.FarnebackOpticalFlow.create()
+        balg.calc_batch(b0, b1, bflows)
+        torch.cuda.synchronize()
+        reps = max(2, args.steps)
+        tb = time.perf_counter()
+        for _ in range(reps):
+            balg.calc_batch(b0, b1, bflows)
+        torch.cuda.synchronize()
+        batched = {"pairs_per_s": nb * reps / (time.perf_counter() - tb), "batch": nb,
+                   "equals_single_calc": bool(torch.equal(bflows[nb - 1], flow))}
+        del b0, b1, bflows, balg
+    except Exception as e:
+        batched = {"error": repr(e)[:200]}
     # algorithmic bytes of the fused formulation: per level 2x polyexp 24 + updateMatrices 68 + iters*(M 20 + R0 20 + R1 20 + flow 8 + M' 20)
     px = 0
     w_, h_ = W, H
@@ -239,9 +259,14 @@ def bench_farneback(args):
            "config": {"workload": f"FarnebackOpticalFlow {W}x{H} CV_8UC1, numLevels 5, pyrScale .5, winSize 13, numIters 10, polyN 5 "
                                   f"(BASELINE configs[0]), {n} sequential calc()/step"},
            "epe_vs_analytic_flow_px": float(synth.epe(f[40:-40, 40:-40], gt[40:-40, 40:-40])),
+           "batched_calc_batch": batched,
            "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo * args.steps * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "single small pair: launch-latency bound (about 70 launches of 5-50 us); bytes = fused-iteration accounting"}}
+                        "note": "sequential calc() of ONE small pair: launch-latency bound (about 70 launches of 5-50 us); bytes = "
+                                "fused-iteration accounting"}}
+    if batched and "pairs_per_s" in batched:
+        out["roofline"]["batched_achieved"] = algo * batched["pairs_per_s"] / 1e9
+        out["roofline"]["batched_frac"] = algo * batched["pairs_per_s"] / 1e9 / HBM_PEAK_GBS
     # four independent objects on four streams (distinct handles share nothing: the reference's constant-memory race does not exist
     # here): a 640 x 480 pair alone cannot fill 256 CUs, concurrent pairs can
     try:
@@ -590,7 +615,18 @@ def main():
         vrun("class_defaults_300_eps0.01", 300, 0.01)                      # speculative blocks, device-decided stop
         vrun("iterations10_eps0_exact_math", 10, 0.0, exactMath=True)
         vrun("iterations10_eps0_cuda_compat_semantics", 10, 0.0, semantics=1)
-        vrun("iterations10_eps0_one_lane", 10, 0.0, lanes=1)
+        # one lane: the whole batch on the caller's stream -- the two dominant kernels timed WITHOUT the other half batch's kernels
+        # sharing the GPU (what `roofline` above cannot separate)
+        try:
+            e1, (p_it, p_w), _, _ = run(args.iterations, args.epsilon, hs, 1, profile=True, lanes=1)
+            var["iterations10_eps0_one_lane"] = {"pairs_per_s": B * hs / e1, "iterate_avg_launch_us": 1e3 * p_it[0] / max(p_it[1], 1),
+                                                 "warp_avg_launch_us": 1e3 * p_w[0] / max(p_w[1], 1)}
+            if blocked and args.epsilon == 0 and p_it[0] > 0:
+                ach1 = px_iter_timed / (p_it[0] * 1e-3) * slots * lanes_per_px / 1e12
+                var["iterations10_eps0_one_lane"]["iterate_valu_issue_frac"] = ach1 / VALU_PEAK_TLIPS
+                var["iterations10_eps0_one_lane"]["iterate_pixel_iterations_per_s"] = px_iter_timed / (p_it[0] * 1e-3)
+        except Exception as e:
+            var["iterations10_eps0_one_lane"] = {"error": repr(e)[:200]}
         # SURVEY 8d config 2 "also run CV_8UC1": the same batch as 8-bit frames (the class converts them to f32 once per calc)
         try:
             J0, J1 = (I0 * 255).round().clamp(0, 255).to(torch.uint8), (I1 * 255).round().clamp(0, 255).to(torch.uint8)
@@ -615,7 +651,8 @@ def main():
             var["single_pair_calc_sequential"] = {"error": repr(e)[:200]}
         # north_star "1080p/4K pairs": the same object on 3840x2160 pairs (4 pairs per step = the pixels of 16 1080p pairs)
         try:
-            K0, K1, base4k = make_inputs(4, 2160, 3840, dev, distinct=1)
+            # same motion in pixels as the 1080p pairs (flow_scale 3, texture sigma 6): five 0.8-scales cover it at either size
+            K0, K1, base4k = make_inputs(4, 2160, 3840, dev, distinct=1, flow_scale=3.0, sigma=6.0)
             F4 = torch.empty((4, 2160, 3840, 2), dtype=torch.float32, device=dev)
             e4, _, _, _ = run(args.iterations, args.epsilon, hs, 1, inputs=(K0, K1), out=F4)
             ab4 = algo_bytes_per_pair(3840, 2160, warps, args.iterations)

@@ -187,6 +187,8 @@ MI_API int mi_stereobm_get_params(const mi_stereobm *h, mi_stereobm_params *p);
 /* Replaces: StereoBMImpl::compute, cudastereo/src/stereobm.cpp:134-191.  left,right: MI_8UC1, same size;
  * disp: MI_8UC1 of the same size (allocated by the caller / the C++ shim's OutputArray::create). */
 MI_API int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right, mi_mat *disp, void *stream);
+/* n pairs through one handle, back to back on the stream (a 1080p pair already fills the device: a loop, not a fused launch). */
+MI_API int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const mi_mat *rights, mi_mat *disps, void *stream);
 MI_API void mi_stereobm_destroy(mi_stereobm *h);
 
 /* Stage-level entry points == cv::cuda::device::stereobm:: functions (cudastereo/src/stereobm.cpp:54-63).
@@ -226,6 +228,8 @@ MI_API int mi_farneback_get_params(const mi_farneback *h, mi_farneback_params *p
  * I0,I1: MI_8UC1 or MI_32FC1 (convertTo(CV_32F), no scaling), same size/type; flow: MI_32FC2 of the frame size,
  * read as the initial flow when MI_OPTFLOW_USE_INITIAL_FLOW.  One stream, no host synchronisation. */
 MI_API int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream);
+/* n independent pairs of identical size and type in one pass (blockIdx.z = pair in every kernel of the level loop). */
+MI_API int mi_farneback_calc_batch(mi_farneback *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream);
 MI_API void mi_farneback_destroy(mi_farneback *h);
 
 /* Stage-level entry points == cv::cuda::device::optflow_farneback:: functions (cudaoptflow/src/farneback.cpp:60-92);
@@ -276,6 +280,8 @@ MI_API int mi_surf_max_features(const mi_surf *h, int rows, int cols, int *max_f
  * >= max_features columns.  Features come out in a deterministic order (octave, layer, row, column).
  * Synchronises `stream` once to return the count (the reference's keypoints.cols = featureCounter). */
 MI_API int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, int *n_features, void *stream);
+/* n frames through one handle; masks may be NULL.  keypoints[i] / n_features[i] as mi_surf_detect. */
+MI_API int mi_surf_detect_batch(mi_surf *h, int n, const mi_mat *imgs, const mi_mat *masks, mi_mat *keypoints, int *n_features, void *stream);
 /* Replaces: SURF_CUDA_Invoker::findOrientation for provided keypoints, surf.cuda.cpp:217-225,391-393 */
 MI_API int mi_surf_compute_orientation(mi_surf *h, const mi_mat *img, mi_mat *keypoints, int n_features, void *stream);
 /* Replaces: SURF_CUDA_Invoker::computeDescriptors, surf.cuda.cpp:227-236 (+ normalize_descriptors).

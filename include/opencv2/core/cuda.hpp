@@ -14,6 +14,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <vector>
 #include "miflow/c_api.h"
 
 #ifndef MIFLOW_WITH_OPENCV

@@ -162,6 +162,20 @@ public:
         mi_mat a = miMat(I0), b = miMat(I1), f = miMat(flow);
         miCheck(mi_farneback_calc(h_, &a, &b, &f, stream.hipStream()));
     }
+    // Batched-frames mode (miflow extension; reached through cv::cuda::miflow::calcBatch)
+    void calcBatch(const std::vector<GpuMat> &I0s, const std::vector<GpuMat> &I1s, std::vector<GpuMat> &flows, Stream &stream)
+    {
+        CV_Assert(!I0s.empty() && I0s.size() == I1s.size());
+        const bool init = (p_.flags & MI_OPTFLOW_USE_INITIAL_FLOW) != 0;
+        if (!init) flows.resize(I0s.size());
+        CV_Assert(flows.size() == I0s.size());
+        std::vector<mi_mat> a(I0s.size()), b(I0s.size()), f(I0s.size());
+        for (size_t i = 0; i < I0s.size(); ++i) {
+            if (!init) flows[i].create(I0s[i].size(), CV_32FC2);
+            a[i] = miMat(I0s[i]); b[i] = miMat(I1s[i]); f[i] = miMat(flows[i]);
+        }
+        miCheck(mi_farneback_calc_batch(h_, (int)a.size(), a.data(), b.data(), f.data(), stream.hipStream()));
+    }
     String getDefaultName() const override { return "DenseOpticalFlow.FarnebackOpticalFlow"; }   // farneback.cpp:132
 #define MIFLOW_PROP(T, Name, field) \
     T get##Name() const override { return (T)p_.field; } \
@@ -187,6 +201,17 @@ inline Ptr<FarnebackOpticalFlow> FarnebackOpticalFlow::create(int numLevels, dou
     p.num_iters = numIters; p.poly_n = polyN; p.poly_sigma = polySigma; p.flags = flags;
     return makePtr<miflow_detail::FarnebackImpl>(p);
 }
+
+namespace miflow {
+/** n independent pairs in one pass through a FarnebackOpticalFlow object (blockIdx.z = pair in every kernel of the level loop). */
+inline void calcBatch(const Ptr<FarnebackOpticalFlow> &alg, const std::vector<GpuMat> &I0s, const std::vector<GpuMat> &I1s,
+                      std::vector<GpuMat> &flows, Stream &stream = Stream::Null())
+{
+    auto *impl = dynamic_cast<miflow_detail::FarnebackImpl *>(alg.get());
+    CV_Assert(impl);
+    impl->calcBatch(I0s, I1s, flows, stream);
+}
+}  // namespace miflow
 
 /** cudaoptflow.hpp: class DensePyrLKOpticalFlow; implementation twin of DensePyrLKOpticalFlowImpl, cudaoptflow/src/pyrlk.cpp:354-406 */
 class DensePyrLKOpticalFlow : public DenseOpticalFlow {

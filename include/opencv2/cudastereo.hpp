@@ -60,6 +60,18 @@ public:
         mi_mat l = miMat(left), r = miMat(right), d = miMat(disparity);
         miCheck(mi_stereobm_compute(h_, &l, &r, &d, stream.hipStream()));
     }
+    // n pairs through this object (miflow extension; reached through cv::cuda::miflow::computeBatch)
+    void computeBatch(const std::vector<GpuMat> &lefts, const std::vector<GpuMat> &rights, std::vector<GpuMat> &disps, Stream &stream)
+    {
+        CV_Assert(!lefts.empty() && lefts.size() == rights.size());
+        disps.resize(lefts.size());
+        std::vector<mi_mat> l(lefts.size()), r(lefts.size()), d(lefts.size());
+        for (size_t i = 0; i < lefts.size(); ++i) {
+            disps[i].create(lefts[i].size(), CV_8UC1);
+            l[i] = miMat(lefts[i]); r[i] = miMat(rights[i]); d[i] = miMat(disps[i]);
+        }
+        miCheck(mi_stereobm_compute_batch(h_, (int)l.size(), l.data(), r.data(), d.data(), stream.hipStream()));
+    }
     int getMinDisparity() const override { return 0; }           void setMinDisparity(int) override {}
     int getNumDisparities() const override { return p_.num_disparities; }
     void setNumDisparities(int v) override { p_.num_disparities = v; push(); }
@@ -89,6 +101,17 @@ inline Ptr<cuda::StereoBM> createStereoBM(int numDisparities = 64, int blockSize
 {
     return makePtr<miflow_detail::StereoBMImpl>(numDisparities, blockSize);
 }
+
+namespace miflow {
+/** n stereo pairs through one StereoBM object, back to back on the stream (miflow extension). */
+inline void computeBatch(const Ptr<cuda::StereoBM> &bm, const std::vector<GpuMat> &lefts, const std::vector<GpuMat> &rights,
+                         std::vector<GpuMat> &disps, Stream &stream = Stream::Null())
+{
+    auto *impl = dynamic_cast<miflow_detail::StereoBMImpl *>(bm.get());
+    CV_Assert(impl);
+    impl->computeBatch(lefts, rights, disps, stream);
+}
+}  // namespace miflow
 
 /** cudastereo.hpp: class StereoSGM (cv::StereoSGBM interface subset used by the CUDA class, cudastereo/src/stereosgm.cpp:20-80) */
 class CV_EXPORTS_W StereoSGM : public cv::StereoMatcher {

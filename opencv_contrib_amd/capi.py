@@ -128,6 +128,7 @@ def lib():
         "mi_stereobm_set_params": (i, [vp, C.POINTER(StereoBMParams)]),
         "mi_stereobm_get_params": (i, [vp, C.POINTER(StereoBMParams)]),
         "mi_stereobm_compute": (i, [vp, PM, PM, PM, vp]),
+        "mi_stereobm_compute_batch": (i, [vp, i, PM, PM, PM, vp]),
         "mi_stereobm_destroy": (None, [vp]),
         "mi_stereobm_prefilter_xsobel": (i, [PM, PM, i, vp]),
         "mi_stereobm_prefilter_norm": (i, [PM, PM, i, i, vp]),
@@ -140,6 +141,7 @@ def lib():
         "mi_farneback_set_params": (i, [vp, C.POINTER(FarnebackParams)]),
         "mi_farneback_get_params": (i, [vp, C.POINTER(FarnebackParams)]),
         "mi_farneback_calc": (i, [vp, PM, PM, PM, vp]),
+        "mi_farneback_calc_batch": (i, [vp, i, PM, PM, PM, vp]),
         "mi_farneback_destroy": (None, [vp]),
         "mi_farneback_poly_exp": (i, [PM, PM, i, d, vp]),
         "mi_farneback_update_matrices": (i, [PM, PM, PM, PM, PM, vp]),
@@ -155,6 +157,7 @@ def lib():
         "mi_surf_descriptor_size": (i, [vp]),
         "mi_surf_max_features": (i, [vp, i, i, C.POINTER(i)]),
         "mi_surf_detect": (i, [vp, PM, PM, PM, C.POINTER(i), vp]),
+        "mi_surf_detect_batch": (i, [vp, i, PM, PM, PM, C.POINTER(i), vp]),
         "mi_surf_compute_orientation": (i, [vp, PM, PM, i, vp]),
         "mi_surf_compute_descriptors": (i, [vp, PM, PM, i, PM, vp]),
         "mi_surf_release_memory": (None, [vp]),

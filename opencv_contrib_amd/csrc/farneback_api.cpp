@@ -78,15 +78,15 @@ int prepare_gaussian(int n, double sigma, PolyC *C)
 
 struct mi_farneback {
     mi_farneback_params P;
-    float *arena = nullptr;
-    int capW = 0, capH = 0;
+    float *arena = nullptr;     // capB per-pair blocks of `bs` floats: every plane of pair b lives at (plane of pair 0) + b * bs
+    int capW = 0, capH = 0, capB = 0;
+    long long bs = 0;
     // full-size-capacity planes
     float *frames[2] = {}, *blurred = nullptr, *lvl[2] = {}, *R[2] = {}, *M = nullptr, *bufM = nullptr;
     float *flow[3][2] = {};   // [slot][x,y]: slot 0 = level 0 (and the initial flow), slots 1,2 alternate over the coarse levels
     std::vector<float *> pyr[2];
     std::vector<Plane> pyrg;
-    size_t pyr_floats = 0;
-    float *pyr_arena = nullptr;
+    float *pyr_base = nullptr;  // fast-pyramid levels of pair 0 (inside the pair block)
 };
 
 static int cv_round(double v) { return (int)std::lrint(v); }
@@ -148,36 +148,40 @@ void mi_farneback_destroy(mi_farneback *h)
 {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
-    if (h->pyr_arena) (void)hipFree(h->pyr_arena);
     delete h;
 }
 
-static int ensure(mi_farneback *h, int W, int H)
+static int ensure(mi_farneback *h, int W, int H, int B)
 {
-    if (h->arena && h->capW == W && h->capH == H) return MI_OK;
+    if (h->arena && h->capW == W && h->capH == H && h->capB >= B) return MI_OK;
     if (h->arena) (void)hipFree(h->arena);
     h->arena = nullptr;
     const Plane g = plane_of(W, H);
     const size_t n = (size_t)g.ld * H;
-    // frames 2, blurred 1, lvl 2, R 2x5, M 5, bufM 5, flows 6  = 31 planes
-    MI_HIP_TRY(hipMalloc((void **)&h->arena, sizeof(float) * n * 31));
+    // per pair: frames 2, blurred 1, lvl 2, R 2x5, M 5, bufM 5, flows 6 = 31 planes, + the fast-pyramid levels of both frames
+    // (sum over the half-size levels < 2/3 of a plane per frame: 2 planes reserved)
+    const size_t per_pair = n * 33;
+    MI_HIP_TRY(hipMalloc((void **)&h->arena, sizeof(float) * per_pair * (size_t)B));
     float *p = h->arena;
     auto take = [&](size_t k) { float *q = p; p += n * k; return q; };
     h->frames[0] = take(1); h->frames[1] = take(1); h->blurred = take(1); h->lvl[0] = take(1); h->lvl[1] = take(1);
     h->R[0] = take(5); h->R[1] = take(5); h->M = take(5); h->bufM = take(5);
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) h->flow[a][b] = take(1);
-    h->capW = W; h->capH = H;
+    h->pyr_base = take(2);
+    h->bs = (long long)per_pair;
+    h->capW = W; h->capH = H; h->capB = B;
     return MI_OK;
 }
 
-static void geo_tvl1(const Plane &p, mi::tvl1::Geo &g) { g.w = p.w; g.h = p.h; g.ld = p.ld; g.ps = (long long)p.ld * p.h; g.batch = 1; }
+static void geo_tvl1(const Plane &p, mi::tvl1::Geo &g) { g.w = p.w; g.h = p.h; g.ld = p.ld; g.ps = p.batch > 1 ? p.bs : (long long)p.ld * p.h; g.batch = p.batch; }
 
 // cuda::resize(src -> dst, Size(dw,dh), INTER_LINEAR) followed by convertTo(*alpha) on up to 2 planes
 static int resize2(const float *s0, const float *s1, const Plane &gs, float *d0, float *d1, const Plane &gd, float alpha, hipStream_t st)
 {
     if (gs.w == gd.w && gs.h == gd.h && alpha == 1.f) {   // dsize == src.size(): copy (cudawarping/src/resize.cpp:89-93)
-        MI_HIP_TRY(hipMemcpyAsync(d0, s0, sizeof(float) * (size_t)gs.ld * gs.h, hipMemcpyDeviceToDevice, st));
-        if (s1) MI_HIP_TRY(hipMemcpyAsync(d1, s1, sizeof(float) * (size_t)gs.ld * gs.h, hipMemcpyDeviceToDevice, st));
+        const size_t bytes = sizeof(float) * (size_t)gs.ld * gs.h, pitch = sizeof(float) * (size_t)(gs.batch > 1 ? gs.bs : (long long)gs.ld * gs.h);
+        MI_HIP_TRY(hipMemcpy2DAsync(d0, pitch, s0, pitch, bytes, (size_t)gs.batch, hipMemcpyDeviceToDevice, st));
+        if (s1) MI_HIP_TRY(hipMemcpy2DAsync(d1, pitch, s1, pitch, bytes, (size_t)gs.batch, hipMemcpyDeviceToDevice, st));
         return MI_OK;
     }
     mi::tvl1::Geo a, b;
@@ -188,13 +192,8 @@ static int resize2(const float *s0, const float *s1, const Plane &gs, float *d0,
     return mi::tvl1::resize(MI_SEM_CUDA_COMPAT, s1 ? 2 : 1, src, 1, dst, a, b, (double)gd.w / gs.w, (double)gd.h / gs.h, post, nullptr, 0, st);
 }
 
-int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream)
+static int check_pair(const mi_mat *I0, const mi_mat *I1, const mi_mat *flow, const mi_mat *ref)
 {
-    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
-    hipStream_t st = (hipStream_t)stream;
-    const mi_farneback_params &P = h->P;
-    int rc = validate(&P);
-    if (rc) return rc;
     MI_REQUIRE(I0 && I1 && flow && I0->data && I1->data && flow->data, MI_ERR_BAD_ARG, "null matrix");
     // CV_Assert(frame0.channels() == 1 && frame1.channels() == 1)  farneback.cpp:173; depths supported here: 8U, 32F
     MI_REQUIRE((I0->type == MI_8UC1 || I0->type == MI_32FC1) && I1->type == I0->type, MI_ERR_BAD_TYPE, "frames must be CV_8UC1 or CV_32FC1, same type");
@@ -202,17 +201,37 @@ int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_ma
     MI_REQUIRE(flow->type == MI_32FC2 && flow->rows == I0->rows && flow->cols == I0->cols, MI_ERR_BAD_SIZE, "flow must be CV_32FC2 of the frame size");  // :181-182
     MI_REQUIRE(flow->step % 8 == 0 && ((uintptr_t)flow->data % 8) == 0, MI_ERR_BAD_ARG, "flow must be 8-byte aligned");
     if (I0->type == MI_32FC1) MI_REQUIRE(I0->step % 4 == 0 && I1->step % 4 == 0, MI_ERR_BAD_ARG, "float frames must be 4-byte aligned");
-    const int W = I0->cols, H = I0->rows;
+    MI_REQUIRE(I0->rows == ref->rows && I0->cols == ref->cols && I0->type == ref->type, MI_ERR_BAD_SIZE, "all pairs of a batch must share size and type");
+    return MI_OK;
+}
+
+// n independent pairs per launch sequence: blockIdx.z = pair in every kernel of the level loop (a 640 x 480 pair alone is about
+// 70 launches of 5-50 us, i.e. launch-latency bound; batched, the same 70 launches carry n pairs).
+int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    MI_REQUIRE(nb > 0 && I0s && I1s && flows, MI_ERR_BAD_ARG, "empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    const mi_farneback_params &P = h->P;
+    int rc = validate(&P);
+    if (rc) return rc;
+    for (int i = 0; i < nb; ++i) if ((rc = check_pair(&I0s[i], &I1s[i], &flows[i], &I0s[0]))) return rc;
+    const int W = I0s[0].cols, H = I0s[0].rows, B = nb;
     MI_REQUIRE(W >= 2 && H >= 2, MI_ERR_BAD_SIZE, "frames too small");
-    if ((rc = ensure(h, W, H))) return rc;
-    const Plane g0 = plane_of(W, H);
+    if ((rc = ensure(h, W, H, B))) return rc;
+    const long long bs = h->bs;
+    const Plane g0 = plane_of(W, H, bs, B);
+    const Plane g0s = plane_of(W, H);   // single-pair view for the per-pair conversion kernels
     const bool use_init = (P.flags & MI_OPTFLOW_USE_INITIAL_FLOW) != 0;
     const bool gauss = (P.flags & MI_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
 
-    if ((rc = convert(I0->data, (long long)I0->step, I1->data, (long long)I1->step, I0->type, h->frames[0], h->frames[1], g0, st))) return rc;
     // flowx0/flowy0 (level-0 flow planes; also the caller's initial flow)
     float *fx0 = h->flow[0][0], *fy0 = h->flow[0][1];
-    if (use_init && (rc = split_flow(flow->data, (long long)flow->step, fx0, fy0, g0, st))) return rc;
+    for (int b = 0; b < B; ++b) {
+        if ((rc = convert(I0s[b].data, (long long)I0s[b].step, I1s[b].data, (long long)I1s[b].step, I0s[b].type, h->frames[0] + b * bs,
+                          h->frames[1] + b * bs, g0s, st))) return rc;
+        if (use_init && (rc = split_flow(flows[b].data, (long long)flows[b].step, fx0 + b * bs, fy0 + b * bs, g0s, st))) return rc;
+    }
 
     // crop unnecessary levels, farneback.cpp:330-340
     double scale = 1;
@@ -224,20 +243,13 @@ int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_ma
     if (P.fast_pyramids) {   // :346-359
         std::vector<Plane> pg(levels + 1);
         pg[0] = g0;
-        size_t total = 0;
-        for (int i = 1; i <= levels; ++i) { pg[i] = plane_of((pg[i - 1].w + 1) / 2, (pg[i - 1].h + 1) / 2); total += (size_t)pg[i].ld * pg[i].h; }
-        if (h->pyr_floats < 2 * total) {
-            if (h->pyr_arena) (void)hipFree(h->pyr_arena);
-            h->pyr_arena = nullptr;
-            MI_HIP_TRY(hipMalloc((void **)&h->pyr_arena, sizeof(float) * (2 * total + 64)));
-            h->pyr_floats = 2 * total;
-        }
+        for (int i = 1; i <= levels; ++i) pg[i] = plane_of((pg[i - 1].w + 1) / 2, (pg[i - 1].h + 1) / 2, bs, B);
         h->pyrg = pg;
         for (int f = 0; f < 2; ++f) {
             h->pyr[f].assign(levels + 1, nullptr);
             h->pyr[f][0] = h->frames[f];
         }
-        float *p = h->pyr_arena;
+        float *p = h->pyr_base;
         for (int i = 1; i <= levels; ++i)
             for (int f = 0; f < 2; ++f) {
                 h->pyr[f][i] = p; p += (size_t)pg[i].ld * pg[i].h;
@@ -265,7 +277,7 @@ int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_ma
         int width = cv_round(W * scale), height = cv_round(H * scale);
         if (P.fast_pyramids) { width = h->pyrg[k].w; height = h->pyrg[k].h; }
         MI_REQUIRE(smoothSize / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "pyramid smoothing kernel too large (MAX_KSIZE_HALF)");
-        const Plane g = plane_of(width, height);
+        const Plane g = plane_of(width, height, bs, B);
         float *curx, *cury;
         if (k > 0) { curx = h->flow[1 + (k & 1)][0]; cury = h->flow[1 + (k & 1)][1]; }
         else { curx = fx0; cury = fy0; }
@@ -273,8 +285,9 @@ int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_ma
             if (use_init) {   // :398-404
                 if (k > 0 && (rc = resize2(fx0, fy0, g0, curx, cury, g, (float)scale, st))) return rc;
             } else {
-                MI_HIP_TRY(hipMemsetAsync(curx, 0, sizeof(float) * (size_t)g.ld * g.h, st));
-                MI_HIP_TRY(hipMemsetAsync(cury, 0, sizeof(float) * (size_t)g.ld * g.h, st));
+                const size_t bytes = sizeof(float) * (size_t)g.ld * g.h;
+                MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
+                MI_HIP_TRY(hipMemset2DAsync(cury, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
             }
         } else {              // :412-417
             if ((rc = resize2(prevx, prevy, gprev, curx, cury, g, (float)(1. / P.pyr_scale), st))) return rc;
@@ -306,7 +319,14 @@ int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_ma
         }
         prevx = curx; prevy = cury; gprev = g;
     }
-    return merge_flow(fx0, fy0, flow->data, (long long)flow->step, g0, st);   // cuda::merge :197-198
+    for (int b = 0; b < B; ++b)
+        if ((rc = merge_flow(fx0 + b * bs, fy0 + b * bs, flows[b].data, (long long)flows[b].step, g0s, st))) return rc;   // cuda::merge :197-198
+    return MI_OK;
+}
+
+int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream)
+{
+    return mi_farneback_calc_batch(h, 1, I0, I1, flow, stream);
 }
 
 }  // extern "C"

@@ -8,11 +8,15 @@ enum { MI_BORDER_REPLICATE = 1, MI_BORDER_REFLECT101 = 4 };   /* cv::BorderTypes
 namespace mi {
 namespace fb {
 
-struct Plane { int w, h, ld; };                 // dense f32 plane(s), ld floats per row
+struct Plane {                                  // dense f32 plane(s), ld floats per row
+    int w, h, ld;
+    long long bs;   // floats between the same plane of consecutive pairs of a batch (blockIdx.z = pair); 0 for a single pair
+    int batch;
+};
 struct Taps { float k[MI_FB_MAX_KSIZE_HALF + 1]; };   // centre + positive half of a symmetric kernel (by value)
 struct PolyC { float g[8], xg[8], xxg[8]; float ig11, ig03, ig33, ig55; };
 
-inline Plane plane_of(int w, int h) { Plane p; p.w = w; p.h = h; p.ld = align_up(w, 64); return p; }
+inline Plane plane_of(int w, int h, long long bs = 0, int batch = 1) { Plane p; p.w = w; p.h = h; p.ld = align_up(w, 64); p.bs = bs; p.batch = batch; return p; }
 
 int convert(const void *a, long long sa, const void *b, long long sb, int type, float *A, float *B, const Plane &g, hipStream_t s);
 int split_flow(const void *flow, long long sf, float *fx, float *fy, const Plane &g, hipStream_t s);

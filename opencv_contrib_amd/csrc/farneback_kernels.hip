@@ -70,9 +70,10 @@ __global__ __launch_bounds__(256) void k_merge_flow(const float *fx, const float
 // ------------------------------------------------------------------ single-plane Gaussian blur
 // farneback.cu:455-492.  One block = one row segment of 256 columns.
 template <int BORDER>
-__global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *dst, int w, int h, int ld, int kh, Taps K)
+__global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *dst, int w, int h, int ld, int kh, Taps K, long long bs)
 {
     extern __shared__ float row[];
+    src += (long long)blockIdx.z * bs; dst += (long long)blockIdx.z * bs;   // pair of the batch
     const int tx = threadIdx.x, y = blockIdx.y, x = blockIdx.x * 256 + tx;
     for (int i = tx; i < 256 + 2 * kh; i += 256) {
         const int xe = bidx<BORDER>((int)(blockIdx.x * 256) + i - kh, w);
@@ -93,9 +94,10 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *
 // ------------------------------------------------------------------ polynomial expansion
 // farneback.cu:66-119: vertical pass (g, xg, xxg) into 3 LDS rows, horizontal pass -> 5 coefficient planes.
 template <int N>
-__global__ __launch_bounds__(256) void k_poly_exp(const float *src, float *dst, int w, int h, int ld, PolyC C)
+__global__ __launch_bounds__(256) void k_poly_exp(const float *src, float *dst, int w, int h, int ld, PolyC C, long long bs)
 {
     __shared__ float smem[3 * 256];
+    src += (long long)blockIdx.z * bs; dst += (long long)blockIdx.z * bs;
     const int tx = threadIdx.x, y = blockIdx.y;
     const int x = blockIdx.x * (256 - 2 * N) + tx - N;
     float *row = smem + tx;
@@ -181,13 +183,14 @@ __device__ __forceinline__ void update_matrices_px(int x, int y, int w, int h, i
 }
 
 __global__ __launch_bounds__(256) void k_update_matrices(const float *flowx, const float *flowy, const float *R0, const float *R1,
-                                                         float *M, int w, int h, int ld)
+                                                         float *M, int w, int h, int ld, long long bs)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    const long long po = (long long)blockIdx.z * bs;
     const long long o = (long long)y * ld + x;
-    update_matrices_px(x, y, w, h, ld, flowx[o], flowy[o], R0, R1, M);
+    update_matrices_px(x, y, w, h, ld, flowx[po + o], flowy[po + o], R0 + po, R1 + po, M + po);
 }
 
 // ------------------------------------------------------------------ fused inner iteration
@@ -195,9 +198,13 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *flowx, con
 // and, when `update`, updateMatrices (:156-241) into Mout (a different buffer: other blocks still read M).
 template <bool GAUSS>
 __global__ __launch_bounds__(256) void k_iterate(const float *M, const float *R0, const float *R1, float *flowx, float *flowy,
-                                                 float *Mout, int w, int h, int ld, int kh, float boxAreaInv, int update, Taps K)
+                                                 float *Mout, int w, int h, int ld, int kh, float boxAreaInv, int update, Taps K, long long bs)
 {
     extern __shared__ float smem[];
+    {
+        const long long po = (long long)blockIdx.z * bs;
+        M += po; R0 += po; R1 += po; flowx += po; flowy += po; Mout += po;
+    }
     const int tx = threadIdx.x, y = blockIdx.y, x = blockIdx.x * 256 + tx;
     const int smw = 256 + 2 * kh;
     const long long ps = (long long)ld * h;
@@ -280,8 +287,9 @@ __global__ __launch_bounds__(256) void k_update_flow(const float *M, float *flow
 
 // ------------------------------------------------------------------ pyrDown (fastPyramids)
 // cudawarping/src/cuda/pyr_down.cu:54-175, BrdReflect101, CV_32FC1
-__global__ __launch_bounds__(256) void k_pyr_down(const float *src, int sw, int sh, int sld, float *dst, int dw, int dh, int dld)
+__global__ __launch_bounds__(256) void k_pyr_down(const float *src, int sw, int sh, int sld, float *dst, int dw, int dh, int dld, long long bs)
 {
+    src += (long long)blockIdx.z * bs; dst += (long long)blockIdx.z * bs;
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= dw || y >= dh) return;
@@ -332,12 +340,12 @@ int merge_flow(const float *fx, const float *fy, void *flow, long long sf, const
 int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Taps &K, int border, hipStream_t s)
 {
     MI_REQUIRE(kh >= 0 && kh <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "Gaussian kernel half size out of range");
-    const dim3 grid(div_up(g.w, 256), g.h);
+    const dim3 grid(div_up(g.w, 256), g.h, g.batch);
     const size_t lds = sizeof(float) * (256 + 2 * kh);
     if (border == MI_BORDER_REFLECT101)
-        hipLaunchKernelGGL(k_gaussian_blur<MI_BORDER_REFLECT101>, grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K);
+        hipLaunchKernelGGL(k_gaussian_blur<MI_BORDER_REFLECT101>, grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
     else if (border == MI_BORDER_REPLICATE)
-        hipLaunchKernelGGL(k_gaussian_blur<MI_BORDER_REPLICATE>, grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K);
+        hipLaunchKernelGGL(k_gaussian_blur<MI_BORDER_REPLICATE>, grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
     else { set_error("unsupported border mode %d", border); return MI_ERR_BAD_ARG; }   // farneback.cu:510-517: only these two
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -346,9 +354,9 @@ int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Ta
 int poly_exp(const float *src, float *dst5, const Plane &g, int polyN, const PolyC &C, hipStream_t s)
 {
     if (polyN == 5)
-        hipLaunchKernelGGL(k_poly_exp<5>, dim3(div_up(g.w, 256 - 10), g.h), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C);
+        hipLaunchKernelGGL(k_poly_exp<5>, dim3(div_up(g.w, 256 - 10), g.h, g.batch), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C, g.bs);
     else if (polyN == 7)
-        hipLaunchKernelGGL(k_poly_exp<7>, dim3(div_up(g.w, 256 - 14), g.h), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C);
+        hipLaunchKernelGGL(k_poly_exp<7>, dim3(div_up(g.w, 256 - 14), g.h, g.batch), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C, g.bs);
     else { set_error("polyN must be 5 or 7"); return MI_ERR_BAD_ARG; }   // CV_Assert, farneback.cpp:316
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -356,7 +364,9 @@ int poly_exp(const float *src, float *dst5, const Plane &g, int polyN, const Pol
 
 int update_matrices(const float *flowx, const float *flowy, const float *R0, const float *R1, float *M, const Plane &g, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_update_matrices, grid2d(g.w, g.h), dim3(256), 0, s, flowx, flowy, R0, R1, M, g.w, g.h, g.ld);
+    dim3 grid = grid2d(g.w, g.h);
+    grid.z = g.batch;
+    hipLaunchKernelGGL(k_update_matrices, grid, dim3(256), 0, s, flowx, flowy, R0, R1, M, g.w, g.h, g.ld, g.bs);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -366,13 +376,13 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
 {
     const int kh = ksize / 2;
     MI_REQUIRE(kh >= 0 && kh <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "winSize out of range");
-    const dim3 grid(div_up(g.w, 256), g.h);
+    const dim3 grid(div_up(g.w, 256), g.h, g.batch);
     const size_t lds = sizeof(float) * 5 * (256 + 2 * kh);
     const float inv = 1.f / ((1 + 2 * kh) * (1 + 2 * kh));
     Taps none;
     memset(&none, 0, sizeof(none));
-    if (gauss) hipLaunchKernelGGL(k_iterate<true>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, update ? 1 : 0, *gauss);
-    else hipLaunchKernelGGL(k_iterate<false>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, update ? 1 : 0, none);
+    if (gauss) hipLaunchKernelGGL(k_iterate<true>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, update ? 1 : 0, *gauss, g.bs);
+    else hipLaunchKernelGGL(k_iterate<false>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, update ? 1 : 0, none, g.bs);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -401,7 +411,9 @@ int update_flow(const float *M, float *flowx, float *flowy, const Plane &g, hipS
 
 int pyr_down(const float *src, const Plane &gs, float *dst, const Plane &gd, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pyr_down, grid2d(gd.w, gd.h), dim3(256), 0, s, src, gs.w, gs.h, gs.ld, dst, gd.w, gd.h, gd.ld);
+    dim3 grid = grid2d(gd.w, gd.h);
+    grid.z = gd.batch;
+    hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, s, src, gs.w, gs.h, gs.ld, dst, gd.w, gd.h, gd.ld, gd.bs);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

@@ -150,6 +150,20 @@ int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right,
     return rc;
 }
 
+// n stereo pairs through one handle, back to back on the stream.  One 1080p pair is already ~2 x 10^8 (pixel, disparity) cost
+// updates in a single launch (it fills the device: DESIGN.md 4.2), so the batch entry is a loop that shares the handle's scratch --
+// there is no blockIdx.z fusion to win as there is for the small Farneback frames.
+int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const mi_mat *rights, mi_mat *disps, void *stream)
+{
+    MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
+    MI_REQUIRE(n > 0 && lefts && rights && disps, MI_ERR_BAD_ARG, "empty batch");
+    for (int i = 0; i < n; ++i) {
+        const int rc = mi_stereobm_compute(h, &lefts[i], &rights[i], &disps[i], stream);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 // ---- stage-level entry points (the reference's device-layer functions, stereobm.cpp:54-63)
 int mi_stereobm_prefilter_xsobel(const mi_mat *src, mi_mat *dst, int prefilter_cap, void *stream)
 {

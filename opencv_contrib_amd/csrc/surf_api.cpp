@@ -203,6 +203,18 @@ int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *ke
     return MI_OK;
 }
 
+// n frames through one handle (masks may be NULL, or hold NULL-data entries).  A 4K frame fills the device and the feature
+// count of every frame is read back like SURF_CUDA does (surf.cuda.cpp:205-207), so this is a loop sharing the handle's scratch.
+int mi_surf_detect_batch(mi_surf *h, int n, const mi_mat *imgs, const mi_mat *masks, mi_mat *keypoints, int *n_features, void *stream)
+{
+    MI_REQUIRE(h && n > 0 && imgs && keypoints && n_features, MI_ERR_BAD_ARG, "empty batch");
+    for (int i = 0; i < n; ++i) {
+        const int rc = mi_surf_detect(h, &imgs[i], masks ? &masks[i] : nullptr, &keypoints[i], &n_features[i], stream);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 int mi_surf_compute_orientation(mi_surf *h, const mi_mat *img, mi_mat *keypoints, int n_features, void *stream)
 {
     MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");

@@ -258,6 +258,19 @@ class StereoBM:
         capi.check(capi.lib().mi_stereobm_compute(self._h, C.byref(ml), C.byref(mr), C.byref(md), sp))
         return disparity
 
+    def compute_batch(self, lefts, rights, disparities=None, stream=None):
+        """n stereo pairs through one handle (miflow extension): sequences of tensors or (N,H,W) tensors."""
+        import torch
+        n = len(lefts)
+        if disparities is None:
+            disparities = torch.empty((n, lefts[0].shape[0], lefts[0].shape[1]), dtype=torch.uint8, device=lefts[0].device)
+        AL = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in lefts])
+        AR = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in rights])
+        AD = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in disparities])
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        capi.check(capi.lib().mi_stereobm_compute_batch(self._h, n, AL, AR, AD, sp))
+        return disparities
+
 
 def createStereoBM(numDisparities=64, blockSize=19, **kw) -> StereoBM:
     """cv::cuda::createStereoBM (cudastereo.hpp:90)."""
@@ -824,6 +837,21 @@ class FarnebackOpticalFlow:
         sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
         capi.check(capi.lib().mi_farneback_calc(self._h, C.byref(m0), C.byref(m1), C.byref(mf), sp))
         return flow
+
+    def calc_batch(self, I0s, I1s, flows=None, stream=None):
+        """n independent pairs of one size and type in one pass (miflow extension; blockIdx.z = pair in every kernel)."""
+        import torch
+        n = len(I0s)
+        if flows is None:
+            if self._p.flags & OPTFLOW_USE_INITIAL_FLOW:
+                raise MiError(-1, "OPTFLOW_USE_INITIAL_FLOW requires the flows argument")
+            flows = torch.empty((n, I0s[0].shape[0], I0s[0].shape[1], 2), dtype=torch.float32, device=I0s[0].device)
+        A0 = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in I0s])
+        A1 = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in I1s])
+        AF = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in flows])
+        sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
+        capi.check(capi.lib().mi_farneback_calc_batch(self._h, n, A0, A1, AF, sp))
+        return flows
 
 
 def farneback_polyExp(src, polyN=5, polySigma=1.1):

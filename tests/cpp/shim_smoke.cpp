@@ -145,6 +145,33 @@ int main(int argc, char **argv)
         cuda::GpuMat refined;
         dbf->apply(disp, d0, refined);
         if (refined.type() != CV_8UC1 || refined.size() != disp.size()) return 9;
+        // miflow extensions (everything the reference classes do not have lives in cv::cuda::miflow): the batched-frames mode
+        // returns, for every pair, the bytes of the single call; the numerics switches are accepted
+        {
+            std::vector<cuda::GpuMat> A(3, d0), B(3, d1), F, FB, D;
+            cuda::miflow::calcBatch(tvl1, A, B, F, stream);
+            cuda::miflow::calcBatch(fb, A, B, FB, stream);
+            cuda::miflow::computeBatch(bm, A, B, D, stream);
+            stream.waitForCompletion();
+            if (F.size() != 3 || FB.size() != 3 || D.size() != 3) return 11;
+            std::vector<float> g0((size_t)h * w * 2), g1((size_t)h * w * 2);
+            flow.download(g0.data(), (size_t)w * 8);
+            F[2].download(g1.data(), (size_t)w * 8);
+            if (g0 != g1) return 11;
+            fbflow.download(g0.data(), (size_t)w * 8);
+            FB[1].download(g1.data(), (size_t)w * 8);
+            if (g0 != g1) return 11;
+            std::vector<unsigned char> e0((size_t)h * w), e1((size_t)h * w);
+            disp.download(e0.data(), (size_t)w);
+            D[0].download(e1.data(), (size_t)w);
+            if (e0 != e1) return 11;
+            Ptr<cuda::OpticalFlowDual_TVL1> t2 = cuda::OpticalFlowDual_TVL1::create(0.25, 0.15, 0.3, 3, 2, 0.0, 4);
+            cuda::miflow::setSemantics(t2, MI_SEM_CUDA_COMPAT);
+            cuda::miflow::setExactMath(t2, true);
+            cuda::GpuMat f2;
+            t2->calc(d0, d1, f2);
+            if (f2.type() != CV_32FC2) return 11;
+        }
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;
         try { cuda::GpuMat bad(h, w, CV_32FC1); bm->compute(bad, bad, disp); } catch (const cv::Exception &) { threw = true; }

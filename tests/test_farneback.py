@@ -239,3 +239,36 @@ def test_calc_argument_errors_and_determinism(gpu):
     f1 = N(alg.calc(T(I0, gpu), T(I1, gpu)))
     f2 = N(cuda.FarnebackOpticalFlow.create().calc(T(I0, gpu), T(I1, gpu)))
     np.testing.assert_array_equal(f1, f2)
+
+
+@gpu_mark
+@pytest.mark.parametrize("kw", [dict(), dict(fastPyramids=True), dict(flags=256, winSize=9), dict(flags=4)],
+                         ids=["defaults", "fast_pyramids", "gaussian", "initial_flow"])
+def test_calc_batch_equals_single_calcs(gpu, oracle, kw):
+    """mi_farneback_calc_batch (blockIdx.z = pair in every kernel of the level loop): every pair of a batch of distinct
+    pairs equals, bit for bit, the single calc() of that pair -- and with it the oracle -- for the default path, fast pyramids,
+    the Gaussian window and a caller-supplied initial flow."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(240, 320, seed=60 + k, dtype="u8")[:2] for k in range(5)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    alg, one = cuda.FarnebackOpticalFlow.create(**kw), cuda.FarnebackOpticalFlow.create(**kw)
+    flows = None
+    if kw.get("flags", 0) & 4:   # OPTFLOW_USE_INITIAL_FLOW: flows carry the initial guess in, the result out
+        rng = np.random.default_rng(3)
+        init = [torch.from_numpy((rng.standard_normal((240, 320, 2)) * 0.5).astype(np.float32)).to(gpu) for _ in range(5)]
+        flows = torch.stack(init).clone()
+        singles = [one.calc(I0s[k], I1s[k], init[k].clone()) for k in range(5)]
+    else:
+        singles = [one.calc(I0s[k], I1s[k]).clone() for k in range(5)]
+    out = alg.calc_batch(I0s, I1s, flows)
+    torch.cuda.synchronize()
+    for k in range(5):
+        assert torch.equal(out[k], singles[k]), f"pair {k}"
+    assert not torch.equal(out[0], out[1])
+    if not kw.get("flags", 0) & 4:
+        p = oracle.fb_params(fast_pyramids=int(kw.get("fastPyramids", False)), flags=kw.get("flags", 0), win_size=kw.get("winSize", 13))
+        _assert_flow_close(N(out[3]), oracle.fb_calc(pairs[3][0], pairs[3][1], p))
+    # a smaller batch through the same handle afterwards (capacity is kept), and a larger one (arena regrown)
+    again = alg.calc_batch(I0s[:2], I1s[:2], None if flows is None else torch.stack(init[:2]).clone())
+    assert torch.equal(again[1], singles[1])

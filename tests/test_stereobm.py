@@ -294,3 +294,18 @@ def test_1080p_config3_properties(gpu):
     R = 7
     assert not d1[:R].any() and not d1[-R:].any() and not d1[:, : 128 + R].any() and not d1[:, -R:].any()
     assert (d1[R:-R, 128 + R : -R - 37] == 37).all()
+
+
+@gpu_mark
+def test_compute_batch_equals_single_computes(gpu):
+    """mi_stereobm_compute_batch: n pairs through one handle, each equal to its own compute()."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.stereo_pair(120, 260, seed=70 + k, max_disp=30)[:2] for k in range(4)]
+    L, R = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    bm = cuda.createStereoBM(64, 11)
+    out = bm.compute_batch(L, R)
+    one = cuda.createStereoBM(64, 11)
+    for k in range(4):
+        assert torch.equal(out[k], one.compute(L[k], R[k]))
+    assert not torch.equal(out[0], out[1])
