@@ -52,6 +52,9 @@ trace_defaults)
   tail -1 $O/trace_defaults_bench.log | cut -c1-600
   for f in $(find $O/trace_defaults -name "*kernel_stats.csv" | head -1); do cp $f $O/kernel_stats_defaults.csv; head -12 $f; done
   find $O -type f -size +4M -delete ;;
+tests_batch)
+  (timeout 600 python -m pytest tests/test_farneback.py tests/test_stereobm.py tests/test_cpp_shim.py tests/test_tvl1_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -30) > $O/pytest_batch.log; cat $O/pytest_batch.log
+  (timeout 300 python bench.py --workload farneback --steps 3 2>$O/fb.err | tail -1) > $O/farneback_bench.json; cut -c1-1200 $O/farneback_bench.json; tail -3 $O/fb.err ;;
 test_one)
   (timeout 600 python -m pytest "tests/test_baseline_sizes.py" -m gpu -q -x -p no:cacheprovider -k "two_lanes or speculative" 2>&1 | tail -30) > $O/pytest_one.log; cat $O/pytest_one.log ;;
 esac
