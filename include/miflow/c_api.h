@@ -134,6 +134,20 @@ MI_API int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches
 MI_API int mi_tvl1_get_profile_kind(mi_tvl1 *h, int kind, double *ms_total, long long *launches, double *algo_bytes);
 MI_API void mi_tvl1_destroy(mi_tvl1 *h);
 
+/* Batched-frames mode over the GPUs of one node (BASELINE configs[4]): independent pairs are cut into contiguous shards,
+ * one per device, one host thread + handle + stream pair per device (the reference's multi-device idiom is cv::cuda::setDevice per
+ * thread, cudaoptflow/test/test_optflow.cpp:62).  device_ids[0] is the ROOT device: the caller's I0 / I1 / flow matrices live
+ * there; shards of the other devices travel peer-to-peer over xGMI (2-D copies, double buffered in chunks, overlapping the
+ * compute), no collective.  device_ids == NULL: devices 0 .. n_devices - 1; n_devices <= 0: all.  The same id may be listed more
+ * than once (several workers on one GPU).  calc_batch returns when every flow is in the caller's matrices; results are
+ * bit-identical to mi_tvl1_calc_batch. */
+typedef struct mi_tvl1_multi mi_tvl1_multi;
+MI_API int mi_tvl1_multi_create(const mi_tvl1_params *p, int n_devices, const int *device_ids, mi_tvl1_multi **out);
+MI_API int mi_tvl1_multi_device_count(const mi_tvl1_multi *m);
+MI_API int mi_tvl1_multi_set_chunk(mi_tvl1_multi *m, int pairs_per_chunk);   /* pairs staged per copy / compute step (default 16) */
+MI_API int mi_tvl1_multi_calc_batch(mi_tvl1_multi *m, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows);
+MI_API void mi_tvl1_multi_destroy(mi_tvl1_multi *m);
+
 /* Stage-level entry points (dense or pitched MI_32FC1 planes) == the reference's internal
  * device-layer boundary, exported for plane-by-plane parity tests.
  * Replaces: tvl1flow::centeredGradient  cudaoptflow/src/cuda/tvl1flow.cu:59-81 */

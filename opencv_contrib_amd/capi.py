@@ -118,6 +118,11 @@ def lib():
         "mi_tvl1_get_profile": (i, [vp, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
         "mi_tvl1_get_profile_kind": (i, [vp, i, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
         "mi_tvl1_destroy": (None, [vp]),
+        "mi_tvl1_multi_create": (i, [C.POINTER(TVL1Params), i, C.POINTER(i), C.POINTER(vp)]),
+        "mi_tvl1_multi_device_count": (i, [vp]),
+        "mi_tvl1_multi_set_chunk": (i, [vp, i]),
+        "mi_tvl1_multi_calc_batch": (i, [vp, i, PM, PM, PM]),
+        "mi_tvl1_multi_destroy": (None, [vp]),
         "mi_tvl1_centered_gradient": (i, [PM, PM, PM, vp]),
         "mi_tvl1_warp_backward": (i, [i] + [PM] * 11),
         "mi_tvl1_iterate": (i, [i, i, i, PM, PM, PM, PM, PM, PM, PM, PM, f, f, f, C.POINTER(d), vp]),

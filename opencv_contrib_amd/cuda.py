@@ -134,6 +134,43 @@ class OpticalFlowDual_TVL1:
         return [[buf[s * nw + w] for w in range(nw)] for s in range(ns.value)]
 
 
+class TVL1MultiDevice:
+    """Batched-frames mode over the GPUs of one node through the C-ABI (mi_tvl1_multi_*): contiguous shards of independent pairs,
+    one host thread + handle + stream pair per device, peer-to-peer staging from / to the ROOT device (devices[0]), no collective.
+    `alg` is an OpticalFlowDual_TVL1 whose parameters are used (create it with the reference's factory arguments).
+    The same device id may appear several times (several workers on one GPU)."""
+
+    def __init__(self, alg: "OpticalFlowDual_TVL1", devices=None, chunk=16):
+        self._h = C.c_void_p()
+        ids = None if devices is None else (C.c_int * len(devices))(*devices)
+        capi.check(capi.lib().mi_tvl1_multi_create(C.byref(alg._p), 0 if devices is None else len(devices), ids, C.byref(self._h)))
+        capi.check(capi.lib().mi_tvl1_multi_set_chunk(self._h, chunk))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                capi.lib().mi_tvl1_multi_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def deviceCount(self):
+        return capi.lib().mi_tvl1_multi_device_count(self._h)
+
+    def calc_batch(self, I0s, I1s, flows=None):
+        """All tensors on the root device.  Synchronous: earlier work on the inputs must be complete (synchronised here)."""
+        import torch
+        n = len(I0s)
+        if flows is None:
+            flows = torch.empty((n, I0s[0].shape[0], I0s[0].shape[1], 2), dtype=torch.float32, device=I0s[0].device)
+        torch.cuda.synchronize()
+        A0 = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in I0s])
+        A1 = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in I1s])
+        AF = (capi.Mat * n)(*[capi.mat_from_tensor(t) for t in flows])
+        capi.check(capi.lib().mi_tvl1_multi_calc_batch(self._h, n, A0, A1, AF))
+        return flows
+
+
 # ---------------------------------------------------------------------------------------------
 # stage-level functions (the reference's internal device-layer boundary), used by parity tests
 def _m(t):

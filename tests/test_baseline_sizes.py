@@ -122,6 +122,35 @@ def test_two_lanes_equal_one_lane(gpu, eps, iters):
         assert single.lastIterations(0) == a1.lastIterations(k)
 
 
+@pytest.mark.parametrize("devices,chunk", [([0], 4), ([0, 0], 2), ([0, 0, 0], 16)])
+def test_multi_device_host_entry_equals_calc_batch(gpu, devices, chunk):
+    """mi_tvl1_multi_calc_batch (host threads, one per device; peer-to-peer staging in double-buffered chunks): on the one-GPU
+    test box the worker list names device 0 several times, which runs every code path -- the in-place root worker, the staged
+    workers with their copy / compute streams, the chunking with a ragged last chunk -- and must give, pair for pair, the bytes
+    of mi_tvl1_calc_batch.  Inputs include pitched (ROI) matrices."""
+    import torch
+    from opencv_contrib_amd import cuda
+    n = 11
+    pairs = [synth.flow_pair(96, 160, seed=80 + k)[:2] for k in range(4)]
+    big0 = torch.zeros((n, 96, 200), dtype=torch.float32, device=gpu)
+    I0s, I1s = [], []
+    for k in range(n):
+        a, b = T(pairs[k % 4][0], gpu), T(pairs[k % 4][1], gpu)
+        a, b = torch.roll(a, 5 * (k // 4), 1), torch.roll(b, 5 * (k // 4), 1)
+        big0[k, :, 20:180] = a
+        I0s.append(big0[k, :, 20:180])          # pitched view: step = 800 bytes, 640 used
+        I1s.append(b.contiguous())
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0)
+    ref = alg.calc_batch(I0s, I1s)
+    torch.cuda.synchronize()
+    multi = cuda.TVL1MultiDevice(alg, devices=devices, chunk=chunk)
+    assert multi.deviceCount() == len(devices)
+    out = multi.calc_batch(I0s, I1s)
+    assert torch.equal(out, ref)
+    out2 = multi.calc_batch(I0s[:3], I1s[:3])   # fewer pairs than workers x chunk: some workers idle
+    assert torch.equal(out2, ref[:3])
+
+
 @pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class_rule", "cv_cuda_schedule"])
 @pytest.mark.parametrize("shape,seed", [((120, 160), 11), ((388, 584), 78)])
 def test_class_defaults_speculative_convergence(gpu, oracle, sem, shape, seed):
