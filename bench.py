@@ -84,8 +84,9 @@ def bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows_ref):
     inputs already resident on every GPU)."""
     import torch
     from opencv_contrib_amd import cuda
-    x = torch.stack([I0, I1], 1)                                   # (B, 2, H, W): rank 0's batch is what every rank receives
-    parts = [x] * world if rank == 0 else None
+    x = torch.stack([I0, I1], 1)                                   # (B, 2, H, W)
+    # rank 0 holds `world` DISTINCT shards (its own batch rolled by 16 r columns): every rank receives and computes different pairs
+    parts = [torch.roll(x, 16 * r, 3).contiguous() for r in range(world)] if rank == 0 else None
     local_in = [torch.empty_like(x) for _ in range(2)]
     local_out = [torch.empty_like(flows_ref) for _ in range(2)]
     root_out = [[torch.empty_like(flows_ref) for _ in range(world)] for _ in range(2)] if rank == 0 else None
@@ -102,12 +103,18 @@ def bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows_ref):
     B = x.shape[0]
     res = {"value": B * world * args.steps / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / args.steps,
            "exchange_GB_per_step": (world - 1) * (x.numel() + flows_ref.numel()) * 4 / 1e9,
-           "note": "inputs on GPU 0 only: scatter (grouped RCCL send/recv) -> calc_batch -> gather of the flows to GPU 0 inside "
-                   "the timed region, double buffered"}
+           "note": "inputs on GPU 0 only (one distinct shard per rank): scatter (grouped RCCL send/recv) -> calc_batch -> gather of the "
+                   "flows to GPU 0 inside the timed region, double buffered"}
     if rank == 0:
         last = root_out[(args.steps - 1) & 1]
-        # every rank received rank 0's batch and the kernels are deterministic: all gathered flows equal the resident run's
-        res["gathered_flows_identical"] = bool(all(torch.equal(o, flows_ref) for o in last))
+        # the kernels are deterministic: the flows gathered from rank r must equal rank 0's own computation of shard r
+        ok = True
+        chk = torch.empty_like(flows_ref)
+        for r in range(world):
+            alg.calc_batch(parts[r][:, 0], parts[r][:, 1], chk)
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(last[r], chk))
+        res["gathered_flows_identical"] = ok
     return res
 
 

@@ -151,7 +151,7 @@ cuda.OpticalFlowDual_TVL1 = types.SimpleNamespace(create=lambda **kw: FakeAlg())
 torch.cuda.synchronize = lambda: None
 dist, rank, world, local = parallel.init_distributed("gloo")
 args = types.SimpleNamespace(iterations=10, epsilon=0.0, exact_math=False, time_block=0, warmup=1, steps=4)
-g = torch.Generator().manual_seed(5)          # rank 0's batch is what every rank receives
+g = torch.Generator().manual_seed(5)          # rank 0 derives one DISTINCT shard per rank from its batch
 I0 = torch.rand(3, 6, 8, generator=g) + rank   # other ranks hold different data of their own: it must not matter
 I1 = torch.rand(3, 6, 8, generator=g) + rank
 ref = torch.empty(3, 6, 8, 2)
@@ -164,8 +164,9 @@ dist.destroy_process_group()
 
 
 def test_bench_exchange_leg_two_ranks_with_a_stand_in_algorithm(tmp_path):
-    """bench.py's "with_scatter_gather" leg end to end on 2 gloo ranks (the TV-L1 object replaced by a stand-in): rank 0's batch reaches
-    both ranks, both flows come back identical to the resident result, one throughput figure for the job."""
+    """bench.py's "with_scatter_gather" leg end to end on 2 gloo ranks (the TV-L1 object replaced by a stand-in): rank 0 sends a
+    distinct shard to every rank, the flows gathered from rank r equal rank 0's own computation of shard r, one throughput figure
+    for the job."""
     import json
     script = tmp_path / "bench_exchange_worker.py"
     script.write_text(BENCH_EXCHANGE_WORKER % {"root": ROOT})
