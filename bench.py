@@ -672,31 +672,42 @@ def main():
         out["variants"] = var
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        # CPU baseline: the oracle (a port of the reference CPU class; the class itself cannot be built here: it needs opencv core /
-        # imgproc) on pairs of the same workload, all host cores (OpenMP rows).  kind "port": its per-pixel loops are the reference's,
-        # including the serial float error sum -- the ratio to `value` says nothing about kernel quality (roofline.frac does).
+        # CPU baseline on this box's host cores.  kind "reference": the reference's OWN class cv::optflow::DualTVL1OpticalFlow --
+        # modules/optflow/src/tvl1flow.cpp compiled verbatim against a stub core (oracle/_ref/libref_cpu.so, oracle/Makefile.ref;
+        # parallel_for_ over OpenMP stripes like the library's, cv::remap / cv::resize from oracle/imgproc_ref.c) -- when that
+        # prebuilt library travelled with the tree and the run uses the CPU class's arithmetic; otherwise kind "port": the oracle
+        # (bit-identical to that class, tests/test_ref_pin.py).  Either way its per-pixel loops are the reference's, including the
+        # SERIAL float error sum of estimateU: the GPU / CPU ratio says nothing about kernel quality (roofline.frac does).
         from oracle import oracle as O
+        from oracle import refocl
         cit = args.cpu_iterations or (args.iterations if args.epsilon == 0 else 300)
+        use_ref = int(P.semantics) == 0 and os.path.exists(refocl.cpu_lib_path())
         p = O.tvl1_params(iterations=cit, epsilon=args.epsilon, semantics=int(P.semantics))
+
+        def cpu_calc(a, b):
+            if use_ref:
+                return refocl.cpu_tvl1_calc(a, b, inner_iterations=1, outer_iterations=cit, median_filtering=1, epsilon=args.epsilon)[0]
+            return O.tvl1_calc(a, b, p)
+
         npairs, t0 = 0, time.perf_counter()
         ref0 = None
-        while npairs < len(base) * 4 and (npairs == 0 or time.perf_counter() - t0 < 10.0):
+        while npairs < len(base) * 4 and (npairs == 0 or time.perf_counter() - t0 < 12.0):
             b_ = base[npairs % len(base)]
-            r_ = O.tvl1_calc(b_[0], b_[1], p)
+            r_ = cpu_calc(b_[0], b_[1])
             if npairs == 0:
                 ref0 = r_
             npairs += 1
         ct = time.perf_counter() - t0
         if ref0 is not None and cit == args.iterations:
-            # BASELINE.json metric: "... EPE vs CPU ref" -- pair 0 of the timed batch against the CPU restatement with the same
+            # BASELINE.json metric: "... EPE vs CPU ref" -- pair 0 of the timed batch against the CPU reference with the same
             # parameters; |1 - CCORR| is the reference's own comparator (cudaoptflow/test/test_optflow.cpp:465, 4e-3 there)
             out["epe_vs_cpu_ref_px"] = float(synth.epe(f0, ref0))
             out["ccorr_dissimilarity_vs_cpu_ref"] = float(max(synth.ccorr_dissimilarity(f0[..., 0], ref0[..., 0]),
                                                               synth.ccorr_dissimilarity(f0[..., 1], ref0[..., 1])))
-        out["cpu_baseline"] = {"value": npairs / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-                               "sample": f"{npairs} pair(s) {W}x{H} CV_32FC1, iterations={cit}, epsilon={args.epsilon}, "
-                                         f"{ct:.1f} s wall, oracle/tvl1_ref.c (OpenMP rows, all host cores; serial float error sum "
-                                         f"like the reference)"}
+        out["cpu_baseline"] = {"value": npairs / ct, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "reference" if use_ref else "port",
+                               "sample": f"{npairs} pair(s) {W}x{H} CV_32FC1, iterations={cit}, epsilon={args.epsilon}, {ct:.1f} s wall, "
+                                         + ("cv::optflow::DualTVL1OpticalFlow (tvl1flow.cpp verbatim, stub core, OpenMP stripes)" if use_ref
+                                            else "oracle/tvl1_ref.c (OpenMP rows, all host cores)")}
     if rank == 0 and world == 1 and not args.no_secondary:
         del I0, I1, flows
         torch.cuda.empty_cache()

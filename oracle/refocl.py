@@ -39,7 +39,11 @@ def build(force: bool = False) -> bool:
 
 
 def available() -> bool:
-    return os.path.exists(lib_path(False)) and os.path.exists(lib_path(True))
+    return os.path.exists(lib_path(False)) and os.path.exists(lib_path(True)) and os.path.exists(cpu_lib_path())
+
+
+def cpu_lib_path() -> str:
+    return os.path.join(_DIR, "libref_cpu.so")
 
 
 def lib(fma: bool = False):
@@ -162,3 +166,40 @@ def surf_descriptors(img, kp, extended=False, fma=False):
     desc = np.zeros((k.shape[1], dsz), np.float32)
     lib(fma).ref_ocl_surf_descriptors(img, img.shape[0], img.shape[1], k.reshape(-1), k.shape[1], k.shape[1], dsz, desc.reshape(-1))
     return desc
+
+
+# ------------------------------------------------------------------------- the reference's CPU class (tvl1flow.cpp, verbatim)
+_cpu = None
+
+
+def cpu_lib():
+    """oracle/_ref/libref_cpu.so: modules/optflow/src/tvl1flow.cpp compiled verbatim against the stub core headers of
+    oracle/refshim/cvstub (cv::resize / remap / medianBlur forwarded to oracle/imgproc_ref.c)."""
+    global _cpu
+    if _cpu is None:
+        if not os.path.exists(cpu_lib_path()):
+            build()
+        L = C.CDLL(cpu_lib_path())
+        i, d = C.c_int, C.c_double
+        L.ref_cpu_tvl1_calc.restype = i
+        L.ref_cpu_tvl1_calc.argtypes = [d, d, d, i, i, d, i, i, d, d, i, i, C.c_void_p, C.c_void_p, i, i, i, _f32p, C.POINTER(i)]
+        _cpu = L
+    return _cpu
+
+
+def cpu_tvl1_calc(I0, I1, tau=0.25, lambda_=0.15, theta=0.3, nscales=5, warps=5, epsilon=0.01, inner_iterations=30,
+                  outer_iterations=10, scale_step=0.8, gamma=0.0, median_filtering=5, init_flow=None):
+    """cv::optflow::DualTVL1OpticalFlow::create(...)->calc(I0, I1, flow) -- the reference class itself.  Returns (flow, nscales)."""
+    I0, I1 = np.ascontiguousarray(I0), np.ascontiguousarray(I1)
+    assert I0.dtype == I1.dtype and I0.dtype in (np.uint8, np.float32) and I0.shape == I1.shape
+    h, w = I0.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    if init_flow is not None:
+        flow[...] = init_flow
+    ns = C.c_int(0)
+    rc = cpu_lib().ref_cpu_tvl1_calc(tau, lambda_, theta, nscales, warps, epsilon, inner_iterations, outer_iterations, scale_step, gamma,
+                                     median_filtering, int(init_flow is not None), I0.ctypes.data, I1.ctypes.data,
+                                     0 if I0.dtype == np.uint8 else 1, w, h, flow.reshape(-1), C.byref(ns))
+    if rc:
+        raise ValueError(f"the reference class threw (rc {rc})")
+    return flow, ns.value

@@ -191,6 +191,43 @@ def test_surf_orientation_and_descriptors_against_reference_kernels(oracle, h, w
     np.testing.assert_allclose(np.linalg.norm(desc, axis=1), 1.0, atol=1e-5)
 
 
+# ------------------------------------------------------------------------------- the CPU class: oracle vs tvl1flow.cpp itself
+CPU_CASES = [dict(),                                                                         # class defaults: median 5, inner 30, outer 10
+             dict(inner_iterations=1, outer_iterations=10, median_filtering=1, epsilon=0.0),  # the cv::cuda-equivalent test setting
+             dict(inner_iterations=1, outer_iterations=300, median_filtering=1),              # convergence-checked, no median filter
+             dict(inner_iterations=3, outer_iterations=4, median_filtering=3, epsilon=0.0),
+             dict(inner_iterations=1, outer_iterations=10, median_filtering=1, epsilon=0.0, gamma=1.0),
+             dict(nscales=3, warps=2, scale_step=0.5, tau=0.2, lambda_=0.3, theta=0.25, inner_iterations=1, outer_iterations=8,
+                  median_filtering=1, epsilon=0.0)]
+
+
+@pytest.mark.parametrize("kw", CPU_CASES, ids=["defaults", "test_setting", "eps_check", "median3", "gamma", "other_params"])
+@pytest.mark.parametrize("h,w,seed,dtype", [(96, 128, 3, "f32"), (120, 160, 5, "u8"), (50, 70, 9, "f32")])
+def test_cpu_class_oracle_equals_reference_class(oracle, h, w, seed, dtype, kw):
+    """oracle.tvl1_calc (semantics CPU_REF) against cv::optflow::DualTVL1OpticalFlow ITSELF: modules/optflow/src/tvl1flow.cpp
+    compiled verbatim (oracle/_ref/libref_cpu.so) against the stub core of oracle/refshim/cvstub.  Every line of arithmetic in
+    that file -- gradients, divergence, thresholding, primal / dual updates with the f64 hypot, the serial float error sum and
+    the loops around them, level sizes, flow rescaling -- is the reference's; cv::resize / cv::remap / cv::medianBlur are
+    main-repo functions (absent from /root/reference) and both sides use the restatement of oracle/imgproc_ref.c for them.
+    Flows equal bit for bit."""
+    I0, I1, _ = synth.flow_pair(h, w, seed=seed, dtype=dtype)
+    ref, ns = refocl.cpu_tvl1_calc(I0, I1, **kw)
+    okw = dict(kw)
+    got, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(**okw), return_stats=True)
+    np.testing.assert_array_equal(got, ref)
+    assert st["nscales"] == ns
+
+
+def test_cpu_class_oracle_equals_reference_class_initial_flow_and_shrinking_scales(oracle):
+    I0, I1, gt = synth.flow_pair(40, 56, seed=13)
+    init = (gt * 0.7).astype(np.float32)
+    kw = dict(inner_iterations=1, outer_iterations=6, median_filtering=1, epsilon=0.0, nscales=8)   # levels fall below 16 px: nscales shrinks
+    ref, ns = refocl.cpu_tvl1_calc(I0, I1, init_flow=init, **kw)
+    got, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(use_initial_flow=1, **kw), init_flow=init, return_stats=True)
+    np.testing.assert_array_equal(got, ref)
+    assert ns == st["nscales"] < 8
+
+
 # ------------------------------------------------------------------------------------------- HIP vs the reference kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("h,w,seed", SIZES[:2])
