@@ -1,0 +1,182 @@
+"""ctypes front-end of oracle/_ref/libref_cu.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+The reference's own CUDA kernel sources -- cudastereo/src/cuda/stereobm.cu, cudaoptflow/src/cuda/farneback.cu,
+cudaoptflow/src/cuda/tvl1flow.cu, cudastereo/src/cuda/disparity_bilateral_filter.cu -- compiled for the HOST: oracle/Makefile.ref
+rewrites only their launch sites (oracle/refshim/cu2host.py) into oracle/_ref/ and compiles the result against
+oracle/refshim/cudashim (thread blocks as cooperatively scheduled contexts, __shared__ as static storage, the few main-repo device
+headers stubbed).  Every line of kernel arithmetic that runs is the reference's.  Built where /root/reference exists; the .so
+travels with the tree.  tests/test_ref_pin_cuda.py holds the restated oracles to it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import refocl
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "_ref", "libref_cu.so")
+_lib = None
+_f32 = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def available() -> bool:
+    return os.path.exists(LIB)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            refocl.build()
+        L = C.CDLL(LIB)
+        i, f, vp = C.c_int, C.c_float, C.c_void_p
+        L.ref_cu_sbm_block_match.argtypes = [_u8, _u8, i, i, i, i, i, _u8, vp]
+        L.ref_cu_sbm_prefilter_xsobel.argtypes = [_u8, i, i, i, _u8]
+        L.ref_cu_sbm_prefilter_norm.argtypes = [_u8, i, i, i, i, _u8]
+        L.ref_cu_sbm_textureness.argtypes = [_u8, i, i, i, f, _u8]
+        L.ref_cu_fb_poly_exp.argtypes = [_f32, i, i, i, _f32, _f32, _f32, f, f, f, f, _f32]
+        L.ref_cu_fb_update_matrices.argtypes = [_f32, _f32, _f32, _f32, i, i, _f32]
+        L.ref_cu_fb_update_flow.argtypes = [_f32, i, i, _f32, _f32]
+        L.ref_cu_fb_box5.argtypes = [_f32, i, i, i, _f32]
+        L.ref_cu_fb_gaussian_blur.argtypes = [_f32, i, i, _f32, i, i, _f32]
+        L.ref_cu_fb_gaussian_blur5.argtypes = [_f32, i, i, _f32, i, i, _f32]
+        L.ref_cu_tvl1_centered_gradient.argtypes = [_f32, i, i, _f32, _f32]
+        L.ref_cu_tvl1_warp.argtypes = [_f32] * 6 + [i, i] + [_f32] * 5
+        L.ref_cu_tvl1_estimate_u.argtypes = [_f32] * 4 + [vp] * 10 + [i, i, f, f, f, i]
+        L.ref_cu_tvl1_estimate_dual.argtypes = [vp] * 9 + [i, i, f, f]
+        L.ref_cu_dbf_apply.restype = i
+        L.ref_cu_dbf_apply.argtypes = [vp, i, _u8, i, i, i, i, i, i, f, f, f]
+        _lib = L
+    return _lib
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ---------------------------------------------------------------------------------------------------------- StereoBM
+def sbm_block_match(left, right, ndisp=64, winsz=19, uniqueness_ratio=0):
+    left, right = _c(left, np.uint8), _c(right, np.uint8)
+    d = np.zeros_like(left)
+    ssd = np.zeros(left.shape, np.uint32)
+    rc = lib().ref_cu_sbm_block_match(left, right, left.shape[0], left.shape[1], ndisp, winsz, uniqueness_ratio, d, ssd.ctypes.data)
+    if rc:
+        raise ValueError("stereoBM_CUDA threw")
+    return d, ssd
+
+
+def sbm_prefilter_xsobel(img, cap=31):
+    img = _c(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().ref_cu_sbm_prefilter_xsobel(img, img.shape[0], img.shape[1], cap, out)
+    return out
+
+
+def sbm_prefilter_norm(img, cap=31, winsize=9):
+    img = _c(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().ref_cu_sbm_prefilter_norm(img, img.shape[0], img.shape[1], cap, winsize, out)
+    return out
+
+
+def sbm_textureness(img, disp, winsz=19, avg_threshold=3.0):
+    img, d = _c(img, np.uint8), _c(disp, np.uint8).copy()
+    lib().ref_cu_sbm_textureness(img, img.shape[0], img.shape[1], winsz, avg_threshold, d)
+    return d
+
+
+# --------------------------------------------------------------------------------------------------------- Farneback
+def fb_poly_exp(src, poly_n, g, xg, xxg, ig):
+    src = _c(src)
+    h, w = src.shape
+    pad = lambda a: np.ascontiguousarray(np.concatenate([a, np.zeros(8 - len(a), np.float32)]))
+    dst = np.zeros((5 * h, w), np.float32)
+    lib().ref_cu_fb_poly_exp(src, h, w, poly_n, pad(g), pad(xg), pad(xxg), ig[0], ig[1], ig[2], ig[3], dst)
+    return dst
+
+
+def fb_update_matrices(flowx, flowy, R0, R1):
+    flowx, flowy, R0, R1 = map(_c, (flowx, flowy, R0, R1))
+    h, w = flowx.shape
+    M = np.zeros((5 * h, w), np.float32)
+    lib().ref_cu_fb_update_matrices(flowx, flowy, R0, R1, h, w, M)
+    return M
+
+
+def fb_update_flow(M):
+    M = _c(M)
+    h, w = M.shape[0] // 5, M.shape[1]
+    fx, fy = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    lib().ref_cu_fb_update_flow(M, h, w, fx, fy)
+    return fx, fy
+
+
+def fb_box5(M, ksize):
+    M = _c(M)
+    out = np.zeros_like(M)
+    lib().ref_cu_fb_box5(M, M.shape[0] // 5, M.shape[1], ksize // 2, out)
+    return out
+
+
+def fb_gaussian_blur(src, half_kernel, border):
+    src, k = _c(src), _c(half_kernel)
+    out = np.zeros_like(src)
+    lib().ref_cu_fb_gaussian_blur(src, src.shape[0], src.shape[1], k, len(k) - 1, border, out)
+    return out
+
+
+def fb_gaussian_blur5(M, half_kernel, border=1):
+    M, k = _c(M), _c(half_kernel)
+    out = np.zeros_like(M)
+    lib().ref_cu_fb_gaussian_blur5(M, M.shape[0] // 5, M.shape[1], k, len(k) - 1, border, out)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ TV-L1 (cv::cuda kernels)
+def tvl1_centered_gradient(src):
+    src = _c(src)
+    dx, dy = np.zeros_like(src), np.zeros_like(src)
+    lib().ref_cu_tvl1_centered_gradient(src, src.shape[0], src.shape[1], dx, dy)
+    return dx, dy
+
+
+def tvl1_warp(I0, I1, I1x, I1y, u1, u2):
+    a = [_c(x) for x in (I0, I1, I1x, I1y, u1, u2)]
+    h, w = a[0].shape
+    out = [np.zeros((h, w), np.float32) for _ in range(5)]
+    lib().ref_cu_tvl1_warp(*a, h, w, *out)
+    return tuple(out)
+
+
+def tvl1_iteration(I1wx, I1wy, grad, rho_c, u1, u2, p11, p12, p21, p22, l_t, theta, taut, gamma=0.0, u3=None, p31=None, p32=None):
+    """estimateU (error plane on) then estimateDualVariables, on copies.  -> (error plane, u1, u2, p11..p22[, u3, p31, p32])."""
+    st = [_c(x) for x in (I1wx, I1wy, grad, rho_c)]
+    h, w = st[0].shape
+    u = [_c(x).copy() for x in (u1, u2)]
+    p = [_c(x).copy() for x in (p11, p12, p21, p22)]
+    g3 = [_c(x).copy() if x is not None else np.zeros((h, w), np.float32) for x in (u3, p31, p32)]
+    err = np.zeros((h, w), np.float32)
+    ptr = lambda a: a.ctypes.data
+    L = lib()
+    L.ref_cu_tvl1_estimate_u(*st, ptr(p[0]), ptr(p[1]), ptr(p[2]), ptr(p[3]), ptr(g3[1]), ptr(g3[2]), ptr(u[0]), ptr(u[1]), ptr(g3[0]), ptr(err),
+                             h, w, l_t, theta, gamma, 1)
+    L.ref_cu_tvl1_estimate_dual(ptr(u[0]), ptr(u[1]), ptr(g3[0]), ptr(p[0]), ptr(p[1]), ptr(p[2]), ptr(p[3]), ptr(g3[1]), ptr(g3[2]), h, w, taut, gamma)
+    out = (err, u[0], u[1], *p)
+    return out + tuple(g3) if u3 is not None else out
+
+
+# ------------------------------------------------------------------------------------------ DisparityBilateralFilter
+def dbf_apply(disp, img, ndisp=64, radius=3, iters=1, edge_threshold=0.1, max_disc_threshold=0.2, sigma_range=10.0):
+    disp = np.ascontiguousarray(disp).copy()
+    img = np.ascontiguousarray(img, np.uint8)
+    assert disp.dtype in (np.uint8, np.int16)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    rc = lib().ref_cu_dbf_apply(disp.ctypes.data, 0 if disp.dtype == np.uint8 else 3, img.reshape(-1), ch, disp.shape[0], disp.shape[1], ndisp, radius,
+                                iters, edge_threshold, max_disc_threshold, sigma_range)
+    if rc:
+        raise ValueError("unsupported disparity type")
+    return disp

@@ -39,7 +39,7 @@ def build(force: bool = False) -> bool:
 
 
 def available() -> bool:
-    return os.path.exists(lib_path(False)) and os.path.exists(lib_path(True)) and os.path.exists(cpu_lib_path())
+    return all(os.path.exists(p) for p in (lib_path(False), lib_path(True), cpu_lib_path(), os.path.join(_DIR, "libref_cu.so")))
 
 
 def cpu_lib_path() -> str:

@@ -176,3 +176,10 @@ int oclrt_convert_int_rtn(float x) __asm__("_Z15convert_int_rtnf");
 int oclrt_convert_int_rtn(float x) { return (int)floorf(x); }
 int oclrt_convert_int_rtp(float x) __asm__("_Z15convert_int_rtpf");
 int oclrt_convert_int_rtp(float x) { return (int)ceilf(x); }
+
+/* plain-C names of the same state for the CUDA-on-host shim (cudashim.h) */
+size_t oclrt_local_id(unsigned d) { return d < 3 ? g_wi.lid[d] : 0; }
+size_t oclrt_group_id(unsigned d) { return d < 3 ? g_wi.grp[d] : 0; }
+size_t oclrt_local_size(unsigned d) { return d < 3 ? g_wi.lsz[d] : 1; }
+size_t oclrt_num_groups(unsigned d) { return d < 3 ? g_wi.ngrp[d] : 1; }
+void oclrt_barrier_plain(void) { oclrt_barrier(0); }

@@ -1,0 +1,180 @@
+"""PINNING, part 2: the restated oracles against the reference's own CUDA kernel SOURCES, executed here on the CPU.
+
+oracle/_ref/libref_cu.so = cudastereo/src/cuda/stereobm.cu, cudaoptflow/src/cuda/farneback.cu, cudaoptflow/src/cuda/tvl1flow.cu and
+cudastereo/src/cuda/disparity_bilateral_filter.cu compiled for the host (oracle/Makefile.ref): cu2host.py rewrites only the
+`k<<<...>>>(...)` launch sites and the `extern __shared__` declarations; oracle/refshim/cudashim supplies the execution model
+(thread blocks as cooperatively scheduled contexts, __syncthreads = yield, __shared__ = static storage) and stand-ins for the
+few main-repo device headers (PtrStepSz, border index maps, numeric_limits, the texture fetch rules of the CUDA programming guide).
+Every line of kernel arithmetic that runs is the reference's.
+
+Asserted: oracle/stereobm_ref.c, oracle/farneback_ref.c, the CUDA_COMPAT half of oracle/tvl1_ref.c and oracle/dbf_ref.c equal those
+kernels BIT FOR BIT on the same seeded inputs (the one exception, a data race inside the reference's bilateral filter, is
+isolated below).
+"""
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+from oracle import refcu, refocl
+
+pytestmark = pytest.mark.skipif(not (refcu.available() or refocl.can_build()), reason="oracle/_ref not built and /root/reference absent")
+
+
+# ------------------------------------------------------------------------------------------------------------ StereoBM
+@pytest.mark.parametrize("nd,ws,uq", [(64, 15, 0), (32, 11, 0), (64, 9, 10), (128, 19, 0), (16, 5, 25), (64, 21, 3)])
+@pytest.mark.parametrize("kind", ["ramp", "noise"])
+def test_stereobm_block_match_equals_reference_kernel(oracle, nd, ws, uq, kind):
+    """stereoKernel<RADIUS> (SSD over the window, winner-take-all in batches of 8 disparities with its tie rules, the
+    uniqueness-ratio state machine, the 128-column block edge) on textured pairs and on pure noise (ties everywhere)."""
+    if kind == "ramp":
+        left, right, _ = synth.stereo_pair(96, 300, seed=42 + nd, max_disp=min(30, nd - 2))
+    else:
+        rng = np.random.default_rng(nd * 31 + ws)
+        left = rng.integers(0, 4, size=(60, 300)).astype(np.uint8)      # 2-bit noise: many equal SSDs
+        right = rng.integers(0, 4, size=(60, 300)).astype(np.uint8)
+    ref, ssd = refcu.sbm_block_match(left, right, nd, ws, uq)
+    got = oracle.sbm_block_match(left, right, ndisp=nd, winsz=ws, uniqueness_ratio=uq, emulate_edge=True)
+    np.testing.assert_array_equal(got, ref)
+    assert (ref > 0).any()
+
+
+@pytest.mark.parametrize("cap", [31, 15, 63])
+def test_stereobm_prefilters_equal_reference_kernels(oracle, cap):
+    img = np.rint(synth.texture(90, 130, 7, 1.5)).astype(np.uint8)
+    np.testing.assert_array_equal(oracle.sbm_prefilter_xsobel(img, cap), refcu.sbm_prefilter_xsobel(img, cap))
+    for win in (9, 5, 15):
+        np.testing.assert_array_equal(oracle.sbm_prefilter_norm(img, cap, win), refcu.sbm_prefilter_norm(img, cap, win))
+
+
+@pytest.mark.parametrize("winsz,thr", [(15, 3.0), (9, 10.0), (19, 1.0)])
+def test_stereobm_textureness_equals_reference_kernel(oracle, winsz, thr):
+    """postfilter_textureness on an image with flat regions (they must be zeroed) and textured ones.  The kernel reads the image
+    through a linearly filtered texture at integer coordinates, i.e. the mean of a 2 x 2 texel block (CUDA programming guide,
+    texture fetching; 1.8 fixed-point weights are exact at 0.5): the oracle's exact-integer quarter-weight definition."""
+    img = np.rint(synth.texture(100, 260, 5, 1.5)).astype(np.uint8)
+    img[20:60, 40:130] = 117                     # flat patch
+    img[70:95, 150:250] = (img[70:95, 150:250] // 64) * 64   # weak texture
+    disp = np.random.default_rng(2).integers(1, 64, size=img.shape).astype(np.uint8)
+    ref = refcu.sbm_textureness(img, disp, winsz, thr)
+    got = oracle.sbm_textureness(img, disp, winsz, thr)
+    np.testing.assert_array_equal(got, ref)
+    z = (ref == 0) & (disp != 0)
+    assert 0.02 < z.mean() < 0.9, z.mean()
+
+
+# ----------------------------------------------------------------------------------------------------------- Farneback
+@pytest.fixture(scope="module")
+def fb_inputs(oracle):
+    I0, I1, _ = synth.flow_pair(120, 300, seed=5, dtype="u8")
+    a, b = I0.astype(np.float32), I1.astype(np.float32)
+    rng = np.random.default_rng(0)
+    fx = (rng.standard_normal(a.shape) * 2).astype(np.float32)
+    fy = (rng.standard_normal(a.shape) * 2).astype(np.float32)
+    fx[:, :3] = -9.0; fy[-2:, :] = 7.5          # flows leaving the image: the border-scale table of updateMatrices
+    return a, b, fx, fy
+
+
+@pytest.mark.parametrize("n,sigma", [(5, 1.1), (7, 1.5), (5, 0.8)])
+def test_farneback_poly_exp_equals_reference_kernel(oracle, fb_inputs, n, sigma):
+    a = fb_inputs[0]
+    g, xg, xxg, ig = oracle.fb_prepare_gaussian(n, sigma)
+    np.testing.assert_array_equal(oracle.fb_poly_exp(a, n, sigma), refcu.fb_poly_exp(a, n, g, xg, xxg, ig))
+
+
+def test_farneback_update_matrices_and_flow_equal_reference_kernels(oracle, fb_inputs):
+    a, b, fx, fy = fb_inputs
+    R0, R1 = oracle.fb_poly_exp(a), oracle.fb_poly_exp(b)
+    M = oracle.fb_update_matrices(fx, fy, R0, R1)
+    np.testing.assert_array_equal(M, refcu.fb_update_matrices(fx, fy, R0, R1))
+    B = oracle.fb_blur5(M, 13)
+    ox, oy = oracle.fb_update_flow(B)
+    rx, ry = refcu.fb_update_flow(B)
+    np.testing.assert_array_equal(ox, rx)
+    np.testing.assert_array_equal(oy, ry)
+
+
+@pytest.mark.parametrize("ksize", [5, 13, 21, 33])
+def test_farneback_window_filters_equal_reference_kernels(oracle, fb_inputs, ksize):
+    """boxFilter5 and gaussianBlur5<BrdReplicate> on the 5-plane matrix stack (the two window types of updateFlow)."""
+    a, b, fx, fy = fb_inputs
+    M = oracle.fb_update_matrices(fx, fy, oracle.fb_poly_exp(a), oracle.fb_poly_exp(b))
+    np.testing.assert_array_equal(oracle.fb_blur5(M, ksize), refcu.fb_box5(M, ksize))
+    sigma = ksize // 2 * 0.3
+    half = oracle.fb_gaussian_kernel(ksize, sigma)[ksize // 2:]
+    np.testing.assert_array_equal(oracle.fb_blur5(M, ksize, sigma), refcu.fb_gaussian_blur5(M, half, 1))
+
+
+@pytest.mark.parametrize("ksize,sigma,border", [(5, 1.0, 4), (9, 2.0, 4), (7, 1.5, 1), (3, 0.5, 4), (41, 7.5, 4)])
+def test_farneback_pyramid_blur_equals_reference_kernel(oracle, fb_inputs, ksize, sigma, border):
+    a = fb_inputs[0]
+    half = oracle.fb_gaussian_kernel(ksize, sigma)[ksize // 2:]
+    np.testing.assert_array_equal(oracle.fb_gaussian_blur(a, ksize, sigma, border), refcu.fb_gaussian_blur(a, half, border))
+
+
+# ------------------------------------------------------------------------------------------- TV-L1: the cv::cuda kernels
+@pytest.mark.parametrize("h,w,seed", [(77, 101, 3), (64, 64, 11), (33, 250, 7)])
+@pytest.mark.parametrize("gamma", [0.0, 1.0])
+def test_tvl1_cuda_kernels_equal_oracle(oracle, h, w, seed, gamma):
+    """centeredGradientKernel, warpBackwardKernel (point-sampled clamp-addressed textures), estimateUKernel (with the error
+    plane) and estimateDualVariablesKernel of cudaoptflow/src/cuda/tvl1flow.cu -- the kernels of the class being replaced --
+    against the CUDA_COMPAT oracle, including the illumination channel (gamma != 0: u3, p31, p32)."""
+    I0, I1, _ = synth.flow_pair(h, w, seed=seed)
+    I0, I1 = (I0 * np.float32(255)).astype(np.float32), (I1 * np.float32(255)).astype(np.float32)
+    rx, ry = refcu.tvl1_centered_gradient(I1)
+    ox, oy = oracle.tvl1_centered_gradient(I1)
+    np.testing.assert_array_equal(ox, rx); np.testing.assert_array_equal(oy, ry)
+    rng = np.random.default_rng(seed)
+    for amp in (0.0, 2.5, 300.0):
+        u1 = (rng.standard_normal((h, w)) * amp).astype(np.float32); u2 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+        if amp == 0.0:
+            u1[::3, ::5] = 1.0; u2[1::4, ::2] = -2.0
+        r = refcu.tvl1_warp(I0, I1, rx, ry, u1, u2)
+        o = oracle.tvl1_warp(1, I0, I1, ox, oy, u1, u2)
+        for name, a, b in zip(("I1w", "I1wx", "I1wy", "grad", "rho_c"), o, r):
+            np.testing.assert_array_equal(a, b, err_msg=f"{name} amp {amp}")
+    p = [(rng.standard_normal((h, w)) * 0.4).astype(np.float32) for _ in range(4)]
+    g3 = [(rng.standard_normal((h, w)) * 0.1).astype(np.float32) for _ in range(3)] if gamma else [None] * 3
+    l_t, theta, taut = np.float32(0.045), np.float32(0.3), np.float32(0.25 / 0.3)
+    u1 = (rng.standard_normal((h, w)) * 2).astype(np.float32); u2 = (rng.standard_normal((h, w)) * 2).astype(np.float32)
+    _, wx, wy, gr, rc = refcu.tvl1_warp(I0, I1, rx, ry, u1, u2)
+    gr[::7, ::3] = 0
+    r = refcu.tvl1_iteration(wx, wy, gr, rc, u1, u2, *p, l_t, theta, taut, gamma, *g3)
+    o = oracle.tvl1_iteration(1, wx, wy, gr, rc, u1, u2, *p, l_t, theta, taut, gamma, *g3)
+    for k in range(1, len(o)):
+        np.testing.assert_array_equal(o[k], r[k], err_msg=f"plane {k}")
+    assert np.float32(r[0].astype(np.float64).sum()) == np.float32(o[0])   # cuda::calcSum: float terms, double accumulator
+
+
+# --------------------------------------------------------------------------------------------- DisparityBilateralFilter
+@pytest.mark.parametrize("radius,iters", [(3, 1), (3, 2), (5, 1)])
+@pytest.mark.parametrize("dtype,bgr", [(np.uint8, False), (np.int16, True)])
+def test_disparity_bilateral_filter_equals_reference_kernel_where_it_is_deterministic(oracle, radius, iters, dtype, bgr):
+    """The reference kernel refines a pixel IN PLACE while neighbouring threads of the same red/black pass read the window it
+    lies in (disparity_bilateral_filter.cu:118-131): a data race whenever two pixels of one pass within a window both change.
+    The oracle (and the HIP kernel) read the pass's input snapshot.  On inputs where refined pixels are isolated -- spikes on
+    plateaus -- the two definitions coincide and the whole arithmetic (weights, truncated costs, the ordered minimum search)
+    is compared bit for bit."""
+    rng = np.random.default_rng(radius * 10 + iters)
+    h, w = 90, 150
+    disp = np.full((h, w), 20, dtype)
+    ys, xs = np.meshgrid(np.arange(radius + 3, h - radius - 3, 2 * radius + 3), np.arange(radius + 3, w - radius - 3, 2 * radius + 3), indexing="ij")
+    disp[ys, xs] = rng.integers(30, 60, size=ys.shape).astype(dtype)
+    scale = 16 if dtype == np.int16 else 1
+    disp = (disp * scale).astype(dtype)
+    g = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    img = np.stack([g, 255 - g, g // 2], -1) if bgr else g
+    ref = refcu.dbf_apply(disp, img, 64 * scale, radius, iters)
+    got = oracle.dbf_apply(disp, img, oracle.dbf_params(ndisp=64 * scale, radius=radius, iters=iters))
+    np.testing.assert_array_equal(got, ref)
+    assert (ref != disp).sum() >= ys.size // 2
+
+
+def test_disparity_bilateral_filter_on_a_real_map_differs_only_by_the_reference_race(oracle):
+    """On a block-matching disparity map (edges: neighbouring refined pixels) the sequential execution of the reference kernel
+    realises ONE outcome of its race; the snapshot definition agrees with it on all but a fraction of a percent of the pixels."""
+    left, right, _ = synth.stereo_pair(96, 224, seed=42, max_disp=30)
+    d = oracle.sbm_compute(left, right, oracle.sbm_params(num_disparities=64, block_size=15))
+    ref = refcu.dbf_apply(d, left, 64, 3, 1)
+    got = oracle.dbf_apply(d, left, oracle.dbf_params(ndisp=64, radius=3, iters=1))
+    assert (ref != d).mean() > 0.02
+    assert (ref != got).mean() < 0.02
