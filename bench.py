@@ -464,6 +464,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stop-slack", type=int, default=0, help="mi_tvl1_params.stop_slack (miflow extension; 0 = the reference's exact stopping point)")
     ap.add_argument("--cpu-iterations", type=int, default=None)
     args = ap.parse_args()
     if args.defaults:
@@ -499,7 +500,7 @@ def main():
         # A DEFAULT-CONSTRUCTED object with the reference test's two setter calls (setNumIterations / setEpsilon); the miflow
         # extensions stay at the library defaults (CPU-class arithmetic, fast math, automatic fusing and lanes) unless a variant
         # or a command-line flag names them
-        ext = dict(exactMath=True if args.exact_math else None, timeBlock=args.time_block, lanes=args.lanes, semantics=args.semantics)
+        ext = dict(exactMath=True if args.exact_math else None, timeBlock=args.time_block, lanes=args.lanes, semantics=args.semantics, stopSlack=args.stop_slack)
         ext.update(kw)
         return cuda.OpticalFlowDual_TVL1.create(iterations=iterations, epsilon=epsilon, **ext)
 
@@ -620,6 +621,7 @@ def main():
         vrun("iterations2_eps0", 2, 0.0)
         vrun("iterations30_eps0", 30, 0.0)
         vrun("class_defaults_300_eps0.01", 300, 0.01)                      # speculative blocks, device-decided stop
+        vrun("class_defaults_300_eps0.01_stop_slack1", 300, 0.01, stopSlack=1)   # miflow extension: up to one iteration past the reference's stop
         vrun("iterations10_eps0_exact_math", 10, 0.0, exactMath=True)
         vrun("iterations10_eps0_cuda_compat_semantics", 10, 0.0, semantics=1)
         # one lane: the whole batch on the caller's stream -- the two dominant kernels timed WITHOUT the other half batch's kernels

@@ -104,6 +104,10 @@ typedef struct mi_tvl1_params {
                           * 1: IEEE divide + f64 hypot, separately rounded operations in the reference's order */
     int time_block;      /* inner iterations fused per HBM pass (0 = auto, 1 = one iteration per launch) */
     int lanes;           /* internal streams a batch is split over: 0 = automatic (2 from 4 pairs on), 1, 2 */
+    int stop_slack;      /* 0 (default): a warp's inner loop stops exactly where the reference's convergence test stops it.
+                          * s > 0 (fast math, epsilon > 0 only): a fused block of iterations is also kept when the test first
+                          * passed up to s iterations before the block's end, i.e. up to s iterations MORE than the reference
+                          * may run (each of them below the convergence threshold); saves the pass that re-runs the exact count */
 } mi_tvl1_params;
 
 typedef struct mi_tvl1 mi_tvl1;

@@ -71,6 +71,13 @@ public:
         miCheck(mi_tvl1_set_params(h_, &q));
         p_ = q;
     }
+    void setStopSlack(int slack)
+    {
+        mi_tvl1_params q = p_;
+        q.stop_slack = slack;
+        miCheck(mi_tvl1_set_params(h_, &q));
+        p_ = q;
+    }
     const mi_tvl1_params &params() const { return p_; }
     String getDefaultName() const override { return "DenseOpticalFlow.OpticalFlowDual_TVL1"; }   // tvl1flow.cpp:122
 #define MIFLOW_PROP(T, Name, field) \
@@ -122,6 +129,14 @@ inline void setExactMath(const Ptr<OpticalFlowDual_TVL1> &alg, bool exact)
     auto *impl = dynamic_cast<miflow_detail::TVL1Impl *>(alg.get());
     CV_Assert(impl);
     impl->setExtra(impl->params().semantics, exact ? 1 : 0, impl->params().time_block, impl->params().lanes);
+}
+/** 0 (default): the inner loop of a warp stops exactly where the reference's convergence test stops it; s > 0: it may run up
+ *  to s iterations further (mi_tvl1_params.stop_slack). */
+inline void setStopSlack(const Ptr<OpticalFlowDual_TVL1> &alg, int slack)
+{
+    auto *impl = dynamic_cast<miflow_detail::TVL1Impl *>(alg.get());
+    CV_Assert(impl);
+    impl->setStopSlack(slack);
 }
 /** n independent image pairs of identical size and type in one pass (the batched-frames mode of BASELINE configs[4]). */
 inline void calcBatch(const Ptr<OpticalFlowDual_TVL1> &alg, const std::vector<GpuMat> &I0s, const std::vector<GpuMat> &I1s,

@@ -241,6 +241,67 @@ __global__ __launch_bounds__(256) void k_iterate(const float *M, const float *R0
     if (update) update_matrices_px(x, y, w, h, ld, fx, fy, R0, R1, Mout);
 }
 
+// The same iteration for compile-time window half sizes, tiled: a workgroup owns R rows x 256 columns.  The vertical pass loads
+// the R + 2 KH rows of a column ONCE per plane into registers -- independent loads, one L2 round trip instead of KH dependent
+// ones, and (R + 2 KH) / R instead of 2 KH + 1 loads per output -- and forms the R sums in the reference's order (centre, then
+// the symmetric pairs outwards), so results are bit-identical to k_iterate.  (column, plane) tasks are dealt round-robin to the
+// threads: 5 x (256 + 2 KH) tasks in ceil(./256) rounds.
+template <bool GAUSS, int KH, int R>
+__global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *R0, const float *R1, float *flowx, float *flowy,
+                                                   float *Mout, int w, int h, int ld, float boxAreaInv, int update, Taps K, long long bs)
+{
+    constexpr int SMW = 256 + 2 * KH;
+    __shared__ float smem[5][R][SMW];
+    {
+        const long long po = (long long)blockIdx.z * bs;
+        M += po; R0 += po; R1 += po; flowx += po; flowy += po; Mout += po;
+    }
+    const int tx = threadIdx.x, y0 = blockIdx.y * R, x = blockIdx.x * 256 + tx;
+    const long long ps = (long long)ld * h;
+    for (int t = tx; t < 5 * SMW; t += 256) {
+        const int k = t / SMW, i = t - k * SMW;
+        const int xe = clampi((int)(blockIdx.x * 256) + i - KH, 0, w - 1);
+        const float *P = M + k * ps + xe;
+        float c[R + 2 * KH];
+#pragma unroll
+        for (int r = 0; r < R + 2 * KH; ++r) c[r] = P[(long long)clampi(y0 + r - KH, 0, h - 1) * ld];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float v = GAUSS ? c[r + KH] * K.k[0] : c[r + KH];
+#pragma unroll
+            for (int j = 1; j <= KH; ++j) {
+                const float sj = c[r + KH - j] + c[r + KH + j];
+                v += GAUSS ? sj * K.k[j] : sj;
+            }
+            smem[k][r][i] = v;
+        }
+    }
+    __syncthreads();
+    if (x >= w) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        float res[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float *q = &smem[k][r][tx + KH];
+            float v = GAUSS ? q[0] * K.k[0] : q[0];
+#pragma unroll
+            for (int i = 1; i <= KH; ++i) v += GAUSS ? (q[-i] + q[i]) * K.k[i] : q[-i] + q[i];
+            res[k] = GAUSS ? v : v * boxAreaInv;
+        }
+        const float g11 = res[0], g12 = res[1], g22 = res[2], h1 = res[3], h2 = res[4];
+        const float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
+        const float fx = (g11 * h2 - g12 * h1) * detInv;
+        const float fy = (g22 * h1 - g12 * h2) * detInv;
+        const long long o = (long long)y * ld + x;
+        flowx[o] = fx;
+        flowy[o] = fy;
+        if (update) update_matrices_px(x, y, w, h, ld, fx, fy, R0, R1, Mout);
+    }
+}
+
 // 5-plane blur only / flow solve only (stage-level entry points and tests)
 template <bool GAUSS>
 __global__ __launch_bounds__(256) void k_blur5(const float *M, float *dst, int w, int h, int ld, int kh, float boxAreaInv, Taps K)
@@ -381,8 +442,22 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
     const float inv = 1.f / ((1 + 2 * kh) * (1 + 2 * kh));
     Taps none;
     memset(&none, 0, sizeof(none));
-    if (gauss) hipLaunchKernelGGL(k_iterate<true>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, update ? 1 : 0, *gauss, g.bs);
-    else hipLaunchKernelGGL(k_iterate<false>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, update ? 1 : 0, none, g.bs);
+    constexpr int R = 4;
+    const dim3 tgrid(div_up(g.w, 256), div_up(g.h, R), g.batch);
+    const Taps &K = gauss ? *gauss : none;
+    const int upd = update ? 1 : 0;
+#define MI_FB_TILED(KH)                                                                                                           \
+    case KH:                                                                                                                      \
+        if (gauss) hipLaunchKernelGGL((k_iterate_t<true, KH, R>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs); \
+        else hipLaunchKernelGGL((k_iterate_t<false, KH, R>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs);     \
+        break;
+    switch (tuning().fb_tiled ? kh : -1) {
+        MI_FB_TILED(4) MI_FB_TILED(6) MI_FB_TILED(7) MI_FB_TILED(10)   // winSize 9, 13 (the default), 15, 21
+    default:
+        if (gauss) hipLaunchKernelGGL(k_iterate<true>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, upd, K, g.bs);
+        else hipLaunchKernelGGL(k_iterate<false>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, upd, K, g.bs);
+    }
+#undef MI_FB_TILED
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

@@ -30,6 +30,7 @@ const Tuning &tuning()
         t.tb_verbose = getenv("MIFLOW_TB_VERBOSE") != nullptr;
         t.lanes = env_int("MIFLOW_LANES", 0);
         t.spec = env_int("MIFLOW_SPEC", 1);
+        t.fb_tiled = env_int("MIFLOW_FB_TILED", 1);
     });
     return g_tuning;
 }

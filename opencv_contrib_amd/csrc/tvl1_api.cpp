@@ -45,6 +45,7 @@ struct Lane {
     int2 *S = nullptr;
     unsigned long long *E = nullptr;
     double *Pd = nullptr;   // per slot prevError (cv::cuda check schedule)
+    int4 *X = nullptr;      // per slot state of the speculative steps (SpecK::X)
     long long Q = 0;
     int ctlB = 0;
     std::vector<SlotInfo> slots;
@@ -89,7 +90,7 @@ void mi_tvl1_default_params(mi_tvl1_params *p)
     // fma, iterations fused per HBM pass) by default, which the reference's own test tolerates (CUDA vs CPU |1 - CCORR| <= 4e-3,
     // test_optflow.cpp:465; here <= 1e-4 and mean EPE <= 5e-3 px against the oracle); exact_math = 1 performs the separately
     // rounded IEEE operations of the reference in its order.
-    p->semantics = MI_SEM_CPU_REF; p->exact_math = 0; p->time_block = 0; p->lanes = 0;
+    p->semantics = MI_SEM_CPU_REF; p->exact_math = 0; p->time_block = 0; p->lanes = 0; p->stop_slack = 0;
 }
 
 // upper bound of control slots per pair (scales x warps x iterations) a convergence-checked calc may enqueue
@@ -109,6 +110,7 @@ static int validate_params(const mi_tvl1_params *p)
     MI_REQUIRE(p->median_filtering <= 1 || p->median_filtering == 3 || p->median_filtering == 5, MI_ERR_BAD_ARG,
                "medianFiltering must be 1 (off), 3 or 5 (cv::medianBlur on CV_32F)");
     MI_REQUIRE(p->lanes >= 0 && p->lanes <= 2, MI_ERR_BAD_ARG, "lanes must be 0 (automatic), 1 or 2");
+    MI_REQUIRE(p->stop_slack >= 0 && p->stop_slack <= 8, MI_ERR_BAD_ARG, "stop_slack must be in 0..8");
     return MI_OK;
 }
 
@@ -203,6 +205,7 @@ void mi_tvl1_destroy(mi_tvl1 *h)
         if (ln.S) (void)hipFree(ln.S);
         if (ln.E) (void)hipFree(ln.E);
         if (ln.Pd) (void)hipFree(ln.Pd);
+        if (ln.X) (void)hipFree(ln.X);
         if (ln.done) (void)hipEventDestroy(ln.done);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
@@ -332,24 +335,34 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     const bool check = P.epsilon > 0.0 && iters_per_warp > 0;
     // convergence-checked path in fast math: speculative blocks (k_iterate_tbr MODE 1 / 2) instead of one launch per iteration
     const bool spec = check && !P.exact_math && P.time_block != 1 && P.gamma == 0.0 && P.median_filtering <= 1 && tuning().spec != 0;
-    std::vector<int> spec_plan;
-    if (spec) {
-        spec_plan.resize(iters_per_warp);
-        spec_plan.resize(tb_spec_plan(iters_per_warp, spec_plan.data(), iters_per_warp));
-    }
-    // control slots per pair: one per launch (S, P) and one error sum per iteration (E); both index spaces fit max(.,.)
+    // control slots per pair: one per launch (S, P, X) and one error sum per iteration (E); both index spaces fit max(.,.)
     long long Q = (long long)ns * P.warps * iters_per_warp;
-    if (spec) Q = std::max(Q, 2LL * ns * P.warps * (long long)spec_plan.size());
+    std::vector<int> spec_plan[2];   // kernel block sizes of the speculative steps: first warp of a scale / later warps
+    if (spec) {
+        long long e_sum = 0, launches = 0;
+        for (int k = 0; k < 2; ++k) {
+            spec_plan[k].resize(iters_per_warp + 8);
+            spec_plan[k].resize(tb_spec_plan(iters_per_warp, k, spec_plan[k].data(), (int)spec_plan[k].size()));
+            long long t = 0;
+            for (int v : spec_plan[k]) t += v;
+            const long long nw = k == 0 ? 1 : P.warps - 1;
+            e_sum += nw * t;
+            launches += nw * ((long long)spec_plan[k].size() + 1);
+        }
+        Q = std::max((long long)ns * e_sum, (long long)ns * launches);
+    }
     if (check) {
         MI_REQUIRE(Q <= kMaxSlots, MI_ERR_BAD_ARG, "scales x warps x iterations = %lld control slots exceed the limit of %lld", Q, kMaxSlots);
         if (ln.Q < Q || ln.ctlB < B) {
             if (ln.S) (void)hipFree(ln.S);
             if (ln.E) (void)hipFree(ln.E);
             if (ln.Pd) (void)hipFree(ln.Pd);
-            ln.S = nullptr; ln.E = nullptr; ln.Pd = nullptr; ln.Q = 0; ln.ctlB = 0;
+            if (ln.X) (void)hipFree(ln.X);
+            ln.S = nullptr; ln.E = nullptr; ln.Pd = nullptr; ln.X = nullptr; ln.Q = 0; ln.ctlB = 0;
             MI_HIP_TRY(hipMalloc((void **)&ln.S, sizeof(int2) * (size_t)Q * B));
             MI_HIP_TRY(hipMalloc((void **)&ln.E, sizeof(unsigned long long) * (size_t)Q * B));
             MI_HIP_TRY(hipMalloc((void **)&ln.Pd, sizeof(double) * (size_t)Q * B));
+            MI_HIP_TRY(hipMalloc((void **)&ln.X, sizeof(int4) * (size_t)Q * B));
             ln.Q = Q; ln.ctlB = B;
         }
         MI_HIP_TRY(hipMemsetAsync(ln.E, 0, sizeof(unsigned long long) * (size_t)ln.Q * B, st));
@@ -413,6 +426,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
 
     int q = 0, q_last = -1;   // device-control slot counters
     int e_next = 0;           // next per-iteration error-sum index (speculative path)
+    int q_settle_prev = -1, q_settle_prev2 = -1, q_settle_scale = -1;   // settling launches of the previous warp / of the coarser scale's first warp
     int cur = 0;              // host-known buffer set (fixed-work mode)
     Ctl ctl;
     memset(&ctl, 0, sizeof(ctl));
@@ -486,28 +500,47 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     }
                 }
             } else if (spec) {
-                // Per block of T iterations two launches: A runs the block speculatively and records the T error sums, B applies
-                // the reference's stopping rule to them and, if the loop would have stopped inside the block, replays exactly that
-                // many iterations from the block's input.  After convergence the remaining launches of the warp end at once.
-                int n0 = 0;
-                for (size_t k = 0; k < spec_plan.size(); ++k) {
-                    const int T = spec_plan[k];
-                    Ctl a = ctl;
-                    a.q = q; a.q_prev = q_last; a.first_of_warp = (k == 0); a.reset_cur = first_of_scale; a.n = n0;
-                    rc = iterate_tb_spec(T, 1, pl, g, l_t, theta, taut, first_of_scale, a, e_next, st);
-                    if (rc) return rc;
-                    ln.slots.push_back({s, wp});
-                    q_last = q++;
-                    Ctl b = ctl;
-                    b.q = q; b.q_prev = q_last; b.first_of_warp = 0; b.reset_cur = 0; b.n = n0;
-                    rc = iterate_tb_spec(T, 2, pl, g, l_t, theta, taut, first_of_scale, b, e_next, st);
-                    if (rc) return rc;
-                    ln.slots.push_back({s, wp});
-                    q_last = q++;
-                    nlaunch += 2;
-                    e_next += T; n0 += T;
-                    first_of_scale = false;
+                // Speculative steps (k_iterate_tbr MODE 1): a launch runs a block of iterations recording their error sums; the next
+                // launch applies the reference's stopping rule to them and either builds on the block or replays the exact
+                // count from its input.  One settling launch ends the warp.  After convergence the remaining launches end at once.
+                const std::vector<int> &plan = spec_plan[wp > 0 ? 1 : 0];
+                int t_after = 0;
+                for (int v : plan) t_after += v;
+                SpecK sk;
+                memset(&sk, 0, sizeof(sk));
+                sk.X = ln.X; sk.iters = iters_per_warp;
+                // the first block's length: a fraction of what an earlier warp needed (measured on textured pairs: the second
+                // warp of a scale needs about half of the first, later warps slightly fewer than their predecessor, the first
+                // warp of a scale about 0.7 of the first warp one scale coarser)
+                sk.q_hist = wp > 0 ? q_settle_prev : q_settle_scale;
+                sk.q_hist2 = wp > 2 ? q_settle_prev2 : -1;   // ... and never fewer than the warp before that (counts alternate)
+                sk.hist_num = wp == 0 ? 7 : wp == 1 ? 1 : 1;
+                sk.hist_den = wp == 0 ? 10 : wp == 1 ? 2 : 1;
+                sk.slack = P.stop_slack;
+                if (first_of_scale) {   // a replay of the scale's first block must see p = 0 in the input set as well
+                    for (int j = 0; j < 4; ++j) MI_HIP_TRY(hipMemsetAsync(ln.pbuf[0][j], 0, sizeof(float) * (size_t)g.ps * B, st));
                 }
+                int e_prev = 0;
+                for (size_t k = 0; k <= plan.size(); ++k) {
+                    const bool last = k == plan.size();
+                    const int T = last ? plan.back() : plan[k];
+                    if (!last) t_after -= T;
+                    Ctl a = ctl;
+                    a.q = q; a.q_prev = q_last; a.first_of_warp = (k == 0); a.reset_cur = (k == 0 && first_of_scale); a.n = 0;
+                    sk.e0_prev = e_prev; sk.final_launch = last ? 1 : 0; sk.t_after = t_after;
+                    sk.defer = (!last && T < 10 && k + 1 < plan.size()) ? 1 : 0;
+                    rc = iterate_tb_spec(T, pl, g, l_t, theta, taut, false, a, sk, e_next, st);
+                    if (rc) return rc;
+                    ln.slots.push_back({s, wp});
+                    q_last = q++;
+                    ++nlaunch;
+                    e_prev = e_next;
+                    if (!last) e_next += T;
+                }
+                q_settle_prev2 = wp > 0 ? q_settle_prev : -1;
+                q_settle_prev = q_last;
+                if (wp == 0) q_settle_scale = q_last;
+                first_of_scale = false;
             } else for (int it = 0; it < iters_per_warp; ++it) {
                 ++nlaunch;
                 if (mf && it % P.inner_iterations == 0) {   // cv::medianBlur before each outer iteration (optflow tvl1flow.cpp:1381-1384)

@@ -34,8 +34,9 @@ struct TbArgs {
     int rows_per_band;
     int cur;  // input set
     int swz, nstrips;
-    CtlK ctl;   // speculative convergence path only (MODE != 0): slot protocol of Ctl, e0 = first error-sum index of the block
+    CtlK ctl;   // speculative convergence path only (MODE 1): slot protocol of Ctl, e0 = first error-sum index of this launch's block
     int e0;
+    SpecK sk;
 };
 
 // flags of a control slot (S[..].y): bit 0 = the launch moved the state to the other buffer set, bit 1 = it summed the

@@ -156,7 +156,7 @@ struct CtxR {
     bool st_ok;
     bool right_ok[PPL];
     float l_t, theta, taut;
-    int nit;        // active stages (MODE 2: the replayed iteration count, < T; otherwise T)
+    int nit;        // active stages (MODE 1: the length of the speculative block or of the replay; otherwise T)
 };
 
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
@@ -204,17 +204,13 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         const float m2 = __uint_as_float((a == c.H) ? 0u : 0x3f800000u);
         const float taum2 = __uint_as_float((a == c.H) ? 0u : __float_as_uint(c.taut));
         if (MODE == 1) {
-            // speculative block: every level's error sum, over the rows of this wave's band only (halo rows belong to a neighbour)
+            // speculative step: nit <= T active stages, each summing its error over the rows of this wave's band only (halo rows
+            // belong to a neighbour).  A skipped stage writes nothing, which IS the identity of the rotating scheme: its output
+            // set still holds the unmodified input row of the previous step.
             const float es = __uint_as_float((a >= c.y0 && a < c.y1) ? 0x4b800000u : 0u);   // 2^24 or 0, kept on the scalar unit
-            stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
-                               c.taut, acc[t], es);
-        } else if (MODE == 2) {
-            // replay of nit < T iterations: a skipped stage writes nothing, which IS the identity of the rotating scheme
-            // (its output set still holds the unmodified input row of the previous step)
-            unsigned long long dummy = 0;
             if (t < c.nit)
-                stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
-                                    c.taut, dummy, 0.f);
+                stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
+                                   c.taut, acc[t], es);
         } else {
             unsigned long long dummy = 0;
             stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
@@ -249,13 +245,16 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
     (step_r<T, PPL, PZ, PF, MODE, Ks>(c, X, n0, slot0, acc), ...);
 }
 
-// MODE 0: T iterations, fixed work.  The convergence-checked path (epsilon > 0) runs blocks SPECULATIVELY:
-// MODE 1 = launch A of a block: T iterations from set cur into set cur^1 while recording the T per-iteration error sums;
-// MODE 2 = launch B: every workgroup evaluates the reference's stopping rule on those sums (CPU class: after every iteration,
-//          optflow/src/tvl1flow.cpp:1376-1390; cv::cuda: the sparse schedule of cudaoptflow/src/tvl1flow.cpp:357-377); if the
-//          loop would have stopped after k < T iterations the block is REPLAYED with exactly k iterations from the block's
-//          input (still intact in set cur), otherwise the speculative result stands and the launch ends at once.
-// Control travels through the per-launch slots of Ctl, so the whole calc stays stream-ordered.
+// MODE 0: T iterations, fixed work.
+// MODE 1: one SPECULATIVE STEP of the convergence-checked path (epsilon > 0).  The reference tests the error after every
+//   iteration (CPU class, optflow/src/tvl1flow.cpp:1376-1390) or on cv::cuda's sparse schedule (cudaoptflow/src/tvl1flow.cpp:357-377)
+//   and the flow depends on where the loop stops, so a block of iterations cannot simply be fused.  Instead a launch runs a block
+//   of nit <= T iterations from set `base` into set base^1 while recording the nit per-iteration error sums; the NEXT launch
+//   applies the stopping rule to those sums: the block stands (and the next block starts from its output), or the loop would have
+//   stopped after k < nit iterations and this launch REPLAYS exactly k iterations from the block's input, which is still intact.
+//   nit is chosen on the device from the error history (the previous warp's count, then the decay of the sums).  The last
+//   launch of a warp only settles.  Control travels through the per-launch slots of Ctl / SpecK, so the calc stays stream-ordered
+//   and bit-reproducible (integer error sums, decisions from device data only).
 template <int T, int PPL, bool PZ, int WPS, int PF, int MODE>
 __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 {
@@ -298,45 +297,94 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     const long long pb = (long long)b * A.g.ps;
     int cur = A.cur;
     c.nit = T;
-    if (MODE != 0) {
+    bool record = false;
+    if (MODE == 1) {
         const CtlK &ck = A.ctl;
-        int cur_in = 0, done = 0;
-        double prev = 0.0;   // cv::cuda's prevError as the block's first iteration sees it
+        const SpecK &sk = A.sk;
+        // (1) settle the block the previous launch of this warp ran speculatively (every workgroup, redundantly, from the same
+        //     device data => the same decision); (2) pick this launch's work: replay, the next speculative block, or nothing.
+        int base = 0, done = 0, n = 0, replay = 0, accepted = 0, pbase = 0;
+        double prev = 0.0;                    // cv::cuda's prevError
+        float e_last = 0.f, e_before = 0.f;   // error / threshold of the last two accepted iterations (0: unknown)
+        int deferred = 0;                     // block length the previous launch wanted but left to this one
         if (ck.q_prev >= 0) {
             const long long sp = (long long)b * ck.Q + ck.q_prev;
             const int2 sl = ck.S[sp];
-            cur_in = ck.reset_cur ? 0 : (sl.x ^ (sl.y & MI_SLOT_FLIP));
-            if (!ck.first_of_warp) { done = (sl.y & MI_SLOT_DONE) != 0; prev = ck.P[sp]; }
-        }
-        const bool writer = strip == 0 && bgrp == 0 && threadIdx.x == 0;   // the REMAPPED indices: one writer per pair b
-        const long long sq = (long long)b * ck.Q + ck.q;
-        if (MODE == 1) {
-            if (writer) { ck.S[sq] = make_int2(cur_in, done ? MI_SLOT_DONE : 0); ck.P[sq] = prev; }
-            if (done) return;
-        } else {
-            int kk = 0, conv = 0;
-            if (!done) {
-                for (int t = 0; t < T; ++t) {
-                    const int n = ck.n + t;
-                    const bool calc = !ck.sched || ((n & 1) && prev < ck.thr);
-                    if (calc) {
-                        const double e = (double)ck.E[(long long)b * ck.Q + A.e0 + t] * (1.0 / ERR_FIX_SCALE);
-                        prev = e;
-                        if (!(e > ck.thr)) { kk = t + 1; conv = 1; break; }
-                    } else {
-                        prev -= ck.thr;
+            pbase = sl.x ^ (sl.y & MI_SLOT_FLIP);
+            base = pbase;
+            if (!ck.first_of_warp) {
+                const int4 px = sk.X[sp];
+                prev = ck.P[sp];
+                n = px.x;
+                e_last = __int_as_float(px.z);
+                if (sl.y & MI_SLOT_DONE) {
+                    done = 1;
+                } else if (px.y == 0) {
+                    deferred = px.w;
+                } else {
+                    const int pn = px.y;
+                    int kk = 0, conv = 0;
+                    for (int t = 0; t < pn; ++t) {
+                        const int na = n + t;
+                        const bool calc = !ck.sched || ((na & 1) && prev < ck.thr);
+                        const double e = (double)ck.E[(long long)b * ck.Q + sk.e0_prev + t] * (1.0 / ERR_FIX_SCALE);
+                        e_before = e_last;
+                        e_last = (float)(e / ck.thr);
+                        if (calc) {
+                            prev = e;
+                            if (!(e > ck.thr)) { kk = t + 1; conv = 1; break; }
+                        } else {
+                            prev -= ck.thr;
+                        }
+                    }
+                    if (conv && kk + sk.slack < pn) {   // the loop would have stopped inside the block: redo exactly kk iterations from its input
+                        replay = kk; accepted = kk; n += kk; done = 1;
+                    } else {                 // the block stands
+                        base = pbase ^ 1; accepted = pn; n += pn;
+                        done = conv || n >= sk.iters;
                     }
                 }
-                if (!conv) kk = T;
             }
-            if (writer) {
-                ck.S[sq] = make_int2(cur_in, (kk > 0 ? MI_SLOT_FLIP : 0) | ((conv || done) ? MI_SLOT_DONE : 0) | (kk << 8));
-                ck.P[sq] = prev;
-            }
-            if (done || kk == T) return;   // nothing to do / the speculative block stands
-            c.nit = __builtin_amdgcn_readfirstlane(kk);
         }
-        cur = cur_in;
+        if (ck.reset_cur) base = pbase = 0;
+        int nit = 0, want = 0;
+        if (replay) {
+            nit = replay;
+        } else if (!done && !sk.final_launch) {
+            // block length: an estimate of the iterations still needed.  ANY value in [lo, hi] gives the same results; a good one
+            // avoids both a replay (too long) and extra passes (too short).
+            int pred = T;
+            if (deferred > 0) {
+                pred = deferred;
+            } else if (!ck.sched) {
+                if (ck.first_of_warp) {
+                    if (sk.q_hist >= 0) pred = (sk.X[(long long)b * ck.Q + sk.q_hist].x * sk.hist_num + sk.hist_den - 1) / sk.hist_den;
+                    if (sk.q_hist2 >= 0) pred = max(pred, sk.X[(long long)b * ck.Q + sk.q_hist2].x);
+                } else if (e_before > e_last && e_last > 1.f) {
+                    // geometric decay of the error sum; the decay slows down, and a block that is too long costs exactly one
+                    // more pass (the replay) while one that is too short may cost several: round up
+                    pred = (int)ceilf(__logf(e_last) / __logf(e_before / e_last)) + 1;
+                } else if (e_last > 0.f) {
+                    pred = 2;
+                }
+            }
+            const int hi = min(T, sk.iters - n), lo = max(1, sk.iters - n - sk.t_after);
+            if (sk.defer && pred > T && sk.iters - n <= sk.t_after) {
+                want = pred;   // a kernel with a longer block follows: one pass there instead of two
+            } else {
+                nit = max(lo, min(hi, pred));
+                record = true;
+            }
+        }
+        if (strip == 0 && bgrp == 0 && threadIdx.x == 0) {   // the REMAPPED indices: one writer per pair b
+            const long long sq = (long long)b * ck.Q + ck.q;
+            ck.S[sq] = make_int2(replay ? pbase : base, (replay ? MI_SLOT_FLIP : 0) | (done ? MI_SLOT_DONE : 0) | (accepted << 8));
+            ck.P[sq] = prev;
+            sk.X[sq] = make_int4(n, record ? nit : 0, __float_as_int(e_last), want);
+        }
+        if (nit == 0) return;
+        cur = replay ? pbase : base;
+        c.nit = __builtin_amdgcn_readfirstlane(nit);
     }
     c.uin[0] = A.pl.u[cur][0] + pb; c.uin[1] = A.pl.u[cur][1] + pb;
     c.uout[0] = A.pl.u[cur ^ 1][0] + pb; c.uout[1] = A.pl.u[cur ^ 1][1] + pb;
@@ -365,14 +413,14 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0;
     for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE>(c, X, n0, slot0, acc, std::make_integer_sequence<int, P>{});
-    if (MODE == 1) {
+    if (MODE == 1 && record) {
         // integer error sums: exact wave reduction of the owned lanes, one device-scope add per wave and level
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             unsigned long long sacc = c.st_ok ? acc[t] : 0ull;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-            if (c.lane == 0) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + t], sacc);
+            if (c.lane == 0 && t < c.nit) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + t], sacc);
         }
     }
 }
@@ -416,9 +464,9 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 typedef int (*TbLaunchFn)(const TbArgs &, bool, hipStream_t);
 struct TbrEntry {
     int T, PPL, WPS, PF, PLAN;
-    TbLaunchFn launch, spec_a, spec_b;
+    TbLaunchFn launch, spec;
 };
-#define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr, nullptr}
+#define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr}
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
@@ -426,10 +474,9 @@ static const TbrEntry g_tbr[] = {
     // alternatives (tuning sweeps, MIFLOW_TB_VARIANT)
     TBR(10, 2, 2, 2, 2), TBR(8, 1, 4, 2, 2), TBR(6, 2, 3, 2, 3),
 };
-// The speculative launches A (MODE 1: T accumulator registers more, hence one wave/SIMD less at T = 10) and B (MODE 2) of the
-// convergence-checked path, for the block sizes its plan uses.
-#define TBRS(T, PPL, WPS, PF, PLAN, WPSA) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPSA, PF, 1>, launch_tbr<T, PPL, WPS, PF, 2>}
-static const TbrEntry g_spec[] = {TBRS(10, 1, 4, 2, 3, 3), TBRS(5, 1, 6, 2, 4, 4), TBRS(2, 1, 8, 2, 8, 8), TBRS(1, 1, 8, 2, 8, 8)};
+// The speculative steps (MODE 1: T accumulator registers more, hence one wave/SIMD less than MODE 0 at T = 10).
+#define TBRS(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1>}
+static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 3), TBRS(5, 1, 4, 2, 4)};
 
 // First entry of time block T, or the entry matching MIFLOW_TB_VARIANT=ppl,wps,pf.  Returns nullptr if T has none.
 static const TbrEntry *tbr_pick(int T)
@@ -527,24 +574,26 @@ int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta
     return e->launch(A, p_zero, s);
 }
 
-// Block sizes the speculative path may use (those with MODE 1 / 2 instantiations)
-int tb_spec_plan(int n, int *blocks, int max_blocks)
+// Kernel block sizes of a warp's speculative steps (MODE 1 instantiations: 10 and 5).  The first warp of a scale needs the most
+// iterations, the later ones a few (the flow is nearly there): they start with two short blocks.  The plan covers
+// n + 3 x 10 iterations so that blocks cut short by the device's estimate cannot make the iteration limit unreachable.
+int tb_spec_plan(int n, int warp_index, int *blocks, int max_blocks)
 {
-    static const int sup[] = {10, 5, 2, 1};
-    int k = 0;
-    for (int left = n; left > 0 && k < max_blocks;) {
-        int t = 1;
-        for (int c : sup) if (c <= left) { t = c; break; }
+    int k = 0, sum = 0;
+    if (n <= 0) return 0;
+    const int want = n + (n > 10 ? 30 : n > 1 ? 10 : 0);
+    while (sum < want && k < max_blocks) {
+        const int t = (warp_index > 0 && k < 2) || n <= 5 ? 5 : 10;
         blocks[k++] = t;
-        left -= t;
+        sum += t;
     }
     return k;
 }
 
-// Launch A (mode 1) or B (mode 2) of a speculative block of T iterations; ctl carries the slot protocol, e0 the index of the
-// block's first per-iteration error sum.
-int iterate_tb_spec(int T, int mode, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, const Ctl &ctl,
-                    int e0, hipStream_t s)
+// One speculative step with kernel block size T (see k_iterate_tbr MODE 1); ctl carries the slot protocol, sk the step's
+// constants, e0 the index of the first per-iteration error sum this launch may write.
+int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, const Ctl &ctl,
+                    const SpecK &sk, int e0, hipStream_t s)
 {
     const TbrEntry *e = nullptr;
     for (const TbrEntry &c : g_spec) if (c.T == T) e = &c;
@@ -554,7 +603,8 @@ int iterate_tb_spec(int T, int mode, const IterPlanes &pl, const Geo &g, float l
     A.rows_per_band = plan_band_rows(*e, g);
     A.ctl = make_ctlk(&ctl);
     A.e0 = e0;
-    return (mode == 1 ? e->spec_a : e->spec_b)(A, p_zero, s);
+    A.sk = sk;
+    return e->spec(A, p_zero, s);
 }
 
 // self-test of the DPP wave-shift semantics the kernels rely on (tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics)

@@ -31,11 +31,12 @@ class OpticalFlowDual_TVL1:
     @staticmethod
     def create(tau=0.25, lambda_=0.15, theta=0.3, nscales=5, warps=5, epsilon=0.01, iterations=300,
                scaleStep=0.8, gamma=0.0, useInitialFlow=False, *, semantics=None, exactMath=None, innerIterations=1,
-               medianFiltering=1, timeBlock=0, lanes=0) -> "OpticalFlowDual_TVL1":
+               medianFiltering=1, timeBlock=0, lanes=0, stopSlack=0) -> "OpticalFlowDual_TVL1":
         """The keyword-only arguments are miflow extensions; None = the library default (mi_tvl1_default_params):
         semantics MI_SEM_CPU_REF (the arithmetic of the CPU class, the acceptance reference; MI_SEM_CUDA_COMPAT = cv::cuda's
         own kernels, ~0.1 px mean EPE away, mostly at borders), fast device math (exactMath=True: IEEE operations in the
-        reference's order, one iteration per launch)."""
+        reference's order, one iteration per launch); stopSlack > 0 lets the convergence-checked loop run up to that many
+        iterations past the reference's stopping point (mi_tvl1_params.stop_slack)."""
         p = capi.TVL1Params()
         capi.lib().mi_tvl1_default_params(C.byref(p))
         p.tau, p.lambda_, p.theta, p.nscales, p.warps = tau, lambda_, theta, nscales, warps
@@ -46,6 +47,7 @@ class OpticalFlowDual_TVL1:
         if exactMath is not None:
             p.exact_math = int(bool(exactMath))
         p.inner_iterations, p.median_filtering, p.time_block, p.lanes = innerIterations, medianFiltering, timeBlock, lanes
+        p.stop_slack = stopSlack
         return OpticalFlowDual_TVL1(p)
 
     def __del__(self):

@@ -178,6 +178,24 @@ def test_class_defaults_speculative_convergence(gpu, oracle, sem, shape, seed):
     np.testing.assert_array_equal(flow, flow2)
 
 
+def test_stop_slack_runs_at_most_a_few_more_iterations(gpu, oracle):
+    """mi_tvl1_params.stop_slack = 1 (miflow extension, off by default): a speculative block is kept when the reference's test
+    first passed one iteration before its end.  Counts stay within the slack (+ the knock-on of a slightly different start of
+    the following warps) of the exact run, the flow within the change of one converged iteration."""
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(388, 584, seed=78)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=300))
+    exact = cuda.OpticalFlowDual_TVL1.create()
+    loose = cuda.OpticalFlowDual_TVL1.create(stopSlack=1)
+    f0, f1 = N(exact.calc(T(I0, gpu), T(I1, gpu))), N(loose.calc(T(I0, gpu), T(I1, gpu)))
+    i0, i1 = np.array(exact.lastIterations()), np.array(loose.lastIterations())
+    assert np.abs(i1 - i0).max() <= 2, (i0.tolist(), i1.tolist())
+    assert i1.sum() >= i0.sum() - 2
+    assert np.sqrt(((f1 - f0) ** 2).sum(-1)).mean() <= 1.5e-2
+    assert np.sqrt(((f1 - ref) ** 2).sum(-1)).mean() <= 2e-2
+    np.testing.assert_array_equal(f1, N(loose.calc(T(I0, gpu), T(I1, gpu))))
+
+
 def test_speculative_equals_fixed_work_when_nothing_converges(gpu):
     """With an unreachable threshold every speculative block is accepted: the result must be bit-identical to the fixed-work
     run of the same iteration count (same kernels, MODE 1 vs MODE 0), for a count that is not a multiple of the block size."""

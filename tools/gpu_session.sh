@@ -55,7 +55,35 @@ trace_defaults)
 tests_batch)
   (timeout 600 python -m pytest tests/test_farneback.py tests/test_stereobm.py tests/test_cpp_shim.py tests/test_tvl1_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -30) > $O/pytest_batch.log; cat $O/pytest_batch.log
   (timeout 300 python bench.py --workload farneback --steps 3 2>$O/fb.err | tail -1) > $O/farneback_bench.json; cut -c1-1200 $O/farneback_bench.json; tail -3 $O/fb.err ;;
+trace_fb)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace_fb -- python $R/bench.py --workload farneback --no-cpu --steps 3 --warmup 1 > $R/$O/trace_fb_bench.log 2>&1
+  cd $R
+  tail -1 $O/trace_fb_bench.log | cut -c1-900
+  for f in $(find $O/trace_fb -name "*kernel_stats.csv" | head -1); do cp $f $O/kernel_stats_farneback.csv; head -16 $f | cut -c1-220; done
+  find $O -type f -size +4M -delete ;;
+spec_quick)
+  for sl in 0 1; do
+    (timeout 300 python bench.py --defaults --stop-slack $sl --no-variants --no-cpu --no-secondary --steps 4 --warmup 2 2>$O/spec_sl$sl.err | tail -1) > $O/spec_sl$sl.json
+    python - <<PY
+import json
+try:
+    d = json.loads(open('$O/spec_sl$sl.json').read()); print('class defaults stop_slack=$sl', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step', 'its', d['config']['executed_iterations_per_warp_mean'], 'epe', d['epe_vs_analytic_flow_px'])
+except Exception as e: print('spec_quick $sl failed', e); print(open('$O/spec_sl$sl.err').read()[-1500:])
+PY
+  done ;;
+fb_quick)
+  (timeout 600 python -m pytest tests/test_farneback.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -8) > $O/pytest_fb.log; cat $O/pytest_fb.log
+  for t in 1 0; do
+    (MIFLOW_FB_TILED=$t timeout 300 python bench.py --workload farneback --no-cpu --steps 3 2>$O/fb$t.err | tail -1) > $O/farneback_bench_tiled$t.json
+    python - <<PY
+import json
+try:
+    d = json.loads(open('$O/farneback_bench_tiled$t.json').read()); print('farneback tiled=$t', round(d['value'], 1), 'pairs/s sequential;', d['batched_calc_batch'])
+except Exception as e: print('fb_quick $t failed', e); print(open('$O/fb$t.err').read()[-1500:])
+PY
+  done ;;
 test_one)
-  (timeout 600 python -m pytest "tests/test_baseline_sizes.py" -m gpu -q -x -p no:cacheprovider -k "two_lanes or speculative" 2>&1 | tail -30) > $O/pytest_one.log; cat $O/pytest_one.log ;;
+  (timeout 600 python -m pytest "tests/test_baseline_sizes.py" -m gpu -q -x -p no:cacheprovider -k "two_lanes or speculative or slack or class_defaults" 2>&1 | tail -30) > $O/pytest_one.log; cat $O/pytest_one.log ;;
 esac
 done
