@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *
     for (int i = tx; i < 256 + 2 * kh; i += 256) {
         const int xe = bidx<BORDER>((int)(blockIdx.x * 256) + i - kh, w);
         float v = src[(long long)y * ld + xe] * K.k[0];
+        // unrolled so that the loads of four tap pairs are in flight together (the sum itself stays in the reference's order)
+#pragma unroll 4
         for (int j = 1; j <= kh; ++j)
             v += (src[(long long)bidx<BORDER>(y - j, h) * ld + xe] + src[(long long)bidx<BORDER>(y + j, h) * ld + xe]) * K.k[j];
         row[i] = v;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(256) void k_iterate(const float *M, const float *R0
         for (int k = 0; k < 5; ++k) {
             const float *P = M + k * ps;
             float v = GAUSS ? P[(long long)y * ld + xe] * K.k[0] : P[(long long)y * ld + xe];
+#pragma unroll 4
             for (int j = 1; j <= kh; ++j) {
                 const float s = P[(long long)max(y - j, 0) * ld + xe] + P[(long long)min(y + j, h - 1) * ld + xe];
                 v += GAUSS ? s * K.k[j] : s;
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(256) void k_blur5(const float *M, float *dst, int w
         for (int k = 0; k < 5; ++k) {
             const float *P = M + k * ps;
             float v = GAUSS ? P[(long long)y * ld + xe] * K.k[0] : P[(long long)y * ld + xe];
+#pragma unroll 4
             for (int j = 1; j <= kh; ++j) {
                 const float s = P[(long long)max(y - j, 0) * ld + xe] + P[(long long)min(y + j, h - 1) * ld + xe];
                 v += GAUSS ? s * K.k[j] : s;

@@ -17,6 +17,11 @@ MI_API int miflow_selftest_wave_scan(const unsigned *in_host, unsigned *out_host
 /* out_host[0..63] = value received from lane n-1, out_host[64..127] = from lane n+1 when every lane n contributes n+100
  * (DPP wave shifts of the blocked TV-L1 kernels) */
 MI_API int miflow_selftest_lane_shift(int *out_host /*[128]*/);
+/* Control slots of pair `pair` of the last convergence-checked calc: per launch 8 ints {scale, warp, S.x, S.y, X.x, X.y, X.z,
+ * X.w} (tvl1_dev.h); returns the launch count or a negative status.  Used by tools/spec_trace.py to inspect the decisions of the
+ * speculative steps; synchronises `stream`. */
+struct mi_tvl1;
+MI_API int miflow_selftest_tvl1_slots(struct mi_tvl1 *h, int pair, int *out_host, int cap_launches, void *stream);
 #ifdef __cplusplus
 }
 #endif

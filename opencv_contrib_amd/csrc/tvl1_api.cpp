@@ -3,6 +3,7 @@
 // (modules/cudaoptflow/src/tvl1flow.cpp:185-382; CPU modules/optflow/src/tvl1flow.cpp:402-533,
 // 1313-1408) -- but fully stream-ordered: no host read-back inside the iteration loop.
 #include "tvl1_dev.h"
+#include "mi_selftest.h"
 #include <cfloat>
 #include <algorithm>
 #include <cmath>
@@ -337,19 +338,19 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     const bool spec = check && !P.exact_math && P.time_block != 1 && P.gamma == 0.0 && P.median_filtering <= 1 && tuning().spec != 0;
     // control slots per pair: one per launch (S, P, X) and one error sum per iteration (E); both index spaces fit max(.,.)
     long long Q = (long long)ns * P.warps * iters_per_warp;
-    std::vector<int> spec_plan[2];   // kernel block sizes of the speculative steps: first warp of a scale / later warps
+    std::vector<int> spec_plan[3];   // kernel block sizes of the speculative steps: first warp of a large level / of a small one / later warps
+    const double kLargeLevel = 12e6;   // px x pairs from which the T = 10 kernel pays for a long first block
     if (spec) {
-        long long e_sum = 0, launches = 0;
-        for (int k = 0; k < 2; ++k) {
-            spec_plan[k].resize(iters_per_warp + 8);
-            spec_plan[k].resize(tb_spec_plan(iters_per_warp, k, spec_plan[k].data(), (int)spec_plan[k].size()));
+        long long e_max = 0, l_max = 0;
+        for (int k = 0; k < 3; ++k) {
+            spec_plan[k].resize(iters_per_warp + 40);
+            spec_plan[k].resize(tb_spec_plan(iters_per_warp, k == 2 ? 1 : 0, k == 0, spec_plan[k].data(), (int)spec_plan[k].size()));
             long long t = 0;
             for (int v : spec_plan[k]) t += v;
-            const long long nw = k == 0 ? 1 : P.warps - 1;
-            e_sum += nw * t;
-            launches += nw * ((long long)spec_plan[k].size() + 1);
+            e_max = std::max(e_max, t);
+            l_max = std::max(l_max, (long long)spec_plan[k].size() + 1);
         }
-        Q = std::max((long long)ns * e_sum, (long long)ns * launches);
+        Q = std::max((long long)ns * P.warps * e_max, (long long)ns * P.warps * l_max);
     }
     if (check) {
         MI_REQUIRE(Q <= kMaxSlots, MI_ERR_BAD_ARG, "scales x warps x iterations = %lld control slots exceed the limit of %lld", Q, kMaxSlots);
@@ -426,7 +427,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
 
     int q = 0, q_last = -1;   // device-control slot counters
     int e_next = 0;           // next per-iteration error-sum index (speculative path)
-    int q_settle_prev = -1, q_settle_prev2 = -1, q_settle_scale = -1;   // settling launches of the previous warp / of the coarser scale's first warp
+    int q_settle_prev = -1, q_settle_scale = -1;   // settling launches of the previous warp / of the coarser scale's first warp
     int cur = 0;              // host-known buffer set (fixed-work mode)
     Ctl ctl;
     memset(&ctl, 0, sizeof(ctl));
@@ -503,7 +504,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // Speculative steps (k_iterate_tbr MODE 1): a launch runs a block of iterations recording their error sums; the next
                 // launch applies the reference's stopping rule to them and either builds on the block or replays the exact
                 // count from its input.  One settling launch ends the warp.  After convergence the remaining launches end at once.
-                const std::vector<int> &plan = spec_plan[wp > 0 ? 1 : 0];
+                const std::vector<int> &plan = spec_plan[wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
                 int t_after = 0;
                 for (int v : plan) t_after += v;
                 SpecK sk;
@@ -513,9 +514,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // warp of a scale needs about half of the first, later warps slightly fewer than their predecessor, the first
                 // warp of a scale about 0.7 of the first warp one scale coarser)
                 sk.q_hist = wp > 0 ? q_settle_prev : q_settle_scale;
-                sk.q_hist2 = wp > 2 ? q_settle_prev2 : -1;   // ... and never fewer than the warp before that (counts alternate)
-                sk.hist_num = wp == 0 ? 7 : wp == 1 ? 1 : 1;
-                sk.hist_den = wp == 0 ? 10 : wp == 1 ? 2 : 1;
+                sk.hist_num = wp == 0 ? 7 : wp == 1 ? 9 : 4;
+                sk.hist_den = wp == 0 ? 10 : wp == 1 ? 20 : 5;
                 sk.slack = P.stop_slack;
                 if (first_of_scale) {   // a replay of the scale's first block must see p = 0 in the input set as well
                     for (int j = 0; j < 4; ++j) MI_HIP_TRY(hipMemsetAsync(ln.pbuf[0][j], 0, sizeof(float) * (size_t)g.ps * B, st));
@@ -528,7 +528,6 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     Ctl a = ctl;
                     a.q = q; a.q_prev = q_last; a.first_of_warp = (k == 0); a.reset_cur = (k == 0 && first_of_scale); a.n = 0;
                     sk.e0_prev = e_prev; sk.final_launch = last ? 1 : 0; sk.t_after = t_after;
-                    sk.defer = (!last && T < 10 && k + 1 < plan.size()) ? 1 : 0;
                     rc = iterate_tb_spec(T, pl, g, l_t, theta, taut, false, a, sk, e_next, st);
                     if (rc) return rc;
                     ln.slots.push_back({s, wp});
@@ -537,7 +536,6 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     e_prev = e_next;
                     if (!last) e_next += T;
                 }
-                q_settle_prev2 = wp > 0 ? q_settle_prev : -1;
                 q_settle_prev = q_last;
                 if (wp == 0) q_settle_scale = q_last;
                 first_of_scale = false;
@@ -669,4 +667,26 @@ int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int *iters,
         iters[ln.slots[i].scale * nw + ln.slots[i].warp] += k ? k : (S[i].y & 1);
     }
     return MI_OK;
+}
+
+int miflow_selftest_tvl1_slots(mi_tvl1 *h, int pair, int *out_host, int cap_launches, void *stream)
+{
+    MI_REQUIRE(h && out_host, MI_ERR_BAD_ARG, "null argument");
+    MI_REQUIRE(pair >= 0 && pair < h->last_batch, MI_ERR_BAD_ARG, "pair out of range");
+    if (!h->last_check) return 0;
+    Lane &ln = h->lane[(h->last_lanes == 2 && pair >= h->last_split) ? 1 : 0];
+    const int lp = (h->last_lanes == 2 && pair >= h->last_split) ? pair - h->last_split : pair;
+    const int nq = (int)ln.slots.size();
+    MI_REQUIRE(nq <= cap_launches, MI_ERR_BAD_ARG, "capacity too small");
+    std::vector<int2> S(nq);
+    std::vector<int4> X(nq);
+    MI_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    MI_HIP_TRY(hipMemcpy(S.data(), ln.S + (size_t)lp * ln.Q, sizeof(int2) * nq, hipMemcpyDeviceToHost));
+    if (ln.X) MI_HIP_TRY(hipMemcpy(X.data(), ln.X + (size_t)lp * ln.Q, sizeof(int4) * nq, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nq; ++i) {
+        int *o = out_host + 8 * i;
+        o[0] = ln.slots[i].scale; o[1] = ln.slots[i].warp; o[2] = S[i].x; o[3] = S[i].y;
+        o[4] = X[i].x; o[5] = X[i].y; o[6] = X[i].z; o[7] = X[i].w;
+    }
+    return nq;
 }

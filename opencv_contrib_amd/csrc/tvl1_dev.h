@@ -85,19 +85,17 @@ int tb_max_block();
 // Speculative step of the convergence-checked path (k_iterate_tbr MODE 1), host-side constants of one launch.
 struct SpecK {
     int4 *X;            // per slot: {iterations accepted in this warp, iterations this launch ran speculatively (0: none),
-                        //            bits of the last accepted iteration's error / threshold, block length deferred to the next launch}
+                        //            bits of the last accepted iteration's error / threshold, unused}
     int e0_prev;        // first error-sum index of the previous launch's block
     int final_launch;   // 1: settle the previous block (accept / replay) only -- the last launch of a warp
     int iters;          // iteration limit of the warp (iterations x inner iterations)
     int t_after;        // iterations the later launches of this warp can still run (keeps the limit reachable)
     int q_hist;         // slot whose X.x = iteration count of an earlier warp: the first block's estimate is
-    int hist_num, hist_den;   //   ceil(count * num / den) (-1: none),
-    int q_hist2;        //   and at least the count in this slot (-1: none)
+    int hist_num, hist_den;   //   floor(count * num / den), at least 1 (-1: none)
     int slack;          // mi_tvl1_params.stop_slack
-    int defer;          // 1: when the estimate exceeds this kernel's block size, leave the block to the next launch (a longer kernel)
 };
 
-int tb_spec_plan(int n, int warp_index, int *blocks, int max_blocks);
+int tb_spec_plan(int n, int warp_index, bool large_level, int *blocks, int max_blocks);
 int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, const Ctl &ctl,
                     const SpecK &sk, int e0, hipStream_t s);
 // cost-model decomposition of n iterations into supported blocks (largest first); returns the count

@@ -306,7 +306,6 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
         int base = 0, done = 0, n = 0, replay = 0, accepted = 0, pbase = 0;
         double prev = 0.0;                    // cv::cuda's prevError
         float e_last = 0.f, e_before = 0.f;   // error / threshold of the last two accepted iterations (0: unknown)
-        int deferred = 0;                     // block length the previous launch wanted but left to this one
         if (ck.q_prev >= 0) {
             const long long sp = (long long)b * ck.Q + ck.q_prev;
             const int2 sl = ck.S[sp];
@@ -319,9 +318,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
                 e_last = __int_as_float(px.z);
                 if (sl.y & MI_SLOT_DONE) {
                     done = 1;
-                } else if (px.y == 0) {
-                    deferred = px.w;
-                } else {
+                } else if (px.y > 0) {
                     const int pn = px.y;
                     int kk = 0, conv = 0;
                     for (int t = 0; t < pn; ++t) {
@@ -347,40 +344,32 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
             }
         }
         if (ck.reset_cur) base = pbase = 0;
-        int nit = 0, want = 0;
+        int nit = 0;
         if (replay) {
             nit = replay;
         } else if (!done && !sk.final_launch) {
             // block length: an estimate of the iterations still needed.  ANY value in [lo, hi] gives the same results; a good one
-            // avoids both a replay (too long) and extra passes (too short).
+            // avoids both a replay (too long) and extra passes (too short).  A pass costs nearly the same whatever its length
+            // (it is bound by its 64 B/px), so what counts is the number of passes.
             int pred = T;
-            if (deferred > 0) {
-                pred = deferred;
-            } else if (!ck.sched) {
+            if (!ck.sched) {
                 if (ck.first_of_warp) {
-                    if (sk.q_hist >= 0) pred = (sk.X[(long long)b * ck.Q + sk.q_hist].x * sk.hist_num + sk.hist_den - 1) / sk.hist_den;
-                    if (sk.q_hist2 >= 0) pred = max(pred, sk.X[(long long)b * ck.Q + sk.q_hist2].x);
+                    if (sk.q_hist >= 0) pred = (sk.X[(long long)b * ck.Q + sk.q_hist].x * sk.hist_num) / sk.hist_den;
                 } else if (e_before > e_last && e_last > 1.f) {
-                    // geometric decay of the error sum; the decay slows down, and a block that is too long costs exactly one
-                    // more pass (the replay) while one that is too short may cost several: round up
-                    pred = (int)ceilf(__logf(e_last) / __logf(e_before / e_last)) + 1;
+                    pred = (int)ceilf(__logf(e_last) / __logf(e_before / e_last));   // geometric decay of the error sum
                 } else if (e_last > 0.f) {
                     pred = 2;
                 }
             }
             const int hi = min(T, sk.iters - n), lo = max(1, sk.iters - n - sk.t_after);
-            if (sk.defer && pred > T && sk.iters - n <= sk.t_after) {
-                want = pred;   // a kernel with a longer block follows: one pass there instead of two
-            } else {
-                nit = max(lo, min(hi, pred));
-                record = true;
-            }
+            nit = max(lo, min(hi, pred));
+            record = true;
         }
         if (strip == 0 && bgrp == 0 && threadIdx.x == 0) {   // the REMAPPED indices: one writer per pair b
             const long long sq = (long long)b * ck.Q + ck.q;
             ck.S[sq] = make_int2(replay ? pbase : base, (replay ? MI_SLOT_FLIP : 0) | (done ? MI_SLOT_DONE : 0) | (accepted << 8));
             ck.P[sq] = prev;
-            sk.X[sq] = make_int4(n, record ? nit : 0, __float_as_int(e_last), want);
+            sk.X[sq] = make_int4(n, record ? nit : 0, __float_as_int(e_last), 0);
         }
         if (nit == 0) return;
         cur = replay ? pbase : base;
@@ -476,7 +465,9 @@ static const TbrEntry g_tbr[] = {
 };
 // The speculative steps (MODE 1: T accumulator registers more, hence one wave/SIMD less than MODE 0 at T = 10).
 #define TBRS(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1>}
-static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 3), TBRS(5, 1, 4, 2, 4)};
+// PLAN = 2: the bands are cut for two waves per SIMD -- fewer, taller bands (less halo) than the fixed-work kernels use; the other
+// lane's kernels fill the rest of the device (r02m at 1080p x 16, class defaults: 517 -> 545 pairs/s; fixed work loses 7 %).
+static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 2), TBRS(5, 1, 4, 2, 2)};
 
 // First entry of time block T, or the entry matching MIFLOW_TB_VARIANT=ppl,wps,pf.  Returns nullptr if T has none.
 static const TbrEntry *tbr_pick(int T)
@@ -574,16 +565,18 @@ int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta
     return e->launch(A, p_zero, s);
 }
 
-// Kernel block sizes of a warp's speculative steps (MODE 1 instantiations: 10 and 5).  The first warp of a scale needs the most
-// iterations, the later ones a few (the flow is nearly there): they start with two short blocks.  The plan covers
-// n + 3 x 10 iterations so that blocks cut short by the device's estimate cannot make the iteration limit unreachable.
-int tb_spec_plan(int n, int warp_index, int *blocks, int max_blocks)
+// Kernel block sizes of a warp's speculative steps (MODE 1 instantiations: 10 and 5).  A pass of the T = 5 kernel costs half
+// of a T = 10 pass on the small pyramid levels and two thirds on a large one (profiles/r02k), and most warps settle within a few
+// iterations: only the first warp of a LARGE level (px x pairs >= 12M) starts with the long kernel; after twelve short blocks
+// the plan continues with long ones to bound the launch count.  It covers n + 30 iterations so that blocks cut short by the
+// device's estimate cannot make the iteration limit unreachable.
+int tb_spec_plan(int n, int warp_index, bool large_level, int *blocks, int max_blocks)
 {
     int k = 0, sum = 0;
     if (n <= 0) return 0;
     const int want = n + (n > 10 ? 30 : n > 1 ? 10 : 0);
     while (sum < want && k < max_blocks) {
-        const int t = (warp_index > 0 && k < 2) || n <= 5 ? 5 : 10;
+        const int t = n <= 5 ? 5 : (large_level && warp_index == 0) ? 10 : k < 12 ? 5 : 10;
         blocks[k++] = t;
         sum += t;
     }

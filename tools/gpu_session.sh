@@ -83,6 +83,54 @@ try:
 except Exception as e: print('fb_quick $t failed', e); print(open('$O/fb$t.err').read()[-1500:])
 PY
   done ;;
+ab_planwps)
+  for wps in 0 2 1; do
+    for mode in fixed defaults; do
+      extra=""; [ $mode = defaults ] && extra="--defaults"
+      (MIFLOW_TB_WPS=$wps timeout 300 python bench.py $extra --no-variants --no-cpu --no-secondary --steps 6 --warmup 2 2>$O/ab_wps${wps}_$mode.err | tail -1) > $O/ab_wps${wps}_$mode.json
+      python - <<PY
+import json
+try:
+    d = json.loads(open('$O/ab_wps${wps}_$mode.json').read()); print('plan wps=$wps $mode', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step')
+except Exception as e: print('ab_planwps $wps $mode failed', e); print(open('$O/ab_wps${wps}_$mode.err').read()[-1500:])
+PY
+    done
+  done ;;
+trace_tb5)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace_tb5 -- python $R/bench.py --time-block 5 --no-variants --no-cpu --no-secondary --steps 3 --warmup 1 > $R/$O/trace_tb5_bench.log 2>&1
+  cd $R
+  python - <<PY
+import csv, glob, collections
+f = glob.glob('$O/trace_tb5/*/*kernel_trace.csv')[0]
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(f)):
+    n = r['Kernel_Name']
+    if 'tbr' in n:
+        key = (n[:44], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
+        a = agg.setdefault(key, [0, 0]); a[0] += 1; a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000
+for k, v in agg.items(): print(k, v[0], round(v[1] / v[0], 1))
+PY
+  find $O -type f -size +4M -delete ;;
+pmc_sq)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -f csv -d $R/$O/pmc_sq -- python $R/bench.py --lanes 1 --no-variants --no-cpu --no-secondary --steps 2 --warmup 1 > $R/$O/pmc_sq.log 2>&1
+  cd $R
+  python - <<PY
+import csv, glob, collections
+fs = glob.glob('$O/pmc_sq/*/*counter_collection.csv')
+print(fs)
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for r in csv.DictReader(open(fs[0])):
+    k = r['Kernel_Name'][:48]
+    agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+for k, v in agg.items():
+    w = v.get('SQ_WAVE_CYCLES', 0) or 1
+    print(k, {n: round(x / w, 3) for n, x in v.items()}, 'wave_cycles', w)
+PY
+  find $O -type f -size +4M -delete ;;
+spec_trace)
+  (timeout 300 python tools/spec_trace.py --pairs 4 2>&1 | tail -120) > $O/spec_trace.log; head -70 $O/spec_trace.log ;;
 test_one)
   (timeout 600 python -m pytest "tests/test_baseline_sizes.py" -m gpu -q -x -p no:cacheprovider -k "two_lanes or speculative or slack or class_defaults" 2>&1 | tail -30) > $O/pytest_one.log; cat $O/pytest_one.log ;;
 esac
