@@ -560,7 +560,7 @@ def main():
                         "kernels share the GPU during these intervals (the rocprofv3 kernel trace shows the same durations)"}
     else:
         kname = "k_iterate (fused estimateU+estimateDualVariables, one iteration per launch)" if not blocked else \
-            "k_iterate_tbr MODE 1/2 (speculative blocks of the convergence-checked path)"
+            "k_iterate_tbr MODE 1 (speculative steps of the convergence-checked path: block, settle, replay)"
         roof = {"bound": "hbm", "kernel": kname, "achieved": hbm_it["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (hbm_it["algorithmic_GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it, "hbm": hbm_it}
@@ -634,6 +634,13 @@ def main():
                 ach1 = px_iter_timed / (p_it[0] * 1e-3) * slots * lanes_per_px / 1e12
                 var["iterations10_eps0_one_lane"]["iterate_valu_issue_frac"] = ach1 / VALU_PEAK_TLIPS
                 var["iterations10_eps0_one_lane"]["iterate_pixel_iterations_per_s"] = px_iter_timed / (p_it[0] * 1e-3)
+            if "iterate_valu_issue_frac" in var["iterations10_eps0_one_lane"]:
+                # the same kernel with the GPU to itself (no second lane): the figure that describes the kernel rather than the overlap
+                out["roofline"]["isolated_one_lane"] = {
+                    "frac": var["iterations10_eps0_one_lane"]["iterate_valu_issue_frac"],
+                    "avg_launch_us": var["iterations10_eps0_one_lane"]["iterate_avg_launch_us"],
+                    "pixel_iterations_per_s": var["iterations10_eps0_one_lane"]["iterate_pixel_iterations_per_s"],
+                    "sq_counters": "profiles/r02p/pmc_sq_summary.md (VALU active 0.46, issue-stalled 0.30, parked on waitcnt 0.07 of the wave cycles)"}
         except Exception as e:
             var["iterations10_eps0_one_lane"] = {"error": repr(e)[:200]}
         # SURVEY 8d config 2 "also run CV_8UC1": the same batch as 8-bit frames (the class converts them to f32 once per calc)

@@ -1,5 +1,6 @@
 // Internal helpers shared by the miflow translation units (not part of the C-ABI).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
@@ -46,6 +47,23 @@ struct Tuning {
 const Tuning &tuning();
 
 // SIMDs of the current device (4 per CU; 1024 on MI355X), queried once per device
+// Temporary device buffers of the stage-level / self-test entry points: freed on every return path.
+struct DevTmp {
+    std::vector<void *> bufs;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() { for (void *p : bufs) (void)hipFree(p); }
+    template <class T>
+    hipError_t alloc(T **out, size_t n)
+    {
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, sizeof(T) * n);
+        if (e == hipSuccess) bufs.push_back(p);
+        *out = (T *)p;
+        return e;
+    }
+};
 int device_simds();
 
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }

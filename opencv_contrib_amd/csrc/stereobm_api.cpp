@@ -211,23 +211,24 @@ int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, float av
     int sld, sh;
     sbm::textureness_scratch_dims(img->rows, img->cols, &sld, &sh);
     int *S = nullptr;
-    MI_HIP_TRY(hipMalloc((void **)&S, sizeof(int) * (size_t)sld * sh));
+    DevTmp tmp;
+    MI_HIP_TRY(tmp.alloc(&S, (size_t)sld * sh));
     rc = sbm::textureness((const unsigned char *)img->data, (long long)img->step, (unsigned char *)disp->data,
                           (long long)disp->step, img->rows, img->cols, winsz, avg_texture_threshold, S, (hipStream_t)stream);
-    (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(S);
-    return rc;
+    if (rc) return rc;
+    MI_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // S is freed on return
+    return MI_OK;
 }
 
 int miflow_selftest_tmax16(const unsigned *in_host, unsigned *out_host)
 {
     MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
     unsigned *d = nullptr;
-    MI_HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned) * (1024 + 64)));
+    DevTmp tmp;
+    MI_HIP_TRY(tmp.alloc(&d, 1024 + 64));
     MI_HIP_TRY(hipMemcpy(d, in_host, sizeof(unsigned) * 1024, hipMemcpyHostToDevice));
     int rc = sbm::dbg_tmax16(d, d + 1024, nullptr);
     if (!rc) { MI_HIP_TRY(hipDeviceSynchronize()); MI_HIP_TRY(hipMemcpy(out_host, d + 1024, sizeof(unsigned) * 64, hipMemcpyDeviceToHost)); }
-    (void)hipFree(d);
     return rc;
 }
 
@@ -235,11 +236,11 @@ int miflow_selftest_wave_min(const unsigned *in_host, unsigned *out_host)
 {
     MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
     unsigned *d = nullptr;
-    MI_HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned) * 192));
+    DevTmp tmp;
+    MI_HIP_TRY(tmp.alloc(&d, 192));
     MI_HIP_TRY(hipMemcpy(d, in_host, sizeof(unsigned) * 64, hipMemcpyHostToDevice));
     int rc = sbm::dbg_wave_min(d, d + 64, nullptr);
     if (!rc) { MI_HIP_TRY(hipDeviceSynchronize()); MI_HIP_TRY(hipMemcpy(out_host, d + 64, sizeof(unsigned) * 65, hipMemcpyDeviceToHost)); }
-    (void)hipFree(d);
     return rc;
 }
 

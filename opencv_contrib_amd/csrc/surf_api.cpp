@@ -256,13 +256,14 @@ int mi_surf_integral(mi_surf *h, const mi_mat *img, int clamp_to_one, mi_mat *su
                MI_ERR_BAD_ARG, "sum must be CV_32SC1 (rows+1) x (cols+1)");   // cuda::integral, cudaarithm/src/cuda/integral.cu:62-83
     const int vld = align_up(img->cols, 64);
     unsigned *V = nullptr, *BT = nullptr;
-    MI_HIP_TRY(hipMalloc((void **)&V, sizeof(unsigned) * (size_t)vld * img->rows));
-    MI_HIP_TRY(hipMalloc((void **)&BT, sizeof(unsigned) * (size_t)vld * surf::integral_bands(img->rows)));
+    DevTmp tmp;
+    MI_HIP_TRY(tmp.alloc(&V, (size_t)vld * img->rows));
+    MI_HIP_TRY(tmp.alloc(&BT, (size_t)vld * surf::integral_bands(img->rows)));
     rc = surf::integral((const unsigned char *)img->data, (long long)img->step, img->rows, img->cols, clamp_to_one != 0, V, BT, vld,
                         (unsigned *)sum->data, (int)(sum->step / 4), st);
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(V); (void)hipFree(BT);
-    return rc;
+    if (rc) return rc;
+    MI_HIP_TRY(hipStreamSynchronize(st));   // the temporaries are freed on return: the kernels must be done (and their faults seen)
+    return MI_OK;
 }
 
 int mi_surf_det_trace(mi_surf *h, const mi_mat *sum, int octave, int n_octave_layers, mi_mat *det, mi_mat *trace, void *stream)
@@ -282,11 +283,11 @@ int miflow_selftest_wave_scan(const unsigned *in_host, unsigned *out_host)
 {
     MI_REQUIRE(in_host && out_host, MI_ERR_BAD_ARG, "null argument");
     unsigned *d = nullptr;
-    MI_HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned) * 128));
+    DevTmp tmp;
+    MI_HIP_TRY(tmp.alloc(&d, 128));
     MI_HIP_TRY(hipMemcpy(d, in_host, sizeof(unsigned) * 64, hipMemcpyHostToDevice));
     int rc = surf::dbg_scan(d, d + 64, nullptr);
     if (!rc) { MI_HIP_TRY(hipDeviceSynchronize()); MI_HIP_TRY(hipMemcpy(out_host, d + 64, sizeof(unsigned) * 64, hipMemcpyDeviceToHost)); }
-    (void)hipFree(d);
     return rc;
 }
 

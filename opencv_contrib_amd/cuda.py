@@ -13,6 +13,17 @@ from . import capi
 from .capi import MiError
 
 
+
+def _destroy(obj, fn_name):
+    """Shared __del__ body of the handle wrappers: never raises (interpreter shutdown, failed __init__, library gone)."""
+    try:
+        h = getattr(obj, "_h", None)
+        if h is not None and getattr(h, "value", h):
+            getattr(capi.lib(), fn_name)(h)
+        obj._h = None
+    except Exception:
+        pass
+
 class OpticalFlowDual_TVL1:
     """cv::cuda::OpticalFlowDual_TVL1 (cudaoptflow.hpp:305-386).
 
@@ -332,9 +343,7 @@ class DensePyrLKOpticalFlow:
         return cls(winSize, maxLevel, iters, useInitialFlow)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            capi.lib().mi_densepyrlk_destroy(self._h)
-            self._h = None
+        _destroy(self, "mi_densepyrlk_destroy")
 
     def _set(self, **kw):
         for k, v in kw.items():
@@ -377,9 +386,7 @@ class SparsePyrLKOpticalFlow:
         return cls(winSize, maxLevel, iters, useInitialFlow)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            capi.lib().mi_sparsepyrlk_destroy(self._h)
-            self._h = None
+        _destroy(self, "mi_sparsepyrlk_destroy")
 
     def _set(self, **kw):
         for k, v in kw.items():
@@ -431,9 +438,7 @@ class StereoSGM:
         capi.check(capi.lib().mi_stereosgm_create(C.byref(self._p), C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            capi.lib().mi_stereosgm_destroy(self._h)
-            self._h = None
+        _destroy(self, "mi_stereosgm_destroy")
 
     def _set(self, **kw):
         for k, v in kw.items():
@@ -536,9 +541,7 @@ class BFMatcher:
         self._train = []
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            capi.lib().mi_bf_destroy(self._h)
-            self._h = None
+        _destroy(self, "mi_bf_destroy")
 
     # ---- train collection (brute_force_matcher.cpp:187-211)
     def isMaskSupported(self): return True
@@ -741,9 +744,7 @@ class DisparityBilateralFilter:
         capi.check(capi.lib().mi_disp_bilateral_create(C.byref(self._p), C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            capi.lib().mi_disp_bilateral_destroy(self._h)
-            self._h = None
+        _destroy(self, "mi_disp_bilateral_destroy")
 
     def _set(self, **kw):
         for k, v in kw.items():
