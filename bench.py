@@ -604,6 +604,9 @@ def main():
         except Exception as e:   # the headline number above does not depend on this leg
             out["with_scatter_gather"] = {"error": repr(e)[:300]}
 
+    # the object of the timed run is released here: every variant below creates its own (a handle owns an internal stream, and
+    # streams of live handles share the few hardware queues of the device)
+    del alg
     if not args.no_variants and world == 1:
         var = {}
         hs = max(1, args.steps // 2)

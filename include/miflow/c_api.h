@@ -65,6 +65,10 @@ MI_API const char *mi_last_error(void);
 MI_API const char *mi_version(void);
 MI_API int mi_device_count(void);          /* cv::cuda::getCudaEnabledDeviceCount */
 MI_API int mi_set_device(int device);      /* cv::cuda::setDevice (cudaoptflow/test/test_optflow.cpp:62) */
+/* Destroyed handles leave their large scratch blocks in a small process-wide cache (re-used by the next handle of a similar
+ * size: create / destroy cycles do not go through the driver).  This returns the cached blocks to the driver -- the counterpart of
+ * cv::cuda::BufferPool's release at shutdown. */
+MI_API int mi_release_cached_memory(void);
 MI_API int mi_get_device(int *device);
 
 /* Device memory helpers for hosts without a HIP runtime binding (the C++ shim's GpuMat

@@ -107,6 +107,7 @@ def lib():
         "mi_stream_create": (i, [C.POINTER(vp)]),
         "mi_stream_destroy": (i, [vp]),
         "mi_stream_synchronize": (i, [vp]),
+        "mi_release_cached_memory": (i, []),
         "mi_tvl1_default_params": (None, [C.POINTER(TVL1Params)]),
         "mi_tvl1_create": (i, [C.POINTER(TVL1Params), C.POINTER(vp)]),
         "mi_tvl1_set_params": (i, [vp, C.POINTER(TVL1Params)]),

@@ -1,5 +1,6 @@
 // Error channel, device selection and device-memory helpers of the C-ABI.
 #include "mi_common.h"
+#include <vector>
 #include <cstdlib>
 #include <mutex>
 
@@ -33,6 +34,72 @@ const Tuning &tuning()
         t.fb_tiled = env_int("MIFLOW_FB_TILED", 1);
     });
     return g_tuning;
+}
+
+namespace {
+struct BigBlock { void *p; size_t cap; int dev; };
+std::mutex g_big_mu;
+std::vector<BigBlock> g_big;
+const size_t kBigMaxBlocks = 4, kBigMaxBytes = 24ull << 30;
+}  // namespace
+
+int big_alloc(void **p, size_t bytes, size_t *capacity)
+{
+    int dev = 0;
+    MI_HIP_TRY(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        int best = -1;
+        for (size_t i = 0; i < g_big.size(); ++i)
+            if (g_big[i].dev == dev && g_big[i].cap >= bytes && g_big[i].cap <= bytes + bytes / 2 + (64u << 20) &&
+                (best < 0 || g_big[i].cap < g_big[best].cap))
+                best = (int)i;
+        if (best >= 0) {
+            *p = g_big[best].p; *capacity = g_big[best].cap;
+            g_big.erase(g_big.begin() + best);
+            return MI_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {   // make room and retry once
+        big_trim();
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) { set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return MI_ERR_OOM; }
+    *capacity = bytes;
+    return MI_OK;
+}
+
+void big_free(void *p, size_t capacity)
+{
+    if (!p) return;
+    int dev = 0;
+    void *drop = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        size_t total = capacity;
+        for (const BigBlock &b : g_big) total += b.cap;
+        if (g_big.size() < kBigMaxBlocks && total <= kBigMaxBytes) {
+            g_big.push_back({p, capacity, dev});
+            return;
+        }
+        drop = p;
+    } else {
+        drop = p;
+    }
+    (void)hipFree(drop);
+}
+
+void big_trim()
+{
+    std::vector<BigBlock> all;
+    {
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        all.swap(g_big);
+    }
+    for (const BigBlock &b : all) (void)hipFree(b.p);
 }
 
 int device_simds()
@@ -72,6 +139,7 @@ int mi_device_count(void)
     return n;
 }
 int mi_set_device(int device) { MI_HIP_TRY(hipSetDevice(device)); return MI_OK; }
+int mi_release_cached_memory(void) { mi::big_trim(); return MI_OK; }
 int mi_get_device(int *device) { MI_REQUIRE(device, MI_ERR_BAD_ARG, "null device"); MI_HIP_TRY(hipGetDevice(device)); return MI_OK; }
 
 int mi_malloc(void **dptr, size_t bytes)

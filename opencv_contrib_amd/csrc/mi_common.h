@@ -64,6 +64,14 @@ struct DevTmp {
         return e;
     }
 };
+// Large device blocks (the per-lane TV-L1 arenas) come from a small process-wide cache: a block released by a handle is kept
+// (at most 4 blocks / 24 GB per process) and handed to the next request of a similar size on the same device.  Measured on
+// MI355X / ROCm 7.2 (r02q): an arena obtained by hipMalloc right after a hipFree of the same size runs the same kernels 25 %
+// slower than the freed one did (390 vs 520 pairs/s, class defaults), i.e. create / destroy cycles of handles must not go
+// through the driver.  mi_release_cached_memory() returns everything to the driver.
+int big_alloc(void **p, size_t bytes, size_t *capacity);
+void big_free(void *p, size_t capacity);
+void big_trim();
 int device_simds();
 
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
