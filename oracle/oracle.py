@@ -532,6 +532,15 @@ def surf_detect_describe(img, params: SURFParams | None = None, mask=None, want_
             "descriptors": desc[:n].copy() if want_desc else None}
 
 
+def pyr_down_u8(src):
+    """cuda::pyrDown of a CV_8UC1 image (the pyramid of SparsePyrLKOpticalFlow)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape
+    dst = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().orc_pyr_down_u8(src.ctypes.data_as(C.c_void_p), w, h, dst.ctypes.data_as(C.c_void_p), dst.shape[1], dst.shape[0])
+    return dst
+
+
 def pyrlk_sparse(prev, nxt, prev_pts, win_size=(21, 21), max_level=3, iters=30, next_pts=None):
     """cv::cuda::SparsePyrLKOpticalFlow on CV_8UC1 frames (oracle/pyrlk_ref.c).  prev_pts (N, 2) float32; next_pts given = useInitialFlow.
     -> (next_pts (N, 2), status (N,) uint8, err (N,) float32)."""

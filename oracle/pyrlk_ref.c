@@ -147,6 +147,9 @@ static void pyr_down_u8(const unsigned char *src, int sw, int sh, unsigned char 
     free(fs); free(fd);
 }
 
+/* the 8-bit pyramid step alone (cuda::pyrDown of CV_8UC1), for the pin against cudawarping/src/cuda/pyr_down.cu */
+void orc_pyr_down_u8(const unsigned char *src, int sw, int sh, unsigned char *dst, int dw, int dh) { pyr_down_u8(src, sw, sh, dst, dw, dh); }
+
 static inline float texel_u8(const unsigned char *im, int rows, int cols, int y, int x)
 {
     return (float)im[(size_t)clampi(y, 0, rows - 1) * cols + clampi(x, 0, cols - 1)] / 255.0f;

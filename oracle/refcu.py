@@ -50,6 +50,10 @@ def lib():
         L.ref_cu_tvl1_estimate_dual.argtypes = [vp] * 9 + [i, i, f, f]
         L.ref_cu_dbf_apply.restype = i
         L.ref_cu_dbf_apply.argtypes = [vp, i, _u8, i, i, i, i, i, i, f, f, f]
+        L.ref_cu_resize_linear_f32.argtypes = [_f32, i, i, _f32, i, i, f, f]
+        L.ref_cu_resize_linear_u8.argtypes = [_u8, i, i, _u8, i, i, f, f]
+        L.ref_cu_pyr_down_f32.argtypes = [_f32, i, i, _f32, i, i]
+        L.ref_cu_pyr_down_u8.argtypes = [_u8, i, i, _u8, i, i]
         _lib = L
     return _lib
 
@@ -180,3 +184,28 @@ def dbf_apply(disp, img, ndisp=64, radius=3, iters=1, edge_threshold=0.1, max_di
     if rc:
         raise ValueError("unsupported disparity type")
     return disp
+
+
+def resize_linear(src, dsize):
+    """cuda::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for CV_32FC1 / CV_8UC1: the host arithmetic of cudawarping/src/resize.cpp:83-107
+    (fx = dsize.width / cols in double, the kernel gets float(1 / fx)) around the reference's resize_linear kernel."""
+    src = np.ascontiguousarray(src)
+    sh, sw = src.shape
+    dw, dh = dsize
+    if (dw, dh) == (sw, sh):
+        return src.copy()
+    fx, fy = dw / sw, dh / sh
+    dst = np.empty((dh, dw), src.dtype)
+    fn = lib().ref_cu_resize_linear_f32 if src.dtype == np.float32 else lib().ref_cu_resize_linear_u8
+    fn(src, sh, sw, dst, dh, dw, np.float32(1.0 / fy), np.float32(1.0 / fx))
+    return dst
+
+
+def pyr_down(src):
+    """cuda::pyrDown (dst size (cols + 1) / 2 x (rows + 1) / 2, cudawarping/src/pyramids.cpp:66-94) on the reference's pyrDown kernel."""
+    src = np.ascontiguousarray(src)
+    sh, sw = src.shape
+    dst = np.empty(((sh + 1) // 2, (sw + 1) // 2), src.dtype)
+    fn = lib().ref_cu_pyr_down_f32 if src.dtype == np.float32 else lib().ref_cu_pyr_down_u8
+    fn(src, sh, sw, dst, dst.shape[0], dst.shape[1])
+    return dst

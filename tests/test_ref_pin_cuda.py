@@ -145,6 +145,30 @@ def test_tvl1_cuda_kernels_equal_oracle(oracle, h, w, seed, gamma):
     assert np.float32(r[0].astype(np.float64).sum()) == np.float32(o[0])   # cuda::calcSum: float terms, double accumulator
 
 
+# ------------------------------------------------------------------------------------------ cuda::resize / cuda::pyrDown
+@pytest.mark.parametrize("shape,dsize", [((1080, 1920), (1536, 864)), ((864, 1536), (1229, 691)), ((97, 131), (105, 78)),
+                                          ((60, 80), (160, 120)), ((33, 47), (47, 33)), ((240, 320), (160, 120))])
+def test_cuda_resize_linear_equals_reference_kernel(oracle, shape, dsize):
+    """resize_linear<float> (cudawarping/src/cuda/resize.cu:234-269): the pyramid of cv::cuda::OpticalFlowDual_TVL1 (scale 0.8 per
+    level, the first two 1080p levels included), its flow upsampling, Farneback's level resize.  No half-pixel centres, the source
+    coordinate is dst * (1 / scale) in float, the right / bottom neighbour is clamped."""
+    rng = np.random.default_rng(shape[0] + dsize[0])
+    src = (rng.random(shape) * 255).astype(np.float32)
+    np.testing.assert_array_equal(oracle.resize_linear_cuda(src, dsize=dsize), refcu.resize_linear(src, dsize))
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (97, 131), (66, 258), (5, 7), (301, 517)])
+def test_cuda_pyr_down_equals_reference_kernel(oracle, shape):
+    """pyrDown<T, BrdReflect101> (cudawarping/src/cuda/pyr_down.cu:54-175), float (Farneback's fastPyramids) and 8-bit with
+    round-half-even saturation (the pyramid of SparsePyrLKOpticalFlow); widths that are not multiples of the 256-column block and
+    odd sizes exercise the border branch and the dst_cols guard."""
+    rng = np.random.default_rng(shape[1])
+    f = (rng.random(shape) * 255).astype(np.float32)
+    np.testing.assert_array_equal(oracle.fb_pyr_down(f), refcu.pyr_down(f))
+    u = rng.integers(0, 256, size=shape).astype(np.uint8)
+    np.testing.assert_array_equal(oracle.pyr_down_u8(u), refcu.pyr_down(u))
+
+
 # --------------------------------------------------------------------------------------------- DisparityBilateralFilter
 @pytest.mark.parametrize("radius,iters", [(3, 1), (3, 2), (5, 1)])
 @pytest.mark.parametrize("dtype,bgr", [(np.uint8, False), (np.int16, True)])
