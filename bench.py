@@ -162,7 +162,8 @@ def bench_stereobm(args):
            "roofline": {"bound": "valu_issue", "achieved": pxd * n / el * SBM_VALU_PER_PXD / 1e12, "peak": VALU_PEAK_TLIPS,
                         "unit": "T lane-instr/s", "frac": pxd * n / el * SBM_VALU_PER_PXD / 1e12 / VALU_PEAK_TLIPS,
                         "hbm_algorithmic_GBps": algo_bytes * n / el / 1e9, "hbm_frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None}}
+                        "traffic": pmc_traffic("stereobm")[0], "traffic_kernel": "k_block_match, bytes per launch (one pair)",
+                        "traffic_source": pmc_traffic("stereobm")[1]}}
     # post-filter of the stereo pipeline: DisparityBilateralFilter(ndisp, radius 3, 1 iteration) on the maps above
     dbf = cuda.createDisparityBilateralFilter(nd, 3, 1)
     F = [torch.empty_like(D[0]) for _ in range(B)]
@@ -268,7 +269,10 @@ def bench_farneback(args):
            "epe_vs_analytic_flow_px": float(synth.epe(f[40:-40, 40:-40], gt[40:-40, 40:-40])),
            "batched_calc_batch": batched,
            "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo * args.steps * n / el / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": algo * args.steps * n / el / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("farneback_iterate_level0_batch")[0],
+                        "traffic_kernel": "k_iterate_t, finest level of the batched calc: bytes per launch (32 pairs x 640 x 480 px; "
+                                          "algorithmic 88 B/px = 865 MB)",
+                        "traffic_source": pmc_traffic("farneback_iterate_level0_batch")[1],
                         "note": "sequential calc() of ONE small pair: launch-latency bound (about 70 launches of 5-50 us); bytes = "
                                 "fused-iteration accounting"}}
     if batched and "pairs_per_s" in batched:
@@ -375,7 +379,9 @@ def bench_surf(args):
                                   f"(BASELINE configs[3]), {n} frames/step", "features": nf},
            "detect_only_frames_per_s": args.steps * n / el_det, "features_per_s": nf * args.steps * n / el,
            "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el_det / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo * args.steps * n / el_det / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": algo * args.steps * n / el_det / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("surf_det_trace")[0],
+                        "traffic_kernel": "k_det_trace, bytes per launch (one octave of one frame, mean over the octaves)",
+                        "traffic_source": pmc_traffic("surf_det_trace")[1],
                         "note": "detector stage only; the Haar box sums are gather/latency bound (40 integral taps per sample per "
                                 "layer from a 33 MB L2/MALL-resident table), not HBM-bound (SURVEY 8d config 4)"}}
     # the step after detect/describe: brute-force 2-NN matching of the frame's descriptors against themselves

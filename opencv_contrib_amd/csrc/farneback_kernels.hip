@@ -69,25 +69,38 @@ __global__ __launch_bounds__(256) void k_merge_flow(const float *fx, const float
 
 // ------------------------------------------------------------------ single-plane Gaussian blur
 // farneback.cu:455-492.  One block = one row segment of 256 columns.
-template <int BORDER>
+// FAST: the taps reach less than one image size past the border (kh < w, kh < h), so BrdReflect101's double modulo -- a 30-instruction
+// integer division each, 2 (2 kh + 1) of them per output -- reduces to one mirror step with the same result.
+template <int BORDER, bool FAST>
+__device__ __forceinline__ int gidx(int i, int n)
+{
+    if (!FAST) return bidx<BORDER>(i, n);
+    if (BORDER == MI_BORDER_REFLECT101) {
+        i = abs(i);
+        return i >= n ? 2 * n - 2 - i : i;
+    }
+    return clampi(i, 0, n - 1);
+}
+template <int BORDER, bool FAST>
 __global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *dst, int w, int h, int ld, int kh, Taps K, long long bs)
 {
     extern __shared__ float row[];
     src += (long long)blockIdx.z * bs; dst += (long long)blockIdx.z * bs;   // pair of the batch
     const int tx = threadIdx.x, y = blockIdx.y, x = blockIdx.x * 256 + tx;
     for (int i = tx; i < 256 + 2 * kh; i += 256) {
-        const int xe = bidx<BORDER>((int)(blockIdx.x * 256) + i - kh, w);
+        const int xe = gidx<BORDER, FAST>((int)(blockIdx.x * 256) + i - kh, w);
         float v = src[(long long)y * ld + xe] * K.k[0];
         // unrolled so that the loads of four tap pairs are in flight together (the sum itself stays in the reference's order)
 #pragma unroll 4
         for (int j = 1; j <= kh; ++j)
-            v += (src[(long long)bidx<BORDER>(y - j, h) * ld + xe] + src[(long long)bidx<BORDER>(y + j, h) * ld + xe]) * K.k[j];
+            v += (src[(long long)gidx<BORDER, FAST>(y - j, h) * ld + xe] + src[(long long)gidx<BORDER, FAST>(y + j, h) * ld + xe]) * K.k[j];
         row[i] = v;
     }
     __syncthreads();
     if (x < w) {
         const float *r = row + tx + kh;
         float res = r[0] * K.k[0];
+#pragma unroll 4
         for (int i = 1; i <= kh; ++i) res += (r[-i] + r[i]) * K.k[i];
         dst[(long long)y * ld + x] = res;
     }
@@ -251,19 +264,30 @@ __global__ __launch_bounds__(256) void k_iterate(const float *M, const float *R0
 // threads: 5 x (256 + 2 KH) tasks in ceil(./256) rounds.
 template <bool GAUSS, int KH, int R>
 __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *R0, const float *R1, float *flowx, float *flowy,
-                                                   float *Mout, int w, int h, int ld, float boxAreaInv, int update, Taps K, long long bs)
+                                                   float *Mout, int w, int h, int ld, float boxAreaInv, int update, Taps K, long long bs, int swz)
 {
     constexpr int SMW = 256 + 2 * KH;
     __shared__ float smem[5][R][SMW];
+    // workgroup -> (column tile, row tile, pair).  Consecutive workgroup ids go to different XCDs (8, each with its own L2), so
+    // with the plain mapping the R + 2 KH rows a tile shares with its vertical neighbours are fetched from memory by several
+    // XCDs (r02s: 1.5 GB fetched per launch against 0.59 GB of compulsory reads).  swz: every XCD takes a contiguous run of tiles.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (swz) {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
+        const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        by = lid % gridDim.y; bx = (lid / gridDim.y) % gridDim.x; bz = lid / (gridDim.x * gridDim.y);   // rows of one column tile first
+    }
     {
-        const long long po = (long long)blockIdx.z * bs;
+        const long long po = (long long)bz * bs;
         M += po; R0 += po; R1 += po; flowx += po; flowy += po; Mout += po;
     }
-    const int tx = threadIdx.x, y0 = blockIdx.y * R, x = blockIdx.x * 256 + tx;
+    const int tx = threadIdx.x, y0 = by * R, x = bx * 256 + tx;
     const long long ps = (long long)ld * h;
     for (int t = tx; t < 5 * SMW; t += 256) {
         const int k = t / SMW, i = t - k * SMW;
-        const int xe = clampi((int)(blockIdx.x * 256) + i - KH, 0, w - 1);
+        const int xe = clampi(bx * 256 + i - KH, 0, w - 1);
         const float *P = M + k * ps + xe;
         float c[R + 2 * KH];
 #pragma unroll
@@ -407,10 +431,12 @@ int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Ta
     MI_REQUIRE(kh >= 0 && kh <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "Gaussian kernel half size out of range");
     const dim3 grid(div_up(g.w, 256), g.h, g.batch);
     const size_t lds = sizeof(float) * (256 + 2 * kh);
-    if (border == MI_BORDER_REFLECT101)
-        hipLaunchKernelGGL(k_gaussian_blur<MI_BORDER_REFLECT101>, grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
-    else if (border == MI_BORDER_REPLICATE)
-        hipLaunchKernelGGL(k_gaussian_blur<MI_BORDER_REPLICATE>, grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
+    const bool fast = kh < g.w && kh < g.h && g.w >= 2 && g.h >= 2;
+    if (border == MI_BORDER_REFLECT101) {
+        if (fast) hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
+        else hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, false>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
+    } else if (border == MI_BORDER_REPLICATE)
+        hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REPLICATE, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
     else { set_error("unsupported border mode %d", border); return MI_ERR_BAD_ARG; }   // farneback.cu:510-517: only these two
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -446,14 +472,15 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
     const float inv = 1.f / ((1 + 2 * kh) * (1 + 2 * kh));
     Taps none;
     memset(&none, 0, sizeof(none));
-    constexpr int R = 4;
+    const int R = tuning().fb_rows, swz = tuning().fb_swz;
     const dim3 tgrid(div_up(g.w, 256), div_up(g.h, R), g.batch);
     const Taps &K = gauss ? *gauss : none;
     const int upd = update ? 1 : 0;
-#define MI_FB_TILED(KH)                                                                                                           \
-    case KH:                                                                                                                      \
-        if (gauss) hipLaunchKernelGGL((k_iterate_t<true, KH, R>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs); \
-        else hipLaunchKernelGGL((k_iterate_t<false, KH, R>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs);     \
+#define MI_FB_LAUNCH(G, KH, RR) hipLaunchKernelGGL((k_iterate_t<G, KH, RR>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs, swz)
+#define MI_FB_TILED(KH)                                                                  \
+    case KH:                                                                             \
+        if (gauss) { if (R == 8) MI_FB_LAUNCH(true, KH, 8); else MI_FB_LAUNCH(true, KH, 4); }   \
+        else { if (R == 8) MI_FB_LAUNCH(false, KH, 8); else MI_FB_LAUNCH(false, KH, 4); }       \
         break;
     switch (tuning().fb_tiled ? kh : -1) {
         MI_FB_TILED(4) MI_FB_TILED(6) MI_FB_TILED(7) MI_FB_TILED(10)   // winSize 9, 13 (the default), 15, 21
@@ -462,6 +489,7 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
         else hipLaunchKernelGGL(k_iterate<false>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, upd, K, g.bs);
     }
 #undef MI_FB_TILED
+#undef MI_FB_LAUNCH
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

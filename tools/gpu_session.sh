@@ -129,6 +129,14 @@ for k, v in agg.items():
     print(k, {n: round(x / w, 3) for n, x in v.items()}, 'wave_cycles', w)
 PY
   find $O -type f -size +4M -delete ;;
+pmc_secondary)
+  cd /tmp
+  for wl in stereobm farneback surf; do for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -f csv -d $R/$O/pmc_${wl}_$c -- python $R/bench.py --workload $wl --no-cpu --steps 2 --warmup 1 > $R/$O/pmc_${wl}_$c.log 2>&1
+  done; done
+  cd $R
+  python tools/pmc_secondary.py $O "profiles/$NAME" 2>&1 | tail -5; cp profiles/pmc_traffic.json $O/pmc_traffic.json
+  find $O -type f -size +4M -delete ;;
 spec_trace)
   (timeout 300 python tools/spec_trace.py --pairs 4 2>&1 | tail -120) > $O/spec_trace.log; head -70 $O/spec_trace.log ;;
 test_one)
