@@ -604,11 +604,26 @@ def main():
            "epe_vs_analytic_flow_px": epe_gt,
            "roofline": roof}
 
+    exchange_hung = False
     if world > 1 and os.environ.get("MIFLOW_BENCH_EXCHANGE", "1") != "0":
-        try:
-            out["with_scatter_gather"] = bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows)
-        except Exception as e:   # the headline number above does not depend on this leg
-            out["with_scatter_gather"] = {"error": repr(e)[:300]}
+        # The headline number above does not depend on this leg, and must not be lost to it: the leg runs under a watchdog on every
+        # rank (same limit everywhere); if the point-to-point exchange does not finish, the line is printed without it and the
+        # processes leave without the collective teardown.
+        import threading
+        box = {}
+
+        def leg():
+            try:
+                torch.cuda.set_device(dev)
+                box["res"] = bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows)
+            except Exception as e:
+                box["res"] = {"error": repr(e)[:300]}
+
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("MIFLOW_BENCH_EXCHANGE_TIMEOUT", "180")))
+        exchange_hung = th.is_alive()
+        out["with_scatter_gather"] = {"error": "timed out (watchdog); skipped"} if exchange_hung else box.get("res")
 
     # the object of the timed run is released here: every variant below creates its own (a handle owns an internal stream, and
     # streams of live handles share the few hardware queues of the device)
@@ -731,7 +746,9 @@ def main():
         torch.cuda.empty_cache()
         out["secondary"] = secondary(args)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if exchange_hung:
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 

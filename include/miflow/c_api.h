@@ -107,7 +107,8 @@ typedef struct mi_tvl1_params {
     int exact_math;      /* 0 (default): fast device math (v_rcp / v_sqrt / fma), held to the oracle with a stated tolerance;
                           * 1: IEEE divide + f64 hypot, separately rounded operations in the reference's order */
     int time_block;      /* inner iterations fused per HBM pass (0 = auto, 1 = one iteration per launch) */
-    int lanes;           /* internal streams a batch is split over: 0 = automatic (2 from 4 pairs on), 1, 2 */
+    int lanes;           /* concurrent sub-batches of mi_tvl1_calc_batch (the first on the caller's stream, the others on one internal
+                          * stream each): 0 = automatic (2 from 4 pairs on), 1..4 */
     int stop_slack;      /* 0 (default): a warp's inner loop stops exactly where the reference's convergence test stops it.
                           * s > 0 (fast math, epsilon > 0 only): a fused block of iterations is also kept when the test first
                           * passed up to s iterations before the block's end, i.e. up to s iterations MORE than the reference

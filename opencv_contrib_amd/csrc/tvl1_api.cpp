@@ -64,9 +64,11 @@ struct mi_tvl1 {
     mi_tvl1_params P;
     int device = 0;
     float *cubic_tab = nullptr;
-    Lane lane[2];
+    static const int kMaxLanes = 4;
+    Lane lane[kMaxLanes];
     hipEvent_t fork = nullptr;
-    int last_nscales = 0, last_batch = 0, last_lanes = 1, last_split = 0;
+    int last_nscales = 0, last_batch = 0, last_lanes = 1;
+    int last_first[kMaxLanes + 1] = {};   // pairs [last_first[i], last_first[i + 1]) ran on lane i
     bool last_check = false;
     bool profiling = false;
 };
@@ -110,7 +112,7 @@ static int validate_params(const mi_tvl1_params *p)
     MI_REQUIRE(p->semantics == MI_SEM_CPU_REF || p->semantics == MI_SEM_CUDA_COMPAT, MI_ERR_BAD_ARG, "bad semantics");
     MI_REQUIRE(p->median_filtering <= 1 || p->median_filtering == 3 || p->median_filtering == 5, MI_ERR_BAD_ARG,
                "medianFiltering must be 1 (off), 3 or 5 (cv::medianBlur on CV_32F)");
-    MI_REQUIRE(p->lanes >= 0 && p->lanes <= 2, MI_ERR_BAD_ARG, "lanes must be 0 (automatic), 1 or 2");
+    MI_REQUIRE(p->lanes >= 0 && p->lanes <= 4, MI_ERR_BAD_ARG, "lanes must be 0 (automatic) or 1..4");
     MI_REQUIRE(p->stop_slack >= 0 && p->stop_slack <= 8, MI_ERR_BAD_ARG, "stop_slack must be in 0..8");
     return MI_OK;
 }
@@ -604,35 +606,42 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         int rc = check_pair(&I0s[i], &I1s[i], &flows[i], &I0s[0]);
         if (rc) return rc;
     }
-    // Lanes: a batch of >= 4 pairs is split into two halves that run concurrently on two internal streams, forked from and
-    // joined to the caller's stream with events (stream-ordered for the caller exactly like the single-stream form).  The pairs
-    // are independent, so the result is bit-identical to running them in one lane.
+    // Lanes: a batch of >= 4 pairs is split into contiguous sub-batches that run concurrently, forked from and joined to the
+    // caller's stream with events (stream-ordered for the caller exactly like the single-stream form).  The pairs are
+    // independent, so the result is bit-identical to running them in one lane.
     int lanes = h->P.lanes > 0 ? h->P.lanes : (tuning().lanes > 0 ? tuning().lanes : (n >= 4 ? 2 : 1));
-    if (lanes > 2) lanes = 2;
+    if (lanes > mi_tvl1::kMaxLanes) lanes = mi_tvl1::kMaxLanes;
     if (lanes > n) lanes = n;
-    const int n0 = lanes == 2 ? (n + 1) / 2 : n;
     int ns = 0;
     h->last_check = h->P.epsilon > 0.0 && h->P.iterations * h->P.inner_iterations > 0;
-    h->last_batch = n; h->last_lanes = lanes; h->last_split = n0;
+    h->last_batch = n; h->last_lanes = lanes;
+    for (int i = 0; i <= lanes; ++i) h->last_first[i] = (int)((long long)n * i / lanes);   // contiguous, sizes differ by at most one
     if (lanes == 1) {
         int rc = lane_calc(h, h->lane[0], n, I0s, I1s, flows, st, &ns);
         if (rc) return rc;
     } else {
-        // The second half batch runs on ONE internal stream, the first on the caller's own: a handle adds a single stream to the
-        // process.  (HIP multiplexes streams onto a few hardware queues -- 4 by default, GPU_MAX_HW_QUEUES; two lanes that land on
-        // one queue run back to back: measured 400 instead of 520 pairs/s when enough streams of other handles were alive.)
-        Lane &l1 = h->lane[1];
+        // Lane 0 runs on the caller's own stream, every further lane on ONE internal stream each: a handle adds lanes - 1 streams
+        // to the process.  (HIP multiplexes streams onto a few hardware queues -- 4 by default, GPU_MAX_HW_QUEUES; two lanes that
+        // land on one queue run back to back: measured 400 instead of 520 pairs/s when enough streams of other handles were alive.)
         if (!h->fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
-        if (!l1.stream) MI_HIP_TRY(hipStreamCreateWithFlags(&l1.stream, hipStreamNonBlocking));
-        if (!l1.done) MI_HIP_TRY(hipEventCreateWithFlags(&l1.done, hipEventDisableTiming));
         MI_HIP_TRY(hipEventRecord(h->fork, st));
-        MI_HIP_TRY(hipStreamWaitEvent(l1.stream, h->fork, 0));
-        const int rc1 = lane_calc(h, l1, n - n0, I0s + n0, I1s + n0, flows + n0, l1.stream, &ns);
-        // always join, also after an error: the caller's stream must not run ahead of work already enqueued
-        MI_HIP_TRY(hipEventRecord(l1.done, l1.stream));
-        const int rc0 = lane_calc(h, h->lane[0], n0, I0s, I1s, flows, st, &ns);
-        MI_HIP_TRY(hipStreamWaitEvent(st, l1.done, 0));
-        const int rc_first = rc0 ? rc0 : rc1;
+        int rc_first = MI_OK;
+        for (int li = lanes - 1; li >= 0; --li) {   // the internal lanes first: they start while lane 0 is still being enqueued
+            Lane &ln = h->lane[li];
+            const int off = h->last_first[li], cnt = h->last_first[li + 1] - off;
+            hipStream_t ls = st;
+            if (li > 0) {
+                if (!ln.stream) MI_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+                if (!ln.done) MI_HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+                MI_HIP_TRY(hipStreamWaitEvent(ln.stream, h->fork, 0));
+                ls = ln.stream;
+            }
+            const int rc = lane_calc(h, ln, cnt, I0s + off, I1s + off, flows + off, ls, &ns);
+            if (rc && !rc_first) rc_first = rc;
+            // always join, also after an error: the caller's stream must not run ahead of work already enqueued
+            if (li > 0) MI_HIP_TRY(hipEventRecord(ln.done, ln.stream));
+        }
+        for (int li = 1; li < lanes; ++li) MI_HIP_TRY(hipStreamWaitEvent(st, h->lane[li].done, 0));
         if (rc_first) return rc_first;
     }
     h->last_nscales = ns;
@@ -658,8 +667,10 @@ int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int *iters,
         for (int i = 0; i < ns * nw; ++i) iters[i] = h->P.iterations * h->P.inner_iterations;
         return MI_OK;
     }
-    Lane &ln = h->lane[(h->last_lanes == 2 && pair >= h->last_split) ? 1 : 0];
-    const int lp = (h->last_lanes == 2 && pair >= h->last_split) ? pair - h->last_split : pair;
+    int li = 0;
+    while (li + 1 < h->last_lanes && pair >= h->last_first[li + 1]) ++li;
+    Lane &ln = h->lane[li];
+    const int lp = pair - h->last_first[li];
     const int nq = (int)ln.slots.size();
     std::vector<int2> S(nq);
     MI_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -677,8 +688,10 @@ int miflow_selftest_tvl1_slots(mi_tvl1 *h, int pair, int *out_host, int cap_laun
     MI_REQUIRE(h && out_host, MI_ERR_BAD_ARG, "null argument");
     MI_REQUIRE(pair >= 0 && pair < h->last_batch, MI_ERR_BAD_ARG, "pair out of range");
     if (!h->last_check) return 0;
-    Lane &ln = h->lane[(h->last_lanes == 2 && pair >= h->last_split) ? 1 : 0];
-    const int lp = (h->last_lanes == 2 && pair >= h->last_split) ? pair - h->last_split : pair;
+    int li = 0;
+    while (li + 1 < h->last_lanes && pair >= h->last_first[li + 1]) ++li;
+    Lane &ln = h->lane[li];
+    const int lp = pair - h->last_first[li];
     const int nq = (int)ln.slots.size();
     MI_REQUIRE(nq <= cap_launches, MI_ERR_BAD_ARG, "capacity too small");
     std::vector<int2> S(nq);

@@ -97,17 +97,18 @@ def test_tvl1_batch_of_64_equals_64_single_calcs(gpu):
     assert not torch.equal(flows[0], flows[4])
 
 
+@pytest.mark.parametrize("nlanes", [2, 3, 4])
 @pytest.mark.parametrize("eps,iters", [(0.0, 10), (0.01, 60)])
-def test_two_lanes_equal_one_lane(gpu, eps, iters):
-    """A batch split over two internal streams (lanes = 2, the default from 4 pairs on) is bit-identical to the same
-    batch on the caller's stream (lanes = 1), for fixed work and for the device-decided convergence path, whose
-    per-pair iteration counts must come back from the right lane."""
+def test_two_lanes_equal_one_lane(gpu, eps, iters, nlanes):
+    """A batch split over several lanes (the caller's stream + internal streams; 2 is the default from 4 pairs on) is
+    bit-identical to the same batch on the caller's stream alone (lanes = 1), for fixed work and for the device-decided
+    convergence path, whose per-pair iteration counts must come back from the right lane."""
     import torch
     from opencv_contrib_amd import cuda
     pairs = [synth.flow_pair(150, 210, seed=40 + k)[:2] for k in range(5)]
     I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
     a1 = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps, lanes=1)
-    a2 = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps, lanes=2)
+    a2 = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps, lanes=nlanes)
     f1, f2 = a1.calc_batch(I0s, I1s), a2.calc_batch(I0s, I1s)
     torch.cuda.synchronize()
     assert torch.equal(f1, f2)
