@@ -26,7 +26,8 @@ def load(d):
 def main():
     d, label = sys.argv[1], sys.argv[2]
     acc = load(d)
-    out = {}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}   # keys of other workloads (tools/pmc_secondary.py) are kept
 
     def mean(kpred, counter):
         s = n = 0
@@ -50,7 +51,7 @@ def main():
         out["convert"]["expected_fetch_bytes"] = px * 8
         out["convert"]["expected_write_bytes"] = px * 8
     out["v1"] = {"hbm_bytes_per_launch": None, "source": "not collected for the exact-math kernel"}
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
