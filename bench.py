@@ -557,6 +557,9 @@ def main():
         roof = {"bound": "valu_issue", "kernel": "k_iterate_tbr<10,1,.,4,2,0> (10 fused estimateU+estimateDualVariables iterations per HBM pass)",
                 "achieved": ach, "peak": VALU_PEAK_TLIPS, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLIPS,
                 "pixel_iterations_per_s": px_iter_timed / (ms_it * 1e-3),
+                # what a plain f32 VALU stream actually issues on this chip: 3.1 SIMD cycles per wave-instruction at 4 waves/SIMD
+                # (tools/ubench/valu_rates.hip, profiles/r01p/valu_rates.txt) against the 2 of the 157.3 TF figure
+                "peak_measured_plain_valu": VALU_PEAK_TLIPS * 2.0 / 3.1, "frac_of_measured_peak": ach / (VALU_PEAK_TLIPS * 2.0 / 3.1),
                 "issue_slots_per_pixel_iteration": slots, "lanes_executed_per_owned_pixel": lanes_per_px,
                 "band_halo_rows_not_counted": True,
                 "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it,
