@@ -179,6 +179,30 @@ def test_class_defaults_speculative_convergence(gpu, oracle, sem, shape, seed):
     np.testing.assert_array_equal(flow, flow2)
 
 
+@pytest.mark.parametrize("iters", [1, 2, 3, 5, 7, 12, 23])
+@pytest.mark.parametrize("shape", [(16, 16), (21, 37), (64, 9), (5, 300), (97, 131)])
+def test_speculative_steps_iteration_limits_and_small_images(gpu, oracle, shape, iters):
+    """The convergence-checked fast path on the sizes and iteration limits where its plan degenerates: limits below, at and
+    between the kernels' block sizes (5, 10), images narrower than a wave's strip or with fewer rows than a band, levels dropped
+    by the 16-px rule.  Counts never exceed the limit, stay within 2 of the oracle's, and the flow stays within the change of the
+    last iterations; with an unreachable threshold the count equals the limit exactly."""
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(*shape, seed=shape[0] * 7 + iters)
+    ref, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=iters, epsilon=0.05), return_stats=True)
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=0.05)
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    it = np.array(alg.lastIterations())
+    rit = np.array(st["iters"])[:it.shape[0], :it.shape[1]]
+    assert it.shape == rit.shape
+    assert it.min() >= 1 and it.max() <= iters
+    assert np.abs(it - rit).max() <= 2, (it.tolist(), rit.tolist())
+    assert np.isfinite(flow).all()
+    assert np.sqrt(((flow - ref) ** 2).sum(-1)).mean() <= 5e-2
+    full = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=1e-12)
+    full.calc(T(I0, gpu), T(I1, gpu))
+    assert np.array(full.lastIterations()).min() == iters and np.array(full.lastIterations()).max() == iters
+
+
 def test_stop_slack_runs_at_most_a_few_more_iterations(gpu, oracle):
     """mi_tvl1_params.stop_slack = 1 (miflow extension, off by default): a speculative block is kept when the reference's test
     first passed one iteration before its end.  Counts stay within the slack (+ the knock-on of a slightly different start of
