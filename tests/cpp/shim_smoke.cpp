@@ -171,6 +171,15 @@ int main(int argc, char **argv)
             cuda::GpuMat f2;
             t2->calc(d0, d1, f2);
             if (f2.type() != CV_32FC2) return 11;
+            // class defaults (300 iterations, epsilon 0.01: the device-decided stop) with and without the stop-slack extension
+            Ptr<cuda::OpticalFlowDual_TVL1> t3 = cuda::OpticalFlowDual_TVL1::create();
+            cuda::GpuMat f3, f4;
+            t3->calc(d0, d1, f3);
+            cuda::miflow::setStopSlack(t3, 1);
+            t3->calc(d0, d1, f4);
+            bool rejected = false;
+            try { cuda::miflow::setStopSlack(t3, 99); } catch (const cv::Exception &) { rejected = true; }
+            if (!rejected || f3.size() != f4.size()) return 12;
         }
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;
