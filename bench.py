@@ -146,6 +146,17 @@ def bench_stereobm(args):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     n = B * args.steps
+    # the batched entry: block matching of the B pairs in one launch (taller row bands), results identical to compute()
+    Db = [torch.empty_like(D[0]) for _ in range(B)]
+    bm.compute_batch(L, Rr, Db)
+    torch.cuda.synchronize()
+    same = all(bool(torch.equal(Db[i], D[i])) for i in range(B))
+    tb = time.perf_counter()
+    for _ in range(args.steps):
+        bm.compute_batch(L, Rr, Db)
+    torch.cuda.synchronize()
+    elb = time.perf_counter() - tb
+    batched = {"pairs_per_s": n / elb, "batch": B, "equals_single_compute": same}
     R = bs // 2
     pxd = float((W - nd - 2 * R) * (H - 2 * R)) * nd
     algo_bytes = 3.0 * W * H   # read left + right, write disparity (u8)
@@ -155,12 +166,14 @@ def bench_stereobm(args):
            "config": {"workload": f"StereoBM {W}x{H} numDisparities={nd} blockSize={bs} (BASELINE configs[2]), {B} pairs/step",
                       "texture_threshold": 3, "uniqueness_ratio": 0},
            "pixel_disparities_per_s": pxd * n / el,
+           "batched_compute_batch": batched, "batched_pixel_disparities_per_s": pxd * n / elb,
            # not HBM-bound (6.2 MB/pair); the work is (pixel, disparity) cost updates on the integer VALU.
            # k_block_match spends SBM_VALU_PER_PXD lane-instructions per (pixel, disparity) in its row loop (column-sum slide
            # v_sub_u32_sdwa + v_mad_i32_i24, window sum add/sub, packed compare/select of the running minimum: static count of the
            # R = 7 instantiation), against the lane-instruction issue peak of the chip
            "roofline": {"bound": "valu_issue", "achieved": pxd * n / el * SBM_VALU_PER_PXD / 1e12, "peak": VALU_PEAK_TLIPS,
                         "unit": "T lane-instr/s", "frac": pxd * n / el * SBM_VALU_PER_PXD / 1e12 / VALU_PEAK_TLIPS,
+                        "batched_frac": pxd * n / elb * SBM_VALU_PER_PXD / 1e12 / VALU_PEAK_TLIPS,
                         "hbm_algorithmic_GBps": algo_bytes * n / el / 1e9, "hbm_frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS,
                         "traffic": pmc_traffic("stereobm")[0], "traffic_kernel": "k_block_match, bytes per launch (one pair)",
                         "traffic_source": pmc_traffic("stereobm")[1]}}

@@ -2,6 +2,8 @@
 // (modules/cudastereo/src/stereobm.cpp:67-197): validation, optional prefilter of both images,
 // block matching, textureness post-filter -- all stream-ordered on the caller's stream.
 #include "stereobm_dev.h"
+#include <vector>
+#include <algorithm>
 #include "mi_selftest.h"
 
 using namespace mi;
@@ -12,8 +14,12 @@ struct mi_stereobm {
     unsigned *minssd = nullptr;
     unsigned char *lebuf = nullptr, *ribuf = nullptr;
     int *tex = nullptr;   // |Sobel| plane of the textureness filter (extended domain)
-    int cap_rows = 0, cap_cols = 0;
+    int cap_rows = 0, cap_cols = 0, cap_pairs = 0;
     long long step = 0;   // bytes per row of lebuf/ribuf; minssd uses step elements
+    // batch: per-pair pointer table (device) and the host copy the asynchronous upload reads
+    sbm::BmPair *tab_dev = nullptr;
+    int tab_cap = 0;
+    std::vector<sbm::BmPair> tab_host;
 };
 
 extern "C" {
@@ -62,6 +68,7 @@ void mi_stereobm_destroy(mi_stereobm *h)
     if (h->lebuf) (void)hipFree(h->lebuf);
     if (h->ribuf) (void)hipFree(h->ribuf);
     if (h->tex) (void)hipFree(h->tex);
+    if (h->tab_dev) (void)hipFree(h->tab_dev);
     delete h;
 }
 
@@ -87,21 +94,22 @@ static int check_bm_params(int ndisp, int winsz, int rows, int cols)
     return MI_OK;
 }
 
-static int ensure_scratch(mi_stereobm *h, int rows, int cols, bool need_bufs)
+static int ensure_scratch(mi_stereobm *h, int rows, int cols, bool need_bufs, int pairs = 1)
 {
-    if (h->cap_rows < rows || h->cap_cols < cols) {
+    if (h->cap_rows < rows || h->cap_cols < cols || h->cap_pairs < pairs) {
         if (h->minssd) (void)hipFree(h->minssd);
         if (h->lebuf) (void)hipFree(h->lebuf);
         if (h->ribuf) (void)hipFree(h->ribuf);
         if (h->tex) (void)hipFree(h->tex);
         h->minssd = nullptr; h->lebuf = h->ribuf = nullptr; h->tex = nullptr;
-        h->cap_rows = rows; h->cap_cols = cols;
-        h->step = align_up(cols, 256);
+        h->cap_rows = std::max(h->cap_rows, rows); h->cap_cols = std::max(h->cap_cols, cols); h->cap_pairs = std::max(h->cap_pairs, pairs);
+        h->step = align_up(h->cap_cols, 256);
     }
-    if (!h->minssd) MI_HIP_TRY(hipMalloc((void **)&h->minssd, sizeof(unsigned) * (size_t)h->step * h->cap_rows));
+    const size_t per_pair = (size_t)h->step * h->cap_rows;
+    if (!h->minssd) MI_HIP_TRY(hipMalloc((void **)&h->minssd, sizeof(unsigned) * per_pair * h->cap_pairs));
     if (need_bufs && !h->lebuf) {
-        MI_HIP_TRY(hipMalloc((void **)&h->lebuf, (size_t)h->step * h->cap_rows));
-        MI_HIP_TRY(hipMalloc((void **)&h->ribuf, (size_t)h->step * h->cap_rows));
+        MI_HIP_TRY(hipMalloc((void **)&h->lebuf, per_pair * h->cap_pairs));
+        MI_HIP_TRY(hipMalloc((void **)&h->ribuf, per_pair * h->cap_pairs));
     }
     return MI_OK;
 }
@@ -150,16 +158,67 @@ int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right,
     return rc;
 }
 
-// n stereo pairs through one handle, back to back on the stream.  One 1080p pair is already ~2 x 10^8 (pixel, disparity) cost
-// updates in a single launch (it fills the device: DESIGN.md 4.2), so the batch entry is a loop that shares the handle's scratch --
-// there is no blockIdx.z fusion to win as there is for the small Farneback frames.
+// n stereo pairs of one size through one handle: prefilters and the textureness post-filter run pair by pair (small, bandwidth-bound
+// kernels sharing the handle's scratch), the block matching -- where the time goes -- as ONE launch with blockIdx.z = pair.  A single
+// 1080p pair needs ~16-row bands to put enough waves on the device, and every band spends 2R rows building its first window
+// (47 % of the rows at block size 15); the batch supplies the waves, so its bands are up to 96 rows tall (13 %).
 int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const mi_mat *rights, mi_mat *disps, void *stream)
 {
     MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");
     MI_REQUIRE(n > 0 && lefts && rights && disps, MI_ERR_BAD_ARG, "empty batch");
+    if (n == 1) return mi_stereobm_compute(h, lefts, rights, disps, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const mi_stereobm_params &P = h->P;
+    int rc;
     for (int i = 0; i < n; ++i) {
-        const int rc = mi_stereobm_compute(h, &lefts[i], &rights[i], &disps[i], stream);
-        if (rc) return rc;
+        if ((rc = check_u8(&lefts[i], "left")) || (rc = check_u8(&rights[i], "right")) || (rc = check_u8(&disps[i], "disparity"))) return rc;
+        MI_REQUIRE(lefts[i].rows == lefts[0].rows && lefts[i].cols == lefts[0].cols, MI_ERR_BAD_SIZE, "the pairs of a batch must have one size");
+        MI_REQUIRE(lefts[i].rows == rights[i].rows && lefts[i].cols == rights[i].cols, MI_ERR_BAD_SIZE, "left.size() != right.size()");
+        MI_REQUIRE(disps[i].rows == lefts[i].rows && disps[i].cols == lefts[i].cols, MI_ERR_BAD_SIZE, "disparity.size() != left.size()");
+    }
+    const int rows = lefts[0].rows, cols = lefts[0].cols;
+    if ((rc = check_bm_params(P.num_disparities, P.block_size, rows, cols))) return rc;
+    const bool pre = P.prefilter_type == MI_PREFILTER_XSOBEL || P.prefilter_type == MI_PREFILTER_NORMALIZED_RESPONSE;
+    if ((rc = ensure_scratch(h, rows, cols, pre, n))) return rc;
+    if (h->tab_cap < n) {
+        if (h->tab_dev) (void)hipFree(h->tab_dev);
+        h->tab_dev = nullptr; h->tab_cap = 0;
+        MI_HIP_TRY(hipMalloc((void **)&h->tab_dev, sizeof(sbm::BmPair) * n));
+        h->tab_cap = n;
+    }
+    const long long pp = h->step * h->cap_rows;   // bytes (lebuf / ribuf) = elements (minssd) per pair
+    h->tab_host.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const unsigned char *le = (const unsigned char *)lefts[i].data, *ri = (const unsigned char *)rights[i].data;
+        long long ls = (long long)lefts[i].step, rs = (long long)rights[i].step;
+        if (pre) {
+            unsigned char *lb = h->lebuf + i * pp, *rb = h->ribuf + i * pp;
+            if (P.prefilter_type == MI_PREFILTER_XSOBEL) {
+                if ((rc = sbm::prefilter_xsobel(le, ls, lb, h->step, rows, cols, P.prefilter_cap, st))) return rc;
+                if ((rc = sbm::prefilter_xsobel(ri, rs, rb, h->step, rows, cols, P.prefilter_cap, st))) return rc;
+            } else {
+                if ((rc = sbm::prefilter_norm(le, ls, lb, h->step, rows, cols, P.prefilter_cap, P.prefilter_size, st))) return rc;
+                if ((rc = sbm::prefilter_norm(ri, rs, rb, h->step, rows, cols, P.prefilter_cap, P.prefilter_size, st))) return rc;
+            }
+            le = lb; ri = rb; ls = rs = h->step;
+        }
+        MI_HIP_TRY(hipMemset2DAsync(disps[i].data, disps[i].step, 0, (size_t)cols, (size_t)rows, st));
+        h->tab_host[i] = {le, ri, (unsigned char *)disps[i].data, ls, rs, (long long)disps[i].step};
+    }
+    MI_HIP_TRY(hipMemcpyAsync(h->tab_dev, h->tab_host.data(), sizeof(sbm::BmPair) * n, hipMemcpyHostToDevice, st));
+    if ((rc = sbm::block_match_batch(h->tab_dev, n, h->minssd, h->step, pp, rows, cols, P.num_disparities, P.block_size, P.uniqueness_ratio,
+                                     P.emulate_cuda_edge, st)))
+        return rc;
+    if (P.texture_threshold > 0) {
+        if (!h->tex) {
+            int sld, sh;
+            sbm::textureness_scratch_dims(h->cap_rows, h->cap_cols, &sld, &sh);
+            MI_HIP_TRY(hipMalloc((void **)&h->tex, sizeof(int) * (size_t)sld * sh));
+        }
+        for (int i = 0; i < n; ++i)
+            if ((rc = sbm::textureness(h->tab_host[i].left, h->tab_host[i].lstep, (unsigned char *)disps[i].data, (long long)disps[i].step, rows,
+                                       cols, P.block_size, P.texture_threshold, h->tex, st)))
+                return rc;
     }
     return MI_OK;
 }

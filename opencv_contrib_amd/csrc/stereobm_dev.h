@@ -11,6 +11,11 @@ namespace sbm {
 int block_match(const unsigned char *left, long long lstep, const unsigned char *right, long long rstep, unsigned char *disp,
                 long long dstep, unsigned *minssd, long long mstep, int rows, int cols, int ndisp, int winsz,
                 int uniqueness_ratio, int emulate_edge, hipStream_t s);
+// the same for `pairs` image pairs of one size in ONE launch (blockIdx.z = pair): the batch supplies the parallelism, so the row
+// bands are taller and the 2R-row start-up of a band weighs less.  tab_dev: device array of the pairs' pointers; minssd: pairs x mpair
+struct BmPair { const unsigned char *left, *right; unsigned char *disp; long long lstep, rstep, dstep; };
+int block_match_batch(const BmPair *tab_dev, int pairs, unsigned *minssd, long long mstep, long long mpair, int rows, int cols, int ndisp,
+                      int winsz, int uniqueness_ratio, int emulate_edge, hipStream_t s);
 int prefilter_xsobel(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,
                      int cap, hipStream_t s);
 int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,

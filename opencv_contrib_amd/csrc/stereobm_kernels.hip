@@ -152,6 +152,9 @@ struct BmArgs {
     int rows, cols, ndisp, nsets, rb;
     int emulate_edge;
     float thresh_scale;    // (float)(1.0 + uniquenessRatio / 100.0f)  stereobm.cu:273
+    int batch;
+    const BmPair *tab;     // batch: blockIdx.z = pair, image pointers from this device table, minssd advances by mpair elements
+    long long mpair;
 };
 
 template <int R>
@@ -171,6 +174,11 @@ struct Cfg {
 template <int R, int MODE>
 __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
 {
+    if (A.tab) {
+        const BmPair p = A.tab[blockIdx.z];
+        A.left = p.left; A.right = p.right; A.disp = p.disp; A.lstep = p.lstep; A.rstep = p.rstep; A.dstep = p.dstep;
+        if (A.minssd) A.minssd += (long long)blockIdx.z * A.mpair;
+    }
     using C = Cfg<R>;
     constexpr int TW = C::TW, NC = C::NC, LS = C::LS, NLW = C::NLW, NRW = C::NRW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -536,7 +544,10 @@ __global__ __launch_bounds__(256) void k_tex_sobel(const unsigned char *img, lon
     S[(long long)ye * sld + xe] = tex_sobel(img, istep, rows, cols, xe - TEX_MX, ye - TEX_MY);
 }
 
-// pass 2: winsz x winsz window sums of S by sliding column sums (one wave per 64 columns x 32 rows) + threshold
+// pass 2: winsz x winsz window sums of S by sliding column sums (one wave per 64 columns x TEX_RPW rows) + threshold.
+// 8 rows per wave: 32 put one wave on each SIMD at 1080p, every row a dependent LDS / global round trip (36 us); integer sums, so
+// the strip height does not change the result.
+#define TEX_RPW 8
 __global__ __launch_bounds__(256) void k_textureness(const int *S, int sld, unsigned char *disp, long long dstep, int rows, int cols,
                                                      int winsz, float threshold)
 {
@@ -544,9 +555,9 @@ __global__ __launch_bounds__(256) void k_textureness(const int *S, int sld, unsi
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int W2 = winsz / 2;   // <= 25
     const int x = blockIdx.x * 64 + lane;
-    const int yb = (blockIdx.y * 4 + wv) * 32;
+    const int yb = (blockIdx.y * 4 + wv) * TEX_RPW;
     if (yb >= rows) return;
-    const int ye = min(yb + 32, rows);
+    const int ye = min(yb + TEX_RPW, rows);
     const int xh = lane < 32 ? blockIdx.x * 64 - 32 + lane : blockIdx.x * 64 + 64 + (lane - 32);
     const int *S0 = S + (long long)TEX_MY * sld + TEX_MX + x, *S1 = S + (long long)TEX_MY * sld + TEX_MX + xh;
     int s0 = 0, s1 = 0;
@@ -581,7 +592,7 @@ static int launch_bm(const BmArgs &A, int mode, hipStream_t s)
     using C = Cfg<R>;
     const int RS = (C::NC + A.nsets * 64 - 1 + 3) / 4 * 4 + 4;
     const size_t lds = (size_t)(A.rb + 2 * R) * (C::LS + RS) + (size_t)2 * A.nsets * 128 * sizeof(unsigned);
-    const dim3 grid(div_up(A.cols - A.ndisp - 2 * R, C::TW), div_up(A.rows - 2 * R, A.rb));
+    const dim3 grid(div_up(A.cols - A.ndisp - 2 * R, C::TW), div_up(A.rows - 2 * R, A.rb), A.tab ? A.batch : 1);
     const dim3 block(64 * A.nsets);
     if (mode == 0) {
         (void)hipFuncSetAttribute((const void *)k_block_match<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -609,32 +620,49 @@ static int tile_w_of(int R)
     return t < 16 ? 16 : t;
 }
 
-int block_match(const unsigned char *left, long long lstep, const unsigned char *right, long long rstep, unsigned char *disp,
-                long long dstep, unsigned *minssd, long long mstep, int rows, int cols, int ndisp, int winsz,
-                int uniqueness_ratio, int emulate_edge, hipStream_t s)
+static int block_match_impl(BmArgs &A, int winsz, int uniqueness_ratio, int pairs, hipStream_t s)
 {
     const int R = winsz >> 1;
     MI_REQUIRE(R >= 1 && R <= 25, MI_ERR_BAD_ARG, "Unsupported window size");   // stereobm.cu:503-504
-    BmArgs A;
-    A.left = left; A.right = right; A.lstep = lstep; A.rstep = rstep; A.disp = disp; A.dstep = dstep;
-    A.minssd = minssd; A.mstep = mstep; A.rows = rows; A.cols = cols; A.ndisp = ndisp;
-    A.nsets = div_up(ndisp, 64);
-    A.emulate_edge = emulate_edge;
+    A.nsets = div_up(A.ndisp, 64);
     A.thresh_scale = (float)(1.0 + uniqueness_ratio / 100.0f);
-    // rows per band: enough waves for the 1024 SIMDs (target ~5 per SIMD) but keep the 2R-row start-up
-    // of every band (column sums of the first window) a modest fraction of the work
-    const int xt = div_up(cols - ndisp - 2 * R, tile_w_of(R));
-    const int vrows = rows - 2 * R;
-    int bands = div_up(5120, xt * A.nsets);   // r01f sweep: ~16 rows per band is the optimum at 1080p / 128 disparities
+    // rows per band: enough waves for the 1024 SIMDs (target ~5 per SIMD) but keep the 2R-row start-up of every band (column
+    // sums of the first window) a modest fraction of the work.  A batch supplies the waves, so its bands can be taller.
+    const int xt = div_up(A.cols - A.ndisp - 2 * R, tile_w_of(R));
+    const int vrows = A.rows - 2 * R;
+    int bands = div_up(5120, xt * A.nsets * pairs);   // r01f sweep: ~16 rows per band is the optimum for ONE 1080p / 128-disparity pair
     int rb = div_up(vrows, bands > 0 ? bands : 1);
     rb = rb < 2 * R + 2 ? 2 * R + 2 : rb;
-    rb = rb > 96 ? 96 : rb;
+    rb = rb > 48 ? 48 : rb;   // taller bands cost occupancy (LDS per workgroup grows with rb): r02w at 1080p x 16: 32 | 48 | 64 | 96 rows = 4990 | 5070 | . | 4575 pairs/s
     if (const char *e = getenv("MIFLOW_SBM_ROWS")) rb = atoi(e) > 0 ? atoi(e) : rb;
     A.rb = rb;
     int rc = g_bm[R](A, 0, s);
     if (rc) return rc;
     if (uniqueness_ratio > 0) rc = g_bm[R](A, 1, s);
     return rc;
+}
+
+int block_match(const unsigned char *left, long long lstep, const unsigned char *right, long long rstep, unsigned char *disp,
+                long long dstep, unsigned *minssd, long long mstep, int rows, int cols, int ndisp, int winsz,
+                int uniqueness_ratio, int emulate_edge, hipStream_t s)
+{
+    BmArgs A;
+    memset(&A, 0, sizeof(A));
+    A.left = left; A.right = right; A.lstep = lstep; A.rstep = rstep; A.disp = disp; A.dstep = dstep;
+    A.minssd = minssd; A.mstep = mstep; A.rows = rows; A.cols = cols; A.ndisp = ndisp;
+    A.emulate_edge = emulate_edge;
+    return block_match_impl(A, winsz, uniqueness_ratio, 1, s);
+}
+
+int block_match_batch(const BmPair *tab_dev, int pairs, unsigned *minssd, long long mstep, long long mpair, int rows, int cols, int ndisp,
+                      int winsz, int uniqueness_ratio, int emulate_edge, hipStream_t s)
+{
+    BmArgs A;
+    memset(&A, 0, sizeof(A));
+    A.tab = tab_dev; A.batch = pairs; A.mpair = mpair;
+    A.minssd = minssd; A.mstep = mstep; A.rows = rows; A.cols = cols; A.ndisp = ndisp;
+    A.emulate_edge = emulate_edge;
+    return block_match_impl(A, winsz, uniqueness_ratio, pairs, s);
 }
 
 int prefilter_xsobel(const unsigned char *src, long long sstep, unsigned char *dst, long long dstep, int rows, int cols,
@@ -672,7 +700,7 @@ int textureness(const unsigned char *img, long long istep, unsigned char *disp, 
     int sld, sh;
     textureness_scratch_dims(rows, cols, &sld, &sh);
     hipLaunchKernelGGL(k_tex_sobel, dim3(div_up(sld, 64), div_up(sh, 4)), dim3(256), 0, s, img, istep, rows, cols, S, sld, sh);
-    hipLaunchKernelGGL(k_textureness, dim3(div_up(cols, 64), div_up(div_up(rows, 32), 4)), dim3(256), 0, s, (const int *)S, sld, disp,
+    hipLaunchKernelGGL(k_textureness, dim3(div_up(cols, 64), div_up(div_up(rows, TEX_RPW), 4)), dim3(256), 0, s, (const int *)S, sld, disp,
                        dstep, rows, cols, winsz, threshold);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

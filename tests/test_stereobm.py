@@ -309,3 +309,26 @@ def test_compute_batch_equals_single_computes(gpu):
     for k in range(4):
         assert torch.equal(out[k], one.compute(L[k], R[k]))
     assert not torch.equal(out[0], out[1])
+
+
+@gpu_mark
+@pytest.mark.parametrize("kw", [dict(), dict(uniqueness_ratio=10), dict(prefilter_type=1, texture_threshold=0), dict(prefilter_type=0, uniqueness_ratio=5)],
+                         ids=["defaults", "uniqueness", "xsobel", "norm_uniqueness"])
+@pytest.mark.parametrize("n", [2, 5])
+def test_compute_batch_one_launch_block_matching(gpu, kw, n):
+    """The batched block matching (blockIdx.z = pair, taller row bands) with every optional stage: uniqueness second pass reading the
+    per-pair winner-SSD planes, both prefilters writing per-pair buffers, the textureness post-filter; pitched outputs; a handle
+    reused for a smaller batch afterwards."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.stereo_pair(150, 420, seed=90 + k, max_disp=40)[:2] for k in range(n)]
+    L, R = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    bm = cuda.createStereoBM(64, 15)
+    one = cuda.createStereoBM(64, 15)
+    for alg in (bm, one):
+        alg._set(**kw)
+    out = bm.compute_batch(L, R)
+    for k in range(n):
+        assert torch.equal(out[k], one.compute(L[k], R[k])), k
+    out2 = bm.compute_batch(L[:2], R[:2])
+    assert torch.equal(out2[0], out[0]) and torch.equal(out2[1], out[1])
