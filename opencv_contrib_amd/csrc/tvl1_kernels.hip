@@ -155,66 +155,97 @@ struct ResizeArgs {
     double scale_x, scale_y;  // CPU_REF: 1/inv_scale (double).  CUDA_COMPAT: (float)(1/f) stored as double
 };
 
-// One destination pixel (dx, dy) of source plane S.
+// One destination pixel = column side x row side.  CPU_REF: cv::resize INTER_LINEAR f32 (main repo imgproc/resize.cpp): half-pixel
+// centres, coordinates in double -> float, horizontal pass then vertical pass in float.  CUDA_COMPAT: cudawarping/src/cuda/
+// resize.cu:234-269.  Split so that a thread evaluates the (double precision) coordinate arithmetic of its four columns once for
+// all the rows it produces.
+struct RszX { int i0, i1; float w0, w1; };
 template <int SEM>
-__device__ __forceinline__ float resize_px(const float *S, int sw, int sh, int ld, int dx, int dy, double scale_x, double scale_y)
+__device__ __forceinline__ RszX resize_xside(int dx, int sw, double scale_x)
 {
+    RszX r;
     if (SEM == MI_SEM_CPU_REF) {
-        // cv::resize INTER_LINEAR f32 (main repo imgproc/resize.cpp): half-pixel centres,
-        // coordinates in double -> float, horizontal pass then vertical pass in float.
         float fx = (float)((dx + 0.5) * scale_x - 0.5);
         int sx = (int)floorf(fx);
         fx -= (float)sx;
         if (sx < 0) { fx = 0.f; sx = 0; }
         if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= (float)sy;
-        const int sx1 = min(sx + 1, sw - 1);
-        const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
-        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-        const float *R0 = S + (long long)y0 * ld, *R1 = S + (long long)y1 * ld;
-        const float h0 = R0[sx] * a0 + R0[sx1] * a1;
-        const float h1 = R1[sx] * a0 + R1[sx1] * a1;
-        return h0 * b0 + h1 * b1;
+        r.i0 = sx; r.i1 = min(sx + 1, sw - 1); r.w0 = 1.f - fx; r.w1 = fx;
+    } else {
+        const float fx = (float)scale_x, src_x = (float)dx * fx;
+        const int x1 = (int)floorf(src_x), x2 = x1 + 1;
+        r.i0 = x1; r.i1 = min(x2, sw - 1); r.w0 = (float)x2 - src_x; r.w1 = src_x - (float)x1;
     }
-    // cudawarping/src/cuda/resize.cu:234-269
-    const float fx = (float)scale_x, fy = (float)scale_y;
-    const float src_x = (float)dx * fx, src_y = (float)dy * fy;
-    const int x1 = (int)floorf(src_x), y1 = (int)floorf(src_y);
-    const int x2 = x1 + 1, y2 = y1 + 1;
-    const int x2r = min(x2, sw - 1), y2r = min(y2, sh - 1);
+    return r;
+}
+template <int SEM>
+__device__ __forceinline__ RszX resize_yside(int dy, int sh, double scale_y)
+{
+    RszX r;
+    if (SEM == MI_SEM_CPU_REF) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        r.i0 = min(max(sy, 0), sh - 1); r.i1 = min(max(sy + 1, 0), sh - 1); r.w0 = 1.f - fy; r.w1 = fy;
+    } else {
+        const float fy = (float)scale_y, src_y = (float)dy * fy;
+        const int y1 = (int)floorf(src_y), y2 = y1 + 1;
+        r.i0 = y1; r.i1 = min(y2, sh - 1); r.w0 = (float)y2 - src_y; r.w1 = src_y - (float)y1;
+    }
+    return r;
+}
+template <int SEM>
+__device__ __forceinline__ float resize_combine(const float *R0, const float *R1, const RszX &X, const RszX &Y)
+{
+    if (SEM == MI_SEM_CPU_REF) {
+        const float h0 = R0[X.i0] * X.w0 + R0[X.i1] * X.w1;
+        const float h1 = R1[X.i0] * X.w0 + R1[X.i1] * X.w1;
+        return h0 * Y.w0 + h1 * Y.w1;
+    }
     float out = 0.f;
-    out = out + S[(long long)y1 * ld + x1] * (((float)x2 - src_x) * ((float)y2 - src_y));
-    out = out + S[(long long)y1 * ld + x2r] * ((src_x - (float)x1) * ((float)y2 - src_y));
-    out = out + S[(long long)y2r * ld + x1] * (((float)x2 - src_x) * (src_y - (float)y1));
-    out = out + S[(long long)y2r * ld + x2r] * ((src_x - (float)x1) * (src_y - (float)y1));
+    out = out + R0[X.i0] * (X.w0 * Y.w0);
+    out = out + R0[X.i1] * (X.w1 * Y.w0);
+    out = out + R1[X.i0] * (X.w0 * Y.w1);
+    out = out + R1[X.i1] * (X.w1 * Y.w1);
     return out;
 }
 
-// Four consecutive destination pixels per thread (one dwordx4 store; the 4 x 2 x 2 source taps of neighbouring threads share
-// their cache lines), blockIdx.z = plane + nplanes * pair.  r02b: the one-pixel-per-thread form ran at 1.5 TB/s.
-template <int SEM>
+// PX consecutive destination pixels x ROWS rows per thread, blockIdx.z = plane + nplanes * pair.  With one row per thread the kernel
+// was issue-stalled on the double-precision column coordinates (r02p: SQ WAIT_INST 0.70); amortised over 8 rows, one pixel per
+// lane (coalesced dword rows, source taps of a wave within two or three cache lines) is the fastest shape.
+#define RSZ_ROWS 8
+template <int SEM, int PX, int ROWS>
 __global__ __launch_bounds__(256) void k_resize(ResizeArgs A, CtlK ctl, int cur_host)
 {
-    const int dx = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dx = (blockIdx.x * 64 + (threadIdx.x & 63)) * PX;
+    const int dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS;
     const int pl = blockIdx.z % A.nplanes, b = blockIdx.z / A.nplanes;
-    if (dx >= A.gd.w || dy >= A.gd.h) return;
+    if (dx >= A.gd.w || dy0 >= A.gd.h) return;
     const int cur = A.nsets == 2 ? resolve_cur_k(ctl, b, cur_host) : 0;
     const float *S = A.src[pl][cur] + (long long)b * A.gs.ps;
     const int sw = A.gs.w, sh = A.gs.h, ld = A.gs.ld;
     const float ps = A.post[pl];
-    float o[4];
+    RszX X[PX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        o[j] = resize_px<SEM>(S, sw, sh, ld, min(dx + j, A.gd.w - 1), dy, A.scale_x, A.scale_y);
-        if (ps != 1.0f) o[j] = o[j] * ps;  // cuda::multiply(u, 1/scaleStep)  tvl1flow.cpp:299-300
+    for (int j = 0; j < PX; ++j) X[j] = resize_xside<SEM>(min(dx + j, A.gd.w - 1), sw, A.scale_x);
+    float *D = A.dst[pl] + (long long)b * A.gd.ps + dx;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int dy = dy0 + r;
+        if (dy >= A.gd.h) break;
+        const RszX Y = resize_yside<SEM>(dy, sh, A.scale_y);
+        const float *R0 = S + (long long)Y.i0 * ld, *R1 = S + (long long)Y.i1 * ld;
+        float o[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            o[j] = resize_combine<SEM>(R0, R1, X[j], Y);
+            if (ps != 1.0f) o[j] = o[j] * ps;  // cuda::multiply(u, 1/scaleStep)  tvl1flow.cpp:299-300
+        }
+        // rows are `ld` floats apart (a multiple of 64) from a 256-B aligned base: dx % 4 == 0 is 16-B aligned; pixels past w
+        // fall into the row padding
+        if (PX == 4) *reinterpret_cast<float4 *>(D + (long long)dy * A.gd.ld) = make_float4(o[0], o[1], o[2], o[3]);
+        else D[(long long)dy * A.gd.ld] = o[0];
     }
-    float *D = A.dst[pl] + (long long)b * A.gd.ps + (long long)dy * A.gd.ld + dx;
-    // rows are `ld` floats apart (a multiple of 64) from a 256-B aligned base: dx % 4 == 0 is 16-B aligned; pixels past w
-    // fall into the row padding
-    *reinterpret_cast<float4 *>(D) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------ centered gradient
@@ -730,16 +761,18 @@ int resize(int semantics, int nplanes, const float *const src[3][2], int src_set
     A.gs = gs;
     A.gd = gd;
     const CtlK ck = make_ctlk(ctl);
-    const dim3 grid(div_up(gd.w, 256), div_up(gd.h, 4), nplanes * gd.batch);
+#define MI_RSZ(SEMV, PX, ROWS) hipLaunchKernelGGL((k_resize<SEMV, PX, ROWS>), dim3(div_up(gd.w, 64 * PX), div_up(gd.h, 4 * ROWS), nplanes * gd.batch), dim3(256), 0, s, A, ck, cur_host)
+    // r02w at 1080p x 16 (total of the resize launches of a calc): 4 px x 4 rows 4.75 | 4 x 8 5.06 | 1 x 8 3.72 | 1 x 16 3.67 ms
     if (semantics == MI_SEM_CPU_REF) {
         A.scale_x = 1.0 / inv_scale_x;
         A.scale_y = 1.0 / inv_scale_y;
-        hipLaunchKernelGGL(k_resize<MI_SEM_CPU_REF>, grid, dim3(256), 0, s, A, ck, cur_host);
+        MI_RSZ(MI_SEM_CPU_REF, 1, RSZ_ROWS);
     } else {
         A.scale_x = (double)(float)(1.0 / inv_scale_x);  // cudawarping/src/resize.cpp:107
         A.scale_y = (double)(float)(1.0 / inv_scale_y);
-        hipLaunchKernelGGL(k_resize<MI_SEM_CUDA_COMPAT>, grid, dim3(256), 0, s, A, ck, cur_host);
+        MI_RSZ(MI_SEM_CUDA_COMPAT, 1, RSZ_ROWS);
     }
+#undef MI_RSZ
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
