@@ -1,0 +1,56 @@
+"""Randomised parity sweep of cv::cuda::OpticalFlowDual_TVL1 (HIP through the C-ABI) against the oracle: image sizes that are not
+multiples of anything (strip / band / tile edges of the blocked iteration kernel, the 6 x 6 windows of the fused warp, the 8-row
+strips of the resize), random pyramid depth, warps, iteration counts on both sides of the kernels' block sizes, scale steps,
+both semantics, u8 and f32 input, fixed work and the device-decided stop.  Seeded: the same 40 configurations every run."""
+import numpy as np
+import pytest
+
+from opencv_contrib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _configs():
+    rng = np.random.default_rng(20260923)
+    out = []
+    for k in range(40):
+        h, w = int(rng.integers(17, 260)), int(rng.integers(17, 330))
+        out.append(dict(shape=(h, w), seed=int(rng.integers(1, 10 ** 6)), dtype=("u8", "f32")[int(rng.integers(2))],
+                        nscales=int(rng.integers(1, 6)), warps=int(rng.integers(1, 6)), iterations=int(rng.integers(1, 34)),
+                        epsilon=float((0.0, 0.0, 0.02, 0.05)[int(rng.integers(4))]), scale_step=float((0.8, 0.5, 0.9)[int(rng.integers(3))]),
+                        semantics=int(rng.integers(2)), flow_scale=float(rng.uniform(0.2, 1.5))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _configs(), ids=lambda c: f"{c['shape'][0]}x{c['shape'][1]}-{c['dtype']}-s{c['nscales']}w{c['warps']}i{c['iterations']}"
+                                                          f"-e{c['epsilon']}-sem{c['semantics']}")
+def test_random_configuration_matches_oracle(gpu, oracle, cfg):
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(*cfg["shape"], seed=cfg["seed"], dtype=cfg["dtype"], flow_scale=cfg["flow_scale"])
+    p = oracle.tvl1_params(iterations=cfg["iterations"], epsilon=cfg["epsilon"], nscales=cfg["nscales"], warps=cfg["warps"],
+                           scale_step=cfg["scale_step"], semantics=cfg["semantics"])
+    ref, st = oracle.tvl1_calc(I0, I1, p, return_stats=True)
+    alg = cuda.OpticalFlowDual_TVL1.create(nscales=cfg["nscales"], warps=cfg["warps"], epsilon=cfg["epsilon"], iterations=cfg["iterations"],
+                                           scaleStep=cfg["scale_step"], semantics=cfg["semantics"])
+    t0, t1 = torch.from_numpy(I0).to(gpu), torch.from_numpy(I1).to(gpu)
+    flow = alg.calc(t0, t1).cpu().numpy()
+    assert np.isfinite(flow).all()
+    assert alg.getNumScales() == st["nscales"]                       # levels dropped by the 16-px rule, tvl1flow.cpp:243-247
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    if cfg["epsilon"] == 0.0:
+        # fast math against the exact restatement: the stated bound of the default path
+        assert d.mean() <= 5e-3, d.mean()
+    else:
+        it = np.array(alg.lastIterations())
+        rit = np.array(st["iters"])[:it.shape[0], :it.shape[1]]
+        assert it.max() <= cfg["iterations"] and it.min() >= 1
+        assert np.abs(it - rit).max() <= 2, (it.tolist(), rit.tolist())
+        assert d.mean() <= 5e-2, d.mean()
+    # a second object, exact math: bit-comparable arithmetic, tight tolerance
+    ex = cuda.OpticalFlowDual_TVL1.create(nscales=cfg["nscales"], warps=cfg["warps"], epsilon=0.0, iterations=min(cfg["iterations"], 8),
+                                          scaleStep=cfg["scale_step"], semantics=cfg["semantics"], exactMath=True)
+    p.outer_iterations = min(cfg["iterations"], 8); p.epsilon = 0.0
+    ref2 = oracle.tvl1_calc(I0, I1, p)
+    d2 = np.sqrt(((ex.calc(t0, t1).cpu().numpy() - ref2) ** 2).sum(-1))
+    assert d2.mean() <= 2e-4, d2.mean()
