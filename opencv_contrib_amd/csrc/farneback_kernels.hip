@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *
     src += (long long)blockIdx.z * bs; dst += (long long)blockIdx.z * bs;   // pair of the batch
     const int tx = threadIdx.x, y = blockIdx.y, x = blockIdx.x * 256 + tx;
     for (int i = tx; i < 256 + 2 * kh; i += 256) {
-        const int xe = gidx<BORDER, FAST>((int)(blockIdx.x * 256) + i - kh, w);
+        // columns past w + kh feed no output (x < w below) but are loaded: keep them inside the range one mirror step covers
+        const int xe = gidx<BORDER, FAST>(min((int)(blockIdx.x * 256) + i - kh, w - 1 + kh), w);
         float v = src[(long long)y * ld + xe] * K.k[0];
         // unrolled so that the loads of four tap pairs are in flight together (the sum itself stays in the reference's order)
 #pragma unroll 4

@@ -272,3 +272,39 @@ def test_calc_batch_equals_single_calcs(gpu, oracle, kw):
     # a smaller batch through the same handle afterwards (capacity is kept), and a larger one (arena regrown)
     again = alg.calc_batch(I0s[:2], I1s[:2], None if flows is None else torch.stack(init[:2]).clone())
     assert torch.equal(again[1], singles[1])
+
+
+def _random_fb_configs():
+    rng = np.random.default_rng(7702)
+    out = []
+    for k in range(24):
+        out.append(dict(shape=(int(rng.integers(40, 300)), int(rng.integers(40, 420))), seed=int(rng.integers(1, 10 ** 6)),
+                        winSize=int((9, 13, 15, 21, 11, 5, 27)[int(rng.integers(7))]),   # 9 / 13 / 15 / 21: tiled kernel; others: one-row kernel
+                        flags=int((0, 256)[int(rng.integers(2))]), numLevels=int(rng.integers(1, 6)), numIters=int(rng.integers(1, 7)),
+                        pyrScale=float((0.5, 0.7, 0.35)[int(rng.integers(3))]), fastPyramids=bool(rng.integers(2)),
+                        batch=int((1, 1, 3)[int(rng.integers(3))])))
+    return out
+
+
+@gpu_mark
+@pytest.mark.parametrize("cfg", _random_fb_configs(), ids=lambda c: f"{c['shape'][0]}x{c['shape'][1]}-w{c['winSize']}-f{c['flags']}-l{c['numLevels']}"
+                                                                   f"-i{c['numIters']}-b{c['batch']}")
+def test_random_configuration_matches_oracle(gpu, oracle, cfg):
+    """Seeded sweep over frame sizes that are multiples of nothing (row / column tile edges of the tiled iteration kernel, its
+    XCD-contiguous tile order, the mirror-step border indices of the pyramid blur), window sizes of the tiled and of the one-row
+    kernel, box and Gaussian windows, pyramid depth and scale, fast pyramids, and batches."""
+    from opencv_contrib_amd import cuda
+    if cfg["fastPyramids"]:
+        cfg = dict(cfg, pyrScale=0.5)   # CV_Assert(!fastPyramids || std::abs(pyrScale - 0.5) < 1e-6), farneback.cpp:317
+    kw = dict(numLevels=cfg["numLevels"], pyrScale=cfg["pyrScale"], fastPyramids=cfg["fastPyramids"], winSize=cfg["winSize"],
+              numIters=cfg["numIters"], flags=cfg["flags"])
+    okw = dict(num_levels=cfg["numLevels"], pyr_scale=cfg["pyrScale"], fast_pyramids=int(cfg["fastPyramids"]), win_size=cfg["winSize"],
+               num_iters=cfg["numIters"], flags=cfg["flags"])
+    pairs = [synth.flow_pair(*cfg["shape"], seed=cfg["seed"] + b, dtype="u8") for b in range(cfg["batch"])]
+    alg = cuda.FarnebackOpticalFlow.create(**kw)
+    if cfg["batch"] == 1:
+        flows = [alg.calc(T(pairs[0][0], gpu), T(pairs[0][1], gpu))]
+    else:
+        flows = list(alg.calc_batch([T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]))
+    for b, p in enumerate(pairs):
+        _assert_flow_close(N(flows[b]), oracle.fb_calc(p[0], p[1], oracle.fb_params(**okw)))
