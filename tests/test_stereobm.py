@@ -332,3 +332,43 @@ def test_compute_batch_one_launch_block_matching(gpu, kw, n):
         assert torch.equal(out[k], one.compute(L[k], R[k])), k
     out2 = bm.compute_batch(L[:2], R[:2])
     assert torch.equal(out2[0], out[0]) and torch.equal(out2[1], out[1])
+
+
+def _random_sbm_configs():
+    rng = np.random.default_rng(4242)
+    out = []
+    for k in range(24):
+        nd = int((16, 32, 64, 72, 128, 200, 256)[int(rng.integers(7))])
+        bs = int((5, 9, 11, 15, 19, 21, 31, 51)[int(rng.integers(8))])
+        h = int(rng.integers(bs + 8, 260))
+        w = int(rng.integers(nd + bs + 8, nd + bs + 400))
+        out.append(dict(shape=(h, w), seed=int(rng.integers(1, 10 ** 6)), nd=nd, bs=bs, uniq=int((0, 0, 5, 15)[int(rng.integers(4))]),
+                        pre=int((-1, -1, 0, 1)[int(rng.integers(4))]), tex=float((0.0, 3.0, 10.0)[int(rng.integers(3))]),
+                        batch=int((1, 2, 5)[int(rng.integers(3))]), noise=bool(rng.integers(4) == 0)))
+    return out
+
+
+@gpu_mark
+@pytest.mark.parametrize("cfg", _random_sbm_configs(), ids=lambda c: f"{c['shape'][0]}x{c['shape'][1]}-d{c['nd']}-b{c['bs']}-u{c['uniq']}-p{c['pre']}"
+                                                                    f"-t{c['tex']}-n{c['batch']}")
+def test_random_configuration_bit_exact(gpu, oracle, cfg):
+    """Seeded sweep: image sizes down to the smallest the parameters allow (one tile, one band), every disparity-range / block
+    size family of the kernel (packed and generic winner search, one to four disparity sets), uniqueness, both prefilters,
+    textureness on / off, 2-bit-noise images (ties everywhere), single pairs and batches: bit-exact against the oracle."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = []
+    for b in range(cfg["batch"]):
+        if cfg["noise"]:
+            rng = np.random.default_rng(cfg["seed"] + b)
+            pairs.append((rng.integers(0, 4, size=cfg["shape"]).astype(np.uint8), rng.integers(0, 4, size=cfg["shape"]).astype(np.uint8)))
+        else:
+            pairs.append(synth.stereo_pair(*cfg["shape"], seed=cfg["seed"] + b, max_disp=min(cfg["nd"] - 2, 60))[:2])
+    p = oracle.sbm_params(num_disparities=cfg["nd"], block_size=cfg["bs"], uniqueness_ratio=cfg["uniq"], prefilter_type=cfg["pre"],
+                          texture_threshold=cfg["tex"])
+    bm = cuda.createStereoBM(cfg["nd"], cfg["bs"])
+    bm._set(uniqueness_ratio=cfg["uniq"], prefilter_type=cfg["pre"], texture_threshold=cfg["tex"])
+    L, R = [T(q[0], gpu) for q in pairs], [T(q[1], gpu) for q in pairs]
+    out = [bm.compute(L[0], R[0])] if cfg["batch"] == 1 else list(bm.compute_batch(L, R))
+    for b, q in enumerate(pairs):
+        np.testing.assert_array_equal(out[b].cpu().numpy(), oracle.sbm_compute(q[0], q[1], p), err_msg=f"pair {b}")
