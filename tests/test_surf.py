@@ -195,3 +195,40 @@ def test_cross_fixture_and_errors(gpu, oracle):
     k1, d1 = a1.detectWithDescriptors(T(b, gpu)); k2, d2 = alg2.detectWithDescriptors(T(b, gpu))
     # compare bit patterns: the LAPLACIAN row stores int -1 = 0xFFFFFFFF, a NaN when read as float
     assert torch.equal(k1.view(torch.int32), k2.view(torch.int32)) and torch.equal(d1, d2)
+
+
+def _random_surf_configs():
+    rng = np.random.default_rng(90210)
+    out = []
+    for k in range(12):
+        out.append(dict(shape=(int(rng.integers(120, 520)), int(rng.integers(160, 700))), seed=int(rng.integers(1, 10 ** 6)),
+                        thr=float((50.0, 100.0, 400.0, 1500.0)[int(rng.integers(4))]), octaves=int(rng.integers(2, 5)), layers=int(rng.integers(1, 4)),
+                        extended=bool(rng.integers(2)), upright=bool(rng.integers(2))))
+    return out
+
+
+@gpu_mark
+@pytest.mark.parametrize("cfg", _random_surf_configs(), ids=lambda c: f"{c['shape'][0]}x{c['shape'][1]}-t{int(c['thr'])}-o{c['octaves']}l{c['layers']}"
+                                                                     f"-e{int(c['extended'])}u{int(c['upright'])}")
+def test_random_configuration_matches_oracle(gpu, oracle, cfg):
+    """Seeded sweep over image sizes (band / chunk edges of the integral, NMS rows, octave sub-sampling remainders), thresholds,
+    octave and layer counts, 64 / 128-element descriptors, oriented and upright: same keypoint set, >= 99 % of the orientations and
+    descriptors within the stated tolerances."""
+    from opencv_contrib_amd import cuda
+    from opencv_contrib_amd import capi
+    img = synth.blob_image(*cfg["shape"], seed=cfg["seed"])
+    alg = cuda.SURF_CUDA.create(cfg["thr"], cfg["octaves"], cfg["layers"], cfg["extended"], 0.05, cfg["upright"])
+    try:
+        ref = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=cfg["thr"], n_octaves=cfg["octaves"], n_octave_layers=cfg["layers"],
+                                                                  extended=int(cfg["extended"]), upright=int(cfg["upright"]), keypoints_ratio=0.05))
+    except ValueError:
+        # the image is too small for the last octave's filters: CV_Assert(layer_rows - 2 * min_margin > 0), surf.cuda.cpp:154-156
+        with pytest.raises(capi.MiError):
+            alg.detect(T(img, gpu))
+        return
+    if ref["n"] == 0:
+        kpg = alg.detect(T(img, gpu))
+        assert cuda.SURF_CUDA.downloadKeypoints(kpg)["x"].shape[0] == 0
+        return
+    kpg, desc = alg.detectWithDescriptors(T(img, gpu))
+    _compare(cuda.SURF_CUDA.downloadKeypoints(kpg), N(desc), ref)

@@ -54,3 +54,27 @@ def test_random_configuration_matches_oracle(gpu, oracle, cfg):
     ref2 = oracle.tvl1_calc(I0, I1, p)
     d2 = np.sqrt(((ex.calc(t0, t1).cpu().numpy() - ref2) ** 2).sum(-1))
     assert d2.mean() <= 2e-4, d2.mean()
+
+
+def _batch_configs():
+    rng = np.random.default_rng(77)
+    return [dict(shape=(int(rng.integers(20, 200)), int(rng.integers(20, 300))), n=int(rng.integers(2, 10)), lanes=int(rng.integers(0, 5)),
+                 iterations=int(rng.integers(1, 25)), epsilon=float((0.0, 0.03)[int(rng.integers(2))]), semantics=int(rng.integers(2)),
+                 seed=int(rng.integers(1, 10 ** 6))) for _ in range(10)]
+
+
+@pytest.mark.parametrize("cfg", _batch_configs(), ids=lambda c: f"{c['shape'][0]}x{c['shape'][1]}-n{c['n']}-l{c['lanes']}-i{c['iterations']}-e{c['epsilon']}")
+def test_random_batch_equals_single_calcs(gpu, cfg):
+    """calc_batch over random batch sizes and lane counts (sub-batches of unequal size, more lanes than pairs) is bit-identical to
+    the single calcs, iteration counts included."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(*cfg["shape"], seed=cfg["seed"] + k)[:2] for k in range(cfg["n"])]
+    I0s, I1s = [torch.from_numpy(p[0]).to(gpu) for p in pairs], [torch.from_numpy(p[1]).to(gpu) for p in pairs]
+    kw = dict(iterations=cfg["iterations"], epsilon=cfg["epsilon"], semantics=cfg["semantics"])
+    batch = cuda.OpticalFlowDual_TVL1.create(lanes=cfg["lanes"], **kw)
+    single = cuda.OpticalFlowDual_TVL1.create(**kw)
+    out = batch.calc_batch(I0s, I1s)
+    for k in range(cfg["n"]):
+        assert torch.equal(out[k], single.calc(I0s[k], I1s[k])), k
+        assert batch.lastIterations(k) == single.lastIterations(0), k
