@@ -105,7 +105,8 @@ typedef struct mi_tvl1_params {
                           * addressing, cuda::resize, sparse check schedule), for callers validated against cv::cuda: the two
                           * differ by ~0.1 px mean EPE, mostly at image borders (see mi_tvl1_default_params) */
     int exact_math;      /* 0 (default): fast device math (v_rcp / v_sqrt / fma), held to the oracle with a stated tolerance;
-                          * 1: IEEE divide + f64 hypot, separately rounded operations in the reference's order */
+                          * 1: IEEE divide + f64 hypot, separately rounded operations in the reference's order (with fixed work, epsilon = 0,
+                          * still fused in blocks of up to 5 iterations per pass: bit-identical to one launch per iteration) */
     int time_block;      /* inner iterations fused per HBM pass (0 = auto, 1 = one iteration per launch) */
     int lanes;           /* concurrent sub-batches of mi_tvl1_calc_batch (the first on the caller's stream, the others on one internal
                           * stream each): 0 = automatic (2 from 4 pairs on), 1..4 */

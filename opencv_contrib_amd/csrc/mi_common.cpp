@@ -31,6 +31,7 @@ const Tuning &tuning()
         t.tb_verbose = getenv("MIFLOW_TB_VERBOSE") != nullptr;
         t.lanes = env_int("MIFLOW_LANES", 0);
         t.spec = env_int("MIFLOW_SPEC", 1);
+        t.exact_tb = env_int("MIFLOW_EXACT_TB", 1);
         t.fb_tiled = env_int("MIFLOW_FB_TILED", 1);
         t.fb_rows = env_int("MIFLOW_FB_ROWS", 4) == 8 ? 8 : 4;
         t.fb_swz = env_int("MIFLOW_FB_SWZ", 1);

@@ -41,6 +41,7 @@ struct Tuning {
     int tb_rows;             // MIFLOW_TB_ROWS: band height (0: planner)
     int tb_verbose;          // MIFLOW_TB_VERBOSE
     int lanes;               // MIFLOW_LANES: internal streams a TV-L1 batch is split over (0: automatic)
+    int exact_tb;            // MIFLOW_EXACT_TB: exact math, fixed work: fused blocks (1) or one launch per iteration (0)
     int spec;                // MIFLOW_SPEC: speculative blocked convergence path (1) or one launch per iteration (0)
     int fb_rows, fb_swz;     // MIFLOW_FB_ROWS (4 | 8 rows per workgroup), MIFLOW_FB_SWZ (XCD-contiguous tile order) of the tiled kernel
     int fb_tiled;            // MIFLOW_FB_TILED: Farneback iteration kernel tiled over 4 rows (1) or one row per workgroup (0)

@@ -488,6 +488,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[e0], st));
             }
             const bool blocked = !check && !P.exact_math && P.time_block != 1 && !gam;
+            const bool exact_blocked = !check && P.exact_math && P.time_block != 1 && !gam && P.median_filtering <= 1 && tuning().exact_tb != 0;
             long long nlaunch = 0;
             const int mf = P.median_filtering > 1 ? P.median_filtering : 0;
             float *const mu1[2] = {Lv.u[0][0], Lv.u[1][0]}, *const mu2[2] = {Lv.u[0][1], Lv.u[1][1]};
@@ -506,6 +507,19 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                         cur ^= 1;
                         first_of_scale = false;
                     }
+                }
+            } else if (exact_blocked) {
+                // exact math, fixed work: blocks of up to 5 fused iterations (k_iterate_tbr MODE 2), bit-identical to the
+                // one-iteration launches below
+                for (int left = iters_per_warp; left > 0;) {
+                    const int cap = P.time_block > 0 ? std::min(P.time_block, tb_exact_max_block()) : tb_exact_max_block();
+                    const int T = std::min(left, cap);
+                    ++nlaunch;
+                    rc = iterate_tb_exact(T, pl, g, l_t, theta, taut, first_of_scale, cur, st);
+                    if (rc) return rc;
+                    cur ^= 1;
+                    left -= T;
+                    first_of_scale = false;
                 }
             } else if (spec) {
                 // Speculative steps (k_iterate_tbr MODE 1): a launch runs a block of iterations recording their error sums; the next

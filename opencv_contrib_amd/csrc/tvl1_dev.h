@@ -81,6 +81,9 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s);
 int tb_max_block();
+// the same in exact math (bit-identical to T one-iteration launches of iterate(exact = true)); T in 1..tb_exact_max_block()
+int iterate_tb_exact(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, int cur, hipStream_t s);
+int tb_exact_max_block();
 // speculative steps of the convergence-checked path (epsilon > 0, fast math): see k_iterate_tbr MODE 1
 // Speculative step of the convergence-checked path (k_iterate_tbr MODE 1), host-side constants of one launch.
 struct SpecK {

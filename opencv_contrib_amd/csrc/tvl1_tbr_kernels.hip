@@ -96,6 +96,58 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
     }
 }
 
+// The same stage in EXACT math (MODE 2): separately rounded binary32 operations in the CPU reference's order, IEEE division,
+// the dual update's norm as a double-precision square root -- the expressions of k_iterate<EXACT> (tvl1_kernels.hip:
+// px_update_u / px_update_p / row_update_u; optflow/src/tvl1flow.cpp:857-899, 989-1041, 1096-1112, 1140-1181), so a block of T
+// fused iterations is BIT-IDENTICAL to T one-iteration launches.  The border cuts are the reference's case distinctions (they
+// pick the association order of the divergence), evaluated as selects: top = (a == 0) and bottom = (a == H) are wave-uniform,
+// x0 marks the lane holding column 0.  st.rg is the RAW |grad|^2 here (finish_static is skipped).  PPL = 1 only.
+__device__ __forceinline__ void stage_r_exact(Dyn<1> &A, Dyn<1> &B, const Stat<1> &st, bool right_ok, bool x0, bool top, bool bottom,
+                                              float l_t, float theta, float taut)
+{
+    const float p11l = dpp_from_prev(A.p11[0]), p21l = dpp_from_prev(A.p21[0]);
+    const float r1 = dpp_from_next(B.u1[0]), r2 = dpp_from_next(B.u2[0]);
+    const float p11 = A.p11[0], p12 = A.p12[0], p21 = A.p21[0], p22 = A.p22[0];
+    const float up12 = B.p12[0], up22 = B.p22[0];
+    // divergence, optflow/src/tvl1flow.cpp:857-899
+    float d1, d2;
+    {
+        const float a1 = x0 ? p11 : p11 - p11l, a2 = x0 ? p21 : p21 - p21l;       // x > 0: (p11 - p11l) first in both row cases
+        const float in1 = (p11 - p11l) + (p12 - up12), in2 = (p21 - p21l) + (p22 - up22);   // y > 0, x > 0
+        const float le1 = p11 + p12 - up12, le2 = p21 + p22 - up22;               // y > 0, x == 0
+        const float tp1 = a1 + p12, tp2 = a2 + p22;                                // y == 0: p11 - p11l + p12 / p11 + p12
+        d1 = top ? tp1 : (x0 ? le1 : in1);
+        d2 = top ? tp2 : (x0 ? le2 : in2);
+    }
+    // u_t(a): estimateV + estimateU, :989-1041, 1096-1112
+    const float ix = st.ix[0], iy = st.iy[0], g = st.rg[0], rc = st.rc[0], u1 = A.u1[0], u2 = A.u2[0];
+    const float rho = rc + (ix * u1 + iy * u2);
+    const float ltg = l_t * g;
+    float e1 = 0.f, e2 = 0.f;
+    if (rho < -ltg) { e1 = l_t * ix; e2 = l_t * iy; }
+    else if (rho > ltg) { e1 = -l_t * ix; e2 = -l_t * iy; }
+    else if (g > 1.1920928955078125e-7f) { const float fi = -rho / g; e1 = fi * ix; e2 = fi * iy; }
+    const float v1 = u1 + e1, v2 = u2 + e2;
+    const float nu1 = v1 + theta * d1, nu2 = v2 + theta * d2;
+    // p_t(a-1): forward differences of u_t with the right / bottom cuts (:826-838), dual update (:1140-1181)
+    const float u1x = right_ok ? r1 - B.u1[0] : 0.f, u2x = right_ok ? r2 - B.u2[0] : 0.f;
+    const float u1y = bottom ? 0.f : nu1 - B.u1[0], u2y = bottom ? 0.f : nu2 - B.u2[0];
+    {
+        const float gn = (float)sqrt((double)u1x * (double)u1x + (double)u1y * (double)u1y);
+        const float ng = 1.0f + taut * gn;
+        B.p11[0] = (B.p11[0] + taut * u1x) / ng;
+        B.p12[0] = (B.p12[0] + taut * u1y) / ng;
+    }
+    {
+        const float gn = (float)sqrt((double)u2x * (double)u2x + (double)u2y * (double)u2y);
+        const float ng = 1.0f + taut * gn;
+        B.p21[0] = (B.p21[0] + taut * u2x) / ng;
+        B.p22[0] = (B.p22[0] + taut * u2y) / ng;
+    }
+    A.u1[0] = nu1;
+    A.u2[0] = nu2;
+}
+
 // Row accesses as `global_* v, voffset, s[base]`: the row base (plane + row * ld) is wave-uniform and the lane offset is made
 // opaque per row (empty asm), otherwise LICM re-associates base + lane offset into per-plane 64-bit VGPR addresses.
 template <int PPL>
@@ -153,7 +205,7 @@ struct CtxR {
     float *ring;
     int lane, H, ld, y0, y1, ystart, nsteps;
     unsigned xc;
-    bool st_ok;
+    bool st_ok, x0;   // x0: this lane holds column 0 (MODE 2)
     bool right_ok[PPL];
     float l_t, theta, taut;
     int nit;        // active stages (MODE 1: the length of the speculative block or of the replay; otherwise T)
@@ -169,7 +221,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     constexpr int K = T > 2 ? T - 1 : 1;
     const int n = n0 + k;
     const int r0 = c.ystart + n;
-    finish_static<PPL>(X[k].s);
+    if (MODE != 2) finish_static<PPL>(X[k].s);
 #ifndef TBR_X_NOLOAD   // timing experiments only (wrong results): no row loads after the prologue
     load_row_r<PPL, PZ>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
 #else
@@ -211,6 +263,9 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             if (t < c.nit)
                 stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
                                    c.taut, acc[t], es);
+        } else if (MODE == 2) {
+            if constexpr (PPL == 1)
+                stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
         } else {
             unsigned long long dummy = 0;
             stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
@@ -292,6 +347,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 #pragma unroll
     for (int j = 0; j < PPL; ++j) c.right_ok[j] = (xl + j + 1 < W);
     c.st_ok = xl >= own_lo && xl < own_hi;
+    c.x0 = xl == 0;
     c.xc = 4u * (unsigned)min(xl, c.ld - PPL);   // clamped column of the unconditional loads, bytes
 
     const long long pb = (long long)b * A.g.ps;
@@ -469,6 +525,12 @@ static const TbrEntry g_tbr[] = {
 // lane's kernels fill the rest of the device (r02m at 1080p x 16, class defaults: 517 -> 545 pairs/s; fixed work loses 7 %).
 static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 2), TBRS(5, 1, 4, 2, 2)};
 
+// Exact-math blocks (MODE 2; 1 px per lane).  The stage costs about four times the fast one (three IEEE divisions, two double
+// square roots), so short blocks already move the kernel from the HBM bound of the one-iteration kernel to the issue bound.
+#define TBRX(T, WPS, PLAN) {T, 1, WPS, 2, PLAN, launch_tbr<T, 1, WPS, 2, 2>, nullptr}
+// r02y at 1080p x 16, N = 10: blocks of 2 | 3 | 5 | 10 = 345 | 423 | 532 | 451 pairs/s (one launch per iteration: 228)
+static const TbrEntry g_exact[] = {TBRX(5, 4, 3), TBRX(4, 4, 3), TBRX(3, 5, 4), TBRX(2, 6, 4), TBRX(1, 8, 4)};
+
 // First entry of time block T, or the entry matching MIFLOW_TB_VARIANT=ppl,wps,pf.  Returns nullptr if T has none.
 static const TbrEntry *tbr_pick(int T)
 {
@@ -562,6 +624,20 @@ int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta
             fprintf(stderr, "[tb] T=%d ppl=%d wps=%d pf=%d %dx%d batch=%d rows_per_band=%d\n", T, e->PPL, e->WPS, e->PF, g.w, g.h, g.batch,
                     A.rows_per_band);
     }
+    return e->launch(A, p_zero, s);
+}
+
+// T fused EXACT iterations, set cur -> cur^1 (bit-identical to T launches of the one-iteration exact kernel).  T in 1..5.
+int tb_exact_max_block() { return 5; }
+int iterate_tb_exact(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, int cur, hipStream_t s)
+{
+    const TbrEntry *e = nullptr;
+    for (const TbrEntry &c : g_exact) if (c.T == T) e = &c;
+    if (!e) { set_error("no exact-math kernel for time block %d", T); return MI_ERR_BAD_ARG; }
+    TbArgs A;
+    memset(&A, 0, sizeof(A));
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur;
+    A.rows_per_band = plan_band_rows(*e, g);
     return e->launch(A, p_zero, s);
 }
 

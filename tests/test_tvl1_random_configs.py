@@ -78,3 +78,20 @@ def test_random_batch_equals_single_calcs(gpu, cfg):
     for k in range(cfg["n"]):
         assert torch.equal(out[k], single.calc(I0s[k], I1s[k])), k
         assert batch.lastIterations(k) == single.lastIterations(0), k
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (37, 101), (64, 9), (5, 300), (150, 211), (240, 427)])
+@pytest.mark.parametrize("iters", [1, 2, 3, 4, 5, 6, 7, 10, 13])
+def test_exact_math_fused_blocks_bit_identical_to_single_iterations(gpu, shape, iters):
+    """exact_math = 1 with fixed work runs blocks of up to five fused iterations (k_iterate_tbr MODE 2: the exact kernel's
+    expressions on the rotating-register pipeline); timeBlock = 1 forces one launch per iteration.  Bit-identical flows for both
+    semantics, on sizes narrower than a strip, shorter than a band, and with the border columns / rows inside halo lanes."""
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(*shape, seed=shape[1] + iters)
+    t0, t1 = torch.from_numpy(I0).to(gpu), torch.from_numpy(I1).to(gpu)
+    for sem in (0, 1):
+        a = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=0.0, exactMath=True, semantics=sem)
+        b = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=0.0, exactMath=True, semantics=sem, timeBlock=1)
+        fa, fb = a.calc(t0, t1), b.calc(t0, t1)
+        assert torch.equal(fa, fb), (sem, float((fa - fb).abs().max()))
