@@ -581,8 +581,12 @@ def main():
                 "note": "HIP events on the launch streams around each warp's iteration launch; with lanes = 2 the other half batch's "
                         "kernels share the GPU during these intervals (the rocprofv3 kernel trace shows the same durations)"}
     else:
-        kname = "k_iterate (fused estimateU+estimateDualVariables, one iteration per launch)" if not blocked else \
-            "k_iterate_tbr MODE 1 (speculative steps of the convergence-checked path: block, settle, replay)"
+        if blocked:
+            kname = "k_iterate_tbr MODE 1 (speculative steps of the convergence-checked path: block, settle, replay)"
+        elif P.exact_math and args.epsilon == 0 and P.time_block != 1:
+            kname = "k_iterate_tbr MODE 2 (exact math, blocks of up to 5 fused iterations, bit-identical to one launch per iteration)"
+        else:
+            kname = "k_iterate (fused estimateU+estimateDualVariables, one iteration per launch)"
         roof = {"bound": "hbm", "kernel": kname, "achieved": hbm_it["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (hbm_it["algorithmic_GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it, "hbm": hbm_it}

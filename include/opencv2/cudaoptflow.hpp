@@ -122,7 +122,7 @@ inline void setSemantics(const Ptr<OpticalFlowDual_TVL1> &alg, int semantics)
     CV_Assert(impl);
     impl->setExtra(semantics, impl->params().exact_math, impl->params().time_block, impl->params().lanes);
 }
-/** true: IEEE divide, f64 hypot, separately rounded operations in the reference's order, one iteration per launch
+/** true: IEEE divide, f64 hypot, separately rounded operations in the reference's order (fused in blocks of up to 5 iterations when epsilon == 0)
  *  (bit-comparable with the CPU restatement); false (default): v_rcp / v_sqrt / fma, temporally blocked. */
 inline void setExactMath(const Ptr<OpticalFlowDual_TVL1> &alg, bool exact)
 {

@@ -46,7 +46,7 @@ class OpticalFlowDual_TVL1:
         """The keyword-only arguments are miflow extensions; None = the library default (mi_tvl1_default_params):
         semantics MI_SEM_CPU_REF (the arithmetic of the CPU class, the acceptance reference; MI_SEM_CUDA_COMPAT = cv::cuda's
         own kernels, ~0.1 px mean EPE away, mostly at borders), fast device math (exactMath=True: IEEE operations in the
-        reference's order, one iteration per launch); stopSlack > 0 lets the convergence-checked loop run up to that many
+        reference's order -- fused in blocks of up to 5 iterations when the work is fixed, bit-identical to one launch per iteration); stopSlack > 0 lets the convergence-checked loop run up to that many
         iterations past the reference's stopping point (mi_tvl1_params.stop_slack)."""
         p = capi.TVL1Params()
         capi.lib().mi_tvl1_default_params(C.byref(p))
