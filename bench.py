@@ -85,7 +85,12 @@ def bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows_ref):
     import torch
     from opencv_contrib_amd import cuda
     x = torch.stack([I0, I1], 1)                                   # (B, 2, H, W)
-    # rank 0 holds `world` DISTINCT shards (its own batch rolled by 16 r columns): every rank receives and computes different pairs
+    # BASELINE configs[4]: 64 pairs per GPU (512 over 8) -- the timed batch tiled with row shifts so that the 64 pairs are distinct
+    per_gpu = max(int(os.environ.get("MIFLOW_BENCH_EXCHANGE_PAIRS", "64")), x.shape[0])
+    reps = (per_gpu + x.shape[0] - 1) // x.shape[0]
+    x = torch.cat([torch.roll(x, 8 * k, 2) for k in range(reps)], 0)[:per_gpu].contiguous()
+    flows_ref = torch.empty((x.shape[0],) + tuple(flows_ref.shape[1:]), dtype=flows_ref.dtype, device=flows_ref.device)
+    # rank 0 holds `world` DISTINCT shards (the batch rolled by 16 r columns): every rank receives and computes different pairs
     parts = [torch.roll(x, 16 * r, 3).contiguous() for r in range(world)] if rank == 0 else None
     local_in = [torch.empty_like(x) for _ in range(2)]
     local_out = [torch.empty_like(flows_ref) for _ in range(2)]
@@ -101,7 +106,7 @@ def bench_exchange(args, parallel, dist, rank, world, dev, I0, I1, flows_ref):
     el = parallel.run_exchange_pipeline(dist, rank, world, parts, local_in, local_out, root_out, compute, args.steps, sync)
     el = parallel.max_over_ranks(dist, el, dev)
     B = x.shape[0]
-    res = {"value": B * world * args.steps / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / args.steps,
+    res = {"value": B * world * args.steps / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / args.steps, "pairs_per_gpu": B,
            "exchange_GB_per_step": (world - 1) * (x.numel() + flows_ref.numel()) * 4 / 1e9,
            "note": "inputs on GPU 0 only (one distinct shard per rank): scatter (grouped RCCL send/recv) -> calc_batch -> gather of the "
                    "flows to GPU 0 inside the timed region, double buffered"}
@@ -460,6 +465,15 @@ def secondary(args):
     return out
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["tvl1", "stereobm", "farneback", "surf"], default="tvl1")
@@ -505,6 +519,8 @@ def main():
     # one process per GPU; every rank runs its own batch of independent pairs (no data-path collective);
     # RCCL ("nccl") only carries the barriers and the max-over-ranks timing reduction
     from opencv_contrib_amd import parallel
+    if int(os.environ.get("RANK", "0")) != 0:
+        os.dup2(2, 1)   # only rank 0 owns stdout (the one JSON line); whatever the other ranks' libraries print goes to stderr
     dist, rank, world, local = parallel.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -625,7 +641,14 @@ def main():
            "roofline": roof}
 
     exchange_hung = False
-    if world > 1 and os.environ.get("MIFLOW_BENCH_EXCHANGE", "1") != "0":
+    if world == 1 and os.environ.get("MIFLOW_BENCH_EXCHANGE_FORCE"):
+        # development aid: the exchange leg on ONE GPU through a single-rank RCCL group (scatter / gather to self) -- exercises the
+        # group set-up, the pipeline, the watchdog and the verification where no multi-GPU node is at hand
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist = tdist
+    if (world > 1 or os.environ.get("MIFLOW_BENCH_EXCHANGE_FORCE")) and os.environ.get("MIFLOW_BENCH_EXCHANGE", "1") != "0":
         # The headline number above does not depend on this leg, and must not be lost to it: the leg runs under a watchdog on every
         # rank (same limit everywhere); if the point-to-point exchange does not finish, the line is printed without it and the
         # processes leave without the collective teardown.
@@ -765,12 +788,15 @@ def main():
         del I0, I1, flows
         torch.cuda.empty_cache()
         out["secondary"] = secondary(args)
+    # The JSON line must be the LAST thing on stdout: RCCL writes a version banner to the C-level stdout, which stays in the C
+    # buffer until the process exits when stdout is a pipe.  Tear the group down first, push the C buffer out, then print.
+    if dist is not None and not exchange_hung:
+        dist.destroy_process_group()
+    _flush_c_stdio()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if exchange_hung:
         os._exit(0)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
