@@ -521,7 +521,12 @@ def main():
     from opencv_contrib_amd import parallel
     if int(os.environ.get("RANK", "0")) != 0:
         os.dup2(2, 1)   # only rank 0 owns stdout (the one JSON line); whatever the other ranks' libraries print goes to stderr
-    dist, rank, world, local = parallel.init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    # MIFLOW_BENCH_BACKEND=gloo + MIFLOW_BENCH_DEVICE=0: development aid, several ranks of the launcher on ONE GPU (barriers and the
+    # timing reduction over gloo on the CPU) -- exercises the multi-process control flow where no multi-GPU node is at hand
+    backend = os.environ.get("MIFLOW_BENCH_BACKEND", "nccl")
+    dist, rank, world, local = parallel.init_distributed(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if "MIFLOW_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MIFLOW_BENCH_DEVICE"])
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     from opencv_contrib_amd import capi, cuda, synth
@@ -544,7 +549,7 @@ def main():
         alg.setProfiling(profile)
         a0, a1 = inputs if inputs is not None else (I0, I1)
         el = time_steps(alg, a0, a1, flows if out is None else out, steps, warmup, dist)
-        el = parallel.max_over_ranks(dist, el, dev)
+        el = parallel.max_over_ranks(dist, el, dev if backend == "nccl" else None)
         prof = (alg.getProfile(0), alg.getProfile(1)) if profile else None
         its = alg.lastIterations(0)
         return float(el), prof, its, alg
@@ -648,7 +653,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         dist = tdist
-    if (world > 1 or os.environ.get("MIFLOW_BENCH_EXCHANGE_FORCE")) and os.environ.get("MIFLOW_BENCH_EXCHANGE", "1") != "0":
+    if (world > 1 or os.environ.get("MIFLOW_BENCH_EXCHANGE_FORCE")) and os.environ.get("MIFLOW_BENCH_EXCHANGE", "1") != "0" and backend == "nccl":
         # The headline number above does not depend on this leg, and must not be lost to it: the leg runs under a watchdog on every
         # rank (same limit everywhere); if the point-to-point exchange does not finish, the line is printed without it and the
         # processes leave without the collective teardown.
