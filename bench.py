@@ -420,6 +420,25 @@ def bench_surf(args):
                         "traffic_source": pmc_traffic("surf_det_trace")[1],
                         "note": "detector stage only; the Haar box sums are gather/latency bound (40 integral taps per sample per "
                                 "layer from a 33 MB L2/MALL-resident table), not HBM-bound (SURVEY 8d config 4)"}}
+    # two handles on two streams, frames alternating: distinct handles share nothing (the reference serialises every SURF_CUDA call
+    # process-wide with a static mutex, surf.cuda.cpp:117,371,383), so one frame's descriptor kernel overlaps the next frame's detector
+    try:
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        algs = [cuda.SURF_CUDA.create(400.0) for _ in range(2)]
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                algs[i].detectWithDescriptors(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps * n * 2):
+            with torch.cuda.stream(streams[i & 1]):
+                kp2, desc2 = algs[i & 1].detectWithDescriptors(t)
+        torch.cuda.synchronize()
+        out["two_handles_two_streams_frames_per_s"] = args.steps * n * 2 / (time.perf_counter() - t0)
+        out["two_handles_same_result"] = bool(torch.equal(desc2, desc))
+        del algs, streams
+    except Exception as e:
+        out["two_handles_two_streams_frames_per_s"] = {"error": repr(e)[:200]}
     # the step after detect/describe: brute-force 2-NN matching of the frame's descriptors against themselves
     bfm = cuda.createBFMatcher()
     bfm.knnMatchDevice(desc, desc, k=2)
