@@ -211,7 +211,10 @@ MI_API int mi_stereobm_get_params(const mi_stereobm *h, mi_stereobm_params *p);
 /* Replaces: StereoBMImpl::compute, cudastereo/src/stereobm.cpp:134-191.  left,right: MI_8UC1, same size;
  * disp: MI_8UC1 of the same size (allocated by the caller / the C++ shim's OutputArray::create). */
 MI_API int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right, mi_mat *disp, void *stream);
-/* n pairs through one handle, back to back on the stream (a 1080p pair already fills the device: a loop, not a fused launch). */
+/* n pairs of one size through one handle: the block matching of all pairs is ONE launch (blockIdx.z = pair; the batch supplies the
+ * waves, so the row bands are taller and their 2R-row start-up weighs less), prefilters and the textureness post-filter pair by
+ * pair; every disparity map equals mi_stereobm_compute's.  The concurrency the reference offers for this is one StereoBM object per
+ * stream (cudastereo/perf/perf_stereo.cpp). */
 MI_API int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const mi_mat *rights, mi_mat *disps, void *stream);
 MI_API void mi_stereobm_destroy(mi_stereobm *h);
 
