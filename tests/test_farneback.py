@@ -7,6 +7,8 @@ Tolerances (float path, stated):
   * full calc vs oracle: mean EPE <= 2e-3 px and |1-CCORR| <= 1e-5 -- far inside the reference's own
     CUDA-vs-CPU acceptance |1-CCORR| <= 1e-4 (box) / 2e-2 (Gaussian), cudaoptflow/test/test_optflow.cpp:349.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -275,9 +277,9 @@ def test_calc_batch_equals_single_calcs(gpu, oracle, kw):
 
 
 def _random_fb_configs():
-    rng = np.random.default_rng(7702)
+    rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "7702")))
     out = []
-    for k in range(24):
+    for k in range(int(os.environ.get("MIFLOW_SWEEP_N", "24"))):
         out.append(dict(shape=(int(rng.integers(40, 300)), int(rng.integers(40, 420))), seed=int(rng.integers(1, 10 ** 6)),
                         winSize=int((9, 13, 15, 21, 11, 5, 27)[int(rng.integers(7))]),   # 9 / 13 / 15 / 21: tiled kernel; others: one-row kernel
                         flags=int((0, 256)[int(rng.integers(2))]), numLevels=int(rng.integers(1, 6)), numIters=int(rng.integers(1, 7)),

@@ -2,6 +2,8 @@
 
 Integer path: every comparison is exact (np.array_equal).  The oracle restates
 modules/cudastereo/src/cuda/stereobm.cu sequentially (oracle/stereobm_ref.c)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -335,9 +337,9 @@ def test_compute_batch_one_launch_block_matching(gpu, kw, n):
 
 
 def _random_sbm_configs():
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "4242")))
     out = []
-    for k in range(24):
+    for k in range(int(os.environ.get("MIFLOW_SWEEP_N", "24"))):
         nd = int((16, 32, 64, 72, 128, 200, 256)[int(rng.integers(7))])
         bs = int((5, 9, 11, 15, 19, 21, 31, 51)[int(rng.integers(8))])
         h = int(rng.integers(bs + 8, 260))

@@ -11,6 +11,8 @@ Stated tolerances:
 The reference's own CUDA-vs-CPU acceptance is far looser (matched-keypoint ratio > 0.95, descriptor match ratio > 0.6,
 xfeatures2d/test/test_surf.cuda.cpp:102-107,166-173).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -198,9 +200,9 @@ def test_cross_fixture_and_errors(gpu, oracle):
 
 
 def _random_surf_configs():
-    rng = np.random.default_rng(90210)
+    rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "90210")))
     out = []
-    for k in range(12):
+    for k in range(int(os.environ.get("MIFLOW_SWEEP_N", "12"))):
         out.append(dict(shape=(int(rng.integers(120, 520)), int(rng.integers(160, 700))), seed=int(rng.integers(1, 10 ** 6)),
                         thr=float((50.0, 100.0, 400.0, 1500.0)[int(rng.integers(4))]), octaves=int(rng.integers(2, 5)), layers=int(rng.integers(1, 4)),
                         extended=bool(rng.integers(2)), upright=bool(rng.integers(2))))

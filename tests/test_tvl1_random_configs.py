@@ -2,6 +2,8 @@
 multiples of anything (strip / band / tile edges of the blocked iteration kernel, the 6 x 6 windows of the fused warp, the 8-row
 strips of the resize), random pyramid depth, warps, iteration counts on both sides of the kernels' block sizes, scale steps,
 both semantics, u8 and f32 input, fixed work and the device-decided stop.  Seeded: the same 40 configurations every run."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _configs():
-    rng = np.random.default_rng(20260923)
+    rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "20260923")))
     out = []
-    for k in range(40):
+    for k in range(int(os.environ.get("MIFLOW_SWEEP_N", "40"))):
         h, w = int(rng.integers(17, 260)), int(rng.integers(17, 330))
         out.append(dict(shape=(h, w), seed=int(rng.integers(1, 10 ** 6)), dtype=("u8", "f32")[int(rng.integers(2))],
                         nscales=int(rng.integers(1, 6)), warps=int(rng.integers(1, 6)), iterations=int(rng.integers(1, 34)),
