@@ -181,4 +181,7 @@ def test_bench_exchange_leg_two_ranks_with_a_stand_in_algorithm(tmp_path):
     assert len(res) == 2
     assert res[0]["res"]["gathered_flows_identical"] is True and "gathered_flows_identical" not in res[1]["res"]
     assert res[0]["res"]["value"] == res[1]["res"]["value"] > 0
-    assert abs(res[0]["res"]["exchange_GB_per_step"] - (3 * 2 * 6 * 8 + 3 * 6 * 8 * 2) * 4 / 1e9) < 1e-15
+    # the leg tiles the 3-pair batch up to configs[4]'s 64 distinct pairs per GPU (MIFLOW_BENCH_EXCHANGE_PAIRS)
+    n = res[0]["res"]["pairs_per_gpu"]
+    assert n == 64
+    assert abs(res[0]["res"]["exchange_GB_per_step"] - (n * 2 * 6 * 8 + n * 6 * 8 * 2) * 4 / 1e9) < 1e-15
