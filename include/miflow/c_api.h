@@ -170,7 +170,9 @@ MI_API int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *
 /* Replaces: tvl1flow::estimateU + estimateDualVariables  tvl1flow.cu:209-363, fused into
  * one pass.  `niter` iterations from (u,p) in -> out (separate buffers); err_host[niter]
  * (HOST pointer, may be NULL) receives the per-iteration sum of (du1^2 + du2^2); when it is
- * non-NULL the call synchronises `stream` before returning (test hook). */
+ * non-NULL the call synchronises `stream` before returning (test hook).  time_block > 0: the
+ * streaming temporally blocked kernel with blocks of at most that many iterations; time_block < 0: the
+ * register-tile kernel of the small pyramid levels, variant -time_block - 1 (both fast math). */
 MI_API int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1wx, const mi_mat *I1wy,
                            const mi_mat *grad, const mi_mat *rho_c, const mi_mat *u_in /*[2]*/,
                            const mi_mat *p_in /*[4]*/, mi_mat *u_out /*[2]*/, mi_mat *p_out /*[4]*/,

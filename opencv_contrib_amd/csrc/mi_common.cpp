@@ -29,6 +29,11 @@ const Tuning &tuning()
         t.tb_plan_wps = env_int("MIFLOW_TB_WPS", 0);
         t.tb_rows = env_int("MIFLOW_TB_ROWS", 0);
         t.tb_verbose = getenv("MIFLOW_TB_VERBOSE") != nullptr;
+        {
+            const char *e = getenv("MIFLOW_TILE_MAXPX");
+            t.tile_maxpx = e && *e ? atoll(e) : 2300000;   // the three coarsest levels of a 1080p pyramid at 8..16 pairs per lane
+        }
+        t.tile_variant = env_int("MIFLOW_TILE_VARIANT", 0);
         t.lanes = env_int("MIFLOW_LANES", 0);
         t.spec = env_int("MIFLOW_SPEC", 1);
         t.exact_tb = env_int("MIFLOW_EXACT_TB", 1);

@@ -40,6 +40,8 @@ struct Tuning {
     int tb_plan_wps;         // MIFLOW_TB_WPS: waves/SIMD the band planner assumes (0: table)
     int tb_rows;             // MIFLOW_TB_ROWS: band height (0: planner)
     int tb_verbose;          // MIFLOW_TB_VERBOSE
+    long long tile_maxpx;    // MIFLOW_TILE_MAXPX: levels of at most this many pixels x pairs iterate on the register-tile kernel (0: never)
+    int tile_variant;        // MIFLOW_TILE_VARIANT: index into the (rows per wave, waves) table of tvl1_tile_kernels.hip
     int lanes;               // MIFLOW_LANES: internal streams a TV-L1 batch is split over (0: automatic)
     int exact_tb;            // MIFLOW_EXACT_TB: exact math, fixed work: fused blocks (1) or one launch per iteration (0)
     int spec;                // MIFLOW_SPEC: speculative blocked convergence path (1) or one launch per iteration (0)

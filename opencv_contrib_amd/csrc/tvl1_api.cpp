@@ -497,7 +497,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // filter sits between outer iterations, so blocks never span more than inner_iterations
                 const int per = mf ? P.inner_iterations : iters_per_warp, nouter = mf ? P.iterations : 1;
                 std::vector<int> plan(per + 1);
-                const int nb = tb_plan(per, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), per);
+                const int nb = tb_plan_level(g, per, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), per);
                 for (int no = 0; no < nouter; ++no) {
                     if (mf && (rc = median_flow(mf, mu1, mu2, ln.scr[0], ln.scr[1], g, nullptr, cur, st))) return rc;
                     for (int k = 0; k < nb; ++k) {

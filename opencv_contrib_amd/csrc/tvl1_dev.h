@@ -81,6 +81,13 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s);
 int tb_max_block();
+// Register-tile formulation of the same fused iterations for the small pyramid levels (tvl1_tile_kernels.hip): nit in
+// 1..tile_max_block() iterations per launch, bit-identical to iterate_tb.  variant < 0: default of the table.
+int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, int cur,
+                 hipStream_t s);
+int tile_max_block();
+int tile_variants();
+bool tile_eligible(const Geo &g);   // this level (pixels x pairs) runs on the register-tile kernel
 // the same in exact math (bit-identical to T one-iteration launches of iterate(exact = true)); T in 1..tb_exact_max_block()
 int iterate_tb_exact(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, int cur, hipStream_t s);
 int tb_exact_max_block();
@@ -103,6 +110,8 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
                     const SpecK &sk, int e0, hipStream_t s);
 // cost-model decomposition of n iterations into supported blocks (largest first); returns the count
 int tb_plan(int n, int cap, int *blocks, int max_blocks);
+// the same for level g: greedy blocks of tile_max_block() where the level runs on the register-tile kernel
+int tb_plan_level(const Geo &g, int n, int cap, int *blocks, int max_blocks);
 // largest supported block <= n (n >= 1)
 inline int tb_pick_block(int n, int cap)
 {

@@ -2,6 +2,7 @@
 // boundary: tvl1flow::centeredGradient / warpBackward / estimateU / estimateDualVariables,
 // modules/cudaoptflow/src/tvl1flow.cpp:58-76, and cuda::resize).  Caller planes may be
 // arbitrarily pitched; they are staged through dense 256-B-aligned scratch planes.
+#include <algorithm>
 #include "tvl1_dev.h"
 #include "mi_selftest.h"
 #include <vector>
@@ -123,7 +124,9 @@ int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1w
 {
     hipStream_t st = (hipStream_t)stream;
     MI_REQUIRE(niter >= 1, MI_ERR_BAD_ARG, "niter must be >= 1");
-    const bool blocked = !exact_math && time_block > 0;
+    const bool tiled = !exact_math && time_block < 0;   // test hook: register-tile kernel, variant -time_block - 1
+    MI_REQUIRE(!tiled || -time_block - 1 < tile_variants(), MI_ERR_BAD_ARG, "no such register-tile variant");
+    const bool blocked = (!exact_math && time_block > 0) || tiled;
     MI_REQUIRE(!(blocked && err_host), MI_ERR_BAD_ARG, "per-iteration error sums are not available from the blocked kernel");
     MI_REQUIRE(u_in && p_in && u_out && p_out, MI_ERR_BAD_ARG, "null plane array");
     const mi_mat *stat[4] = {I1wx, I1wy, grad, rho_c};
@@ -152,9 +155,17 @@ int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1w
     }
     int cur = 0;
     for (int it = 0; it < niter;) {
+        if (tiled) {
+            const int T = std::min(niter - it, tile_max_block());
+            TRY(iterate_tile(-time_block - 1, T, pl, g, l_t, theta, taut, false, cur, st));
+            it += T;
+            cur ^= 1;
+            continue;
+        }
         if (blocked) {
             const int T = tb_pick_block(niter - it, time_block);
-            TRY(iterate_tb(T, pl, g, l_t, theta, taut, false, cur, 0, st));
+            // rows_per_band = -1: always the streaming kernel (the tile kernel is compared against it)
+            TRY(iterate_tb(T, pl, g, l_t, theta, taut, false, cur, -1, st));
             it += T;
             cur ^= 1;
             continue;

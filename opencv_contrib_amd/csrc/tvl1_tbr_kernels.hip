@@ -578,6 +578,20 @@ int tb_plan(int n, int cap, int *blocks, int max_blocks)
     return k;
 }
 
+int tb_plan_level(const Geo &g, int n, int cap, int *blocks, int max_blocks)
+{
+    if (!tile_eligible(g) || tuning().tb_force) return tb_plan(n, cap, blocks, max_blocks);
+    // register-tile kernel: any block length up to its margin costs one launch; fewest launches win
+    int k = 0;
+    const int top = cap < tile_max_block() ? cap : tile_max_block();
+    for (int left = n; left > 0 && k < max_blocks;) {
+        const int t = left < top ? left : top;
+        blocks[k++] = t;
+        left -= t;
+    }
+    return k;
+}
+
 // Band height: every wave streams rows_per_band + 2T rows, in whole blocks of P = T + 1 + PF steps.  Pick the band count
 // that minimises rounds x steps, rounds = ceil(waves / resident-wave capacity), so that the grid fills the SIMDs of the
 // device in whole rounds (no half-empty tail round) while the 2T-row band overlap stays small.
@@ -613,6 +627,8 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s)
 {
+    if (rows_per_band == 0 && tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force)
+        return iterate_tile(-1, T, pl, g, l_t, theta, taut, p_zero, cur, s);
     const TbrEntry *e = tbr_pick(T);
     if (!e) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
     TbArgs A;

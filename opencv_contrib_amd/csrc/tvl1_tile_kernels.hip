@@ -1,0 +1,212 @@
+// Dual TV-L1 -- fused iterations on a 2-D REGISTER TILE (gfx950, wave64): the small pyramid levels.
+//
+// The streaming pipeline of tvl1_tbr_kernels.hip walks a row band from top to bottom with its T iteration levels as
+// pipeline stages: one dependent chain of T stages per row step, (rows + 2T) steps per band.  On a large level that chain
+// is hidden by the other waves of the SIMD; on the coarse levels of the pyramid (a few hundred waves in all) nothing hides
+// it and a launch costs its serial depth: 130-170 us for 0.1-2 % of the pixels (profiles/r02w: the three coarsest of the
+// five levels took 28 % of the iteration time of a 1080p calc).
+//
+// Here a workgroup of NW waves holds a whole tile of (NW * RW) rows x 64 columns in registers -- every lane a column, every
+// wave RW consecutive rows, {u1, u2, p11, p12, p21, p22} and the four static planes of each row -- and runs the iterations
+// in place, all rows of a phase at once:
+//
+//   U phase:  u_t(a)  = f(u_(t-1)(a), p_(t-1)(a), p_(t-1)(a-1))     for every row a of the tile   (x-1 neighbour by DPP)
+//   P phase:  p_t(a)  = g(p_(t-1)(a), u_t(a), u_t(a+1))              for every row a of the tile   (x+1 neighbour by DPP)
+//
+// The RW rows of a wave are independent inside a phase (RW-fold instruction-level parallelism instead of one chain); the
+// row above a wave's first row and the row below its last row belong to the neighbouring waves and cross through LDS
+// (two 64-float rows per wave and phase, two workgroup barriers per iteration).  The serial depth of a launch is
+// nit x (2 phases + 2 barriers), independent of the image height.
+//
+// The tile carries a margin of M = 10 rows / columns per side (dependency cone +-1 px per iteration), so up to 10 iterations
+// run per launch; the columns are cut exactly like the strips of k_iterate_tbr (strip 0 starts at x = 0 in lane 0).
+// Arithmetic and border cuts are those of stage_r (tvl1_tbr_kernels.hip), operation by operation, so the results are
+// BIT-IDENTICAL to the streaming kernel's (tests/test_tvl1_gpu.py::test_iterate_tile_equals_streaming_kernel): which of the
+// two kernels a level runs on never changes a flow.
+#include "tvl1_tb_dev.h"
+#include <cstdio>
+
+namespace mi {
+namespace tvl1 {
+
+struct TileArgs {
+    IterPlanes pl;
+    Geo g;
+    float l_t, theta, taut;
+    int cur;   // input set
+    int nit;   // iterations of this launch, 1..10
+};
+
+constexpr int TILE_M = 10;   // validity margin per side = the most iterations one launch may run
+
+template <int RW, int NW, bool PZ>
+__global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
+{
+    constexpr int M = TILE_M;
+    constexpr int LW = 64;
+    constexpr int STRIDE = LW - 2 * M;        // owned columns of the strips >= 1 (strip 0 owns LW - M)
+    constexpr int BR = NW * RW - 2 * M;       // owned rows of a tile
+    static_assert(BR > 0, "tile too small for its margin");
+    // [wave][0,1: u1,u2 of the wave's first row (after the U phase)  2,3: p12,p22 of its last row][lane]
+    __shared__ float xch[NW][4][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x, band = blockIdx.y, b = blockIdx.z;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    const int y0 = band * BR, y1 = min(y0 + BR, H);
+    const int own_lo = strip == 0 ? 0 : (LW - M) + (strip - 1) * STRIDE;
+    const int own_hi = min(strip == 0 ? LW - M : own_lo + STRIDE, W);
+    const int xl = (strip == 0 ? 0 : own_lo - M) + lane;   // this lane's column, >= 0
+    const bool right_ok = xl + 1 < W;
+    const bool st_ok = xl >= own_lo && xl < own_hi;
+    const unsigned xc = 4u * (unsigned)min(xl, ld - 1);    // clamped column of the unconditional loads, bytes
+    const int ys = y0 - M + wave * RW;                     // image row of this wave's first register row
+
+    const long long pb = (long long)b * A.g.ps;
+    const int cur = A.cur;
+    const float *const uin[2] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb};
+    const float *const pin[4] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb};
+    const float *const stp[4] = {A.pl.ix + pb, A.pl.iy + pb, A.pl.g + pb, A.pl.rc + pb};
+
+    float u1[RW], u2[RW], p11[RW], p12[RW], p21[RW], p22[RW];
+    float ix[RW], iy[RW], rg[RW], rc[RW];
+    // rows above / below the image are loaded from clamped addresses (finite data); the four border cuts below isolate the
+    // valid region from them exactly as in stage_r
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const long long ro = (long long)min(max(ys + r, 0), H - 1) * ld;   // wave-uniform
+        const auto ldv = [&](const float *plane) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(plane + ro) + xc); };
+        ix[r] = ldv(stp[0]); iy[r] = ldv(stp[1]); rg[r] = ldv(stp[2]); rc[r] = ldv(stp[3]);
+        u1[r] = ldv(uin[0]); u2[r] = ldv(uin[1]);
+        if (!PZ) { p11[r] = ldv(pin[0]); p12[r] = ldv(pin[1]); p21[r] = ldv(pin[2]); p22[r] = ldv(pin[3]); }
+        else p11[r] = p12[r] = p21[r] = p22[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) rg[r] = __builtin_amdgcn_rcpf(fmaxf(rg[r], 1e-30f));   // finish_static
+    xch[wave][2][lane] = p12[RW - 1];
+    xch[wave][3][lane] = p22[RW - 1];
+    __syncthreads();
+
+    const float l_t = A.l_t, theta = A.theta, taut = A.taut;
+    const int nit = A.nit;
+    for (int t = 0; t < nit; ++t) {
+        // ---- U phase: u_t(a) for every row (stage_r, first half; optflow/src/tvl1flow.cpp:989-1041, 1096-1112)
+        // the row above the tile's first row does not exist: any finite value (that row is margin, or cut by negm1 at a = 0)
+        const float pa12 = wave > 0 ? xch[wave - 1][2][lane] : 0.f;
+        const float pa22 = wave > 0 ? xch[wave - 1][3][lane] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int a = ys + r;
+            const float negm1 = __uint_as_float((a == 0) ? 0u : 0xbf800000u);   // -(a != 0): the p(y-1) term of row 0 is cut
+            const float dx1 = p11[r] - dpp_from_prev(p11[r]);
+            const float dx2 = p21[r] - dpp_from_prev(p21[r]);
+            const float ab12 = r == 0 ? pa12 : p12[r > 0 ? r - 1 : 0];
+            const float ab22 = r == 0 ? pa22 : p22[r > 0 ? r - 1 : 0];
+            const float div1 = dx1 + fmaf(negm1, ab12, p12[r]);
+            const float div2 = dx2 + fmaf(negm1, ab22, p22[r]);
+            const float rho = fmaf(ix[r], u1[r], fmaf(iy[r], u2[r], rc[r]));
+            const float fi = __builtin_amdgcn_fmed3f(-rho * rg[r], -l_t, l_t);
+            u1[r] = fmaf(theta, div1, fmaf(fi, ix[r], u1[r]));
+            u2[r] = fmaf(theta, div2, fmaf(fi, iy[r], u2[r]));
+        }
+        xch[wave][0][lane] = u1[0];
+        xch[wave][1][lane] = u2[0];
+        __syncthreads();
+        // ---- P phase: p_t(a) for every row (stage_r, second half; :1140-1181).  Below the tile's last row: the row itself
+        // (zero y-difference; margin)
+        const float nb1 = wave + 1 < NW ? xch[wave + 1][0][lane] : u1[RW - 1];
+        const float nb2 = wave + 1 < NW ? xch[wave + 1][1][lane] : u2[RW - 1];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int a = ys + r;
+            const bool last = (a + 1 == H);   // forward y-difference of row H-1 is cut (:826-831)
+            const float m2 = __uint_as_float(last ? 0u : 0x3f800000u);
+            const float taum2 = __uint_as_float(last ? 0u : __float_as_uint(taut));
+            const float r1 = dpp_from_next(u1[r]);
+            const float r2 = dpp_from_next(u2[r]);
+            const float bl1 = r + 1 < RW ? u1[r + 1 < RW ? r + 1 : r] : nb1;
+            const float bl2 = r + 1 < RW ? u2[r + 1 < RW ? r + 1 : r] : nb2;
+            const float u1x = right_ok ? r1 - u1[r] : 0.f;
+            const float u2x = right_ok ? r2 - u2[r] : 0.f;
+            const float d1 = bl1 - u1[r];
+            const float d2 = bl2 - u2[r];
+            const float g1 = __builtin_amdgcn_sqrtf(fmaf(d1 * d1, m2, u1x * u1x));
+            const float g2 = __builtin_amdgcn_sqrtf(fmaf(d2 * d2, m2, u2x * u2x));
+            const float q1 = __builtin_amdgcn_rcpf(fmaf(taut, g1, 1.0f));
+            const float q2 = __builtin_amdgcn_rcpf(fmaf(taut, g2, 1.0f));
+            p11[r] = fmaf(taut, u1x, p11[r]) * q1;
+            p12[r] = fmaf(taum2, d1, p12[r]) * q1;
+            p21[r] = fmaf(taut, u2x, p21[r]) * q2;
+            p22[r] = fmaf(taum2, d2, p22[r]) * q2;
+        }
+        xch[wave][2][lane] = p12[RW - 1];
+        xch[wave][3][lane] = p22[RW - 1];
+        __syncthreads();
+    }
+
+    if (st_ok) {
+        float *const uout[2] = {A.pl.u[cur ^ 1][0] + pb, A.pl.u[cur ^ 1][1] + pb};
+        float *const pout[4] = {A.pl.p[cur ^ 1][0] + pb, A.pl.p[cur ^ 1][1] + pb, A.pl.p[cur ^ 1][2] + pb, A.pl.p[cur ^ 1][3] + pb};
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int a = ys + r;
+            if (a >= y0 && a < y1) {   // wave-uniform
+                const long long o = (long long)a * ld + xl;
+                uout[0][o] = u1[r]; uout[1][o] = u2[r];
+                pout[0][o] = p11[r]; pout[1][o] = p12[r]; pout[2][o] = p21[r]; pout[3][o] = p22[r];
+            }
+        }
+    }
+}
+
+template <int RW, int NW>
+static int launch_tile(const TileArgs &A, bool pz, hipStream_t s)
+{
+    constexpr int M = TILE_M, LW = 64, STRIDE = LW - 2 * M, BR = NW * RW - 2 * M;
+    const int nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
+    const dim3 grid(nstrips, div_up(A.g.h, BR), A.g.batch);
+    if (pz) hipLaunchKernelGGL((k_iterate_tile<RW, NW, true>), grid, dim3(NW * 64), 0, s, A);
+    else hipLaunchKernelGGL((k_iterate_tile<RW, NW, false>), grid, dim3(NW * 64), 0, s, A);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+typedef int (*TileLaunchFn)(const TileArgs &, bool, hipStream_t);
+struct TileEntry {
+    int RW, NW;
+    TileLaunchFn launch;
+};
+#define TILE(RW, NW) {RW, NW, launch_tile<RW, NW>}
+static const TileEntry g_tile[] = {TILE(4, 16), TILE(6, 16), TILE(8, 16), TILE(8, 8), TILE(6, 8), TILE(3, 16)};
+constexpr int kTileVariants = (int)(sizeof(g_tile) / sizeof(g_tile[0]));
+
+int tile_variants() { return kTileVariants; }
+int tile_max_block() { return TILE_M; }
+
+// Levels of at most this many pixels x pairs run on the register-tile kernel (0: never).  MIFLOW_TILE_MAXPX.
+bool tile_eligible(const Geo &g)
+{
+    const long long lim = tuning().tile_maxpx;
+    return lim > 0 && (long long)g.w * g.h * g.batch <= lim;
+}
+
+// nit (1..10) fused iterations, set cur -> cur^1, on register tiles.  variant < 0: the table default (MIFLOW_TILE_VARIANT).
+int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, int cur,
+                 hipStream_t s)
+{
+    if (nit < 1 || nit > TILE_M) { set_error("register-tile kernel: %d iterations per launch (1..%d)", nit, TILE_M); return MI_ERR_BAD_ARG; }
+    if (variant < 0) variant = tuning().tile_variant;
+    if (variant < 0 || variant >= kTileVariants) { set_error("register-tile kernel: no variant %d", variant); return MI_ERR_BAD_ARG; }
+    TileArgs A;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.nit = nit;
+    if (tuning().tb_verbose) {
+        static int shown = 0;
+        if (shown++ < 40)
+            fprintf(stderr, "[tile] rw=%d nw=%d nit=%d %dx%d batch=%d\n", g_tile[variant].RW, g_tile[variant].NW, nit, g.w, g.h, g.batch);
+    }
+    return g_tile[variant].launch(A, p_zero, s);
+}
+
+}  // namespace tvl1
+}  // namespace mi

@@ -130,45 +130,53 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
             v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
         }
     } else if (SEM == MI_SEM_CPU_REF) {
-        if ((unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0)) {
-            // the 4 x 4 window is inside the image (cv::remap's interior formula, row sums added row by row) but the 6 x 6
-            // window of the derivative taps is not: same association, tap values with clamped neighbours
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        // Windows touching the border.  R[r][c] = I1(sy - 1 + r, sx - 1 + c) with CLAMPED rows and columns -- for a tap inside
+        // the image that is exactly how centeredGradient clamps its neighbours, and taps outside the image are not used -- as 32
+        // independent loads (one memory round trip; the earlier per-tap loops with their dependent loads made every launch wait
+        // ~30 us for its border waves: the whole launch on the small pyramid levels).  Buffer loads: a wave-uniform descriptor
+        // of the pair's plane + one 32-bit byte offset per load.
+        float R[6][6];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, (unsigned)H * (unsigned)ld * 4u, 0x00020000);
+        unsigned cxs[6];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t0[4], t1[4], t2[4], w[4];
+        for (int c = 0; c < 6; ++c) cxs[c] = 4u * (unsigned)min(max(sx - 1 + c, 0), W - 1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    w[i] = wyv[j] * wxv[i];
-                    fetch3(P, W, H, ld, sx + i, sy + j, t0[i], t1[i], t2[i]);
-                }
-                const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
-                const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
-                const float r2 = t2[0] * w[0] + t2[1] * w[1] + t2[2] * w[2] + t2[3] * w[3];
-                if (j == 0) { s0 = r0; s1 = r1; s2 = r2; } else { s0 += r0; s1 += r1; s2 += r2; }
-            }
-            v0 = s0; v1 = s1; v2 = s2;
-        } else if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
-            v0 = v1 = v2 = 0.f;
-        } else {
-            // cv::remap border path: taps outside the image contribute the border value 0, one tap at a time
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            for (int j = 0; j < 4; ++j) {
-                const int yj = sy + j;
-                if (yj < 0 || yj >= H) continue;
-                for (int i = 0; i < 4; ++i) {
-                    const int xi = sx + i;
-                    if (xi < 0 || xi >= W) continue;
-                    float t0, t1, t2;
-                    fetch3(P, W, H, ld, xi, yj, t0, t1, t2);
-                    const float w = wyv[j] * wxv[i];
-                    s0 += (t0 - 0.f) * w;
-                    s1 += (t1 - 0.f) * w;
-                    s2 += (t2 - 0.f) * w;
-                }
-            }
-            v0 = s0; v1 = s1; v2 = s2;
+        for (int r = 0; r < 6; ++r) {
+            const unsigned ro = (unsigned)min(max(sy - 1 + r, 0), H - 1) * (unsigned)ld * 4u;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (!((r == 0 || r == 5) && (c == 0 || c == 5)))
+                    R[r][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ro + cxs[c], 0, 0));
         }
+        // the 4 x 4 window of taps is inside the image (only the ring of derivative neighbours is not): cv::remap's interior
+        // formula, sum += S[0]*w[0] + S[1]*w[1] + S[2]*w[2] + S[3]*w[3] per row, w = wy[j]*wx[i].  Otherwise its border path: one
+        // tap at a time, taps outside the image contribute the border value 0 (skipped: s + (0 - 0) * w == s); a window entirely
+        // outside the image has no valid tap and yields 0.
+        const bool win4 = (unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t0[4], t1[4], t2[4], w[4];
+            const bool okj = (unsigned)(sy + j) < (unsigned)H;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i] = wyv[j] * wxv[i];
+                t0[i] = R[j + 1][i + 1];
+                t1[i] = 0.5f * (R[j + 1][i + 2] - R[j + 1][i]);
+                t2[i] = 0.5f * (R[j + 2][i + 1] - R[j][i + 1]);
+            }
+            const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
+            const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
+            const float r2 = t2[0] * w[0] + t2[1] * w[1] + t2[2] * w[2] + t2[3] * w[3];
+            if (j == 0) { s0 = r0; s1 = r1; s2 = r2; } else { s0 += r0; s1 += r1; s2 += r2; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = okj && (unsigned)(sx + i) < (unsigned)W;
+                const float n0 = b0 + (t0[i] - 0.f) * w[i], n1 = b1 + (t1[i] - 0.f) * w[i], n2 = b2 + (t2[i] - 0.f) * w[i];
+                b0 = ok ? n0 : b0; b1 = ok ? n1 : b1; b2 = ok ? n2 : b2;
+            }
+        }
+        v0 = win4 ? s0 : b0; v1 = win4 ? s1 : b1; v2 = win4 ? s2 : b2;
     } else {
         // the reference's own loop bounds (zero-weight taps included: they read finite clamped data)
         const int xmin = (int)ceilf(wxp - 2.0f), xmax = (int)floorf(wxp + 2.0f);

@@ -166,6 +166,25 @@ def test_iterate_blocked_matches_exact(gpu, T, shape):
             np.testing.assert_allclose(N(b), N(a), rtol=0, atol=2e-5 * niter, err_msg=f"{nm} T={T} niter={niter}")
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [(68, 120), (135, 240), (300, 531)])
+def test_iterate_tile_equals_streaming_kernel(gpu, variant, shape):
+    """The register-tile formulation of the fused iterations (tvl1_tile_kernels.hip, the small pyramid levels) against the
+    streaming temporally blocked kernel: the same operations in the same order, so BIT-IDENTICAL planes -- which kernel a level
+    runs on never changes a flow.  Shapes: the two coarsest 1080p levels, and one spanning several strips and row tiles;
+    niter 10 = one launch, 7 = a short launch, 23 = 10 + 10 + 3."""
+    from opencv_contrib_amd import cuda
+    I1wx, I1wy, grad, rho, u, p = _iter_inputs(*shape, seed=11)
+    args = [T_(a, gpu) for a in (I1wx, I1wy, grad, rho)] + [[T_(a, gpu) for a in u], [T_(a, gpu) for a in p],
+                                                            0.045, 0.3, 0.25 / 0.3]
+    for niter, tb in ((10, 10), (7, 5), (23, 8)):
+        # streaming kernel in blocks of 10 | 5 + 2 | 8 + 8 + 6 + 1 (every decomposition of it gives the same bits)
+        us, ps, _ = cuda.tvl1_iterate(*args, niter=niter, exact=False, time_block=tb, want_err=False)
+        ut, pt, _ = cuda.tvl1_iterate(*args, niter=niter, exact=False, time_block=-(variant + 1), want_err=False)
+        for nm, a, b in zip(["u1", "u2", "p11", "p12", "p21", "p22"], us + ps, ut + pt):
+            np.testing.assert_array_equal(N(b), N(a), err_msg=f"{nm} variant={variant} niter={niter}")
+
+
 @pytest.mark.parametrize("tb", [0, 5])
 def test_calc_fast_blocked_matches_oracle(gpu, oracle, tb):
     """Product fast path (fast math + temporal blocking) against the CPU oracle, stated tolerance."""

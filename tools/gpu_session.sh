@@ -9,6 +9,21 @@ mkdir -p $O
 R=$PWD
 for step in "$@"; do
 case $step in
+tests_tile)
+  (timeout 600 python -m pytest tests/test_tvl1_gpu.py -m gpu -q -x -p no:cacheprovider -k "tile or warp or calc_fast or iterate_blocked" 2>&1 | tail -15) > $O/pytest_tile.log; cat $O/pytest_tile.log ;;
+ab_tile)
+  # register-tile kernel on the small levels: threshold (pixels x pairs per lane) and variant
+  for cfg in ${AB_TILE_CFGS:-"0,0 300000,0 1200000,0 2300000,0 2300000,2 9000000,0 9000000,2 40000000,2"}; do
+    mx=${cfg%,*}; v=${cfg#*,}
+    (MIFLOW_TILE_MAXPX=$mx MIFLOW_TILE_VARIANT=$v timeout 300 python bench.py --no-variants --no-cpu --no-secondary --steps 12 --warmup 3 2>$O/ab_tile_${mx}_$v.err | tail -1) > $O/ab_tile_${mx}_$v.json
+    python - <<PY
+import json
+try:
+    d = json.loads(open('$O/ab_tile_${mx}_$v.json').read()); r = d['roofline']
+    print('ab_tile maxpx=$mx variant=$v', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step | iterate us', round(r['avg_launch_us'], 1), 'warp us', round(r['second_kernel']['avg_launch_us'], 1), 'epe', d.get('epe_vs_analytic_flow_px'))
+except Exception as e: print('ab_tile $mx $v failed', e); print(open('$O/ab_tile_${mx}_$v.err').read()[-2000:])
+PY
+  done ;;
 tests_new)
   (timeout 900 python -m pytest tests/test_baseline_sizes.py tests/test_ref_pin.py tests/test_tvl1_gpu.py tests/test_superres_flowio.py tests/test_cpp_shim.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -30) > $O/pytest_new.log; cat $O/pytest_new.log ;;
 tests_all)
