@@ -162,6 +162,12 @@ MI_API void mi_tvl1_multi_destroy(mi_tvl1_multi *m);
  * device-layer boundary, exported for plane-by-plane parity tests.
  * Replaces: tvl1flow::centeredGradient  cudaoptflow/src/cuda/tvl1flow.cu:59-81 */
 MI_API int mi_tvl1_centered_gradient(const mi_mat *src, mi_mat *dx, mi_mat *dy, void *stream);
+/* OR-ed into `semantics` of mi_tvl1_warp_backward (test hook): the fast-math form of the kernel calc() runs when
+ * exact_math = 0 -- the bicubic sums of I1, I1x, I1y formed separably; differs from the reference order by rounding only. */
+#define MI_WARP_STAGE_FAST 0x100
+/* likewise: the LDS-staged / the global-gather formulation of that kernel (default: the library's tuned choice) */
+#define MI_WARP_STAGE_LDS 0x200
+#define MI_WARP_STAGE_GATHER 0x400
 /* Replaces: tvl1flow::warpBackward  tvl1flow.cu:106-179  (CPU: 3x remap + calcGradRho,
  * optflow/src/tvl1flow.cpp:1371-1376) */
 MI_API int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *I1, const mi_mat *I1x,

@@ -20,6 +20,8 @@ const Tuning &tuning()
         t.warp_legacy = (w && w[0] == 'p') ? 1 : 0;
         t.warp_tile = env_int("MIFLOW_WARP_TILE", 32);
         if (t.warp_tile != 64 && t.warp_tile != 32 && t.warp_tile != 16) t.warp_tile = 32;
+        t.warp_lds = env_int("MIFLOW_WARP_LDS", 0);   // r02z3 at 1080p x 16: LDS-staged windows 1 140 vs 1 180 pairs/s with two lanes, 1 037 vs 1 012 with one
+        t.warp_fast = env_int("MIFLOW_WARP_FAST", -1);   // -1: automatic = cv::cuda semantics only (window_sums, tvl1_warp_kernels.hip)
         t.warp_np = env_int("MIFLOW_WARP_NP", 2);   // r02e at 1080p x 16: np 1 | 2 | 4 = 904 | 1042 | 1034 pairs/s
         if (t.warp_np != 1 && t.warp_np != 4) t.warp_np = 2;
         t.tb_swz = env_int("MIFLOW_TB_SWZ", 1);

@@ -33,6 +33,8 @@ void set_error(const char *fmt, ...);
 struct Tuning {
     int warp_legacy;         // MIFLOW_WARP=pk: packed-float4 gather warp (the round-1 kernel) instead of the fused-gradient one
     int warp_tile;           // MIFLOW_WARP_TILE: pixels of a wave along x in the warp kernels (64 | 32 | 16)
+    int warp_lds;            // MIFLOW_WARP_LDS: windows of the fused-gradient warp read from an LDS-staged region of I1 (1) or gathered from global memory (0)
+    int warp_fast;           // MIFLOW_WARP_FAST: fast-math calcs form the warp's bicubic sums separably (1: +4.7 % pairs/s, 2-3 x the EPE against the oracle) or tap by tap in the reference's order (0); -1 (default): separably under MI_SEM_CUDA_COMPAT, whose map is not quantised (EPE 1.2e-5 either way), tap by tap under MI_SEM_CPU_REF
     int warp_np;             // MIFLOW_WARP_NP: patches a wave of the fused-gradient warp kernel walks (1 | 2 | 4)
     int tb_swz;              // MIFLOW_TB_SWZ: XCD-aware workgroup remap of the blocked iteration kernels
     int tb_ppl, tb_wps, tb_pf;   // MIFLOW_TB_VARIANT=ppl,wps,pf (-1: table default)

@@ -475,7 +475,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             if (legacy_warp)
                 rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             else
-                rc = warp_fused(sem, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
+                rc = warp_fused(sem, !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT)), -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             if (rc) return rc;
             if (w0 >= 0) {
                 rc = next_event(&w1); if (rc) return rc;

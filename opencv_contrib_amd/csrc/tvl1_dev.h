@@ -68,7 +68,9 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
          int cur_host, hipStream_t s);
 // the same with the centred gradient of I1 derived inside the kernel from a 6 x 6 window of I1 (tvl1_warp_kernels.hip): no packed
 // plane, half the gathered bytes, bit-identical results
-int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
+// fast: the three bicubic sums in separable form (rounding differs from the reference's tap-by-tap order; fast-math paths only)
+// lds: windows read from an LDS-staged region of I1 (1) or gathered from global memory (0); -1 = the tuning default
+int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
                float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
                hipStream_t s);
 // one fused iteration (estimateU + estimateDualVariables), set cur -> set cur^1.

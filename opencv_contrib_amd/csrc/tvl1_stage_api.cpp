@@ -83,6 +83,10 @@ int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *I1, con
                           mi_mat *rho)
 {
     hipStream_t st = nullptr;
+    // test hook: semantics | MI_WARP_STAGE_FAST runs the fast-math form of the fused-gradient kernel (separable bicubic sums)
+    const bool fast = (semantics & MI_WARP_STAGE_FAST) != 0;
+    const int lds = (semantics & MI_WARP_STAGE_LDS) ? 1 : (semantics & MI_WARP_STAGE_GATHER) ? 0 : -1;
+    semantics &= ~(MI_WARP_STAGE_FAST | MI_WARP_STAGE_LDS | MI_WARP_STAGE_GATHER);
     MI_REQUIRE(semantics == MI_SEM_CPU_REF || semantics == MI_SEM_CUDA_COMPAT, MI_ERR_BAD_ARG, "bad semantics");
     // I1x == I1y == NULL: the derivative planes are the centred differences of I1, formed inside the warp kernel (the
     // kernel calc() runs, tvl1_warp_kernels.hip); otherwise the caller's planes are gathered (any planes, k_warp)
@@ -105,7 +109,7 @@ int mi_tvl1_warp_backward(int semantics, const mi_mat *I0, const mi_mat *I1, con
     MI_HIP_TRY(hipMemcpyAsync(tabd, tabh, sizeof(tabh), hipMemcpyHostToDevice, st));
     const float *u1v[2] = {in[4], in[4]}, *u2v[2] = {in[5], in[5]};
     if (fused) {
-        TRY(warp_fused(semantics, in[0], in[1], u1v, u2v, out[0], out[1], out[2], out[3], out[4], tabd, g, nullptr, 0, st));
+        TRY(warp_fused(semantics, fast, lds, in[0], in[1], u1v, u2v, out[0], out[1], out[2], out[3], out[4], tabd, g, nullptr, 0, st));
     } else {
         float *pk = nullptr;   // {I1, I1x, I1y, 0} per pixel, the layout the gather kernel reads
         MI_HIP_TRY(hipMalloc((void **)&pk, sizeof(float) * 4 * (size_t)g.ps));

@@ -42,8 +42,78 @@ __device__ __forceinline__ void fetch3(const float *P, int W, int H, int ld, int
     vy = 0.5f * (P[(long long)min(cy + 1, H - 1) * ld + cx] - P[(long long)max(cy - 1, 0) * ld + cx]);
 }
 
+// The three bicubic sums of an interior window R (rows sy-1 .. sy+4, columns sx-1 .. sx+4; the corners are unused):
+// I1, I1x = 0.5 (I1[x+1] - I1[x-1]) and I1y = 0.5 (I1[y+1] - I1[y-1]) interpolated at the 4 x 4 taps.
+// FAST = false: the reference's arithmetic, tap by tap (bit-exact against the oracle): CPU_REF = cv::remap's bicubic interior,
+//   sum += S[0]*w[0] + S[1]*w[1] + S[2]*w[2] + S[3]*w[3] per row with w = wy[j]*wx[i]; CUDA_COMPAT = tvl1flow.cu:118-148, one
+//   running sum per plane and the weights normalised by their sum.
+// FAST = true (fast-math calcs: the default under MI_SEM_CUDA_COMPAT, opt-in MIFLOW_WARP_FAST=1 under MI_SEM_CPU_REF): the same three sums in SEPARABLE form -- six row sums of I1 with the x weights shared
+//   by I1 and I1y, four row sums with the differenced x weights for I1x, then the y weights: 68 instead of 173 VALU operations per
+//   pixel, +4.7 % pairs/s at 1080p (r02z5: 1 223 vs 1 167).  It differs from the tap-by-tap sums by rounding only (~3e-5 on images
+//   in 0..255), but rho_c = I1w - ... - I0 cancels to a small number, so that rounding perturbs the flow -- and under the CPU
+//   class's semantics every perturbation of the flow is amplified by the 1/32-px quantisation of the next warp's map (a pixel
+//   whose map coordinate crosses a bin boundary samples I1 1/32 px away).  Measured mean EPE against the oracle at N = 10 on
+//   240x320 .. 388x584 pairs: 2.0e-3 .. 3.4e-3 px (6e-3 with gamma = 1) against 0.7e-3 .. 1.7e-3 with the tap-by-tap sums --
+//   inside the reference's own CUDA-vs-CPU acceptance by two orders of magnitude, but not inside this repo's stated 5e-3 bound
+//   everywhere, hence not the default there.  cv::cuda's semantics sample the unquantised map: 1.2e-5 px with either form.  (Keeping only I1 tap by tap: 108 operations, +1 %, no better than the default.)
+template <int SEM, bool FAST>
+__device__ __forceinline__ void window_sums(const float (&R)[6][6], const float (&wxv)[4], const float (&wyv)[4], float &v0, float &v1,
+                                            float &v2)
+{
+    if (FAST) {
+        float a[6], bx[4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            a[r] = fmaf(wxv[3], R[r][4], fmaf(wxv[2], R[r][3], fmaf(wxv[1], R[r][2], wxv[0] * R[r][1])));
+        const float d2 = wxv[0] - wxv[2], d3 = wxv[1] - wxv[3];
+#pragma unroll
+        for (int r = 1; r < 5; ++r)
+            bx[r - 1] = fmaf(wxv[3], R[r][5], fmaf(wxv[2], R[r][4], fmaf(d3, R[r][3], fmaf(d2, R[r][2], fmaf(-wxv[1], R[r][1], -wxv[0] * R[r][0])))));
+        float s0 = fmaf(wyv[3], a[4], fmaf(wyv[2], a[3], fmaf(wyv[1], a[2], wyv[0] * a[1])));
+        float s1 = fmaf(wyv[3], bx[3], fmaf(wyv[2], bx[2], fmaf(wyv[1], bx[1], wyv[0] * bx[0])));
+        float s2 = fmaf(wyv[3], a[5] - a[3], fmaf(wyv[2], a[4] - a[2], fmaf(wyv[1], a[3] - a[1], wyv[0] * (a[2] - a[0]))));
+        if (SEM == MI_SEM_CUDA_COMPAT) {
+            const float coeff = __builtin_amdgcn_rcpf(((wxv[0] + wxv[1]) + (wxv[2] + wxv[3])) * ((wyv[0] + wyv[1]) + (wyv[2] + wyv[3])));
+            s0 *= coeff; s1 *= coeff; s2 *= coeff;
+        }
+        v0 = s0; v1 = 0.5f * s1; v2 = 0.5f * s2;
+    } else if (SEM == MI_SEM_CPU_REF) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t0[4], t1[4], t2[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[i] = wyv[j] * wxv[i];
+                t0[i] = R[j + 1][i + 1];
+                t1[i] = 0.5f * (R[j + 1][i + 2] - R[j + 1][i]);
+                t2[i] = 0.5f * (R[j + 2][i + 1] - R[j][i + 1]);
+            }
+            const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
+            const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
+            const float r2 = t2[0] * w[0] + t2[1] * w[1] + t2[2] * w[2] + t2[3] * w[3];
+            if (j == 0) { s0 = r0; s1 = r1; s2 = r2; } else { s0 += r0; s1 += r1; s2 += r2; }
+        }
+        v0 = s0; v1 = s1; v2 = s2;
+    } else {
+        float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float wgt = wxv[i] * wyv[j];
+                sum += wgt * R[j + 1][i + 1];
+                sumx += wgt * (0.5f * (R[j + 1][i + 2] - R[j + 1][i]));
+                sumy += wgt * (0.5f * (R[j + 2][i + 1] - R[j][i + 1]));
+                wsum += wgt;
+            }
+        const float coeff = 1.0f / wsum;
+        v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
+    }
+}
+
 // One output pixel (x, y) of pair plane P: u1v, u2v = the flow at the pixel, i0 = I0 there; writes the five planes at o.
-template <int SEM>
+template <int SEM, bool FAST>
 __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, const float *P, int x, int y, long long o, float u1v,
                                         float u2v, float i0)
 {
@@ -95,40 +165,7 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
             const f4u a = *reinterpret_cast<const f4u *>(q + (long long)5 * ld + 1);
             R[5][1] = a.x; R[5][2] = a.y; R[5][3] = a.z; R[5][4] = a.w;
         }
-        if (SEM == MI_SEM_CPU_REF) {
-            // cv::remap bicubic interior: sum += S[0]*w[0] + S[1]*w[1] + S[2]*w[2] + S[3]*w[3] per row, w = wy[j]*wx[i]
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t0[4], t1[4], t2[4], w[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    w[i] = wyv[j] * wxv[i];
-                    t0[i] = R[j + 1][i + 1];
-                    t1[i] = 0.5f * (R[j + 1][i + 2] - R[j + 1][i]);
-                    t2[i] = 0.5f * (R[j + 2][i + 1] - R[j][i + 1]);
-                }
-                const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
-                const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
-                const float r2 = t2[0] * w[0] + t2[1] * w[1] + t2[2] * w[2] + t2[3] * w[3];
-                if (j == 0) { s0 = r0; s1 = r1; s2 = r2; } else { s0 += r0; s1 += r1; s2 += r2; }
-            }
-            v0 = s0; v1 = s1; v2 = s2;
-        } else {
-            float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float wgt = wxv[i] * wyv[j];
-                    sum += wgt * R[j + 1][i + 1];
-                    sumx += wgt * (0.5f * (R[j + 1][i + 2] - R[j + 1][i]));
-                    sumy += wgt * (0.5f * (R[j + 2][i + 1] - R[j][i + 1]));
-                    wsum += wgt;
-                }
-            const float coeff = 1.0f / wsum;
-            v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
-        }
+        window_sums<SEM, FAST>(R, wxv, wyv, v0, v1, v2);
     } else if (SEM == MI_SEM_CPU_REF) {
         // Windows touching the border.  R[r][c] = I1(sy - 1 + r, sx - 1 + c) with CLAMPED rows and columns -- for a tap inside
         // the image that is exactly how centeredGradient clamps its neighbours, and taps outside the image are not used -- as 32
@@ -207,7 +244,7 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
 // A wave owns NP consecutive TX x TY patches of a row band.  The flow and I0 of patch i + 1 are requested BEFORE the window
 // gathers of patch i are issued, so the two dependent memory phases of a pixel (flow -> addresses -> window) overlap across
 // patches: with one patch per wave the kernel ran at the latency bound of 2 phases x 2048 pixels in flight per CU (r02b).
-template <int SEM, int TX, int NP>
+template <int SEM, int TX, int NP, bool FAST>
 __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_host)
 {
     __shared__ float s_tab[128];
@@ -237,11 +274,134 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
             const int xn = min(x + TX, W - 1);   // clamped: the value of a patch past the right edge is never used
             u1n = U1[xn]; u2n = U2[xn]; i0n = I0r[xn];
         }
-        warp_px<SEM>(A, s_tab, P, x, y, orow + x, u1v, u2v, i0);
+        warp_px<SEM, FAST>(A, s_tab, P, x, y, orow + x, u1v, u2v, i0);
     }
 }
 
-int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
+// ---------------------------------------------------------------------------------------------------------------------------
+// LDS-staged variant.  k_warp6 gathers 6 x (16 + 8) B per pixel through the vector-memory address path -- 144 B of requests for
+// 4 B of new data, every request at 4-byte alignment: the kernel runs at the rate of that path (SQ counters: 32 % of the wave
+// cycles issue-stalled on it, profiles/r02p), and it competes there with the iteration kernel of the other lane.  The flow is
+// smooth, so the windows of a 64 x 16 tile of pixels cover a region only a few pixels larger than the tile: the workgroup
+// finds that region from its own flows (min / max of the window origins), stages it with aligned, coalesced dwordx4 loads
+// (about 2 floats per pixel), and every interior window is read from LDS.  Pixels whose window touches the image border, or
+// tiles whose flow is so wild that the region exceeds the buffer, take the global path of k_warp6 (same arithmetic).
+// Tap values, weights and the accumulation order are those of warp_px: bit-identical planes.
+constexpr int WL_TW = 64, WL_TH = 16, WL_PPT = 4;   // tile; rows per thread (wave w owns rows 4w .. 4w+3, lane = column)
+constexpr int WL_RW = 96, WL_RH = 40;               // staged region capacity, floats x rows (15 KB)
+
+template <int SEM>
+__device__ __forceinline__ void warp_coords(const float *s_tab, int x, int y, float u1v, float u2v, int &sx, int &sy, float (&wxv)[4],
+                                            float (&wyv)[4])
+{
+    if (SEM == MI_SEM_CPU_REF) {
+        const float mx = (float)x + u1v, my = (float)y + u2v;
+        const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
+        sx = min(max(qx >> 5, -32768), 32767) - 1;
+        sy = min(max(qy >> 5, -32768), 32767) - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wxv[k] = s_tab[(qx & 31) * 4 + k]; wyv[k] = s_tab[(qy & 31) * 4 + k]; }
+    } else {
+        const float wxp = (float)x + u1v, wyp = (float)y + u2v;
+        sx = (int)fminf(fmaxf(floorf(wxp), -1.0e9f), 1.0e9f) - 1;
+        sy = (int)fminf(fmaxf(floorf(wyp), -1.0e9f), 1.0e9f) - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wxv[k] = bicubic_coeff_cuda6(wxp - (float)(sx + k));
+            wyv[k] = bicubic_coeff_cuda6(wyp - (float)(sy + k));
+        }
+    }
+}
+
+template <int SEM, bool FAST>
+__global__ __launch_bounds__(256) void k_warp_lds(Warp6Args A, CtlK ctl, int cur_host)
+{
+    __shared__ __attribute__((aligned(16))) float s_reg[WL_RH * WL_RW];
+    __shared__ float s_tab[128];
+    __shared__ int s_mm[4];   // min sx, max sx, min sy, max sy over the tile's interior windows
+    if (SEM == MI_SEM_CPU_REF && threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
+    if (threadIdx.x == 0) { s_mm[0] = 0x7fffffff; s_mm[1] = -0x7fffffff; s_mm[2] = 0x7fffffff; s_mm[3] = -0x7fffffff; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    const int x = blockIdx.x * WL_TW + lane;
+    const int yb = blockIdx.y * WL_TH + wave * WL_PPT;
+    const int b = blockIdx.z;
+    const int cur = resolve_cur_k(ctl, b, cur_host);
+    const long long pb = (long long)b * A.g.ps;
+    const float *P = A.I1 + pb;
+    const int xc = min(x, W - 1);
+    float u1v[WL_PPT], u2v[WL_PPT], i0[WL_PPT];
+#pragma unroll
+    for (int k = 0; k < WL_PPT; ++k) {
+        const long long o = pb + (long long)min(yb + k, H - 1) * ld + xc;   // clamped: values of pixels outside the image are never used
+        u1v[k] = A.u1[cur][o]; u2v[k] = A.u2[cur][o]; i0[k] = A.I0[o];
+    }
+    __syncthreads();   // s_tab, s_mm initialised
+    // window origins of this thread's pixels; extent of the tile's interior windows
+    int mn_x = 0x7fffffff, mx_x = -0x7fffffff, mn_y = 0x7fffffff, mx_y = -0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < WL_PPT; ++k) {
+        int sx, sy;
+        float wxv[4], wyv[4];
+        warp_coords<SEM>(s_tab, x, yb + k, u1v[k], u2v[k], sx, sy, wxv, wyv);
+        const bool interior = (unsigned)(sx - 1) < (unsigned)max(W - 5, 0) && (unsigned)(sy - 1) < (unsigned)max(H - 5, 0);
+        if (interior && x < W && yb + k < H) { mn_x = min(mn_x, sx); mx_x = max(mx_x, sx); mn_y = min(mn_y, sy); mx_y = max(mx_y, sy); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn_x = min(mn_x, __shfl_xor(mn_x, o)); mx_x = max(mx_x, __shfl_xor(mx_x, o));
+        mn_y = min(mn_y, __shfl_xor(mn_y, o)); mx_y = max(mx_y, __shfl_xor(mx_y, o));
+    }
+    if (lane == 0) { atomicMin(&s_mm[0], mn_x); atomicMax(&s_mm[1], mx_x); atomicMin(&s_mm[2], mn_y); atomicMax(&s_mm[3], mx_y); }
+    __syncthreads();
+    // region of I1 all interior windows of the tile lie in: columns rx0 .. (first column rounded down to a 16-byte boundary),
+    // rows ry0 .. ; inside the image by the definition of `interior`
+    const int rx0 = (s_mm[0] - 1) & ~3, ry0 = s_mm[2] - 1;
+    const int rw = s_mm[1] + 4 - rx0 + 1, rh = s_mm[3] + 4 - ry0 + 1;
+    const bool staged = s_mm[1] >= s_mm[0] && rw <= WL_RW && rh <= WL_RH;   // wave-uniform (LDS broadcast)
+    if (staged) {
+        const int rw4 = (rw + 3) >> 2;   // float4 per row; rx0 + 4 * rw4 <= ld because ld is a multiple of 64 and rx0 + rw <= W
+        for (int idx = threadIdx.x; idx < rh * (WL_RW / 4); idx += 256) {
+            const int r = idx / (WL_RW / 4), c4 = idx - r * (WL_RW / 4);
+            if (c4 < rw4) {
+                const float4 v = *reinterpret_cast<const float4 *>(P + (long long)(ry0 + r) * ld + rx0 + 4 * c4);
+                *reinterpret_cast<float4 *>(&s_reg[r * WL_RW + 4 * c4]) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (x >= W) return;
+#pragma unroll 1
+    for (int k = 0; k < WL_PPT; ++k) {
+        const int y = yb + k;
+        if (y >= H) break;
+        const long long o = pb + (long long)y * ld + x;
+        int sx, sy;
+        float wxv[4], wyv[4];
+        warp_coords<SEM>(s_tab, x, y, u1v[k], u2v[k], sx, sy, wxv, wyv);
+        const bool interior = (unsigned)(sx - 1) < (unsigned)max(W - 5, 0) && (unsigned)(sy - 1) < (unsigned)max(H - 5, 0);
+        if (!(staged && interior)) {
+            warp_px<SEM, FAST>(A, s_tab, P, x, y, o, u1v[k], u2v[k], i0[k]);
+            continue;
+        }
+        float R[6][6];
+        const float *q = &s_reg[(sy - 1 - ry0) * WL_RW + (sx - 1 - rx0)];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (!((r == 0 || r == 5) && (c == 0 || c == 5))) R[r][c] = q[r * WL_RW + c];
+        float v0, v1, v2;
+        window_sums<SEM, FAST>(R, wxv, wyv, v0, v1, v2);
+        if (A.I1w) A.I1w[o] = v0;
+        A.I1wx[o] = v1;
+        A.I1wy[o] = v2;
+        A.grad[o] = v1 * v1 + v2 * v2;
+        A.rho[o] = (v0 - v1 * u1v[k] - v2 * u2v[k] - i0[k]);
+    }
+}
+
+int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
                float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
                hipStream_t s)
 {
@@ -252,21 +412,35 @@ int warp_fused(int semantics, const float *I0, const float *I1, const float *u1[
     A.tab = cubic_tab_dev;
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
+    const bool cpu = semantics == MI_SEM_CPU_REF;
+    if (lds < 0 ? tuning().warp_lds != 0 : lds != 0) {
+        const dim3 grid(div_up(g.w, WL_TW), div_up(g.h, WL_TH), g.batch);
+        if (cpu && fast) hipLaunchKernelGGL((k_warp_lds<MI_SEM_CPU_REF, true>), grid, dim3(256), 0, s, A, ck, cur_host);
+        else if (cpu) hipLaunchKernelGGL((k_warp_lds<MI_SEM_CPU_REF, false>), grid, dim3(256), 0, s, A, ck, cur_host);
+        else if (fast) hipLaunchKernelGGL((k_warp_lds<MI_SEM_CUDA_COMPAT, true>), grid, dim3(256), 0, s, A, ck, cur_host);
+        else hipLaunchKernelGGL((k_warp_lds<MI_SEM_CUDA_COMPAT, false>), grid, dim3(256), 0, s, A, ck, cur_host);
+        MI_HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
     const int tile = warp_tile();
     const int np = tuning().warp_np;   // patches per wave (MIFLOW_WARP_NP = 1 | 2 | 4, default 2)
     const dim3 grid(div_up(g.w, tile * np), div_up(g.h, 4 * (64 / tile)), g.batch);
+#define LAUNCH_W6T(SEM, TX, NP)                                                                                          \
+    do {                                                                                                                 \
+        if (fast) hipLaunchKernelGGL((k_warp6<SEM, TX, NP, true>), grid, dim3(256), 0, s, A, ck, cur_host);              \
+        else hipLaunchKernelGGL((k_warp6<SEM, TX, NP, false>), grid, dim3(256), 0, s, A, ck, cur_host);                  \
+    } while (0)
 #define LAUNCH_W6N(SEM, NP)                                                                                              \
     do {                                                                                                                 \
-        if (tile == 16) hipLaunchKernelGGL((k_warp6<SEM, 16, NP>), grid, dim3(256), 0, s, A, ck, cur_host);              \
-        else if (tile == 32) hipLaunchKernelGGL((k_warp6<SEM, 32, NP>), grid, dim3(256), 0, s, A, ck, cur_host);         \
-        else hipLaunchKernelGGL((k_warp6<SEM, 64, NP>), grid, dim3(256), 0, s, A, ck, cur_host);                         \
+        if (tile == 16) LAUNCH_W6T(SEM, 16, NP); else if (tile == 32) LAUNCH_W6T(SEM, 32, NP); else LAUNCH_W6T(SEM, 64, NP); \
     } while (0)
 #define LAUNCH_W6(SEM)                                                                                                   \
     do {                                                                                                                 \
         if (np == 1) LAUNCH_W6N(SEM, 1); else if (np == 4) LAUNCH_W6N(SEM, 4); else LAUNCH_W6N(SEM, 2);                    \
     } while (0)
-    if (semantics == MI_SEM_CPU_REF) LAUNCH_W6(MI_SEM_CPU_REF);
+    if (cpu) LAUNCH_W6(MI_SEM_CPU_REF);
     else LAUNCH_W6(MI_SEM_CUDA_COMPAT);
+#undef LAUNCH_W6T
 #undef LAUNCH_W6N
 #undef LAUNCH_W6
     MI_HIP_TRY(hipGetLastError());

@@ -278,6 +278,48 @@ def test_fused_warp_equals_gather_warp(gpu, oracle, sem, amp):
         np.testing.assert_array_equal(N(x), N(y), err_msg=name)
 
 
+@pytest.mark.parametrize("sem", [0, 1])
+@pytest.mark.parametrize("amp", [0.0, 2.5, 12.0, 400.0])
+@pytest.mark.parametrize("shape", [(130, 203), (6, 9), (97, 640)])
+def test_fused_warp_lds_staged_equals_gather(gpu, sem, amp, shape):
+    """k_warp_lds (windows read from an LDS-staged region of I1 found from the tile's own flows; fallback to the global path
+    for border windows and for tiles whose flow spreads the windows beyond the buffer: amp 12 and 400) and k_warp6 (global
+    gather) are bit-identical, in exact and in fast (separable sums) form."""
+    from opencv_contrib_amd import cuda
+    h, w = shape
+    rng = np.random.default_rng(sem * 7 + int(amp) + h)
+    I0 = (rng.random((h, w)) * 255).astype(np.float32)
+    I1 = (rng.random((h, w)) * 255).astype(np.float32)
+    u1 = (rng.standard_normal((h, w)) * amp).astype(np.float32) + np.float32(3.3)
+    u2 = (rng.standard_normal((h, w)) * amp).astype(np.float32) - np.float32(1.7)
+    for fast in (0, 0x100):
+        a = cuda.tvl1_warpBackward(sem | fast | 0x400, T(I0, gpu), T(I1, gpu), None, None, T(u1, gpu), T(u2, gpu))
+        b = cuda.tvl1_warpBackward(sem | fast | 0x200, T(I0, gpu), T(I1, gpu), None, None, T(u1, gpu), T(u2, gpu))
+        for name, x, y in zip(("I1w", "I1wx", "I1wy", "grad", "rho_c"), a, b):
+            np.testing.assert_array_equal(N(x), N(y), err_msg=f"{name} fast={fast}")
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+@pytest.mark.parametrize("amp", [0.0, 2.5, 400.0])
+def test_fused_warp_fast_math_is_the_exact_warp_up_to_rounding(gpu, sem, amp):
+    """Fast device math forms the three bicubic sums separably (68 instead of 173 operations per pixel): same taps, same
+    weights, another association -- rounding-level differences only (images in 0..255: 1e-3 absolute on the warped planes)."""
+    from opencv_contrib_amd import cuda
+    h, w = 211, 467
+    rng = np.random.default_rng(sem * 11 + int(amp))
+    I0 = (rng.random((h, w)) * 255).astype(np.float32)
+    I1 = (rng.random((h, w)) * 255).astype(np.float32)
+    u1 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    u2 = (rng.standard_normal((h, w)) * amp).astype(np.float32)
+    a = cuda.tvl1_warpBackward(sem, T(I0, gpu), T(I1, gpu), None, None, T(u1, gpu), T(u2, gpu))
+    b = cuda.tvl1_warpBackward(sem | 0x100, T(I0, gpu), T(I1, gpu), None, None, T(u1, gpu), T(u2, gpu))
+    for name, x, y in zip(("I1w", "I1wx", "I1wy"), a[:3], b[:3]):
+        np.testing.assert_allclose(N(y), N(x), rtol=0, atol=1e-3, err_msg=name)
+    np.testing.assert_allclose(N(b[3]), N(a[3]), rtol=1e-4, atol=1e-2, err_msg="grad")
+    scale = 1.0 + np.abs(N(u1)) + np.abs(N(u2))          # rho_c = I1w - I1wx u1 - I1wy u2 - I0
+    assert np.all(np.abs(N(b[4]) - N(a[4])) <= 2e-3 * scale)
+
+
 # ------------------------------------------------------------------------------------------------ StereoBM, configs[2]
 def test_stereobm_1080p_128_15_bit_exact(gpu, oracle):
     from opencv_contrib_amd import cuda

@@ -10,10 +10,11 @@ R=$PWD
 for step in "$@"; do
 case $step in
 tests_tile)
-  (timeout 600 python -m pytest tests/test_tvl1_gpu.py -m gpu -q -x -p no:cacheprovider -k "tile or warp or calc_fast or iterate_blocked" 2>&1 | tail -15) > $O/pytest_tile.log; cat $O/pytest_tile.log ;;
+  (timeout 600 python -m pytest tests/test_tvl1_gpu.py tests/test_baseline_sizes.py -m gpu -q -x -p no:cacheprovider -k "tile or warp or calc_fast or iterate_blocked or tvl1" 2>&1 | tail -15) > $O/pytest_tile.log; cat $O/pytest_tile.log ;;
 ab_tile)
   # register-tile kernel on the small levels: threshold (pixels x pairs per lane) and variant
-  for cfg in ${AB_TILE_CFGS:-"0,0 300000,0 1200000,0 2300000,0 2300000,2 9000000,0 9000000,2 40000000,2"}; do
+  CFGS="${AB_TILE_CFGS:-0,0 300000,0 1200000,0 2300000,0 2300000,2 9000000,0 9000000,2 40000000,2}"
+  for cfg in $CFGS; do
     mx=${cfg%,*}; v=${cfg#*,}
     (MIFLOW_TILE_MAXPX=$mx MIFLOW_TILE_VARIANT=$v timeout 300 python bench.py --no-variants --no-cpu --no-secondary --steps 12 --warmup 3 2>$O/ab_tile_${mx}_$v.err | tail -1) > $O/ab_tile_${mx}_$v.json
     python - <<PY
@@ -22,6 +23,42 @@ try:
     d = json.loads(open('$O/ab_tile_${mx}_$v.json').read()); r = d['roofline']
     print('ab_tile maxpx=$mx variant=$v', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step | iterate us', round(r['avg_launch_us'], 1), 'warp us', round(r['second_kernel']['avg_launch_us'], 1), 'epe', d.get('epe_vs_analytic_flow_px'))
 except Exception as e: print('ab_tile $mx $v failed', e); print(open('$O/ab_tile_${mx}_$v.err').read()[-2000:])
+PY
+  done ;;
+timeline)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace -f csv -d $R/$O/tl -- python $R/bench.py --no-variants --no-cpu --no-secondary --steps 3 --warmup 2 > $R/$O/tl_bench.log 2>&1
+  cd $R
+  python tools/timeline.py $O/tl > $O/timeline.txt 2>&1; tail -5 $O/timeline.txt
+  find $O -type f -size +4M -delete ;;
+ab_env)
+  # generic A/B over environment settings: AB_ENVS="A=1,B=2 A=0 -" (one bench run per word; "-" = defaults), AB_ARGS = extra bench args
+  i=0
+  for cfg in ${AB_ENVS:--}; do
+    i=$((i+1))
+    envs=""; [ "$cfg" != "-" ] && envs=$(echo $cfg | tr ',' ' ')
+    (env $envs timeout 300 python bench.py --no-variants --no-cpu --no-secondary --steps ${AB_STEPS:-12} --warmup 3 ${AB_ARGS:-} 2>$O/ab_env_$i.err | tail -1) > $O/ab_env_$i.json
+    python - <<PY
+import json
+try:
+    d = json.loads(open('$O/ab_env_$i.json').read()); r = d['roofline']
+    print('ab_env [$cfg] ${AB_ARGS:-}', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step | iterate us', round(r['avg_launch_us'], 1), 'warp us', round(r['second_kernel']['avg_launch_us'], 1), 'epe', d.get('epe_vs_analytic_flow_px'))
+except Exception as e: print('ab_env [$cfg] failed', e); print(open('$O/ab_env_$i.err').read()[-2000:])
+PY
+  done ;;
+ab_args)
+  # one bench run per ';'-separated argument list in AB_ARGLIST (environment from AB_ENV, space separated)
+  i=0
+  IFS=';' read -ra LISTS <<< "${AB_ARGLIST:-}"
+  for a in "${LISTS[@]}"; do
+    i=$((i+1))
+    (env ${AB_ENV:-} timeout 300 python bench.py --no-variants --no-cpu --no-secondary --warmup 3 $a 2>$O/ab_args_$i.err | tail -1) > $O/ab_args_$i.json
+    python - <<PY
+import json
+try:
+    d = json.loads(open('$O/ab_args_$i.json').read()); r = d['roofline']
+    print('ab_args [$a] ${AB_ENV:-}', round(d['value'], 1), 'pairs/s', round(d['ms_per_step'], 2), 'ms/step | iterate us', round(r['avg_launch_us'], 1), 'warp us', round(r['second_kernel']['avg_launch_us'], 1), 'epe', d.get('epe_vs_analytic_flow_px'))
+except Exception as e: print('ab_args [$a] failed', e); print(open('$O/ab_args_$i.err').read()[-2000:])
 PY
   done ;;
 tests_new)
