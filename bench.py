@@ -52,6 +52,29 @@ def algo_bytes_per_pair(w, h, warps, iters_per_warp, nscales=5, step=0.8):
     return float(sum(p * (12 + warps * (44 + 64 * iters_per_warp)) for p in level_pixels(w, h, nscales, step)))
 
 
+WARP_VALU_PER_PX = 234.0   # static count of the interior path of k_warp6<CPU_REF, 32, ., exact sums>: 52 (map, phase weights) + 169 (window) + 13 (grad, rho_c)
+
+
+def tbr_band_rows(w, h, pairs, T=10, PF=2, plan_wps=3, simds=1024):
+    """Band height the planner of tvl1_tbr_kernels.hip (plan_band_rows) picks for the T = 10, 1 px/lane kernel: every wave streams
+    rows + 2 T rows, so (rows + 2 T) / rows of the iteration kernel's work is band-halo recomputation."""
+    P = T + 1 + PF
+    M, LW = T, 64
+    strips = 1 if w <= LW - M else 1 + -(-(w - (LW - M)) // (LW - 2 * M))
+    per_band, cap = strips * pairs, simds * plan_wps
+    best = None
+    for nb in range(1, h + 1):
+        R = -(-h // nb)
+        if R < 8 and nb > 1:
+            break
+        cap_nb = simds * nb if nb < 4 and nb < plan_wps else cap
+        rounds = -(-(per_band * nb) // cap_nb)
+        steps = -(-(R + 2 * T) // P) * P
+        if best is None or rounds * steps < best[0]:
+            best = (rounds * steps, nb)
+    return -(-h // best[1])
+
+
 def make_inputs(n, h, w, dev, distinct=4, **kw):
     import torch
     from opencv_contrib_amd import synth
@@ -519,7 +542,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (r02z4 at 1080p: 16 | 32 | 64 pairs = 1 142 | 1 202 | 1 092 pairs/s before the band planner change; 16 was the step of the r01 / early r02 records)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iterations", type=int, default=10)
@@ -664,6 +687,27 @@ def main():
     roof["second_kernel"] = roof_warp
     roof["time_share"] = {"iterate_ms_per_calc": ms_it, "warp_ms_per_calc": ms_w, "calc_ms": 1e3 * el / args.steps,
                           "note": "event intervals of the two lanes add up; they overlap in wall time"}
+    if blocked and args.epsilon == 0:
+        # Whole job in issue terms: lane-instruction slots of the two dominant kernels per second of WALL time (the per-kernel
+        # figures above are event intervals during which the other lane's kernels share the GPU).  executed = what the SIMDs run:
+        # owned pixels x column halo (64/44) x band halo ((R + 2T)/R, R from the planner) for the iteration kernel + the warp's
+        # static count; useful = the same without the two halo factors.
+        lanes_n = out_lanes = (2 if (P.lanes == 0 and B >= 4) or P.lanes == 2 else max(1, P.lanes))
+        dims = [(max(int(round(W * 0.8 ** s)), 1), max(int(round(H * 0.8 ** s)), 1)) for s in range(5)]
+        per_lane = max(1, B // lanes_n)
+        it_exec = sum(w_ * h_ * (tbr_band_rows(w_, h_, per_lane) + 20.0) / tbr_band_rows(w_, h_, per_lane) for w_, h_ in dims) \
+            * B * warps * mean_it * slots * lanes_per_px
+        it_useful = px_levels * B * warps * mean_it * slots
+        wp = px_levels * B * warps * WARP_VALU_PER_PX
+        step_s = el / args.steps
+        roof["whole_job_valu"] = {
+            "executed_T_lane_instr_per_s": (it_exec + wp) / step_s / 1e12, "useful_T_lane_instr_per_s": (it_useful + wp) / step_s / 1e12,
+            "peak": VALU_PEAK_TLIPS, "frac_executed": (it_exec + wp) / step_s / 1e12 / VALU_PEAK_TLIPS,
+            "frac_useful": (it_useful + wp) / step_s / 1e12 / VALU_PEAK_TLIPS,
+            "frac_executed_of_measured_plain_valu_peak": (it_exec + wp) / step_s / 1e12 / (VALU_PEAK_TLIPS * 2.0 / 3.1),
+            "band_rows_finest_level": tbr_band_rows(W, H, per_lane), "warp_valu_per_pixel": WARP_VALU_PER_PX,
+            "note": "iteration kernel (static mix x pixel-iterations x halo factors) + warp kernel (static count x pixels) over the wall "
+                    "time of a step; resize / convert / pack (4 % of the kernel time) not counted"}
 
     out = {"metric": "frame-pairs/sec dense TV-L1 flow @1080p", "value": fps, "unit": "pairs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -752,6 +796,21 @@ def main():
                     "sq_counters": "profiles/r02p/pmc_sq_summary.md (VALU active 0.46, issue-stalled 0.30, parked on waitcnt 0.07 of the wave cycles)"}
         except Exception as e:
             var["iterations10_eps0_one_lane"] = {"error": repr(e)[:200]}
+        # other batch sizes of the same call (16 = the step of the earlier records; 64 = the per-GPU share of BASELINE configs[4])
+        for nb_ in (16, 64):
+            if nb_ == B:
+                continue
+            try:
+                reps = -(-nb_ // B)
+                Ib0 = torch.cat([torch.roll(I0, 8 * k, 1) for k in range(reps)], 0)[:nb_].contiguous()
+                Ib1 = torch.cat([torch.roll(I1, 8 * k, 1) for k in range(reps)], 0)[:nb_].contiguous()
+                Fb = torch.empty((nb_, H, W, 2), dtype=torch.float32, device=dev)
+                hb = max(1, hs * B // nb_)
+                eb, _, _, _ = run(args.iterations, args.epsilon, hb, 1, inputs=(Ib0, Ib1), out=Fb)
+                var[f"batch{nb_}_pairs_per_step"] = {"pairs_per_s": nb_ * hb / eb}
+                del Ib0, Ib1, Fb
+            except Exception as e:
+                var[f"batch{nb_}_pairs_per_step"] = {"error": repr(e)[:200]}
         # SURVEY 8d config 2 "also run CV_8UC1": the same batch as 8-bit frames (the class converts them to f32 once per calc)
         try:
             J0, J1 = (I0 * 255).round().clamp(0, 255).to(torch.uint8), (I1 * 255).round().clamp(0, 255).to(torch.uint8)

@@ -615,10 +615,11 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
     for (int nb = 1; nb <= g.h; ++nb) {
         const int R = div_up(g.h, nb);
         if (R < 8 && nb > 1) break;
-        // a workgroup is four consecutive bands of a strip: a band count that is no multiple of four leaves waves that exit at
-        // once but keep their share of the workgroup's LDS ring allocated (r02z4: 2 bands at 32 pairs per lane ran 1.3 x slower
-        // than 4) -- rounds are counted in allocated waves
-        const long long rounds = (per_band * ((nb + 3) / 4 * 4) + cap - 1) / cap;
+        // a workgroup is four consecutive bands of a strip and the LDS rings admit four workgroups per CU: with fewer than four
+        // bands every workgroup has only nb live waves (the others exit at once, their ring stays allocated), i.e. at most nb
+        // waves per SIMD (r02z4: 2 bands at 32 pairs per lane ran 1.3 x slower than 4)
+        const long long cap_nb = nb < 4 && nb < wps ? (long long)device_simds() * nb : cap;
+        const long long rounds = (per_band * nb + cap_nb - 1) / cap_nb;
         const long long steps = (long long)div_up(R + 2 * T, P) * P;
         const long long cost = rounds * steps;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_nb = nb; }

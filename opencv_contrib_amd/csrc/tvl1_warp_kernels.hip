@@ -112,6 +112,16 @@ __device__ __forceinline__ void window_sums(const float (&R)[6][6], const float 
     }
 }
 
+// fetch3 through a buffer descriptor of the pair's plane: one 32-bit byte offset per load instead of a 64-bit address pair
+__device__ __forceinline__ void fetch3b(__amdgpu_buffer_rsrc_t rs, int W, int H, int ld, int cx, int cy, float &v, float &vx, float &vy)
+{
+    const unsigned ro = (unsigned)cy * (unsigned)ld;
+    const auto L = [&](unsigned e) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4u * e, 0, 0)); };
+    v = L(ro + cx);
+    vx = 0.5f * (L(ro + min(cx + 1, W - 1)) - L(ro + max(cx - 1, 0)));
+    vy = 0.5f * (L((unsigned)min(cy + 1, H - 1) * (unsigned)ld + cx) - L((unsigned)max(cy - 1, 0) * (unsigned)ld + cx));
+}
+
 // One output pixel (x, y) of pair plane P: u1v, u2v = the flow at the pixel, i0 = I0 there; writes the five planes at o.
 template <int SEM, bool FAST>
 __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, const float *P, int x, int y, long long o, float u1v,
@@ -167,40 +177,43 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
         }
         window_sums<SEM, FAST>(R, wxv, wyv, v0, v1, v2);
     } else if (SEM == MI_SEM_CPU_REF) {
-        // Windows touching the border.  R[r][c] = I1(sy - 1 + r, sx - 1 + c) with CLAMPED rows and columns -- for a tap inside
-        // the image that is exactly how centeredGradient clamps its neighbours, and taps outside the image are not used -- as 32
-        // independent loads (one memory round trip; the earlier per-tap loops with their dependent loads made every launch wait
-        // ~30 us for its border waves: the whole launch on the small pyramid levels).  Buffer loads: a wave-uniform descriptor
-        // of the pair's plane + one 32-bit byte offset per load.
-        float R[6][6];
+        // Windows touching the border.  The values a tap row needs are I1(sy + j - 1 .. sy + j + 1, sx - 1 .. sx + 4) with CLAMPED
+        // rows and columns -- for a tap inside the image that is exactly how centeredGradient clamps its neighbours, and taps
+        // outside the image are not used.  One tap row per trip of a rolled loop: its 14 loads are independent (one memory round
+        // trip per row; the earlier tap-by-tap loops waited for every tap's five loads in turn, ~30 us at the end of EVERY
+        // launch), and the rolled loop keeps the kernel at the interior path's register count.  Buffer loads: a wave-uniform
+        // descriptor of the pair's plane + one 32-bit byte offset per load.
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, (unsigned)H * (unsigned)ld * 4u, 0x00020000);
+        const auto L = [&](unsigned e) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4u * e, 0, 0)); };
         unsigned cxs[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) cxs[c] = 4u * (unsigned)min(max(sx - 1 + c, 0), W - 1);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const unsigned ro = (unsigned)min(max(sy - 1 + r, 0), H - 1) * (unsigned)ld * 4u;
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-                if (!((r == 0 || r == 5) && (c == 0 || c == 5)))
-                    R[r][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ro + cxs[c], 0, 0));
-        }
+        for (int c = 0; c < 6; ++c) cxs[c] = (unsigned)min(max(sx - 1 + c, 0), W - 1);
         // the 4 x 4 window of taps is inside the image (only the ring of derivative neighbours is not): cv::remap's interior
         // formula, sum += S[0]*w[0] + S[1]*w[1] + S[2]*w[2] + S[3]*w[3] per row, w = wy[j]*wx[i].  Otherwise its border path: one
         // tap at a time, taps outside the image contribute the border value 0 (skipped: s + (0 - 0) * w == s); a window entirely
         // outside the image has no valid tap and yields 0.
         const bool win4 = (unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
+            const int yj = sy + j;
+            const unsigned ra = (unsigned)min(max(yj - 1, 0), H - 1) * (unsigned)ld, rb = (unsigned)min(max(yj, 0), H - 1) * (unsigned)ld,
+                           rc = (unsigned)min(max(yj + 1, 0), H - 1) * (unsigned)ld;
+            float Ra[4], Rb[6], Rc[4];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Rb[c] = L(rb + cxs[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { Ra[c] = L(ra + cxs[c + 1]); Rc[c] = L(rc + cxs[c + 1]); }
+            // wy[j] with a rolled j: select instead of a dynamically indexed register array
+            const float wyj = j == 0 ? wyv[0] : j == 1 ? wyv[1] : j == 2 ? wyv[2] : wyv[3];
             float t0[4], t1[4], t2[4], w[4];
-            const bool okj = (unsigned)(sy + j) < (unsigned)H;
+            const bool okj = (unsigned)yj < (unsigned)H;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                w[i] = wyv[j] * wxv[i];
-                t0[i] = R[j + 1][i + 1];
-                t1[i] = 0.5f * (R[j + 1][i + 2] - R[j + 1][i]);
-                t2[i] = 0.5f * (R[j + 2][i + 1] - R[j][i + 1]);
+                w[i] = wyj * wxv[i];
+                t0[i] = Rb[i + 1];
+                t1[i] = 0.5f * (Rb[i + 2] - Rb[i]);
+                t2[i] = 0.5f * (Rc[i] - Ra[i]);
             }
             const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
             const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
@@ -215,20 +228,29 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
         }
         v0 = win4 ? s0 : b0; v1 = win4 ? s1 : b1; v2 = win4 ? s2 : b2;
     } else {
-        // the reference's own loop bounds (zero-weight taps included: they read finite clamped data)
-        const int xmin = (int)ceilf(wxp - 2.0f), xmax = (int)floorf(wxp + 2.0f);
-        const int ymin = (int)ceilf(wyp - 2.0f), ymax = (int)floorf(wyp + 2.0f);
+        // Border windows of cv::cuda's semantics (clamp-addressed taps).  The reference visits cx = ceil(wx - 2) .. floor(wx + 2),
+        // four taps, or five when wx is an integer (the outer two then weigh exactly 0); the fixed five-tap window
+        // floor(wx) - 2 .. floor(wx) + 2 adds the same values in the same order plus terms +-0 * (finite clamped data), i.e. the same
+        // bits.  The five taps of a row are unrolled -- their 25 loads are independent, one memory round trip per row; the
+        // earlier tap-by-tap loop waited for every tap's loads in turn (~30 us at the end of every launch).
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, (unsigned)H * (unsigned)ld * 4u, 0x00020000);
         float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
-        for (int cy = ymin; cy <= ymax; ++cy)
-            for (int cx = xmin; cx <= xmax; ++cx) {
-                const float wgt = bicubic_coeff_cuda6(wxp - (float)cx) * bicubic_coeff_cuda6(wyp - (float)cy);
-                float t0, t1, t2;
-                fetch3(P, W, H, ld, min(max(cx, 0), W - 1), min(max(cy, 0), H - 1), t0, t1, t2);
-                sum += wgt * t0;
-                sumx += wgt * t1;
-                sumy += wgt * t2;
+#pragma unroll 1
+        for (int j = 0; j < 5; ++j) {
+            const int cy = sy - 1 + j;
+            const float wyj = bicubic_coeff_cuda6(wyp - (float)cy);
+            float t0[5], t1[5], t2[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) fetch3b(rs, W, H, ld, min(max(sx - 1 + i, 0), W - 1), min(max(cy, 0), H - 1), t0[i], t1[i], t2[i]);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float wgt = bicubic_coeff_cuda6(wxp - (float)(sx - 1 + i)) * wyj;
+                sum += wgt * t0[i];
+                sumx += wgt * t1[i];
+                sumy += wgt * t2[i];
                 wsum += wgt;
             }
+        }
         const float coeff = 1.0f / wsum;
         v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
     }

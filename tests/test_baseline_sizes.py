@@ -316,7 +316,7 @@ def test_fused_warp_fast_math_is_the_exact_warp_up_to_rounding(gpu, sem, amp):
     for name, x, y in zip(("I1w", "I1wx", "I1wy"), a[:3], b[:3]):
         np.testing.assert_allclose(N(y), N(x), rtol=0, atol=1e-3, err_msg=name)
     np.testing.assert_allclose(N(b[3]), N(a[3]), rtol=1e-4, atol=1e-2, err_msg="grad")
-    scale = 1.0 + np.abs(N(u1)) + np.abs(N(u2))          # rho_c = I1w - I1wx u1 - I1wy u2 - I0
+    scale = 1.0 + np.abs(u1) + np.abs(u2)          # rho_c = I1w - I1wx u1 - I1wy u2 - I0
     assert np.all(np.abs(N(b[4]) - N(a[4])) <= 2e-3 * scale)
 
 
