@@ -496,11 +496,16 @@ def static_mix():
         return {"valu_plain": 31.662, "transcendental": 4.069, "dpp": 4.0, "cndmask": 2.223}
 
 
-def pmc_traffic(key):
-    """Measured HBM bytes per launch (separate rocprofv3 --pmc passes of this command, tools/pmc_summary.py), or None."""
+def pmc_traffic(key, pairs_per_launch=None):
+    """Measured HBM bytes per launch (separate rocprofv3 --pmc passes of this command, tools/pmc_summary.py), or None.  The TV-L1
+    figures were collected at `pairs_per_launch` pairs per kernel launch (recorded in the file); they scale with the pairs a launch
+    of the current run processes."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return tj[key]["hbm_bytes_per_launch"], tj[key].get("source")
+        v = tj[key]["hbm_bytes_per_launch"]
+        if pairs_per_launch and v and tj[key].get("pairs_per_launch"):
+            v = v * pairs_per_launch / tj[key]["pairs_per_launch"]
+        return v, tj[key].get("source")
     except Exception:
         return None, None
 
@@ -635,7 +640,8 @@ def main():
               "algorithmic_GBps": bytes_it / (ms_it * 1e-3) / 1e9 if ms_it > 0 else None,
               "note": "64 B x px x iterations executed by the launch (SURVEY 8d) / launch time; with T iterations per HBM pass this "
                       "exceeds the HBM peak by construction -- the kernel is not under the HBM roofline, see `traffic`"}
-    traffic, tsrc = pmc_traffic("tbr" if blocked else "v1")
+    per_lane_pairs = max(1, B // (2 if (P.lanes == 0 and B >= 4) or P.lanes == 2 else max(1, P.lanes)))
+    traffic, tsrc = pmc_traffic("tbr" if blocked else "v1", per_lane_pairs)
     if traffic:
         hbm_it.update({"traffic_bytes_per_launch": traffic, "traffic_GBps": traffic / (ms_it * 1e-3 / max(n_it, 1)) / 1e9,
                        "traffic_frac_of_hbm_peak": traffic / (ms_it * 1e-3 / max(n_it, 1)) / 1e9 / HBM_PEAK_GBS, "traffic_source": tsrc})
@@ -681,7 +687,7 @@ def main():
     if roof_warp["achieved"]:
         roof_warp["frac"] = roof_warp["achieved"] / VMEM_PATH_PEAK_GBS
         roof_warp["hbm_algorithmic_frac"] = roof_warp["hbm_algorithmic_GBps"] / HBM_PEAK_GBS
-    wtraffic, wsrc = pmc_traffic("warp6")
+    wtraffic, wsrc = pmc_traffic("warp6", per_lane_pairs)
     if wtraffic:
         roof_warp.update({"traffic": wtraffic, "traffic_source": wsrc})
     roof["second_kernel"] = roof_warp

@@ -25,6 +25,7 @@ def load(d):
 
 def main():
     d, label = sys.argv[1], sys.argv[2]
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32   # pairs per step of the profiled bench command (2 lanes)
     acc = load(d)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     out = json.load(open(path)) if os.path.exists(path) else {}   # keys of other workloads (tools/pmc_secondary.py) are kept
@@ -43,11 +44,12 @@ def main():
         if f is None or w is None:
             continue
         out[key] = {"hbm_bytes_per_launch": (2 * f + w) * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024, "launches": [nf, nw],
+                    "pairs_per_launch": batch // 2,
                     "source": f"{label}: mean over the launches of two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of "
-                              "`python bench.py --no-variants --no-cpu --no-secondary --steps 2 --warmup 1` (16 pairs, 2 lanes of 8): "
+                              f"`python bench.py --no-variants --no-cpu --no-secondary --steps 2 --warmup 1` ({batch} pairs, 2 lanes of {batch // 2}): "
                               "(FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE) x 1024"}
-    if "convert" in out:   # calibration: 1920 x 1080 x 8 pairs x (2 x 4 B read, 2 x 4 B written)
-        px = 1920 * 1080 * 8
+    if "convert" in out:   # calibration: 1920 x 1080 x (pairs per lane) x (2 x 4 B read, 2 x 4 B written)
+        px = 1920 * 1080 * (batch // 2)
         out["convert"]["expected_fetch_bytes"] = px * 8
         out["convert"]["expected_write_bytes"] = px * 8
     out["v1"] = {"hbm_bytes_per_launch": None, "source": "not collected for the exact-math kernel"}
