@@ -36,6 +36,7 @@ const Tuning &tuning()
             t.tile_maxpx = e && *e ? atoll(e) : 2300000;   // the three coarsest levels of a 1080p pyramid at 8..16 pairs per lane
         }
         t.tile_variant = env_int("MIFLOW_TILE_VARIANT", 0);
+        t.tile_spec = env_int("MIFLOW_TILE_SPEC", 1);
         t.lanes = env_int("MIFLOW_LANES", 0);
         t.spec = env_int("MIFLOW_SPEC", 1);
         t.exact_tb = env_int("MIFLOW_EXACT_TB", 1);

@@ -108,6 +108,9 @@ struct SpecK {
 };
 
 int tb_spec_plan(int n, int warp_index, bool large_level, int *blocks, int max_blocks);
+// the same step on register tiles (tvl1_tile_kernels.hip); iterate_tb_spec dispatches to it where tile_eligible(g)
+int iterate_tile_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, const Ctl &ctl, const SpecK &sk, int e0,
+                      hipStream_t s);
 int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, const Ctl &ctl,
                     const SpecK &sk, int e0, hipStream_t s);
 // cost-model decomposition of n iterations into supported blocks (largest first); returns the count

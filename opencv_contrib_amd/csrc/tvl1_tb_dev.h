@@ -47,6 +47,90 @@ struct TbArgs {
 #define MI_SLOT_ITERS(y) (((y) >> 8) & 0xff)
 #define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */
 
+// One SPECULATIVE STEP of the convergence-checked path (epsilon > 0), shared by the streaming kernel (k_iterate_tbr MODE 1) and the
+// register-tile kernel (k_iterate_tile SPEC): (1) settle the block the previous launch of this warp ran speculatively -- every
+// workgroup, redundantly, from the same device data => the same decision; (2) pick this launch's work: a replay of exactly the
+// iterations the reference would have run, the next speculative block (record = true: its per-iteration error sums are
+// recorded), or nothing (returns false).  T = the most iterations this launch's kernel can run; `writer` = the one thread per
+// pair that publishes the decision in the launch's control slot.  cur = the buffer set this launch reads.
+__device__ __forceinline__ bool spec_settle(const CtlK &ck, const SpecK &sk, int T, int b, bool writer, int &cur, int &nit_out, bool &record)
+{
+    // (1) settle the block the previous launch of this warp ran speculatively (every workgroup, redundantly, from the same
+    //     device data => the same decision); (2) pick this launch's work: replay, the next speculative block, or nothing.
+    int base = 0, done = 0, n = 0, replay = 0, accepted = 0, pbase = 0;
+    double prev = 0.0;                    // cv::cuda's prevError
+    float e_last = 0.f, e_before = 0.f;   // error / threshold of the last two accepted iterations (0: unknown)
+    if (ck.q_prev >= 0) {
+        const long long sp = (long long)b * ck.Q + ck.q_prev;
+        const int2 sl = ck.S[sp];
+        pbase = sl.x ^ (sl.y & MI_SLOT_FLIP);
+        base = pbase;
+        if (!ck.first_of_warp) {
+            const int4 px = sk.X[sp];
+            prev = ck.P[sp];
+            n = px.x;
+            e_last = __int_as_float(px.z);
+            if (sl.y & MI_SLOT_DONE) {
+                done = 1;
+            } else if (px.y > 0) {
+                const int pn = px.y;
+                int kk = 0, conv = 0;
+                for (int t = 0; t < pn; ++t) {
+                    const int na = n + t;
+                    const bool calc = !ck.sched || ((na & 1) && prev < ck.thr);
+                    const double e = (double)ck.E[(long long)b * ck.Q + sk.e0_prev + t] * (1.0 / ERR_FIX_SCALE);
+                    e_before = e_last;
+                    e_last = (float)(e / ck.thr);
+                    if (calc) {
+                        prev = e;
+                        if (!(e > ck.thr)) { kk = t + 1; conv = 1; break; }
+                    } else {
+                        prev -= ck.thr;
+                    }
+                }
+                if (conv && kk + sk.slack < pn) {   // the loop would have stopped inside the block: redo exactly kk iterations from its input
+                    replay = kk; accepted = kk; n += kk; done = 1;
+                } else {                 // the block stands
+                    base = pbase ^ 1; accepted = pn; n += pn;
+                    done = conv || n >= sk.iters;
+                }
+            }
+        }
+    }
+    if (ck.reset_cur) base = pbase = 0;
+    int nit = 0;
+    if (replay) {
+        nit = replay;
+    } else if (!done && !sk.final_launch) {
+        // block length: an estimate of the iterations still needed.  ANY value in [lo, hi] gives the same results; a good one
+        // avoids both a replay (too long) and extra passes (too short).  A pass costs nearly the same whatever its length
+        // (it is bound by its 64 B/px), so what counts is the number of passes.
+        int pred = T;
+        if (!ck.sched) {
+            if (ck.first_of_warp) {
+                if (sk.q_hist >= 0) pred = (sk.X[(long long)b * ck.Q + sk.q_hist].x * sk.hist_num) / sk.hist_den;
+            } else if (e_before > e_last && e_last > 1.f) {
+                pred = (int)ceilf(__logf(e_last) / __logf(e_before / e_last));   // geometric decay of the error sum
+            } else if (e_last > 0.f) {
+                pred = 2;
+            }
+        }
+        const int hi = min(T, sk.iters - n), lo = max(1, sk.iters - n - sk.t_after);
+        nit = max(lo, min(hi, pred));
+        record = true;
+    }
+    if (writer) {
+        const long long sq = (long long)b * ck.Q + ck.q;
+        ck.S[sq] = make_int2(replay ? pbase : base, (replay ? MI_SLOT_FLIP : 0) | (done ? MI_SLOT_DONE : 0) | (accepted << 8));
+        ck.P[sq] = prev;
+        sk.X[sq] = make_int4(n, record ? nit : 0, __float_as_int(e_last), 0);
+    }
+    if (nit == 0) return false;
+    cur = replay ? pbase : base;
+    nit_out = nit;
+    return true;
+}
+
 // per-wave LDS ring of static rows: slot layout [plane 0..3][64*PPL floats]
 template <int PPL>
 __device__ __forceinline__ void lds_put(float *slot, int lane, const Stat<PPL> &s)

@@ -355,80 +355,10 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     c.nit = T;
     bool record = false;
     if (MODE == 1) {
-        const CtlK &ck = A.ctl;
-        const SpecK &sk = A.sk;
-        // (1) settle the block the previous launch of this warp ran speculatively (every workgroup, redundantly, from the same
-        //     device data => the same decision); (2) pick this launch's work: replay, the next speculative block, or nothing.
-        int base = 0, done = 0, n = 0, replay = 0, accepted = 0, pbase = 0;
-        double prev = 0.0;                    // cv::cuda's prevError
-        float e_last = 0.f, e_before = 0.f;   // error / threshold of the last two accepted iterations (0: unknown)
-        if (ck.q_prev >= 0) {
-            const long long sp = (long long)b * ck.Q + ck.q_prev;
-            const int2 sl = ck.S[sp];
-            pbase = sl.x ^ (sl.y & MI_SLOT_FLIP);
-            base = pbase;
-            if (!ck.first_of_warp) {
-                const int4 px = sk.X[sp];
-                prev = ck.P[sp];
-                n = px.x;
-                e_last = __int_as_float(px.z);
-                if (sl.y & MI_SLOT_DONE) {
-                    done = 1;
-                } else if (px.y > 0) {
-                    const int pn = px.y;
-                    int kk = 0, conv = 0;
-                    for (int t = 0; t < pn; ++t) {
-                        const int na = n + t;
-                        const bool calc = !ck.sched || ((na & 1) && prev < ck.thr);
-                        const double e = (double)ck.E[(long long)b * ck.Q + sk.e0_prev + t] * (1.0 / ERR_FIX_SCALE);
-                        e_before = e_last;
-                        e_last = (float)(e / ck.thr);
-                        if (calc) {
-                            prev = e;
-                            if (!(e > ck.thr)) { kk = t + 1; conv = 1; break; }
-                        } else {
-                            prev -= ck.thr;
-                        }
-                    }
-                    if (conv && kk + sk.slack < pn) {   // the loop would have stopped inside the block: redo exactly kk iterations from its input
-                        replay = kk; accepted = kk; n += kk; done = 1;
-                    } else {                 // the block stands
-                        base = pbase ^ 1; accepted = pn; n += pn;
-                        done = conv || n >= sk.iters;
-                    }
-                }
-            }
-        }
-        if (ck.reset_cur) base = pbase = 0;
+        // settle the previous launch's speculative block and pick this launch's work (tvl1_tb_dev.h); one writer per pair b: the
+        // REMAPPED block indices
         int nit = 0;
-        if (replay) {
-            nit = replay;
-        } else if (!done && !sk.final_launch) {
-            // block length: an estimate of the iterations still needed.  ANY value in [lo, hi] gives the same results; a good one
-            // avoids both a replay (too long) and extra passes (too short).  A pass costs nearly the same whatever its length
-            // (it is bound by its 64 B/px), so what counts is the number of passes.
-            int pred = T;
-            if (!ck.sched) {
-                if (ck.first_of_warp) {
-                    if (sk.q_hist >= 0) pred = (sk.X[(long long)b * ck.Q + sk.q_hist].x * sk.hist_num) / sk.hist_den;
-                } else if (e_before > e_last && e_last > 1.f) {
-                    pred = (int)ceilf(__logf(e_last) / __logf(e_before / e_last));   // geometric decay of the error sum
-                } else if (e_last > 0.f) {
-                    pred = 2;
-                }
-            }
-            const int hi = min(T, sk.iters - n), lo = max(1, sk.iters - n - sk.t_after);
-            nit = max(lo, min(hi, pred));
-            record = true;
-        }
-        if (strip == 0 && bgrp == 0 && threadIdx.x == 0) {   // the REMAPPED indices: one writer per pair b
-            const long long sq = (long long)b * ck.Q + ck.q;
-            ck.S[sq] = make_int2(replay ? pbase : base, (replay ? MI_SLOT_FLIP : 0) | (done ? MI_SLOT_DONE : 0) | (accepted << 8));
-            ck.P[sq] = prev;
-            sk.X[sq] = make_int4(n, record ? nit : 0, __float_as_int(e_last), 0);
-        }
-        if (nit == 0) return;
-        cur = replay ? pbase : base;
+        if (!spec_settle(A.ctl, A.sk, T, b, strip == 0 && bgrp == 0 && threadIdx.x == 0, cur, nit, record)) return;
         c.nit = __builtin_amdgcn_readfirstlane(nit);
     }
     c.uin[0] = A.pl.u[cur][0] + pb; c.uin[1] = A.pl.u[cur][1] + pb;
@@ -684,6 +614,10 @@ int tb_spec_plan(int n, int warp_index, bool large_level, int *blocks, int max_b
 int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, const Ctl &ctl,
                     const SpecK &sk, int e0, hipStream_t s)
 {
+    // small levels: the same step on register tiles (serial depth of a launch = its iterations, not the image height); integer
+    // error sums and identical per-pixel arithmetic => the same decisions and the same flows as the streaming kernel
+    if (tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
+        return iterate_tile_spec(T, pl, g, l_t, theta, taut, ctl, sk, e0, s);
     const TbrEntry *e = nullptr;
     for (const TbrEntry &c : g_spec) if (c.T == T) e = &c;
     if (!e) { set_error("no speculative kernel for time block %d", T); return MI_ERR_BAD_ARG; }

@@ -25,6 +25,7 @@
 // two kernels a level runs on never changes a flow.
 #include "tvl1_tb_dev.h"
 #include <cstdio>
+#include <cstring>
 
 namespace mi {
 namespace tvl1 {
@@ -34,12 +35,19 @@ struct TileArgs {
     Geo g;
     float l_t, theta, taut;
     int cur;   // input set
-    int nit;   // iterations of this launch, 1..10
+    int nit;   // iterations of this launch, 1..10 (SPEC: the most this launch may run; the device picks the count)
+    // SPEC only: slot protocol of the speculative steps (tvl1_tb_dev.h spec_settle), e0 = index of the first error sum of this block
+    CtlK ctl;
+    SpecK sk;
+    int e0;
 };
 
 constexpr int TILE_M = 10;   // validity margin per side = the most iterations one launch may run
 
-template <int RW, int NW, bool PZ>
+// SPEC: one speculative step of the convergence-checked path (k_iterate_tbr MODE 1 on register tiles): the block length comes from
+// the device-side settle logic, and every iteration's error sum(du1^2 + du2^2) over the tile's OWNED pixels is added -- as 2^-24
+// fixed-point integers, so the totals do not depend on the tiling -- to the per-iteration slots the next launch reads.
+template <int RW, int NW, bool PZ, bool SPEC>
 __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
 {
     constexpr int M = TILE_M;
@@ -64,7 +72,12 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     const int ys = y0 - M + wave * RW;                     // image row of this wave's first register row
 
     const long long pb = (long long)b * A.g.ps;
-    const int cur = A.cur;
+    int cur = A.cur, nit = A.nit;
+    bool record = false;
+    if (SPEC) {
+        // every thread takes the same decision from the same device data: the whole workgroup leaves or stays
+        if (!spec_settle(A.ctl, A.sk, A.nit, b, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, cur, nit, record)) return;
+    }
     const float *const uin[2] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb};
     const float *const pin[4] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb};
     const float *const stp[4] = {A.pl.ix + pb, A.pl.iy + pb, A.pl.g + pb, A.pl.rc + pb};
@@ -89,8 +102,8 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     __syncthreads();
 
     const float l_t = A.l_t, theta = A.theta, taut = A.taut;
-    const int nit = A.nit;
     for (int t = 0; t < nit; ++t) {
+        unsigned long long acc = 0;
         // ---- U phase: u_t(a) for every row (stage_r, first half; optflow/src/tvl1flow.cpp:989-1041, 1096-1112)
         // the row above the tile's first row does not exist: any finite value (that row is margin, or cut by negm1 at a = 0)
         const float pa12 = wave > 0 ? xch[wave - 1][2][lane] : 0.f;
@@ -107,8 +120,21 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
             const float div2 = dx2 + fmaf(negm1, ab22, p22[r]);
             const float rho = fmaf(ix[r], u1[r], fmaf(iy[r], u2[r], rc[r]));
             const float fi = __builtin_amdgcn_fmed3f(-rho * rg[r], -l_t, l_t);
-            u1[r] = fmaf(theta, div1, fmaf(fi, ix[r], u1[r]));
-            u2[r] = fmaf(theta, div2, fmaf(fi, iy[r], u2[r]));
+            const float nu1 = fmaf(theta, div1, fmaf(fi, ix[r], u1[r]));
+            const float nu2 = fmaf(theta, div2, fmaf(fi, iy[r], u2[r]));
+            if (SPEC) {   // stage_r<ERR>: the pixel's term rounded to 2^-24 px^2; es doubles as the row-ownership mask
+                const float es = __uint_as_float((a >= y0 && a < y1) ? 0x4b800000u : 0u);
+                const float e1 = nu1 - u1[r], e2 = nu2 - u2[r];
+                acc += (unsigned long long)__float2uint_rn(fmaf(e1, e1, e2 * e2) * es);
+            }
+            u1[r] = nu1;
+            u2[r] = nu2;
+        }
+        if (SPEC && record) {   // exact integer reduction over the wave's owned lanes, one device-scope add per wave and iteration
+            unsigned long long sacc = st_ok ? acc : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+            if (lane == 0) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + t], sacc);
         }
         xch[wave][0][lane] = u1[0];
         xch[wave][1][lane] = u2[0];
@@ -160,14 +186,14 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     }
 }
 
-template <int RW, int NW>
+template <int RW, int NW, bool SPEC>
 static int launch_tile(const TileArgs &A, bool pz, hipStream_t s)
 {
     constexpr int M = TILE_M, LW = 64, STRIDE = LW - 2 * M, BR = NW * RW - 2 * M;
     const int nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
     const dim3 grid(nstrips, div_up(A.g.h, BR), A.g.batch);
-    if (pz) hipLaunchKernelGGL((k_iterate_tile<RW, NW, true>), grid, dim3(NW * 64), 0, s, A);
-    else hipLaunchKernelGGL((k_iterate_tile<RW, NW, false>), grid, dim3(NW * 64), 0, s, A);
+    if (pz && !SPEC) hipLaunchKernelGGL((k_iterate_tile<RW, NW, true, false>), grid, dim3(NW * 64), 0, s, A);
+    else hipLaunchKernelGGL((k_iterate_tile<RW, NW, false, SPEC>), grid, dim3(NW * 64), 0, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -175,9 +201,9 @@ static int launch_tile(const TileArgs &A, bool pz, hipStream_t s)
 typedef int (*TileLaunchFn)(const TileArgs &, bool, hipStream_t);
 struct TileEntry {
     int RW, NW;
-    TileLaunchFn launch;
+    TileLaunchFn launch, spec;
 };
-#define TILE(RW, NW) {RW, NW, launch_tile<RW, NW>}
+#define TILE(RW, NW) {RW, NW, launch_tile<RW, NW, false>, launch_tile<RW, NW, true>}
 static const TileEntry g_tile[] = {TILE(4, 16), TILE(6, 16), TILE(8, 16), TILE(8, 8), TILE(6, 8), TILE(3, 16)};
 constexpr int kTileVariants = (int)(sizeof(g_tile) / sizeof(g_tile[0]));
 
@@ -199,6 +225,7 @@ int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float
     if (variant < 0) variant = tuning().tile_variant;
     if (variant < 0 || variant >= kTileVariants) { set_error("register-tile kernel: no variant %d", variant); return MI_ERR_BAD_ARG; }
     TileArgs A;
+    memset(&A, 0, sizeof(A));
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.nit = nit;
     if (tuning().tb_verbose) {
         static int shown = 0;
@@ -206,6 +233,22 @@ int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float
             fprintf(stderr, "[tile] rw=%d nw=%d nit=%d %dx%d batch=%d\n", g_tile[variant].RW, g_tile[variant].NW, nit, g.w, g.h, g.batch);
     }
     return g_tile[variant].launch(A, p_zero, s);
+}
+
+// One speculative step on register tiles (see iterate_tb_spec): T = the most iterations the launch may run (1..10).
+int iterate_tile_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, const Ctl &ctl, const SpecK &sk, int e0,
+                      hipStream_t s)
+{
+    if (T < 1 || T > TILE_M) { set_error("register-tile kernel: block of %d iterations (1..%d)", T, TILE_M); return MI_ERR_BAD_ARG; }
+    int variant = tuning().tile_variant;
+    if (variant < 0 || variant >= kTileVariants) variant = 0;
+    TileArgs A;
+    memset(&A, 0, sizeof(A));
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.nit = T;
+    A.ctl = make_ctlk(&ctl);
+    A.sk = sk;
+    A.e0 = e0;
+    return g_tile[variant].spec(A, false, s);
 }
 
 }  // namespace tvl1

@@ -203,6 +203,26 @@ def test_speculative_steps_iteration_limits_and_small_images(gpu, oracle, shape,
     assert np.array(full.lastIterations()).min() == iters and np.array(full.lastIterations()).max() == iters
 
 
+@pytest.mark.parametrize("eps,iters", [(0.0, 10), (0.01, 300), (0.05, 23)])
+def test_flows_do_not_depend_on_which_iteration_kernel_a_level_runs_on(gpu, eps, iters):
+    """A level of at most 2.3 M pixels x pairs per lane iterates on the register-tile kernel, a larger one on the streaming kernel
+    (tvl1_tile_kernels.hip): the same 150 x 210 pairs alone (tile kernel, also for the speculative steps of the convergence path)
+    and inside a batch of 160 (streaming kernel on the two finest levels) must give bit-identical flows and iteration counts --
+    identical per-pixel arithmetic, integer error sums."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(150, 210, seed=70 + k)[:2] for k in range(4)]
+    I0s = [T(pairs[k % 4][0], gpu) for k in range(160)]
+    I1s = [T(pairs[k % 4][1], gpu) for k in range(160)]
+    big = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps)
+    fb = big.calc_batch(I0s, I1s)
+    torch.cuda.synchronize()
+    single = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps)
+    for k in (0, 1, 2, 3, 157):
+        assert torch.equal(single.calc(I0s[k], I1s[k]), fb[k]), f"pair {k}"
+        assert single.lastIterations(0) == big.lastIterations(k)
+
+
 def test_stop_slack_runs_at_most_a_few_more_iterations(gpu, oracle):
     """mi_tvl1_params.stop_slack = 1 (miflow extension, off by default): a speculative block is kept when the reference's test
     first passed one iteration before its end.  Counts stay within the slack (+ the knock-on of a slightly different start of
