@@ -839,6 +839,24 @@ def main():
             del a1, one
         except Exception as e:
             var["single_pair_calc_sequential"] = {"error": repr(e)[:200]}
+        # the reference's own perf test of the class (cudaoptflow/perf/perf_optflow.cpp:283-311): ONE pair per calc(), class defaults
+        # (300 iterations, epsilon 0.01), a 640 x 480 frame pair -- and the same at 1080p
+        for (ww, hh, tag) in ((640, 480, "reference_perf_test_scenario_640x480_class_defaults_single_calc"), (W, H, "class_defaults_single_pair_calc_sequential")):
+            try:
+                q0, q1, _ = make_inputs(1, hh, ww, dev, distinct=1)
+                a1 = cuda.OpticalFlowDual_TVL1.create()
+                one = torch.empty((hh, ww, 2), dtype=torch.float32, device=dev)
+                for _ in range(2):
+                    a1.calc(q0[0], q1[0], one)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(8):
+                    a1.calc(q0[0], q1[0], one)
+                torch.cuda.synchronize()
+                var[tag] = {"calcs_per_s": 8 / (time.perf_counter() - t1), "executed_iterations_per_warp_mean": float(np.mean(a1.lastIterations(0)))}
+                del a1, one, q0, q1
+            except Exception as e:
+                var[tag] = {"error": repr(e)[:200]}
         # north_star "1080p/4K pairs": the same object on 3840x2160 pairs (4 pairs per step = the pixels of 16 1080p pairs)
         try:
             # same motion in pixels as the 1080p pairs (flow_scale 3, texture sigma 6): five 0.8-scales cover it at either size

@@ -345,12 +345,20 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     const bool spec = check && !P.exact_math && P.time_block != 1 && P.gamma == 0.0 && P.median_filtering <= 1 && tuning().spec != 0;
     // control slots per pair: one per launch (S, P, X) and one error sum per iteration (E); both index spaces fit max(.,.)
     long long Q = (long long)ns * P.warps * iters_per_warp;
-    std::vector<int> spec_plan[3];   // kernel block sizes of the speculative steps: first warp of a large level / of a small one / later warps
+    std::vector<int> spec_plan[4];   // kernel block sizes of the speculative steps: first warp of a large level / of a small one / later warps / levels on the register-tile kernel
     const double kLargeLevel = 12e6;   // px x pairs from which the T = 10 kernel pays for a long first block
     if (spec) {
         long long e_max = 0, l_max = 0;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             spec_plan[k].resize(iters_per_warp + 40);
+            if (k == 3) {
+                // register-tile kernel: a launch costs its iterations, not its block size, and a converged warp pays ~3 us per
+                // remaining (empty) launch -- the fewest launches: blocks of the kernel's margin
+                int kk = 0, sum = 0;
+                const int want = iters_per_warp + (iters_per_warp > 10 ? 30 : iters_per_warp > 1 ? 10 : 0);
+                while (sum < want && kk < (int)spec_plan[k].size()) { spec_plan[k][kk++] = tile_max_block(); sum += tile_max_block(); }
+                spec_plan[k].resize(kk);
+            } else
             spec_plan[k].resize(tb_spec_plan(iters_per_warp, k == 2 ? 1 : 0, k == 0, spec_plan[k].data(), (int)spec_plan[k].size()));
             long long t = 0;
             for (int v : spec_plan[k]) t += v;
@@ -525,7 +533,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // Speculative steps (k_iterate_tbr MODE 1): a launch runs a block of iterations recording their error sums; the next
                 // launch applies the reference's stopping rule to them and either builds on the block or replays the exact
                 // count from its input.  One settling launch ends the warp.  After convergence the remaining launches end at once.
-                const std::vector<int> &plan = spec_plan[wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
+                const std::vector<int> &plan = spec_plan[(tile_eligible(g) && tuning().tile_spec != 0) ? 3 : wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
                 int t_after = 0;
                 for (int v : plan) t_after += v;
                 SpecK sk;

@@ -57,6 +57,9 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     static_assert(BR > 0, "tile too small for its margin");
     // [wave][0,1: u1,u2 of the wave's first row (after the U phase)  2,3: p12,p22 of its last row][lane]
     __shared__ float xch[NW][4][64];
+    // SPEC: per-iteration error sums of the workgroup; one global add per workgroup and iteration at the end (one per WAVE and
+    // iteration -- 17 600 waves at 1080p -- made the launch 10 x slower: the adds of a slot serialise in L2)
+    __shared__ unsigned long long s_err[TILE_M];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     for (int r = 0; r < RW; ++r) rg[r] = __builtin_amdgcn_rcpf(fmaxf(rg[r], 1e-30f));   // finish_static
     xch[wave][2][lane] = p12[RW - 1];
     xch[wave][3][lane] = p22[RW - 1];
+    if (SPEC && threadIdx.x < TILE_M) s_err[threadIdx.x] = 0ull;
     __syncthreads();
 
     const float l_t = A.l_t, theta = A.theta, taut = A.taut;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
             unsigned long long sacc = st_ok ? acc : 0ull;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-            if (lane == 0) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + t], sacc);
+            if (lane == 0) atomicAdd(&s_err[t], sacc);
         }
         xch[wave][0][lane] = u1[0];
         xch[wave][1][lane] = u2[0];
@@ -171,6 +175,8 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
         __syncthreads();
     }
 
+    // (the last barrier of the loop has made every wave's s_err adds visible)
+    if (SPEC && record && threadIdx.x < nit) atomicAdd(&A.ctl.E[(long long)b * A.ctl.Q + A.e0 + threadIdx.x], s_err[threadIdx.x]);
     if (st_ok) {
         float *const uout[2] = {A.pl.u[cur ^ 1][0] + pb, A.pl.u[cur ^ 1][1] + pb};
         float *const pout[4] = {A.pl.p[cur ^ 1][0] + pb, A.pl.p[cur ^ 1][1] + pb, A.pl.p[cur ^ 1][2] + pb, A.pl.p[cur ^ 1][3] + pb};
