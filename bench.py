@@ -32,7 +32,25 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 VALU_PEAK_TLIPS = 157.3 / 2
 # vector-memory data path: 64 B/clk per CU (MI355X_MICROARCH.md: a dwordx4 wave load = 16 clk) x 256 CUs x 2.4 GHz
 VMEM_PATH_PEAK_GBS = 64 * 256 * 2.4
-SBM_VALU_PER_PXD = 10.0   # ~10 integer operations per (pixel, disparity)
+
+
+def sbm_valu_per_pxd():
+    """VALU instructions of k_block_match's row loop per (output pixel, disparity) of a tile row: static count of the R = 7
+    instantiation (tools/static_mix.py sbm -> profiles/static_mix_sbm.json): column-sum slide (v_sub_u32_sdwa + v_mad_i32_i24, both
+    rows), window slide, score packing and the transposed wave max-reduction with its selects -- 29.4, not the ~10 arithmetic
+    operations SURVEY 8d config 3 estimated (which the round-1 figure used)."""
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "static_mix_sbm.json")))["valu_per_output_pixel_and_disparity"])
+    except Exception:
+        return 29.375
+
+
+def sbm_band_rows(rows, cols, ndisp, R, pairs):
+    """Rows per band of block_match_impl (stereobm_kernels.hip): every band slides 2R rows before its first output row."""
+    xt = -(-(cols - ndisp - 2 * R) // 48)
+    bands = -(-5120 // (xt * -(-ndisp // 64) * pairs))
+    rb = -(-(rows - 2 * R) // max(bands, 1))
+    return min(max(rb, 2 * R + 2), 48)
 
 
 def level_pixels(w, h, nscales=5, step=0.8):
@@ -188,6 +206,9 @@ def bench_stereobm(args):
     R = bs // 2
     pxd = float((W - nd - 2 * R) * (H - 2 * R)) * nd
     algo_bytes = 3.0 * W * H   # read left + right, write disparity (u8)
+    vpd, R_ = sbm_valu_per_pxd(), bs // 2
+    rb1, rbb = sbm_band_rows(H, W, nd, R_, 1), sbm_band_rows(H, W, nd, R_, B)
+    halo_seq, halo_b = (rb1 + 2.0 * R_) / rb1, (rbb + 2.0 * R_) / rbb
     out = {"metric": "frames/sec StereoBM @1080p", "value": n / el, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -196,12 +217,14 @@ def bench_stereobm(args):
            "pixel_disparities_per_s": pxd * n / el,
            "batched_compute_batch": batched, "batched_pixel_disparities_per_s": pxd * n / elb,
            # not HBM-bound (6.2 MB/pair); the work is (pixel, disparity) cost updates on the integer VALU.
-           # k_block_match spends SBM_VALU_PER_PXD lane-instructions per (pixel, disparity) in its row loop (column-sum slide
-           # v_sub_u32_sdwa + v_mad_i32_i24, window sum add/sub, packed compare/select of the running minimum: static count of the
-           # R = 7 instantiation), against the lane-instruction issue peak of the chip
-           "roofline": {"bound": "valu_issue", "achieved": pxd * n / el * SBM_VALU_PER_PXD / 1e12, "peak": VALU_PEAK_TLIPS,
-                        "unit": "T lane-instr/s", "frac": pxd * n / el * SBM_VALU_PER_PXD / 1e12 / VALU_PEAK_TLIPS,
-                        "batched_frac": pxd * n / elb * SBM_VALU_PER_PXD / 1e12 / VALU_PEAK_TLIPS,
+           # achieved = EXECUTED lane-instructions per second: static VALU count of the row loop per (output pixel, disparity)
+           # x (rb + 2R) / rb rows slid per output row (rb = rows per band of the launch plan), against the issue peak
+           "roofline": {"bound": "valu_issue", "achieved": pxd * n / el * vpd * halo_seq / 1e12, "peak": VALU_PEAK_TLIPS,
+                        "unit": "T lane-instr/s", "frac": pxd * n / el * vpd * halo_seq / 1e12 / VALU_PEAK_TLIPS,
+                        "batched_frac": pxd * n / elb * vpd * halo_b / 1e12 / VALU_PEAK_TLIPS,
+                        "valu_per_pixel_disparity": vpd, "rows_slid_per_output_row": {"sequential": halo_seq, "batched": halo_b},
+                        "useful_frac_batched": pxd * n / elb * vpd / 1e12 / VALU_PEAK_TLIPS,
+                        "batched_frac_of_measured_plain_valu_peak": pxd * n / elb * vpd * halo_b / 1e12 / (VALU_PEAK_TLIPS * 2.0 / 3.1),
                         "hbm_algorithmic_GBps": algo_bytes * n / el / 1e9, "hbm_frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS,
                         "traffic": pmc_traffic("stereobm")[0], "traffic_kernel": "k_block_match, bytes per launch (one pair)",
                         "traffic_source": pmc_traffic("stereobm")[1]}}
@@ -212,7 +235,7 @@ def bench_stereobm(args):
         out["ms_per_step"] = 1e3 * B / batched["pairs_per_s"]
         out["config"]["workload"] += "; value = compute_batch"
         out["roofline"]["sequential_frac"] = out["roofline"]["frac"]
-        out["roofline"]["achieved"] = pxd * n / elb * SBM_VALU_PER_PXD / 1e12
+        out["roofline"]["achieved"] = pxd * n / elb * vpd * halo_b / 1e12
         out["roofline"]["frac"] = out["roofline"]["batched_frac"]
     # post-filter of the stereo pipeline: DisparityBilateralFilter(ndisp, radius 3, 1 iteration) on the maps above
     dbf = cuda.createDisparityBilateralFilter(nd, 3, 1)

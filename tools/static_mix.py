@@ -61,6 +61,42 @@ def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0):
     raise SystemExit("instantiation not found: " + pat)
 
 
+def mix_sbm(R=7, MODE=0):
+    """Static instruction count of the row loop of k_block_match<R, MODE> (stereobm_kernels.hip): per trip a lane (= one disparity)
+    slides the column sums of its NC = TW + 2R tile columns down one row and produces the TW window SSDs / winners of that row, so
+    loop VALU / TW = lane-instructions per (output pixel, disparity) of a tile row.  Output of record: profiles/static_mix_sbm.json."""
+    src = os.path.join(ROOT, "opencv_contrib_amd", "csrc", "stereobm_kernels.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-x", "hip", "-S", "--cuda-device-only", src,
+                        "-o", out], check=True, stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    name = f"_ZN2mi3sbm13k_block_matchILi{R}ELi{MODE}EEEvNS0_6BmArgsE"
+    i = txt.index("\n" + name + ":")
+    lines = txt[i:txt.index(".Lfunc_end", i)].split("\n")
+    labels = {m.group(1): k for k, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    best = None
+    for k, l in enumerate(lines):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+        if m and labels.get(m.group(1), k) < k and (best is None or k - labels[m.group(1)] > best[1] - best[0]):
+            best = (labels[m.group(1)], k)
+    cnt = collections.Counter()
+    for l in lines[best[0]:best[1] + 1]:
+        l = l.strip()
+        if l and not l.startswith((".", ";", "//")) and not l.endswith(":"):
+            cnt[l.split()[0]] += 1
+    tw = 48 if R <= 12 else max(16, (64 - 2 * R) & ~3)
+    valu = sum(n for o, n in cnt.items() if o.startswith("v_"))
+    return {"kernel": f"k_block_match<{R},{MODE}>", "row_loop_instructions": sum(cnt.values()), "row_loop_valu": valu,
+            "row_loop_salu": sum(n for o, n in cnt.items() if o.startswith("s_")), "row_loop_lds": sum(n for o, n in cnt.items() if o.startswith("ds_")),
+            "tile_output_columns": tw, "valu_per_output_pixel_and_disparity": round(valu / tw, 3),
+            "top": dict(cnt.most_common(10))}
+
+
 if __name__ == "__main__":
-    a = [int(x) for x in sys.argv[1:7]] or [10, 1, 0, 4, 2, 0]
-    print(json.dumps(mix(*a), indent=1))
+    if len(sys.argv) > 1 and sys.argv[1] == "sbm":   # python tools/static_mix.py sbm [R MODE]
+        print(json.dumps(mix_sbm(*[int(x) for x in sys.argv[2:4]]), indent=1))
+    else:
+        a = [int(x) for x in sys.argv[1:7]] or [10, 1, 0, 4, 2, 0]
+        print(json.dumps(mix(*a), indent=1))
