@@ -42,7 +42,7 @@ def sbm_valu_per_pxd():
     try:
         return float(json.load(open(os.path.join(ROOT, "profiles", "static_mix_sbm.json")))["valu_per_output_pixel_and_disparity"])
     except Exception:
-        return 29.375
+        return 17.375
 
 
 def sbm_warmup_ratio():
@@ -51,7 +51,7 @@ def sbm_warmup_ratio():
         d = json.load(open(os.path.join(ROOT, "profiles", "static_mix_sbm.json")))
         return float(d["warmup_row_valu"]) / float(d["row_loop_valu"])
     except Exception:
-        return 157.0 / 1410.0
+        return 157.0 / 834.0
 
 
 def sbm_band_rows(rows, cols, ndisp, R, pairs):

@@ -233,7 +233,11 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
     // inactive lanes (d >= ndisp) carry a bias above any real SSD (max 51*51*255^2 < 2^28) so they never win
     const unsigned bias = active ? 0u : 0x40000000u;
     // wave-uniform facts about the tile
+#ifdef MI_STATIC_MIX_INTERIOR_TILES   // tools/static_mix.py sbm: count the row loop of a tile away from the right image edge
+    const bool edge_tile = false;
+#else
     const bool edge_tile = A.emulate_edge && (X0 + ncols + R > A.cols - R);   // some X + R >= cols - R
+#endif
 
     unsigned vd = 0, vo = 0;   // MODE 1: per-lane (lane = tile column) winner disparity / SSD of the row
 

@@ -69,6 +69,7 @@ def mix_sbm(R=7, MODE=0):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+                        "-DMI_STATIC_MIX_INTERIOR_TILES",   # the edge-emulation variant of the row stage (right-most tiles only) is compiled out
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-x", "hip", "-S", "--cuda-device-only", src,
                         "-o", out], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
