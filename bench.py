@@ -734,7 +734,16 @@ def main():
         lanes_n = out_lanes = (2 if (P.lanes == 0 and B >= 4) or P.lanes == 2 else max(1, P.lanes))
         dims = [(max(int(round(W * 0.8 ** s)), 1), max(int(round(H * 0.8 ** s)), 1)) for s in range(5)]
         per_lane = max(1, B // lanes_n)
-        it_exec = sum(w_ * h_ * (tbr_band_rows(w_, h_, per_lane) + 20.0) / tbr_band_rows(w_, h_, per_lane) for w_, h_ in dims) \
+
+        def band_rows(w_, h_):   # the library's own plan (mi_tvl1_query_plan); tbr_band_rows mirrors it for builds without the entry
+            try:
+                import ctypes as C_
+                k_, r_ = C_.c_int(0), C_.c_int(0)
+                capi.check(capi.lib().mi_tvl1_query_plan(w_, h_, per_lane, 10, C_.byref(k_), C_.byref(r_)))
+                return float(r_.value)
+            except Exception:
+                return float(tbr_band_rows(w_, h_, per_lane))
+        it_exec = sum(w_ * h_ * (band_rows(w_, h_) + 20.0) / band_rows(w_, h_) for w_, h_ in dims) \
             * B * warps * mean_it * slots * lanes_per_px
         it_useful = px_levels * B * warps * mean_it * slots
         wp = px_levels * B * warps * WARP_VALU_PER_PX
@@ -744,7 +753,7 @@ def main():
             "peak": VALU_PEAK_TLIPS, "frac_executed": (it_exec + wp) / step_s / 1e12 / VALU_PEAK_TLIPS,
             "frac_useful": (it_useful + wp) / step_s / 1e12 / VALU_PEAK_TLIPS,
             "frac_executed_of_measured_plain_valu_peak": (it_exec + wp) / step_s / 1e12 / (VALU_PEAK_TLIPS * 2.0 / 3.1),
-            "band_rows_finest_level": tbr_band_rows(W, H, per_lane), "warp_valu_per_pixel": WARP_VALU_PER_PX,
+            "band_rows_finest_level": band_rows(W, H), "warp_valu_per_pixel": WARP_VALU_PER_PX,
             "note": "iteration kernel (static mix x pixel-iterations x halo factors) + warp kernel (static count x pixels) over the wall "
                     "time of a step; resize / convert / pack (4 % of the kernel time) not counted"}
 

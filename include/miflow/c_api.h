@@ -139,6 +139,11 @@ MI_API int mi_tvl1_last_iterations(mi_tvl1 *h, int pair, int *nscales_used, int 
  * returns, for the last calc: total ms inside those regions, the number of iteration launches inside
  * them, and their algorithmic bytes (64 B x level pixels x batch per launch). */
 MI_API int mi_tvl1_set_profiling(mi_tvl1 *h, int enable);
+/* Introspection of the launch plan (for roofline accounting; no reference counterpart): what a fast-math calc launches for a
+ * pyramid level of `width` x `height` with `pairs_per_lane` pairs and `iterations_per_launch` fused iterations -- *kernel 0: the
+ * streaming temporally blocked kernel, *rows_per_band = its band height (every band also streams 2 x iterations halo rows);
+ * *kernel 1: the register-tile kernel of the small levels, *rows_per_band = the rows a tile owns.  Needs a HIP device. */
+MI_API int mi_tvl1_query_plan(int width, int height, int pairs_per_lane, int iterations_per_launch, int *kernel, int *rows_per_band);
 MI_API int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, double *algo_bytes);
 /* The same for kind 0 (iteration launches, as above) or kind 1 (the warp launches; algorithmic bytes 44 B x level pixels x batch). */
 MI_API int mi_tvl1_get_profile_kind(mi_tvl1 *h, int kind, double *ms_total, long long *launches, double *algo_bytes);

@@ -116,6 +116,7 @@ def lib():
         "mi_tvl1_calc_batch": (i, [vp, i, PM, PM, PM, vp]),
         "mi_tvl1_last_iterations": (i, [vp, i, C.POINTER(i), C.POINTER(i), i, vp]),
         "mi_tvl1_set_profiling": (i, [vp, i]),
+        "mi_tvl1_query_plan": (i, [i, i, i, i, C.POINTER(i), C.POINTER(i)]),
         "mi_tvl1_get_profile": (i, [vp, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
         "mi_tvl1_get_profile_kind": (i, [vp, i, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
         "mi_tvl1_destroy": (None, [vp]),

@@ -168,6 +168,17 @@ static void free_arena(Lane &ln)
     ln.L.clear();
 }
 
+int mi_tvl1_query_plan(int width, int height, int pairs_per_lane, int iterations_per_launch, int *kernel, int *rows_per_band)
+{
+    MI_REQUIRE(kernel && rows_per_band, MI_ERR_BAD_ARG, "null output");
+    MI_REQUIRE(width > 0 && height > 0 && pairs_per_lane > 0 && iterations_per_launch > 0, MI_ERR_BAD_ARG, "bad plan query");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("no HIP device"); return MI_ERR_NO_DEVICE; }
+    Geo g;
+    g.w = width; g.h = height; g.ld = (width + 63) / 64 * 64; g.ps = (long long)g.ld * height; g.batch = pairs_per_lane;
+    return tb_query_plan(iterations_per_launch, g, kernel, rows_per_band);
+}
+
 int mi_tvl1_set_profiling(mi_tvl1 *h, int enable)
 {
     MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");

@@ -88,6 +88,8 @@ int tb_max_block();
 int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero, int cur,
                  hipStream_t s);
 int tile_max_block();
+int tile_owned_rows();   // rows a tile of the default variant owns
+int tb_query_plan(int T, const Geo &g, int *kernel, int *rows);   // kernel 0 = streaming (band height), 1 = register tile
 int tile_variants();
 bool tile_eligible(const Geo &g);   // this level (pixels x pairs) runs on the register-tile kernel
 // the same in exact math (bit-identical to T one-iteration launches of iterate(exact = true)); T in 1..tb_exact_max_block()

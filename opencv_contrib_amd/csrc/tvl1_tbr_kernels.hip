@@ -557,6 +557,22 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
     return div_up(g.h, best_nb);
 }
 
+// What iterate_tb(T, ...) would launch for level g (introspection for the bench's accounting): kernel 0 = streaming (rows = band
+// height), 1 = register tile (rows = owned rows of a tile).
+int tb_query_plan(int T, const Geo &g, int *kernel, int *rows)
+{
+    if (tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force) {
+        *kernel = 1;
+        *rows = tile_owned_rows();
+        return MI_OK;
+    }
+    const TbrEntry *e = tbr_pick(T);
+    if (!e) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
+    *kernel = 0;
+    *rows = plan_band_rows(*e, g);
+    return MI_OK;
+}
+
 // T fused iterations, set cur -> cur^1.  Returns MI_ERR_BAD_ARG for unsupported T.
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s)

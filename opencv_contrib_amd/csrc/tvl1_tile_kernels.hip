@@ -215,6 +215,12 @@ constexpr int kTileVariants = (int)(sizeof(g_tile) / sizeof(g_tile[0]));
 
 int tile_variants() { return kTileVariants; }
 int tile_max_block() { return TILE_M; }
+int tile_owned_rows()
+{
+    int v = tuning().tile_variant;
+    if (v < 0 || v >= kTileVariants) v = 0;
+    return g_tile[v].RW * g_tile[v].NW - 2 * TILE_M;
+}
 
 // Levels of at most this many pixels x pairs run on the register-tile kernel (0: never).  MIFLOW_TILE_MAXPX.
 bool tile_eligible(const Geo &g)

@@ -185,6 +185,21 @@ def test_iterate_tile_equals_streaming_kernel(gpu, variant, shape):
             np.testing.assert_array_equal(N(b), N(a), err_msg=f"{nm} variant={variant} niter={niter}")
 
 
+def test_query_plan_reports_the_kernel_a_level_runs_on(gpu):
+    """mi_tvl1_query_plan: the three coarse... small levels (pixels x pairs per lane <= 2.3 M) iterate on the register-tile kernel
+    (owned rows of a tile), larger ones on the streaming kernel (band height, a divisor-like cut of the image height)."""
+    import ctypes as C
+    from opencv_contrib_amd import capi
+    k, r = C.c_int(-1), C.c_int(-1)
+    capi.check(capi.lib().mi_tvl1_query_plan(1920, 1080, 16, 10, C.byref(k), C.byref(r)))
+    assert k.value == 0 and 8 <= r.value <= 1080
+    capi.check(capi.lib().mi_tvl1_query_plan(1920, 1080, 1, 10, C.byref(k), C.byref(r)))
+    assert k.value == 1 and r.value == 44
+    capi.check(capi.lib().mi_tvl1_query_plan(320, 240, 128, 10, C.byref(k), C.byref(r)))
+    assert k.value == 0
+    assert capi.lib().mi_tvl1_query_plan(0, 240, 1, 10, C.byref(k), C.byref(r)) != 0
+
+
 @pytest.mark.parametrize("tb", [0, 5])
 def test_calc_fast_blocked_matches_oracle(gpu, oracle, tb):
     """Product fast path (fast math + temporal blocking) against the CPU oracle, stated tolerance."""
