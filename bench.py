@@ -899,15 +899,16 @@ def main():
                 del a1, one, q0, q1
             except Exception as e:
                 var[tag] = {"error": repr(e)[:200]}
-        # north_star "1080p/4K pairs": the same object on 3840x2160 pairs (4 pairs per step = the pixels of 16 1080p pairs)
+        # north_star "1080p/4K pairs": the same object on 3840x2160 pairs (B / 4 pairs per step = the pixels of the 1080p batch)
         try:
             # same motion in pixels as the 1080p pairs (flow_scale 3, texture sigma 6): five 0.8-scales cover it at either size
-            K0, K1, base4k = make_inputs(4, 2160, 3840, dev, distinct=1, flow_scale=3.0, sigma=6.0)
-            F4 = torch.empty((4, 2160, 3840, 2), dtype=torch.float32, device=dev)
+            n4 = max(4, B // 4)   # the pixels of B 1080p pairs
+            K0, K1, base4k = make_inputs(n4, 2160, 3840, dev, distinct=1, flow_scale=3.0, sigma=6.0)
+            F4 = torch.empty((n4, 2160, 3840, 2), dtype=torch.float32, device=dev)
             e4, _, _, _ = run(args.iterations, args.epsilon, hs, 1, inputs=(K0, K1), out=F4)
             ab4 = algo_bytes_per_pair(3840, 2160, warps, args.iterations)
-            var["tvl1_4k_3840x2160"] = {"pairs_per_s": 4 * hs / e4, "batch": 4, "algorithmic_GB_per_pair": ab4 / 1e9,
-                                        "megapixels_per_s": 4 * hs / e4 * 3840 * 2160 / 1e6,
+            var["tvl1_4k_3840x2160"] = {"pairs_per_s": n4 * hs / e4, "batch": n4, "algorithmic_GB_per_pair": ab4 / 1e9,
+                                        "megapixels_per_s": n4 * hs / e4 * 3840 * 2160 / 1e6,
                                         "epe_vs_analytic_flow_px": float(synth.epe(F4[0].cpu().numpy()[80:-80, 80:-80], base4k[0][2][80:-80, 80:-80]))}
             del K0, K1, F4
         except Exception as e:
