@@ -228,23 +228,23 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
         }
         v0 = win4 ? s0 : b0; v1 = win4 ? s1 : b1; v2 = win4 ? s2 : b2;
     } else {
-        // Border windows of cv::cuda's semantics (clamp-addressed taps).  The reference visits cx = ceil(wx - 2) .. floor(wx + 2),
-        // four taps, or five when wx is an integer (the outer two then weigh exactly 0); the fixed five-tap window
-        // floor(wx) - 2 .. floor(wx) + 2 adds the same values in the same order plus terms +-0 * (finite clamped data), i.e. the same
-        // bits.  The five taps of a row are unrolled -- their 25 loads are independent, one memory round trip per row; the
+        // Border windows of cv::cuda's semantics (clamp-addressed taps).  The reference visits cx = ceil(wx - 2) .. floor(wx + 2):
+        // the four taps floor(wx) - 1 .. floor(wx) + 2 plus, when wx is an integer, one more on each side whose weight is exactly 0
+        // -- terms +-0 * (finite clamped data), which change no sum: the fixed 4 x 4 window of the interior path gives the same
+        // bits.  The four taps of a row are unrolled -- their 20 loads are independent, one memory round trip per row; the
         // earlier tap-by-tap loop waited for every tap's loads in turn (~30 us at the end of every launch).
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, (unsigned)H * (unsigned)ld * 4u, 0x00020000);
         float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
 #pragma unroll 1
-        for (int j = 0; j < 5; ++j) {
-            const int cy = sy - 1 + j;
-            const float wyj = bicubic_coeff_cuda6(wyp - (float)cy);
-            float t0[5], t1[5], t2[5];
+        for (int j = 0; j < 4; ++j) {
+            const int cy = sy + j;
+            const float wyj = j == 0 ? wyv[0] : j == 1 ? wyv[1] : j == 2 ? wyv[2] : wyv[3];
+            float t0[4], t1[4], t2[4];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) fetch3b(rs, W, H, ld, min(max(sx - 1 + i, 0), W - 1), min(max(cy, 0), H - 1), t0[i], t1[i], t2[i]);
+            for (int i = 0; i < 4; ++i) fetch3b(rs, W, H, ld, min(max(sx + i, 0), W - 1), min(max(cy, 0), H - 1), t0[i], t1[i], t2[i]);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const float wgt = bicubic_coeff_cuda6(wxp - (float)(sx - 1 + i)) * wyj;
+            for (int i = 0; i < 4; ++i) {
+                const float wgt = wxv[i] * wyj;
                 sum += wgt * t0[i];
                 sumx += wgt * t1[i];
                 sumy += wgt * t2[i];
