@@ -122,18 +122,16 @@ __device__ __forceinline__ void fetch3b(__amdgpu_buffer_rsrc_t rs, int W, int H,
     vy = 0.5f * (L((unsigned)min(cy + 1, H - 1) * (unsigned)ld + cx) - L((unsigned)max(cy - 1, 0) * (unsigned)ld + cx));
 }
 
-// One output pixel (x, y) of pair plane P: u1v, u2v = the flow at the pixel, i0 = I0 there; writes the five planes at o.
-template <int SEM, bool FAST>
-__device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, const float *P, int x, int y, long long o, float u1v,
-                                        float u2v, float i0)
+// Window origin (first tap column / row of the 4 x 4 window) and the eight tap weights of output pixel (x, y) with flow (u1v, u2v).
+// CPU_REF: buildFlowMap + cv::remap(INTER_CUBIC): optflow/src/tvl1flow.cpp:650-666,1371-1374 -- the map quantised to 1/32 px, the
+// weights from the 32-phase table (a = -0.75).  CUDA_COMPAT: tvl1flow.cu:106-149 -- the reference visits cx = ceil(wx - 2) ..
+// floor(wx + 2): the four taps floor(wx) - 1 .. floor(wx) + 2 plus, when a bound lands on an integer, taps at distance >= 2 whose
+// weight is exactly 0 and which therefore add +-0 to every sum -- the fixed 4-tap window gives the same bits.
+template <int SEM>
+__device__ __forceinline__ void warp_coords(const float *s_tab, int x, int y, float u1v, float u2v, int &sx, int &sy, float (&wxv)[4],
+                                            float (&wyv)[4])
 {
-    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
-    int sx, sy;          // first tap column / row of the 4 x 4 window
-    float wxv[4], wyv[4];
-    float wxp = 0.f, wyp = 0.f;
     if (SEM == MI_SEM_CPU_REF) {
-        // buildFlowMap + cv::remap(INTER_CUBIC, BORDER_CONSTANT 0): optflow/src/tvl1flow.cpp:650-666,1371-1374;
-        // map quantised to 1/32 px, weights from the 32-phase table (a = -0.75)
         const float mx = (float)x + u1v, my = (float)y + u2v;
         const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
         sx = min(max(qx >> 5, -32768), 32767) - 1;
@@ -141,10 +139,7 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { wxv[k] = s_tab[(qx & 31) * 4 + k]; wyv[k] = s_tab[(qy & 31) * 4 + k]; }
     } else {
-        // tvl1flow.cu:106-149.  The reference visits cx = ceil(wx - 2) .. floor(wx + 2): the four taps
-        // floor(wx) - 1 .. floor(wx) + 2 plus, when a bound lands on an integer, taps at distance >= 2 whose weight
-        // is exactly 0 and which therefore add +0 to every sum -- the fixed 4-tap window gives the same bits.
-        wxp = (float)x + u1v; wyp = (float)y + u2v;
+        const float wxp = (float)x + u1v, wyp = (float)y + u2v;
         sx = (int)fminf(fmaxf(floorf(wxp), -1.0e9f), 1.0e9f) - 1;
         sy = (int)fminf(fmaxf(floorf(wyp), -1.0e9f), 1.0e9f) - 1;
 #pragma unroll
@@ -153,6 +148,17 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
             wyv[k] = bicubic_coeff_cuda6(wyp - (float)(sy + k));
         }
     }
+}
+
+// One output pixel (x, y) of pair plane P: u1v, u2v = the flow at the pixel, i0 = I0 there; writes the five planes at o.
+template <int SEM, bool FAST>
+__device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, const float *P, int x, int y, long long o, float u1v,
+                                        float u2v, float i0)
+{
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    int sx, sy;          // first tap column / row of the 4 x 4 window
+    float wxv[4], wyv[4];
+    warp_coords<SEM>(s_tab, x, y, u1v, u2v, sx, sy, wxv, wyv);
 
     float v0, v1, v2;
     const bool interior = (unsigned)(sx - 1) < (unsigned)max(W - 5, 0) && (unsigned)(sy - 1) < (unsigned)max(H - 5, 0);
@@ -311,29 +317,6 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
 // Tap values, weights and the accumulation order are those of warp_px: bit-identical planes.
 constexpr int WL_TW = 64, WL_TH = 16, WL_PPT = 4;   // tile; rows per thread (wave w owns rows 4w .. 4w+3, lane = column)
 constexpr int WL_RW = 96, WL_RH = 40;               // staged region capacity, floats x rows (15 KB)
-
-template <int SEM>
-__device__ __forceinline__ void warp_coords(const float *s_tab, int x, int y, float u1v, float u2v, int &sx, int &sy, float (&wxv)[4],
-                                            float (&wyv)[4])
-{
-    if (SEM == MI_SEM_CPU_REF) {
-        const float mx = (float)x + u1v, my = (float)y + u2v;
-        const int qx = __float2int_rn(mx * 32.0f), qy = __float2int_rn(my * 32.0f);
-        sx = min(max(qx >> 5, -32768), 32767) - 1;
-        sy = min(max(qy >> 5, -32768), 32767) - 1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { wxv[k] = s_tab[(qx & 31) * 4 + k]; wyv[k] = s_tab[(qy & 31) * 4 + k]; }
-    } else {
-        const float wxp = (float)x + u1v, wyp = (float)y + u2v;
-        sx = (int)fminf(fmaxf(floorf(wxp), -1.0e9f), 1.0e9f) - 1;
-        sy = (int)fminf(fmaxf(floorf(wyp), -1.0e9f), 1.0e9f) - 1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wxv[k] = bicubic_coeff_cuda6(wxp - (float)(sx + k));
-            wyv[k] = bicubic_coeff_cuda6(wyp - (float)(sy + k));
-        }
-    }
-}
 
 template <int SEM, bool FAST>
 __global__ __launch_bounds__(256) void k_warp_lds(Warp6Args A, CtlK ctl, int cur_host)
