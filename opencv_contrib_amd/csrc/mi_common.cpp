@@ -37,7 +37,6 @@ const Tuning &tuning()
         }
         t.tile_variant = env_int("MIFLOW_TILE_VARIANT", 0);
         t.tile_spec = env_int("MIFLOW_TILE_SPEC", 1);
-        t.graphs = env_int("MIFLOW_GRAPHS", 1);
         t.lanes = env_int("MIFLOW_LANES", 0);
         t.spec = env_int("MIFLOW_SPEC", 1);
         t.exact_tb = env_int("MIFLOW_EXACT_TB", 1);

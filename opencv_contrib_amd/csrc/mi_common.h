@@ -43,7 +43,6 @@ struct Tuning {
     int tb_rows;             // MIFLOW_TB_ROWS: band height (0: planner)
     int tb_verbose;          // MIFLOW_TB_VERBOSE
     long long tile_maxpx;    // MIFLOW_TILE_MAXPX: levels of at most this many pixels x pairs iterate on the register-tile kernel (0: never)
-    int graphs;              // MIFLOW_GRAPHS: launch-bound TV-L1 calcs (finest level <= tile_maxpx pixels x pairs per lane) replay a captured HIP graph of their launch sequence (1) or enqueue every launch (0)
     int tile_spec;           // MIFLOW_TILE_SPEC: speculative steps of the convergence-checked path on the register-tile kernel where it is eligible (1) or always on the streaming kernel (0)
     int tile_variant;        // MIFLOW_TILE_VARIANT: index into the (rows per wave, waves) table of tvl1_tile_kernels.hip
     int lanes;               // MIFLOW_LANES: internal streams a TV-L1 batch is split over (0: automatic)

@@ -2,7 +2,6 @@
 // Host-side twin of OpticalFlowDual_TVL1_Impl::calcImpl / procOneScale
 // (modules/cudaoptflow/src/tvl1flow.cpp:185-382; CPU modules/optflow/src/tvl1flow.cpp:402-533,
 // 1313-1408) -- but fully stream-ordered: no host read-back inside the iteration loop.
-#include <cstring>
 #include "tvl1_dev.h"
 #include "mi_selftest.h"
 #include <cfloat>
@@ -59,23 +58,6 @@ struct Lane {
     // internal stream of a concurrent lane + its completion event
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    // HIP graph of the launch sequence of a launch-bound calc (lane_calc): the signature last seen, and the executable graph of
-    // the signature `gkey`
-    struct GraphKey {
-        int W = 0, H = 0, B = 0, type = 0;
-        mi_tvl1_params P = {};
-        const void *arena = nullptr, *tab = nullptr, *S = nullptr;
-        long long Q = 0;
-        bool operator==(const GraphKey &o) const
-        {
-            return W == o.W && H == o.H && B == o.B && type == o.type && memcmp(&P, &o.P, sizeof(P)) == 0 && arena == o.arena && tab == o.tab &&
-                   S == o.S && Q == o.Q;
-        }
-    };
-    GraphKey gseen, gkey;
-    bool gseen_valid = false, gdisabled = false;
-    hipGraphExec_t gexec = nullptr;
-    hipStream_t cap_stream = nullptr;   // the launch sequence is captured on this stream (the caller's may be the legacy stream)
 };
 
 struct mi_tvl1 {
@@ -240,8 +222,6 @@ void mi_tvl1_destroy(mi_tvl1 *h)
         if (ln.X) (void)hipFree(ln.X);
         if (ln.done) (void)hipEventDestroy(ln.done);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
-        if (ln.gexec) (void)hipGraphExecDestroy(ln.gexec);
-        if (ln.cap_stream) (void)hipStreamDestroy(ln.cap_stream);
     }
     if (h->fork) (void)hipEventDestroy(h->fork);
     if (h->cubic_tab) (void)hipFree(h->cubic_tab);
@@ -412,59 +392,6 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             MI_HIP_TRY(hipMalloc((void **)&ln.X, sizeof(int4) * (size_t)Q * B));
             ln.Q = Q; ln.ctlB = B;
         }
-    }
-    // ---- HIP graph of everything enqueued below.  A calc of a small frame or a single pair is bound by its LAUNCHES -- 75 for a
-    // 640 x 480 pair at fixed work, ~900 with the class defaults, whose convergence path must enqueue every launch the device might
-    // need (~3.5 us of host time each, against ~1.5 us the GPU needs for one that finds its warp converged).  The sequence depends
-    // only on the signature below (sizes, parameters, the lane's buffers: the caller's image pointers travel through the device
-    // table uploaded above), so the second calc with a signature captures it and later ones replay it with one call.
-    struct Capture {
-        Lane &ln; hipStream_t launch_on; bool active = false; Lane::GraphKey key;
-        Capture(Lane &l, hipStream_t s) : ln(l), launch_on(s) {}
-        ~Capture()   // an error return while capturing: end the capture, nothing was executed, no graph is kept
-        {
-            if (!active) return;
-            hipGraph_t g = nullptr;
-            (void)hipStreamEndCapture(ln.cap_stream, &g);
-            if (g) (void)hipGraphDestroy(g);
-            ln.gdisabled = true;
-        }
-        int finish()
-        {
-            if (!active) return MI_OK;
-            active = false;
-            hipGraph_t g = nullptr;
-            MI_HIP_TRY(hipStreamEndCapture(ln.cap_stream, &g));
-            hipGraphExec_t ex = nullptr;
-            const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            MI_HIP_TRY(e);
-            if (ln.gexec) (void)hipGraphExecDestroy(ln.gexec);
-            ln.gexec = ex; ln.gkey = key;
-            MI_HIP_TRY(hipGraphLaunch(ln.gexec, launch_on));
-            return MI_OK;
-        }
-    } cap(ln, st);
-    {
-        Lane::GraphKey key;
-        key.W = W; key.H = H; key.B = B; key.type = I0s[0].type; key.P = P; key.arena = ln.arena; key.tab = ln.tab_dev; key.S = ln.S; key.Q = ln.Q;
-        const bool want = tuning().graphs != 0 && !ln.gdisabled && !h->profiling && (long long)W * H * B <= tuning().tile_maxpx;
-        if (want && ln.gexec && ln.gkey == key) {
-            MI_HIP_TRY(hipGraphLaunch(ln.gexec, st));
-            return MI_OK;   // ln.slots as recorded by the capturing call: the same signature enqueues the same launches
-        }
-        if (want && ln.gseen_valid && ln.gseen == key) {
-            if (!ln.cap_stream && hipStreamCreateWithFlags(&ln.cap_stream, hipStreamNonBlocking) != hipSuccess) ln.cap_stream = nullptr;
-            if (ln.cap_stream && hipStreamBeginCapture(ln.cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                cap.active = true; cap.key = key;
-                st = ln.cap_stream;   // everything below is recorded, not executed, until cap.finish()
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-        ln.gseen = key; ln.gseen_valid = true;
-    }
-    if (check) {
         MI_HIP_TRY(hipMemsetAsync(ln.E, 0, sizeof(unsigned long long) * (size_t)ln.Q * B, st));
         MI_HIP_TRY(hipMemsetAsync(ln.S, 0, sizeof(int2) * (size_t)ln.Q * B, st));
     }
@@ -700,7 +627,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     dev_cur ? &ec : nullptr, cur, st);
         if (rc) return rc;
     }
-    return cap.finish();
+    return MI_OK;
 }
 
 int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream_)

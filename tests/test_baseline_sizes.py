@@ -223,35 +223,6 @@ def test_flows_do_not_depend_on_which_iteration_kernel_a_level_runs_on(gpu, eps,
         assert single.lastIterations(0) == big.lastIterations(k)
 
 
-@pytest.mark.parametrize("eps,iters", [(0.0, 10), (0.01, 300)])
-@pytest.mark.parametrize("npairs", [1, 5])
-def test_graph_replay_of_a_launch_bound_calc_equals_the_eager_calc(gpu, eps, iters, npairs):
-    """Small calcs replay a captured HIP graph of their launch sequence from the third call with one signature on (the first runs
-    eagerly, the second captures): every call gives the flows and iteration counts of a fresh object's first (eager) call, also
-    with other inputs (the image pointers travel through the device table, not through the graph), on both lanes, and again after
-    a parameter change (new signature)."""
-    import torch
-    from opencv_contrib_amd import cuda
-    sets = [[synth.flow_pair(120, 168, seed=300 + 10 * j + k)[:2] for k in range(npairs)] for j in range(2)]
-    alg = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps)
-    for rep in range(5):
-        pairs = sets[rep % 2]
-        I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
-        got = alg.calc_batch(I0s, I1s).clone()
-        its = [alg.lastIterations(k) for k in range(npairs)]
-        fresh = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps)
-        ref = fresh.calc_batch(I0s, I1s)
-        torch.cuda.synchronize()
-        assert torch.equal(got, ref), f"call {rep}"
-        assert its == [fresh.lastIterations(k) for k in range(npairs)]
-    alg.setTau(0.2)
-    pairs = sets[0]
-    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
-    fresh = cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps, tau=0.2)
-    for rep in range(3):
-        assert torch.equal(alg.calc_batch(I0s, I1s), fresh.calc_batch(I0s, I1s)), f"after setTau, call {rep}"
-
-
 def test_stop_slack_runs_at_most_a_few_more_iterations(gpu, oracle):
     """mi_tvl1_params.stop_slack = 1 (miflow extension, off by default): a speculative block is kept when the reference's test
     first passed one iteration before its end.  Counts stay within the slack (+ the knock-on of a slightly different start of
