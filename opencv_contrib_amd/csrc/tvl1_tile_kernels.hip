@@ -2,9 +2,9 @@
 //
 // The streaming pipeline of tvl1_tbr_kernels.hip walks a row band from top to bottom with its T iteration levels as
 // pipeline stages: one dependent chain of T stages per row step, (rows + 2T) steps per band.  On a large level that chain
-// is hidden by the other waves of the SIMD; on the coarse levels of the pyramid (a few hundred waves in all) nothing hides
-// it and a launch costs its serial depth: 130-170 us for 0.1-2 % of the pixels (profiles/r02w: the three coarsest of the
-// five levels took 28 % of the iteration time of a 1080p calc).
+// is hidden by the other waves of the SIMD; on a level of a few hundred waves (small frames, the levels of a single pair)
+// nothing hides it and a launch costs its serial depth -- 130 us and more whatever the pixel count (r02z4: 320 x 240 x 16
+// pairs 7 850 pairs/s; a single 1080p pair per calc() 486 calcs/s).
 //
 // Here a workgroup of NW waves holds a whole tile of (NW * RW) rows x 64 columns in registers -- every lane a column, every
 // wave RW consecutive rows, {u1, u2, p11, p12, p21, p22} and the four static planes of each row -- and runs the iterations
