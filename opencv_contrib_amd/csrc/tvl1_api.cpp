@@ -305,6 +305,9 @@ static int check_pair(const mi_mat *I0, const mi_mat *I1, const mi_mat *flow, co
     MI_REQUIRE(flow->type == MI_32FC2, MI_ERR_BAD_TYPE, "flow must be CV_32FC2");
     MI_REQUIRE(flow->rows == I0->rows && flow->cols == I0->cols, MI_ERR_BAD_SIZE, "flow.size() != I0.size()");  // :190
     MI_REQUIRE(I0->rows >= 3 && I0->cols >= 3, MI_ERR_BAD_SIZE, "image must be at least 3x3");
+    // the dense float planes are addressed with 32-bit byte offsets from a per-pair base (buffer loads of the warp's border windows)
+    MI_REQUIRE((long long)((I0->cols + 63) / 64 * 64) * I0->rows * 4 < (1LL << 32), MI_ERR_BAD_SIZE,
+               "image too large: a float plane of it must stay below 4 GiB");
     const size_t es = I0->type == MI_8UC1 ? 1 : 4;
     MI_REQUIRE(I0->step >= (size_t)I0->cols * es && I1->step >= (size_t)I1->cols * es, MI_ERR_BAD_ARG, "step < cols*elemSize");
     MI_REQUIRE(flow->step >= (size_t)flow->cols * 8, MI_ERR_BAD_ARG, "flow step < cols*8");
