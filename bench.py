@@ -710,16 +710,20 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": hbm_it["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (hbm_it["algorithmic_GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it, "hbm": hbm_it}
-    # second kernel: the fused-gradient warp.  Bound: bytes through the vector-memory path (128 B gathered per pixel as 4-byte-aligned
-    # dwordx4 / dwordx2 + 12 B coalesced in + 16 B out), 64 B/clk per CU
+    # second kernel: the fused-gradient warp.  Bound: HBM -- alone it moves its 44 B/px at 0.5-0.6 of the peak (r02z3, one lane; the
+    # LDS-staged variant that takes the 128 B/px of gathered windows off the vector-memory path is only 11 % faster, so that path
+    # is not what limits it); with the other lane's iteration kernel on the chip, as in the intervals timed here, about half that.
+    # The vector-memory-path view (128 B gathered per pixel as 4-byte-aligned dwordx4 / dwordx2 + 12 B in + 16 B out against
+    # 64 B/clk per CU) is kept next to it.
     warp_bytes_px = 128.0 + 12.0 + 16.0
-    roof_warp = {"bound": "vector_memory_path", "kernel": "k_warp6 (bicubic warp, centred gradient of I1 formed from a 6x6 window)",
-                 "achieved": px_levels * B * warps * warp_bytes_px / (ms_w * 1e-3) / 1e9 if ms_w > 0 else None,
-                 "peak": VMEM_PATH_PEAK_GBS, "unit": "GB/s", "avg_launch_us": 1e3 * ms_w / max(n_w, 1), "launches_timed": n_w,
-                 "hbm_algorithmic_GBps": bytes_w / (ms_w * 1e-3) / 1e9 if ms_w > 0 else None}
-    if roof_warp["achieved"]:
-        roof_warp["frac"] = roof_warp["achieved"] / VMEM_PATH_PEAK_GBS
-        roof_warp["hbm_algorithmic_frac"] = roof_warp["hbm_algorithmic_GBps"] / HBM_PEAK_GBS
+    hbm_w = bytes_w / (ms_w * 1e-3) / 1e9 if ms_w > 0 else None
+    roof_warp = {"bound": "hbm", "kernel": "k_warp6 (bicubic warp, centred gradient of I1 formed from a 6x6 window)",
+                 "achieved": hbm_w, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_w / HBM_PEAK_GBS if hbm_w else None,
+                 "avg_launch_us": 1e3 * ms_w / max(n_w, 1), "launches_timed": n_w,
+                 "hbm_algorithmic_GBps": hbm_w, "hbm_algorithmic_frac": hbm_w / HBM_PEAK_GBS if hbm_w else None,
+                 "vector_memory_path_GBps": px_levels * B * warps * warp_bytes_px / (ms_w * 1e-3) / 1e9 if ms_w > 0 else None,
+                 "vector_memory_path_peak_GBps": VMEM_PATH_PEAK_GBS,
+                 "alone_one_lane": "0.5-0.6 of the HBM peak (profiles/r02z/README.md, r02z3: 173 us average launch of 16 pairs)"}
     wtraffic, wsrc = pmc_traffic("warp6", per_lane_pairs)
     if wtraffic:
         roof_warp.update({"traffic": wtraffic, "traffic_source": wsrc})
@@ -830,7 +834,10 @@ def main():
         try:
             e1, (p_it, p_w), _, _ = run(args.iterations, args.epsilon, hs, 1, profile=True, lanes=1)
             var["iterations10_eps0_one_lane"] = {"pairs_per_s": B * hs / e1, "iterate_avg_launch_us": 1e3 * p_it[0] / max(p_it[1], 1),
-                                                 "warp_avg_launch_us": 1e3 * p_w[0] / max(p_w[1], 1)}
+                                                 "warp_avg_launch_us": 1e3 * p_w[0] / max(p_w[1], 1),
+                                                 # the warp kernel with the GPU to itself: algorithmic 44 B/px over its own launch time
+                                                 "warp_hbm_algorithmic_GBps": p_w[2] / (p_w[0] * 1e-3) / 1e9 if p_w[0] > 0 else None,
+                                                 "warp_hbm_algorithmic_frac": p_w[2] / (p_w[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if p_w[0] > 0 else None}
             if blocked and args.epsilon == 0 and p_it[0] > 0:
                 ach1 = px_iter_timed / (p_it[0] * 1e-3) * slots * lanes_per_px / 1e12
                 var["iterations10_eps0_one_lane"]["iterate_valu_issue_frac"] = ach1 / VALU_PEAK_TLIPS
