@@ -55,6 +55,9 @@ def test_no_cpu_fallback_without_device():
         with pytest.raises(capi.MiError) as ei:
             make()
         assert "no CPU fallback" in str(ei.value) or ei.value.args[0] == -7
+    # ... and so does the plan introspection (the plan depends on the device's SIMD count)
+    k, r = C.c_int(-1), C.c_int(-1)
+    assert L.mi_tvl1_query_plan(1920, 1080, 16, 10, C.byref(k), C.byref(r)) == -7 and (k.value, r.value) == (-1, -1)
 
 
 
