@@ -103,6 +103,11 @@ inline void miCheck(int rc)
 inline int getCudaEnabledDeviceCount() { return mi_device_count(); }
 inline void setDevice(int d) { miCheck(mi_set_device(d)); }
 inline int getDevice() { int d = 0; miCheck(mi_get_device(&d)); return d; }
+namespace miflow {
+/** miflow extension: return the scratch blocks that destroyed handles left in the library's cache to the driver (the counterpart of
+ * BufferPool's release; call it when another allocator of the process runs out of device memory). */
+inline void releaseCachedMemory() { miCheck(mi_release_cached_memory()); }
+}  // namespace miflow
 
 class Stream {
 public:

@@ -49,6 +49,7 @@ public:
         mi_stereobm_default_params(&p_);
         p_.num_disparities = numDisparities; p_.block_size = blockSize;
         miCheck(mi_stereobm_create(&p_, &h_));
+        ok_ = p_;
     }
     ~StereoBMImpl() override { mi_stereobm_destroy(h_); }
     StereoBMImpl(const StereoBMImpl &) = delete;
@@ -91,7 +92,7 @@ public:
 private:
     void push() { const int rc = mi_stereobm_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_stereobm_params p_;
-    mi_stereobm_params ok_ = p_;   // last parameters the library accepted
+    mi_stereobm_params ok_{};   // last parameters the library accepted (set at the end of the constructor)
     mi_stereobm *h_ = nullptr;
 };
 }  // namespace miflow_detail
@@ -136,6 +137,7 @@ public:
         p_.min_disparity = minDisparity; p_.num_disparities = numDisparities; p_.P1 = P1; p_.P2 = P2;
         p_.uniqueness_ratio = uniquenessRatio; p_.mode = mode;
         miCheck(mi_stereosgm_create(&p_, &h_));
+        ok_ = p_;
     }
     ~StereoSGMImpl() override { mi_stereosgm_destroy(h_); }
     StereoSGMImpl(const StereoSGMImpl &) = delete;
@@ -161,7 +163,7 @@ public:
 private:
     void push() { const int rc = mi_stereosgm_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_stereosgm_params p_;
-    mi_stereosgm_params ok_ = p_;   // last parameters the library accepted
+    mi_stereosgm_params ok_{};   // last parameters the library accepted (set at the end of the constructor)
     mi_stereosgm *h_ = nullptr;
 };
 }  // namespace miflow_detail
@@ -194,6 +196,7 @@ public:
         mi_disp_bilateral_default_params(&p_);
         p_.ndisp = ndisp; p_.radius = radius; p_.iters = iters;
         miCheck(mi_disp_bilateral_create(&p_, &h_));
+        ok_ = p_;
     }
     ~DispBilateralFilterImpl() override { mi_disp_bilateral_destroy(h_); }
     DispBilateralFilterImpl(const DispBilateralFilterImpl &) = delete;
@@ -213,7 +216,7 @@ public:
 private:
     void push() { const int rc = mi_disp_bilateral_set_params(h_, &p_); if (rc) p_ = ok_; miCheck(rc); ok_ = p_; }   // a rejected value is rolled back
     mi_disp_bilateral_params p_;
-    mi_disp_bilateral_params ok_ = p_;   // last parameters the library accepted
+    mi_disp_bilateral_params ok_{};   // last parameters the library accepted (set at the end of the constructor)
     mi_disp_bilateral *h_ = nullptr;
 };
 }  // namespace miflow_detail

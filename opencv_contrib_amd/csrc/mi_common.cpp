@@ -51,7 +51,17 @@ namespace {
 struct BigBlock { void *p; size_t cap; int dev; };
 std::mutex g_big_mu;
 std::vector<BigBlock> g_big;
-const size_t kBigMaxBlocks = 4, kBigMaxBytes = 24ull << 30;
+const size_t kBigMaxBlocks = 4;   // PER DEVICE (two lanes of two handles): eight GPUs of a node each keep their own
+// upper bound of what the cache may hold; MIFLOW_CACHE_GB (0 = cache nothing) for hosts whose own allocator wants the memory back
+size_t big_max_bytes()
+{
+    static const size_t v = [] {
+        const char *e = getenv("MIFLOW_CACHE_GB");
+        const long long gb = e && *e ? atoll(e) : 24;
+        return (size_t)(gb < 0 ? 0 : gb) << 30;
+    }();
+    return v;
+}
 }  // namespace
 
 int big_alloc(void **p, size_t bytes, size_t *capacity)
@@ -88,11 +98,19 @@ void big_free(void *p, size_t capacity)
     void *drop = nullptr;
     if (hipGetDevice(&dev) == hipSuccess) {
         hipPointerAttribute_t at;
+        const int cur = dev;
         if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;
+        // a cached block may be handed to another handle / stream at once: nothing enqueued by its previous owner may still use it.
+        // hipFree synchronised the device implicitly; the cache keeps that guarantee explicitly (free_arena runs on destroy and on
+        // a change of the image size only, never in a steady-state calc).
+        if (dev != cur) (void)hipSetDevice(dev);
+        const bool idle = hipDeviceSynchronize() == hipSuccess;
+        if (dev != cur) (void)hipSetDevice(cur);
         std::lock_guard<std::mutex> lk(g_big_mu);
-        size_t total = capacity;
-        for (const BigBlock &b : g_big) total += b.cap;
-        if (g_big.size() < kBigMaxBlocks && total <= kBigMaxBytes) {
+        size_t total = capacity, blocks = 0;
+        for (const BigBlock &b : g_big)
+            if (b.dev == dev) { total += b.cap; ++blocks; }
+        if (idle && blocks < kBigMaxBlocks && total <= big_max_bytes()) {
             g_big.push_back({p, capacity, dev});
             return;
         }
@@ -110,7 +128,10 @@ void big_trim()
         std::lock_guard<std::mutex> lk(g_big_mu);
         all.swap(g_big);
     }
-    for (const BigBlock &b : all) (void)hipFree(b.p);
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (const BigBlock &b : all) (void)hipFree(b.p);   // hipFree takes pointers of any device
+    if (have) (void)hipSetDevice(cur);
 }
 
 int device_simds()

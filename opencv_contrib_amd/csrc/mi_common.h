@@ -72,7 +72,8 @@ struct DevTmp {
     }
 };
 // Large device blocks (the per-lane TV-L1 arenas) come from a small process-wide cache: a block released by a handle is kept
-// (at most 4 blocks / 24 GB per process) and handed to the next request of a similar size on the same device.  Measured on
+// (at most 4 blocks / MIFLOW_CACHE_GB = 24 GB PER DEVICE, after a device synchronisation: nothing of its previous owner is still
+// in flight when the next taker gets it) and handed to the next request of a similar size on the same device.  Measured on
 // MI355X / ROCm 7.2 (r02q): an arena obtained by hipMalloc right after a hipFree of the same size runs the same kernels 25 %
 // slower than the freed one did (390 vs 520 pairs/s, class defaults), i.e. create / destroy cycles of handles must not go
 // through the driver.  mi_release_cached_memory() returns everything to the driver.

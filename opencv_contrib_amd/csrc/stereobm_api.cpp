@@ -161,7 +161,9 @@ int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right,
 // n stereo pairs of one size through one handle: prefilters and the textureness post-filter run pair by pair (small, bandwidth-bound
 // kernels sharing the handle's scratch), the block matching -- where the time goes -- as ONE launch with blockIdx.z = pair.  A single
 // 1080p pair needs ~16-row bands to put enough waves on the device, and every band spends 2R rows building its first window
-// (47 % of the rows at block size 15); the batch supplies the waves, so its bands are up to 96 rows tall (13 %).
+// (47 % of the rows at block size 15); the batch supplies the waves, so its bands are up to 48 rows tall (23 %;
+// block_match_impl caps the band height at 48 rows for single pairs and batches alike -- 96-row bands lost occupancy to the
+// staged rows in LDS: 32 | 48 | 96 rows = 4 990 | 5 070 | 4 575 pairs/s, which also retuned the single-pair path).
 int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const mi_mat *rights, mi_mat *disps, void *stream)
 {
     MI_REQUIRE(h, MI_ERR_BAD_ARG, "null handle");

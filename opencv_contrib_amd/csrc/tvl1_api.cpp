@@ -659,25 +659,37 @@ int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, 
         // Lane 0 runs on the caller's own stream, every further lane on ONE internal stream each: a handle adds lanes - 1 streams
         // to the process.  (HIP multiplexes streams onto a few hardware queues -- 4 by default, GPU_MAX_HW_QUEUES; two lanes that
         // land on one queue run back to back: measured 400 instead of 520 pairs/s when enough streams of other handles were alive.)
+        // every stream and event the fork / join needs exists BEFORE anything is enqueued, so no failure between the fork and the
+        // join can leave an internal lane un-joined
         if (!h->fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
+        for (int li = 1; li < lanes; ++li) {
+            Lane &ln = h->lane[li];
+            if (!ln.stream) MI_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            if (!ln.done) MI_HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        }
         MI_HIP_TRY(hipEventRecord(h->fork, st));
         int rc_first = MI_OK;
+        auto note = [&](hipError_t e) {
+            if (e != hipSuccess && !rc_first) { set_error("HIP error in the lane fork / join: %s", hipGetErrorString(e)); rc_first = MI_ERR_HIP; }
+            return e == hipSuccess;
+        };
         for (int li = lanes - 1; li >= 0; --li) {   // the internal lanes first: they start while lane 0 is still being enqueued
             Lane &ln = h->lane[li];
             const int off = h->last_first[li], cnt = h->last_first[li + 1] - off;
-            hipStream_t ls = st;
-            if (li > 0) {
-                if (!ln.stream) MI_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-                if (!ln.done) MI_HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-                MI_HIP_TRY(hipStreamWaitEvent(ln.stream, h->fork, 0));
-                ls = ln.stream;
+            hipStream_t ls = li > 0 ? ln.stream : st;
+            // a lane that could not be forked behind the caller's stream must not run at all (it would read inputs too early)
+            const bool forked = li == 0 || note(hipStreamWaitEvent(ln.stream, h->fork, 0));
+            if (forked && !rc_first) {
+                const int rc = lane_calc(h, ln, cnt, I0s + off, I1s + off, flows + off, ls, &ns);
+                if (rc && !rc_first) rc_first = rc;
             }
-            const int rc = lane_calc(h, ln, cnt, I0s + off, I1s + off, flows + off, ls, &ns);
-            if (rc && !rc_first) rc_first = rc;
-            // always join, also after an error: the caller's stream must not run ahead of work already enqueued
-            if (li > 0) MI_HIP_TRY(hipEventRecord(ln.done, ln.stream));
         }
-        for (int li = 1; li < lanes; ++li) MI_HIP_TRY(hipStreamWaitEvent(st, h->lane[li].done, 0));
+        // always join, also after an error: the caller's stream must not run ahead of work already enqueued.  If the join itself
+        // fails, fall back to blocking the host until the lane has drained.
+        for (int li = 1; li < lanes; ++li) {
+            Lane &ln = h->lane[li];
+            if (!(note(hipEventRecord(ln.done, ln.stream)) && note(hipStreamWaitEvent(st, ln.done, 0)))) (void)hipStreamSynchronize(ln.stream);
+        }
         if (rc_first) return rc_first;
     }
     h->last_nscales = ns;

@@ -24,6 +24,12 @@ def _destroy(obj, fn_name):
     except Exception:
         pass
 
+def release_cached_memory():
+    """miflow extension: hand the scratch blocks that destroyed handles left in libmiflow's process-wide cache (up to
+    MIFLOW_CACHE_GB, default 24) back to the driver, e.g. before torch's allocator needs the memory."""
+    capi.check(capi.lib().mi_release_cached_memory())
+
+
 class OpticalFlowDual_TVL1:
     """cv::cuda::OpticalFlowDual_TVL1 (cudaoptflow.hpp:305-386).
 

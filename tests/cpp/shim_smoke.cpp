@@ -181,6 +181,23 @@ int main(int argc, char **argv)
             try { cuda::miflow::setStopSlack(t3, 99); } catch (const cv::Exception &) { rejected = true; }
             if (!rejected || f3.size() != f4.size()) return 12;
         }
+        {   // a setter rejected as the FIRST call after construction leaves the constructor's values in place (the rollback
+            // copy used to be taken before the constructor body had filled the parameters)
+            Ptr<cuda::StereoBM> b2 = cuda::createStereoBM(64, 15);
+            bool rej = false;
+            try { b2->setNumDisparities(7); } catch (const cv::Exception &) { rej = true; }
+            if (!rej || b2->getNumDisparities() != 64 || b2->getBlockSize() != 15) return 13;
+            b2->setBlockSize(9);
+            if (b2->getNumDisparities() != 64 || b2->getBlockSize() != 9) return 13;
+            Ptr<cuda::StereoSGM> s2 = cuda::createStereoSGM(0, 128, 10, 120, 5, cuda::StereoSGM::MODE_HH4);
+            rej = false;
+            try { s2->setNumDisparities(100); } catch (const cv::Exception &) { rej = true; }
+            if (!rej || s2->getNumDisparities() != 128 || s2->getP1() != 10 || s2->getP2() != 120 || s2->getUniquenessRatio() != 5) return 14;
+            Ptr<cuda::DisparityBilateralFilter> f2 = cuda::createDisparityBilateralFilter(64, 3, 1);
+            rej = false;
+            try { f2->setRadius(-1); } catch (const cv::Exception &) { rej = true; }
+            if (!rej || f2->getNumDisparities() != 64 || f2->getRadius() != 3 || f2->getNumIters() != 1) return 15;
+        }
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;
         try { cuda::GpuMat bad(h, w, CV_32FC1); bm->compute(bad, bad, disp); } catch (const cv::Exception &) { threw = true; }

@@ -185,3 +185,18 @@ def test_bench_exchange_leg_two_ranks_with_a_stand_in_algorithm(tmp_path):
     n = res[0]["res"]["pairs_per_gpu"]
     assert n == 64
     assert abs(res[0]["res"]["exchange_GB_per_step"] - (n * 2 * 6 * 8 + n * 6 * 8 * 2) * 4 / 1e9) < 1e-15
+
+
+def test_multi_device_state_machine_on_a_fake_device_table(tmp_path):
+    """tests/cpp/multi_sm_test.cpp: the worker state machine of mi_tvl1_multi_* (csrc/tvl1_multi_sm.h, the source the HIP backend
+    instantiates) against a recording fake with DISTINCT device ids {5, 3, 6}: per-thread device currency of every object, peer
+    access enabled both ways, randomised lazy stream scheduling with real byte movement (a missing event wait corrupts a flow),
+    sharding, up-front validation, a failing worker (error names the device, both streams drained, machine stays usable),
+    construction failures, release of everything."""
+    exe = str(tmp_path / "multi_sm_test")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "opencv_contrib_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "multi_sm_test.cpp"),
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "multi_sm_test: ok" in r.stdout, r.stderr
