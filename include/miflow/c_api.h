@@ -147,6 +147,8 @@ MI_API int mi_tvl1_query_plan(int width, int height, int pairs_per_lane, int ite
 MI_API int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, double *algo_bytes);
 /* The same for kind 0 (iteration launches, as above) or kind 1 (the warp launches; algorithmic bytes 44 B x level pixels x batch). */
 MI_API int mi_tvl1_get_profile_kind(mi_tvl1 *h, int kind, double *ms_total, long long *launches, double *algo_bytes);
+/* ... restricted to pyramid level `level` (0 = finest; -1 = all levels): where the kernel time of a calc goes, level by level. */
+MI_API int mi_tvl1_get_profile_level(mi_tvl1 *h, int kind, int level, double *ms_total, long long *launches, double *algo_bytes);
 MI_API void mi_tvl1_destroy(mi_tvl1 *h);
 
 /* Batched-frames mode over the GPUs of one node (BASELINE configs[4]): independent pairs are cut into contiguous shards,

@@ -119,6 +119,7 @@ def lib():
         "mi_tvl1_query_plan": (i, [i, i, i, i, C.POINTER(i), C.POINTER(i)]),
         "mi_tvl1_get_profile": (i, [vp, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
         "mi_tvl1_get_profile_kind": (i, [vp, i, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
+        "mi_tvl1_get_profile_level": (i, [vp, i, i, C.POINTER(d), C.POINTER(C.c_longlong), C.POINTER(d)]),
         "mi_tvl1_destroy": (None, [vp]),
         "mi_tvl1_multi_create": (i, [C.POINTER(TVL1Params), i, C.POINTER(i), C.POINTER(vp)]),
         "mi_tvl1_multi_device_count": (i, [vp]),

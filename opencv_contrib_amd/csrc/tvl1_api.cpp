@@ -53,7 +53,7 @@ struct Lane {
     int batch = 0;          // pairs of the last calc
     // profiling (mi_tvl1_set_profiling)
     std::vector<hipEvent_t> ev_pool;
-    struct Region { int e0, e1; long long launches; double bytes; int kind; };   // kind 0: iteration launches, 1: warp launch
+    struct Region { int e0, e1; long long launches; double bytes; int kind; int level; };   // kind 0: iteration launches, 1: warp launch; level = pyramid scale
     std::vector<Region> regions;
     // internal stream of a concurrent lane + its completion event
     hipStream_t stream = nullptr;
@@ -193,13 +193,18 @@ int mi_tvl1_get_profile(mi_tvl1 *h, double *ms_total, long long *launches, doubl
 
 int mi_tvl1_get_profile_kind(mi_tvl1 *h, int kind, double *ms_total, long long *launches, double *algo_bytes)
 {
+    return mi_tvl1_get_profile_level(h, kind, -1, ms_total, launches, algo_bytes);
+}
+
+int mi_tvl1_get_profile_level(mi_tvl1 *h, int kind, int level, double *ms_total, long long *launches, double *algo_bytes)
+{
     MI_REQUIRE(h && ms_total && launches && algo_bytes, MI_ERR_BAD_ARG, "null argument");
     MI_REQUIRE(kind == 0 || kind == 1, MI_ERR_BAD_ARG, "kind must be 0 (iteration launches) or 1 (warp launches)");
     *ms_total = 0; *launches = 0; *algo_bytes = 0;
     for (int li = 0; li < h->last_lanes; ++li) {
         Lane &ln = h->lane[li];
         for (const auto &r : ln.regions) {
-            if (r.kind != kind) continue;
+            if (r.kind != kind || (level >= 0 && r.level != level)) continue;
             MI_HIP_TRY(hipEventSynchronize(ln.ev_pool[r.e1]));
             float ms = 0.f;
             MI_HIP_TRY(hipEventElapsedTime(&ms, ln.ev_pool[r.e0], ln.ev_pool[r.e1]));
@@ -502,7 +507,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             if (w0 >= 0) {
                 rc = next_event(&w1); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[w1], st));
-                ln.regions.push_back({w0, w1, 1, 44.0 * g.w * g.h * B, 1});   // 44 B/px per warp
+                ln.regions.push_back({w0, w1, 1, 44.0 * g.w * g.h * B, 1, s});   // 44 B/px per warp
             }
             int e0 = -1, e1 = -1;
             if (h->profiling && iters_per_warp > 0) {
@@ -608,7 +613,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             if (e0 >= 0) {
                 rc = next_event(&e1); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[e1], st));
-                ln.regions.push_back({e0, e1, nlaunch, 64.0 * g.w * g.h * B * iters_per_warp, 0});
+                ln.regions.push_back({e0, e1, nlaunch, 64.0 * g.w * g.h * B * iters_per_warp, 0, s});
             }
         }
         Ctl ec = ctl;

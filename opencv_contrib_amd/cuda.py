@@ -136,11 +136,11 @@ class OpticalFlowDual_TVL1:
     def setProfiling(self, on=True):
         capi.check(capi.lib().mi_tvl1_set_profiling(self._h, int(bool(on))))
 
-    def getProfile(self, kind=0):
+    def getProfile(self, kind=0, level=-1):
         """(ms inside the iteration-launch regions [kind 0] or the warp launches [kind 1], launches, algorithmic bytes) of the
-        last calc."""
+        last calc; level >= 0 restricts it to one pyramid level (0 = finest)."""
         ms, n, by = C.c_double(), C.c_longlong(), C.c_double()
-        capi.check(capi.lib().mi_tvl1_get_profile_kind(self._h, kind, C.byref(ms), C.byref(n), C.byref(by)))
+        capi.check(capi.lib().mi_tvl1_get_profile_level(self._h, kind, level, C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
 
     def lastIterations(self, pair=0):

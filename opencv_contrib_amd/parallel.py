@@ -50,6 +50,17 @@ def max_over_ranks(dist, value: float, device=None) -> float:
     return float(t.item())
 
 
+def all_over_ranks(dist, value: float, device=None) -> list:
+    """Every rank's value, in rank order (per-rank rates of a weak-scaling job)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
 def sum_over_ranks(dist, value: float, device=None) -> float:
     if dist is None:
         return float(value)

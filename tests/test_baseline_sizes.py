@@ -123,6 +123,122 @@ def test_two_lanes_equal_one_lane(gpu, eps, iters, nlanes):
         assert single.lastIterations(0) == a1.lastIterations(k)
 
 
+# ------------------------------------------------------------------------------------------------ TV-L1 at 4K, class defaults at 1080p,
+# the reference test's literal setting
+@pytest.fixture(scope="module")
+def pair4k(oracle):
+    I0, I1, gt = synth.flow_pair(2160, 3840, seed=1234)
+    return I0, I1, gt, oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0))
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["default_fast_fused", "exact_math"])
+def test_tvl1_4k_against_oracle(gpu, pair4k, exact):
+    """north_star "synthetic 1080p/4K pairs": 3840 x 2160 CV_32FC1, iterations = 10, against oracle.tvl1_calc with the 1080p bounds
+    (reference call path cudaoptflow/src/tvl1flow.cpp:185-302; the plane offsets of a 4K batch are where the 32-bit guard of
+    c3a8dde sits)."""
+    from opencv_contrib_amd import cuda
+    I0, I1, gt, ref = pair4k
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0, exactMath=exact)
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    assert np.isfinite(flow).all()
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= (2e-3 if exact else 5e-3), d.mean()
+    assert synth.ccorr_dissimilarity(flow, ref) <= 1e-4
+    assert (d <= 0.02).mean() >= 0.99
+    assert synth.epe(flow, gt) < 0.15
+
+
+def test_tvl1_4k_batch_equals_single_calcs(gpu, pair4k):
+    """A 4K batch (two lanes, 5 pairs: 1.6 GB of planes per lane) is bit-identical to single calcs."""
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, _, _ = pair4k
+    a, b = T(I0, gpu), T(I1, gpu)
+    I0s = [torch.roll(a, 11 * k, 1).contiguous() for k in range(5)]
+    I1s = [torch.roll(b, 11 * k, 1).contiguous() for k in range(5)]
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0)
+    fb = alg.calc_batch(I0s, I1s)
+    torch.cuda.synchronize()
+    single = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0)
+    for k in (0, 2, 4):
+        assert torch.equal(single.calc(I0s[k], I1s[k]), fb[k]), f"pair {k}"
+
+
+@pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class_rule", "cv_cuda_schedule"])
+def test_class_defaults_at_1080p(gpu, oracle, sem):
+    """The class defaults (300 iterations, epsilon 0.01: cudaoptflow.hpp:382) at the BASELINE size, the configuration bench.py's
+    `class_defaults_300_eps0.01` variant publishes: device-decided stop, iteration counts within 2 of the oracle's per (scale,
+    warp), flow within the change of the last converged iterations, deterministic."""
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(1080, 1920, seed=1234)
+    ref, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=300, semantics=sem), return_stats=True)
+    alg = cuda.OpticalFlowDual_TVL1.create(semantics=sem)
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    it = np.array(alg.lastIterations())
+    rit = np.array(st["iters"])[:it.shape[0], :it.shape[1]]
+    assert it.shape == rit.shape == (5, 5)
+    assert it.min() >= 1 and (it < 300).any()
+    assert np.abs(it - rit).max() <= 2, (it.tolist(), rit.tolist())
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= 2e-2, d.mean()
+    assert synth.ccorr_dissimilarity(flow, ref) <= 4e-3
+    assert synth.epe(flow, gt) < 0.15
+    np.testing.assert_array_equal(flow, N(alg.calc(T(I0, gpu), T(I1, gpu))))
+
+
+@pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class_rule", "cv_cuda_schedule"])
+@pytest.mark.parametrize("shape,seed,dtype", [((388, 584), 78, "u8"), ((480, 640), 5, "f32"), ((1080, 1920), 1234, "f32")])
+def test_reference_accuracy_test_literal_setting(gpu, oracle, sem, shape, seed, dtype):
+    """cudaoptflow/test/test_optflow.cpp:440-466 LITERALLY: `OpticalFlowDual_TVL1::create(); setNumIterations(10);` -- nothing else,
+    so epsilon stays 0.01 and "N = 10" is the convergence-checked loop with at most 10 iterations per warp, not fixed work
+    (the CPU twin there: medianFiltering 1, innerIterations 1, outerIterations = the CUDA object's iterations).  Counts within 2 of
+    the oracle's and never above 10, flow inside the reference's own acceptance |1 - CCORR| <= 4e-3 by a wide margin."""
+    from opencv_contrib_amd import cuda
+    I0, I1, _ = synth.flow_pair(*shape, seed=seed, dtype=dtype)
+    alg = cuda.OpticalFlowDual_TVL1.create(semantics=sem)
+    alg.setNumIterations(10)
+    assert (alg.getNumIterations(), alg.getEpsilon()) == (10, 0.01)
+    ref, st = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, semantics=sem), return_stats=True)
+    flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
+    it = np.array(alg.lastIterations())
+    rit = np.array(st["iters"])[:it.shape[0], :it.shape[1]]
+    assert it.shape == rit.shape
+    assert it.min() >= 1 and it.max() <= 10
+    assert np.abs(it - rit).max() <= 2, (it.tolist(), rit.tolist())
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= 2e-2, d.mean()
+    assert synth.ccorr_dissimilarity(flow, ref) <= 1e-3       # test_optflow.cpp:465 accepts 4e-3
+
+
+def test_sixteen_handles_sixteen_streams_one_calc_each(gpu, oracle):
+    """cudaoptflow/test/test_optflow.cpp:468-527 (the reference's async test): 16 objects, 16 streams, one calc() each, all in
+    flight together; every flow must equal the flow of a lone calc on the default stream bit for bit (handles share nothing)."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(388, 584, seed=300 + k)[:2] for k in range(16)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    algs = [cuda.OpticalFlowDual_TVL1.create() for _ in range(16)]
+    for a in algs:
+        a.setNumIterations(10)
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(16)]
+    torch.cuda.synchronize()
+    # outputs allocated up front (a tensor freed while another stream still writes it could be handed out again)
+    outs = [[torch.empty((388, 584, 2), dtype=torch.float32, device=gpu) for _ in range(16)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(2):   # the second round re-uses warm handles while the first may still be running
+        for k in range(16):
+            algs[k].calc(I0s[k], I1s[k], flow=outs[rep][k], stream=streams[k].cuda_stream)
+    flows = outs[1]
+    for s in streams:
+        s.synchronize()
+    lone = cuda.OpticalFlowDual_TVL1.create()
+    lone.setNumIterations(10)
+    for k in range(16):
+        assert torch.equal(lone.calc(I0s[k], I1s[k]), flows[k]), f"handle {k}"
+    ref = oracle.tvl1_calc(pairs[3][0], pairs[3][1], oracle.tvl1_params(iterations=10))
+    assert np.sqrt(((N(flows[3]) - ref) ** 2).sum(-1)).mean() <= 2e-2
+
+
 @pytest.mark.parametrize("devices,chunk", [([0], 4), ([0, 0], 2), ([0, 0, 0], 16)])
 def test_multi_device_host_entry_equals_calc_batch(gpu, devices, chunk):
     """mi_tvl1_multi_calc_batch (host threads, one per device; peer-to-peer staging in double-buffered chunks): on the one-GPU

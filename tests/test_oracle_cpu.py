@@ -135,3 +135,33 @@ def test_tvl1_oracle_matches_golden(oracle, path):
     flow, st = oracle.tvl1_calc(z["I0"], z["I1"], oracle.tvl1_params(**kw), return_stats=True)
     np.testing.assert_array_equal(np.array(st["iters"], np.int32), z["iters"])
     np.testing.assert_allclose(flow, z["flow"], rtol=0, atol=1e-6)
+
+
+def test_bench_cpu_baseline_protocol_and_distinct_inputs(oracle):
+    """bench.py's cpu_baseline leg: thread sweep capped at the physical cores, a warm-up, >= 5 repetitions,
+    median / min, a one-core figure -- run here on a small pair through the real oracle; and the input builder makes >= 16
+    distinct pairs (the class-default variant's iteration histogram was that of 4 images)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    base = bench.gen_base_pairs(16, 60, 80)
+    assert len(base) == 16
+    sigs = {b[0].tobytes() for b in base}
+    assert len(sigs) == 16
+    I0, I1, gt = synth.flow_pair(60, 80, seed=1234)
+    np.testing.assert_array_equal(base[0][0], I0)       # pair 0 is the pair of the parity tests
+    p = oracle.tvl1_params(iterations=10, epsilon=0.0)
+    calls = []
+
+    def cpu_calc(a, b):
+        calls.append(a.shape)
+        return oracle.tvl1_calc(a, b, p)
+
+    cb = bench.timed_cpu_baseline(cpu_calc, base[:3], budget_s=0.0)
+    assert len(cb["times"]) >= 5 and cb["median_s"] > 0 and cb["threads"] <= cb["physical_cores"]
+    assert cb["one_core"] and cb["one_core"]["cores"] == 1
+    assert len(calls) >= 1 + 1 + 5 + 1                  # sweep, warm-up, repetitions, one core
+    np.testing.assert_array_equal(cb["ref0"], oracle.tvl1_calc(base[0][0], base[0][1], p))   # the thread count never changes a flow
