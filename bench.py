@@ -158,7 +158,7 @@ def physical_cores():
 
 def timed_cpu_baseline(cpu_calc, base, budget_s=12.0, hard_s=25.0, with_one_core=True):
     """CPU-baseline protocol of BASELINE.md section 3 on a bounded sample: thread count capped at the PHYSICAL cores (a short sweep
-    picks the fastest of {physical, 64, 32, 16}: stripes of a parallel_for_ over-subscribe badly on a 256-thread host), one warm-up
+    picks the fastest of {physical, 64, 32, 16, 8}: stripes of a parallel_for_ over-subscribe badly on a 256-thread host), one warm-up
     at the chosen count, then >= 5 timed repetitions (up to 9 inside `budget_s`; never past `hard_s` once 3 are in) over the distinct
     pairs of `base`; median and min; plus pair 0 on ONE core.  cpu_calc(I0, I1) -> flow."""
     import numpy as np
@@ -171,7 +171,7 @@ def timed_cpu_baseline(cpu_calc, base, budget_s=12.0, hard_s=25.0, with_one_core
     phys = physical_cores()
     b0_ = base[0]
     sweep, ref0 = {}, None
-    for nt in sorted({phys, min(phys, 64), min(phys, 32), min(phys, 16)}, reverse=True):
+    for nt in sorted({phys, min(phys, 64), min(phys, 32), min(phys, 16), min(phys, 8)}, reverse=True):
         if not omp_set_threads(nt):
             nt = os.cpu_count() or 1
         dt, ref0 = one(b0_[0], b0_[1])      # the first one doubles as a warm-up (first touch of the buffers, thread pool start)

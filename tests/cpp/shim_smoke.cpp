@@ -181,22 +181,32 @@ int main(int argc, char **argv)
             try { cuda::miflow::setStopSlack(t3, 99); } catch (const cv::Exception &) { rejected = true; }
             if (!rejected || f3.size() != f4.size()) return 12;
         }
-        {   // a setter rejected as the FIRST call after construction leaves the constructor's values in place (the rollback
-            // copy used to be taken before the constructor body had filled the parameters)
-            Ptr<cuda::StereoBM> b2 = cuda::createStereoBM(64, 15);
+        {   // Setters of the stereo classes validate at compute() / apply(), like the reference's (stereobm.cpp:143-146): an invalid value
+            // as the FIRST call after construction is stored, the compute throws, and every other parameter still holds the
+            // constructor's value (the rollback copy used to be taken before the constructor body had filled them).
+            Ptr<cuda::StereoBM> b2 = cuda::createStereoBM(32, 9);
+            b2->setNumDisparities(7);
+            if (b2->getNumDisparities() != 7 || b2->getBlockSize() != 9 || b2->getPreFilterCap() != 31 || b2->getTextureThreshold() != 3) return 13;
             bool rej = false;
-            try { b2->setNumDisparities(7); } catch (const cv::Exception &) { rej = true; }
-            if (!rej || b2->getNumDisparities() != 64 || b2->getBlockSize() != 15) return 13;
-            b2->setBlockSize(9);
-            if (b2->getNumDisparities() != 64 || b2->getBlockSize() != 9) return 13;
+            cuda::GpuMat dd;
+            try { b2->compute(d0, d1, dd); } catch (const cv::Exception &) { rej = true; }
+            if (!rej) return 13;
+            b2->setNumDisparities(32);
+            b2->compute(d0, d1, dd);
+            std::vector<unsigned char> e0((size_t)h * w), e1((size_t)h * w);
+            disp.download(e0.data(), (size_t)w);
+            dd.download(e1.data(), (size_t)w);
+            if (e0 != e1) return 13;
             Ptr<cuda::StereoSGM> s2 = cuda::createStereoSGM(0, 128, 10, 120, 5, cuda::StereoSGM::MODE_HH4);
-            rej = false;
-            try { s2->setNumDisparities(100); } catch (const cv::Exception &) { rej = true; }
-            if (!rej || s2->getNumDisparities() != 128 || s2->getP1() != 10 || s2->getP2() != 120 || s2->getUniquenessRatio() != 5) return 14;
+            s2->setNumDisparities(100);
+            if (s2->getNumDisparities() != 100 || s2->getP1() != 10 || s2->getP2() != 120 || s2->getUniquenessRatio() != 5 ||
+                s2->getMode() != cuda::StereoSGM::MODE_HH4) return 14;
             Ptr<cuda::DisparityBilateralFilter> f2 = cuda::createDisparityBilateralFilter(64, 3, 1);
+            f2->setRadius(-1);
+            if (f2->getNumDisparities() != 64 || f2->getRadius() != -1 || f2->getNumIters() != 1) return 15;
             rej = false;
-            try { f2->setRadius(-1); } catch (const cv::Exception &) { rej = true; }
-            if (!rej || f2->getNumDisparities() != 64 || f2->getRadius() != 3 || f2->getNumIters() != 1) return 15;
+            try { cuda::GpuMat o2; f2->apply(disp, d0, o2, stream); } catch (const cv::Exception &) { rej = true; }
+            if (!rej) return 15;
         }
         // error mapping: CV_Assert-style failures surface as cv::Exception
         bool threw = false;
