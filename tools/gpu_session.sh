@@ -32,11 +32,11 @@ timeline)
   python tools/timeline.py $O/tl > $O/timeline.txt 2>&1; tail -5 $O/timeline.txt
   find $O -type f -size +4M -delete ;;
 ab_env)
-  # generic A/B over environment settings: AB_ENVS="A=1,B=2 A=0 -" (one bench run per word; "-" = defaults), AB_ARGS = extra bench args
+  # generic A/B over environment settings: AB_ENVS="A=1+B=2 A=0 -" (one bench run per word; "-" = defaults), AB_ARGS = extra bench args
   i=0
   for cfg in ${AB_ENVS:--}; do
     i=$((i+1))
-    envs=""; [ "$cfg" != "-" ] && envs=$(echo $cfg | tr ',' ' ')
+    envs=""; [ "$cfg" != "-" ] && envs=$(echo $cfg | tr '+' ' ')
     (env $envs timeout 300 python bench.py --no-variants --no-cpu --no-secondary --steps ${AB_STEPS:-12} --warmup 3 ${AB_ARGS:-} 2>$O/ab_env_$i.err | tail -1) > $O/ab_env_$i.json
     python - <<PY
 import json
