@@ -131,6 +131,7 @@ def lib():
         "mi_tvl1_iterate": (i, [i, i, i, PM, PM, PM, PM, PM, PM, PM, PM, f, f, f, C.POINTER(d), vp]),
         "mi_resize_linear": (i, [i, PM, PM, d, d, i, f, vp]),
         "miflow_selftest_lane_shift": (i, [C.POINTER(i)]),
+        "miflow_selftest_jw_fault": (i, [C.POINTER(i)]),
         "miflow_selftest_tvl1_slots": (i, [vp, i, C.POINTER(i), i, vp]),
         "mi_stereobm_default_params": (None, [C.POINTER(StereoBMParams)]),
         "mi_stereobm_create": (i, [C.POINTER(StereoBMParams), C.POINTER(vp)]),

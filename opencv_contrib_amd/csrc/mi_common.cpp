@@ -25,6 +25,7 @@ const Tuning &tuning()
         t.warp_np = env_int("MIFLOW_WARP_NP", 2);   // r02e at 1080p x 16: np 1 | 2 | 4 = 904 | 1042 | 1034 pairs/s
         if (t.warp_np != 1 && t.warp_np != 4) t.warp_np = 2;
         t.tb_swz = env_int("MIFLOW_TB_SWZ", 1);
+        t.tb_jw = env_int("MIFLOW_TB_JW", 0);   // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip)
         t.tb_ppl = t.tb_wps = t.tb_pf = -1;
         if (const char *v = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(v, "%d,%d,%d", &t.tb_ppl, &t.tb_wps, &t.tb_pf);
         t.tb_force = getenv("MIFLOW_TB_FORCE") != nullptr;

@@ -36,7 +36,8 @@ struct Tuning {
     int warp_lds;            // MIFLOW_WARP_LDS: windows of the fused-gradient warp read from an LDS-staged region of I1 (1) or gathered from global memory (0)
     int warp_fast;           // MIFLOW_WARP_FAST: fast-math calcs form the warp's bicubic sums separably (1: +4.7 % pairs/s, 2-3 x the EPE against the oracle) or tap by tap in the reference's order (0); -1 (default): separably under MI_SEM_CUDA_COMPAT, whose map is not quantised (EPE 1.2e-5 either way), tap by tap under MI_SEM_CPU_REF
     int warp_np;             // MIFLOW_WARP_NP: patches a wave of the fused-gradient warp kernel walks (1 | 2 | 4)
-    int tb_swz;              // MIFLOW_TB_SWZ: XCD-aware workgroup remap of the blocked iteration kernels
+    int tb_swz;             // MIFLOW_TB_SWZ: XCD-aware workgroup remap of the blocked iteration kernels
+    int tb_jw;              // MIFLOW_TB_JW: joined-wave form of the T = 10 blocked iteration kernel
     int tb_ppl, tb_wps, tb_pf;   // MIFLOW_TB_VARIANT=ppl,wps,pf (-1: table default)
     int tb_force;            // MIFLOW_TB_FORCE: greedy blocks of exactly the cap (tuning sweeps)
     int tb_plan_wps;         // MIFLOW_TB_WPS: waves/SIMD the band planner assumes (0: table)

@@ -20,6 +20,9 @@ MI_API int miflow_selftest_lane_shift(int *out_host /*[128]*/);
 /* Control slots of pair `pair` of the last convergence-checked calc: per launch 8 ints {scale, warp, S.x, S.y, X.x, X.y, X.z,
  * X.w} (tvl1_dev.h); returns the launch count or a negative status.  Used by tools/spec_trace.py to inspect the decisions of the
  * speculative steps; synchronises `stream`. */
+/* *fault = 1 if a wave of a joined-wave blocked iteration kernel ever gave up waiting for its neighbour (never expected: the
+ * results of that launch are invalid); synchronises the device */
+MI_API int miflow_selftest_jw_fault(int *fault);
 struct mi_tvl1;
 MI_API int miflow_selftest_tvl1_slots(struct mi_tvl1 *h, int pair, int *out_host, int cap_launches, void *stream);
 #ifdef __cplusplus

@@ -127,6 +127,7 @@ inline int tb_pick_block(int n, int cap)
     return 1;
 }
 int dbg_lane_shift(int *out_dev, hipStream_t s);
+int tb_jw_fault(int *fault_host);   // sticky fault flag of the joined-wave blocked kernels (synchronises the device)
 
 void host_cubic_table(float tab[128]);  // cv::remap INTER_CUBIC phase table (a = -0.75)
 

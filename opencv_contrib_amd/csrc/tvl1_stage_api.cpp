@@ -238,4 +238,10 @@ int miflow_selftest_lane_shift(int *out_host)
     return rc;
 }
 
+int miflow_selftest_jw_fault(int *fault)
+{
+    MI_REQUIRE(fault, MI_ERR_BAD_ARG, "null out");
+    return tb_jw_fault(fault);
+}
+
 }  // extern "C"

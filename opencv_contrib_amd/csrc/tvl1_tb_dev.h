@@ -17,6 +17,17 @@ __device__ __forceinline__ float dpp_from_next(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
+// The same with the lane that has no source lane (lane 0 / lane 63) taking `fill` instead of 0: the value the neighbouring wave of
+// a joined group handed over through LDS (k_iterate_tbr JW).  bound_ctrl off = "keep the old value of the destination".
+__device__ __forceinline__ float dpp_from_prev_fill(float v, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_next_fill(float v, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
 // Dynamic state of one pipeline stage: u_t(a) and p_(t-1)(a) of the row it holds.
 template <int PPL>
 struct Dyn {

@@ -45,17 +45,20 @@ struct Slot {
 // accumulator, so the sum does not depend on how rows are split into bands or pairs into batches and lanes -- a pair stops
 // after the same iteration whatever batch it is computed in.  es = 2^24 for rows inside the wave's band, 0 for its halo rows
 // (the scale doubles as the row mask); ownership of the column is applied once, when the accumulators are reduced.
-template <int PPL, bool ERR>
+// JW (joined waves, see k_iterate_tbr): the lane without a source lane takes what the neighbouring wave handed over -- (xl1, xl2) =
+// p11, p21 of the column left of lane 0, (xr1, xr2) = u1, u2 of the column right of lane 63 -- instead of the zero fill.
+template <int PPL, bool ERR, int JW = 0>
 __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
-                                        float m2, float taum2, float l_t, float theta, float taut, unsigned long long &acc, float es)
+                                        float m2, float taum2, float l_t, float theta, float taut, unsigned long long &acc, float es,
+                                        float xl1 = 0.f, float xl2 = 0.f, float xr1 = 0.f, float xr2 = 0.f)
 {
     float dx1[PPL], dx2[PPL];
-    dx1[0] = A.p11[0] - dpp_from_prev(A.p11[PPL - 1]);
-    dx2[0] = A.p21[0] - dpp_from_prev(A.p21[PPL - 1]);
+    dx1[0] = A.p11[0] - (JW ? dpp_from_prev_fill(A.p11[PPL - 1], xl1) : dpp_from_prev(A.p11[PPL - 1]));
+    dx2[0] = A.p21[0] - (JW ? dpp_from_prev_fill(A.p21[PPL - 1], xl2) : dpp_from_prev(A.p21[PPL - 1]));
 #pragma unroll
     for (int j = 1; j < PPL; ++j) { dx1[j] = A.p11[j] - A.p11[j - 1]; dx2[j] = A.p21[j] - A.p21[j - 1]; }
-    const float r1 = dpp_from_next(B.u1[0]);
-    const float r2 = dpp_from_next(B.u2[0]);
+    const float r1 = JW ? dpp_from_next_fill(B.u1[0], xr1) : dpp_from_next(B.u1[0]);
+    const float r2 = JW ? dpp_from_next_fill(B.u2[0], xr2) : dpp_from_next(B.u2[0]);
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
         // ---- u_t(a)   (optflow/src/tvl1flow.cpp:989-1041, 1096-1112; TH written as clamp(-rho/grad, +-l_t))
@@ -211,17 +214,70 @@ struct CtxR {
     int nit;        // active stages (MODE 1: the length of the speculative block or of the replay; otherwise T)
 };
 
+// ---- joined waves (JW): LDS hand-over between the four waves of a workgroup that sit on four ADJACENT 64-column segments of one
+// band.  A consumer wave owns an AREA of 2 buffers (step parity) x T slots (stage) x XS bytes:
+//     +0  p11, p21 of the column left of its lane 0   (written by lane 63 of the wave to its left)   } input of stage t of
+//     +8  u1, u2   of the column right of its lane 63 (written by lane 0 of the wave to its right)   } the step with that parity
+//     +16 tag: low half = step + 1 of the left writer, high half = step + 1 of the right writer's TARGET step
+// Dependences (tvl1_tbr_kernels.hip header): stage t of step n needs p_(t-1)(row a) of the left neighbour -- its stage t-1 of the
+// SAME step (stage 0: the row it loaded) -- and u_t(row a-1) of the right neighbour -- its stage t of step n-1.  Every dependence
+// points to a lexicographically smaller (step, stage), so waiting cannot cycle; the waves of a workgroup are co-resident, so
+// waiting cannot starve.  In steady state a wave trails its left neighbour by one to T stages.  Two buffers suffice: the writer of
+// a slot depends (through the opposite dependence) on the reader having passed the slot's previous use.  Data is written before
+// its tag and read after it; LDS executes a wave's DS operations in order.
+constexpr int XS = 32;   // bytes per slot: {p11, p21 | u1, u2 | tag | pad}
+__host__ __device__ constexpr int xarea_bytes(int T) { return 2 * T * XS; }
+__host__ __device__ constexpr int xdump_bytes(int T) { return 2 * T * XS + 64 * 8; }   // where the 63 non-publishing lanes write
+// pointers into LDS keep their address space (a generic pointer makes every access a flat_load / flat_store)
+#define MI_LDS __attribute__((address_space(3)))
+typedef MI_LDS char *lds_ptr;
+struct Xchg {
+    // byte addresses in LDS, all for the CURRENT step's parity: own = the slots this wave consumes (wave-uniform, kept in a VGPR);
+    // pub_r / pub_l = where a lane's hand-over to the right / left neighbour goes: the neighbour's area for the ONE lane that holds the
+    // boundary column (lane 63 / lane 0), a per-lane dump address for all others -- so a publish is an ordinary full-wave store
+    unsigned own, pub_r, pub_l;
+    unsigned mul;               // 1 if a left neighbour feeds this wave | 0x10000 if a right one does: expected tag = (n + 1) * mul
+    unsigned tag; float l1, l2, r1, r2;   // slot read ahead for the next stage
+    int budget;                 // re-reads this wave may still spend waiting (all stages of the launch together)
+};
+__device__ __forceinline__ void xread(unsigned slot, unsigned &tag, float &l1, float &l2, float &r1, float &r2)
+{
+    const lds_ptr q = (lds_ptr)slot;
+    tag = *reinterpret_cast<volatile MI_LDS unsigned *>(q + 16);          // the tag first: data is written before its tag
+    const unsigned long long L = *reinterpret_cast<volatile MI_LDS unsigned long long *>(q);
+    const unsigned long long R = *reinterpret_cast<volatile MI_LDS unsigned long long *>(q + 8);
+    l1 = __uint_as_float((unsigned)L); l2 = __uint_as_float((unsigned)(L >> 32));
+    r1 = __uint_as_float((unsigned)R); r2 = __uint_as_float((unsigned)(R >> 32));
+}
+// two dwords, then the 16-bit tag
+__device__ __forceinline__ void xwrite(unsigned slot, int data_off, int tag_off, float a, float b, unsigned tag)
+{
+    const lds_ptr q = (lds_ptr)slot;
+    *reinterpret_cast<volatile MI_LDS float *>(q + data_off) = a;
+    *reinterpret_cast<volatile MI_LDS float *>(q + data_off + 4) = b;
+    *reinterpret_cast<volatile MI_LDS unsigned short *>(q + tag_off) = (unsigned short)tag;
+}
+__device__ int g_jw_fault;   // sticky: a bounded wait on a neighbouring wave ran out (never expected; results are then invalid)
+
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
-template <int T, int PPL, bool PZ, int PF, int MODE, int k>
-__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T])
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, int k>
+__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T], Xchg &x)
 {
     constexpr int P = T + 1 + PF;
     constexpr int K = T > 2 ? T - 1 : 1;
     const int n = n0 + k;
     const int r0 = c.ystart + n;
     if (MODE != 2) finish_static<PPL>(X[k].s);
+    unsigned xexpect = 0, vtag_r = 0, vtag_l = 0;
+    if (JW) {
+        vtag_r = (unsigned)(n + 1); vtag_l = (unsigned)(n + 2);
+        asm volatile("" : "+v"(vtag_r), "+v"(vtag_l), "+v"(x.own));   // one VGPR copy per step, not one v_mov per store
+        // the row entering the pipeline: its p11, p21 of lane 63 are the right neighbour's stage-0 input of this step
+        xwrite(x.pub_r, 0, 16, X[k].d.p11[0], X[k].d.p21[0], vtag_r);
+        xexpect = ((unsigned)(n + 1) & 0xffffu) * x.mul;
+    }
 #ifndef TBR_X_NOLOAD   // timing experiments only (wrong results): no row loads after the prologue
     load_row_r<PPL, PZ>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
 #else
@@ -266,11 +322,38 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         } else if (MODE == 2) {
             if constexpr (PPL == 1)
                 stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
+        } else if (JW) {
+            // consume the slot read ahead for this stage (re-read until both writers have delivered), read ahead for the next one
+            // (stage 0 of the next step lives in the other buffer), compute, hand the new boundary values over
+            unsigned tag = x.tag;
+            float l1 = x.l1, l2 = x.l2, r1 = x.r1, r2 = x.r2;
+#pragma nounroll
+            while (__builtin_amdgcn_readfirstlane(tag) != xexpect) {
+                __builtin_amdgcn_s_sleep(1);
+                xread(x.own + t * XS, tag, l1, l2, r1, r2);
+                // every wait is bounded (a wave that never arrives must not hang the device): once the budget of the whole launch
+                // is spent, whatever is there is taken and the launch reports the fault at its end
+                if (--x.budget < 0) xexpect = __builtin_amdgcn_readfirstlane(tag);
+            }
+            // (x.own of the other buffer: own + d with d = -+T * XS, applied to all three addresses at the end of the step)
+            if (t + 1 < T) xread(x.own + (t + 1) * XS, x.tag, x.l1, x.l2, x.r1, x.r2);
+            else xread(x.own + ((n & 1) ? -T * XS : T * XS), x.tag, x.l1, x.l2, x.r1, x.r2);
+            unsigned long long dummy = 0;
+            Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
+            stage_r<PPL, false, 1>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, dummy, 0.f, l1, l2, r1, r2);
+            // p_t(row a-1) of lane 63 -> stage t+1 of the right neighbour, this step; u_t(row a) of lane 0 -> stage t of the left
+            // neighbour, NEXT step (pub_l already points into its other buffer)
+            if (t + 1 < T) xwrite(x.pub_r + (t + 1) * XS, 0, 16, SB.p11[0], SB.p21[0], vtag_r);
+            xwrite(x.pub_l + t * XS, 8, 18, SA.u1[0], SA.u2[0], vtag_l);
         } else {
             unsigned long long dummy = 0;
             stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
                                 c.taut, dummy, 0.f);
         }
+    }
+    if (JW) {   // the other buffer for the next step
+        const int d = (n & 1) ? -T * XS : T * XS;
+        x.own += d; x.pub_r += d; x.pub_l -= d;   // pub_l addresses the left neighbour's buffer of the NEXT step: opposite phase
     }
     {   // level-T row r0 - T leaves the pipeline
         const Dyn<PPL> &r = X[(k - T + 2 * P) % P].d;
@@ -293,11 +376,11 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     }
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
-template <int T, int PPL, bool PZ, int PF, int MODE, int... Ks>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, int... Ks>
 __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
-                                        std::integer_sequence<int, Ks...>)
+                                        Xchg &x, std::integer_sequence<int, Ks...>)
 {
-    (step_r<T, PPL, PZ, PF, MODE, Ks>(c, X, n0, slot0, acc), ...);
+    (step_r<T, PPL, PZ, PF, MODE, JW, Ks>(c, X, n0, slot0, acc, x), ...);
 }
 
 // MODE 0: T iterations, fixed work.
@@ -310,11 +393,18 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 //   nit is chosen on the device from the error history (the previous warp's count, then the decay of the sums).  The last
 //   launch of a warp only settles.  Control travels through the per-launch slots of Ctl / SpecK, so the calc stays stream-ordered
 //   and bit-reproducible (integer error sums, decisions from device data only).
-template <int T, int PPL, bool PZ, int WPS, int PF, int MODE>
+//
+// JW = 1 (joined waves; T = 10, 1 px per lane, MODE 0): the four waves of a workgroup are not four bands of one 64-column strip but
+//   four ADJACENT 64-column segments of ONE band, i.e. a 256-column strip whose margin of T columns exists only at its two outer
+//   edges (236 of 256 lanes own a column instead of 44 of 64: 33 instead of 44 waves per 1080p row band).  At the three inner
+//   seams the neighbouring waves hand each other the two values a stage needs from across the seam through LDS (Xchg above).  The
+//   arithmetic of an owned pixel is the same operations on the same values as in the independent-wave form: bit-identical planes.
+template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0>
 __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 {
+    static_assert(!JW || (PPL == 1 && MODE == 0 && T > 2), "joined waves: 1 px per lane, fixed work");
     constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
-    constexpr int LW = 64 * PPL;                   // pixels a wave covers
+    constexpr int LW = (JW ? 256 : 64) * PPL;      // pixels a strip covers: a wave, or the four joined waves of a workgroup
     constexpr int STRIDE = LW - 2 * M;             // owned columns of the strips >= 1 (strip 0 owns LW - M)
     constexpr int P = T + 1 + PF;                  // register sets
     constexpr int K = T > 2 ? T - 1 : 1;           // LDS ring slots: the row of step n is read by stages 2..T-1 at steps n+2..n+T-1
@@ -333,17 +423,39 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
         strip = lid % gridDim.x; bgrp = (lid / gridDim.x) % gridDim.y; b = lid / (gridDim.x * gridDim.y);
     }
     strip = __builtin_amdgcn_readfirstlane(strip); bgrp = __builtin_amdgcn_readfirstlane(bgrp); b = __builtin_amdgcn_readfirstlane(b);
-    const int band = bgrp * 4 + wave;
+    const int band = JW ? bgrp : bgrp * 4 + wave;
     const int W = A.g.w;
     c.H = A.g.h; c.ld = A.g.ld;
     c.y0 = band * A.rows_per_band;
     c.ring = lds + wave * (K * 256 * PPL);
-    if (c.y0 >= c.H) return;
+    if (c.y0 >= c.H) return;   // JW: the same for all four waves
     c.y1 = min(c.y0 + A.rows_per_band, c.H);
     // strip 0 starts at the image border in lane 0; strip s >= 1 starts M px left of what it owns
     const int own_lo = strip == 0 ? 0 : (LW - M) + (strip - 1) * STRIDE;
     const int own_hi = min(strip == 0 ? LW - M : own_lo + STRIDE, W);
-    const int xl = (strip == 0 ? 0 : own_lo - M) + c.lane * PPL;   // first pixel of this lane, >= 0
+    const int xw = (strip == 0 ? 0 : own_lo - M) + (JW ? wave * 64 : 0);   // first pixel of this wave
+    const int xl = xw + c.lane * PPL;   // first pixel of this lane, >= 0
+    Xchg x;
+    x.own = x.pub_r = x.pub_l = 0; x.mul = 0; x.tag = 0; x.l1 = x.l2 = x.r1 = x.r2 = 0.f; x.budget = 1 << 20;
+    if (JW) {
+        // behind the four rings: 4 areas, then 4 dumps.  A wave whose first column lies beyond the image does nothing (and nobody
+        // waits for it): its left neighbour's last columns are cut by right_ok exactly as at the right edge of a strip.
+        constexpr int XA = xarea_bytes(T), XD = xdump_bytes(T);
+        const unsigned xb = (unsigned)(unsigned long long)(lds_ptr)(lds + 4 * (K * 256 * PPL));
+        const bool has_left = wave > 0, has_right = wave < 3 && xw + 64 < W;
+        const unsigned dump = xb + 4 * XA + wave * XD + c.lane * 8;
+        x.own = xb + wave * XA;
+        x.pub_r = (has_right && c.lane == 63) ? xb + (wave + 1) * XA : dump;
+        x.pub_l = ((has_left && c.lane == 0) ? xb + (wave - 1) * XA : dump) + T * XS;   // the left neighbour's buffer of step 1 (the dump addresses toggle alike)
+        x.mul = (has_left ? 1u : 0u) | (has_right ? 0x10000u : 0u);
+        // zero data, tags 0; buffer 0 of step 0 expects "step -1" of the right neighbour: all-zero u (the initial held state)
+        for (int i = c.lane; i < XA / 4; i += 64) {
+            const int w4 = i % (XS / 4), buf = i / (T * XS / 4);
+            reinterpret_cast<volatile MI_LDS unsigned *>((lds_ptr)x.own)[i] = (w4 == 4 && buf == 0 && has_right) ? 0x10000u : 0u;
+        }
+        __syncthreads();
+        if (xw >= W) return;
+    }
 #pragma unroll
     for (int j = 0; j < PPL; ++j) c.right_ok[j] = (xl + j + 1 < W);
     c.st_ok = xl >= own_lo && xl < own_hi;
@@ -387,7 +499,8 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     unsigned long long acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0;
-    for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE>(c, X, n0, slot0, acc, std::make_integer_sequence<int, P>{});
+    for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE, JW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+    if (JW && x.budget < 0 && c.lane == 0) g_jw_fault = 1;
     if (MODE == 1 && record) {
         // integer error sums: exact wave reduction of the owned lanes, one device-scope add per wave and level
 #pragma unroll
@@ -400,36 +513,37 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     }
 }
 
-template <int T, int PPL, int WPS, int PF, int MODE>
+template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0>
 static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
-    constexpr int LW = 64 * PPL;
+    constexpr int LW = (JW ? 256 : 64) * PPL;
     constexpr int STRIDE = LW - 2 * M;
     TbArgs A = A0;
     A.nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
     A.swz = tuning().tb_swz == 1 ? 1 : 0;
-    const dim3 grid(A.nstrips, div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
-    constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float);
+    // JW: a workgroup is one band of a 256-column strip; otherwise four consecutive bands of a 64-column strip
+    const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
+    constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) + (JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         return e;
     }();
     MI_HIP_TRY(attr_rc);
     if (tuning().tb_verbose) {
         static const int nb = [] {
             int n = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE>, 256, lds_bytes);
-            fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, lds_bytes, n);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>, 256, lds_bytes);
+            fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d jw=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, JW, lds_bytes, n);
             return n;
         }();
         (void)nb;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE>), grid, dim3(256), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE>), grid, dim3(256), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>), grid, dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>), grid, dim3(256), lds_bytes, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -440,8 +554,11 @@ typedef int (*TbLaunchFn)(const TbArgs &, bool, hipStream_t);
 struct TbrEntry {
     int T, PPL, WPS, PF, PLAN;
     TbLaunchFn launch, spec;
+    int JW;   // 1: joined waves (a workgroup = one band of a 256-column strip)
 };
-#define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr}
+#define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr, 0}
+// joined waves: the hand-over registers cost 14 VGPRs (3 waves/SIMD), rings + hand-over areas 40.7 KB of LDS = 3 workgroups per CU
+static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 1>, nullptr, 1}};
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
@@ -450,14 +567,14 @@ static const TbrEntry g_tbr[] = {
     TBR(10, 2, 2, 2, 2), TBR(8, 1, 4, 2, 2), TBR(6, 2, 3, 2, 3),
 };
 // The speculative steps (MODE 1: T accumulator registers more, hence one wave/SIMD less than MODE 0 at T = 10).
-#define TBRS(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1>}
+#define TBRS(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1>, 0}
 // PLAN = 2: the bands are cut for two waves per SIMD -- fewer, taller bands (less halo) than the fixed-work kernels use; the other
 // lane's kernels fill the rest of the device (r02m at 1080p x 16, class defaults: 517 -> 545 pairs/s; fixed work loses 7 %).
 static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 2), TBRS(5, 1, 4, 2, 2)};
 
 // Exact-math blocks (MODE 2; 1 px per lane).  The stage costs about four times the fast one (three IEEE divisions, two double
 // square roots), so short blocks already move the kernel from the HBM bound of the one-iteration kernel to the issue bound.
-#define TBRX(T, WPS, PLAN) {T, 1, WPS, 2, PLAN, launch_tbr<T, 1, WPS, 2, 2>, nullptr}
+#define TBRX(T, WPS, PLAN) {T, 1, WPS, 2, PLAN, launch_tbr<T, 1, WPS, 2, 2>, nullptr, 0}
 // r02y at 1080p x 16, N = 10: blocks of 2 | 3 | 5 | 10 = 345 | 423 | 532 | 451 pairs/s (one launch per iteration: 228)
 static const TbrEntry g_exact[] = {TBRX(5, 4, 3), TBRX(4, 4, 3), TBRX(3, 5, 4), TBRX(2, 6, 4), TBRX(1, 8, 4)};
 
@@ -465,6 +582,9 @@ static const TbrEntry g_exact[] = {TBRX(5, 4, 3), TBRX(4, 4, 3), TBRX(3, 5, 4), 
 static const TbrEntry *tbr_pick(int T)
 {
     const Tuning &tn = tuning();
+    if (tn.tb_jw && tn.tb_ppl < 0)
+        for (const TbrEntry &e : g_tbr_jw)
+            if (e.T == T) return &e;
     const TbrEntry *def = nullptr;
     for (const TbrEntry &e : g_tbr) {
         if (e.T != T) continue;
@@ -532,14 +652,14 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
     const int T = e.T, ppl = e.PPL, P = T + 1 + e.PF;
     int wps = e.PLAN;
     const int ring_slots = T > 2 ? T - 1 : 1;
-    const int lds_blocks = (160 * 1024) / (ring_slots * 4 * 256 * ppl * 4);
+    const int lds_blocks = (160 * 1024) / (ring_slots * 4 * 256 * ppl * 4 + (e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
     if (wps > lds_blocks) wps = lds_blocks;
     if (tn.tb_plan_wps > 0) wps = tn.tb_plan_wps;
     const long long cap = (long long)device_simds() * wps;
     const int M = (T + ppl - 1) / ppl * ppl;
-    const int LW = 64 * ppl;
+    const int LW = (e.JW ? 256 : 64) * ppl;
     const long long strips = g.w <= LW - M ? 1 : 1 + div_up(g.w - (LW - M), LW - 2 * M);
-    const long long per_band = strips * g.batch;
+    const long long per_band = strips * g.batch * (e.JW ? 4 : 1);   // waves per band row
     long long best_cost = -1;
     int best_nb = 1;
     for (int nb = 1; nb <= g.h; ++nb) {
@@ -548,7 +668,7 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
         // a workgroup is four consecutive bands of a strip and the LDS rings admit four workgroups per CU: with fewer than four
         // bands every workgroup has only nb live waves (the others exit at once, their ring stays allocated), i.e. at most nb
         // waves per SIMD (r02z4: 2 bands at 32 pairs per lane ran 1.3 x slower than 4)
-        const long long cap_nb = nb < 4 && nb < wps ? (long long)device_simds() * nb : cap;
+        const long long cap_nb = !e.JW && nb < 4 && nb < wps ? (long long)device_simds() * nb : cap;
         const long long rounds = (per_band * nb + cap_nb - 1) / cap_nb;
         const long long steps = (long long)div_up(R + 2 * T, P) * P;
         const long long cost = rounds * steps;
@@ -644,6 +764,13 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
     A.e0 = e0;
     A.sk = sk;
     return e->spec(A, p_zero, s);
+}
+
+// sticky fault flag of the joined-wave kernels (0 = no wait ever ran out of its budget); reading clears nothing
+int tb_jw_fault(int *fault_host)
+{
+    MI_HIP_TRY(hipMemcpyFromSymbol(fault_host, HIP_SYMBOL(g_jw_fault), sizeof(int), 0, hipMemcpyDeviceToHost));
+    return MI_OK;
 }
 
 // self-test of the DPP wave-shift semantics the kernels rely on (tests/test_tvl1_gpu.py::test_dpp_wave_shift_semantics)
