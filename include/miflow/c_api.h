@@ -114,6 +114,14 @@ typedef struct mi_tvl1_params {
                           * s > 0 (fast math, epsilon > 0 only): a fused block of iterations is also kept when the test first
                           * passed up to s iterations before the block's end, i.e. up to s iterations MORE than the reference
                           * may run (each of them below the convergence threshold); saves the pass that re-runs the exact count */
+    int host_feedback;   /* convergence-checked fast path (epsilon > 0): the launches of a warp's inner loop are enqueued before the
+                          * device knows where the loop stops (most of the ~34 per warp then end at once, ~3 us each).
+                          * 0 (default) = automatic: a call of at most 2 pairs -- the reference's own calling pattern, one pair per
+                          * calc() -- reads the device's "converged" flags back between launches and stops enqueuing for a warp as
+                          * soon as every pair has stopped: the host waits inside calc() like the reference's own class does at each
+                          * of its convergence checks (cudaoptflow/src/tvl1flow.cpp:362-368), about once per warp; larger batches stay
+                          * fully stream-ordered.  -1 = never (no host wait inside calc()); 1 = for every single-lane call.  Results
+                          * do not depend on it. */
 } mi_tvl1_params;
 
 typedef struct mi_tvl1 mi_tvl1;
@@ -127,7 +135,8 @@ MI_API int mi_tvl1_get_params(const mi_tvl1 *h, mi_tvl1_params *p);
  * cudaoptflow/src/tvl1flow.cpp:170-382 (CPU twin optflow/src/tvl1flow.cpp:402-533,1313-1408).
  * I0,I1: MI_8UC1 or MI_32FC1 (floats in [0,1], scaled x255), same size/type.
  * flow: MI_32FC2, same size; read as the initial flow when use_initial_flow.
- * Fully stream-ordered: the convergence test runs on the device (no host read-back). */
+ * Stream-ordered: the convergence test runs on the device; see mi_tvl1_params.host_feedback for the one case in which calc()
+ * waits for the device (a convergence-checked call of one or two pairs). */
 MI_API int mi_tvl1_calc(mi_tvl1 *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream);
 /* n independent pairs of identical size/type in one pass (blockIdx.z = pair). */
 MI_API int mi_tvl1_calc_batch(mi_tvl1 *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream);

@@ -78,6 +78,13 @@ public:
         miCheck(mi_tvl1_set_params(h_, &q));
         p_ = q;
     }
+    void setHostFeedback(int mode)
+    {
+        mi_tvl1_params q = p_;
+        q.host_feedback = mode;
+        miCheck(mi_tvl1_set_params(h_, &q));
+        p_ = q;
+    }
     const mi_tvl1_params &params() const { return p_; }
     String getDefaultName() const override { return "DenseOpticalFlow.OpticalFlowDual_TVL1"; }   // tvl1flow.cpp:122
 #define MIFLOW_PROP(T, Name, field) \
@@ -137,6 +144,15 @@ inline void setStopSlack(const Ptr<OpticalFlowDual_TVL1> &alg, int slack)
     auto *impl = dynamic_cast<miflow_detail::TVL1Impl *>(alg.get());
     CV_Assert(impl);
     impl->setStopSlack(slack);
+}
+/** mi_tvl1_params.host_feedback: 0 (default) = a convergence-checked calc() of one or two pairs waits for the device about once per
+ *  warp -- as the reference's class does at every convergence check (cudaoptflow/src/tvl1flow.cpp:362-368) -- and stops enqueuing
+ *  launches for a warp that has converged; -1 = never wait inside calc(); 1 = for every single-lane call.  Same flows either way. */
+inline void setHostFeedback(const Ptr<OpticalFlowDual_TVL1> &alg, int mode)
+{
+    auto *impl = dynamic_cast<miflow_detail::TVL1Impl *>(alg.get());
+    CV_Assert(impl);
+    impl->setHostFeedback(mode);
 }
 /** n independent image pairs of identical size and type in one pass (the batched-frames mode of BASELINE configs[4]). */
 inline void calcBatch(const Ptr<OpticalFlowDual_TVL1> &alg, const std::vector<GpuMat> &I0s, const std::vector<GpuMat> &I1s,

@@ -36,7 +36,7 @@ class TVL1Params(C.Structure):
                 ("scale_step", C.c_double), ("gamma", C.c_double), ("nscales", C.c_int), ("warps", C.c_int),
                 ("iterations", C.c_int), ("use_initial_flow", C.c_int), ("inner_iterations", C.c_int),
                 ("median_filtering", C.c_int), ("semantics", C.c_int), ("exact_math", C.c_int),
-                ("time_block", C.c_int), ("lanes", C.c_int), ("stop_slack", C.c_int)]
+                ("time_block", C.c_int), ("lanes", C.c_int), ("stop_slack", C.c_int), ("host_feedback", C.c_int)]
 
 
 class SURFParams(C.Structure):

@@ -51,6 +51,11 @@ struct Lane {
     int ctlB = 0;
     std::vector<SlotInfo> slots;
     int batch = 0;          // pairs of the last calc
+    // host feedback (mi_tvl1_params.host_feedback): pinned landing area of the control slots read back between launches
+    int2 *fb_host = nullptr;
+    int fb_cap = 0;
+    hipEvent_t fb_ev = nullptr;
+    long long fb_waits = 0, fb_skipped = 0;   // of the last calc: host waits, launches not enqueued
     // profiling (mi_tvl1_set_profiling)
     std::vector<hipEvent_t> ev_pool;
     struct Region { int e0, e1; long long launches; double bytes; int kind; int level; };   // kind 0: iteration launches, 1: warp launch; level = pyramid scale
@@ -93,7 +98,7 @@ void mi_tvl1_default_params(mi_tvl1_params *p)
     // fma, iterations fused per HBM pass) by default, which the reference's own test tolerates (CUDA vs CPU |1 - CCORR| <= 4e-3,
     // test_optflow.cpp:465; here <= 1e-4 and mean EPE <= 5e-3 px against the oracle); exact_math = 1 performs the separately
     // rounded IEEE operations of the reference in its order.
-    p->semantics = MI_SEM_CPU_REF; p->exact_math = 0; p->time_block = 0; p->lanes = 0; p->stop_slack = 0;
+    p->semantics = MI_SEM_CPU_REF; p->exact_math = 0; p->time_block = 0; p->lanes = 0; p->stop_slack = 0; p->host_feedback = 0;
 }
 
 // upper bound of control slots per pair (scales x warps x iterations) a convergence-checked calc may enqueue
@@ -114,6 +119,7 @@ static int validate_params(const mi_tvl1_params *p)
                "medianFiltering must be 1 (off), 3 or 5 (cv::medianBlur on CV_32F)");
     MI_REQUIRE(p->lanes >= 0 && p->lanes <= 4, MI_ERR_BAD_ARG, "lanes must be 0 (automatic) or 1..4");
     MI_REQUIRE(p->stop_slack >= 0 && p->stop_slack <= 8, MI_ERR_BAD_ARG, "stop_slack must be in 0..8");
+    MI_REQUIRE(p->host_feedback >= -1 && p->host_feedback <= 1, MI_ERR_BAD_ARG, "host_feedback must be -1, 0 or 1");
     return MI_OK;
 }
 
@@ -226,6 +232,8 @@ void mi_tvl1_destroy(mi_tvl1 *h)
         if (ln.Pd) (void)hipFree(ln.Pd);
         if (ln.X) (void)hipFree(ln.X);
         if (ln.done) (void)hipEventDestroy(ln.done);
+        if (ln.fb_ev) (void)hipEventDestroy(ln.fb_ev);
+        if (ln.fb_host) (void)hipHostFree(ln.fb_host);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (h->fork) (void)hipEventDestroy(h->fork);
@@ -462,6 +470,19 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     int q = 0, q_last = -1;   // device-control slot counters
     int e_next = 0;           // next per-iteration error-sum index (speculative path)
     int q_settle_prev = -1, q_settle_scale = -1;   // settling launches of the previous warp / of the coarser scale's first warp
+    // host feedback: only where the calc is one lane on the caller's stream (a wait inside lane k would hold up the enqueue of lane k+1)
+    const bool fb = spec && h->last_lanes == 1 && P.host_feedback >= 0 && (P.host_feedback == 1 || B <= 2);
+    int fb_prev_warp = 2, fb_prev_scale = 2;   // launch index at which the previous warp / the coarser scale's first warp was found stopped
+    ln.fb_waits = ln.fb_skipped = 0;
+    if (fb) {
+        if (ln.fb_cap < B) {
+            if (ln.fb_host) (void)hipHostFree(ln.fb_host);
+            ln.fb_host = nullptr; ln.fb_cap = 0;
+            MI_HIP_TRY(hipHostMalloc((void **)&ln.fb_host, 2 * sizeof(int2) * (size_t)B, hipHostMallocDefault));
+            ln.fb_cap = B;
+        }
+        if (!ln.fb_ev) MI_HIP_TRY(hipEventCreateWithFlags(&ln.fb_ev, hipEventDisableTiming));
+    }
     int cur = 0;              // host-known buffer set (fixed-work mode)
     Ctl ctl;
     memset(&ctl, 0, sizeof(ctl));
@@ -569,6 +590,14 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     for (int j = 0; j < 4; ++j) MI_HIP_TRY(hipMemsetAsync(ln.pbuf[0][j], 0, sizeof(float) * (size_t)g.ps * B, st));
                 }
                 int e_prev = 0;
+                // Host feedback (mi_tvl1_params.host_feedback): a call of one or two pairs reads the pairs' control slots back
+                // between launches and stops enqueuing for this warp once every pair's slot says DONE -- the state is then settled
+                // (a replay, if one was due, ran inside the launch that wrote the flag) and the slot is the one the following kernels
+                // look at.  First read-back where the previous warp of this scale stopped (the first warp: where the coarser scale's
+                // first warp did), then after every second launch.  The host waits like the reference's class does at each of its
+                // checks (cudaoptflow/src/tvl1flow.cpp:362-368); the flows do not depend on any of it.
+                int fb_next = fb ? std::max(1, wp > 0 ? fb_prev_warp : fb_prev_scale) : -1;
+                int fb_done_at = (int)plan.size();
                 for (size_t k = 0; k <= plan.size(); ++k) {
                     const bool last = k == plan.size();
                     const int T = last ? plan.back() : plan[k];
@@ -583,6 +612,29 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     ++nlaunch;
                     e_prev = e_next;
                     if (!last) e_next += T;
+                    if (fb && !last && (int)k == fb_next) {
+                        // the slots of this launch and of the one before it (k >= 1), per pair
+                        MI_HIP_TRY(hipMemcpy2DAsync(ln.fb_host, 2 * sizeof(int2), ln.S + (q_last - 1), sizeof(int2) * (size_t)ln.Q, 2 * sizeof(int2),
+                                                    (size_t)B, hipMemcpyDeviceToHost, st));
+                        MI_HIP_TRY(hipEventRecord(ln.fb_ev, st));
+                        MI_HIP_TRY(hipEventSynchronize(ln.fb_ev));
+                        ++ln.fb_waits;
+                        bool all = true, all_before = true;
+                        for (int b = 0; b < B; ++b) {
+                            all_before = all_before && (ln.fb_host[2 * b].y & MI_SLOT_DONE);
+                            all = all && (ln.fb_host[2 * b + 1].y & MI_SLOT_DONE);
+                        }
+                        if (all) {
+                            ln.fb_skipped += (long long)plan.size() - (long long)k;
+                            fb_done_at = all_before ? (int)k - 1 : (int)k;   // where the next warp's first read-back goes
+                            break;
+                        }
+                        fb_next = (int)k + 2;
+                    }
+                }
+                if (fb) {
+                    fb_prev_warp = fb_done_at;
+                    if (wp == 0) fb_prev_scale = fb_done_at;
                 }
                 q_settle_prev = q_last;
                 if (wp == 0) q_settle_scale = q_last;

@@ -31,6 +31,14 @@ struct Ctl {
     int n;           // iteration index inside the warp
 };
 
+// (host code reads the flags too: mi_tvl1_last_iterations, the host feedback of tvl1_api.cpp)
+// flags of a control slot (S[..].y): bit 0 = the launch moved the state to the other buffer set, bit 1 = it summed the
+// error (one-iteration launches), bit 2 = the warp has converged, bits 8..15 = iterations this launch contributed
+#define MI_SLOT_FLIP 1
+#define MI_SLOT_CHECKED 2
+#define MI_SLOT_DONE 4
+#define MI_SLOT_ITERS(y) (((y) >> 8) & 0xff)
+
 struct PtrTab {          // per-pair external image pointers (device array)
     const void *a, *b;   // I0, I1 (convert) or unused
     void *out;           // flow (pack)

@@ -50,12 +50,6 @@ struct TbArgs {
     SpecK sk;
 };
 
-// flags of a control slot (S[..].y): bit 0 = the launch moved the state to the other buffer set, bit 1 = it summed the
-// error (one-iteration launches), bit 2 = the warp has converged, bits 8..15 = iterations this launch contributed
-#define MI_SLOT_FLIP 1
-#define MI_SLOT_CHECKED 2
-#define MI_SLOT_DONE 4
-#define MI_SLOT_ITERS(y) (((y) >> 8) & 0xff)
 #define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */
 
 // One SPECULATIVE STEP of the convergence-checked path (epsilon > 0), shared by the streaming kernel (k_iterate_tbr MODE 1) and the

@@ -242,7 +242,7 @@ struct Xchg {
 };
 __device__ __forceinline__ void xread(unsigned slot, unsigned &tag, float &l1, float &l2, float &r1, float &r2)
 {
-    const lds_ptr q = (lds_ptr)slot;
+    const lds_ptr q = (lds_ptr)(unsigned long long)slot;
     tag = *reinterpret_cast<volatile MI_LDS unsigned *>(q + 16);          // the tag first: data is written before its tag
     const unsigned long long L = *reinterpret_cast<volatile MI_LDS unsigned long long *>(q);
     const unsigned long long R = *reinterpret_cast<volatile MI_LDS unsigned long long *>(q + 8);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void xread(unsigned slot, unsigned &tag, float &l1, f
 // two dwords, then the 16-bit tag
 __device__ __forceinline__ void xwrite(unsigned slot, int data_off, int tag_off, float a, float b, unsigned tag)
 {
-    const lds_ptr q = (lds_ptr)slot;
+    const lds_ptr q = (lds_ptr)(unsigned long long)slot;
     *reinterpret_cast<volatile MI_LDS float *>(q + data_off) = a;
     *reinterpret_cast<volatile MI_LDS float *>(q + data_off + 4) = b;
     *reinterpret_cast<volatile MI_LDS unsigned short *>(q + tag_off) = (unsigned short)tag;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
         // zero data, tags 0; buffer 0 of step 0 expects "step -1" of the right neighbour: all-zero u (the initial held state)
         for (int i = c.lane; i < XA / 4; i += 64) {
             const int w4 = i % (XS / 4), buf = i / (T * XS / 4);
-            reinterpret_cast<volatile MI_LDS unsigned *>((lds_ptr)x.own)[i] = (w4 == 4 && buf == 0 && has_right) ? 0x10000u : 0u;
+            reinterpret_cast<volatile MI_LDS unsigned *>((lds_ptr)(unsigned long long)x.own)[i] = (w4 == 4 && buf == 0 && has_right) ? 0x10000u : 0u;
         }
         __syncthreads();
         if (xw >= W) return;

@@ -48,7 +48,7 @@ class OpticalFlowDual_TVL1:
     @staticmethod
     def create(tau=0.25, lambda_=0.15, theta=0.3, nscales=5, warps=5, epsilon=0.01, iterations=300,
                scaleStep=0.8, gamma=0.0, useInitialFlow=False, *, semantics=None, exactMath=None, innerIterations=1,
-               medianFiltering=1, timeBlock=0, lanes=0, stopSlack=0) -> "OpticalFlowDual_TVL1":
+               medianFiltering=1, timeBlock=0, lanes=0, stopSlack=0, hostFeedback=0) -> "OpticalFlowDual_TVL1":
         """The keyword-only arguments are miflow extensions; None = the library default (mi_tvl1_default_params):
         semantics MI_SEM_CPU_REF (the arithmetic of the CPU class, the acceptance reference; MI_SEM_CUDA_COMPAT = cv::cuda's
         own kernels, ~0.1 px mean EPE away, mostly at borders), fast device math (exactMath=True: IEEE operations in the
@@ -65,6 +65,7 @@ class OpticalFlowDual_TVL1:
             p.exact_math = int(bool(exactMath))
         p.inner_iterations, p.median_filtering, p.time_block, p.lanes = innerIterations, medianFiltering, timeBlock, lanes
         p.stop_slack = stopSlack
+        p.host_feedback = hostFeedback   # 0 automatic (a call of <= 2 pairs reads the converged flags back between launches), -1 never, 1 every single-lane call
         return OpticalFlowDual_TVL1(p)
 
     def __del__(self):

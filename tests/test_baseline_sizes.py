@@ -297,6 +297,34 @@ def test_class_defaults_speculative_convergence(gpu, oracle, sem, shape, seed):
     np.testing.assert_array_equal(flow, flow2)
 
 
+@pytest.mark.parametrize("iters,eps", [(300, 0.01), (10, 0.01), (23, 0.05)])
+def test_host_feedback_never_changes_a_flow(gpu, iters, eps):
+    """mi_tvl1_params.host_feedback (round 3): a convergence-checked calc of one or two pairs reads the converged flags back between
+    launches and stops enqueuing for a warp that has stopped (the host waits inside calc() about once per warp, as the reference's
+    class does at each of its checks, cudaoptflow/src/tvl1flow.cpp:362-368).  Which launches were enqueued must not show: flows and
+    per-(scale, warp) iteration counts with feedback off (-1), automatic (0) and forced (1, also for a 3-pair single-lane batch) are
+    identical, singles equal the batch, and repeated calls of one handle (warm predictions) reproduce."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(240, 320, seed=90 + k)[:2] for k in range(3)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    algs = {fb: cuda.OpticalFlowDual_TVL1.create(iterations=iters, epsilon=eps, hostFeedback=fb, lanes=1) for fb in (-1, 0, 1)}
+    ref = algs[-1].calc_batch(I0s, I1s)
+    torch.cuda.synchronize()
+    counts = [algs[-1].lastIterations(k) for k in range(3)]
+    f1 = algs[1].calc_batch(I0s, I1s)                      # forced: three pairs, one lane
+    assert torch.equal(f1, ref) and [algs[1].lastIterations(k) for k in range(3)] == counts
+    for rep in range(2):
+        for k in range(3):
+            for fb in (0, 1, -1):
+                f = algs[fb].calc(I0s[k], I1s[k])
+                assert torch.equal(f, ref[k]), (rep, k, fb)
+                assert algs[fb].lastIterations(0) == counts[k]
+    f2 = algs[0].calc_batch(I0s[:2], I1s[:2])              # automatic: two pairs
+    assert torch.equal(f2, ref[:2])
+    assert np.array(counts).max() <= iters and (iters < 300 or np.array(counts).max() < 300)
+
+
 @pytest.mark.parametrize("iters", [1, 2, 3, 5, 7, 12, 23])
 @pytest.mark.parametrize("shape", [(16, 16), (21, 37), (64, 9), (5, 300), (97, 131)])
 def test_speculative_steps_iteration_limits_and_small_images(gpu, oracle, shape, iters):
