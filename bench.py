@@ -564,8 +564,38 @@ def bench_surf(args):
                         "frac": algo * args.steps * n / el_det / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("surf_det_trace")[0],
                         "traffic_kernel": "k_det_trace, bytes per launch (one octave of one frame, mean over the octaves)",
                         "traffic_source": pmc_traffic("surf_det_trace")[1],
-                        "note": "detector stage only; the Haar box sums are gather/latency bound (40 integral taps per sample per "
-                                "layer from a 33 MB L2/MALL-resident table), not HBM-bound (SURVEY 8d config 4)"}}
+                        "note": "detector stage only; round 3: 32 shared-corner taps per sample with wave-uniform offsets, box sums in u32, "
+                                "division by the box area as reciprocal + one fma correction (exact), XCD-contiguous band order; the row "
+                                "scan of the non-maximum suppression split over 8 waves per 4K row (profiles/r03k: k_det_trace 159 -> 99 us, "
+                                "k_nms_flag 91 -> 54 us per octave launch).  Not HBM-bound (SURVEY 8d config 4): the integral table "
+                                "(33 MB) is L2 / MALL resident; what is left is the f64 arithmetic of the box sums and ~24 small launches "
+                                "per frame"}}
+    # the descriptor half of a frame (k_orientation + k_descriptors on the keypoints just found): its bound is the gather, not HBM and
+    # not VALU (r03l: halving the per-texel arithmetic changed nothing) -- a patch sample of a feature of scale s reads ~s x s texels
+    # of the ROTATED window, the 64 lanes of a wave sit in 64 different cells of the 21 x 21 patch, so every wave-level byte load
+    # touches 64 different 64-B lines: one line per clock and CU through the vector L1
+    try:
+        kd = cuda.SURF_CUDA.downloadKeypoints(kp)
+        sc = np.maximum(np.asarray(kd["size"], np.float64) * 1.2 / 9.0, 1.0)
+        texels = float((441.0 * (sc * sc + 2.0 * sc)).sum())      # s x s interior texels + the fractional border rows / columns of a cell
+        for _ in range(2):
+            alg.detectWithDescriptors(t, keypoints=kp, useProvidedKeypoints=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps * n):
+            alg.detectWithDescriptors(t, keypoints=kp, useProvidedKeypoints=True)
+        torch.cuda.synchronize()
+        el_desc = (time.perf_counter() - t0) / (args.steps * n)
+        peak_lines = 256 * 2.4e9
+        out["descriptor_roofline"] = {"bound": "l1_gather_lines", "kernel": "k_descriptors (+ k_orientation, integral): orientation and 64-d "
+                                      "descriptors of the frame's keypoints (useProvidedKeypoints)",
+                                      "achieved": texels / el_desc / 1e9, "peak": peak_lines / 1e9, "unit": "G lines/s",
+                                      "frac": texels / el_desc / peak_lines, "texel_reads_per_frame": texels, "ms_per_frame": 1e3 * el_desc,
+                                      "note": "achieved = rotated-window texel reads (441 cells x (s^2 + 2 s) per feature, s = size x 1.2 / 9) "
+                                              "per second, each a different 64-B line per lane; peak = one line per clock and CU (64 B/clk "
+                                              "vector L1, MI355X_MICROARCH.md)"}
+    except Exception as e:
+        out["descriptor_roofline"] = {"error": repr(e)[:200]}
     # two handles on two streams, frames alternating: distinct handles share nothing (the reference serialises every SURF_CUDA call
     # process-wide with a static mutex, surf.cuda.cpp:117,371,383), so one frame's descriptor kernel overlaps the next frame's detector
     try:

@@ -18,7 +18,7 @@ struct mi_surf {
     unsigned *sum = nullptr, *msum = nullptr, *V = nullptr, *BT = nullptr;
     float *det = nullptr, *trace = nullptr;
     unsigned long long *bits = nullptr;
-    unsigned *rowcnt = nullptr;
+    unsigned *rowcnt = nullptr, *segcnt = nullptr;
     int4 *cand = nullptr;
     void *itmp = nullptr;   // per-candidate interpolation results
     unsigned *counters = nullptr;   // [0] = features, [1 + octave] = candidates of the octave (surf.cuda.cpp:158-159)
@@ -84,9 +84,9 @@ int mi_surf_get_params(const mi_surf *h, mi_surf_params *p) { MI_REQUIRE(h && p,
 
 static void free_scratch(mi_surf *h)
 {
-    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->rowcnt, h->cand, h->itmp};
+    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->rowcnt, h->segcnt, h->cand, h->itmp};
     for (void *p : ps) if (p) (void)hipFree(p);
-    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->rowcnt = nullptr; h->cand = nullptr; h->itmp = nullptr;
+    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->rowcnt = nullptr; h->segcnt = nullptr; h->cand = nullptr; h->itmp = nullptr;
     h->capR = h->capC = h->capL = h->capCand = 0;
 }
 
@@ -142,6 +142,7 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
         MI_HIP_TRY(hipMalloc((void **)&h->trace, sizeof(float) * (size_t)h->dld * rows * (layers + 2)));
         MI_HIP_TRY(hipMalloc((void **)&h->bits, sizeof(unsigned long long) * (size_t)layers * rows * div_up(cols, 64)));
         MI_HIP_TRY(hipMalloc((void **)&h->rowcnt, sizeof(unsigned) * ((size_t)layers * rows + 1)));
+        MI_HIP_TRY(hipMalloc((void **)&h->segcnt, sizeof(unsigned) * (size_t)layers * rows * surf::nms_segments(cols)));
         MI_HIP_TRY(hipMalloc((void **)&h->cand, sizeof(int4) * (size_t)maxCand));
         MI_HIP_TRY(hipMalloc(&h->itmp, surf::interp_tmp_bytes(maxCand)));
         h->capR = rows; h->capC = cols; h->capL = layers; h->capCand = maxCand;
@@ -192,7 +193,7 @@ int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *ke
     for (int octave = 0; octave < P.n_octaves; ++octave) {                                                           // :182-204
         if ((rc = surf::det_trace(h->sum, h->sld, rows, cols, octave, P.n_octave_layers, h->det, h->trace, h->dld, st))) return rc;
         if ((rc = surf::find_maxima(h->det, h->trace, h->dld, use_mask ? h->msum : nullptr, h->sld, rows, cols, octave, P.n_octave_layers,
-                                    (float)P.hessian_threshold, h->bits, h->rowcnt, h->cand, maxC, h->counters + 1 + octave, st))) return rc;
+                                    (float)P.hessian_threshold, h->bits, h->rowcnt, h->segcnt, h->cand, maxC, h->counters + 1 + octave, st))) return rc;
         if ((rc = surf::interpolate(h->det, h->dld, rows, cols, octave, h->cand, h->counters + 1 + octave, maxC, h->itmp, kp, kld, maxF, h->counters, st))) return rc;
     }
     if ((rc = surf::orientation(h->sum, h->sld, rows, cols, kp, kld, h->counters, maxF, P.upright != 0, h->apt, st))) return rc;   // :211-214

@@ -13,8 +13,9 @@ int det_trace(const unsigned *sum, int sld, int rows, int cols, int octave, int 
               hipStream_t s);
 // bits: nOctaveLayers*layer_rows*ceil(layer_cols/64) u64; rowcnt: nOctaveLayers*layer_rows + 1 u32
 int find_maxima(const float *det, const float *trace, int dld, const unsigned *mask_sum, int sld, int rows, int cols, int octave,
-                int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, int4 *cand, int max_candidates,
+                int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
                 unsigned *ncand, hipStream_t s);
+int nms_segments(int cols);   // row segments k_nms_flag cuts a row of `cols` samples into (segcnt: layers x rows x segments)
 // tmp: interp_tmp_bytes(max_candidates) bytes of scratch
 int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, int max_candidates,
                 void *tmp, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s);

@@ -123,25 +123,105 @@ __device__ __forceinline__ float haar(const SumTex &t, const float (&src)[N][5],
 
 // surf.cu:175-203.  Grid covers the whole layer region; samples outside the valid window are written as 0
 // (the reference leaves them unwritten = stale memory).
-__global__ __launch_bounds__(256) void k_det_trace(SumTex t, float *det, float *trace, int dld, int octave, int nlayers2)
+//
+// Round 3 formulation (the round-2 kernel was the reference's shape -- 40 clamped taps and ten double-precision
+// divisions per sample, ~700 VALU slots per sample, and that arithmetic, not the gathers, was its time):
+//   * a VALID sample never needs the clamp of the reference's texture fetch: its filter lies inside the image by the definition of
+//     samples_i / samples_j, so every tap address is base(sample) + a wave-uniform offset -- one 32-bit lane offset per sample,
+//     the tap's offset rides the scalar base of the load (`global_load_dword v, voff, s[base]`): no address arithmetic per tap;
+//   * the ten boxes share corners: Dxx and Dyy are three boxes on a 4 x 2 / 2 x 4 corner grid, Dxy four boxes on a 4 x 4 grid:
+//     32 distinct taps instead of 40;
+//   * a box sum is formed in u32 (exact: the reference adds the same four integers, each < 2^32, in double, which is exact too),
+//     converted once, and divided by its area as q = a y, q += fma(-q, b, a) y with y = RN(1 / b): for integer |a| < 2^35 and
+//     integer b < 2^24 this is the correctly rounded quotient a / b -- the value the reference's division gives -- checked on
+//     4.1e8 cases incl. every area that can occur (tests/test_surf.py::test_box_division_by_reciprocal_is_exact);
+//   * workgroups walk the layer in XCD-contiguous row bands (the eight L2s each keep their own rows of the integral table, all
+//     layers of an octave back to back) -- profiles/r02u counted 3.2 x the table in FETCH_SIZE with the plain order.
+// det / trace planes stay bit-identical to the oracle (hence to surf.cl / surf.cu).
+struct HaarGeo {       // per layer: tap offsets (elements, relative to the sample's top-left corner) and 1 / area, area of the 10 boxes
+    int xx[4][2];      // Dxx corners [x edge 0..3][y edge 0..1]
+    int yy[2][4];      // Dyy corners [x edge 0..1][y edge 0..3]
+    int xy[4][4];      // Dxy corners [y edge][x edge]
+    double ry[10], area[10];   // boxes: Dxx 0..2, Dyy 3..5, Dxy 6..9
+};
+// host side (the geometry of a layer does not depend on the sample): rintf = round-half-even = __float2int_rn of the device code
+static HaarGeo haar_geo(int size, int sld)
 {
-    const float c_DX[3][5] = {{0, 2, 3, 7, 1}, {3, 2, 6, 7, -2}, {6, 2, 9, 7, 1}};      // surf.cu:157-159
-    const float c_DY[3][5] = {{2, 0, 7, 3, 1}, {2, 3, 7, 6, -2}, {2, 6, 7, 9, 1}};
-    const float c_DXY[4][5] = {{1, 1, 4, 4, 1}, {5, 1, 8, 4, -1}, {1, 5, 4, 8, -1}, {5, 5, 8, 8, 1}};
+    HaarGeo g;
+    const float ratio = (float)size / 9;
+    const auto rnh = [](float v) { return (int)rintf(v); };
+    const int e0369[4] = {rnh(ratio * 0.f), rnh(ratio * 3.f), rnh(ratio * 6.f), rnh(ratio * 9.f)};
+    const int e27[2] = {rnh(ratio * 2.f), rnh(ratio * 7.f)};
+    const int e1458[4] = {rnh(ratio * 1.f), rnh(ratio * 4.f), rnh(ratio * 5.f), rnh(ratio * 8.f)};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) { g.xx[i][j] = e27[j] * sld + e0369[i]; g.yy[j][i] = e0369[i] * sld + e27[j]; }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) g.xy[i][j] = e1458[i] * sld + e1458[j];
+    for (int k = 0; k < 3; ++k) {
+        g.area[k] = (double)((e0369[k + 1] - e0369[k]) * (e27[1] - e27[0]));
+        g.area[3 + k] = g.area[k];   // Dyy is Dxx transposed: the same edge differences
+    }
+    g.area[6] = (double)((e1458[1] - e1458[0]) * (e1458[1] - e1458[0]));
+    g.area[7] = (double)((e1458[3] - e1458[2]) * (e1458[1] - e1458[0]));
+    g.area[8] = g.area[7];
+    g.area[9] = (double)((e1458[3] - e1458[2]) * (e1458[3] - e1458[2]));
+    for (int k = 0; k < 10; ++k) g.ry[k] = 1.0 / g.area[k];
+    return g;
+}
+constexpr int kDetLayers = 6;   // layers of one launch (nOctaveLayers + 2 <= 6; more layers: several launches)
+struct HaarGeoSet { HaarGeo l[kDetLayers]; };
+// (tt * w) / area, correctly rounded (w = +-1, +-2: the product is exact)
+__device__ __forceinline__ double box_div(unsigned tt, double w, double area, double ry)
+{
+    const double a = (double)tt * w;
+    const double q = a * ry;
+    return fma(fma(-q, area, a), ry, q);
+}
+__global__ __launch_bounds__(256) void k_det_trace(SumTex t, float *det, float *trace, int dld, int octave, int layer0, int nlayers2, int nbx, int nby, HaarGeoSet G)
+{
+    // XCD-contiguous order: workgroup id -> XCD id % 8 (MI355X_MICROARCH.md); each XCD takes a contiguous run of row bands, and inside
+    // it the layers of a band follow each other
+    const unsigned nwg = nbx * nby * nlayers2, orig = blockIdx.x;
+    const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
+    const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int bx = lid % nbx, ll = (lid / nbx) % nlayers2, by = lid / (nbx * nlayers2), layer = layer0 + ll;
     const int layer_rows = t.rows >> octave, layer_cols = t.cols >> octave;
-    const int jj = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ii = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int layer = blockIdx.z;
-    if (jj >= layer_cols || ii >= layer_rows || layer >= nlayers2) return;
+    const int jj = bx * 64 + (threadIdx.x & 63);
+    const int ii = by * 4 + (threadIdx.x >> 6);
+    if (jj >= layer_cols || ii >= layer_rows) return;
     const int size = calc_size(octave, layer);
     const int samples_i = 1 + ((t.rows - size) >> octave), samples_j = 1 + ((t.cols - size) >> octave);
     const int margin = (size >> 1) >> octave;
     const int i = ii - margin, j = jj - margin;
     float d = 0.f, tr = 0.f;
     if (size <= t.rows && size <= t.cols && i >= 0 && j >= 0 && i < samples_i && j < samples_j) {
-        const float dx = haar<3>(t, c_DX, 9, size, i << octave, j << octave);
-        const float dy = haar<3>(t, c_DY, 9, size, i << octave, j << octave);
-        const float dxy = haar<4>(t, c_DXY, 9, size, i << octave, j << octave);
+        const HaarGeo &g = G.l[ll];   // kernel argument: scalar registers
+        unsigned voff = 4u * ((unsigned)(i << octave) * (unsigned)t.sld + (unsigned)(j << octave));
+        asm volatile("" : "+v"(voff));             // keep the lane offset a 32-bit VGPR: tap offsets stay on the scalar base
+        const auto T = [&](int o) { return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(t.s + o) + voff); };
+        // the reference's order (surf.cu:133-150): per box +(y1,x1) -(y2,x1) -(y1,x2) +(y2,x2); d accumulates box by box in double
+        unsigned cxx[4][2], cyy[2][4], cxy[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { cxx[a][b] = T(g.xx[a][b]); cyy[b][a] = T(g.yy[b][a]); }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) cxy[a][b] = T(g.xy[a][b]);
+        const double wxx[3] = {1.0, -2.0, 1.0};
+        double sx = 0, sy = 0, sxy = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            sx += box_div(cxx[k][0] - cxx[k][1] - cxx[k + 1][0] + cxx[k + 1][1], wxx[k], g.area[k], g.ry[k]);
+            sy += box_div(cyy[0][k] - cyy[0][k + 1] - cyy[1][k] + cyy[1][k + 1], wxx[k], g.area[3 + k], g.ry[3 + k]);
+        }
+        // c_DXY (surf.cu:159): {1,1,4,4,+1}, {5,1,8,4,-1}, {1,5,4,8,-1}, {5,5,8,8,+1}  (x1, y1, x2, y2, w); cxy[y edge][x edge]
+        sxy += box_div(cxy[0][0] - cxy[1][0] - cxy[0][1] + cxy[1][1], 1.0, g.area[6], g.ry[6]);
+        sxy += box_div(cxy[0][2] - cxy[1][2] - cxy[0][3] + cxy[1][3], -1.0, g.area[7], g.ry[7]);
+        sxy += box_div(cxy[2][0] - cxy[3][0] - cxy[2][1] + cxy[3][1], -1.0, g.area[8], g.ry[8]);
+        sxy += box_div(cxy[2][2] - cxy[3][2] - cxy[2][3] + cxy[3][3], 1.0, g.area[9], g.ry[9]);
+        const float dx = (float)sx, dy = (float)sy, dxy = (float)sxy;
         d = dx * dy - 0.81f * dxy * dxy;
         tr = dx + dy;
     }
@@ -171,14 +251,19 @@ struct NmsArgs {
     float thr;
     SumTex mask;                            // mask.s == nullptr: no mask
     unsigned long long *bits;               // [nlayers][layer_rows][chunks] ballot of the maxima
-    unsigned *rowcnt;                       // [nlayers * layer_rows (+1)]  counts, then exclusive offsets
-    int chunks;
+    unsigned *rowcnt;                       // [nlayers * layer_rows (+1)]  exclusive offsets of the rows (k_scan_counts), total at the end
+    unsigned *segcnt;                       // [nlayers * layer_rows][nseg]  maxima per row segment (k_nms_flag)
+    int chunks, nseg;                       // 64-sample chunks per row; row segments of kNmsSeg chunks
 };
 
-// surf.cu:263-355: one wave per (layer, row); flags per 64-column chunk
+// surf.cu:263-355: one wave per (layer, row); flags per 64-column chunk.  The centre values of four chunks are loaded together (the
+// round-2 loop issued one load per chunk and waited for it: 60 dependent round trips per 4K row, 176 us per octave-0 launch for
+// 66 MB); a chunk without a value above the threshold -- nearly all -- costs nothing more.
+constexpr int kNmsSeg = 8;   // chunks of one wave: a 4K row is 8 waves (one wave per row left the loop at 60 dependent round trips)
 __global__ __launch_bounds__(256) void k_nms_flag(NmsArgs A)
 {
     const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.y, cbeg = seg * kNmsSeg, cend = min(cbeg + kNmsSeg, A.chunks);
     const int layer_rows = A.rows >> A.octave, layer_cols = A.cols >> A.octave;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= A.nlayers * layer_rows) return;
@@ -187,42 +272,57 @@ __global__ __launch_bounds__(256) void k_nms_flag(NmsArgs A)
     const int margin = ((calc_size(A.octave, layer + 1) >> 1) >> A.octave) + 1;
     unsigned cnt = 0;
     const bool row_ok = i >= margin && i < layer_rows - margin;
-    for (int c = 0; c < A.chunks; ++c) {
-        const int j = c * 64 + lane;
-        bool ismax = false;
-        if (row_ok && j >= margin && j < layer_cols - margin) {
 #define DET(l, ii, jj) A.det[(long long)((l) * layer_rows + clampi(ii, 0, A.rows - 1)) * A.dld + clampi(jj, 0, A.cols - 1)]
-            const float v = DET(layer, i, j);
-            if (v > A.thr) {
+    constexpr int CB = 4;
+    for (int c0 = cbeg; c0 < cend; c0 += CB) {
+        float v[CB];
+        bool in[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int j = (c0 + k) * 64 + lane;
+            in[k] = row_ok && c0 + k < cend && j >= margin && j < layer_cols - margin;
+            v[k] = in[k] ? DET(layer, i, j) : -FLT_MAX;
+        }
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            if (c0 + k >= cend) break;
+            const int j = (c0 + k) * 64 + lane;
+            bool ismax = false;
+            if (in[k] && v[k] > A.thr) {
                 const int sum_i = (i - ((size >> 1) >> A.octave)) << A.octave, sum_j = (j - ((size >> 1) >> A.octave)) << A.octave;
                 if (!A.mask.s || mask_check(A.mask, sum_i, sum_j, size)) {
+                    // 26 neighbours: margin >= 1 and 1 <= layer <= nlayers keep all of them inside the planes, so the nine rows
+                    // are nine pointers and the columns j - 1, j, j + 1 immediate offsets (the round-2 form clamped and rebuilt
+                    // a 64-bit address per neighbour: ~300 VALU per chunk that holds a single value above the threshold)
+                    const float *ctr = A.det + (long long)(layer * layer_rows + i) * A.dld + j;
                     ismax = true;
 #pragma unroll
                     for (int dl = -1; dl <= 1; ++dl)
 #pragma unroll
-                        for (int di = -1; di <= 1; ++di)
-#pragma unroll
-                            for (int dj = -1; dj <= 1; ++dj)
-                                if (dl || di || dj) ismax = ismax && (v > DET(layer + dl, i + di, j + dj));
+                        for (int di = -1; di <= 1; ++di) {
+                            const float *q = ctr + (long long)(dl * layer_rows + di) * A.dld;
+                            ismax = ismax && v[k] > q[-1] && v[k] > q[1] && ((dl == 0 && di == 0) || v[k] > q[0]);
+                        }
                 }
             }
-#undef DET
+            const unsigned long long m = __ballot(ismax);
+            if (lane == 0) A.bits[(long long)r * A.chunks + c0 + k] = m;
+            cnt += __popcll(m);
         }
-        const unsigned long long m = __ballot(ismax);
-        if (lane == 0) A.bits[(long long)r * A.chunks + c] = m;
-        cnt += __popcll(m);
     }
-    if (lane == 0) A.rowcnt[r] = cnt;
+#undef DET
+    if (lane == 0) A.segcnt[(long long)r * A.nseg + seg] = cnt;
 }
 
 // exclusive scan of n (<= 1024 * per) counts by ONE block; total -> cnt[n]
-__global__ __launch_bounds__(1024) void k_scan_counts(unsigned *cnt, int n)
+__global__ __launch_bounds__(1024) void k_scan_counts(unsigned *cnt, const unsigned *seg, int nseg, int n)
 {
     __shared__ unsigned part[1024];
     const int per = (n + 1023) / 1024;
     const int b = threadIdx.x * per, e = min(b + per, n);
+    const auto row_total = [&](int k) { unsigned c = 0; for (int q = 0; q < nseg; ++q) c += seg[(long long)k * nseg + q]; return c; };
     unsigned s = 0;
-    for (int k = b; k < e; ++k) s += cnt[k];
+    for (int k = b; k < e; ++k) s += row_total(k);
     part[threadIdx.x] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -232,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(unsigned *cnt, int n)
         __syncthreads();
     }
     unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
-    for (int k = b; k < e; ++k) { const unsigned c = cnt[k]; cnt[k] = run; run += c; }
+    for (int k = b; k < e; ++k) { const unsigned c = row_total(k); cnt[k] = run; run += c; }
     if (threadIdx.x == 1023) cnt[n] = part[1023];
 }
 
@@ -611,14 +711,21 @@ int det_trace(const unsigned *sum, int sld, int rows, int cols, int octave, int 
 {
     SumTex t = {sum, sld, rows, cols};
     const int lr = rows >> octave, lc = cols >> octave;
-    hipLaunchKernelGGL(k_det_trace, dim3(div_up(lc, 64), div_up(lr, 4), nOctaveLayers + 2), dim3(256), 0, s, t, det, trace, dld, octave,
-                       nOctaveLayers + 2);
+    const int nbx = div_up(lc, 64), nby = div_up(lr, 4);
+    for (int l0 = 0; l0 < nOctaveLayers + 2; l0 += kDetLayers) {
+        const int nl = std::min(kDetLayers, nOctaveLayers + 2 - l0);
+        HaarGeoSet G;
+        memset(&G, 0, sizeof(G));
+        for (int l = 0; l < nl; ++l) G.l[l] = haar_geo(calc_size(octave, l0 + l), sld);
+        hipLaunchKernelGGL(k_det_trace, dim3(nbx * nby * nl), dim3(256), 0, s, t, det, trace, dld, octave, l0, nl, nbx, nby, G);
+    }
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
+int nms_segments(int cols) { return div_up(div_up(cols, 64), kNmsSeg); }
 int find_maxima(const float *det, const float *trace, int dld, const unsigned *mask_sum, int sld, int rows, int cols, int octave,
-                int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, int4 *cand, int max_candidates,
+                int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
                 unsigned *ncand, hipStream_t s)
 {
     NmsArgs A;
@@ -627,9 +734,10 @@ int find_maxima(const float *det, const float *trace, int dld, const unsigned *m
     A.bits = bits; A.rowcnt = rowcnt;
     const int lr = rows >> octave, lc = cols >> octave;
     A.chunks = div_up(lc, 64);
+    A.segcnt = segcnt; A.nseg = div_up(A.chunks, kNmsSeg);
     const int nrows = nOctaveLayers * lr;
-    hipLaunchKernelGGL(k_nms_flag, dim3(div_up(nrows, 4)), dim3(256), 0, s, A);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, rowcnt, nrows);
+    hipLaunchKernelGGL(k_nms_flag, dim3(div_up(nrows, 4), A.nseg), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, rowcnt, (const unsigned *)segcnt, A.nseg, nrows);
     hipLaunchKernelGGL(k_nms_write, dim3(div_up(nrows, 4)), dim3(256), 0, s, A, cand, max_candidates, ncand);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

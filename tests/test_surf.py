@@ -236,3 +236,55 @@ def test_random_configuration_matches_oracle(gpu, oracle, cfg):
         return
     kpg, desc = alg.detectWithDescriptors(T(img, gpu))
     _compare(cuda.SURF_CUDA.downloadKeypoints(kpg), N(desc), ref)
+
+
+def test_box_division_by_reciprocal_is_exact(tmp_path):
+    """k_det_trace (round 3) divides a box sum by its area as q = a y, q += fma(-q, b, a) y with y = RN(1 / b) instead of a / b.  For
+    the integers that occur -- |a| = box sum x weight < 2^35, b = box area < 2^24 -- this must BE the correctly rounded quotient,
+    or det / trace would stop being bit-identical to the reference's double-precision division (surf.cu:148): every area of every
+    filter size of 5 octaves x 6 layers against 20 000 dividends each (incl. near multiples), and 2e7 random (a, b)."""
+    import subprocess
+    src = tmp_path / "divtest.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+static uint64_t s = 88172645463325252ull;
+static inline uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+static long check(double a, double b)
+{
+    const double y = 1.0 / b, q = a * y;
+    return fma(fma(-q, b, a), y, q) != a / b;
+}
+int main(void)
+{
+    long bad = 0, n = 0;
+    for (int octave = 0; octave < 5; ++octave)
+        for (int layer = 0; layer < 6; ++layer) {
+            const int size = (9 + 6 * layer) << octave;
+            const float ratio = (float)size / 9;
+            int e[10];
+            for (int k = 0; k < 10; ++k) e[k] = (int)rintf(ratio * (float)k);
+            const int areas[6] = {(e[3] - e[0]) * (e[7] - e[2]), (e[6] - e[3]) * (e[7] - e[2]), (e[9] - e[6]) * (e[7] - e[2]),
+                                  (e[4] - e[1]) * (e[4] - e[1]), (e[8] - e[5]) * (e[4] - e[1]), (e[8] - e[5]) * (e[8] - e[5])};
+            for (int ai = 0; ai < 6; ++ai)
+                for (int t = 0; t < 20000; ++t) {
+                    int64_t a = (int64_t)(rnd() % (1ull << 35)) - (1ll << 34);
+                    if (t < 200) a = (int64_t)areas[ai] * (t - 100) * 977 + (t % 3) - 1;
+                    bad += check((double)a, (double)areas[ai]); ++n;
+                }
+        }
+    for (long t = 0; t < 20000000; ++t) {
+        const int64_t a = (int64_t)(rnd() % (1ull << 35)) - (1ll << 34);
+        bad += check((double)a, (double)(1 + rnd() % (1u << 24))); ++n;
+    }
+    printf("%ld %ld\n", n, bad);
+    return bad != 0;
+}
+''')
+    exe = str(tmp_path / "divtest")
+    r = subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", str(src), "-o", exe, "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    n, bad = (int(x) for x in r.stdout.split())
+    assert r.returncode == 0 and n > 2.3e7 and bad == 0, r.stdout
