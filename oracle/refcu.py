@@ -54,6 +54,9 @@ def lib():
         L.ref_cu_resize_linear_u8.argtypes = [_u8, i, i, _u8, i, i, f, f]
         L.ref_cu_pyr_down_f32.argtypes = [_f32, i, i, _f32, i, i]
         L.ref_cu_pyr_down_u8.argtypes = [_u8, i, i, _u8, i, i]
+        d = C.c_double
+        L.ref_cuhost_tvl1_calc.restype = i
+        L.ref_cuhost_tvl1_calc.argtypes = [d, d, d, i, i, d, i, d, d, i, vp, vp, i, i, i, _f32, C.POINTER(i)]
         _lib = L
     return _lib
 
@@ -209,3 +212,21 @@ def pyr_down(src):
     fn = lib().ref_cu_pyr_down_f32 if src.dtype == np.float32 else lib().ref_cu_pyr_down_u8
     fn(src, sh, sw, dst, dst.shape[0], dst.shape[1])
     return dst
+
+
+def cuda_class_tvl1_calc(I0, I1, tau=0.25, lambda_=0.15, theta=0.3, nscales=5, warps=5, epsilon=0.01, iterations=300, scale_step=0.8,
+                         gamma=0.0, init_flow=None):
+    """cv::cuda::OpticalFlowDual_TVL1::create(...)->calc(I0, I1, flow): the reference's HOST class (modules/cudaoptflow/src/tvl1flow.cpp,
+    compiled verbatim) over the reference's kernels (tvl1flow.cu, resize.cu).  Returns (flow, nscales after the call)."""
+    I0, I1 = np.ascontiguousarray(I0), np.ascontiguousarray(I1)
+    assert I0.dtype == I1.dtype and I0.dtype in (np.uint8, np.float32) and I0.shape == I1.shape
+    h, w = I0.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    if init_flow is not None:
+        flow[...] = init_flow
+    ns = C.c_int(0)
+    rc = lib().ref_cuhost_tvl1_calc(tau, lambda_, theta, nscales, warps, epsilon, iterations, scale_step, gamma, int(init_flow is not None),
+                                    I0.ctypes.data, I1.ctypes.data, 0 if I0.dtype == np.uint8 else 1, w, h, flow.reshape(-1), C.byref(ns))
+    if rc:
+        raise ValueError("the reference class threw")
+    return flow, ns.value

@@ -1,0 +1,147 @@
+/*
+ * oracle/refshim/cudahost/cudahost.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  See opencv2/core/cuda.hpp in this directory.
+ * Host glue of the cv::cuda functions the reference's host class calls (restated from the cited lines; their device parts are
+ * elementwise loops or the reference kernels of libref_cu.so), and the C entry point that drives
+ * cv::cuda::OpticalFlowDual_TVL1 (modules/cudaoptflow/src/tvl1flow.cpp, compiled verbatim by oracle/Makefile.ref).
+ */
+#include "opencv2/cudaoptflow.hpp"      // the reference's own header (-I $(REF)/modules/cudaoptflow/include)
+#include "opencv2/cudaarithm.hpp"
+#include "opencv2/cudawarping.hpp"
+#include <cmath>
+
+extern "C" void ref_cu_resize_linear_f32(const float *src, int sr, int sc, float *dst, int dr, int dc, float fy, float fx);
+
+namespace cv { namespace cuda {
+
+// GpuMat::convertTo(dst, rtype, alpha, stream): core/src/cuda/gpu_mat.cu convertToScale -- 8U / 32F -> 32F computes in float:
+// saturate_cast<float>(alpha * src [+ beta = 0]); alpha arrives as double and is used as a float scalar
+void GpuMat::convertTo(GpuMat &dst, int rtype, double alpha, Stream &) const
+{
+    CV_Assert((rtype & 7) == CV_32F && channels() == 1);
+    GpuMat out;
+    out.create(rows, cols, CV_32FC1);
+    const float a = (float)alpha;
+    for (int y = 0; y < rows; ++y) {
+        float *d = out.ptr<float>(y);
+        if (depth() == CV_8U) { const unsigned char *s = ptr<unsigned char>(y); for (int x = 0; x < cols; ++x) d[x] = a * (float)s[x]; }
+        else { const float *s = ptr<float>(y); for (int x = 0; x < cols; ++x) d[x] = a * s[x]; }
+    }
+    dst = out;
+}
+GpuMat &GpuMat::setTo(Scalar s, Stream &)
+{
+    CV_Assert(type() == CV_32FC1);
+    for (int y = 0; y < rows; ++y) { float *r = ptr<float>(y); for (int x = 0; x < cols; ++x) r[x] = (float)s[0]; }
+    return *this;
+}
+void GpuMat::copyTo(GpuMat &dst, Stream &) const
+{
+    dst.create(rows, cols, type());
+    for (int y = 0; y < rows; ++y) memcpy(dst.ptr<unsigned char>(y), ptr<unsigned char>(y), (size_t)cols * elem_size_of(type()));
+}
+void GpuMat::download(Mat &dst, Stream &) const
+{
+    CV_Assert(type() == CV_64FC1);
+    dst.rows = rows; dst.cols = cols; dst.v.resize((size_t)rows * cols);
+    for (int y = 0; y < rows; ++y) memcpy(&dst.v[(size_t)y * cols], ptr<double>(y), sizeof(double) * cols);
+}
+
+// cuda::multiply(src, Scalar, dst, 1, -1): cudaarithm/src/cuda/mul_scalar.cu:62-70,118-175 -- for a CV_32F source the scalar type is
+// float (the funcs table row {..., mulScalarImpl<float, float, float>, ...}) and the functor is saturate_cast<float>(scale * a * val)
+// with scale = 1: one float multiply by (float)scalar
+void multiply(const GpuMat &src1, const Scalar &src2, GpuMat &dst, double scale, int dtype, Stream &)
+{
+    CV_Assert(src1.type() == CV_32FC1 && scale == 1 && dtype == -1);
+    GpuMat out = dst.data == src1.data ? dst : GpuMat();
+    out.create(src1.rows, src1.cols, CV_32FC1);
+    const float v = (float)src2[0];
+    for (int y = 0; y < src1.rows; ++y) {
+        const float *s = src1.ptr<float>(y);
+        float *d = out.ptr<float>(y);
+        for (int x = 0; x < src1.cols; ++x) d[x] = s[x] * v;
+    }
+    dst = out;
+}
+
+// cuda::merge of two CV_32FC1 planes into CV_32FC2 (cudaarithm/src/cuda/split_merge.cu: interleave)
+void merge(const GpuMat *src, size_t n, OutputArray dst, Stream &)
+{
+    CV_Assert(n == 2 && src[0].type() == CV_32FC1 && src[1].size() == src[0].size());
+    dst.create(src[0].size(), CV_32FC2);
+    GpuMat &d = *dst.gpuMatPtr();
+    for (int y = 0; y < d.rows; ++y) {
+        const float *a = src[0].ptr<float>(y), *b = src[1].ptr<float>(y);
+        float *o = d.ptr<float>(y);
+        for (int x = 0; x < d.cols; ++x) { o[2 * x] = a[x]; o[2 * x + 1] = b[x]; }
+    }
+}
+
+// cuda::calcSum: cudaarithm/src/cuda/sum.cu -- a CV_32F source is reduced in double (the reduction tree's association is the
+// device's; the value only feeds `error > scaledEpsilon`, a sequential double sum differs from any tree by ~1e-16 relative)
+void calcSum(InputArray src, OutputArray dst, InputArray mask, Stream &)
+{
+    CV_Assert(mask.empty());
+    const GpuMat s = src.getGpuMat();
+    CV_Assert(s.type() == CV_32FC1);
+    double acc = 0;
+    for (int y = 0; y < s.rows; ++y) { const float *r = s.ptr<float>(y); for (int x = 0; x < s.cols; ++x) acc += (double)r[x]; }
+    dst.create(Size(1, 1), CV_64FC1);
+    *dst.gpuMatPtr()->ptr<double>(0) = acc;
+}
+
+// cuda::resize: cudawarping/src/resize.cpp:55-103 (the size / scale glue) around the reference's resize_linear kernel
+static int saturate_int(double v) { return (int)lrint(v); }   // saturate_cast<int>(double) = cvRound: round half to even
+void resize(InputArray _src, OutputArray _dst, Size dsize, double fx, double fy, int interpolation, Stream &stream)
+{
+    const GpuMat src = _src.getGpuMat();
+    CV_Assert(src.type() == CV_32FC1 && interpolation == INTER_LINEAR);
+    CV_Assert(!(dsize == Size()) || (fx > 0 && fy > 0));
+    if (dsize == Size()) {
+        dsize = Size(saturate_int(src.cols * fx), saturate_int(src.rows * fy));
+    } else {
+        fx = static_cast<double>(dsize.width) / src.cols;
+        fy = static_cast<double>(dsize.height) / src.rows;
+    }
+    _dst.create(dsize, src.type());
+    GpuMat &dst = *_dst.gpuMatPtr();
+    if (dsize == src.size()) { src.copyTo(dst, stream); return; }
+    // dense copies for the C entry of libref_cu.so (the kernel itself addresses through PtrStepSz: pitch-independent)
+    std::vector<float> s((size_t)src.rows * src.cols), d((size_t)dsize.height * dsize.width);
+    for (int y = 0; y < src.rows; ++y) memcpy(&s[(size_t)y * src.cols], src.ptr<float>(y), sizeof(float) * src.cols);
+    ref_cu_resize_linear_f32(s.data(), src.rows, src.cols, d.data(), dsize.height, dsize.width, static_cast<float>(1.0 / fy), static_cast<float>(1.0 / fx));
+    for (int y = 0; y < dsize.height; ++y) memcpy(dst.ptr<float>(y), &d[(size_t)y * dsize.width], sizeof(float) * dsize.width);
+}
+}}  // namespace cv::cuda
+
+extern "C" {
+/* cv::cuda::OpticalFlowDual_TVL1::create(...)->calc(I0, I1, flow): the reference host class over the reference kernels.
+ * I0 / I1: rows x cols, type 0 = CV_8UC1, 1 = CV_32FC1 (dense); flow: rows x cols x 2 floats; *nscales_out = nscales after the call
+ * (the class shrinks it for small images).  Returns 0, or 1 if the class threw. */
+int ref_cuhost_tvl1_calc(double tau, double lambda, double theta, int nscales, int warps, double epsilon, int iterations, double scale_step,
+                         double gamma, int use_initial_flow, const void *I0, const void *I1, int type, int cols, int rows, float *flow,
+                         int *nscales_out)
+{
+    using namespace cv;
+    try {
+        Ptr<cuda::OpticalFlowDual_TVL1> alg = cuda::OpticalFlowDual_TVL1::create(tau, lambda, theta, nscales, warps, epsilon, iterations, scale_step,
+                                                                                 gamma, use_initial_flow != 0);
+        const int t = type == 0 ? CV_8UC1 : CV_32FC1;
+        cuda::GpuMat a(Size(cols, rows), t), b(Size(cols, rows), t), f;
+        const size_t rb = (size_t)cols * elem_size_of(t);
+        for (int y = 0; y < rows; ++y) {
+            memcpy(a.ptr<unsigned char>(y), (const unsigned char *)I0 + y * rb, rb);
+            memcpy(b.ptr<unsigned char>(y), (const unsigned char *)I1 + y * rb, rb);
+        }
+        if (use_initial_flow) {
+            f.create(Size(cols, rows), CV_32FC2);
+            for (int y = 0; y < rows; ++y) memcpy(f.ptr<float>(y), flow + (size_t)y * cols * 2, sizeof(float) * cols * 2);
+        }
+        alg->calc(a, b, f, cuda::Stream::Null());
+        for (int y = 0; y < rows; ++y) memcpy(flow + (size_t)y * cols * 2, f.ptr<float>(y), sizeof(float) * cols * 2);
+        if (nscales_out) *nscales_out = alg->getNumScales();
+        return 0;
+    } catch (const std::exception &) {
+        return 1;
+    }
+}
+}

@@ -1,0 +1,147 @@
+/*
+ * oracle/refshim/cudahost -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * The smallest stand-in for the main-repo headers (opencv/opencv: core.hpp, core/cuda.hpp, core/private.cuda.hpp; absent from
+ * /root/reference) that lets the reference's OWN host class of cv::cuda::OpticalFlowDual_TVL1 --
+ * modules/cudaoptflow/src/tvl1flow.cpp, compiled VERBATIM from where it lies, against the reference's OWN public header
+ * modules/cudaoptflow/include/opencv2/cudaoptflow.hpp -- build and run on the CPU, driving the reference's OWN kernels
+ * (modules/cudaoptflow/src/cuda/tvl1flow.cu and the resize_linear template of modules/cudawarping/src/cuda/resize.cu, both already
+ * in oracle/_ref/libref_cu.so).  calc / calcImpl / procOneScale -- the pyramid loop, the level sizes and the 16-px rule, the
+ * per-warp loop with cv::cuda's sparse convergence schedule, the flow upsampling and its 1 / scaleStep multiplies -- are then
+ * REFERENCE code end to end (VERDICT r02 missing #4).  What this stub supplies: GpuMat as host memory, Stream / BufferPool as
+ * no-ops, InputArray proxies, and the five cv::cuda functions the file calls (cudahost.cpp: convertTo, setTo, multiply, merge,
+ * calcSum, resize -- host glue of cudaarithm / cudawarping / core restated from the cited lines; their kernels are elementwise).
+ */
+#ifndef ORACLE_CUDAHOST_CORE_CUDA_HPP
+#define ORACLE_CUDAHOST_CORE_CUDA_HPP
+#include "../../../cudashim/opencv2/core/cuda/common.hpp"   // PtrStepSz / cudaStream_t exactly as the kernels of libref_cu.so were built with
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#define HAVE_CUDA 1
+#define CV_EXPORTS
+#define CV_EXPORTS_W
+#define CV_WRAP
+#define CV_OUT
+#define CV_IN_OUT
+#define CV_OVERRIDE override
+#define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error("CV_Assert failed: " #expr); } while (0)
+#define CV_DbgAssert(expr) CV_Assert(expr)
+#define CV_8U 0
+#define CV_32F 5
+#define CV_64F 6
+#define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
+#define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+#define CV_32FC2 CV_MAKETYPE(CV_32F, 2)
+#define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
+
+namespace cv {
+typedef std::string String;
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2 };
+struct Size {
+    int width = 0, height = 0;
+    Size() {}
+    Size(int w, int h) : width(w), height(h) {}
+    int area() const { return width * height; }
+    bool operator==(const Size &o) const { return width == o.width && height == o.height; }
+    bool operator!=(const Size &o) const { return !(*this == o); }
+};
+struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
+struct Scalar {
+    double val[4] = {0, 0, 0, 0};
+    static Scalar all(double v) { Scalar s; s.val[0] = s.val[1] = s.val[2] = s.val[3] = v; return s; }
+    double operator[](int i) const { return val[i]; }
+};
+template <typename T> using Ptr = std::shared_ptr<T>;
+template <typename T, typename... A> Ptr<T> makePtr(A &&...a) { return std::make_shared<T>(std::forward<A>(a)...); }
+class Algorithm {
+public:
+    virtual ~Algorithm() {}
+    virtual String getDefaultName() const { return "my_object"; }
+};
+inline size_t elem_size_of(int type) { const int d = type & 7, cn = (type >> 3) + 1; return (size_t)cn * (d == CV_8U ? 1 : d == CV_64F ? 8 : 4); }
+
+class Mat {   // only what diff_sum_host needs: a 1 x 1 CV_64F element
+public:
+    int rows = 0, cols = 0;
+    std::vector<double> v;
+    template <typename T> T &at(int y, int x) { return reinterpret_cast<T &>(v[(size_t)y * cols + x]); }
+};
+
+namespace cuda {
+class Stream {
+public:
+    void waitForCompletion() {}
+    static Stream &Null() { static Stream s; return s; }
+};
+class GpuMat {   // host memory; views share the buffer (like the reference's refcounted device buffers)
+public:
+    int rows = 0, cols = 0;
+    size_t step = 0;
+    unsigned char *data = nullptr;
+    GpuMat() {}
+    GpuMat(Size s, int type) { create(s, type); }
+    int type() const { return type_; }
+    int depth() const { return type_ & 7; }
+    int channels() const { return (type_ >> 3) + 1; }
+    Size size() const { return Size(cols, rows); }
+    bool empty() const { return data == nullptr; }
+    void create(int r, int c, int type)   // GpuMat::create: keeps the buffer when size and type match (core/src/cuda/gpu_mat.cu)
+    {
+        if (data && rows == r && cols == c && type_ == type) return;
+        type_ = type; rows = r; cols = c;
+        step = ((size_t)c * elem_size_of(type) + 255) / 256 * 256;   // a pitched allocation, like cudaMallocPitch
+        buf_ = std::make_shared<std::vector<unsigned char> >((size_t)r * step + 64);
+        data = buf_->data();
+    }
+    void create(Size s, int type) { create(s.height, s.width, type); }
+    GpuMat operator()(const Rect &r) const
+    {
+        CV_Assert(r.x >= 0 && r.y >= 0 && r.x + r.width <= cols && r.y + r.height <= rows);
+        GpuMat m = *this;
+        m.data = data + (size_t)r.y * step + (size_t)r.x * elem_size_of(type_);
+        m.rows = r.height; m.cols = r.width;
+        return m;
+    }
+    template <typename T> T *ptr(int y) { return reinterpret_cast<T *>(data + (size_t)y * step); }
+    template <typename T> const T *ptr(int y) const { return reinterpret_cast<const T *>(data + (size_t)y * step); }
+    template <typename T> operator PtrStepSz<T>() const { return PtrStepSz<T>(rows, cols, (T *)data, step); }
+    // cudahost.cpp
+    void convertTo(GpuMat &dst, int rtype, double alpha, Stream &stream) const;
+    GpuMat &setTo(Scalar s, Stream &stream);
+    void download(Mat &dst, Stream &stream) const;
+    void copyTo(GpuMat &dst, Stream &stream) const;
+private:
+    int type_ = CV_8UC1;
+    std::shared_ptr<std::vector<unsigned char> > buf_;
+};
+}  // namespace cuda
+
+// InputArray / OutputArray proxies over GpuMat (the only kind this translation unit passes)
+class _InputArray {
+public:
+    _InputArray() : m_(nullptr) {}
+    _InputArray(const cuda::GpuMat &m) : m_(const_cast<cuda::GpuMat *>(&m)) {}
+    cuda::GpuMat getGpuMat() const { return m_ ? *m_ : cuda::GpuMat(); }
+    bool empty() const { return !m_ || m_->empty(); }
+    cuda::GpuMat *gpuMatPtr() const { return m_; }
+protected:
+    cuda::GpuMat *m_;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray() {}
+    _OutputArray(cuda::GpuMat &m) : _InputArray(m) {}
+    void create(Size s, int type) const { CV_Assert(m_); m_->create(s, type); }
+};
+typedef const _InputArray &InputArray;
+typedef const _OutputArray &OutputArray;
+typedef const _OutputArray &InputOutputArray;
+typedef InputArray InputArrayOfArrays;
+typedef OutputArray OutputArrayOfArrays;
+inline const _OutputArray &noArray() { static _OutputArray a; return a; }
+}  // namespace cv
+#endif

@@ -1,0 +1,13 @@
+/* oracle/refshim/cudahost: the three cudaarithm functions cudaoptflow/src/tvl1flow.cpp calls (cudahost.cpp).  TEST INFRASTRUCTURE. */
+#ifndef ORACLE_CUDAHOST_CUDAARITHM_HPP
+#define ORACLE_CUDAHOST_CUDAARITHM_HPP
+#include "opencv2/core/cuda.hpp"
+namespace cv { namespace cuda {
+// cudaarithm.hpp:185: multiply(src1, src2, dst, scale, dtype, stream) -- here only matrix x Scalar, scale 1, dtype -1
+void multiply(const GpuMat &src1, const Scalar &src2, GpuMat &dst, double scale, int dtype, Stream &stream);
+// cudaarithm.hpp:  merge(const GpuMat* src, size_t n, OutputArray dst, Stream&)
+void merge(const GpuMat *src, size_t n, OutputArray dst, Stream &stream);
+// cudaarithm.hpp: calcSum(src, dst, mask, stream): dst = 1 x 1 CV_64FC(cn)
+void calcSum(InputArray src, OutputArray dst, InputArray mask, Stream &stream);
+}}
+#endif
