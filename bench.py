@@ -113,7 +113,10 @@ def gen_base_pairs(n, h, w, **kw):
     call of the process: the workers are forked)."""
     import multiprocessing as mp
     jobs = [(h, w, 1234 + i, kw) for i in range(n)]
-    if n <= 1:
+    # under rocprofv3 (LD_PRELOAD of its tool library) forked workers never return (r03n: three profiled runs sat in the pool until
+    # their timeouts): generate in-process there
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if n <= 1 or profiled or os.environ.get("MIFLOW_BENCH_NO_FORK"):
         return [_gen_pair(j) for j in jobs]
     try:
         with mp.get_context("fork").Pool(min(n, max(1, (os.cpu_count() or 2) // 2))) as pool:
@@ -1039,12 +1042,14 @@ def main():
             var["single_pair_calc_sequential"] = {"error": repr(e)[:200]}
         # the reference's own concurrency pattern (cudaoptflow/test/test_optflow.cpp:468-527): 16 objects, 16 streams, one calc() per
         # object and round, all in flight together -- what an UNCHANGED caller uses to get throughput
-        for (it_, eps_, tag) in ((args.iterations, args.epsilon, "16_handles_16_streams_calc"),
-                                 (10, 0.01, "16_handles_16_streams_calc_iterations10_eps0.01"),
-                                 (300, 0.01, "16_handles_16_streams_calc_class_defaults")):
+        for (it_, eps_, tag, fbk) in ((args.iterations, args.epsilon, "16_handles_16_streams_calc", {}),
+                                      (10, 0.01, "16_handles_16_streams_calc_iterations10_eps0.01", {}),
+                                      (300, 0.01, "16_handles_16_streams_calc_class_defaults", {}),
+                                      # host_feedback = -1: nothing waits inside calc(), the 16 calcs of a round are all in flight (r02 behaviour)
+                                      (300, 0.01, "16_handles_16_streams_calc_class_defaults_no_host_feedback", {"hostFeedback": -1})):
             try:
                 nh = 16
-                hs_ = [create(it_, eps_) for _ in range(nh)]
+                hs_ = [create(it_, eps_, **fbk) for _ in range(nh)]
                 sts = [torch.cuda.Stream(device=dev) for _ in range(nh)]
                 outs = [torch.empty((H, W, 2), dtype=torch.float32, device=dev) for _ in range(nh)]
                 torch.cuda.synchronize()
@@ -1058,7 +1063,7 @@ def main():
                         hs_[k].calc(I0[k % B], I1[k % B], outs[k], stream=sts[k].cuda_stream)
                 torch.cuda.synchronize()
                 e16 = time.perf_counter() - t1
-                lone = create(it_, eps_)
+                lone = create(it_, eps_, **fbk)
                 chk = lone.calc(I0[3 % B], I1[3 % B])
                 torch.cuda.synchronize()
                 var[tag] = {"pairs_per_s": nh * rounds / e16, "handles": nh, "streams": nh, "iterations": it_, "epsilon": eps_,

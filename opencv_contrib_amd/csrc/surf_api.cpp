@@ -3,6 +3,7 @@
 // One stream, no host round trip inside the octave loop; the only synchronisation is the final read-back of the
 // feature count (the reference's keypoints.cols = featureCounter, :205-209).
 #include "surf_dev.h"
+#include <cstdlib>
 #include "mi_selftest.h"
 #include <cmath>
 #include <vector>
@@ -23,6 +24,10 @@ struct mi_surf {
     void *itmp = nullptr;   // per-candidate interpolation results
     unsigned *counters = nullptr;   // [0] = features, [1 + octave] = candidates of the octave (surf.cuda.cpp:158-159)
     int sld = 0, vld = 0, dld = 0;
+    // all octaves per launch (surf::detect_fused): region sizes and the per-(octave, layer) filter geometry on the device
+    bool fused = false;
+    int capO = 0;
+    void *geo = nullptr;
 };
 
 static int calc_size(int octave, int layer) { return (9 + 6 * layer) << octave; }
@@ -84,10 +89,10 @@ int mi_surf_get_params(const mi_surf *h, mi_surf_params *p) { MI_REQUIRE(h && p,
 
 static void free_scratch(mi_surf *h)
 {
-    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->rowcnt, h->segcnt, h->cand, h->itmp};
+    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->rowcnt, h->segcnt, h->cand, h->itmp, h->geo};
     for (void *p : ps) if (p) (void)hipFree(p);
-    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->rowcnt = nullptr; h->segcnt = nullptr; h->cand = nullptr; h->itmp = nullptr;
-    h->capR = h->capC = h->capL = h->capCand = 0;
+    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->rowcnt = nullptr; h->segcnt = nullptr; h->cand = nullptr; h->itmp = nullptr; h->geo = nullptr;
+    h->capR = h->capC = h->capL = h->capCand = h->capO = 0;
 }
 
 void mi_surf_release_memory(mi_surf *h) { if (h) free_scratch(h); }   // SURF_CUDA::releaseMemory, surf.cuda.cpp:434-442
@@ -132,20 +137,38 @@ int mi_surf_max_features(const mi_surf *h, int rows, int cols, int *max_features
 
 static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool need_mask)
 {
-    if (!(h->capR == rows && h->capC == cols && h->capL >= layers && h->capCand >= maxCand)) {
+    const int octaves = h->P.n_octaves;
+    if (!(h->capR == rows && h->capC == cols && h->capL >= layers && h->capCand >= maxCand && h->capO == octaves)) {
         free_scratch(h);
         h->sld = align_up(cols + 1, 64); h->vld = align_up(cols, 64); h->dld = align_up(cols, 64);
+        // one launch per stage for all octaves where the kernel arguments hold them (surf::fused_supported), else octave by octave
+        // through one set of planes; the fused form keeps every octave's planes: ~4/3 of octave 0's
+        h->fused = surf::fused_supported(octaves, layers) && !(getenv("MIFLOW_SURF_FUSED") && atoi(getenv("MIFLOW_SURF_FUSED")) == 0);
+        surf::FusedSizes z;
+        z.plane_floats = (size_t)h->dld * rows * (layers + 2);
+        z.bits_words = (size_t)layers * rows * div_up(cols, 64);
+        z.row_counts = (size_t)layers * rows + 1;
+        z.seg_counts = (size_t)layers * rows * surf::nms_segments(cols);
+        z.geo_bytes = 0;
+        if (h->fused) surf::fused_sizes(rows, cols, h->dld, octaves, layers, &z);
+        const size_t nlists = h->fused ? (size_t)octaves : 1;
         MI_HIP_TRY(hipMalloc((void **)&h->sum, sizeof(unsigned) * (size_t)h->sld * (rows + 1)));
         MI_HIP_TRY(hipMalloc((void **)&h->V, sizeof(unsigned) * (size_t)h->vld * rows));
         MI_HIP_TRY(hipMalloc((void **)&h->BT, sizeof(unsigned) * (size_t)h->vld * surf::integral_bands(rows)));
-        MI_HIP_TRY(hipMalloc((void **)&h->det, sizeof(float) * (size_t)h->dld * rows * (layers + 2)));
-        MI_HIP_TRY(hipMalloc((void **)&h->trace, sizeof(float) * (size_t)h->dld * rows * (layers + 2)));
-        MI_HIP_TRY(hipMalloc((void **)&h->bits, sizeof(unsigned long long) * (size_t)layers * rows * div_up(cols, 64)));
-        MI_HIP_TRY(hipMalloc((void **)&h->rowcnt, sizeof(unsigned) * ((size_t)layers * rows + 1)));
-        MI_HIP_TRY(hipMalloc((void **)&h->segcnt, sizeof(unsigned) * (size_t)layers * rows * surf::nms_segments(cols)));
-        MI_HIP_TRY(hipMalloc((void **)&h->cand, sizeof(int4) * (size_t)maxCand));
-        MI_HIP_TRY(hipMalloc(&h->itmp, surf::interp_tmp_bytes(maxCand)));
-        h->capR = rows; h->capC = cols; h->capL = layers; h->capCand = maxCand;
+        MI_HIP_TRY(hipMalloc((void **)&h->det, sizeof(float) * z.plane_floats));
+        MI_HIP_TRY(hipMalloc((void **)&h->trace, sizeof(float) * z.plane_floats));
+        MI_HIP_TRY(hipMalloc((void **)&h->bits, sizeof(unsigned long long) * z.bits_words));
+        MI_HIP_TRY(hipMalloc((void **)&h->rowcnt, sizeof(unsigned) * z.row_counts));
+        MI_HIP_TRY(hipMalloc((void **)&h->segcnt, sizeof(unsigned) * z.seg_counts));
+        MI_HIP_TRY(hipMalloc((void **)&h->cand, sizeof(int4) * (size_t)maxCand * nlists));
+        MI_HIP_TRY(hipMalloc(&h->itmp, surf::interp_tmp_bytes(maxCand) * nlists));
+        if (h->fused) {
+            std::vector<unsigned char> g(z.geo_bytes);
+            surf::fused_geometry(h->sld, octaves, layers, g.data());
+            MI_HIP_TRY(hipMalloc(&h->geo, z.geo_bytes));
+            MI_HIP_TRY(hipMemcpy(h->geo, g.data(), z.geo_bytes, hipMemcpyHostToDevice));
+        }
+        h->capR = rows; h->capC = cols; h->capL = layers; h->capCand = maxCand; h->capO = octaves;
     }
     if (need_mask && !h->msum) MI_HIP_TRY(hipMalloc((void **)&h->msum, sizeof(unsigned) * (size_t)h->sld * (rows + 1)));
     return MI_OK;
@@ -190,6 +213,11 @@ int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *ke
     if (use_mask && (rc = surf::integral((const unsigned char *)mask->data, (long long)mask->step, rows, cols, true, h->V, h->BT, h->vld, h->msum, h->sld, st)))
         return rc;                                                                                                    // :165-169
     MI_HIP_TRY(hipMemset2DAsync(kp, keypoints->step, 0, (size_t)maxF * 4, 7, st));                                   // keypoints.setTo(0) :180
+    if (h->fused) {                                                                                                  // :182-204, all octaves per launch
+        if ((rc = surf::detect_fused(h->sum, use_mask ? h->msum : nullptr, h->sld, rows, cols, P.n_octaves, P.n_octave_layers,
+                                     (float)P.hessian_threshold, h->det, h->trace, h->dld, h->bits, h->rowcnt, h->segcnt, h->cand, maxC,
+                                     h->counters + 1, h->itmp, h->geo, kp, kld, maxF, h->counters, st))) return rc;
+    } else
     for (int octave = 0; octave < P.n_octaves; ++octave) {                                                           // :182-204
         if ((rc = surf::det_trace(h->sum, h->sld, rows, cols, octave, P.n_octave_layers, h->det, h->trace, h->dld, st))) return rc;
         if ((rc = surf::find_maxima(h->det, h->trace, h->dld, use_mask ? h->msum : nullptr, h->sld, rows, cols, octave, P.n_octave_layers,

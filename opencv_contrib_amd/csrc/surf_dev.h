@@ -16,6 +16,14 @@ int find_maxima(const float *det, const float *trace, int dld, const unsigned *m
                 int nOctaveLayers, float thr, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
                 unsigned *ncand, hipStream_t s);
 int nms_segments(int cols);   // row segments k_nms_flag cuts a row of `cols` samples into (segcnt: layers x rows x segments)
+// all octaves of a frame in one launch per stage (surf_kernels.hip: k_*_all)
+struct FusedSizes { size_t plane_floats, bits_words, seg_counts, row_counts, geo_bytes; };
+bool fused_supported(int n_octaves, int nOctaveLayers);
+void fused_sizes(int rows, int cols, int dld, int n_octaves, int nOctaveLayers, FusedSizes *z);
+void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host);
+int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int rows, int cols, int n_octaves, int nOctaveLayers, float thr,
+                 float *det, float *trace, int dld, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
+                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s);
 // tmp: interp_tmp_bytes(max_candidates) bytes of scratch
 int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, int max_candidates,
                 void *tmp, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s);

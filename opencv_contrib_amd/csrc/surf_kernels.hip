@@ -177,6 +177,37 @@ __device__ __forceinline__ double box_div(unsigned tt, double w, double area, do
     const double q = a * ry;
     return fma(fma(-q, area, a), ry, q);
 }
+// Dxx, Dyy, Dxy of the sample whose top-left corner sits at lane byte offset voff, then det and trace (surf.cu:175-203)
+template <class Geo>   // HaarGeo in kernel-argument space, or the same struct behind a constant-address-space reference
+__device__ __forceinline__ void haar_det_trace(const SumTex &t, const Geo &g, unsigned voff, float &d, float &tr)
+{
+    const auto T = [&](int o) { return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(t.s + o) + voff); };
+    // the reference's order (surf.cu:133-150): per box +(y1,x1) -(y2,x1) -(y1,x2) +(y2,x2); d accumulates box by box in double
+    unsigned cxx[4][2], cyy[2][4], cxy[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { cxx[a][b] = T(g.xx[a][b]); cyy[b][a] = T(g.yy[b][a]); }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cxy[a][b] = T(g.xy[a][b]);
+    const double wxx[3] = {1.0, -2.0, 1.0};
+    double sx = 0, sy = 0, sxy = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sx += box_div(cxx[k][0] - cxx[k][1] - cxx[k + 1][0] + cxx[k + 1][1], wxx[k], g.area[k], g.ry[k]);
+        sy += box_div(cyy[0][k] - cyy[0][k + 1] - cyy[1][k] + cyy[1][k + 1], wxx[k], g.area[3 + k], g.ry[3 + k]);
+    }
+    // c_DXY (surf.cu:159): {1,1,4,4,+1}, {5,1,8,4,-1}, {1,5,4,8,-1}, {5,5,8,8,+1}  (x1, y1, x2, y2, w); cxy[y edge][x edge]
+    sxy += box_div(cxy[0][0] - cxy[1][0] - cxy[0][1] + cxy[1][1], 1.0, g.area[6], g.ry[6]);
+    sxy += box_div(cxy[0][2] - cxy[1][2] - cxy[0][3] + cxy[1][3], -1.0, g.area[7], g.ry[7]);
+    sxy += box_div(cxy[2][0] - cxy[3][0] - cxy[2][1] + cxy[3][1], -1.0, g.area[8], g.ry[8]);
+    sxy += box_div(cxy[2][2] - cxy[3][2] - cxy[2][3] + cxy[3][3], 1.0, g.area[9], g.ry[9]);
+    const float dx = (float)sx, dy = (float)sy, dxy = (float)sxy;
+    d = dx * dy - 0.81f * dxy * dxy;
+    tr = dx + dy;
+}
 __global__ __launch_bounds__(256) void k_det_trace(SumTex t, float *det, float *trace, int dld, int octave, int layer0, int nlayers2, int nbx, int nby, HaarGeoSet G)
 {
     // XCD-contiguous order: workgroup id -> XCD id % 8 (MI355X_MICROARCH.md); each XCD takes a contiguous run of row bands, and inside
@@ -198,32 +229,7 @@ __global__ __launch_bounds__(256) void k_det_trace(SumTex t, float *det, float *
         const HaarGeo &g = G.l[ll];   // kernel argument: scalar registers
         unsigned voff = 4u * ((unsigned)(i << octave) * (unsigned)t.sld + (unsigned)(j << octave));
         asm volatile("" : "+v"(voff));             // keep the lane offset a 32-bit VGPR: tap offsets stay on the scalar base
-        const auto T = [&](int o) { return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(t.s + o) + voff); };
-        // the reference's order (surf.cu:133-150): per box +(y1,x1) -(y2,x1) -(y1,x2) +(y2,x2); d accumulates box by box in double
-        unsigned cxx[4][2], cyy[2][4], cxy[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) { cxx[a][b] = T(g.xx[a][b]); cyy[b][a] = T(g.yy[b][a]); }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) cxy[a][b] = T(g.xy[a][b]);
-        const double wxx[3] = {1.0, -2.0, 1.0};
-        double sx = 0, sy = 0, sxy = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            sx += box_div(cxx[k][0] - cxx[k][1] - cxx[k + 1][0] + cxx[k + 1][1], wxx[k], g.area[k], g.ry[k]);
-            sy += box_div(cyy[0][k] - cyy[0][k + 1] - cyy[1][k] + cyy[1][k + 1], wxx[k], g.area[3 + k], g.ry[3 + k]);
-        }
-        // c_DXY (surf.cu:159): {1,1,4,4,+1}, {5,1,8,4,-1}, {1,5,4,8,-1}, {5,5,8,8,+1}  (x1, y1, x2, y2, w); cxy[y edge][x edge]
-        sxy += box_div(cxy[0][0] - cxy[1][0] - cxy[0][1] + cxy[1][1], 1.0, g.area[6], g.ry[6]);
-        sxy += box_div(cxy[0][2] - cxy[1][2] - cxy[0][3] + cxy[1][3], -1.0, g.area[7], g.ry[7]);
-        sxy += box_div(cxy[2][0] - cxy[3][0] - cxy[2][1] + cxy[3][1], -1.0, g.area[8], g.ry[8]);
-        sxy += box_div(cxy[2][2] - cxy[3][2] - cxy[2][3] + cxy[3][3], 1.0, g.area[9], g.ry[9]);
-        const float dx = (float)sx, dy = (float)sy, dxy = (float)sxy;
-        d = dx * dy - 0.81f * dxy * dxy;
-        tr = dx + dy;
+        haar_det_trace(t, g, voff, d, tr);
     }
     const long long o = (long long)(layer * layer_rows + ii) * dld + jj;
     det[o] = d;
@@ -260,12 +266,11 @@ struct NmsArgs {
 // round-2 loop issued one load per chunk and waited for it: 60 dependent round trips per 4K row, 176 us per octave-0 launch for
 // 66 MB); a chunk without a value above the threshold -- nearly all -- costs nothing more.
 constexpr int kNmsSeg = 8;   // chunks of one wave: a 4K row is 8 waves (one wave per row left the loop at 60 dependent round trips)
-__global__ __launch_bounds__(256) void k_nms_flag(NmsArgs A)
+__device__ __forceinline__ void nms_flag_row(const NmsArgs &A, int r, int seg)
 {
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.y, cbeg = seg * kNmsSeg, cend = min(cbeg + kNmsSeg, A.chunks);
+    const int cbeg = seg * kNmsSeg, cend = min(cbeg + kNmsSeg, A.chunks);
     const int layer_rows = A.rows >> A.octave, layer_cols = A.cols >> A.octave;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= A.nlayers * layer_rows) return;
     const int layer = r / layer_rows + 1, i = r % layer_rows;
     const int size = calc_size(A.octave, layer);
@@ -313,9 +318,10 @@ __global__ __launch_bounds__(256) void k_nms_flag(NmsArgs A)
 #undef DET
     if (lane == 0) A.segcnt[(long long)r * A.nseg + seg] = cnt;
 }
+__global__ __launch_bounds__(256) void k_nms_flag(NmsArgs A) { nms_flag_row(A, blockIdx.x * 4 + (threadIdx.x >> 6), blockIdx.y); }
 
 // exclusive scan of n (<= 1024 * per) counts by ONE block; total -> cnt[n]
-__global__ __launch_bounds__(1024) void k_scan_counts(unsigned *cnt, const unsigned *seg, int nseg, int n)
+__device__ __forceinline__ void scan_counts_body(unsigned *cnt, const unsigned *seg, int nseg, int n)
 {
     __shared__ unsigned part[1024];
     const int per = (n + 1023) / 1024;
@@ -335,13 +341,13 @@ __global__ __launch_bounds__(1024) void k_scan_counts(unsigned *cnt, const unsig
     for (int k = b; k < e; ++k) { const unsigned c = row_total(k); cnt[k] = run; run += c; }
     if (threadIdx.x == 1023) cnt[n] = part[1023];
 }
+__global__ __launch_bounds__(1024) void k_scan_counts(unsigned *cnt, const unsigned *seg, int nseg, int n) { scan_counts_body(cnt, seg, nseg, n); }
 
 // write candidates {j, i, layer, laplacian} in scan order; count (clamped) -> ncand
-__global__ __launch_bounds__(256) void k_nms_write(NmsArgs A, int4 *cand, int max_candidates, unsigned *ncand)
+__device__ __forceinline__ void nms_write_row(const NmsArgs &A, int r, int4 *cand, int max_candidates, unsigned *ncand)
 {
     const int lane = threadIdx.x & 63;
     const int layer_rows = A.rows >> A.octave;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nrows = A.nlayers * layer_rows;
     if (r == 0 && lane == 0) *ncand = min(A.rowcnt[nrows], (unsigned)max_candidates);
     if (r >= nrows) return;
@@ -360,6 +366,10 @@ __global__ __launch_bounds__(256) void k_nms_write(NmsArgs A, int4 *cand, int ma
         }
         base += (unsigned)__popcll(m);
     }
+}
+__global__ __launch_bounds__(256) void k_nms_write(NmsArgs A, int4 *cand, int max_candidates, unsigned *ncand)
+{
+    nms_write_row(A, blockIdx.x * 4 + (threadIdx.x >> 6), cand, max_candidates, ncand);
 }
 
 // ------------------------------------------------------------------ sub-pixel interpolation
@@ -386,10 +396,9 @@ __device__ __forceinline__ bool solve3x3(const float A[3][3], const float b[3], 
 // appends the accepted features in candidate order behind the features of the previous octaves.
 struct InterpOut { float px, py, psize, hess; int lap, ok; };
 
-__global__ __launch_bounds__(256) void k_interp_eval(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
-                                                     const unsigned *ncand_p, InterpOut *tmp)
+__device__ __forceinline__ void interp_eval_one(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
+                                                const unsigned *ncand_p, InterpOut *tmp, int c)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= (int)*ncand_p) return;
     const int layer_rows = rows >> octave;
     const int4 mp = cand[c];
@@ -433,12 +442,18 @@ __global__ __launch_bounds__(256) void k_interp_eval(const float *det, int dld, 
     o.ok = ok ? 1 : 0;
     tmp[c] = o;
 }
+__global__ __launch_bounds__(256) void k_interp_eval(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
+                                                     const unsigned *ncand_p, InterpOut *tmp)
+{
+    interp_eval_one(det, dld, rows, cols, octave, cand, ncand_p, tmp, blockIdx.x * 256 + threadIdx.x);
+}
 
-__global__ __launch_bounds__(1024) void k_interp_compact(const InterpOut *tmp, const unsigned *ncand_p, int octave, float *kp, int kld,
-                                                         int max_features, unsigned *nfeat_p)
+// appends the accepted candidates of one octave behind feature nfeat0; returns the new feature count (the same in every thread)
+__device__ __forceinline__ unsigned interp_compact_body(const InterpOut *tmp, const unsigned *ncand_p, int octave, float *kp, int kld,
+                                                        int max_features, unsigned nfeat0)
 {
     __shared__ unsigned part[1024];
-    const unsigned ncand = *ncand_p, nfeat0 = *nfeat_p;
+    const unsigned ncand = *ncand_p;
     const int per = (int)(ncand + 1023) / 1024;
     const int b = threadIdx.x * per, e = min(b + per, (int)ncand);
     unsigned cnt = 0;
@@ -466,7 +481,15 @@ __global__ __launch_bounds__(1024) void k_interp_compact(const InterpOut *tmp, c
         ++ind;
     }
     __syncthreads();
-    if (threadIdx.x == 0) *nfeat_p = min(nfeat0 + part[1023], (unsigned)max_features);
+    const unsigned total = min(nfeat0 + part[1023], (unsigned)max_features);
+    __syncthreads();   // part[] is reused by the next octave of k_interp_compact_all
+    return total;
+}
+__global__ __launch_bounds__(1024) void k_interp_compact(const InterpOut *tmp, const unsigned *ncand_p, int octave, float *kp, int kld,
+                                                         int max_features, unsigned *nfeat_p)
+{
+    const unsigned total = interp_compact_body(tmp, ncand_p, octave, kp, kld, max_features, *nfeat_p);
+    if (threadIdx.x == 0) *nfeat_p = total;
 }
 
 // ------------------------------------------------------------------ orientation
@@ -693,6 +716,115 @@ __global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, l
     if (threadIdx.x < N) desc[(long long)f * dstep + threadIdx.x] = D[threadIdx.x] / len;
 }
 
+// ------------------------------------------------------------------ all octaves of a frame in one launch per stage (round 3)
+// The reference runs its five detector kernels once per octave (surf.cuda.cpp:182-204) and copies two counters to the host in
+// between; round 2 kept the per-octave launches (24 per 4-octave frame, the coarse octaves launch-bound: octave 3 is 1/64 of octave
+// 0's samples and took 1/6 of its time).  Here every stage covers all octaves: the planes, flag words, counts and candidate lists of
+// an octave live at their own offsets (OctSet), a workgroup finds its octave from the cumulative workgroup counts, and the last
+// stage walks the octaves in order so that the features of octave o still follow those of octave o - 1 (deterministic order).
+constexpr int kMaxFusedOctaves = 6;
+struct OctSet {
+    int n;                                   // octaves
+    int nlayers;                             // nOctaveLayers
+    int rows, cols, dld;
+    long long plane0[kMaxFusedOctaves];      // float offset of the octave's first det / trace plane
+    long long bits0[kMaxFusedOctaves];       // u64 offset of its flag words
+    int row0[kMaxFusedOctaves];              // first (layer, row) index in rowcnt space (rowcnt has one extra entry per octave)
+    long long seg0[kMaxFusedOctaves];        // offset of its row-segment counts
+    int blk_dt[kMaxFusedOctaves + 1];        // cumulative workgroup counts of k_det_trace_all
+    int blk_nms[kMaxFusedOctaves + 1];       //   ... of k_nms_flag_all (row groups x segments)
+    int blk_wr[kMaxFusedOctaves + 1];        //   ... of k_nms_write_all (row groups)
+    int nbx[kMaxFusedOctaves], nby[kMaxFusedOctaves], nseg[kMaxFusedOctaves], chunks[kMaxFusedOctaves];
+};
+__device__ __forceinline__ int find_octave(const int *cum, int n, int id)
+{
+    int o = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxFusedOctaves; ++k) o += (k < n && id >= cum[k]) ? 1 : 0;
+    return o;
+}
+__global__ __launch_bounds__(256) void k_det_trace_all(SumTex t, float *det, float *trace, OctSet S, const HaarGeo *geo)
+{
+    // Everything derived from the workgroup id is wave-uniform.  The octave comes from the ORIGINAL id (every octave's range is padded
+    // to a multiple of 8 workgroups), the XCD-contiguous remap is applied INSIDE the octave: a sample of octave o costs up to 10 x one of
+    // octave 0 (its 64 lanes read taps 4 << o bytes apart: 4 .. 32 cache lines per wave load), so an order that hands whole octaves
+    // to single XCDs leaves the other six idle (r03o / r03p: 1 285 us against 395 us for the four per-octave launches)
+    const int orig = blockIdx.x;
+    const int octave = __builtin_amdgcn_readfirstlane(find_octave(S.blk_dt, S.n, orig));
+    const int nbx = S.nbx[octave], nl2 = S.nlayers + 2;
+    const unsigned q = (unsigned)(orig - S.blk_dt[octave]), nwg = (unsigned)(S.blk_dt[octave + 1] - S.blk_dt[octave]);   // nwg % 8 == 0
+    const int loc = (int)((q & 7u) * (nwg >> 3) + (q >> 3));
+    if (loc >= nbx * S.nby[octave] * nl2) return;   // padding
+    const int bx = __builtin_amdgcn_readfirstlane(loc % nbx), layer = __builtin_amdgcn_readfirstlane((loc / nbx) % nl2),
+              by = __builtin_amdgcn_readfirstlane(loc / (nbx * nl2));
+    const int layer_rows = t.rows >> octave, layer_cols = t.cols >> octave;
+    const int jj = bx * 64 + (threadIdx.x & 63);
+    const int ii = by * 4 + (threadIdx.x >> 6);
+    if (jj >= layer_cols || ii >= layer_rows) return;
+    const int size = calc_size(octave, layer);
+    const int samples_i = 1 + ((t.rows - size) >> octave), samples_j = 1 + ((t.cols - size) >> octave);
+    const int margin = (size >> 1) >> octave;
+    const int i = ii - margin, j = jj - margin;
+    float d = 0.f, tr = 0.f;
+    if (size <= t.rows && size <= t.cols && i >= 0 && j >= 0 && i < samples_i && j < samples_j) {
+        // read-only for the life of the launch and wave-uniform: through the constant address space = scalar loads (s_load_dwordx16)
+        typedef const __attribute__((address_space(4))) HaarGeo cgeo_t;
+        cgeo_t &g = *((cgeo_t *)(unsigned long long)geo + (octave * kDetLayers + layer));
+        unsigned voff = 4u * ((unsigned)(i << octave) * (unsigned)t.sld + (unsigned)(j << octave));
+        asm volatile("" : "+v"(voff));
+        haar_det_trace(t, g, voff, d, tr);
+    }
+    const long long o = S.plane0[octave] + (long long)(layer * layer_rows + ii) * S.dld + jj;
+    det[o] = d;
+    trace[o] = tr;
+}
+
+// the octave's view of the shared argument block
+__device__ __forceinline__ NmsArgs oct_args(const NmsArgs &B, const OctSet &S, int octave)
+{
+    NmsArgs A = B;
+    A.octave = octave;
+    A.det = B.det + S.plane0[octave]; A.trace = B.trace + S.plane0[octave];
+    A.bits = B.bits + S.bits0[octave];
+    A.rowcnt = B.rowcnt + S.row0[octave] + octave;            // one extra entry (the total) per octave
+    A.segcnt = B.segcnt + S.seg0[octave];
+    A.chunks = S.chunks[octave]; A.nseg = S.nseg[octave];
+    return A;
+}
+__global__ __launch_bounds__(256) void k_nms_flag_all(NmsArgs B, OctSet S)
+{
+    const int octave = __builtin_amdgcn_readfirstlane(find_octave(S.blk_nms, S.n, blockIdx.x));
+    const int loc = blockIdx.x - S.blk_nms[octave], nseg = S.nseg[octave];
+    nms_flag_row(oct_args(B, S, octave), (loc / nseg) * 4 + (threadIdx.x >> 6), loc % nseg);
+}
+__global__ __launch_bounds__(1024) void k_scan_counts_all(NmsArgs B, OctSet S)
+{
+    const int octave = blockIdx.x;
+    const NmsArgs A = oct_args(B, S, octave);
+    scan_counts_body(A.rowcnt, A.segcnt, A.nseg, A.nlayers * (A.rows >> octave));
+}
+__global__ __launch_bounds__(256) void k_nms_write_all(NmsArgs B, OctSet S, int4 *cand, int max_candidates, unsigned *ncand)
+{
+    const int octave = __builtin_amdgcn_readfirstlane(find_octave(S.blk_wr, S.n, blockIdx.x));
+    nms_write_row(oct_args(B, S, octave), (blockIdx.x - S.blk_wr[octave]) * 4 + (threadIdx.x >> 6), cand + (long long)octave * max_candidates,
+                  max_candidates, ncand + octave);
+}
+__global__ __launch_bounds__(256) void k_interp_eval_all(const float *det, OctSet S, const int4 *cand, const unsigned *ncand, InterpOut *tmp,
+                                                         int max_candidates)
+{
+    const int octave = blockIdx.y;
+    interp_eval_one(det + S.plane0[octave], S.dld, S.rows, S.cols, octave, cand + (long long)octave * max_candidates, ncand + octave,
+                    tmp + (long long)octave * max_candidates, blockIdx.x * 256 + threadIdx.x);
+}
+__global__ __launch_bounds__(1024) void k_interp_compact_all(const InterpOut *tmp, const unsigned *ncand, int n_octaves, int max_candidates,
+                                                             float *kp, int kld, int max_features, unsigned *nfeat_p)
+{
+    unsigned nfeat = *nfeat_p;
+    for (int octave = 0; octave < n_octaves; ++octave)   // in octave order: the features of octave o follow those of octave o - 1
+        nfeat = interp_compact_body(tmp + (long long)octave * max_candidates, ncand + octave, octave, kp, kld, max_features, nfeat);
+    if (threadIdx.x == 0) *nfeat_p = nfeat;
+}
+
 // ------------------------------------------------------------------ host launchers
 int integral(const unsigned char *img, long long istep, int rows, int cols, bool clamp1, unsigned *V, unsigned *BT, int vld,
              unsigned *sum, int sld, hipStream_t s)
@@ -753,6 +885,72 @@ int interpolate(const float *det, int dld, int rows, int cols, int octave, const
     return MI_OK;
 }
 size_t interp_tmp_bytes(int max_candidates) { return sizeof(InterpOut) * (size_t)max_candidates; }
+
+// ---- all octaves per launch (k_*_all).  Sizes of the per-octave regions for a frame of rows x cols (the handle allocates them):
+static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctaveLayers)
+{
+    OctSet S;
+    memset(&S, 0, sizeof(S));
+    S.n = n_octaves; S.nlayers = nOctaveLayers; S.rows = rows; S.cols = cols; S.dld = dld;
+    long long plane = 0, bits = 0, seg = 0;
+    int row = 0;
+    for (int o = 0; o < n_octaves; ++o) {
+        const int lr = rows >> o, lc = cols >> o;
+        S.plane0[o] = plane; S.bits0[o] = bits; S.row0[o] = row; S.seg0[o] = seg;
+        S.chunks[o] = div_up(lc, 64); S.nseg[o] = div_up(S.chunks[o], kNmsSeg);
+        S.nbx[o] = div_up(lc, 64); S.nby[o] = div_up(lr, 4);
+        S.blk_dt[o + 1] = S.blk_dt[o] + align_up(S.nbx[o] * S.nby[o] * (nOctaveLayers + 2), 8);   // padded: see k_det_trace_all
+        S.blk_nms[o + 1] = S.blk_nms[o] + div_up(nOctaveLayers * lr, 4) * S.nseg[o];
+        S.blk_wr[o + 1] = S.blk_wr[o] + div_up(nOctaveLayers * lr, 4);
+        plane += (long long)(nOctaveLayers + 2) * lr * dld;
+        bits += (long long)nOctaveLayers * lr * S.chunks[o];
+        seg += (long long)nOctaveLayers * lr * S.nseg[o];
+        row += nOctaveLayers * lr;
+    }
+    return S;
+}
+bool fused_supported(int n_octaves, int nOctaveLayers) { return n_octaves <= kMaxFusedOctaves && nOctaveLayers + 2 <= kDetLayers; }
+void fused_sizes(int rows, int cols, int dld, int n_octaves, int nOctaveLayers, FusedSizes *z)
+{
+    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers);
+    const int last = n_octaves - 1, lr = rows >> last;
+    z->plane_floats = (size_t)(S.plane0[last] + (long long)(nOctaveLayers + 2) * lr * dld);
+    z->bits_words = (size_t)(S.bits0[last] + (long long)nOctaveLayers * lr * S.chunks[last]);
+    z->seg_counts = (size_t)(S.seg0[last] + (long long)nOctaveLayers * lr * S.nseg[last]);
+    z->row_counts = (size_t)(S.row0[last] + nOctaveLayers * lr + n_octaves);
+    z->geo_bytes = sizeof(HaarGeo) * (size_t)n_octaves * kDetLayers;
+}
+// geometry of every (octave, layer) of the frame size: uploaded by the handle when the size changes
+void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host)
+{
+    HaarGeo *g = (HaarGeo *)geo_host;
+    memset(g, 0, sizeof(HaarGeo) * (size_t)n_octaves * kDetLayers);
+    for (int o = 0; o < n_octaves; ++o)
+        for (int l = 0; l < nOctaveLayers + 2; ++l) g[o * kDetLayers + l] = haar_geo(calc_size(o, l), sld);
+}
+// surf.cuda.cpp:182-204 for all octaves: six launches.  ncand: n_octaves counters; nfeat: the feature counter (zeroed by the caller)
+int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int rows, int cols, int n_octaves, int nOctaveLayers, float thr,
+                 float *det, float *trace, int dld, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
+                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s)
+{
+    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers);
+    SumTex t = {sum, sld, rows, cols};
+    NmsArgs B;
+    memset(&B, 0, sizeof(B));
+    B.det = det; B.trace = trace; B.dld = dld; B.rows = rows; B.cols = cols; B.nlayers = nOctaveLayers; B.thr = thr;
+    B.mask.s = mask_sum; B.mask.sld = sld; B.mask.rows = rows; B.mask.cols = cols;
+    B.bits = bits; B.rowcnt = rowcnt; B.segcnt = segcnt;
+    hipLaunchKernelGGL(k_det_trace_all, dim3(S.blk_dt[n_octaves]), dim3(256), 0, s, t, det, trace, S, (const HaarGeo *)geo_dev);
+    hipLaunchKernelGGL(k_nms_flag_all, dim3(S.blk_nms[n_octaves]), dim3(256), 0, s, B, S);
+    hipLaunchKernelGGL(k_scan_counts_all, dim3(n_octaves), dim3(1024), 0, s, B, S);
+    hipLaunchKernelGGL(k_nms_write_all, dim3(S.blk_wr[n_octaves]), dim3(256), 0, s, B, S, cand, max_candidates, ncand);
+    hipLaunchKernelGGL(k_interp_eval_all, dim3(div_up(max_candidates, 256), n_octaves), dim3(256), 0, s, (const float *)det, S, (const int4 *)cand,
+                       (const unsigned *)ncand, (InterpOut *)tmp, max_candidates);
+    hipLaunchKernelGGL(k_interp_compact_all, dim3(1), dim3(1024), 0, s, (const InterpOut *)tmp, (const unsigned *)ncand, n_octaves, max_candidates, kp,
+                       kld, max_features, nfeat);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
 
 int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int kld, const unsigned *nfeat_dev, int n_or_max,
                 bool upright, const float *apt, hipStream_t s)

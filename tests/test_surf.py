@@ -156,6 +156,23 @@ def test_detect_and_describe_match_oracle(gpu, oracle, thr, octaves, layers, ext
 
 
 @gpu_mark
+@pytest.mark.parametrize("octaves,layers", [(3, 5), (4, 4), (2, 1)])
+def test_detect_per_octave_and_all_octave_launch_plans_agree_with_the_oracle(gpu, oracle, octaves, layers):
+    """Round 3: one launch per detector stage covers all octaves where the kernel arguments hold them (<= 6 octaves, nOctaveLayers + 2
+    <= 6 layers: every default); otherwise the octaves run one after the other through one set of planes (the round-2 plan).
+    (3, 5) takes the per-octave plan, (4, 4) and (2, 1) the all-octave plan at its layer limit / smallest size; one handle re-used
+    across a change of the plan must re-size its scratch."""
+    from opencv_contrib_amd import cuda
+    img = synth.blob_image(300, 400, seed=21)
+    for (o, l) in ((octaves, layers), (2, 2)):
+        ref = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=100.0, n_octaves=o, n_octave_layers=l, keypoints_ratio=0.05))
+        alg = cuda.SURF_CUDA.create(100.0, o, l, False, 0.05, False)
+        kpg, desc = alg.detectWithDescriptors(T(img, gpu))
+        assert ref["n"] > 20
+        _compare(cuda.SURF_CUDA.downloadKeypoints(kpg), N(desc), ref)
+
+
+@gpu_mark
 def test_detect_mask_overflow_and_provided_keypoints(gpu, oracle):
     from opencv_contrib_amd import cuda
     img = synth.blob_image(260, 330, seed=13)
