@@ -86,15 +86,18 @@ __device__ __forceinline__ void window_sums(const float (&R)[6][6], const float 
             for (int i = 0; i < 4; ++i) {
                 w[i] = wyv[j] * wxv[i];
                 t0[i] = R[j + 1][i + 1];
-                t1[i] = 0.5f * (R[j + 1][i + 2] - R[j + 1][i]);
-                t2[i] = 0.5f * (R[j + 2][i + 1] - R[j][i + 1]);
+                // the centred differences WITHOUT their factor 0.5: scaling by a power of two commutes with every rounding below
+                // (products and sums; nothing here comes near the subnormal range), so 0.5 * (sum of d w) == sum of (0.5 d) w bit
+                // for bit, and the 32 multiplies by 0.5 of a pixel become the two at the end
+                t1[i] = R[j + 1][i + 2] - R[j + 1][i];
+                t2[i] = R[j + 2][i + 1] - R[j][i + 1];
             }
             const float r0 = t0[0] * w[0] + t0[1] * w[1] + t0[2] * w[2] + t0[3] * w[3];
             const float r1 = t1[0] * w[0] + t1[1] * w[1] + t1[2] * w[2] + t1[3] * w[3];
             const float r2 = t2[0] * w[0] + t2[1] * w[1] + t2[2] * w[2] + t2[3] * w[3];
             if (j == 0) { s0 = r0; s1 = r1; s2 = r2; } else { s0 += r0; s1 += r1; s2 += r2; }
         }
-        v0 = s0; v1 = s1; v2 = s2;
+        v0 = s0; v1 = 0.5f * s1; v2 = 0.5f * s2;
     } else {
         float sum = 0.f, sumx = 0.f, sumy = 0.f, wsum = 0.f;
 #pragma unroll
@@ -103,12 +106,12 @@ __device__ __forceinline__ void window_sums(const float (&R)[6][6], const float 
             for (int i = 0; i < 4; ++i) {
                 const float wgt = wxv[i] * wyv[j];
                 sum += wgt * R[j + 1][i + 1];
-                sumx += wgt * (0.5f * (R[j + 1][i + 2] - R[j + 1][i]));
-                sumy += wgt * (0.5f * (R[j + 2][i + 1] - R[j][i + 1]));
+                sumx += wgt * (R[j + 1][i + 2] - R[j + 1][i]);   // the 0.5 of the centred difference: hoisted, see above
+                sumy += wgt * (R[j + 2][i + 1] - R[j][i + 1]);
                 wsum += wgt;
             }
         const float coeff = 1.0f / wsum;
-        v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
+        v0 = sum * coeff; v1 = (0.5f * sumx) * coeff; v2 = (0.5f * sumy) * coeff;
     }
 }
 
@@ -258,7 +261,7 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
             }
         }
         const float coeff = 1.0f / wsum;
-        v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
+        v0 = sum * coeff; v1 = (0.5f * sumx) * coeff; v2 = (0.5f * sumy) * coeff;
     }
     if (A.I1w) A.I1w[o] = v0;
     A.I1wx[o] = v1;

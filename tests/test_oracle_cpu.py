@@ -161,7 +161,10 @@ def test_bench_cpu_baseline_protocol_and_distinct_inputs(oracle):
         return oracle.tvl1_calc(a, b, p)
 
     cb = bench.timed_cpu_baseline(cpu_calc, base[:3], budget_s=0.0)
-    assert len(cb["times"]) >= 5 and cb["median_s"] > 0 and cb["threads"] <= cb["physical_cores"]
+    # >= 5 repetitions -- unless the host is so loaded (this suite under xdist beside other OpenMP tests) that 3 of them already passed
+    # the protocol's hard limit of 25 s, the one case in which it stops early
+    nrep = len(cb["times"])
+    assert (nrep >= 5 or (nrep >= 3 and sum(cb["times"]) > 25.0)) and cb["median_s"] > 0 and cb["threads"] <= cb["physical_cores"]
     assert cb["one_core"] and cb["one_core"]["cores"] == 1
-    assert len(calls) >= 1 + 1 + 5 + 1                  # sweep, warm-up, repetitions, one core
+    assert len(calls) >= 1 + 1 + nrep + 1               # sweep, warm-up, repetitions, one core
     np.testing.assert_array_equal(cb["ref0"], oracle.tvl1_calc(base[0][0], base[0][1], p))   # the thread count never changes a flow
