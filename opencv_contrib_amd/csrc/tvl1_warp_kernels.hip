@@ -261,7 +261,7 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
             }
         }
         const float coeff = 1.0f / wsum;
-        v0 = sum * coeff; v1 = (0.5f * sumx) * coeff; v2 = (0.5f * sumy) * coeff;
+        v0 = sum * coeff; v1 = sumx * coeff; v2 = sumy * coeff;
     }
     if (A.I1w) A.I1w[o] = v0;
     A.I1wx[o] = v1;

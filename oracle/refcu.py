@@ -230,3 +230,24 @@ def cuda_class_tvl1_calc(I0, I1, tau=0.25, lambda_=0.15, theta=0.3, nscales=5, w
     if rc:
         raise ValueError("the reference class threw")
     return flow, ns.value
+
+
+def cuda_class_farneback_calc(I0, I1, num_levels=5, pyr_scale=0.5, fast_pyramids=False, win_size=13, num_iters=10, poly_n=5, poly_sigma=1.1,
+                              flags=0, init_flow=None):
+    """cv::cuda::FarnebackOpticalFlow::create(...)->calc(I0, I1, flow): the reference's HOST class (modules/cudaoptflow/src/farneback.cpp,
+    compiled verbatim) over the reference's kernels (farneback.cu, resize.cu, pyr_down.cu)."""
+    I0, I1 = np.ascontiguousarray(I0), np.ascontiguousarray(I1)
+    assert I0.dtype == I1.dtype and I0.dtype in (np.uint8, np.float32) and I0.shape == I1.shape
+    h, w = I0.shape
+    flow = np.zeros((h, w, 2), np.float32)
+    if init_flow is not None:
+        flow[...] = init_flow
+    L = lib()
+    L.ref_cuhost_farneback_calc.restype = C.c_int
+    L.ref_cuhost_farneback_calc.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_int, _f32]
+    rc = L.ref_cuhost_farneback_calc(num_levels, pyr_scale, int(fast_pyramids), win_size, num_iters, poly_n, poly_sigma, flags,
+                                     I0.ctypes.data, I1.ctypes.data, 0 if I0.dtype == np.uint8 else 1, w, h, flow.reshape(-1))
+    if rc:
+        raise ValueError("the reference class threw")
+    return flow

@@ -7,9 +7,11 @@
 #include "opencv2/cudaoptflow.hpp"      // the reference's own header (-I $(REF)/modules/cudaoptflow/include)
 #include "opencv2/cudaarithm.hpp"
 #include "opencv2/cudawarping.hpp"
+#include "opencv2/video.hpp"
 #include <cmath>
 
 extern "C" void ref_cu_resize_linear_f32(const float *src, int sr, int sc, float *dst, int dr, int dc, float fy, float fx);
+extern "C" void ref_cu_pyr_down_f32(const float *src, int sr, int sc, float *dst, int dr, int dc);
 
 namespace cv { namespace cuda {
 
@@ -28,6 +30,20 @@ void GpuMat::convertTo(GpuMat &dst, int rtype, double alpha, Stream &) const
     }
     dst = out;
 }
+// GpuMat::convertTo(dst, rtype, stream): no scale -- 8U -> 32F is the exact conversion, 32F -> 32F a copy
+void GpuMat::convertTo(GpuMat &dst, int rtype, Stream &stream) const
+{
+    CV_Assert((rtype & 7) == CV_32F && channels() == 1);
+    if (depth() == CV_32F) { if (dst.data != data) copyTo(dst, stream); return; }
+    GpuMat out;
+    out.create(rows, cols, CV_32FC1);
+    for (int y = 0; y < rows; ++y) {
+        const unsigned char *s = ptr<unsigned char>(y);
+        float *d = out.ptr<float>(y);
+        for (int x = 0; x < cols; ++x) d[x] = (float)s[x];
+    }
+    dst = out;
+}
 GpuMat &GpuMat::setTo(Scalar s, Stream &)
 {
     CV_Assert(type() == CV_32FC1);
@@ -37,6 +53,7 @@ GpuMat &GpuMat::setTo(Scalar s, Stream &)
 void GpuMat::copyTo(GpuMat &dst, Stream &) const
 {
     dst.create(rows, cols, type());
+    if (dst.data == data) return;
     for (int y = 0; y < rows; ++y) memcpy(dst.ptr<unsigned char>(y), ptr<unsigned char>(y), (size_t)cols * elem_size_of(type()));
 }
 void GpuMat::download(Mat &dst, Stream &) const
@@ -76,6 +93,20 @@ void merge(const GpuMat *src, size_t n, OutputArray dst, Stream &)
     }
 }
 
+// cuda::split of a CV_32FC2 matrix into two CV_32FC1 planes (cudaarithm/src/cuda/split_merge.cu: de-interleave)
+void split(InputArray _src, std::vector<GpuMat> &dst, Stream &)
+{
+    const GpuMat src = _src.getGpuMat();
+    CV_Assert(src.type() == CV_32FC2);
+    dst.resize(2);
+    for (int c = 0; c < 2; ++c) dst[c].create(src.rows, src.cols, CV_32FC1);
+    for (int y = 0; y < src.rows; ++y) {
+        const float *s = src.ptr<float>(y);
+        float *a = dst[0].ptr<float>(y), *b = dst[1].ptr<float>(y);
+        for (int x = 0; x < src.cols; ++x) { a[x] = s[2 * x]; b[x] = s[2 * x + 1]; }
+    }
+}
+
 // cuda::calcSum: cudaarithm/src/cuda/sum.cu -- a CV_32F source is reduced in double (the reduction tree's association is the
 // device's; the value only feeds `error > scaledEpsilon`, a sequential double sum differs from any tree by ~1e-16 relative)
 void calcSum(InputArray src, OutputArray dst, InputArray mask, Stream &)
@@ -111,9 +142,52 @@ void resize(InputArray _src, OutputArray _dst, Size dsize, double fx, double fy,
     ref_cu_resize_linear_f32(s.data(), src.rows, src.cols, d.data(), dsize.height, dsize.width, static_cast<float>(1.0 / fy), static_cast<float>(1.0 / fx));
     for (int y = 0; y < dsize.height; ++y) memcpy(dst.ptr<float>(y), &d[(size_t)y * dsize.width], sizeof(float) * dsize.width);
 }
+
+// cuda::pyrDown: cudawarping/src/pyramids.cpp:60-88 (dst size) around the reference's pyrDown kernel
+void pyrDown(InputArray _src, OutputArray _dst, Stream &)
+{
+    const GpuMat src = _src.getGpuMat();
+    CV_Assert(src.type() == CV_32FC1);
+    _dst.create(Size((src.cols + 1) / 2, (src.rows + 1) / 2), src.type());
+    GpuMat &dst = *_dst.gpuMatPtr();
+    std::vector<float> s((size_t)src.rows * src.cols), d((size_t)dst.rows * dst.cols);
+    for (int y = 0; y < src.rows; ++y) memcpy(&s[(size_t)y * src.cols], src.ptr<float>(y), sizeof(float) * src.cols);
+    ref_cu_pyr_down_f32(s.data(), src.rows, src.cols, d.data(), dst.rows, dst.cols);
+    for (int y = 0; y < dst.rows; ++y) memcpy(dst.ptr<float>(y), &d[(size_t)y * dst.cols], sizeof(float) * dst.cols);
+}
 }}  // namespace cv::cuda
 
 extern "C" {
+/* cv::cuda::FarnebackOpticalFlow::create(...)->calc(I0, I1, flow): the reference host class (modules/cudaoptflow/src/farneback.cpp,
+ * verbatim) over the reference kernels.  Frames as in ref_cuhost_tvl1_calc; flags & OPTFLOW_USE_INITIAL_FLOW reads `flow`.
+ * Returns 0, or 1 if the class threw. */
+int ref_cuhost_farneback_calc(int num_levels, double pyr_scale, int fast_pyramids, int win_size, int num_iters, int poly_n, double poly_sigma,
+                              int flags, const void *I0, const void *I1, int type, int cols, int rows, float *flow)
+{
+    using namespace cv;
+    try {
+        Ptr<cuda::FarnebackOpticalFlow> alg = cuda::FarnebackOpticalFlow::create(num_levels, pyr_scale, fast_pyramids != 0, win_size, num_iters,
+                                                                                 poly_n, poly_sigma, flags);
+        const int t = type == 0 ? CV_8UC1 : CV_32FC1;
+        cuda::GpuMat a(Size(cols, rows), t), b(Size(cols, rows), t), f;
+        const size_t rb = (size_t)cols * elem_size_of(t);
+        for (int y = 0; y < rows; ++y) {
+            memcpy(a.ptr<unsigned char>(y), (const unsigned char *)I0 + y * rb, rb);
+            memcpy(b.ptr<unsigned char>(y), (const unsigned char *)I1 + y * rb, rb);
+        }
+        if (flags & OPTFLOW_USE_INITIAL_FLOW) {
+            f.create(Size(cols, rows), CV_32FC2);
+            for (int y = 0; y < rows; ++y) memcpy(f.ptr<float>(y), flow + (size_t)y * cols * 2, sizeof(float) * cols * 2);
+        }
+        alg->calc(a, b, f, cuda::Stream::Null());
+        CV_Assert(f.rows == rows && f.cols == cols && f.type() == CV_32FC2);
+        for (int y = 0; y < rows; ++y) memcpy(flow + (size_t)y * cols * 2, f.ptr<float>(y), sizeof(float) * cols * 2);
+        return 0;
+    } catch (const std::exception &) {
+        return 1;
+    }
+}
+
 /* cv::cuda::OpticalFlowDual_TVL1::create(...)->calc(I0, I1, flow): the reference host class over the reference kernels.
  * I0 / I1: rows x cols, type 0 = CV_8UC1, 1 = CV_32FC1 (dense); flow: rows x cols x 2 floats; *nscales_out = nscales after the call
  * (the class shrinks it for small images).  Returns 0, or 1 if the class threw. */

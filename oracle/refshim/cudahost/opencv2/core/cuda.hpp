@@ -11,10 +11,18 @@
  * REFERENCE code end to end (VERDICT r02 missing #4).  What this stub supplies: GpuMat as host memory, Stream / BufferPool as
  * no-ops, InputArray proxies, and the five cv::cuda functions the file calls (cudahost.cpp: convertTo, setTo, multiply, merge,
  * calcSum, resize -- host glue of cudaarithm / cudawarping / core restated from the cited lines; their kernels are elementwise).
+ *
+ * The same for cv::cuda::FarnebackOpticalFlow -- modules/cudaoptflow/src/farneback.cpp, verbatim, over the reference's farneback.cu,
+ * resize.cu and pyr_down.cu kernels: calc / calcImpl (level cropping, the per-level blur + resize or the pyrDown pyramid, the flow
+ * upsampling, prepareGaussian, the iteration loop) are reference code.  Added for it: Event, Stream's bool / waitEvent, Mat_<double>
+ * with the Cholesky inverse of a 6 x 6 matrix (main repo core/src/matrix_decomp.cpp CholImpl, restated), getGaussianKernel (main
+ * repo imgproc/src/smooth.dispatch.cpp, restated), cuda::split / pyrDown.
  */
 #ifndef ORACLE_CUDAHOST_CORE_CUDA_HPP
 #define ORACLE_CUDAHOST_CORE_CUDA_HPP
 #include "../../../cudashim/opencv2/core/cuda/common.hpp"   // PtrStepSz / cudaStream_t exactly as the kernels of libref_cu.so were built with
+#include <cfloat>
+#include <cmath>
 #include <limits>
 #include <memory>
 #include <string>
@@ -41,6 +49,9 @@
 namespace cv {
 typedef std::string String;
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2 };
+enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRAP = 3, BORDER_REFLECT101 = 4 };
+enum { DECOMP_LU = 0, DECOMP_SVD = 1, DECOMP_EIG = 2, DECOMP_CHOLESKY = 3 };
+inline int cvRound(double v) { return (int)lrint(v); }   // round half to even, like the SSE2 path of core/fast_math.hpp
 struct Size {
     int width = 0, height = 0;
     Size() {}
@@ -52,6 +63,8 @@ struct Size {
 struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
 struct Scalar {
     double val[4] = {0, 0, 0, 0};
+    Scalar() {}
+    Scalar(double v0) { val[0] = v0; }
     static Scalar all(double v) { Scalar s; s.val[0] = s.val[1] = s.val[2] = s.val[3] = v; return s; }
     double operator[](int i) const { return val[i]; }
 };
@@ -64,18 +77,95 @@ public:
 };
 inline size_t elem_size_of(int type) { const int d = type & 7, cn = (type >> 3) + 1; return (size_t)cn * (d == CV_8U ? 1 : d == CV_64F ? 8 : 4); }
 
-class Mat {   // only what diff_sum_host needs: a 1 x 1 CV_64F element
+class Mat {   // only what the two host files need: a 1 x 1 CV_64F element (diff_sum_host), an n x 1 CV_32F column (getGaussianKernel)
 public:
     int rows = 0, cols = 0;
-    std::vector<double> v;
+    std::vector<double> v;   // 8 bytes per element whatever the type: at<T> / ptr<T> reinterpret the front of each
     template <typename T> T &at(int y, int x) { return reinterpret_cast<T &>(v[(size_t)y * cols + x]); }
+    std::vector<float> f;    // CV_32F storage (dense)
+    template <typename T> T *ptr(int y) { static_assert(sizeof(T) == 4, "CV_32F rows only"); return reinterpret_cast<T *>(&f[(size_t)y * cols]); }
 };
+// Mat_<double>: the 6 x 6 normal matrix of FarnebackOpticalFlowImpl::prepareGaussian and its inverse
+template <typename T> class Mat_ {
+public:
+    int rows = 0, cols = 0;
+    std::vector<T> v;
+    Mat_() {}
+    Mat_(int r, int c) : rows(r), cols(c), v((size_t)r * c) {}
+    void setTo(T s) { for (auto &e : v) e = s; }
+    T &operator()(int y, int x) { return v[(size_t)y * cols + x]; }
+    const T &operator()(int y, int x) const { return v[(size_t)y * cols + x]; }
+    // Mat::inv(DECOMP_CHOLESKY) of an n x n matrix, n > 3 (core/src/lapack.cpp cv::invert: dst = I, then hal::Cholesky(src, dst) solves
+    // L L^T X = I in place; core/src/matrix_decomp.cpp CholImpl: L stored with RECIPROCAL diagonal, sums accumulated in double)
+    Mat_ inv(int method) const
+    {
+        CV_Assert(method == DECOMP_CHOLESKY && rows == cols);
+        const int m = rows;
+        Mat_ A = *this, B(m, m);
+        B.setTo(0);
+        for (int i = 0; i < m; ++i) B(i, i) = 1;
+        for (int i = 0; i < m; ++i) {
+            for (int j = 0; j < i; ++j) {
+                double s = A(i, j);
+                for (int k = 0; k < j; ++k) s -= A(i, k) * A(j, k);
+                A(i, j) = s * A(j, j);
+            }
+            double s = A(i, i);
+            for (int k = 0; k < i; ++k) { const double t = A(i, k); s -= t * t; }
+            if (s < std::numeric_limits<T>::epsilon()) { B.setTo(0); return B; }   // cv::invert returns 0 and zeroes dst
+            A(i, i) = 1. / std::sqrt(s);
+        }
+        for (int i = 0; i < m; ++i)          // L y = b
+            for (int j = 0; j < m; ++j) {
+                double s = B(i, j);
+                for (int k = 0; k < i; ++k) s -= A(i, k) * B(k, j);
+                B(i, j) = s * A(i, i);
+            }
+        for (int i = m - 1; i >= 0; --i)     // L^T x = y
+            for (int j = 0; j < m; ++j) {
+                double s = B(i, j);
+                for (int k = m - 1; k > i; --k) s -= A(k, i) * B(k, j);
+                B(i, j) = s * A(i, i);
+            }
+        return B;
+    }
+};
+// cv::getGaussianKernel(n, sigma, CV_32F) (imgproc.hpp; main repo imgproc/src/smooth.dispatch.cpp): the fixed tables for n <= 7 with
+// sigma <= 0, else exp(-x^2 / (2 sigma^2)) over x = i - (n - 1) / 2, normalised in double, rounded to float
+inline Mat getGaussianKernel(int n, double sigma, int ktype)
+{
+    CV_Assert(ktype == CV_32F && n > 0);
+    Mat k;
+    k.rows = n; k.cols = 1; k.f.resize(n);
+    static const float small[4][7] = {{1.f}, {0.25f, 0.5f, 0.25f}, {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                      {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    if (sigma <= 0 && (n & 1) && n <= 7) {
+        for (int i = 0; i < n; ++i) k.f[i] = small[n >> 1][i];
+        return k;
+    }
+    const double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8, s2 = -0.5 / (sx * sx);
+    std::vector<double> w(n);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = std::exp(s2 * x * x); sum += w[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) k.f[i] = (float)(w[i] * sum);
+    return k;
+}
 
 namespace cuda {
-class Stream {
+enum FeatureSet { FEATURE_SET_COMPUTE_10 = 10, FEATURE_SET_COMPUTE_11 = 11, FEATURE_SET_COMPUTE_12 = 12, FEATURE_SET_COMPUTE_13 = 13 };
+inline bool deviceSupports(FeatureSet) { return true; }
+class Event;
+class Stream {   // every call of this stub runs synchronously on the host: the streams only order work that is already ordered
 public:
     void waitForCompletion() {}
+    void waitEvent(const Event &) {}
+    explicit operator bool() const { return false; }   // "the default stream": FarnebackOpticalFlowImpl::calcImpl then skips its event plumbing
     static Stream &Null() { static Stream s; return s; }
+};
+class Event {
+public:
+    void record(Stream & = Stream::Null()) {}
 };
 class GpuMat {   // host memory; views share the buffer (like the reference's refcounted device buffers)
 public:
@@ -84,6 +174,7 @@ public:
     unsigned char *data = nullptr;
     GpuMat() {}
     GpuMat(Size s, int type) { create(s, type); }
+    GpuMat(int r, int c, int type) { create(r, c, type); }
     int type() const { return type_; }
     int depth() const { return type_ & 7; }
     int channels() const { return (type_ >> 3) + 1; }
@@ -111,6 +202,7 @@ public:
     template <typename T> operator PtrStepSz<T>() const { return PtrStepSz<T>(rows, cols, (T *)data, step); }
     // cudahost.cpp
     void convertTo(GpuMat &dst, int rtype, double alpha, Stream &stream) const;
+    void convertTo(GpuMat &dst, int rtype, Stream &stream) const;
     GpuMat &setTo(Scalar s, Stream &stream);
     void download(Mat &dst, Stream &stream) const;
     void copyTo(GpuMat &dst, Stream &stream) const;
@@ -118,6 +210,7 @@ private:
     int type_ = CV_8UC1;
     std::shared_ptr<std::vector<unsigned char> > buf_;
 };
+inline void swap(GpuMat &a, GpuMat &b) { GpuMat t = a; a = b; b = t; }
 }  // namespace cuda
 
 // InputArray / OutputArray proxies over GpuMat (the only kind this translation unit passes)

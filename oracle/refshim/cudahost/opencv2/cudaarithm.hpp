@@ -9,5 +9,7 @@ void multiply(const GpuMat &src1, const Scalar &src2, GpuMat &dst, double scale,
 void merge(const GpuMat *src, size_t n, OutputArray dst, Stream &stream);
 // cudaarithm.hpp: calcSum(src, dst, mask, stream): dst = 1 x 1 CV_64FC(cn)
 void calcSum(InputArray src, OutputArray dst, InputArray mask, Stream &stream);
+// cudaarithm.hpp: split(InputArray src, std::vector<GpuMat>& dst, Stream&) -- farneback.cpp:185 (OPTFLOW_USE_INITIAL_FLOW)
+void split(InputArray src, std::vector<GpuMat> &dst, Stream &stream);
 }}
 #endif

@@ -5,5 +5,8 @@
 #include "opencv2/core/cuda.hpp"
 namespace cv { namespace cuda {
 void resize(InputArray src, OutputArray dst, Size dsize, double fx, double fy, int interpolation, Stream &stream);
+// cudawarping.hpp: pyrDown(src, dst, stream); host glue cudawarping/src/pyramids.cpp (dst = ((rows + 1) / 2, (cols + 1) / 2)), kernel = the
+// reference's pyrDown of libref_cu.so
+void pyrDown(InputArray src, OutputArray dst, Stream &stream);
 }}
 #endif
