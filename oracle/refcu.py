@@ -251,3 +251,22 @@ def cuda_class_farneback_calc(I0, I1, num_levels=5, pyr_scale=0.5, fast_pyramids
     if rc:
         raise ValueError("the reference class threw")
     return flow
+
+
+def cuda_class_stereobm_compute(left, right, ndisp=64, block=19, prefilter_type=-1, prefilter_size=-1, prefilter_cap=-1, texture_threshold=-1,
+                                uniqueness_ratio=-1):
+    """cv::cuda::createStereoBM(ndisp, block)->compute(left, right, disp): the reference's HOST class (modules/cudastereo/src/stereobm.cpp,
+    compiled verbatim) over the reference's kernels (stereobm.cu).  -1 = leave the constructor's value (no prefilter, cap 31, size 9,
+    texture threshold 3, uniqueness 0)."""
+    left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+    assert left.dtype == np.uint8 and right.dtype == np.uint8 and left.shape == right.shape
+    h, w = left.shape
+    disp = np.zeros((h, w), np.uint8)
+    L = lib()
+    L.ref_cuhost_stereobm_compute.restype = C.c_int
+    L.ref_cuhost_stereobm_compute.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rc = L.ref_cuhost_stereobm_compute(ndisp, block, prefilter_type, prefilter_size, prefilter_cap, texture_threshold, uniqueness_ratio,
+                                       left.ctypes.data, right.ctypes.data, w, h, disp.ctypes.data)
+    if rc:
+        raise ValueError("the reference class threw")
+    return disp

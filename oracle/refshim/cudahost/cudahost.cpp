@@ -4,7 +4,8 @@
  * elementwise loops or the reference kernels of libref_cu.so), and the C entry point that drives
  * cv::cuda::OpticalFlowDual_TVL1 (modules/cudaoptflow/src/tvl1flow.cpp, compiled verbatim by oracle/Makefile.ref).
  */
-#include "opencv2/cudaoptflow.hpp"      // the reference's own header (-I $(REF)/modules/cudaoptflow/include)
+#include "opencv2/cudaoptflow.hpp"      // the reference's own headers (-I $(REF)/modules/cudaoptflow/include, .../cudastereo/include)
+#include "opencv2/cudastereo.hpp"
 #include "opencv2/cudaarithm.hpp"
 #include "opencv2/cudawarping.hpp"
 #include "opencv2/video.hpp"
@@ -213,6 +214,36 @@ int ref_cuhost_tvl1_calc(double tau, double lambda, double theta, int nscales, i
         alg->calc(a, b, f, cuda::Stream::Null());
         for (int y = 0; y < rows; ++y) memcpy(flow + (size_t)y * cols * 2, f.ptr<float>(y), sizeof(float) * cols * 2);
         if (nscales_out) *nscales_out = alg->getNumScales();
+        return 0;
+    } catch (const std::exception &) {
+        return 1;
+    }
+}
+
+/* cv::cuda::createStereoBM(ndisp, block)->compute(left, right, disp): the reference host class (modules/cudastereo/src/stereobm.cpp, verbatim)
+ * over the reference kernels (stereobm.cu).  prefilter_type -1 = none (the constructor's preset_), 0 / 1 = cv::StereoBM::PREFILTER_*.
+ * Returns 0, or 1 if the class threw (its CV_Asserts on ndisp / block size / types). */
+int ref_cuhost_stereobm_compute(int ndisp, int block, int prefilter_type, int prefilter_size, int prefilter_cap, int texture_threshold,
+                                int uniqueness_ratio, const unsigned char *left, const unsigned char *right, int cols, int rows,
+                                unsigned char *disp)
+{
+    using namespace cv;
+    try {
+        Ptr<cuda::StereoBM> bm = cuda::createStereoBM(ndisp, block);
+        if (prefilter_type >= 0) bm->setPreFilterType(prefilter_type);
+        if (prefilter_size >= 0) bm->setPreFilterSize(prefilter_size);
+        if (prefilter_cap >= 0) bm->setPreFilterCap(prefilter_cap);
+        if (texture_threshold >= 0) bm->setTextureThreshold(texture_threshold);
+        if (uniqueness_ratio >= 0) bm->setUniquenessRatio(uniqueness_ratio);
+        cuda::GpuMat l(Size(cols, rows), CV_8UC1), r(Size(cols, rows), CV_8UC1), d;
+        for (int y = 0; y < rows; ++y) {
+            memcpy(l.ptr<unsigned char>(y), left + (size_t)y * cols, cols);
+            memcpy(r.ptr<unsigned char>(y), right + (size_t)y * cols, cols);
+        }
+        for (int rep = 0; rep < 2; ++rep)   // twice: the second call reuses minSSD_ / leBuf_ / riBuf_ (ensureSizeIsEnough keeps them)
+            bm->compute(l, r, d, cuda::Stream::Null());
+        CV_Assert(d.rows == rows && d.cols == cols && d.type() == CV_8UC1);
+        for (int y = 0; y < rows; ++y) memcpy(disp + (size_t)y * cols, d.ptr<unsigned char>(y), cols);
         return 0;
     } catch (const std::exception &) {
         return 1;

@@ -34,14 +34,17 @@
 #define CV_WRAP
 #define CV_OUT
 #define CV_IN_OUT
+#define CV_WRAP_AS(x)
 #define CV_OVERRIDE override
 #define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error("CV_Assert failed: " #expr); } while (0)
 #define CV_DbgAssert(expr) CV_Assert(expr)
 #define CV_8U 0
+#define CV_32S 4
 #define CV_32F 5
 #define CV_64F 6
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_32SC1 CV_MAKETYPE(CV_32S, 1)
 #define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
 #define CV_32FC2 CV_MAKETYPE(CV_32F, 2)
 #define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
@@ -211,6 +214,12 @@ private:
     std::shared_ptr<std::vector<unsigned char> > buf_;
 };
 inline void swap(GpuMat &a, GpuMat &b) { GpuMat t = a; a = b; b = t; }
+// cuda::ensureSizeIsEnough (core/src/cuda/gpu_mat.cu... core/cuda.inl.hpp): keep a buffer that is large enough and take its top-left view
+inline void ensureSizeIsEnough(Size s, int type, GpuMat &m)
+{
+    if (!m.empty() && m.type() == type && m.rows >= s.height && m.cols >= s.width) m = m(Rect(0, 0, s.width, s.height));
+    else m.create(s, type);
+}
 }  // namespace cuda
 
 // InputArray / OutputArray proxies over GpuMat (the only kind this translation unit passes)
@@ -218,6 +227,7 @@ class _InputArray {
 public:
     _InputArray() : m_(nullptr) {}
     _InputArray(const cuda::GpuMat &m) : m_(const_cast<cuda::GpuMat *>(&m)) {}
+    _InputArray(const Mat &) : m_(nullptr) {}   // cudastereo.hpp:360 casts a Mat Q; never called here
     cuda::GpuMat getGpuMat() const { return m_ ? *m_ : cuda::GpuMat(); }
     bool empty() const { return !m_ || m_->empty(); }
     cuda::GpuMat *gpuMatPtr() const { return m_; }
