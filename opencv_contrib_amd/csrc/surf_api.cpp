@@ -32,13 +32,18 @@ struct mi_surf {
 
 static int calc_size(int octave, int layer) { return (9 + 6 * layer) << octave; }
 
-static void gauss(int n, double sigma, float *k)   // cv::getGaussianKernel(n, sigma > 0, CV_32F)
+// The Gaussian kernel behind surf.cu's literal weight tables (c_aptW :522, c_DW :685-707): cv::getGaussianKernel(n, sigma, CV_32F) as
+// OpenCV 2.4 rounded it -- exp() in double rounded to float, the float terms summed in double, float * (1 / sum) in double rounded to
+// float -- for the CPU class's float sigmas promoted to double.  The outer products below reproduce every literal bit for bit
+// (tests/test_ref_pin_cuda.py::test_surf_weight_tables_equal_the_literals_of_surf_cu checks the same generator in the oracle against the
+// parsed reference file).
+static void gauss_tab(int n, float sigma_f, float *k)
 {
-    const double scale2 = -0.5 / (sigma * sigma);
-    std::vector<double> w(n);
+    const double sigma = (double)sigma_f, scale2 = -0.5 / (sigma * sigma);
     double sum = 0;
-    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = std::exp(scale2 * x * x); sum += w[i]; }
-    for (int i = 0; i < n; ++i) k[i] = (float)(w[i] / sum);
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = (float)std::exp(scale2 * x * x); sum += k[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
 }
 
 extern "C" {
@@ -61,15 +66,15 @@ int mi_surf_create(const mi_surf_params *p, mi_surf **out)
     }
     mi_surf *h = new mi_surf();
     if (p) h->P = *p; else mi_surf_default_params(&h->P);
-    // orientation samples: disc of radius 6, weights = outer product of getGaussianKernel(13, 2.5) (surf.cpp:544-556);
-    // descriptor weights: outer product of getGaussianKernel(20, 3.3) (surf.cpp:560-565)
+    // orientation samples: disc of radius 6 (c_aptX / c_aptY, surf.cu:520-521), weights c_aptW (:522) = outer product of the 13-tap
+    // kernel for sigma 2.5f; descriptor weights c_DW (:685-707) = outer product of the 20-tap kernel for sigma 3.3f
     float g[13], G[20], apt[3 * 113], dw[400];
-    gauss(13, 2.5, g);
+    gauss_tab(13, 2.5f, g);
     int k = 0;
     for (int i = -6; i <= 6; i++)
         for (int j = -6; j <= 6; j++)
             if (i * i + j * j <= 36) { apt[k] = (float)i; apt[113 + k] = (float)j; apt[226 + k] = g[i + 6] * g[j + 6]; ++k; }
-    gauss(20, 3.3, G);
+    gauss_tab(20, 3.3f, G);
     for (int i = 0; i < 20; i++) for (int j = 0; j < 20; j++) dw[i * 20 + j] = G[i] * G[j];
     auto upload = [&]() -> int {
         MI_HIP_TRY(hipMalloc((void **)&h->apt, sizeof(apt)));

@@ -1,8 +1,12 @@
 // SURF detect + describe (cv::cuda::SURF_CUDA) -- HIP kernels for gfx950 (MI355X, CDNA4), wave64.
 //
-// Reference: modules/xfeatures2d/src/cuda/surf.cu:122-942 driven by src/surf.cuda.cpp:134-255; texture-free
-// definitions (clamped point reads, bilinear/area patch filters, 3x3 solve) from the reference's OpenCL twin
-// src/opencl/surf.cl:55-68,413-441,873-952 (CDNA has no sampler path worth relying on).
+// Reference: modules/xfeatures2d/src/cuda/surf.cu:122-942 driven by src/surf.cuda.cpp:134-255.  What surf.cu reaches through main-repo
+// device headers is written out here as those headers define it (and as oracle/refshim/cudashim restates them to RUN surf.cu on the
+// host, tests/test_ref_pin_cuda.py): point-sampled clamp-addressed texture reads = texel (floor(x), floor(y)); core/cuda/filters.hpp's
+// LinearFilter / AreaFilter return saturate_cast<uchar> for WinReader (8-bit patch samples) and AreaFilter normalises by the window's
+// remainder in its last row / column; core/cuda/utility.hpp's solve3x3 takes 1 / det in double; reduce<N> is the shfl_down tree per
+// warp, then over the warps' partials.  (Rounds 1-2 followed the OpenCL twin surf.cl:55-68,413-441,873-952 for these; the CUDA-source
+// pin of round 3 showed where the CUDA class differs.)  CDNA has no sampler path worth relying on: plain loads.
 // MI355X formulation:
 //   * no __constant__ state (the reference loads 9 symbols per call and serialises every call behind a mutex,
 //     surf.cuda.cpp:117,371): parameters are kernel arguments, tables live in the handle;
@@ -373,19 +377,19 @@ __global__ __launch_bounds__(256) void k_nms_write(NmsArgs A, int4 *cand, int ma
 }
 
 // ------------------------------------------------------------------ sub-pixel interpolation
-// surf.cl:413-441
+// core/cuda/utility.hpp solve3x3<float>: the reciprocal of the determinant in double, the components rounded back to float
 __device__ __forceinline__ bool solve3x3(const float A[3][3], const float b[3], float x[3])
 {
     const float det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
     if (det != 0) {
-        const float invdet = 1.0f / det;
-        x[0] = invdet * (b[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (b[1] * A[2][2] - A[1][2] * b[2]) +
-                         A[0][2] * (b[1] * A[2][1] - A[1][1] * b[2]));
-        x[1] = invdet * (A[0][0] * (b[1] * A[2][2] - A[1][2] * b[2]) - b[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                         A[0][2] * (A[1][0] * b[2] - b[1] * A[2][0]));
-        x[2] = invdet * (A[0][0] * (A[1][1] * b[2] - b[1] * A[2][1]) - A[0][1] * (A[1][0] * b[2] - b[1] * A[2][0]) +
-                         b[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]));
+        const double invdet = 1.0 / (double)det;
+        x[0] = (float)(invdet * (double)(b[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (b[1] * A[2][2] - A[1][2] * b[2]) +
+                                         A[0][2] * (b[1] * A[2][1] - A[1][1] * b[2])));
+        x[1] = (float)(invdet * (double)(A[0][0] * (b[1] * A[2][2] - A[1][2] * b[2]) - b[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                                         A[0][2] * (A[1][0] * b[2] - b[1] * A[2][0])));
+        x[2] = (float)(invdet * (double)(A[0][0] * (A[1][1] * b[2] - b[1] * A[2][1]) - A[0][1] * (A[1][0] * b[2] - b[1] * A[2][0]) +
+                                         b[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0])));
         return true;
     }
     return false;
@@ -582,24 +586,26 @@ __global__ __launch_bounds__(256) void k_fill_angle(float *kp, int kld, const un
 }
 
 // ------------------------------------------------------------------ descriptors
-struct Win { const unsigned char *img; long long step; int rows, cols; float cx, cy, off, c, s; };
+struct Win { const unsigned char *img; long long step; int rows, cols, win; float cx, cy, off, c, s; };
 __device__ __forceinline__ float win_get(const Win &w, int i, int j)
 {
-    // WinReader (surf.cu:709-731) + read_imgTex_ (surf.cl:62-68): nearest texel, round-to-nearest-even, clamp
+    // WinReader (surf.cu:709-731) over a point-sampled, clamp-addressed texture: texel (floor(x), floor(y))
     const float px = w.cx + (w.off + j) * w.c + (w.off + i) * w.s;
     const float py = w.cy - (w.off + j) * w.s + (w.off + i) * w.c;
-    const int x = clampi(rn(px), 0, w.cols - 1), y = clampi(rn(py), 0, w.rows - 1);
+    const int x = clampi(__float2int_rd(px), 0, w.cols - 1), y = clampi(__float2int_rd(py), 0, w.rows - 1);
     return (float)w.img[(long long)y * w.step + x];
 }
-__device__ float linear_filter(const Win &w, float y, float x)   // surf.cl:873-898
+// saturate_cast<uchar>(float) = cvt.rni.sat.u8.f32: round to nearest even, saturate -- the filters below return WinReader::elem_type
+__device__ __forceinline__ float sat_u8(float v) { return fminf(fmaxf(rintf(v), 0.f), 255.f); }
+__device__ float linear_filter(const Win &w, float y, float x)   // core/cuda/filters.hpp LinearFilter (s <= 1: provided keypoints only)
 {
     float out = 0.0f;
-    const int x1 = (int)roundf(x), y1 = (int)roundf(y), x2 = x1 + 1, y2 = y1 + 1;
+    const int x1 = __float2int_rd(x), y1 = __float2int_rd(y), x2 = x1 + 1, y2 = y1 + 1;
     out = out + win_get(w, y1, x1) * ((x2 - x) * (y2 - y));
     out = out + win_get(w, y1, x2) * ((x - x1) * (y2 - y));
     out = out + win_get(w, y2, x1) * ((x2 - x) * (y - y1));
     out = out + win_get(w, y2, x2) * ((x - x1) * (y - y1));
-    return out;
+    return sat_u8(out);
 }
 // sum_{dx in [a, b)} win_get(w, dy, dx) * wgt accumulated onto `out` in ascending dx order (the reference's order);
 // the texel reads of 8 consecutive dx are issued together so their latencies overlap (the adds stay sequential)
@@ -624,13 +630,13 @@ __device__ __forceinline__ float row_accum(const Win &w, int dy, int a, int b, f
     return out;
 }
 
-__device__ float area_filter(const Win &w, float x, float y, float s)   // surf.cl:900-952
+__device__ float area_filter(const Win &w, float x, float y, float s)   // core/cuda/filters.hpp AreaFilter with scale_x = scale_y = s
 {
     const float fsx1 = x * s, fsx2 = fsx1 + s;
     const int sx1 = (int)ceilf(fsx1), sx2 = (int)floorf(fsx2);
     const float fsy1 = y * s, fsy2 = fsy1 + s;
     const int sy1 = (int)ceilf(fsy1), sy2 = (int)floorf(fsy2);
-    const float scale = 1.f / (s * s);
+    const float scale = 1.f / (fminf(s, w.win - fsx1) * fminf(s, w.win - fsy1));   // src.width = src.height = win_size (surf.cu:754)
     float out = 0.f;
     for (int dy = sy1; dy < sy2; ++dy) {
         out = row_accum(w, dy, sx1, sx2, scale, out);
@@ -643,7 +649,7 @@ __device__ float area_filter(const Win &w, float x, float y, float s)   // surf.
     if ((sy1 > fsy1) && (sx2 < fsx2)) out = out + win_get(w, sy1 - 1, sx2) * ((sy1 - fsy1) * (fsx2 - sx2) * scale);
     if ((sy2 < fsy2) && (sx2 < fsx2)) out = out + win_get(w, sy2, sx2) * ((fsy2 - sy2) * (fsx2 - sx2) * scale);
     if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + win_get(w, sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
-    return out;
+    return sat_u8(out);
 }
 
 // surf.cu:733-912: one workgroup (8 waves) per feature: 21x21 patch (one sample per thread) -> 16 sub-regions of 25
@@ -662,6 +668,7 @@ __global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, l
     w.img = img; w.step = istep; w.rows = rows; w.cols = cols; w.cx = kp[f]; w.cy = kp[kld + f];
     const float s = kp[4 * kld + f] * 1.2f / 9.0f;
     const int win_size = (int)(21 * s);
+    w.win = win_size;
     w.off = -(win_size - 1.0f) / 2.0f;
     float ddir = 360.0f - kp[5 * kld + f];
     if (fabsf(ddir - 360.f) < FLT_EPSILON) ddir = 0.f;
@@ -700,19 +707,17 @@ __global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, l
         }
     }
     __syncthreads();
-    // normalize_descriptors<N> (surf.cu:891-912): halving tree over the squares, val / sqrt(len)
+    // normalize_descriptors<N> (surf.cu:891-912): len = device::reduce<N> of the squares = the 32-lane tree in each of the N / 32 warps,
+    // then the tree over the warps' partials (core/cuda/detail/reduce.hpp, GenericOptimized32); val / sqrt(len)
     constexpr int N = EXT ? 128 : 64;
-    __shared__ float sq[128];
-    if (threadIdx.x < N) sq[threadIdx.x] = D[threadIdx.x] * D[threadIdx.x];
-    __syncthreads();
-    for (int off = N / 2; off >= 1; off >>= 1) {
-        float v = 0.f;
-        if ((int)threadIdx.x < off) v = sq[threadIdx.x] + sq[threadIdx.x + off];
-        __syncthreads();
-        if ((int)threadIdx.x < off) sq[threadIdx.x] = v;
-        __syncthreads();
+    __shared__ float part[4];
+    if (threadIdx.x < N) {
+        const float v = D[threadIdx.x] * D[threadIdx.x];
+        const float r = reduce32(v);
+        if ((threadIdx.x & 31) == 0) part[threadIdx.x >> 5] = r;
     }
-    const float len = sqrtf(sq[0]);
+    __syncthreads();
+    const float len = sqrtf(EXT ? (part[0] + part[2]) + (part[1] + part[3]) : part[0] + part[1]);
     if (threadIdx.x < N) desc[(long long)f * dstep + threadIdx.x] = D[threadIdx.x] / len;
 }
 

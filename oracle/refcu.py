@@ -270,3 +270,46 @@ def cuda_class_stereobm_compute(left, right, ndisp=64, block=19, prefilter_type=
     if rc:
         raise ValueError("the reference class threw")
     return disp
+
+
+def cuda_class_surf(img, hessian_threshold=100.0, n_octaves=4, n_octave_layers=2, extended=False, keypoints_ratio=0.01, upright=False, mask=None,
+                    want_desc=True, provided=None):
+    """cv::cuda::SURF_CUDA::create(...) then operator(): the reference's HOST class (modules/xfeatures2d/src/surf.cuda.cpp, compiled
+    verbatim) over the reference's kernels (xfeatures2d/src/cuda/surf.cu on the fiber shim).  -> the dict of oracle.surf_detect_describe,
+    sorted by (octave, y, x, size) -- the class appends through atomicInc, its own order is arbitrary.  provided = dict of keypoint
+    rows (x, y, octave, size, angle) for useProvidedKeypoints."""
+    img = np.ascontiguousarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 2
+    rows, cols = img.shape
+    cap = 65536
+    kp = np.zeros((7, cap), np.uint32)
+    dsz = 128 if extended else 64
+    n_in = 0
+    if provided is not None:
+        n_in = len(provided["x"])
+        kf = kp.view(np.float32)
+        ki = kp.view(np.int32)
+        kf[0, :n_in] = provided["x"]; kf[1, :n_in] = provided["y"]; ki[2, :n_in] = 1; ki[3, :n_in] = provided["octave"]
+        kf[4, :n_in] = provided["size"]; kf[5, :n_in] = provided["angle"]; kf[6, :n_in] = provided.get("hessian", 0.0)
+    desc = np.zeros((cap if provided is None else max(n_in, 1), dsz), np.float32) if want_desc else None
+    m = np.ascontiguousarray(mask) if mask is not None else None
+    L = lib()
+    L.ref_cuhost_surf.restype = C.c_int
+    L.ref_cuhost_surf.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_void_p]
+    n = L.ref_cuhost_surf(hessian_threshold, n_octaves, n_octave_layers, int(extended), keypoints_ratio, int(upright), img.ctypes.data,
+                          m.ctypes.data if m is not None else None, cols, rows, int(provided is not None), n_in, kp.ctypes.data, cap,
+                          desc.ctypes.data if want_desc else None)
+    if n < 0:
+        raise ValueError("the reference class threw" if n == -1 else "keypoint capacity")
+    kf, ki = kp.view(np.float32), kp.view(np.int32)
+    out = {"n": n, "x": kf[0, :n].copy(), "y": kf[1, :n].copy(), "laplacian": ki[2, :n].copy(), "octave": ki[3, :n].copy(),
+           "size": kf[4, :n].copy(), "angle": kf[5, :n].copy(), "hessian": kf[6, :n].copy(),
+           "descriptors": desc[:n].copy() if want_desc else None}
+    if provided is None:
+        order = np.lexsort((out["size"], out["x"], out["y"], out["octave"]))
+        for k in ("x", "y", "laplacian", "octave", "size", "angle", "hessian"):
+            out[k] = out[k][order]
+        if want_desc:
+            out["descriptors"] = out["descriptors"][order]
+    return out

@@ -6,6 +6,7 @@
  */
 #include "opencv2/cudaoptflow.hpp"      // the reference's own headers (-I $(REF)/modules/cudaoptflow/include, .../cudastereo/include)
 #include "opencv2/cudastereo.hpp"
+#include "opencv2/xfeatures2d/cuda.hpp"
 #include "opencv2/cudaarithm.hpp"
 #include "opencv2/cudawarping.hpp"
 #include "opencv2/video.hpp"
@@ -57,11 +58,27 @@ void GpuMat::copyTo(GpuMat &dst, Stream &) const
     if (dst.data == data) return;
     for (int y = 0; y < rows; ++y) memcpy(dst.ptr<unsigned char>(y), ptr<unsigned char>(y), (size_t)cols * elem_size_of(type()));
 }
-void GpuMat::download(Mat &dst, Stream &) const
+void GpuMat::download(Mat &dst) const
 {
-    CV_Assert(type() == CV_64FC1);
-    dst.rows = rows; dst.cols = cols; dst.v.resize((size_t)rows * cols);
-    for (int y = 0; y < rows; ++y) memcpy(&dst.v[(size_t)y * cols], ptr<double>(y), sizeof(double) * cols);
+    if (dst.empty() || dst.rows != rows || dst.cols != cols || dst.type() != type()) dst.create(rows, cols, type());   // a user buffer of the right shape is kept
+    for (int y = 0; y < rows; ++y) memcpy(dst.ptr<unsigned char>(y), ptr<unsigned char>(y), (size_t)cols * elem_size_of(type()));
+}
+void GpuMat::download(Mat &dst, Stream &) const { download(dst); }
+void GpuMat::upload(const Mat &src)
+{
+    create(src.rows, src.cols, src.type());
+    for (int y = 0; y < rows; ++y) memcpy(ptr<unsigned char>(y), src.ptr<unsigned char>(y), (size_t)cols * elem_size_of(type()));
+}
+GpuMat &GpuMat::setTo(Scalar s)
+{
+    const int d = depth();
+    CV_Assert(d == CV_32F || d == CV_32S);
+    for (int y = 0; y < rows; ++y) {
+        float *rf = ptr<float>(y);
+        int *ri = ptr<int>(y);
+        for (int x = 0; x < cols * channels(); ++x) { if (d == CV_32F) rf[x] = (float)s[0]; else ri[x] = (int)s[0]; }
+    }
+    return *this;
 }
 
 // cuda::multiply(src, Scalar, dst, 1, -1): cudaarithm/src/cuda/mul_scalar.cu:62-70,118-175 -- for a CV_32F source the scalar type is
@@ -105,6 +122,39 @@ void split(InputArray _src, std::vector<GpuMat> &dst, Stream &)
         const float *s = src.ptr<float>(y);
         float *a = dst[0].ptr<float>(y), *b = dst[1].ptr<float>(y);
         for (int x = 0; x < src.cols; ++x) { a[x] = s[2 * x]; b[x] = s[2 * x + 1]; }
+    }
+}
+
+// cuda::integral of a CV_8UC1 image: sum(y, x) = the sum over rows < y, columns < x, CV_32SC1, (rows + 1) x (cols + 1) -- exact
+// integer arithmetic whatever the device's scan order (cudaarithm/src/cuda/integral.cu in the main repo)
+void integral(InputArray _src, OutputArray _sum, Stream &)
+{
+    const GpuMat src = _src.getGpuMat();
+    CV_Assert(src.type() == CV_8UC1);
+    _sum.create(Size(src.cols + 1, src.rows + 1), CV_32SC1);
+    GpuMat &sum = *_sum.gpuMatPtr();
+    memset(sum.ptr<unsigned char>(0), 0, sizeof(unsigned) * (src.cols + 1));
+    for (int y = 0; y < src.rows; ++y) {
+        const unsigned char *s = src.ptr<unsigned char>(y);
+        const unsigned *up = sum.ptr<unsigned>(y);
+        unsigned *o = sum.ptr<unsigned>(y + 1);
+        unsigned run = 0;
+        o[0] = 0;
+        for (int x = 0; x < src.cols; ++x) { run += s[x]; o[x + 1] = up[x + 1] + run; }
+    }
+}
+// cuda::min(src CV_8UC1, scalar, dst)
+void min(InputArray _src1, InputArray src2, OutputArray _dst, Stream &)
+{
+    const GpuMat src = _src1.getGpuMat();
+    CV_Assert(src.type() == CV_8UC1 && src2.isScalar());
+    _dst.create(src.size(), CV_8UC1);
+    GpuMat &dst = *_dst.gpuMatPtr();
+    const double v = src2.scalar();
+    for (int y = 0; y < src.rows; ++y) {
+        const unsigned char *s = src.ptr<unsigned char>(y);
+        unsigned char *d = dst.ptr<unsigned char>(y);
+        for (int x = 0; x < src.cols; ++x) d[x] = (double)s[x] < v ? s[x] : (unsigned char)v;
     }
 }
 
@@ -247,6 +297,44 @@ int ref_cuhost_stereobm_compute(int ndisp, int block, int prefilter_type, int pr
         return 0;
     } catch (const std::exception &) {
         return 1;
+    }
+}
+
+/* cv::cuda::SURF_CUDA::create(...) then operator()(img, mask, keypoints[, descriptors, useProvidedKeypoints]): the reference host class
+ * (modules/xfeatures2d/src/surf.cuda.cpp, verbatim: SURF_CUDA_Invoker and the upload / download helpers) over the reference kernels
+ * (xfeatures2d/src/cuda/surf.cu on the fiber shim).  mask may be NULL.  kp: ROWS_COUNT (7) rows of `cap` 32-bit words, the GpuMat
+ * rows as they are (X, Y, LAPLACIAN [int], OCTAVE [int], SIZE, ANGLE, HESSIAN); with use_provided the first n_in columns are the
+ * caller's keypoints in that layout.  desc: cap x descriptorSize floats (NULL: detect only).  Returns the number of features, -1 if
+ * the class threw, -2 if cap is too small.  Feature ORDER is that of the fibers' atomicInc calls -- as arbitrary as on a GPU. */
+int ref_cuhost_surf(double hessian_threshold, int n_octaves, int n_octave_layers, int extended, float keypoints_ratio, int upright,
+                    const unsigned char *img, const unsigned char *mask, int cols, int rows, int use_provided, int n_in, unsigned *kp, int cap,
+                    float *desc)
+{
+    using namespace cv;
+    try {
+        Ptr<cuda::SURF_CUDA> surf = cuda::SURF_CUDA::create(hessian_threshold, n_octaves, n_octave_layers, extended != 0, keypoints_ratio, upright != 0);
+        cuda::GpuMat g(Size(cols, rows), CV_8UC1), m, k, d;
+        for (int y = 0; y < rows; ++y) memcpy(g.ptr<unsigned char>(y), img + (size_t)y * cols, cols);
+        if (mask) {
+            m.create(Size(cols, rows), CV_8UC1);
+            for (int y = 0; y < rows; ++y) memcpy(m.ptr<unsigned char>(y), mask + (size_t)y * cols, cols);
+        }
+        if (use_provided) {
+            k.create(cuda::SURF_CUDA::ROWS_COUNT, n_in, CV_32FC1);
+            for (int r = 0; r < cuda::SURF_CUDA::ROWS_COUNT; ++r) memcpy(k.ptr<unsigned>(r), kp + (size_t)r * cap, sizeof(unsigned) * n_in);
+        }
+        if (desc) (*surf)(g, m, k, d, use_provided != 0);
+        else (*surf)(g, m, k);
+        const int n = k.cols;
+        if (n > cap) return -2;
+        for (int r = 0; r < cuda::SURF_CUDA::ROWS_COUNT && n > 0; ++r) memcpy(kp + (size_t)r * cap, k.ptr<unsigned>(r), sizeof(unsigned) * n);
+        if (desc && n > 0) {
+            CV_Assert(d.rows == n && d.cols == surf->descriptorSize() && d.type() == CV_32FC1);
+            for (int i = 0; i < n; ++i) memcpy(desc + (size_t)i * d.cols, d.ptr<float>(i), sizeof(float) * d.cols);
+        }
+        return n;
+    } catch (const std::exception &) {
+        return -1;
     }
 }
 }

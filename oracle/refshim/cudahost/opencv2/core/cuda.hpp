@@ -35,6 +35,8 @@
 #define CV_OUT
 #define CV_IN_OUT
 #define CV_WRAP_AS(x)
+#define CV_PROP
+#define CV_PROP_RW
 #define CV_OVERRIDE override
 #define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error("CV_Assert failed: " #expr); } while (0)
 #define CV_DbgAssert(expr) CV_Assert(expr)
@@ -45,6 +47,7 @@
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
 #define CV_32SC1 CV_MAKETYPE(CV_32S, 1)
+#define CV_32SC4 CV_MAKETYPE(CV_32S, 4)
 #define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
 #define CV_32FC2 CV_MAKETYPE(CV_32F, 2)
 #define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
@@ -53,6 +56,7 @@ namespace cv {
 typedef std::string String;
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_CUBIC = 2 };
 enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRAP = 3, BORDER_REFLECT101 = 4 };
+enum { NORM_INF = 1, NORM_L1 = 2, NORM_L2 = 4 };
 enum { DECOMP_LU = 0, DECOMP_SVD = 1, DECOMP_EIG = 2, DECOMP_CHOLESKY = 3 };
 inline int cvRound(double v) { return (int)lrint(v); }   // round half to even, like the SSE2 path of core/fast_math.hpp
 struct Size {
@@ -63,6 +67,10 @@ struct Size {
     bool operator==(const Size &o) const { return width == o.width && height == o.height; }
     bool operator!=(const Size &o) const { return !(*this == o); }
 };
+struct Point2f { float x = 0, y = 0; };
+struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };   // core/types.hpp
+class Mutex { public: void lock() {} void unlock() {} };
+class AutoLock { public: explicit AutoLock(Mutex &) {} };
 struct Rect { int x = 0, y = 0, width = 0, height = 0; Rect() {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
 struct Scalar {
     double val[4] = {0, 0, 0, 0};
@@ -80,13 +88,31 @@ public:
 };
 inline size_t elem_size_of(int type) { const int d = type & 7, cn = (type >> 3) + 1; return (size_t)cn * (d == CV_8U ? 1 : d == CV_64F ? 8 : 4); }
 
-class Mat {   // only what the two host files need: a 1 x 1 CV_64F element (diff_sum_host), an n x 1 CV_32F column (getGaussianKernel)
-public:
+namespace cuda { class GpuMat; }
+class Mat {   // a dense host matrix: what diff_sum_host (1 x 1 CV_64F), getGaussianKernel (n x 1 CV_32F) and SURF_CUDA's keypoint /
+public:       // descriptor transfers (7 x n CV_32F, n x 64|128 CV_32F over a caller's buffer) need
     int rows = 0, cols = 0;
-    std::vector<double> v;   // 8 bytes per element whatever the type: at<T> / ptr<T> reinterpret the front of each
-    template <typename T> T &at(int y, int x) { return reinterpret_cast<T &>(v[(size_t)y * cols + x]); }
-    std::vector<float> f;    // CV_32F storage (dense)
-    template <typename T> T *ptr(int y) { static_assert(sizeof(T) == 4, "CV_32F rows only"); return reinterpret_cast<T *>(&f[(size_t)y * cols]); }
+    size_t step = 0;
+    unsigned char *data = nullptr;
+    Mat() {}
+    Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(Size s, int type, void *user) : rows(s.height), cols(s.width), step((size_t)s.width * elem_size_of(type)), data((unsigned char *)user), type_(type) {}
+    explicit Mat(const cuda::GpuMat &m);   // downloads (core/src/cuda_gpu_mat... Mat::Mat(const GpuMat&))
+    void create(int r, int c, int type)
+    {
+        rows = r; cols = c; type_ = type; step = (size_t)c * elem_size_of(type);
+        buf_ = std::make_shared<std::vector<unsigned char> >((size_t)r * step + 16);
+        data = buf_->data();
+    }
+    int type() const { return type_; }
+    Size size() const { return Size(cols, rows); }
+    bool empty() const { return data == nullptr; }
+    template <typename T> T &at(int y, int x) { return reinterpret_cast<T *>(data + (size_t)y * step)[x]; }
+    template <typename T> T *ptr(int y = 0) { return reinterpret_cast<T *>(data + (size_t)y * step); }
+    template <typename T> const T *ptr(int y = 0) const { return reinterpret_cast<const T *>(data + (size_t)y * step); }
+private:
+    int type_ = CV_8UC1;
+    std::shared_ptr<std::vector<unsigned char> > buf_;
 };
 // Mat_<double>: the 6 x 6 normal matrix of FarnebackOpticalFlowImpl::prepareGaussian and its inverse
 template <typename T> class Mat_ {
@@ -138,12 +164,12 @@ public:
 inline Mat getGaussianKernel(int n, double sigma, int ktype)
 {
     CV_Assert(ktype == CV_32F && n > 0);
-    Mat k;
-    k.rows = n; k.cols = 1; k.f.resize(n);
+    Mat k(n, 1, CV_32FC1);
+    float *kf = k.ptr<float>(0);
     static const float small[4][7] = {{1.f}, {0.25f, 0.5f, 0.25f}, {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
                                       {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
     if (sigma <= 0 && (n & 1) && n <= 7) {
-        for (int i = 0; i < n; ++i) k.f[i] = small[n >> 1][i];
+        for (int i = 0; i < n; ++i) kf[i] = small[n >> 1][i];
         return k;
     }
     const double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8, s2 = -0.5 / (sx * sx);
@@ -151,7 +177,7 @@ inline Mat getGaussianKernel(int n, double sigma, int ktype)
     double sum = 0;
     for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = std::exp(s2 * x * x); sum += w[i]; }
     sum = 1. / sum;
-    for (int i = 0; i < n; ++i) k.f[i] = (float)(w[i] * sum);
+    for (int i = 0; i < n; ++i) kf[i] = (float)(w[i] * sum);
     return k;
 }
 
@@ -200,14 +226,20 @@ public:
         m.rows = r.height; m.cols = r.width;
         return m;
     }
-    template <typename T> T *ptr(int y) { return reinterpret_cast<T *>(data + (size_t)y * step); }
-    template <typename T> const T *ptr(int y) const { return reinterpret_cast<const T *>(data + (size_t)y * step); }
+    template <typename T> T *ptr(int y = 0) { return reinterpret_cast<T *>(data + (size_t)y * step); }
+    template <typename T> const T *ptr(int y = 0) const { return reinterpret_cast<const T *>(data + (size_t)y * step); }
+    GpuMat row(int y) const { return (*this)(Rect(0, y, cols, 1)); }
+    void release() { *this = GpuMat(); }
+    template <typename T> operator PtrStep<T>() const { return PtrStep<T>((T *)data, step); }
     template <typename T> operator PtrStepSz<T>() const { return PtrStepSz<T>(rows, cols, (T *)data, step); }
     // cudahost.cpp
     void convertTo(GpuMat &dst, int rtype, double alpha, Stream &stream) const;
     void convertTo(GpuMat &dst, int rtype, Stream &stream) const;
     GpuMat &setTo(Scalar s, Stream &stream);
+    GpuMat &setTo(Scalar s);                      // any 4-byte-element type (CV_32F / CV_32S, any channel count): s[0] everywhere is all SURF_CUDA asks
     void download(Mat &dst, Stream &stream) const;
+    void download(Mat &dst) const;
+    void upload(const Mat &src);
     void copyTo(GpuMat &dst, Stream &stream) const;
 private:
     int type_ = CV_8UC1;
@@ -220,7 +252,9 @@ inline void ensureSizeIsEnough(Size s, int type, GpuMat &m)
     if (!m.empty() && m.type() == type && m.rows >= s.height && m.cols >= s.width) m = m(Rect(0, 0, s.width, s.height));
     else m.create(s, type);
 }
+inline void ensureSizeIsEnough(int rows, int cols, int type, GpuMat &m) { ensureSizeIsEnough(Size(cols, rows), type, m); }
 }  // namespace cuda
+inline Mat::Mat(const cuda::GpuMat &m) { m.download(*this); }
 
 // InputArray / OutputArray proxies over GpuMat (the only kind this translation unit passes)
 class _InputArray {
@@ -228,11 +262,16 @@ public:
     _InputArray() : m_(nullptr) {}
     _InputArray(const cuda::GpuMat &m) : m_(const_cast<cuda::GpuMat *>(&m)) {}
     _InputArray(const Mat &) : m_(nullptr) {}   // cudastereo.hpp:360 casts a Mat Q; never called here
+    _InputArray(const double &v) : m_(nullptr), scalar_(v), is_scalar_(true) {}   // cuda::min(mask, 1.0, dst) of surf.cuda.cpp:164
+    bool isScalar() const { return is_scalar_; }
+    double scalar() const { return scalar_; }
     cuda::GpuMat getGpuMat() const { return m_ ? *m_ : cuda::GpuMat(); }
     bool empty() const { return !m_ || m_->empty(); }
     cuda::GpuMat *gpuMatPtr() const { return m_; }
 protected:
     cuda::GpuMat *m_;
+    double scalar_ = 0;
+    bool is_scalar_ = false;
 };
 class _OutputArray : public _InputArray {
 public:

@@ -11,5 +11,8 @@ void merge(const GpuMat *src, size_t n, OutputArray dst, Stream &stream);
 void calcSum(InputArray src, OutputArray dst, InputArray mask, Stream &stream);
 // cudaarithm.hpp: split(InputArray src, std::vector<GpuMat>& dst, Stream&) -- farneback.cpp:185 (OPTFLOW_USE_INITIAL_FLOW)
 void split(InputArray src, std::vector<GpuMat> &dst, Stream &stream);
+// cudaarithm.hpp: integral(src CV_8UC1, sum CV_32SC1 of (rows + 1) x (cols + 1)), min(src1, scalar, dst) -- SURF_CUDA_Invoker (surf.cuda.cpp:160-166)
+void integral(InputArray src, OutputArray sum, Stream &stream = Stream::Null());
+void min(InputArray src1, InputArray src2, OutputArray dst, Stream &stream = Stream::Null());
 }}
 #endif

@@ -1,0 +1,1 @@
+/* oracle/refshim/cudahost: nothing of opencv2/imgproc.hpp is used by xfeatures2d/src/surf.cuda.cpp.  TEST INFRASTRUCTURE. */

@@ -70,6 +70,7 @@ template <typename F> void launch(dim3 grid, dim3 block, size_t smem, F f)
     oclrt_run(3, g, l, 1, 0, &body_tramp<F>, &f);
 }
 template <typename F> void launch(dim3 grid, dim3 block, size_t smem, void *, F f) { launch(grid, block, smem, f); }
+template <typename F> void launch(dim3 grid, dim3 block, F f) { launch(grid, block, 0, f); }   // k<<<grid, block>>>(...)
 }  // namespace cudashim
 
 #define threadIdx (cudashim::tid())
@@ -86,6 +87,15 @@ static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 static inline float min(float a, float b) { return fminf(a, b); }
 static inline float max(float a, float b) { return fmaxf(a, b); }
 static inline int __mul24(int a, int b) { return a * b; }
+// float -> int conversions with an explicit rounding mode (PTX cvt.r{n,m,p}i.s32.f32)
+static inline int __float2int_rn(float v) { return (int)nearbyintf(v); }
+static inline int __float2int_rd(float v) { return (int)floorf(v); }
+static inline int __float2int_ru(float v) { return (int)ceilf(v); }
+// atomicInc(p, limit): old = *p; *p = old >= limit ? 0 : old + 1 (threads of a block are fibers of one host thread: no race)
+static inline unsigned atomicInc(unsigned *p, unsigned limit) { const unsigned old = *p; *p = old >= limit ? 0u : old + 1u; return old; }
+#ifndef CV_PI_F
+#define CV_PI_F 3.14159265f   /* main repo core/cuda/common.hpp */
+#endif
 static inline float __fdividef(float a, float b) { return a / b; }
 
 // runtime calls of the launch wrappers
@@ -107,6 +117,8 @@ template <typename T> static inline cudaError_t cudaMemcpyToSymbol(T &symbol, co
     memcpy((void *)&symbol, src, count);   // __constant__ objects are plain statics here
     return cudaSuccess;
 }
+enum cudaMemcpyKind { cudaMemcpyHostToHost = 0, cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2, cudaMemcpyDeviceToDevice = 3 };
+static inline cudaError_t cudaMemcpy(void *dst, const void *src, size_t count, cudaMemcpyKind) { memcpy(dst, src, count); return cudaSuccess; }
 #define cudaSafeCall(expr) ((void)(expr))
 #define CV_Error(code, msg) throw std::runtime_error(msg)
 namespace cv { namespace Error { enum { StsBadArg = -5 }; } }

@@ -43,24 +43,30 @@ static inline int rn(float v) { return (int)lrintf(v); }   /* __float2int_rn */
 
 int orc_surf_calc_size(int octave, int layer) { return (9 + 6 * layer) << octave; }   /* surf.cu:161-173 */
 
-/* cv::getGaussianKernel(n, sigma > 0, CV_32F) */
-static void gauss(int n, double sigma, float *k)
+/* The weight tables of surf.cu (c_aptW :522, c_DW :685-707) are LITERALS; tests/test_ref_pin_cuda.py parses them out of the reference and
+ * asserts that this generator reproduces every one bit for bit: they are the outer products, in float, of cv::getGaussianKernel(n,
+ * sigma, CV_32F) as OpenCV 2.4 computed it -- exp() in double ROUNDED TO FLOAT, the float terms summed in double, each float term times
+ * (1 / sum) in double rounded to float again -- with sigma the float constants of the CPU class (surf.cpp: SURF_ORI_SIGMA = 2.5f,
+ * SURF_DESC_SIGMA = 3.3f) promoted to double.  (Today's getGaussianKernel rounds once; 60 / 113 and 188 / 400 entries would differ by
+ * 1-2 ulp.) */
+static void gauss_tab(int n, float sigma_f, float *k)
 {
-    const double scale2 = -0.5 / (sigma * sigma);
-    double w[32], sum = 0;
-    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = exp(scale2 * x * x); sum += w[i]; }
-    for (int i = 0; i < n; ++i) k[i] = (float)(w[i] / sum);
+    const double sigma = (double)sigma_f, scale2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = (float)exp(scale2 * x * x); sum += k[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
 }
 
 void orc_surf_tables(float aptx[ORI_SAMPLES], float apty[ORI_SAMPLES], float aptw[ORI_SAMPLES], float dw[PATCH_SZ * PATCH_SZ])
 {
     float g[13], G[PATCH_SZ];
-    gauss(13, 2.5, g);                 /* SURF_ORI_SIGMA, surf.cpp:544 */
+    gauss_tab(13, 2.5f, g);            /* c_aptW, surf.cu:522 */
     int n = 0;
     for (int i = -6; i <= 6; i++)      /* surf.cpp:546-556 */
         for (int j = -6; j <= 6; j++)
             if (i * i + j * j <= 36) { aptx[n] = (float)i; apty[n] = (float)j; aptw[n++] = g[i + 6] * g[j + 6]; }
-    gauss(PATCH_SZ, 3.3, G);           /* SURF_DESC_SIGMA, surf.cpp:560-565 */
+    gauss_tab(PATCH_SZ, 3.3f, G);      /* c_DW, surf.cu:685-707 */
     for (int i = 0; i < PATCH_SZ; i++)
         for (int j = 0; j < PATCH_SZ; j++) dw[i * PATCH_SZ + j] = G[i] * G[j];
 }
@@ -183,19 +189,20 @@ int orc_surf_find_maxima(const float *det, const float *trace, const uint32_t *m
     return n;
 }
 
-/* surf.cl:413-441 */
+/* core/cuda/utility.hpp solve3x3<float> (main repo; restated in oracle/refshim/cudashim/opencv2/core/cuda/utility.hpp): Cramer's rule with
+ * the reciprocal of the determinant in DOUBLE, the components rounded back to float (surf.cl:413-441 is the all-float twin) */
 static int solve3x3(const float A[3][3], const float b[3], float x[3])
 {
     const float det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
     if (det != 0) {
-        const float invdet = 1.0f / det;
-        x[0] = invdet * (b[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (b[1] * A[2][2] - A[1][2] * b[2]) +
-                         A[0][2] * (b[1] * A[2][1] - A[1][1] * b[2]));
-        x[1] = invdet * (A[0][0] * (b[1] * A[2][2] - A[1][2] * b[2]) - b[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                         A[0][2] * (A[1][0] * b[2] - b[1] * A[2][0]));
-        x[2] = invdet * (A[0][0] * (A[1][1] * b[2] - b[1] * A[2][1]) - A[0][1] * (A[1][0] * b[2] - b[1] * A[2][0]) +
-                         b[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]));
+        const double invdet = 1.0 / det;
+        x[0] = (float)(invdet * (b[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (b[1] * A[2][2] - A[1][2] * b[2]) +
+                         A[0][2] * (b[1] * A[2][1] - A[1][1] * b[2])));
+        x[1] = (float)(invdet * (A[0][0] * (b[1] * A[2][2] - A[1][2] * b[2]) - b[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                         A[0][2] * (A[1][0] * b[2] - b[1] * A[2][0])));
+        x[2] = (float)(invdet * (A[0][0] * (A[1][1] * b[2] - b[1] * A[2][1]) - A[0][1] * (A[1][0] * b[2] - b[1] * A[2][0]) +
+                         b[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0])));
         return 1;
     }
     return 0;
@@ -305,24 +312,35 @@ float orc_surf_orientation(const uint32_t *sum, int rows, int cols, float fx, fl
     return kp_dir;
 }
 
-/* ---- descriptor: rotated window reader + patch filters (surf.cu:709-778 with surf.cl:62-68,873-952) */
-typedef struct { const uint8_t *img; int rows, cols; float cx, cy, off, c, s; } Win;
+/* ---- descriptor: rotated window reader + patch filters (surf.cu:709-778).  WinReader reads the 8-bit image through a point-sampled,
+ * clamp-addressed texture: texel (floor(x), floor(y)) (CUDA programming guide, nearest-point sampling of unnormalised coordinates).  The two
+ * patch filters are core/cuda/filters.hpp's (main repo; restated in oracle/refshim/cudashim/opencv2/core/cuda/filters.hpp): float
+ * accumulation in the order below, then saturate_cast<elem_type> -- WinReader::elem_type is uchar (surf.cu:711), so every patch sample is
+ * ROUNDED to an 8-bit value (cvt.rni.sat.u8.f32); LinearFilter takes floor(x), floor(y); AreaFilter normalises by
+ * 1 / (min(s, width - fsx1) * min(s, height - fsy1)) with width = height = win_size (surf.cu:754) -- smaller than s * s in the last
+ * patch row / column.  (The OpenCL twin, surf.cl:62-68,873-952, rounds the coordinates, keeps the samples in float and divides by s * s.) */
+typedef struct { const uint8_t *img; int rows, cols, win; float cx, cy, off, c, s; } Win;
 static inline float win_get(const Win *w, int i, int j)
 {
     const float px = w->cx + (w->off + j) * w->c + (w->off + i) * w->s;
     const float py = w->cy - (w->off + j) * w->s + (w->off + i) * w->c;
-    const int x = clampi(rn(px), 0, w->cols - 1), y = clampi(rn(py), 0, w->rows - 1);
+    const int x = clampi((int)floorf(px), 0, w->cols - 1), y = clampi((int)floorf(py), 0, w->rows - 1);
     return (float)w->img[(size_t)y * w->cols + x];
+}
+static inline float sat_u8(float v)   /* saturate_cast<uchar>(float): round to nearest even, saturate */
+{
+    const float r = nearbyintf(v);
+    return r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
 }
 static float linear_filter(const Win *w, float y, float x)
 {
     float out = 0.0f;
-    const int x1 = (int)roundf(x), y1 = (int)roundf(y), x2 = x1 + 1, y2 = y1 + 1;
+    const int x1 = (int)floorf(x), y1 = (int)floorf(y), x2 = x1 + 1, y2 = y1 + 1;
     out = out + win_get(w, y1, x1) * ((x2 - x) * (y2 - y));
     out = out + win_get(w, y1, x2) * ((x - x1) * (y2 - y));
     out = out + win_get(w, y2, x1) * ((x2 - x) * (y - y1));
     out = out + win_get(w, y2, x2) * ((x - x1) * (y - y1));
-    return out;
+    return sat_u8(out);
 }
 static float area_filter(const Win *w, float x, float y, float s)
 {
@@ -330,7 +348,7 @@ static float area_filter(const Win *w, float x, float y, float s)
     const int sx1 = (int)ceilf(fsx1), sx2 = (int)floorf(fsx2);
     const float fsy1 = y * s, fsy2 = fsy1 + s;
     const int sy1 = (int)ceilf(fsy1), sy2 = (int)floorf(fsy2);
-    const float scale = 1.f / (s * s);
+    const float scale = 1.f / (fminf(s, w->win - fsx1) * fminf(s, w->win - fsy1));
     float out = 0.f;
     for (int dy = sy1; dy < sy2; ++dy) {
         for (int dx = sx1; dx < sx2; ++dx) out = out + win_get(w, dy, dx) * scale;
@@ -343,7 +361,7 @@ static float area_filter(const Win *w, float x, float y, float s)
     if ((sy1 > fsy1) && (sx2 < fsx2)) out = out + win_get(w, sy1 - 1, sx2) * ((sy1 - fsy1) * (fsx2 - sx2) * scale);
     if ((sy2 < fsy2) && (sx2 < fsx2)) out = out + win_get(w, sy2, sx2) * ((fsy2 - sy2) * (fsx2 - sx2) * scale);
     if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + win_get(w, sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
-    return out;
+    return sat_u8(out);
 }
 
 /* surf.cu:733-912: one descriptor (64 or 128 floats), normalised */
@@ -354,6 +372,7 @@ void orc_surf_descriptor(const uint8_t *img, int rows, int cols, float fx, float
     w.img = img; w.rows = rows; w.cols = cols; w.cx = fx; w.cy = fy;
     const float s = fsize * 1.2f / 9.0f;
     const int win_size = (int)((PATCH_SZ + 1) * s);
+    w.win = win_size;
     w.off = -(win_size - 1.0f) / 2.0f;
     float ddir = 360.0f - fdir;
     if (fabsf(ddir - 360.f) < FLT_EPSILON) ddir = 0.f;
@@ -395,12 +414,18 @@ void orc_surf_descriptor(const uint8_t *img, int rows, int cols, float fx, float
             desc[ty * 8 + 4] = reduce32(a); desc[ty * 8 + 5] = reduce32(b); desc[ty * 8 + 6] = reduce32(c); desc[ty * 8 + 7] = reduce32(d);
         }
     }
-    /* normalize_descriptors<N> surf.cu:891-912: len = tree sum of squares (halving: i += i + N/2 ...), val / sqrt(len) */
-    float sq[128];
-    for (int k = 0; k < dsz; ++k) sq[k] = desc[k] * desc[k];
-    for (int off = dsz / 2; off >= 1; off >>= 1)
-        for (int i = 0; i < off; ++i) sq[i] = sq[i] + sq[i + off];
-    const float len = sqrtf(sq[0]);
+    /* normalize_descriptors<N> surf.cu:891-912: len = device::reduce<N> of the squares, N = 64 / 128 threads = 2 / 4 warps
+     * (core/cuda/detail/reduce.hpp GenericOptimized32 on sm_30+: the shfl_down tree in every warp, then the tree of width N / 32 over
+     * the warps' partials in the first warp); val / sqrt(len) */
+    float part[4];
+    for (int wv = 0; wv < dsz / 32; ++wv) {
+        float sq[32];
+        for (int k = 0; k < 32; ++k) sq[k] = desc[wv * 32 + k] * desc[wv * 32 + k];
+        part[wv] = reduce32(sq);
+    }
+    for (int off = dsz / 64; off >= 1; off >>= 1)
+        for (int i = 0; i < off; ++i) part[i] = part[i] + part[i + off];
+    const float len = sqrtf(part[0]);
     for (int k = 0; k < dsz; ++k) desc[k] = desc[k] / len;
 }
 

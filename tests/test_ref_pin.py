@@ -155,8 +155,10 @@ def test_surf_det_trace_and_maxima_equal_reference_kernels(oracle, h, w, seed, t
 @pytest.mark.parametrize("h,w,seed,thr,octaves,layers", SURF_CASES)
 def test_surf_keypoints_equal_reference_detector(oracle, h, w, seed, thr, octaves, layers):
     """SURF_OCL::detectKeypoints on the reference kernels (det/trace -> maxima -> SURF_interpolateKeypoint, the octave loop of
-    surf.ocl.cpp:152-200) against oracle.surf_detect_describe: the same set of keypoints, x / y / size / response / laplacian /
-    octave bit for bit (the reference appends with atomic_inc, so order is not compared)."""
+    surf.ocl.cpp:152-200) against oracle.surf_detect_describe: the same set of keypoints, size / response / laplacian / octave bit
+    for bit (the reference appends with atomic_inc, so order is not compared); x / y to one unit in the last place -- the oracle
+    follows the CUDA class bit for bit (tests/test_ref_pin_cuda.py: surf.cu itself), whose solve3x3 (core/cuda/utility.hpp) takes
+    the reciprocal of the determinant in double where the OpenCL twin (surf.cl:413-441) stays in float."""
     img = synth.blob_image(h, w, seed=seed)
     S = oracle.surf_integral(img)
     ro = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=thr, n_octaves=octaves, n_octave_layers=layers,
@@ -166,17 +168,27 @@ def test_surf_keypoints_equal_reference_detector(oracle, h, w, seed, thr, octave
     ko = _kp_matrix(ro)
     order = lambda K: np.lexsort((K[6], K[4], K[1], K[0]))
     a, b = kp[:, order(kp)], ko[:, order(ko)]
-    for row in (0, 1, 4, 6):
+    for row in (4, 6):
         np.testing.assert_array_equal(a[row], b[row])
+    for row in (0, 1):
+        assert (np.abs(a[row] - b[row]) <= np.spacing(np.abs(b[row]))).all()
+        assert (a[row] != b[row]).mean() < 0.02
     np.testing.assert_array_equal(a[2:4].view(np.int32), b[2:4].view(np.int32))
 
 
 @pytest.mark.parametrize("extended", [False, True])
 @pytest.mark.parametrize("h,w,seed,thr,octaves,layers", SURF_CASES[:2])
 def test_surf_orientation_and_descriptors_against_reference_kernels(oracle, h, w, seed, thr, octaves, layers, extended):
-    """SURF_calcOrientation and SURF_computeDescriptors64/128 + normalize on the oracle's keypoints.  The OpenCL twins read the
-    integral image as float and reduce in another order than surf.cu, so these two stages are held to a tolerance: every
-    orientation within 1e-3 degrees, every descriptor element within 1e-6."""
+    """SURF_calcOrientation and SURF_computeDescriptors64/128 + normalize of the OpenCL class on the oracle's keypoints -- a CROSS-CHECK
+    of a sibling implementation, not the pin: the oracle is pinned bit for bit on the CUDA class itself (tests/test_ref_pin_cuda.py runs
+    surf.cu and surf.cuda.cpp).  Orientation: the twin reads the integral image as float and reduces in another order: within 1e-3
+    degrees.  Descriptors: the twin samples the rotated window differently from the CUDA class -- coordinates rounded (surf.cl:62-68)
+    instead of floor-addressed texture reads, patch samples kept in float where core/cuda/filters.hpp rounds them to 8 bits
+    (WinReader::elem_type = uchar), 1 / s^2 everywhere where AreaFilter normalises the last patch row / column by the window's
+    remainder -- so the two unit vectors agree to a few hundredths per element: L2 distance < 0.35 for every keypoint, < 0.1 on
+    average, cosine > 0.93 (64 floats; the 128-float form splits the sums by the SIGN of the other derivative, which the 8-bit patch
+    often makes exactly 0: < 0.7, < 0.25, > 0.75).  (Until round 3 the oracle followed the twin here and this test held 1e-6; the CUDA source pin showed the
+    CUDA class differs.)"""
     img = synth.blob_image(h, w, seed=seed)
     S = oracle.surf_integral(img)
     ro = oracle.surf_detect_describe(img, oracle.surf_params(hessian_threshold=thr, n_octaves=octaves, n_octave_layers=layers,
@@ -187,7 +199,9 @@ def test_surf_orientation_and_descriptors_against_reference_kernels(oracle, h, w
     assert d.max() <= 1e-3, d.max()
     desc = refocl.surf_descriptors(img, K, extended)
     assert desc.shape == ro["descriptors"].shape
-    assert np.abs(desc - ro["descriptors"]).max() <= 1e-6
+    dist = np.linalg.norm(desc - ro["descriptors"], axis=1)
+    assert dist.max() < (0.7 if extended else 0.35) and dist.mean() < (0.25 if extended else 0.1), (dist.max(), dist.mean())
+    assert (desc * ro["descriptors"]).sum(1).min() > (0.75 if extended else 0.93)
     np.testing.assert_allclose(np.linalg.norm(desc, axis=1), 1.0, atol=1e-5)
 
 

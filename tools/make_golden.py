@@ -63,6 +63,17 @@ def surf():
     for name, kw in {"surf_160x200_thr300": dict(hessian_threshold=300.0, n_octaves=3, keypoints_ratio=0.05),
                      "surf_160x200_thr300_ext_upright": dict(hessian_threshold=300.0, n_octaves=3, keypoints_ratio=0.05, extended=1, upright=1)}.items():
         r = O.surf_detect_describe(img, O.surf_params(**kw))
+        # these two fixtures ARE outputs of the reference: the reference's own host class over its own surf.cu, executed here
+        # (oracle/_ref/libref_cu.so, oracle/Makefile.ref), gives the same keypoints and descriptors bit for bit (as a set: it appends
+        # through atomicInc); the file keeps the oracle's deterministic scan order
+        from oracle import refcu
+        if refcu.available():
+            ref = refcu.cuda_class_surf(img, **{k: (bool(v) if k in ("extended", "upright") else v) for k, v in kw.items()})
+            order = np.lexsort((r["size"], r["x"], r["y"], r["octave"]))
+            assert ref["n"] == r["n"]
+            for k in ("x", "y", "laplacian", "octave", "size", "angle", "hessian", "descriptors"):
+                assert np.array_equal(r[k][order], ref[k]), k
+            print(name, "== the reference CUDA class run on the host")
         np.savez_compressed(os.path.join(OUT, name + ".npz"), img=img, x=r["x"], y=r["y"], laplacian=r["laplacian"], octave=r["octave"],
                             size=r["size"], angle=r["angle"], hessian=r["hessian"], descriptors=r["descriptors"].astype(np.float32),
                             params=np.array(json.dumps(kw)))
