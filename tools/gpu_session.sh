@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU session: `gpurun --timeout N -- 'bash tools/gpu_session.sh <name> <steps...>'`; results under gpurun_out/<name>/.
-# Steps: tests_new | tests_all | smoke | ab_warp | bench | trace | pmc | secondary
+# Steps: tests_new | tests_all | smoke | ab_warp | bench | trace | pmc | secondary | surf_bench
 set -u
 export TMPDIR=/tmp
 NAME=$1; shift
@@ -191,6 +191,8 @@ pmc_secondary)
   find $O -type f -size +4M -delete ;;
 spec_trace)
   (timeout 300 python tools/spec_trace.py --pairs 4 2>&1 | tail -120) > $O/spec_trace.log; head -70 $O/spec_trace.log ;;
+surf_bench)
+  (timeout 300 python bench.py --workload surf --no-cpu --steps 5 2>$O/surf.err | tail -1) > $O/surf_bench.json; cut -c1-1800 $O/surf_bench.json; tail -3 $O/surf.err ;;
 test_one)
   (timeout 600 python -m pytest "tests/test_baseline_sizes.py" -m gpu -q -x -p no:cacheprovider -k "two_lanes or speculative or slack or class_defaults" 2>&1 | tail -30) > $O/pytest_one.log; cat $O/pytest_one.log ;;
 esac
