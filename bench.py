@@ -82,19 +82,29 @@ def algo_bytes_per_pair(w, h, warps, iters_per_warp, nscales=5, step=0.8):
 WARP_VALU_PER_PX = 234.0   # static count of the interior path of k_warp6<CPU_REF, 32, ., exact sums>: 52 (map, phase weights) + 169 (window) + 13 (grad, rho_c)
 
 
-def tbr_band_rows(w, h, pairs, T=10, PF=2, plan_wps=3, simds=1024):
+def tbr_jw():
+    """MIFLOW_TB_JW as the library reads it: 2 (default) = joined waves, barrier form; 1 = joined waves, tags; 0 = independent waves."""
+    try:
+        return int(os.environ.get("MIFLOW_TB_JW", "2"))
+    except ValueError:
+        return 2
+
+
+def tbr_band_rows(w, h, pairs, T=10, PF=2, plan_wps=3, simds=1024, jw=None):
     """Band height the planner of tvl1_tbr_kernels.hip (plan_band_rows) picks for the T = 10, 1 px/lane kernel: every wave streams
-    rows + 2 T rows, so (rows + 2 T) / rows of the iteration kernel's work is band-halo recomputation."""
+    rows + 2 T rows, so (rows + 2 T) / rows of the iteration kernel's work is band-halo recomputation.  jw: a workgroup's four waves
+    sit side by side on one band of a 256-column strip (the default) instead of on four bands of a 64-column strip."""
+    jw = tbr_jw() if jw is None else jw
     P = T + 1 + PF
-    M, LW = T, 64
+    M, LW = T, (256 if jw else 64)
     strips = 1 if w <= LW - M else 1 + -(-(w - (LW - M)) // (LW - 2 * M))
-    per_band, cap = strips * pairs, simds * plan_wps
+    per_band, cap = strips * pairs * (4 if jw else 1), simds * plan_wps
     best = None
     for nb in range(1, h + 1):
         R = -(-h // nb)
         if R < 8 and nb > 1:
             break
-        cap_nb = simds * nb if nb < 4 and nb < plan_wps else cap
+        cap_nb = simds * nb if not jw and nb < 4 and nb < plan_wps else cap
         rounds = -(-(per_band * nb) // cap_nb)
         steps = -(-(R + 2 * T) // P) * P
         if best is None or rounds * steps < best[0]:
@@ -645,11 +655,14 @@ def bench_surf(args):
 
 
 def static_mix():
-    """Per pipeline stage and pixel row of k_iterate_tbr<10, 1, ., 4, 2>: tools/static_mix.py -> profiles/static_mix_tbr.json."""
+    """Per pipeline stage and pixel row of the T = 10 kernel that runs (tools/static_mix.py): profiles/static_mix_tbr.json = the default
+    k_iterate_tbr<10, 1, ., 4, 2, 0, 2> (joined waves, barrier form), profiles/static_mix_tbr_jw0.json = the independent-wave form."""
+    jw = tbr_jw()
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "static_mix_tbr.json")))["per_stage_and_pixel"]
+        return json.load(open(os.path.join(ROOT, "profiles", "static_mix_tbr.json" if jw == 2 else "static_mix_tbr_jw0.json")))["per_stage_and_pixel"]
     except Exception:
-        return {"valu_plain": 31.662, "transcendental": 4.069, "dpp": 4.0, "cndmask": 2.223}
+        return ({"valu_plain": 38.138, "transcendental": 4.069, "dpp": 4.0, "cndmask": 1.985} if jw == 2 else
+                {"valu_plain": 31.662, "transcendental": 4.069, "dpp": 4.0, "cndmask": 2.223})
 
 
 def pmc_traffic(key, pairs_per_launch=None):
@@ -811,9 +824,11 @@ def main():
         # (R + 2T) / R with R the band height the planner chose (about 1.15-1.25 at 1080p x 16: reported by MIFLOW_TB_VERBOSE)
         mix = static_mix()
         slots = mix["valu_plain"] + mix["dpp"] + mix["cndmask"] + 4.0 * mix["transcendental"]
-        lanes_per_px = 64.0 / 44.0
+        jw = tbr_jw()
+        lanes_per_px = 256.0 / 236.0 if jw else 64.0 / 44.0   # joined waves: the T-column margin exists at the two outer edges of a 256-column strip only
         ach = px_iter_timed / (ms_it * 1e-3) * slots * lanes_per_px / 1e12
-        roof = {"bound": "valu_issue", "kernel": "k_iterate_tbr<10,1,.,4,2,0> (10 fused estimateU+estimateDualVariables iterations per HBM pass)",
+        roof = {"bound": "valu_issue", "kernel": ("k_iterate_tbr<10,1,.,4,2,0,%d> (10 fused estimateU+estimateDualVariables iterations per HBM pass; " % jw) +
+                ("four joined waves per 256-column strip, seam values handed over through LDS)" if jw else "independent 64-column waves)"),
                 "achieved": ach, "peak": VALU_PEAK_TLIPS, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLIPS,
                 "pixel_iterations_per_s": px_iter_timed / (ms_it * 1e-3),
                 # what a plain f32 VALU stream actually issues on this chip: 3.1 SIMD cycles per wave-instruction at 4 waves/SIMD

@@ -25,7 +25,13 @@ const Tuning &tuning()
         t.warp_np = env_int("MIFLOW_WARP_NP", 2);   // r02e at 1080p x 16: np 1 | 2 | 4 = 904 | 1042 | 1034 pairs/s
         if (t.warp_np != 1 && t.warp_np != 4) t.warp_np = 2;
         t.tb_swz = env_int("MIFLOW_TB_SWZ", 1);
-        t.tb_jw = env_int("MIFLOW_TB_JW", 0);   // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip)
+        // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip): 2 (default since r03w) = hand-over with one
+        // workgroup barrier per stage, 1 = with tags and bounded waits, 0 = independent 64-column waves; all three bit-identical
+        t.tb_jw = env_int("MIFLOW_TB_JW", 2);
+        if (t.tb_jw < 0 || t.tb_jw > 2) t.tb_jw = 2;
+        // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,
+        // epsilon 0.01: 533 -> 593 pairs/s, the same flows
+        t.tb_jw_spec = env_int("MIFLOW_TB_JW_SPEC", 1);
         t.tb_ppl = t.tb_wps = t.tb_pf = -1;
         if (const char *v = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(v, "%d,%d,%d", &t.tb_ppl, &t.tb_wps, &t.tb_pf);
         t.tb_force = getenv("MIFLOW_TB_FORCE") != nullptr;

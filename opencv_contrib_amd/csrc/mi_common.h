@@ -38,6 +38,7 @@ struct Tuning {
     int warp_np;             // MIFLOW_WARP_NP: patches a wave of the fused-gradient warp kernel walks (1 | 2 | 4)
     int tb_swz;             // MIFLOW_TB_SWZ: XCD-aware workgroup remap of the blocked iteration kernels
     int tb_jw;              // MIFLOW_TB_JW: joined-wave form of the T = 10 blocked iteration kernel
+    int tb_jw_spec;         // MIFLOW_TB_JW_SPEC: ... of the speculative steps as well
     int tb_ppl, tb_wps, tb_pf;   // MIFLOW_TB_VARIANT=ppl,wps,pf (-1: table default)
     int tb_force;            // MIFLOW_TB_FORCE: greedy blocks of exactly the cap (tuning sweeps)
     int tb_plan_wps;         // MIFLOW_TB_WPS: waves/SIMD the band planner assumes (0: table)

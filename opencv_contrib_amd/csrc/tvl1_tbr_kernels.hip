@@ -239,6 +239,7 @@ struct Xchg {
     unsigned mul;               // 1 if a left neighbour feeds this wave | 0x10000 if a right one does: expected tag = (n + 1) * mul
     unsigned tag; float l1, l2, r1, r2;   // slot read ahead for the next stage
     int budget;                 // re-reads this wave may still spend waiting (all stages of the launch together)
+    bool on_r, on_l;            // JW == 2: this LANE publishes to the right / left neighbour (lane 63 / lane 0 of a wave that has one)
 };
 __device__ __forceinline__ void xread(unsigned slot, unsigned &tag, float &l1, float &l2, float &r1, float &r2)
 {
@@ -257,6 +258,29 @@ __device__ __forceinline__ void xwrite(unsigned slot, int data_off, int tag_off,
     *reinterpret_cast<volatile MI_LDS float *>(q + data_off + 4) = b;
     *reinterpret_cast<volatile MI_LDS unsigned short *>(q + tag_off) = (unsigned short)tag;
 }
+// JW == 2 (barrier form): the same hand-over without tags.  The four waves of a workgroup pass one s_barrier per stage, so that
+// everything the left neighbour's stage t-1 published in this step (stage 0: the row that entered) is in LDS before stage t of any
+// wave reads it; the right neighbour's u_t is that of the previous step (the other buffer) and long since there.  A slot is 16
+// bytes {p11, p21, u1, u2}: one ds_read_b128 per stage, two exec-masked ds_write_b64 (only lane 63 / lane 0 publish: no dump area,
+// 38.2 KB of LDS per workgroup = four workgroups per CU like the independent-wave kernel).  s_waitcnt lgkmcnt(0) + s_barrier, NOT
+// __syncthreads: the latter also waits for the row prefetches and stores in flight (vmcnt).
+constexpr int XS2 = 16;
+__host__ __device__ constexpr int xarea2_bytes(int T) { return 2 * T * XS2; }
+__device__ __forceinline__ void xbarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void xread2(unsigned slot, float &l1, float &l2, float &r1, float &r2)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = *reinterpret_cast<volatile MI_LDS f4 *>((lds_ptr)(unsigned long long)slot);
+    l1 = v.x; l2 = v.y; r1 = v.z; r2 = v.w;
+}
+__device__ __forceinline__ void xwrite2(bool on, unsigned addr, float a, float b)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    if (on) {
+        f2 v; v.x = a; v.y = b;
+        *reinterpret_cast<volatile MI_LDS f2 *>((lds_ptr)(unsigned long long)addr) = v;
+    }
+}
 __device__ int g_jw_fault;   // sticky: a bounded wait on a neighbouring wave ran out (never expected; results are then invalid)
 
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
@@ -271,7 +295,10 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     const int r0 = c.ystart + n;
     if (MODE != 2) finish_static<PPL>(X[k].s);
     unsigned xexpect = 0, vtag_r = 0, vtag_l = 0;
-    if (JW) {
+    if (JW == 2) {
+        // the row entering the pipeline: its p11, p21 of lane 63 are the right neighbour's stage-0 input of this step
+        xwrite2(x.on_r, x.pub_r, X[k].d.p11[0], X[k].d.p21[0]);
+    } else if (JW) {
         vtag_r = (unsigned)(n + 1); vtag_l = (unsigned)(n + 2);
         asm volatile("" : "+v"(vtag_r), "+v"(vtag_l), "+v"(x.own));   // one VGPR copy per step, not one v_mov per store
         // the row entering the pipeline: its p11, p21 of lane 63 are the right neighbour's stage-0 input of this step
@@ -316,12 +343,37 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             // belong to a neighbour).  A skipped stage writes nothing, which IS the identity of the rotating scheme: its output
             // set still holds the unmodified input row of the previous step.
             const float es = __uint_as_float((a >= c.y0 && a < c.y1) ? 0x4b800000u : 0u);   // 2^24 or 0, kept on the scalar unit
-            if (t < c.nit)
+            if (JW == 2) {
+                // joined waves, barrier form: every wave of the workgroup passes the barrier of every stage (nit is a property of the
+                // pair, i.e. of the whole workgroup); a skipped stage hands over what it holds -- its unmodified input
+                xbarrier();
+                float l1, l2, r1, r2;
+                xread2(x.own + t * XS2, l1, l2, r1, r2);
+                Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
+                if (t < c.nit) stage_r<PPL, true, 1>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, acc[t], es, l1, l2, r1, r2);
+                if (t + 1 < T) xwrite2(x.on_r, x.pub_r + (t + 1) * XS2, SB.p11[0], SB.p21[0]);
+                xwrite2(x.on_l, x.pub_l + t * XS2 + 8, SA.u1[0], SA.u2[0]);
+            } else if (t < c.nit)
                 stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
                                    c.taut, acc[t], es);
         } else if (MODE == 2) {
             if constexpr (PPL == 1)
                 stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
+        } else if (JW == 2) {
+#ifdef TBR_X_NOBAR_SWITCH   // timing experiment only (wrong results): MIFLOW_TB_NOBAR=1 skips the barriers
+            if (!(c.B.swz & 2)) xbarrier();
+#else
+            xbarrier();
+#endif
+            float l1, l2, r1, r2;
+            xread2(x.own + t * XS2, l1, l2, r1, r2);
+            unsigned long long dummy = 0;
+            Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
+            stage_r<PPL, false, 1>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, dummy, 0.f, l1, l2, r1, r2);
+            // p_t(row a-1) of lane 63 -> stage t+1 of the right neighbour, this step; u_t(row a) of lane 0 -> stage t of the left
+            // neighbour, NEXT step (pub_l points into its other buffer)
+            if (t + 1 < T) xwrite2(x.on_r, x.pub_r + (t + 1) * XS2, SB.p11[0], SB.p21[0]);
+            xwrite2(x.on_l, x.pub_l + t * XS2 + 8, SA.u1[0], SA.u2[0]);
         } else if (JW) {
             // consume the slot read ahead for this stage (re-read until both writers have delivered), read ahead for the next one
             // (stage 0 of the next step lives in the other buffer), compute, hand the new boundary values over
@@ -352,7 +404,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         }
     }
     if (JW) {   // the other buffer for the next step
-        const int d = (n & 1) ? -T * XS : T * XS;
+        const int d = (n & 1) ? -T * (JW == 2 ? XS2 : XS) : T * (JW == 2 ? XS2 : XS);
         x.own += d; x.pub_r += d; x.pub_l -= d;   // pub_l addresses the left neighbour's buffer of the NEXT step: opposite phase
     }
     {   // level-T row r0 - T leaves the pipeline
@@ -402,7 +454,7 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0>
 __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 {
-    static_assert(!JW || (PPL == 1 && MODE == 0 && T > 2), "joined waves: 1 px per lane, fixed work");
+    static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW == 2))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
     constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
     constexpr int LW = (JW ? 256 : 64) * PPL;      // pixels a strip covers: a wave, or the four joined waves of a workgroup
     constexpr int STRIDE = LW - 2 * M;             // owned columns of the strips >= 1 (strip 0 owns LW - M)
@@ -415,7 +467,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     // block -> (strip, band group, pair); with swz the linear workgroup id is remapped so that each XCD (id % 8) owns a
     // contiguous run of strips: neighbouring strips share their halo columns through ONE L2
     int strip = blockIdx.x, bgrp = blockIdx.y, b = blockIdx.z;
-    if (A.swz == 1) {
+    if (A.swz & 1) {
         const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
         const unsigned orig = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
@@ -436,8 +488,22 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     const int xw = (strip == 0 ? 0 : own_lo - M) + (JW ? wave * 64 : 0);   // first pixel of this wave
     const int xl = xw + c.lane * PPL;   // first pixel of this lane, >= 0
     Xchg x;
-    x.own = x.pub_r = x.pub_l = 0; x.mul = 0; x.tag = 0; x.l1 = x.l2 = x.r1 = x.r2 = 0.f; x.budget = 1 << 20;
-    if (JW) {
+    x.own = x.pub_r = x.pub_l = 0; x.mul = 0; x.tag = 0; x.l1 = x.l2 = x.r1 = x.r2 = 0.f; x.budget = 1 << 20; x.on_r = x.on_l = false;
+    if (JW == 2) {
+        // behind the four rings: 4 areas of 2 buffers x T slots x 16 bytes, all zero at the start: a wave without a left / right
+        // neighbour keeps reading zeros there -- the fill of the independent-wave form -- and buffer 0 holds the all-zero u of "step -1"
+        constexpr int XA = xarea2_bytes(T);
+        const unsigned xb = (unsigned)(unsigned long long)(lds_ptr)(lds + 4 * (K * 256 * PPL));
+        const bool has_left = wave > 0, has_right = wave < 3 && xw + 64 < W;
+        x.own = xb + wave * XA;
+        x.pub_r = xb + (wave + 1) * XA;                 // used by lane 63 of a wave with a right neighbour only
+        x.pub_l = xb + (wave - 1) * XA + T * XS2;       // the left neighbour's buffer of step 1; lane 0 of a wave with a left neighbour only
+        x.on_r = has_right && c.lane == 63;
+        x.on_l = has_left && c.lane == 0;
+        for (int i = c.lane; i < XA / 4; i += 64) reinterpret_cast<volatile MI_LDS unsigned *>((lds_ptr)(unsigned long long)x.own)[i] = 0u;
+        __syncthreads();
+        if (xw >= W) return;
+    } else if (JW) {
         // behind the four rings: 4 areas, then 4 dumps.  A wave whose first column lies beyond the image does nothing (and nobody
         // waits for it): its left neighbour's last columns are cut by right_ok exactly as at the right edge of a strip.
         constexpr int XA = xarea_bytes(T), XD = xdump_bytes(T);
@@ -500,7 +566,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0;
     for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE, JW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
-    if (JW && x.budget < 0 && c.lane == 0) g_jw_fault = 1;
+    if (JW == 1 && x.budget < 0 && c.lane == 0) g_jw_fault = 1;
     if (MODE == 1 && record) {
         // integer error sums: exact wave reduction of the owned lanes, one device-scope add per wave and level
 #pragma unroll
@@ -522,9 +588,13 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     TbArgs A = A0;
     A.nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
     A.swz = tuning().tb_swz == 1 ? 1 : 0;
+#ifdef TBR_X_NOBAR_SWITCH
+    if (getenv("MIFLOW_TB_NOBAR")) A.swz |= 2;
+#endif
     // JW: a workgroup is one band of a 256-column strip; otherwise four consecutive bands of a 64-column strip
     const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
-    constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) + (JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
+    constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
+                                 (JW == 2 ? 4 * xarea2_bytes(T) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
         hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -554,11 +624,13 @@ typedef int (*TbLaunchFn)(const TbArgs &, bool, hipStream_t);
 struct TbrEntry {
     int T, PPL, WPS, PF, PLAN;
     TbLaunchFn launch, spec;
-    int JW;   // 1: joined waves (a workgroup = one band of a 256-column strip)
+    int JW;   // 1 / 2: joined waves (a workgroup = one band of a 256-column strip), hand-over by tags / by one barrier per stage
 };
 #define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr, 0}
 // joined waves: the hand-over registers cost 14 VGPRs (3 waves/SIMD), rings + hand-over areas 40.7 KB of LDS = 3 workgroups per CU
-static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 1>, nullptr, 1}};
+static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 1>, nullptr, 1},
+                                     // barrier form (MIFLOW_TB_JW=2): no read-ahead registers, no dump area: four waves/SIMD and four workgroups/CU again
+                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2>, nullptr, 2}};
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
@@ -568,9 +640,11 @@ static const TbrEntry g_tbr[] = {
 };
 // The speculative steps (MODE 1: T accumulator registers more, hence one wave/SIMD less than MODE 0 at T = 10).
 #define TBRS(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1>, 0}
+#define TBRSJ(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1, 2>, 2}
 // PLAN = 2: the bands are cut for two waves per SIMD -- fewer, taller bands (less halo) than the fixed-work kernels use; the other
 // lane's kernels fill the rest of the device (r02m at 1080p x 16, class defaults: 517 -> 545 pairs/s; fixed work loses 7 %).
 static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 2), TBRS(5, 1, 4, 2, 2)};
+static const TbrEntry g_spec_jw[] = {TBRSJ(10, 1, 3, 2, 2), TBRSJ(5, 1, 4, 2, 2)};   // MIFLOW_TB_JW=2 and MIFLOW_TB_JW_SPEC=1
 
 // Exact-math blocks (MODE 2; 1 px per lane).  The stage costs about four times the fast one (three IEEE divisions, two double
 // square roots), so short blocks already move the kernel from the HBM bound of the one-iteration kernel to the issue bound.
@@ -584,7 +658,7 @@ static const TbrEntry *tbr_pick(int T)
     const Tuning &tn = tuning();
     if (tn.tb_jw && tn.tb_ppl < 0)
         for (const TbrEntry &e : g_tbr_jw)
-            if (e.T == T) return &e;
+            if (e.T == T && e.JW == tn.tb_jw) return &e;
     const TbrEntry *def = nullptr;
     for (const TbrEntry &e : g_tbr) {
         if (e.T != T) continue;
@@ -652,7 +726,7 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
     const int T = e.T, ppl = e.PPL, P = T + 1 + e.PF;
     int wps = e.PLAN;
     const int ring_slots = T > 2 ? T - 1 : 1;
-    const int lds_blocks = (160 * 1024) / (ring_slots * 4 * 256 * ppl * 4 + (e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
+    const int lds_blocks = (160 * 1024) / (ring_slots * 4 * 256 * ppl * 4 + (e.JW == 2 ? 4 * xarea2_bytes(T) : e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
     if (wps > lds_blocks) wps = lds_blocks;
     if (tn.tb_plan_wps > 0) wps = tn.tb_plan_wps;
     const long long cap = (long long)device_simds() * wps;
@@ -755,7 +829,8 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
     if (tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
         return iterate_tile_spec(T, pl, g, l_t, theta, taut, ctl, sk, e0, s);
     const TbrEntry *e = nullptr;
-    for (const TbrEntry &c : g_spec) if (c.T == T) e = &c;
+    if (tuning().tb_jw == 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }
+    else { for (const TbrEntry &c : g_spec) if (c.T == T) e = &c; }
     if (!e) { set_error("no speculative kernel for time block %d", T); return MI_ERR_BAD_ARG; }
     TbArgs A;
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.swz = 0; A.nstrips = 0;

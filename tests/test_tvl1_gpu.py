@@ -151,24 +151,27 @@ def test_dpp_wave_shift_semantics(gpu):
 
 
 def test_joined_wave_kernel_is_bit_identical_to_the_independent_wave_kernel(gpu):
-    """MIFLOW_TB_JW=1 (round 3): four waves of a workgroup on four adjacent 64-column segments with LDS hand-over
-    of the seam values instead of a 10-column halo per wave.  Not the default (r03f / r03g: no faster than the independent waves),
-    but the same operations on the same values: digests of u and p after 10 and 20 fused iterations on 15 shapes (one to four waves
-    of a group active, ragged last group, several groups) must be equal, and no wait may have run out of its budget.  The switch is
-    read once per process, hence two subprocesses."""
+    """Joined waves (round 3): four waves of a workgroup on four adjacent 64-column segments with LDS hand-over of
+    the seam values instead of a 10-column halo per wave.  MIFLOW_TB_JW=1 hands over with tags and bounded waits (no faster than the
+    independent waves, r03f / r03g); MIFLOW_TB_JW=2 -- the DEFAULT since r03w / r04a -- with one workgroup barrier per stage (+2.5 % at
+    N = 10, +11 % on the class defaults, whose speculative steps are joined too).  All three run the same operations on the same
+    values: digests of u and p after 10 and 20 fused iterations on 15 shapes (one to four waves of a group active, ragged last
+    group, several groups), and of two convergence-checked calcs, must be equal, and no wait of the tag form may have run out of
+    its budget.  The switch is read once per process, hence the subprocesses."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for jw in ("0", "1"):
+    for jw in ("0", "1", "2"):
         env = dict(os.environ, MIFLOW_TB_JW=jw)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "jw_check.py"), "--quick"], capture_output=True, text=True, env=env,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith(("iterate", "jw_fault"))])
-    assert len(outs[0]) >= 25 and outs[0][-1] == "jw_fault 0"
+    assert len(outs[0]) >= 27 and outs[0][-1] == "jw_fault 0" and sum(l.startswith("iterate-spec") for l in outs[0]) == 2
     assert outs[0] == outs[1]
+    assert outs[0] == outs[2]   # MIFLOW_TB_JW=2: the hand-over by one workgroup barrier per stage instead of tags
 
 
 @pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 6, 8, 10])

@@ -166,7 +166,8 @@ PY
   find $O -type f -size +4M -delete ;;
 pmc_sq)
   cd /tmp
-  timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -f csv -d $R/$O/pmc_sq -- python $R/bench.py --lanes 1 --no-variants --no-cpu --no-secondary --steps 2 --warmup 1 > $R/$O/pmc_sq.log 2>&1
+  rm -rf $R/$O/pmc_sq
+  env ${PMC_ENV:-} timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -f csv -d $R/$O/pmc_sq -- python $R/bench.py --lanes 1 --no-variants --no-cpu --no-secondary --steps 2 --warmup 1 > $R/$O/pmc_sq.log 2>&1
   cd $R
   python - <<PY
 import csv, glob, collections
@@ -180,6 +181,7 @@ for k, v in agg.items():
     w = v.get('SQ_WAVE_CYCLES', 0) or 1
     print(k, {n: round(x / w, 3) for n, x in v.items()}, 'wave_cycles', w)
 PY
+  tail -1 $O/pmc_sq.log | cut -c1-200
   find $O -type f -size +4M -delete ;;
 pmc_secondary)
   cd /tmp
@@ -191,6 +193,9 @@ pmc_secondary)
   find $O -type f -size +4M -delete ;;
 spec_trace)
   (timeout 300 python tools/spec_trace.py --pairs 4 2>&1 | tail -120) > $O/spec_trace.log; head -70 $O/spec_trace.log ;;
+jw2)
+  for jw in 0 2; do (MIFLOW_TB_JW=$jw timeout 600 python tools/jw_check.py > $O/jw_digest_$jw.txt 2>$O/jw_$jw.err); tail -3 $O/jw_digest_$jw.txt; tail -2 $O/jw_$jw.err; done
+  if diff <(grep -v "^#" $O/jw_digest_0.txt) <(grep -v "^#" $O/jw_digest_2.txt) > $O/jw_diff.txt; then echo "JW2 DIGESTS EQUAL"; else echo "JW2 DIGESTS DIFFER"; head -20 $O/jw_diff.txt; fi ;;
 surf_bench)
   (timeout 300 python bench.py --workload surf --no-cpu --steps 5 2>$O/surf.err | tail -1) > $O/surf_bench.json; cut -c1-1800 $O/surf_bench.json; tail -3 $O/surf.err ;;
 test_one)

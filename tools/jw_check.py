@@ -1,7 +1,7 @@
 """Digest of what the blocked iteration kernel produces on a list of shapes (stage-level entry mi_tvl1_iterate, 10 fused iterations per
-launch, two launches) and of whole calcs: run once with MIFLOW_TB_JW=0 and once with MIFLOW_TB_JW=1 (the switch is read once per
-process) and compare the two outputs -- the joined-wave kernel must be bit-identical to the independent-wave kernel.
-Usage: MIFLOW_TB_JW=<0|1> python tools/jw_check.py > digest.txt"""
+launch, two launches) and of whole calcs: run once with MIFLOW_TB_JW=0, once with 1 and once with 2 (the switch is read once per
+process) and compare the outputs -- the joined-wave kernels must be bit-identical to the independent-wave kernel.
+Usage: MIFLOW_TB_JW=<0|1|2> python tools/jw_check.py > digest.txt"""
 import ctypes as C
 import hashlib
 import os
@@ -45,6 +45,16 @@ for (h, w) in shapes:
     for niter in (10, 20):
         uo, po, _ = cuda.tvl1_iterate(ix, iy, grad, rc, u, p, 0.045, 0.3, 0.8333, niter=niter, exact=False, time_block=10, want_err=False)
         print(f"iterate {w}x{h} n={niter} u {digest(uo)} p {digest(po)}", flush=True)
+# the speculative steps of the convergence-checked path (MODE 1) are joined under MIFLOW_TB_JW=2 as well: class defaults on pairs whose
+# levels span one to three 256-column strips, in one batch
+sp = [synth.flow_pair(h_, w_, seed=77 + i)[:2] for i, (h_, w_) in enumerate([(300, 531), (300, 531), (300, 531), (300, 531)])]
+algd = cuda.OpticalFlowDual_TVL1.create()
+fd = algd.calc_batch([torch.from_numpy(a).to(dev) for a, _ in sp], [torch.from_numpy(b).to(dev) for _, b in sp])
+torch.cuda.synchronize()
+print("iterate-spec calc 531x300 x4 class defaults", digest([fd]), flush=True)
+f1 = cuda.OpticalFlowDual_TVL1.create(iterations=40, epsilon=0.02).calc(torch.from_numpy(sp[0][0]).to(dev), torch.from_numpy(sp[0][1]).to(dev))
+torch.cuda.synchronize()
+print("iterate-spec calc 531x300 N=40 eps=0.02", digest([f1]), flush=True)
 if QUICK:
     fault = C.c_int(-1)
     capi.check(capi.lib().miflow_selftest_jw_fault(C.byref(fault)))
