@@ -265,6 +265,12 @@ __device__ __forceinline__ void xwrite(unsigned slot, int data_off, int tag_off,
 // 38.2 KB of LDS per workgroup = four workgroups per CU like the independent-wave kernel).  s_waitcnt lgkmcnt(0) + s_barrier, NOT
 // __syncthreads: the latter also waits for the row prefetches and stores in flight (vmcnt).
 constexpr int XS2 = 16;
+// Stages per barrier interval.  With a constant SKEW of XK stages between neighbouring waves (wave w runs XK * w stages behind wave 0:
+// it passes w barriers before its first step) a barrier every XK stages is enough: in global stage index g = step * T + stage, wave w
+// executes g in interval floor(g / XK) + w; its left input comes from wave w-1's g - 1, executed in interval floor((g - 1) / XK) + w - 1
+// -- always an earlier one --, its right input from wave w+1's g - T, executed in interval floor((g - T) / XK) + w + 1 -- earlier iff
+// T >= 2 XK.  T = 10: two barriers per step instead of ten.
+__host__ __device__ constexpr int xk_stages(int T) { return T >= 10 && T % 5 == 0 ? 5 : 1; }
 __host__ __device__ constexpr int xarea2_bytes(int T) { return 2 * T * XS2; }
 __device__ __forceinline__ void xbarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void xread2(unsigned slot, float &l1, float &l2, float &r1, float &r2)
@@ -346,7 +352,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             if (JW == 2) {
                 // joined waves, barrier form: every wave of the workgroup passes the barrier of every stage (nit is a property of the
                 // pair, i.e. of the whole workgroup); a skipped stage hands over what it holds -- its unmodified input
-                xbarrier();
+                if (t % xk_stages(T) == 0) xbarrier();
                 float l1, l2, r1, r2;
                 xread2(x.own + t * XS2, l1, l2, r1, r2);
                 Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
@@ -360,11 +366,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             if constexpr (PPL == 1)
                 stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
         } else if (JW == 2) {
-#ifdef TBR_X_NOBAR_SWITCH   // timing experiment only (wrong results): MIFLOW_TB_NOBAR=1 skips the barriers
-            if (!(c.B.swz & 2)) xbarrier();
-#else
-            xbarrier();
-#endif
+            if (t % xk_stages(T) == 0) xbarrier();
             float l1, l2, r1, r2;
             xread2(x.own + t * XS2, l1, l2, r1, r2);
             unsigned long long dummy = 0;
@@ -565,7 +567,11 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     unsigned long long acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0;
+    if (JW == 2 && xk_stages(T) > 1)   // the skew: wave w starts w barrier intervals after wave 0 ...
+        for (int i = 0; i < wave; ++i) xbarrier();
     for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE, JW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+    if (JW == 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
+        for (int i = wave; i < 3; ++i) xbarrier();
     if (JW == 1 && x.budget < 0 && c.lane == 0) g_jw_fault = 1;
     if (MODE == 1 && record) {
         // integer error sums: exact wave reduction of the owned lanes, one device-scope add per wave and level
@@ -588,9 +594,6 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     TbArgs A = A0;
     A.nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
     A.swz = tuning().tb_swz == 1 ? 1 : 0;
-#ifdef TBR_X_NOBAR_SWITCH
-    if (getenv("MIFLOW_TB_NOBAR")) A.swz |= 2;
-#endif
     // JW: a workgroup is one band of a 256-column strip; otherwise four consecutive bands of a 64-column strip
     const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
     constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
