@@ -269,8 +269,10 @@ constexpr int XS2 = 16;
 // it passes w barriers before its first step) a barrier every XK stages is enough: in global stage index g = step * T + stage, wave w
 // executes g in interval floor(g / XK) + w; its left input comes from wave w-1's g - 1, executed in interval floor((g - 1) / XK) + w - 1
 // -- always an earlier one --, its right input from wave w+1's g - T, executed in interval floor((g - T) / XK) + w + 1 -- earlier iff
-// T >= 2 XK.  T = 10: two barriers per step instead of ten.
-__host__ __device__ constexpr int xk_stages(int T) { return T >= 10 && T % 5 == 0 ? 5 : 1; }
+// T >= 2 XK.  T = 10: XK = 5, two barriers per step instead of ten; T = 5: XK = 2, five per two steps.  A stage starts an interval when
+// its global index is a multiple of XK; the step index enters through the compile-time phase k of the unrolled block (the block's
+// first step n0 is a multiple of P, and P * T is a multiple of XK: checked in the kernel).
+__host__ __device__ constexpr int xk_stages(int T) { return T >= 10 && T % 5 == 0 ? 5 : T >= 4 ? 2 : 1; }
 __host__ __device__ constexpr int xarea2_bytes(int T) { return 2 * T * XS2; }
 __device__ __forceinline__ void xbarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void xread2(unsigned slot, float &l1, float &l2, float &r1, float &r2)
@@ -302,8 +304,10 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     if (MODE != 2) finish_static<PPL>(X[k].s);
     unsigned xexpect = 0, vtag_r = 0, vtag_l = 0;
     if (JW == 2) {
+        // the two hand-over base addresses live in VGPRs (a ds_* address operand is a VGPR: kept scalar they cost one v_mov per access)
+        asm volatile("" : "+v"(x.own), "+v"(x.pub_l));
         // the row entering the pipeline: its p11, p21 of lane 63 are the right neighbour's stage-0 input of this step
-        xwrite2(x.on_r, x.pub_r, X[k].d.p11[0], X[k].d.p21[0]);
+        xwrite2(x.on_r, x.own + xarea2_bytes(T), X[k].d.p11[0], X[k].d.p21[0]);
     } else if (JW) {
         vtag_r = (unsigned)(n + 1); vtag_l = (unsigned)(n + 2);
         asm volatile("" : "+v"(vtag_r), "+v"(vtag_l), "+v"(x.own));   // one VGPR copy per step, not one v_mov per store
@@ -352,13 +356,13 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             if (JW == 2) {
                 // joined waves, barrier form: every wave of the workgroup passes the barrier of every stage (nit is a property of the
                 // pair, i.e. of the whole workgroup); a skipped stage hands over what it holds -- its unmodified input
-                if (t % xk_stages(T) == 0) xbarrier();
+                if ((k * T + t) % xk_stages(T) == 0) xbarrier();
                 float l1, l2, r1, r2;
-                xread2(x.own + t * XS2, l1, l2, r1, r2);
+                xread2(x.own + t * 2 * XS2, l1, l2, r1, r2);
                 Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
                 if (t < c.nit) stage_r<PPL, true, 1>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, acc[t], es, l1, l2, r1, r2);
-                if (t + 1 < T) xwrite2(x.on_r, x.pub_r + (t + 1) * XS2, SB.p11[0], SB.p21[0]);
-                xwrite2(x.on_l, x.pub_l + t * XS2 + 8, SA.u1[0], SA.u2[0]);
+                if (t + 1 < T) xwrite2(x.on_r, x.own + xarea2_bytes(T) + (t + 1) * 2 * XS2, SB.p11[0], SB.p21[0]);
+                xwrite2(x.on_l, x.pub_l + t * 2 * XS2 + 8, SA.u1[0], SA.u2[0]);
             } else if (t < c.nit)
                 stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
                                    c.taut, acc[t], es);
@@ -366,16 +370,16 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             if constexpr (PPL == 1)
                 stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
         } else if (JW == 2) {
-            if (t % xk_stages(T) == 0) xbarrier();
+            if ((k * T + t) % xk_stages(T) == 0) xbarrier();
             float l1, l2, r1, r2;
-            xread2(x.own + t * XS2, l1, l2, r1, r2);
+            xread2(x.own + t * 2 * XS2, l1, l2, r1, r2);
             unsigned long long dummy = 0;
             Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
             stage_r<PPL, false, 1>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, dummy, 0.f, l1, l2, r1, r2);
-            // p_t(row a-1) of lane 63 -> stage t+1 of the right neighbour, this step; u_t(row a) of lane 0 -> stage t of the left
-            // neighbour, NEXT step (pub_l points into its other buffer)
-            if (t + 1 < T) xwrite2(x.on_r, x.pub_r + (t + 1) * XS2, SB.p11[0], SB.p21[0]);
-            xwrite2(x.on_l, x.pub_l + t * XS2 + 8, SA.u1[0], SA.u2[0]);
+            // p_t(row a-1) of lane 63 -> stage t+1 of the right neighbour (the next area), this step; u_t(row a) of lane 0 -> stage t
+            // of the left neighbour, NEXT step (pub_l points at its slots of the other parity)
+            if (t + 1 < T) xwrite2(x.on_r, x.own + xarea2_bytes(T) + (t + 1) * 2 * XS2, SB.p11[0], SB.p21[0]);
+            xwrite2(x.on_l, x.pub_l + t * 2 * XS2 + 8, SA.u1[0], SA.u2[0]);
         } else if (JW) {
             // consume the slot read ahead for this stage (re-read until both writers have delivered), read ahead for the next one
             // (stage 0 of the next step lives in the other buffer), compute, hand the new boundary values over
@@ -405,8 +409,10 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
                                 c.taut, dummy, 0.f);
         }
     }
-    if (JW) {   // the other buffer for the next step
-        const int d = (n & 1) ? -T * (JW == 2 ? XS2 : XS) : T * (JW == 2 ? XS2 : XS);
+    if (JW == 2) {   // the slots of the other parity for the next step (the two parities of a stage are adjacent: one address bit)
+        x.own ^= XS2; x.pub_l ^= XS2;
+    } else if (JW) {   // the other buffer for the next step
+        const int d = (n & 1) ? -T * XS : T * XS;
         x.own += d; x.pub_r += d; x.pub_l -= d;   // pub_l addresses the left neighbour's buffer of the NEXT step: opposite phase
     }
     {   // level-T row r0 - T leaves the pipeline
@@ -457,6 +463,7 @@ template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0>
 __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
 {
     static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW == 2))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
+    static_assert(JW != 2 || (((T + 1 + PF) * T) % xk_stages(T) == 0 && T >= 2 * xk_stages(T)), "barrier intervals must tile the unrolled block and leave the right neighbour a full interval");
     constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
     constexpr int LW = (JW ? 256 : 64) * PPL;      // pixels a strip covers: a wave, or the four joined waves of a workgroup
     constexpr int STRIDE = LW - 2 * M;             // owned columns of the strips >= 1 (strip 0 owns LW - M)
@@ -492,14 +499,14 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     Xchg x;
     x.own = x.pub_r = x.pub_l = 0; x.mul = 0; x.tag = 0; x.l1 = x.l2 = x.r1 = x.r2 = 0.f; x.budget = 1 << 20; x.on_r = x.on_l = false;
     if (JW == 2) {
-        // behind the four rings: 4 areas of 2 buffers x T slots x 16 bytes, all zero at the start: a wave without a left / right
-        // neighbour keeps reading zeros there -- the fill of the independent-wave form -- and buffer 0 holds the all-zero u of "step -1"
+        // behind the four rings: 4 areas of T stages x 2 parities (of the step) x 16 bytes, all zero at the start: a wave without a left
+        // / right neighbour keeps reading zeros there -- the fill of the independent-wave form -- and parity 0 holds the all-zero u of
+        // "step -1".  Slot of (stage t, parity q) = area + t * 32 + q * 16: the step's parity is ONE address bit (areas are 32-byte aligned)
         constexpr int XA = xarea2_bytes(T);
         const unsigned xb = (unsigned)(unsigned long long)(lds_ptr)(lds + 4 * (K * 256 * PPL));
         const bool has_left = wave > 0, has_right = wave < 3 && xw + 64 < W;
-        x.own = xb + wave * XA;
-        x.pub_r = xb + (wave + 1) * XA;                 // used by lane 63 of a wave with a right neighbour only
-        x.pub_l = xb + (wave - 1) * XA + T * XS2;       // the left neighbour's buffer of step 1; lane 0 of a wave with a left neighbour only
+        x.own = xb + wave * XA;                         // parity 0; the right neighbour's area is own + XA (lane 63 of a wave that has one)
+        x.pub_l = xb + (wave - 1) * XA + XS2;           // the left neighbour's slots of step 1 (parity 1); lane 0 of a wave with a left neighbour only
         x.on_r = has_right && c.lane == 63;
         x.on_l = has_left && c.lane == 0;
         for (int i = c.lane; i < XA / 4; i += 64) reinterpret_cast<volatile MI_LDS unsigned *>((lds_ptr)(unsigned long long)x.own)[i] = 0u;
