@@ -96,9 +96,10 @@ def tbr_band_rows(w, h, pairs, T=10, PF=2, plan_wps=3, simds=1024, jw=None):
     sit side by side on one band of a 256-column strip (the default) instead of on four bands of a 64-column strip."""
     jw = tbr_jw() if jw is None else jw
     P = T + 1 + PF
-    M, LW = T, (256 if jw else 64)
+    nw = 8 if jw == 3 else 4
+    M, LW = T, (64 * nw if jw else 64)
     strips = 1 if w <= LW - M else 1 + -(-(w - (LW - M)) // (LW - 2 * M))
-    per_band, cap = strips * pairs * (4 if jw else 1), simds * plan_wps
+    per_band, cap = strips * pairs * (nw if jw else 1), simds * plan_wps
     best = None
     for nb in range(1, h + 1):
         R = -(-h // nb)
@@ -659,9 +660,9 @@ def static_mix():
     k_iterate_tbr<10, 1, ., 4, 2, 0, 2> (joined waves, barrier form), profiles/static_mix_tbr_jw0.json = the independent-wave form."""
     jw = tbr_jw()
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "static_mix_tbr.json" if jw == 2 else "static_mix_tbr_jw0.json")))["per_stage_and_pixel"]
+        return json.load(open(os.path.join(ROOT, "profiles", "static_mix_tbr.json" if jw >= 2 else "static_mix_tbr_jw0.json")))["per_stage_and_pixel"]
     except Exception:
-        return ({"valu_plain": 38.138, "transcendental": 4.069, "dpp": 4.0, "cndmask": 1.985} if jw == 2 else
+        return ({"valu_plain": 35.338, "transcendental": 4.069, "dpp": 4.0, "cndmask": 1.985} if jw >= 2 else
                 {"valu_plain": 31.662, "transcendental": 4.069, "dpp": 4.0, "cndmask": 2.223})
 
 
@@ -825,7 +826,7 @@ def main():
         mix = static_mix()
         slots = mix["valu_plain"] + mix["dpp"] + mix["cndmask"] + 4.0 * mix["transcendental"]
         jw = tbr_jw()
-        lanes_per_px = 256.0 / 236.0 if jw else 64.0 / 44.0   # joined waves: the T-column margin exists at the two outer edges of a 256-column strip only
+        lanes_per_px = 512.0 / 492.0 if jw == 3 else 256.0 / 236.0 if jw else 64.0 / 44.0   # joined waves: the T-column margin exists at the two outer edges of a 256-column strip only
         ach = px_iter_timed / (ms_it * 1e-3) * slots * lanes_per_px / 1e12
         roof = {"bound": "valu_issue", "kernel": ("k_iterate_tbr<10,1,.,4,2,0,%d> (10 fused estimateU+estimateDualVariables iterations per HBM pass; " % jw) +
                 ("four joined waves per 256-column strip, seam values handed over through LDS)" if jw else "independent 64-column waves)"),

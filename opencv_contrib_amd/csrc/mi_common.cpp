@@ -28,7 +28,7 @@ const Tuning &tuning()
         // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip): 2 (default since r03w) = hand-over with one
         // workgroup barrier per stage, 1 = with tags and bounded waits, 0 = independent 64-column waves; all three bit-identical
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);
-        if (t.tb_jw < 0 || t.tb_jw > 2) t.tb_jw = 2;
+        if (t.tb_jw < 0 || t.tb_jw > 3) t.tb_jw = 2;   // 3: eight joined waves (experiment)
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,
         // epsilon 0.01: 533 -> 593 pairs/s, the same flows
         t.tb_jw_spec = env_int("MIFLOW_TB_JW_SPEC", 1);

@@ -265,6 +265,8 @@ __device__ __forceinline__ void xwrite(unsigned slot, int data_off, int tag_off,
 // 38.2 KB of LDS per workgroup = four workgroups per CU like the independent-wave kernel).  s_waitcnt lgkmcnt(0) + s_barrier, NOT
 // __syncthreads: the latter also waits for the row prefetches and stores in flight (vmcnt).
 constexpr int XS2 = 16;
+// waves of a joined group: JW = 1, 2: four (a 256-column strip); JW = 3: eight (512 columns: 492 owned instead of 2 x 236), barrier form
+__host__ __device__ constexpr int jw_waves(int JW) { return JW == 3 ? 8 : 4; }
 // Stages per barrier interval.  With a constant SKEW of XK stages between neighbouring waves (wave w runs XK * w stages behind wave 0:
 // it passes w barriers before its first step) a barrier every XK stages is enough: in global stage index g = step * T + stage, wave w
 // executes g in interval floor(g / XK) + w; its left input comes from wave w-1's g - 1, executed in interval floor((g - 1) / XK) + w - 1
@@ -303,7 +305,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     const int r0 = c.ystart + n;
     if (MODE != 2) finish_static<PPL>(X[k].s);
     unsigned xexpect = 0, vtag_r = 0, vtag_l = 0;
-    if (JW == 2) {
+    if (JW >= 2) {
         // the two hand-over base addresses live in VGPRs (a ds_* address operand is a VGPR: kept scalar they cost one v_mov per access)
         asm volatile("" : "+v"(x.own), "+v"(x.pub_l));
         // the row entering the pipeline: its p11, p21 of lane 63 are the right neighbour's stage-0 input of this step
@@ -353,7 +355,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             // belong to a neighbour).  A skipped stage writes nothing, which IS the identity of the rotating scheme: its output
             // set still holds the unmodified input row of the previous step.
             const float es = __uint_as_float((a >= c.y0 && a < c.y1) ? 0x4b800000u : 0u);   // 2^24 or 0, kept on the scalar unit
-            if (JW == 2) {
+            if (JW >= 2) {
                 // joined waves, barrier form: every wave of the workgroup passes the barrier of every stage (nit is a property of the
                 // pair, i.e. of the whole workgroup); a skipped stage hands over what it holds -- its unmodified input
                 if ((k * T + t) % xk_stages(T) == 0) xbarrier();
@@ -369,7 +371,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         } else if (MODE == 2) {
             if constexpr (PPL == 1)
                 stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
-        } else if (JW == 2) {
+        } else if (JW >= 2) {
             if ((k * T + t) % xk_stages(T) == 0) xbarrier();
             float l1, l2, r1, r2;
             xread2(x.own + t * 2 * XS2, l1, l2, r1, r2);
@@ -409,7 +411,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
                                 c.taut, dummy, 0.f);
         }
     }
-    if (JW == 2) {   // the slots of the other parity for the next step (the two parities of a stage are adjacent: one address bit)
+    if (JW >= 2) {   // the slots of the other parity for the next step (the two parities of a stage are adjacent: one address bit)
         x.own ^= XS2; x.pub_l ^= XS2;
     } else if (JW) {   // the other buffer for the next step
         const int d = (n & 1) ? -T * XS : T * XS;
@@ -460,12 +462,13 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 //   seams the neighbouring waves hand each other the two values a stage needs from across the seam through LDS (Xchg above).  The
 //   arithmetic of an owned pixel is the same operations on the same values as in the independent-wave form: bit-identical planes.
 template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0>
-__global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
+__global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs A)
 {
-    static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW == 2))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
-    static_assert(JW != 2 || (((T + 1 + PF) * T) % xk_stages(T) == 0 && T >= 2 * xk_stages(T)), "barrier intervals must tile the unrolled block and leave the right neighbour a full interval");
+    static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW >= 2))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
+    static_assert(JW < 2 || (((T + 1 + PF) * T) % xk_stages(T) == 0 && T >= 2 * xk_stages(T)), "barrier intervals must tile the unrolled block and leave the right neighbour a full interval");
     constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
-    constexpr int LW = (JW ? 256 : 64) * PPL;      // pixels a strip covers: a wave, or the four joined waves of a workgroup
+    constexpr int NW = jw_waves(JW);               // waves of a workgroup
+    constexpr int LW = (JW ? 64 * NW : 64) * PPL;  // pixels a strip covers: a wave, or the joined waves of a workgroup
     constexpr int STRIDE = LW - 2 * M;             // owned columns of the strips >= 1 (strip 0 owns LW - M)
     constexpr int P = T + 1 + PF;                  // register sets
     constexpr int K = T > 2 ? T - 1 : 1;           // LDS ring slots: the row of step n is read by stages 2..T-1 at steps n+2..n+T-1
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
         strip = lid % gridDim.x; bgrp = (lid / gridDim.x) % gridDim.y; b = lid / (gridDim.x * gridDim.y);
     }
     strip = __builtin_amdgcn_readfirstlane(strip); bgrp = __builtin_amdgcn_readfirstlane(bgrp); b = __builtin_amdgcn_readfirstlane(b);
-    const int band = JW ? bgrp : bgrp * 4 + wave;
+    const int band = JW ? bgrp : bgrp * 4 + wave;   // (independent waves: NW = 4 bands per workgroup)
     const int W = A.g.w;
     c.H = A.g.h; c.ld = A.g.ld;
     c.y0 = band * A.rows_per_band;
@@ -498,13 +501,13 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     const int xl = xw + c.lane * PPL;   // first pixel of this lane, >= 0
     Xchg x;
     x.own = x.pub_r = x.pub_l = 0; x.mul = 0; x.tag = 0; x.l1 = x.l2 = x.r1 = x.r2 = 0.f; x.budget = 1 << 20; x.on_r = x.on_l = false;
-    if (JW == 2) {
-        // behind the four rings: 4 areas of T stages x 2 parities (of the step) x 16 bytes, all zero at the start: a wave without a left
+    if (JW >= 2) {
+        // behind the NW rings: 4 areas of T stages x 2 parities (of the step) x 16 bytes, all zero at the start: a wave without a left
         // / right neighbour keeps reading zeros there -- the fill of the independent-wave form -- and parity 0 holds the all-zero u of
         // "step -1".  Slot of (stage t, parity q) = area + t * 32 + q * 16: the step's parity is ONE address bit (areas are 32-byte aligned)
         constexpr int XA = xarea2_bytes(T);
-        const unsigned xb = (unsigned)(unsigned long long)(lds_ptr)(lds + 4 * (K * 256 * PPL));
-        const bool has_left = wave > 0, has_right = wave < 3 && xw + 64 < W;
+        const unsigned xb = (unsigned)(unsigned long long)(lds_ptr)(lds + NW * (K * 256 * PPL));
+        const bool has_left = wave > 0, has_right = wave < NW - 1 && xw + 64 < W;
         x.own = xb + wave * XA;                         // parity 0; the right neighbour's area is own + XA (lane 63 of a wave that has one)
         x.pub_l = xb + (wave - 1) * XA + XS2;           // the left neighbour's slots of step 1 (parity 1); lane 0 of a wave with a left neighbour only
         x.on_r = has_right && c.lane == 63;
@@ -574,11 +577,11 @@ __global__ __launch_bounds__(256, WPS) void k_iterate_tbr(TbArgs A)
     unsigned long long acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0;
-    if (JW == 2 && xk_stages(T) > 1)   // the skew: wave w starts w barrier intervals after wave 0 ...
+    if (JW >= 2 && xk_stages(T) > 1)   // the skew: wave w starts w barrier intervals after wave 0 ...
         for (int i = 0; i < wave; ++i) xbarrier();
     for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE, JW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
-    if (JW == 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
-        for (int i = wave; i < 3; ++i) xbarrier();
+    if (JW >= 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
+        for (int i = wave; i < NW - 1; ++i) xbarrier();
     if (JW == 1 && x.budget < 0 && c.lane == 0) g_jw_fault = 1;
     if (MODE == 1 && record) {
         // integer error sums: exact wave reduction of the owned lanes, one device-scope add per wave and level
@@ -596,15 +599,16 @@ template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0>
 static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
-    constexpr int LW = (JW ? 256 : 64) * PPL;
+    constexpr int NW = jw_waves(JW);
+    constexpr int LW = (JW ? 64 * NW : 64) * PPL;
     constexpr int STRIDE = LW - 2 * M;
     TbArgs A = A0;
     A.nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
     A.swz = tuning().tb_swz == 1 ? 1 : 0;
     // JW: a workgroup is one band of a 256-column strip; otherwise four consecutive bands of a 64-column strip
     const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
-    constexpr size_t lds_bytes = (size_t)4 * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
-                                 (JW == 2 ? 4 * xarea2_bytes(T) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
+    constexpr size_t lds_bytes = (size_t)NW * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
+                                 (JW >= 2 ? NW * xarea2_bytes(T) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
         hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -616,14 +620,14 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     if (tuning().tb_verbose) {
         static const int nb = [] {
             int n = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>, 256, lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>, 64 * NW, lds_bytes);
             fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d jw=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, JW, lds_bytes, n);
             return n;
         }();
         (void)nb;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>), grid, dim3(256), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>), grid, dim3(256), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>), grid, dim3(64 * NW), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>), grid, dim3(64 * NW), lds_bytes, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -640,7 +644,9 @@ struct TbrEntry {
 // joined waves: the hand-over registers cost 14 VGPRs (3 waves/SIMD), rings + hand-over areas 40.7 KB of LDS = 3 workgroups per CU
 static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 1>, nullptr, 1},
                                      // barrier form (MIFLOW_TB_JW=2): no read-ahead registers, no dump area: four waves/SIMD and four workgroups/CU again
-                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2>, nullptr, 2}};
+                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2>, nullptr, 2},
+                                     // eight joined waves (MIFLOW_TB_JW=3): 512-column strips, two workgroups of eight waves per CU
+                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 3>, nullptr, 3}};
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
@@ -654,7 +660,7 @@ static const TbrEntry g_tbr[] = {
 // PLAN = 2: the bands are cut for two waves per SIMD -- fewer, taller bands (less halo) than the fixed-work kernels use; the other
 // lane's kernels fill the rest of the device (r02m at 1080p x 16, class defaults: 517 -> 545 pairs/s; fixed work loses 7 %).
 static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 2), TBRS(5, 1, 4, 2, 2)};
-static const TbrEntry g_spec_jw[] = {TBRSJ(10, 1, 3, 2, 2), TBRSJ(5, 1, 4, 2, 2)};   // MIFLOW_TB_JW=2 and MIFLOW_TB_JW_SPEC=1
+static const TbrEntry g_spec_jw[] = {TBRSJ(10, 1, 3, 2, 2), TBRSJ(5, 1, 4, 2, 2)};   // MIFLOW_TB_JW >= 2 and MIFLOW_TB_JW_SPEC=1
 
 // Exact-math blocks (MODE 2; 1 px per lane).  The stage costs about four times the fast one (three IEEE divisions, two double
 // square roots), so short blocks already move the kernel from the HBM bound of the one-iteration kernel to the issue bound.
@@ -736,14 +742,16 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
     const int T = e.T, ppl = e.PPL, P = T + 1 + e.PF;
     int wps = e.PLAN;
     const int ring_slots = T > 2 ? T - 1 : 1;
-    const int lds_blocks = (160 * 1024) / (ring_slots * 4 * 256 * ppl * 4 + (e.JW == 2 ? 4 * xarea2_bytes(T) : e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
+    const int nw = e.JW ? jw_waves(e.JW) : 4;
+    int lds_blocks = (160 * 1024) / (ring_slots * nw * 256 * ppl * 4 + (e.JW >= 2 ? nw * xarea2_bytes(T) : e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
+    lds_blocks = lds_blocks * nw / 4;   // in units of four-wave workgroups (= waves per SIMD)
     if (wps > lds_blocks) wps = lds_blocks;
     if (tn.tb_plan_wps > 0) wps = tn.tb_plan_wps;
     const long long cap = (long long)device_simds() * wps;
     const int M = (T + ppl - 1) / ppl * ppl;
-    const int LW = (e.JW ? 256 : 64) * ppl;
+    const int LW = (e.JW ? 64 * nw : 64) * ppl;
     const long long strips = g.w <= LW - M ? 1 : 1 + div_up(g.w - (LW - M), LW - 2 * M);
-    const long long per_band = strips * g.batch * (e.JW ? 4 : 1);   // waves per band row
+    const long long per_band = strips * g.batch * (e.JW ? nw : 1);   // waves per band row
     long long best_cost = -1;
     int best_nb = 1;
     for (int nb = 1; nb <= g.h; ++nb) {
@@ -839,7 +847,7 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
     if (tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
         return iterate_tile_spec(T, pl, g, l_t, theta, taut, ctl, sk, e0, s);
     const TbrEntry *e = nullptr;
-    if (tuning().tb_jw == 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }
+    if (tuning().tb_jw >= 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }
     else { for (const TbrEntry &c : g_spec) if (c.T == T) e = &c; }
     if (!e) { set_error("no speculative kernel for time block %d", T); return MI_ERR_BAD_ARG; }
     TbArgs A;

@@ -194,8 +194,9 @@ pmc_secondary)
 spec_trace)
   (timeout 300 python tools/spec_trace.py --pairs 4 2>&1 | tail -120) > $O/spec_trace.log; head -70 $O/spec_trace.log ;;
 jw2)
-  for jw in 0 2; do (MIFLOW_TB_JW=$jw timeout 600 python tools/jw_check.py > $O/jw_digest_$jw.txt 2>$O/jw_$jw.err); tail -3 $O/jw_digest_$jw.txt; tail -2 $O/jw_$jw.err; done
-  if diff <(grep -v "^#" $O/jw_digest_0.txt) <(grep -v "^#" $O/jw_digest_2.txt) > $O/jw_diff.txt; then echo "JW2 DIGESTS EQUAL"; else echo "JW2 DIGESTS DIFFER"; head -20 $O/jw_diff.txt; fi ;;
+  J=${JW_B:-2}
+  for jw in 0 $J; do (MIFLOW_TB_JW=$jw timeout 600 python tools/jw_check.py > $O/jw_digest_$jw.txt 2>$O/jw_$jw.err); tail -3 $O/jw_digest_$jw.txt; tail -2 $O/jw_$jw.err; done
+  if diff <(grep -v "^#" $O/jw_digest_0.txt) <(grep -v "^#" $O/jw_digest_$J.txt) > $O/jw_diff.txt; then echo "JW$J DIGESTS EQUAL"; else echo "JW$J DIGESTS DIFFER"; head -20 $O/jw_diff.txt; fi ;;
 surf_bench)
   (timeout 300 python bench.py --workload surf --no-cpu --steps 5 2>$O/surf.err | tail -1) > $O/surf_bench.json; cut -c1-1800 $O/surf_bench.json; tail -3 $O/surf.err ;;
 test_one)
