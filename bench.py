@@ -1087,6 +1087,55 @@ def main():
                 del hs_, sts, outs, lone, chk
             except Exception as e:
                 var[tag] = {"error": repr(e)[:200]}
+        # ... and the pattern as the reference's test actually runs it: cv::parallel_for_ over the 16 (object, stream) pairs, i.e. 16 host
+        # THREADS, each calc() followed by stream.waitForCompletion() in its own thread (test_optflow.cpp:474-484).  A wait inside one
+        # thread's calc() (host feedback) holds up nobody else.  ctypes releases the GIL for the duration of the C call.
+        for (it_, eps_, tag) in ((10, 0.01, "16_threads_16_handles_16_streams_calc_iterations10_eps0.01"),
+                                 (300, 0.01, "16_threads_16_handles_16_streams_calc_class_defaults")):
+            try:
+                import threading
+                nh, rounds = 16, 3
+                hs_ = [create(it_, eps_) for _ in range(nh)]
+                sts = [torch.cuda.Stream(device=dev) for _ in range(nh)]
+                outs = [torch.empty((H, W, 2), dtype=torch.float32, device=dev) for _ in range(nh)]
+                errs = []
+                gate = threading.Barrier(nh + 1)
+
+                def worker(k):
+                    try:
+                        torch.cuda.set_device(dev)
+                        hs_[k].calc(I0[k % B], I1[k % B], outs[k], stream=sts[k].cuda_stream)   # warm-up
+                        sts[k].synchronize()
+                        gate.wait()
+                        for _ in range(rounds):
+                            hs_[k].calc(I0[k % B], I1[k % B], outs[k], stream=sts[k].cuda_stream)
+                            sts[k].synchronize()
+                        gate.wait()
+                    except Exception as e:   # never leave the main thread at the barrier
+                        errs.append(repr(e)[:200])
+                        try:
+                            gate.abort()
+                        except Exception:
+                            pass
+
+                ths = [threading.Thread(target=worker, args=(k,)) for k in range(nh)]
+                for t_ in ths:
+                    t_.start()
+                gate.wait(timeout=300)
+                t1 = time.perf_counter()
+                gate.wait(timeout=300)
+                e16 = time.perf_counter() - t1
+                for t_ in ths:
+                    t_.join(timeout=60)
+                torch.cuda.synchronize()
+                lone = create(it_, eps_)
+                chk = lone.calc(I0[3 % B], I1[3 % B])
+                torch.cuda.synchronize()
+                var[tag] = {"pairs_per_s": nh * rounds / e16, "handles": nh, "streams": nh, "host_threads": nh, "iterations": it_, "epsilon": eps_,
+                            "equals_lone_calc": bool(torch.equal(outs[3], chk)), "errors": errs[:2]}
+                del hs_, sts, outs, lone, chk
+            except Exception as e:
+                var[tag] = {"error": repr(e)[:200]}
         # the reference's own perf test of the class (cudaoptflow/perf/perf_optflow.cpp:283-311): ONE pair per calc(), class defaults
         # (300 iterations, epsilon 0.01), a 640 x 480 frame pair -- and the same at 1080p
         for (ww, hh, tag) in ((640, 480, "reference_perf_test_scenario_640x480_class_defaults_single_calc"), (W, H, "class_defaults_single_pair_calc_sequential")):
