@@ -79,7 +79,7 @@ def algo_bytes_per_pair(w, h, warps, iters_per_warp, nscales=5, step=0.8):
     return float(sum(p * (12 + warps * (44 + 64 * iters_per_warp)) for p in level_pixels(w, h, nscales, step)))
 
 
-WARP_VALU_PER_PX = 234.0   # static count of the interior path of k_warp6<CPU_REF, 32, ., exact sums>: 52 (map, phase weights) + 169 (window) + 13 (grad, rho_c)
+WARP_VALU_PER_PX = 204.0   # static count of the interior path of k_warp6<CPU_REF, 32, ., exact sums>: 52 (map, phase weights) + 139 (window; 169 before round 3 hoisted the 32 multiplies by 0.5 out of the tap products) + 13 (grad, rho_c)
 
 
 def tbr_jw():
