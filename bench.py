@@ -717,7 +717,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (r02z4 at 1080p: 16 | 32 | 64 pairs = 1 142 | 1 202 | 1 092 pairs/s before the band planner change; 16 was the step of the r01 / early r02 records)")
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step.  64 = one GPU's share of BASELINE configs[4] (512 pairs over 8 GPUs), so the N = 1 line and the N = 2 / 4 / 8 lines run the same per-GPU workload; 16 was the step of the r01 / early r02 records, 32 that of r02z .. r04z (r05e / r05f with the joined-wave kernel: 32 | 48 | 64 | 96 | 128 pairs = 1 296 | 1 263-1 277 | 1 313-1 377 | 1 299 | 1 306 pairs/s)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iterations", type=int, default=10)
@@ -918,7 +918,7 @@ def main():
     out = {"metric": "frame-pairs/sec dense TV-L1 flow @1080p", "value": fps, "unit": "pairs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"DualTVL1 dense flow, {W}x{H} CV_32FC1, {B} pairs/GPU/step (BASELINE configs[1])",
+           "config": {"workload": f"DualTVL1 dense flow, {W}x{H} CV_32FC1, {B} pairs/GPU/step (BASELINE configs[1]; 64 pairs/GPU = the per-GPU share of configs[4])",
                       "object": "default-constructed OpticalFlowDual_TVL1 + setNumIterations(N) + setEpsilon(eps); miflow extensions at "
                                 "the library defaults unless listed.  NOTE: the reference's accuracy test (cudaoptflow/test/"
                                 "test_optflow.cpp:448-451) calls setNumIterations(10) ONLY, i.e. epsilon stays 0.01 and its loop is "
@@ -1013,8 +1013,11 @@ def main():
                     "sq_counters": "profiles/r02p/pmc_sq_summary.md (VALU active 0.46, issue-stalled 0.30, parked on waitcnt 0.07 of the wave cycles)"}
         except Exception as e:
             var["iterations10_eps0_one_lane"] = {"error": repr(e)[:200]}
-        # other batch sizes of the same call (16 = the step of the earlier records; 64 = the per-GPU share of BASELINE configs[4])
-        for nb_ in (16, 64):
+        # other batch sizes of the same call (16 / 32 = the steps of the earlier records; 64 = the per-GPU share of BASELINE configs[4])
+        if B == 64:   # the headline IS that figure
+            out["configs4_per_gpu_share_64_pairs"] = {"pairs_per_s": out["value"] / max(1, out["n_gpus"]), "pairs_per_step": 64, "steps": out["steps"],
+                                                      "ms_per_step": out["ms_per_step"], "workload": "the headline of this line (one GPU's share of BASELINE configs[4])"}
+        for nb_ in (16, 32, 64):
             if nb_ == B:
                 continue
             try:
@@ -1022,8 +1025,8 @@ def main():
                 Ib0 = torch.cat([torch.roll(I0, 8 * k, 1) for k in range(reps)], 0)[:nb_].contiguous()
                 Ib1 = torch.cat([torch.roll(I1, 8 * k, 1) for k in range(reps)], 0)[:nb_].contiguous()
                 Fb = torch.empty((nb_, H, W, 2), dtype=torch.float32, device=dev)
-                hb = max(1, hs * B // nb_)
-                eb, _, _, _ = run(args.iterations, args.epsilon, hb, 1, inputs=(Ib0, Ib1), out=Fb)
+                hb = max(2, hs * B // nb_)
+                eb, _, _, _ = run(args.iterations, args.epsilon, hb, 2, inputs=(Ib0, Ib1), out=Fb)   # two warm-up steps: the first one of a new batch size allocates
                 var[f"batch{nb_}_pairs_per_step"] = {"pairs_per_s": nb_ * hb / eb}
                 if nb_ == 64:
                     # BASELINE configs[4]: 512 pairs over 8 GPUs = 64 pairs per GPU and step -- a first-class figure of the line
