@@ -95,7 +95,7 @@ pmc)
   done
   cd $R
   python tools/pmc_summary.py $O > $O/pmc_summary.md 2>&1; head -30 $O/pmc_summary.md
-  python tools/pmc_to_traffic.py $O "profiles/$NAME/pmc_summary.md" > $O/pmc_traffic.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; tail -40 $O/pmc_traffic.log
+  python tools/pmc_to_traffic.py $O "profiles/$NAME/pmc_summary.md" ${PMC_BATCH:-64} > $O/pmc_traffic.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; tail -40 $O/pmc_traffic.log
   find $O -type f -size +4M -delete ;;
 trace_defaults)
   cd /tmp

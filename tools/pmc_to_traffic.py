@@ -25,7 +25,7 @@ def load(d):
 
 def main():
     d, label = sys.argv[1], sys.argv[2]
-    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32   # pairs per step of the profiled bench command (2 lanes)
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64   # pairs per step of the profiled bench command (2 lanes)
     acc = load(d)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     out = json.load(open(path)) if os.path.exists(path) else {}   # keys of other workloads (tools/pmc_secondary.py) are kept
