@@ -313,3 +313,21 @@ def cuda_class_surf(img, hessian_threshold=100.0, n_octaves=4, n_octave_layers=2
         if want_desc:
             out["descriptors"] = out["descriptors"][order]
     return out
+
+
+def cuda_class_dbf_apply(disp, img, ndisp=64, radius=3, iters=1, edge_threshold=-1.0, max_disc_threshold=-1.0, sigma_range=-1.0):
+    """cv::cuda::createDisparityBilateralFilter(ndisp, radius, iters)->apply(disp, img, dst): the reference's HOST class
+    (modules/cudastereo/src/disparity_bilateral_filter.cpp, compiled verbatim: weight tables, edge_disc / max_disc, type dispatch) over the
+    reference kernel.  Negative thresholds keep the constructor's defaults (0.1, 0.2, 10)."""
+    disp = np.ascontiguousarray(disp).copy()
+    img = np.ascontiguousarray(img, np.uint8)
+    assert disp.dtype in (np.uint8, np.int16) and img.shape[:2] == disp.shape
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    L = lib()
+    L.ref_cuhost_dbf_apply.restype = C.c_int
+    L.ref_cuhost_dbf_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rc = L.ref_cuhost_dbf_apply(ndisp, radius, iters, edge_threshold, max_disc_threshold, sigma_range, disp.ctypes.data,
+                                0 if disp.dtype == np.uint8 else 3, img.ctypes.data, ch, disp.shape[1], disp.shape[0])
+    if rc:
+        raise ValueError("the reference class threw")
+    return disp

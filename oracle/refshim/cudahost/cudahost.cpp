@@ -337,4 +337,33 @@ int ref_cuhost_surf(double hessian_threshold, int n_octaves, int n_octave_layers
         return -1;
     }
 }
+
+/* cv::cuda::createDisparityBilateralFilter(ndisp, radius, iters)->apply(disp, image, dst): the reference host class
+ * (modules/cudastereo/src/disparity_bilateral_filter.cpp, verbatim: the colour / space weight tables, edge_disc / max_disc, the type
+ * dispatch) over the reference kernel (disparity_bilateral_filter.cu).  disp_type 0 = CV_8UC1, 3 = CV_16SC1; channels 1 or 3.
+ * Thresholds < 0 keep the constructor's values.  In place on `disp`.  Returns 0, or 1 if the class threw. */
+int ref_cuhost_dbf_apply(int ndisp, int radius, int iters, double edge_threshold, double max_disc_threshold, double sigma_range, void *disp,
+                         int disp_type, const unsigned char *img, int channels, int cols, int rows)
+{
+    using namespace cv;
+    try {
+        Ptr<cuda::DisparityBilateralFilter> f = cuda::createDisparityBilateralFilter(ndisp, radius, iters);
+        if (edge_threshold >= 0) f->setEdgeThreshold(edge_threshold);
+        if (max_disc_threshold >= 0) f->setMaxDiscThreshold(max_disc_threshold);
+        if (sigma_range >= 0) f->setSigmaRange(sigma_range);
+        const int dt = disp_type == 0 ? CV_8UC1 : CV_MAKETYPE(CV_16S, 1), it = channels == 3 ? CV_8UC3 : CV_8UC1;
+        cuda::GpuMat d(Size(cols, rows), dt), im(Size(cols, rows), it), out;
+        const size_t db = (size_t)cols * elem_size_of(dt), ib = (size_t)cols * elem_size_of(it);
+        for (int y = 0; y < rows; ++y) {
+            memcpy(d.ptr<unsigned char>(y), (const unsigned char *)disp + y * db, db);
+            memcpy(im.ptr<unsigned char>(y), img + y * ib, ib);
+        }
+        f->apply(d, im, out, cuda::Stream::Null());
+        CV_Assert(out.rows == rows && out.cols == cols && out.type() == dt);
+        for (int y = 0; y < rows; ++y) memcpy((unsigned char *)disp + y * db, out.ptr<unsigned char>(y), db);
+        return 0;
+    } catch (const std::exception &) {
+        return 1;
+    }
+}
 }

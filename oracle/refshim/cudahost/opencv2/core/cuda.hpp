@@ -41,11 +41,13 @@
 #define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error("CV_Assert failed: " #expr); } while (0)
 #define CV_DbgAssert(expr) CV_Assert(expr)
 #define CV_8U 0
+#define CV_16S 3
 #define CV_32S 4
 #define CV_32F 5
 #define CV_64F 6
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
 #define CV_32SC1 CV_MAKETYPE(CV_32S, 1)
 #define CV_32SC4 CV_MAKETYPE(CV_32S, 4)
 #define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
@@ -86,7 +88,7 @@ public:
     virtual ~Algorithm() {}
     virtual String getDefaultName() const { return "my_object"; }
 };
-inline size_t elem_size_of(int type) { const int d = type & 7, cn = (type >> 3) + 1; return (size_t)cn * (d == CV_8U ? 1 : d == CV_64F ? 8 : 4); }
+inline size_t elem_size_of(int type) { const int d = type & 7, cn = (type >> 3) + 1; return (size_t)cn * (d == CV_8U ? 1 : d == CV_16S ? 2 : d == CV_64F ? 8 : 4); }
 
 namespace cuda { class GpuMat; }
 class Mat {   // a dense host matrix: what diff_sum_host (1 x 1 CV_64F), getGaussianKernel (n x 1 CV_32F) and SURF_CUDA's keypoint /

@@ -365,6 +365,33 @@ def test_disparity_bilateral_filter_equals_reference_kernel_where_it_is_determin
     assert (ref != disp).sum() >= ys.size // 2
 
 
+@pytest.mark.parametrize("radius,iters,dtype,bgr,thr", [(3, 1, np.uint8, False, None), (2, 3, np.int16, True, None), (5, 2, np.uint8, True, (0.25, 0.4, 4.0)),
+                                                        (1, 1, np.int16, False, (0.05, 0.1, 25.0))])
+def test_disparity_bilateral_filter_oracle_equals_the_reference_cuda_host_class(oracle, radius, iters, dtype, bgr, thr):
+    """`DispBilateralFilterImpl` (modules/cudastereo/src/disparity_bilateral_filter.cpp:58-191, compiled verbatim against the reference's
+    own cudastereo.hpp and the stub core): the colour / space weight tables (exp in double -> float, exp(-sqrt(float) / dist) in float),
+    edge_disc = max(1, short(ndisp * edge_threshold + 0.5)), max_disc, the in-place copy and the type dispatch are reference code; the
+    kernel is the reference's (inputs with isolated refined pixels, where its in-place race does not show).  oracle.dbf_apply must
+    give the same map bit for bit, also with non-default thresholds and sigma."""
+    rng = np.random.default_rng(radius * 10 + iters)
+    h, w = 90, 150
+    disp = np.full((h, w), 20, dtype)
+    ys, xs = np.meshgrid(np.arange(radius + 3, h - radius - 3, 2 * radius + 3), np.arange(radius + 3, w - radius - 3, 2 * radius + 3), indexing="ij")
+    disp[ys, xs] = rng.integers(30, 60, size=ys.shape).astype(dtype)
+    scale = 16 if dtype == np.int16 else 1
+    disp = (disp * scale).astype(dtype)
+    g = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    img = np.stack([g, 255 - g, g // 2], -1) if bgr else g
+    kw = {} if thr is None else dict(edge_threshold=thr[0], max_disc_threshold=thr[1], sigma_range=thr[2])
+    ref = refcu.cuda_class_dbf_apply(disp, img, 64 * scale, radius, iters, **kw)
+    got = oracle.dbf_apply(disp, img, oracle.dbf_params(ndisp=64 * scale, radius=radius, iters=iters, **kw))
+    np.testing.assert_array_equal(got, ref)
+    assert (ref != disp).sum() >= ys.size // 4
+    for bad in (dict(ndisp=0), dict(radius=0), dict(iters=0)):     # disparity_bilateral_filter.cpp:179
+        with pytest.raises(ValueError):
+            refcu.cuda_class_dbf_apply(disp, img, **{**dict(ndisp=64, radius=3, iters=1), **bad})
+
+
 def test_disparity_bilateral_filter_on_a_real_map_differs_only_by_the_reference_race(oracle):
     """On a block-matching disparity map (edges: neighbouring refined pixels) the sequential execution of the reference kernel
     realises ONE outcome of its race; the snapshot definition agrees with it on all but a fraction of a percent of the pixels."""
