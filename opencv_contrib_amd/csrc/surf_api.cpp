@@ -149,6 +149,11 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
         // one launch per stage for all octaves where the kernel arguments hold them (surf::fused_supported), else octave by octave
         // through one set of planes; the fused form keeps every octave's planes: ~4/3 of octave 0's
         h->fused = surf::fused_supported(octaves, layers) && !(getenv("MIFLOW_SURF_FUSED") && atoi(getenv("MIFLOW_SURF_FUSED")) == 0);
+        {
+            static const bool lds_ok = surf::lds_geometry_self_check();   // the LDS path's compile-time geometry against the host's
+            const char *e = getenv("MIFLOW_SURF_LDS");
+            surf::set_lds_tiles(lds_ok && !(e && atoi(e) == 0));
+        }
         surf::FusedSizes z;
         z.plane_floats = (size_t)h->dld * rows * (layers + 2);
         z.bits_words = (size_t)layers * rows * div_up(cols, 64);

@@ -721,6 +721,98 @@ __global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, l
     if (threadIdx.x < N) desc[(long long)f * dstep + threadIdx.x] = D[threadIdx.x] / len;
 }
 
+// ------------------------------------------------------------------ octave 0 of the fused launch on an LDS tile (round 3)
+// Three quarters of a frame's samples are octave 0, where the four (nOctaveLayers + 2 <= 4) layers of a sample read 4 x 32 taps from
+// the same neighbourhood of the integral image.  A workgroup stages the (16 + 27) x (64 + 27) patch of a 16 x 64 sample tile ONCE
+// (3.9 K words for 131 K taps) and every layer reads its taps from LDS: lanes are consecutive columns (bank-conflict free) and the tap
+// offsets of octave 0 are COMPILE-TIME constants (sizes 9, 15, 21, 27 and the fixed patch stride), so a tap is a `ds_read_b32` with
+// an immediate offset -- no address arithmetic.  Same integers, same box_div, same order: the planes stay bit-identical.
+constexpr int kLdsTX = 64, kLdsTY = 16, kLdsSMax = 27, kLdsPW = 92, kLdsPH = kLdsTY + kLdsSMax;   // patch 43 rows x 92 words (91 used)
+constexpr int kLdsLayers = 4;
+__host__ __device__ constexpr int lds_rn(float v)   // round to nearest, ties to even (= __float2int_rn / rintf), v >= 0
+{
+    const int f = (int)v;
+    const float r = v - (float)f;
+    return r > 0.5f ? f + 1 : (r < 0.5f ? f : ((f & 1) ? f + 1 : f));
+}
+template <int L>
+struct LdsGeo {   // geometry of octave 0, layer L for the patch stride: the compile-time twin of haar_geo(9 + 6 L, kLdsPW)
+    static constexpr int size = 9 + 6 * L;
+    static constexpr float ratio = (float)size / 9;
+    static constexpr int e(int c) { return lds_rn(ratio * (float)c); }
+    static constexpr int xx(int i, int j) { return e(j ? 7 : 2) * kLdsPW + e(3 * i); }
+    static constexpr int yy(int j, int i) { return e(3 * i) * kLdsPW + e(j ? 7 : 2); }
+    static constexpr int xy(int i, int j) { return e(i == 0 ? 1 : i == 1 ? 4 : i == 2 ? 5 : 8) * kLdsPW + e(j == 0 ? 1 : j == 1 ? 4 : j == 2 ? 5 : 8); }
+    static constexpr double axx(int k) { return (double)((e(3 * k + 3) - e(3 * k)) * (e(7) - e(2))); }
+    static constexpr double a6 = (double)((e(4) - e(1)) * (e(4) - e(1))), a7 = (double)((e(8) - e(5)) * (e(4) - e(1))), a9 = (double)((e(8) - e(5)) * (e(8) - e(5)));
+};
+// host check that the compile-time geometry is haar_geo's (surf_api.cpp calls it once; tests/test_surf.py through the C-ABI self-test)
+template <int L>
+static bool lds_geo_matches()
+{
+    typedef LdsGeo<L> G;
+    const HaarGeo h = haar_geo(G::size, kLdsPW);
+    bool ok = true;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) ok = ok && h.xx[i][j] == G::xx(i, j) && h.yy[j][i] == G::yy(j, i);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) ok = ok && h.xy[i][j] == G::xy(i, j);
+    for (int k = 0; k < 3; ++k) ok = ok && h.area[k] == G::axx(k);
+    return ok && h.area[6] == G::a6 && h.area[7] == G::a7 && h.area[9] == G::a9;
+}
+bool lds_geometry_self_check() { return lds_geo_matches<0>() && lds_geo_matches<1>() && lds_geo_matches<2>() && lds_geo_matches<3>(); }
+
+// Dxx, Dyy, Dxy of one sample of octave 0, layer L from the staged patch; q = the LDS word of the sample's top-left corner
+template <int L>
+__device__ __forceinline__ void haar_det_trace_lds(const unsigned *q, float &d, float &tr)
+{
+    typedef LdsGeo<L> G;
+    unsigned cxx[4][2], cyy[2][4], cxy[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { cxx[a][b] = q[G::xx(a, b)]; cyy[b][a] = q[G::yy(b, a)]; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cxy[a][b] = q[G::xy(a, b)];
+    const double wxx[3] = {1.0, -2.0, 1.0};
+    double sx = 0, sy = 0, sxy = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sx += box_div(cxx[k][0] - cxx[k][1] - cxx[k + 1][0] + cxx[k + 1][1], wxx[k], G::axx(k), 1.0 / G::axx(k));
+        sy += box_div(cyy[0][k] - cyy[0][k + 1] - cyy[1][k] + cyy[1][k + 1], wxx[k], G::axx(k), 1.0 / G::axx(k));
+    }
+    sxy += box_div(cxy[0][0] - cxy[1][0] - cxy[0][1] + cxy[1][1], 1.0, G::a6, 1.0 / G::a6);
+    sxy += box_div(cxy[0][2] - cxy[1][2] - cxy[0][3] + cxy[1][3], -1.0, G::a7, 1.0 / G::a7);
+    sxy += box_div(cxy[2][0] - cxy[3][0] - cxy[2][1] + cxy[3][1], -1.0, G::a7, 1.0 / G::a7);
+    sxy += box_div(cxy[2][2] - cxy[3][2] - cxy[2][3] + cxy[3][3], 1.0, G::a9, 1.0 / G::a9);
+    const float dx = (float)sx, dy = (float)sy, dxy = (float)sxy;
+    d = dx * dy - 0.81f * dxy * dxy;
+    tr = dx + dy;
+}
+// one layer of the tile: the four sample rows of this wave
+template <int L>
+__device__ __forceinline__ void lds_layer(const SumTex &t, const unsigned *patch, int ii0, int jj, int w4, int lane, float *det, float *trace, long long plane0,
+                                          int layer_rows, int layer_cols, int dld)
+{
+    constexpr int size = 9 + 6 * L, m = size >> 1, mmax = kLdsSMax >> 1;
+    const int samples_i = 1 + (t.rows - size), samples_j = 1 + (t.cols - size);
+    const int j = jj - m;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int il = w4 * 4 + r4, ii = ii0 + il, i = ii - m;
+        float d = 0.f, tr = 0.f;
+        if (size <= t.rows && size <= t.cols && i >= 0 && j >= 0 && i < samples_i && j < samples_j)
+            haar_det_trace_lds<L>(patch + (il + mmax - m) * kLdsPW + (lane + mmax - m), d, tr);
+        if (jj < layer_cols && ii < layer_rows) {
+            const long long o = plane0 + (long long)(L * layer_rows + ii) * dld + jj;
+            det[o] = d;
+            trace[o] = tr;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ all octaves of a frame in one launch per stage (round 3)
 // The reference runs its five detector kernels once per octave (surf.cuda.cpp:182-204) and copies two counters to the host in
 // between; round 2 kept the per-octave launches (24 per 4-octave frame, the coarse octaves launch-bound: octave 3 is 1/64 of octave
@@ -740,6 +832,7 @@ struct OctSet {
     int blk_nms[kMaxFusedOctaves + 1];       //   ... of k_nms_flag_all (row groups x segments)
     int blk_wr[kMaxFusedOctaves + 1];        //   ... of k_nms_write_all (row groups)
     int nbx[kMaxFusedOctaves], nby[kMaxFusedOctaves], nseg[kMaxFusedOctaves], chunks[kMaxFusedOctaves];
+    int lds0;                                // octave 0 of k_det_trace_all on LDS tiles (all its layers per workgroup): nby[0] counts 16-row tiles
 };
 __device__ __forceinline__ int find_octave(const int *cum, int n, int id)
 {
@@ -759,6 +852,26 @@ __global__ __launch_bounds__(256) void k_det_trace_all(SumTex t, float *det, flo
     const int nbx = S.nbx[octave], nl2 = S.nlayers + 2;
     const unsigned q = (unsigned)(orig - S.blk_dt[octave]), nwg = (unsigned)(S.blk_dt[octave + 1] - S.blk_dt[octave]);   // nwg % 8 == 0
     const int loc = (int)((q & 7u) * (nwg >> 3) + (q >> 3));
+    __shared__ unsigned patch[kLdsPH * kLdsPW];
+    if (octave == 0 && S.lds0) {
+        if (loc >= nbx * S.nby[0]) return;   // padding (the whole workgroup)
+        const int bx = __builtin_amdgcn_readfirstlane(loc % nbx), by = __builtin_amdgcn_readfirstlane(loc / nbx);
+        const int lane = threadIdx.x & 63, w4 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int ii0 = by * kLdsTY, jj0 = bx * kLdsTX, mmax = kLdsSMax >> 1;
+        // stage the patch: sum-image rows ii0 - 13 .. ii0 + 29, columns jj0 - 13 .. jj0 + 77, clamped into the table (what lies outside is
+        // read by samples that are not valid and are written as 0)
+        for (int r = w4; r < kLdsPH; r += 4) {
+            const unsigned *row = t.s + (long long)min(max(ii0 - mmax + r, 0), t.rows) * t.sld;
+            for (int c = lane; c < kLdsPW; c += 64) patch[r * kLdsPW + c] = row[min(max(jj0 - mmax + c, 0), t.cols)];
+        }
+        __syncthreads();
+        const int jj = jj0 + lane;
+        lds_layer<0>(t, patch, ii0, jj, w4, lane, det, trace, S.plane0[0], t.rows, t.cols, S.dld);
+        lds_layer<1>(t, patch, ii0, jj, w4, lane, det, trace, S.plane0[0], t.rows, t.cols, S.dld);
+        if (nl2 > 2) lds_layer<2>(t, patch, ii0, jj, w4, lane, det, trace, S.plane0[0], t.rows, t.cols, S.dld);
+        if (nl2 > 3) lds_layer<3>(t, patch, ii0, jj, w4, lane, det, trace, S.plane0[0], t.rows, t.cols, S.dld);
+        return;
+    }
     if (loc >= nbx * S.nby[octave] * nl2) return;   // padding
     const int bx = __builtin_amdgcn_readfirstlane(loc % nbx), layer = __builtin_amdgcn_readfirstlane((loc / nbx) % nl2),
               by = __builtin_amdgcn_readfirstlane(loc / (nbx * nl2));
@@ -892,11 +1005,14 @@ int interpolate(const float *det, int dld, int rows, int cols, int octave, const
 size_t interp_tmp_bytes(int max_candidates) { return sizeof(InterpOut) * (size_t)max_candidates; }
 
 // ---- all octaves per launch (k_*_all).  Sizes of the per-octave regions for a frame of rows x cols (the handle allocates them):
+static int g_surf_lds = 1;   // MIFLOW_SURF_LDS=0: octave 0 through the gather path like the other octaves
+void set_lds_tiles(int on) { g_surf_lds = on; }
 static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctaveLayers)
 {
     OctSet S;
     memset(&S, 0, sizeof(S));
     S.n = n_octaves; S.nlayers = nOctaveLayers; S.rows = rows; S.cols = cols; S.dld = dld;
+    S.lds0 = (nOctaveLayers + 2 <= kLdsLayers && g_surf_lds) ? 1 : 0;
     long long plane = 0, bits = 0, seg = 0;
     int row = 0;
     for (int o = 0; o < n_octaves; ++o) {
@@ -904,6 +1020,10 @@ static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctav
         S.plane0[o] = plane; S.bits0[o] = bits; S.row0[o] = row; S.seg0[o] = seg;
         S.chunks[o] = div_up(lc, 64); S.nseg[o] = div_up(S.chunks[o], kNmsSeg);
         S.nbx[o] = div_up(lc, 64); S.nby[o] = div_up(lr, 4);
+        if (o == 0 && S.lds0) {   // one workgroup per 16 x 64 tile and ALL layers
+            S.nby[0] = div_up(lr, kLdsTY);
+            S.blk_dt[1] = align_up(S.nbx[0] * S.nby[0], 8);
+        } else
         S.blk_dt[o + 1] = S.blk_dt[o] + align_up(S.nbx[o] * S.nby[o] * (nOctaveLayers + 2), 8);   // padded: see k_det_trace_all
         S.blk_nms[o + 1] = S.blk_nms[o] + div_up(nOctaveLayers * lr, 4) * S.nseg[o];
         S.blk_wr[o + 1] = S.blk_wr[o] + div_up(nOctaveLayers * lr, 4);
