@@ -296,22 +296,36 @@ __device__ __forceinline__ void nms_flag_row(const NmsArgs &A, int r, int seg)
         for (int k = 0; k < CB; ++k) {
             if (c0 + k >= cend) break;
             const int j = (c0 + k) * 64 + lane;
-            bool ismax = false;
-            if (in[k] && v[k] > A.thr) {
+            // The 26 strict comparisons of surf.cu:316-343 in FOUR wave-uniform stages -- same row, the two other rows of the layer, the
+            // layer below, the layer above -- each entered only while some lane of the chunk is still a candidate.  On a textured
+            // frame most chunks hold values above the threshold (r06c) but in-plane maxima are rare: the two loads of the first stage
+            // end nearly every chunk, where the one-stage form issued all 26 loads for every chunk with one value above the threshold.
+            // margin >= 1 and 1 <= layer <= nlayers keep every neighbour inside the planes: nine row pointers, immediate column offsets.
+            bool ismax = in[k] && v[k] > A.thr;
+            if (ismax && A.mask.s) {
                 const int sum_i = (i - ((size >> 1) >> A.octave)) << A.octave, sum_j = (j - ((size >> 1) >> A.octave)) << A.octave;
-                if (!A.mask.s || mask_check(A.mask, sum_i, sum_j, size)) {
-                    // 26 neighbours: margin >= 1 and 1 <= layer <= nlayers keep all of them inside the planes, so the nine rows
-                    // are nine pointers and the columns j - 1, j, j + 1 immediate offsets (the round-2 form clamped and rebuilt
-                    // a 64-bit address per neighbour: ~300 VALU per chunk that holds a single value above the threshold)
-                    const float *ctr = A.det + (long long)(layer * layer_rows + i) * A.dld + j;
-                    ismax = true;
+                ismax = mask_check(A.mask, sum_i, sum_j, size);
+            }
+            const float *ctr = A.det + (long long)(layer * layer_rows + i) * A.dld + j;
+            const float vk = v[k];
+            if (__ballot(ismax) != 0ull) {
+                if (ismax) ismax = vk > ctr[-1] && vk > ctr[1];
+                if (__ballot(ismax) != 0ull) {
+                    if (ismax) {
+                        const float *qa = ctr - A.dld, *qb = ctr + A.dld;
+                        ismax = vk > qa[-1] && vk > qa[0] && vk > qa[1] && vk > qb[-1] && vk > qb[0] && vk > qb[1];
+                    }
 #pragma unroll
-                    for (int dl = -1; dl <= 1; ++dl)
+                    for (int dl = -1; dl <= 1; dl += 2) {
+                        if (__ballot(ismax) == 0ull) break;
+                        if (ismax) {
 #pragma unroll
-                        for (int di = -1; di <= 1; ++di) {
-                            const float *q = ctr + (long long)(dl * layer_rows + di) * A.dld;
-                            ismax = ismax && v[k] > q[-1] && v[k] > q[1] && ((dl == 0 && di == 0) || v[k] > q[0]);
+                            for (int di = -1; di <= 1; ++di) {
+                                const float *q = ctr + (long long)(dl * layer_rows + di) * A.dld;
+                                ismax = ismax && vk > q[-1] && vk > q[0] && vk > q[1];
+                            }
                         }
+                    }
                 }
             }
             const unsigned long long m = __ballot(ismax);
@@ -400,10 +414,10 @@ __device__ __forceinline__ bool solve3x3(const float A[3][3], const float b[3], 
 // appends the accepted features in candidate order behind the features of the previous octaves.
 struct InterpOut { float px, py, psize, hess; int lap, ok; };
 
-__device__ __forceinline__ void interp_eval_one(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
+__device__ __forceinline__ bool interp_eval_one(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
                                                 const unsigned *ncand_p, InterpOut *tmp, int c)
 {
-    if (c >= (int)*ncand_p) return;
+    if (c >= (int)*ncand_p) return false;
     const int layer_rows = rows >> octave;
     const int4 mp = cand[c];
     float N9[3][3][3];
@@ -445,6 +459,7 @@ __device__ __forceinline__ void interp_eval_one(const float *det, int dld, int r
     }
     o.ok = ok ? 1 : 0;
     tmp[c] = o;
+    return ok;
 }
 __global__ __launch_bounds__(256) void k_interp_eval(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
                                                      const unsigned *ncand_p, InterpOut *tmp)
@@ -928,19 +943,26 @@ __global__ __launch_bounds__(256) void k_nms_write_all(NmsArgs B, OctSet S, int4
                   max_candidates, ncand + octave);
 }
 __global__ __launch_bounds__(256) void k_interp_eval_all(const float *det, OctSet S, const int4 *cand, const unsigned *ncand, InterpOut *tmp,
-                                                         int max_candidates)
+                                                         int max_candidates, unsigned *okcnt)
 {
     const int octave = blockIdx.y;
-    interp_eval_one(det + S.plane0[octave], S.dld, S.rows, S.cols, octave, cand + (long long)octave * max_candidates, ncand + octave,
-                    tmp + (long long)octave * max_candidates, blockIdx.x * 256 + threadIdx.x);
+    const bool ok = interp_eval_one(det + S.plane0[octave], S.dld, S.rows, S.cols, octave, cand + (long long)octave * max_candidates, ncand + octave,
+                                    tmp + (long long)octave * max_candidates, blockIdx.x * 256 + threadIdx.x);
+    // accepted candidates of the octave (one atomic per wave): k_interp_compact_all's workgroup of octave o starts at the sum over o' < o
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(okcnt + octave, (unsigned)__popcll(m));
 }
+// One workgroup per octave (round 3; one workgroup walked the octaves in turn: 33 us per 4K frame).  The features of octave o follow
+// those of octave o - 1: its first index is the number of accepted candidates of the octaves before it (okcnt, counted by
+// k_interp_eval_all); the feature counter itself starts at 0 (the caller zeroes it) and is written by the last octave's workgroup.
 __global__ __launch_bounds__(1024) void k_interp_compact_all(const InterpOut *tmp, const unsigned *ncand, int n_octaves, int max_candidates,
-                                                             float *kp, int kld, int max_features, unsigned *nfeat_p)
+                                                             float *kp, int kld, int max_features, unsigned *nfeat_p, const unsigned *okcnt)
 {
-    unsigned nfeat = *nfeat_p;
-    for (int octave = 0; octave < n_octaves; ++octave)   // in octave order: the features of octave o follow those of octave o - 1
-        nfeat = interp_compact_body(tmp + (long long)octave * max_candidates, ncand + octave, octave, kp, kld, max_features, nfeat);
-    if (threadIdx.x == 0) *nfeat_p = nfeat;
+    const int octave = blockIdx.x;
+    unsigned nfeat0 = 0;
+    for (int o = 0; o < octave; ++o) nfeat0 += okcnt[o];
+    const unsigned nfeat = interp_compact_body(tmp + (long long)octave * max_candidates, ncand + octave, octave, kp, kld, max_features, nfeat0);
+    if (octave == n_octaves - 1 && threadIdx.x == 0) *nfeat_p = nfeat;
 }
 
 // ------------------------------------------------------------------ host launchers
@@ -1070,9 +1092,9 @@ int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int row
     hipLaunchKernelGGL(k_scan_counts_all, dim3(n_octaves), dim3(1024), 0, s, B, S);
     hipLaunchKernelGGL(k_nms_write_all, dim3(S.blk_wr[n_octaves]), dim3(256), 0, s, B, S, cand, max_candidates, ncand);
     hipLaunchKernelGGL(k_interp_eval_all, dim3(div_up(max_candidates, 256), n_octaves), dim3(256), 0, s, (const float *)det, S, (const int4 *)cand,
-                       (const unsigned *)ncand, (InterpOut *)tmp, max_candidates);
-    hipLaunchKernelGGL(k_interp_compact_all, dim3(1), dim3(1024), 0, s, (const InterpOut *)tmp, (const unsigned *)ncand, n_octaves, max_candidates, kp,
-                       kld, max_features, nfeat);
+                       (const unsigned *)ncand, (InterpOut *)tmp, max_candidates, nfeat + 32);   // counters[32 + octave]: zeroed with the others
+    hipLaunchKernelGGL(k_interp_compact_all, dim3(n_octaves), dim3(1024), 0, s, (const InterpOut *)tmp, (const unsigned *)ncand, n_octaves, max_candidates, kp,
+                       kld, max_features, nfeat, (const unsigned *)(nfeat + 32));
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
