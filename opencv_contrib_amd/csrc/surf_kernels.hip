@@ -98,6 +98,47 @@ __global__ __launch_bounds__(256) void k_int_rows(const unsigned *V, const unsig
         carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
     }
 }
+// pass B, wide form (round 3): ONE WORKGROUP of 8 waves per row, each wave a contiguous run of up to kRowCpw 64-column chunks whose loads
+// are all in flight together; the waves' totals meet in LDS and each wave adds the sum of the totals to its left before it stores.  The
+// one-wave-per-row form walks a 4K row in 60 dependent round trips (27 us per 4K frame); rows wider than 8 x kRowCpw chunks keep it.
+constexpr int kRowWaves = 8, kRowCpw = 16;
+__global__ __launch_bounds__(64 * kRowWaves) void k_int_rows_wide(const unsigned *V, const unsigned *BT, int vld, int rows, int cols, int band_rows,
+                                                                  unsigned *sum, int sld, int cpw)
+{
+    __shared__ unsigned tot[kRowWaves];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int y = blockIdx.x;   // y == rows: the zero top row
+    if (y == rows) {
+        for (int x = threadIdx.x; x <= cols; x += 64 * kRowWaves) sum[x] = 0;
+        return;
+    }
+    const unsigned *bt = BT + (long long)(y / band_rows) * vld;
+    const unsigned *vr = V + (long long)y * vld;
+    unsigned v[kRowCpw];
+    const int c0 = wv * cpw;
+#pragma unroll
+    for (int k = 0; k < kRowCpw; ++k) {
+        const int x = (c0 + k) * 64 + lane;
+        v[k] = (k < cpw && x < cols) ? vr[x] + bt[x] : 0u;
+    }
+    unsigned carry = 0;
+#pragma unroll
+    for (int k = 0; k < kRowCpw; ++k) {
+        v[k] = wave_incl_scan(v[k]) + carry;
+        carry = (unsigned)__builtin_amdgcn_readlane((int)v[k], 63);
+    }
+    if (lane == 0) tot[wv] = carry;
+    __syncthreads();
+    unsigned off = 0;
+    for (int w = 0; w < wv; ++w) off += tot[w];
+    unsigned *out = sum + (long long)(y + 1) * sld;
+    if (threadIdx.x == 0) out[0] = 0;
+#pragma unroll
+    for (int k = 0; k < kRowCpw; ++k) {
+        const int x = (c0 + k) * 64 + lane;
+        if (k < cpw && x < cols) out[x + 1] = v[k] + off;
+    }
+}
 __global__ void k_dbg_scan(const unsigned *in, unsigned *out) { out[threadIdx.x] = wave_incl_scan(in[threadIdx.x]); }
 
 // ------------------------------------------------------------------ Haar responses
@@ -972,7 +1013,11 @@ int integral(const unsigned char *img, long long istep, int rows, int cols, bool
     const int band_rows = 32, nbands = div_up(rows, band_rows);
     hipLaunchKernelGGL(k_int_cols, dim3(div_up(cols, 256), nbands), dim3(256), 0, s, img, istep, rows, cols, clamp1 ? 1 : 0, V, vld, BT, band_rows);
     hipLaunchKernelGGL(k_int_bands, dim3(div_up(cols, 256)), dim3(256), 0, s, BT, vld, cols, nbands);
-    hipLaunchKernelGGL(k_int_rows, dim3(div_up(rows + 1, 4)), dim3(256), 0, s, V, BT, vld, rows, cols, band_rows, sum, sld);
+    const int cpw = div_up(div_up(cols, 64), kRowWaves);
+    if (cpw <= kRowCpw)
+        hipLaunchKernelGGL(k_int_rows_wide, dim3(rows + 1), dim3(64 * kRowWaves), 0, s, V, BT, vld, rows, cols, band_rows, sum, sld, cpw);
+    else
+        hipLaunchKernelGGL(k_int_rows, dim3(div_up(rows + 1, 4)), dim3(256), 0, s, V, BT, vld, rows, cols, band_rows, sum, sld);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
