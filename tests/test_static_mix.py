@@ -53,3 +53,45 @@ def test_bench_launch_plan_mirrors():
     assert bench.sbm_band_rows(1080, 1920, 128, 7, 8) == 48
     assert 15.0 < bench.sbm_valu_per_pxd() < 20.0
     assert 0.1 < bench.sbm_warmup_ratio() < 0.3
+
+
+def test_blocked_kernels_keep_their_occupancy():
+    """Register budget of the kernels of record (hipcc -Rpass-analysis=kernel-resource-usage, cross-compiled here): the joined-wave T = 10
+    kernel must stay within 128 VGPRs (4 waves per SIMD: r03w / r04f -- the barrier form gave its gain back at 3) without spilling, the
+    speculative kernels may spill SGPRs (they do: DESIGN section 7) but never VGPRs, and the SURF det / trace kernel with its LDS
+    tile and the descriptor kernel must not spill either."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "opencv_contrib_amd", "csrc")
+
+    def usage(src):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-std=c++17", "-ffp-contract=off",
+                            "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-Rpass-analysis=kernel-resource-usage", "-c",
+                            os.path.join(csrc, src), "-o", os.devnull], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = {}
+        name = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                out[name] = {}
+                continue
+            m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+            if m and name:
+                out[name][m.group(1).strip()] = int(m.group(2))
+        return out
+
+    tbr = usage("tvl1_tbr_kernels.hip")
+    rec = [v for k, v in tbr.items() if "k_iterate_tbrILi10ELi1ELb" in k and k.endswith("ELi4ELi2ELi0ELi2EEEvNS0_6TbArgsE")]
+    assert len(rec) == 2   # first pass of a warp (p = 0) and the others
+    for v in rec:
+        assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["SGPRs Spill"] == 0 and v["Occupancy"] >= 4, v
+    for k, v in tbr.items():
+        if k.endswith("ELi2EEEvNS0_6TbArgsE"):      # every joined-wave instantiation (fixed work and speculative steps)
+            assert v.get("VGPRs Spill", 0) == 0, k
+    surf = usage("surf_kernels.hip")
+    for k, v in surf.items():
+        if "k_det_trace_all" in k or "k_descriptors" in k or "k_nms_flag_all" in k:
+            assert v["VGPRs Spill"] == 0 and v["SGPRs Spill"] == 0, (k, v)
+    assert any("k_det_trace_all" in k for k in surf)
