@@ -708,33 +708,11 @@ __device__ float area_filter(const Win &w, float x, float y, float s)   // core/
     return sat_u8(out);
 }
 
-// surf.cu:733-912: one workgroup (8 waves) per feature: 21x21 patch (one sample per thread) -> 16 sub-regions of 25
-// weighted Haar responses, one 32-lane tree per half-wave -> 64 or 128 sums -> L2 normalisation.
+// The 21 x 21 patch P -> 16 sub-regions of 25 weighted Haar responses, one 32-lane tree per half-wave -> 64 or 128 sums -> L2
+// normalisation (surf.cu:786-912); shared by the two patch kernels below.  P and D are the workgroup's shared arrays.
 template <bool EXT>
-__global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
-                                                     int kld, int nfeat, float *desc, long long dstep /* floats */, const float *dw)
+__device__ __forceinline__ void desc_tail(const float (&P)[21][21], float (&D)[128], float (&part)[4], const float *dw, float *desc_row)
 {
-    __shared__ float P[21][21];
-    __shared__ float D[128];
-    // features are ordered by octave, i.e. by patch cost (441 x s^2 texel reads, s up to ~29 at 4 octaves): launch the
-    // expensive ones first so they do not form the tail of the grid
-    const int f = nfeat - 1 - (int)blockIdx.x;
-    if (f < 0) return;
-    Win w;
-    w.img = img; w.step = istep; w.rows = rows; w.cols = cols; w.cx = kp[f]; w.cy = kp[kld + f];
-    const float s = kp[4 * kld + f] * 1.2f / 9.0f;
-    const int win_size = (int)(21 * s);
-    w.win = win_size;
-    w.off = -(win_size - 1.0f) / 2.0f;
-    float ddir = 360.0f - kp[5 * kld + f];
-    if (fabsf(ddir - 360.f) < FLT_EPSILON) ddir = 0.f;
-    ddir *= CV_PI_F / 180.0f;
-    sincosf(ddir, &w.s, &w.c);
-    if (threadIdx.x < 441) {
-        const int tid = threadIdx.x, xl = tid % 21, yl = tid / 21;
-        P[yl][xl] = s > 1 ? area_filter(w, (float)xl, (float)yl, s) : linear_filter(w, yl * s, xl * s);
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tx = lane & 31, half = lane >> 5;
     {
@@ -766,7 +744,6 @@ __global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, l
     // normalize_descriptors<N> (surf.cu:891-912): len = device::reduce<N> of the squares = the 32-lane tree in each of the N / 32 warps,
     // then the tree over the warps' partials (core/cuda/detail/reduce.hpp, GenericOptimized32); val / sqrt(len)
     constexpr int N = EXT ? 128 : 64;
-    __shared__ float part[4];
     if (threadIdx.x < N) {
         const float v = D[threadIdx.x] * D[threadIdx.x];
         const float r = reduce32(v);
@@ -774,7 +751,148 @@ __global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, l
     }
     __syncthreads();
     const float len = sqrtf(EXT ? (part[0] + part[2]) + (part[1] + part[3]) : part[0] + part[1]);
-    if (threadIdx.x < N) desc[(long long)f * dstep + threadIdx.x] = D[threadIdx.x] / len;
+    if (threadIdx.x < N) desc_row[threadIdx.x] = D[threadIdx.x] / len;
+}
+
+// which of the two patch kernels builds feature f's patch: the staged one from cell side s_stage on, as long as one patch row of the
+// feature -- ceil(s) + 3 window rows of floor(21 s) + 2 texels -- fits the tile (a caller may provide keypoints of any size)
+__device__ __forceinline__ bool desc_staged(float s, float s_stage, int tile_bytes)
+{
+    return s >= s_stage && ((long long)ceilf(s) + 3) * ((long long)floorf(20.f * s + s) + 2) <= (long long)tile_bytes;
+}
+// window geometry of feature f (surf.cu:733-760)
+__device__ __forceinline__ float desc_window(Win &w, const unsigned char *img, long long istep, int rows, int cols, const float *kp, int kld, int f)
+{
+    w.img = img; w.step = istep; w.rows = rows; w.cols = cols; w.cx = kp[f]; w.cy = kp[kld + f];
+    const float s = kp[4 * kld + f] * 1.2f / 9.0f;
+    const int win_size = (int)(21 * s);
+    w.win = win_size;
+    w.off = -(win_size - 1.0f) / 2.0f;
+    float ddir = 360.0f - kp[5 * kld + f];
+    if (fabsf(ddir - 360.f) < FLT_EPSILON) ddir = 0.f;
+    ddir *= CV_PI_F / 180.0f;
+    sincosf(ddir, &w.s, &w.c);
+    return s;
+}
+
+// surf.cu:733-912: one workgroup (8 waves) per feature: 21 x 21 patch (one sample per thread, every thread walking its own s x s cell of the
+// rotated window through global memory) -> desc_tail.  Features whose cell side s reaches s_stage are left to k_descriptors_staged.
+template <bool EXT>
+__global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
+                                                     int kld, int nfeat, float *desc, long long dstep /* floats */, const float *dw, float s_stage,
+                                                     int tile_bytes)
+{
+    __shared__ float P[21][21];
+    __shared__ float D[128];
+    __shared__ float part[4];
+    // features are ordered by octave, i.e. by patch cost (441 x s^2 texel reads, s up to ~29 at 4 octaves): launch the
+    // expensive ones first so they do not form the tail of the grid
+    const int f = nfeat - 1 - (int)blockIdx.x;
+    if (f < 0) return;
+    Win w;
+    const float s = desc_window(w, img, istep, rows, cols, kp, kld, f);
+    if (desc_staged(s, s_stage, tile_bytes)) return;
+    if (threadIdx.x < 441) {
+        const int tid = threadIdx.x, xl = tid % 21, yl = tid / 21;
+        P[yl][xl] = s > 1 ? area_filter(w, (float)xl, (float)yl, s) : linear_filter(w, yl * s, xl * s);
+    }
+    __syncthreads();
+    desc_tail<EXT>(P, D, part, dw, desc + (long long)f * dstep);
+}
+
+// The same for LARGE features (round 3, r06w: the 908 octave-3 features of the 4K frame took 743 of the 1 146 us, 818 ns each -- a
+// thread's s x s cell is a rotated lattice, and the 64 cells a wave reads in step lie s pixels apart: 64 cache lines per load, a third
+// of the L1 line rate).  Here the workgroup first STAGES the texels of a strip of patch rows into LDS, lanes arranged as 8 x 8 blocks
+// of the window lattice (a rotated 8 x 8 block covers ~12 image rows: 12-16 lines per load instead of 64), then every sample of the
+// strip accumulates its cell from LDS.  Texel = the same win_get (same float expression per (dy, dx)), accumulation = the same
+// area_filter order: bit-identical patch values.  The strip height is what fits the tile.
+__device__ __forceinline__ float area_filter_lds(const unsigned char *tile, int nc, int dy_lo, float x, float y, float s, int win)
+{
+    const auto T = [&](int dy, int dx) { return (float)tile[(dy - dy_lo) * nc + dx + 1]; };
+    const float fsx1 = x * s, fsx2 = fsx1 + s;
+    const int sx1 = (int)ceilf(fsx1), sx2 = (int)floorf(fsx2);
+    const float fsy1 = y * s, fsy2 = fsy1 + s;
+    const int sy1 = (int)ceilf(fsy1), sy2 = (int)floorf(fsy2);
+    const float scale = 1.f / (fminf(s, win - fsx1) * fminf(s, win - fsy1));
+    float out = 0.f;
+    // a window row of the cell: the texel reads of 8 consecutive dx are issued together, the adds stay in the reference's order
+    const auto row = [&](int dy, float wgt) {
+        const unsigned char *q = tile + (dy - dy_lo) * nc + 1;
+        int dx = sx1;
+        for (; dx + 8 <= sx2; dx += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (float)q[dx + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out = out + v[k] * wgt;
+        }
+        for (; dx < sx2; ++dx) out = out + (float)q[dx] * wgt;
+    };
+    for (int dy = sy1; dy < sy2; ++dy) {
+        row(dy, scale);
+        if (sx1 > fsx1) out = out + T(dy, sx1 - 1) * ((sx1 - fsx1) * scale);
+        if (sx2 < fsx2) out = out + T(dy, sx2) * ((fsx2 - sx2) * scale);
+    }
+    if (sy1 > fsy1) row(sy1 - 1, (sy1 - fsy1) * scale);
+    if (sy2 < fsy2) row(sy2, (fsy2 - sy2) * scale);
+    if ((sy1 > fsy1) && (sx1 > fsx1)) out = out + T(sy1 - 1, sx1 - 1) * ((sy1 - fsy1) * (sx1 - fsx1) * scale);
+    if ((sy1 > fsy1) && (sx2 < fsx2)) out = out + T(sy1 - 1, sx2) * ((sy1 - fsy1) * (fsx2 - sx2) * scale);
+    if ((sy2 < fsy2) && (sx2 < fsx2)) out = out + T(sy2, sx2) * ((fsy2 - sy2) * (fsx2 - sx2) * scale);
+    if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + T(sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
+    return sat_u8(out);
+}
+template <bool EXT>
+__global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
+                                                            int kld, int nfeat, float *desc, long long dstep /* floats */, const float *dw, float s_stage,
+                                                            int tile_bytes)
+{
+    __shared__ float P[21][21];
+    __shared__ float D[128];
+    __shared__ float part[4];
+    extern __shared__ unsigned char tile[];
+    const int f = nfeat - 1 - (int)blockIdx.x;
+    if (f < 0) return;
+    Win w;
+    const float s = desc_window(w, img, istep, rows, cols, kp, kld, f);
+    if (!desc_staged(s, s_stage, tile_bytes)) return;
+    const int dxmax = (int)floorf(20.f * s + s);              // the largest sx2 of area_filter (x = 20)
+    const int nc = dxmax + 2;                                 // tile columns: dx = -1 .. dxmax
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ly = lane >> 3, lx = lane & 7;
+    const int nbc = (nc + 7) >> 3;
+    for (int ya = 0; ya < 21;) {
+        // the strip: patch rows ya .. yb - 1, as many as the tile holds (at least one: the host sizes the tile for that)
+        const int dy_lo = (int)ceilf((float)ya * s) - 1;
+        int yb = ya + 1;
+        while (yb < 21 && ((int)floorf((float)yb * s + s) - dy_lo + 1) * nc <= tile_bytes) ++yb;
+        const int nr = (int)floorf((float)(yb - 1) * s + s) - dy_lo + 1;
+        const int nblk = ((nr + 7) >> 3) * nbc;
+        // 8 x 8 blocks of the window lattice, block row / column carried along (no division per block); eight blocks per trip so that
+        // their loads are in flight together
+        int br = wv / nbc, bc = wv - br * nbc;
+        for (int blk = wv; blk < nblk; blk += 64) {
+            float v[8];
+            int rr[8], cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                rr[u] = br * 8 + ly; cc[u] = bc * 8 + lx;
+                v[u] = (blk + 8 * u < nblk && rr[u] < nr && cc[u] < nc) ? win_get(w, dy_lo + rr[u], cc[u] - 1) : -1.f;
+                bc += 8;
+                while (bc >= nbc) { bc -= nbc; ++br; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] >= 0.f) tile[rr[u] * nc + cc[u]] = (unsigned char)v[u];
+        }
+        __syncthreads();
+        const int nsmp = (yb - ya) * 21;
+        if ((int)threadIdx.x < nsmp) {
+            const int xl = threadIdx.x % 21, yl = ya + threadIdx.x / 21;
+            P[yl][xl] = area_filter_lds(tile, nc, dy_lo, (float)xl, (float)yl, s, w.win);
+        }
+        __syncthreads();
+        ya = yb;
+    }
+    desc_tail<EXT>(P, D, part, dw, desc + (long long)f * dstep);
 }
 
 // ------------------------------------------------------------------ octave 0 of the fused launch on an LDS tile (round 3)
@@ -1158,12 +1276,32 @@ int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int
     return MI_OK;
 }
 
+// Cell side (pixels) from which a feature's patch is built by the staged kernel; MIFLOW_SURF_STAGE_S (0 = never).  The tile must hold
+// one patch row of the largest feature the detector can produce: size <= 27 << 5 would be octave 5; s = size * 1.2 / 9 -- 64 KB
+// holds (s + 3) x (21 s + 2) bytes up to s = 53 (size 400: octave 3's largest is 216).
+static float surf_stage_s()
+{
+    static const float v = [] { const char *e = getenv("MIFLOW_SURF_STAGE_S"); const float x = e ? (float)atof(e) : 5.0f; return x > 0.f ? x : 1e30f; }();
+    return v;
+}
 int descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp, int kld, int nfeat, bool extended,
                 float *desc, long long dstep_floats, const float *dw, hipStream_t s)
 {
     if (nfeat <= 0) return MI_OK;
-    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
-    else hipLaunchKernelGGL(k_descriptors<false>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw);
+    const float ss = surf_stage_s();
+    static const int kTileBytes = [] { const char *e = getenv("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 48; return (kb >= 16 && kb <= 150 ? kb : 48) * 1024; }();
+    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
+    else hipLaunchKernelGGL(k_descriptors<false>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
+    if (ss < 1e29f) {
+        static const hipError_t attr_rc = [] {
+            hipError_t e = hipFuncSetAttribute((const void *)k_descriptors_staged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_descriptors_staged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes);
+            return e;
+        }();
+        MI_HIP_TRY(attr_rc);
+        if (extended) hipLaunchKernelGGL(k_descriptors_staged<true>, dim3(nfeat), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
+        else hipLaunchKernelGGL(k_descriptors_staged<false>, dim3(nfeat), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
+    }
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
