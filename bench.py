@@ -584,14 +584,20 @@ def bench_surf(args):
                                 "k_nms_flag 91 -> 54 us per octave launch).  Not HBM-bound (SURVEY 8d config 4): the integral table "
                                 "(33 MB) is L2 / MALL resident; what is left is the f64 arithmetic of the box sums and ~24 small launches "
                                 "per frame"}}
-    # the descriptor half of a frame (k_orientation + k_descriptors on the keypoints just found): its bound is the gather, not HBM and
-    # not VALU (r03l: halving the per-texel arithmetic changed nothing) -- a patch sample of a feature of scale s reads ~s x s texels
-    # of the ROTATED window, the 64 lanes of a wave sit in 64 different cells of the 21 x 21 patch, so every wave-level byte load
-    # touches 64 different 64-B lines: one line per clock and CU through the vector L1
+    # the descriptor half of a frame (k_orientation + k_descriptors / k_descriptors_staged on the keypoints just found): its bound is the
+    # gather, not HBM and not VALU (r03l: halving the per-texel arithmetic changed nothing).  A patch sample of a feature of scale s reads
+    # ~s x s texels of the ROTATED window.  Small features (s < 5): the 64 lanes of a wave sit in 64 different cells of the 21 x 21 patch, so
+    # a wave-level byte load touches 64 different 64-B lines.  Large features (s >= 5, round 3): the texels are staged through LDS by lanes
+    # arranged as 8 x 8 blocks of the window lattice; a rotated 8 x 8 block covers at most 12 image rows and straddles a line boundary in
+    # a few of them: modelled as 14 lines per 64 texels.  One line per clock and CU through the vector L1 is the peak.
     try:
         kd = cuda.SURF_CUDA.downloadKeypoints(kp)
         sc = np.maximum(np.asarray(kd["size"], np.float64) * 1.2 / 9.0, 1.0)
-        texels = float((441.0 * (sc * sc + 2.0 * sc)).sum())      # s x s interior texels + the fractional border rows / columns of a cell
+        tex = 441.0 * (sc * sc + 2.0 * sc)      # s x s interior texels + the fractional border rows / columns of a cell
+        stage_s = float(os.environ.get("MIFLOW_SURF_STAGE_S", "5") or 5)
+        staged = (sc >= stage_s) if stage_s > 0 else np.zeros_like(sc, bool)
+        texels = float(tex.sum())
+        lines = float(tex[~staged].sum() + tex[staged].sum() * 14.0 / 64.0)
         for _ in range(2):
             alg.detectWithDescriptors(t, keypoints=kp, useProvidedKeypoints=True)
         torch.cuda.synchronize()
@@ -601,13 +607,15 @@ def bench_surf(args):
         torch.cuda.synchronize()
         el_desc = (time.perf_counter() - t0) / (args.steps * n)
         peak_lines = 256 * 2.4e9
-        out["descriptor_roofline"] = {"bound": "l1_gather_lines", "kernel": "k_descriptors (+ k_orientation, integral): orientation and 64-d "
+        out["descriptor_roofline"] = {"bound": "l1_gather_lines", "kernel": "k_descriptors / k_descriptors_staged (+ k_orientation, integral): orientation and 64-d "
                                       "descriptors of the frame's keypoints (useProvidedKeypoints)",
-                                      "achieved": texels / el_desc / 1e9, "peak": peak_lines / 1e9, "unit": "G lines/s",
-                                      "frac": texels / el_desc / peak_lines, "texel_reads_per_frame": texels, "ms_per_frame": 1e3 * el_desc,
-                                      "note": "achieved = rotated-window texel reads (441 cells x (s^2 + 2 s) per feature, s = size x 1.2 / 9) "
-                                              "per second, each a different 64-B line per lane; peak = one line per clock and CU (64 B/clk "
-                                              "vector L1, MI355X_MICROARCH.md)"}
+                                      "achieved": lines / el_desc / 1e9, "peak": peak_lines / 1e9, "unit": "G lines/s",
+                                      "frac": lines / el_desc / peak_lines, "texel_reads_per_frame": texels, "modelled_lines_per_frame": lines,
+                                      "features_staged_through_lds": int(staged.sum()), "ms_per_frame": 1e3 * el_desc,
+                                      "note": "achieved = modelled 64-B line fetches per second: rotated-window texel reads (441 cells x (s^2 + 2 s) per "
+                                              "feature, s = size x 1.2 / 9), one line per read for the features below the staging threshold, 14 lines "
+                                              "per 64 reads for the staged ones; peak = one line per clock and CU (64 B/clk vector L1, "
+                                              "MI355X_MICROARCH.md).  Before the staging (r06w) every read was its own line: 0.45 of the peak"}
     except Exception as e:
         out["descriptor_roofline"] = {"error": repr(e)[:200]}
     # two handles on two streams, frames alternating: distinct handles share nothing (the reference serialises every SURF_CUDA call
