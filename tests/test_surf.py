@@ -307,3 +307,24 @@ int main(void)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     n, bad = (int(x) for x in r.stdout.split())
     assert r.returncode == 0 and n > 2.3e7 and bad == 0, r.stdout
+
+
+@gpu_mark
+def test_staged_descriptor_kernel_is_bit_identical_to_the_global_memory_kernel(gpu):
+    """Round 3: features with a cell side s >= 5 build their 21 x 21 patch in `k_descriptors_staged` -- the texels of a strip of patch rows
+    staged through LDS by lanes arranged as 8 x 8 blocks of the rotated window lattice, then accumulated per sample in the reference's
+    order -- instead of every thread walking its own cell through global memory.  Same texel per (dy, dx), same order of the float
+    adds: the descriptors must be identical to the last bit.  tools/surf_stage_check.py prints digests of the 64- and 128-float
+    descriptors of the 4K blob frame and of 300 provided keypoints of sizes 4 .. 700 px (cells from below the threshold to larger than a
+    tile holds, which stay on the global path); MIFLOW_SURF_STAGE_S is read once per process, hence two subprocesses."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for stage in ("0", "5"):
+        env = dict(os.environ, MIFLOW_SURF_STAGE_S=stage)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "surf_stage_check.py")], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith(("4K blob", "provided sizes"))])
+    assert len(outs[0]) == 4 and all(l.endswith("True") for l in outs[0][2:])
+    assert outs[0] == outs[1]
