@@ -717,6 +717,46 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without an external launcher: re-exec this command line under torch.distributed.run with N
+    ranks on this node (one process per GPU, rendezvous on 127.0.0.1 and a free port) and hand its exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer buffers need it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))   # torchrun would otherwise pin every rank to 1 thread
+    return subprocess.call(cmd, env=env)
+
+
+def rank_identity(torch, dev, dry):
+    """What one rank contributes to `rccl_ranks`: enough to see that N ranks sit on N DIFFERENT GPUs."""
+    import socket
+    d = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(),
+         "host": socket.gethostname()}
+    if not dry:
+        pr = torch.cuda.get_device_properties(dev)
+        d.update({"device_index": dev.index, "name": pr.name,
+                  "uuid": str(getattr(pr, "uuid", "")) or None,
+                  "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                  "hbm_GB": round(pr.total_memory / 2 ** 30, 1)})
+    return d
+
+
+def gather_rank_identities(dist, world, backend, me):
+    ids = [me]
+    if dist is not None:
+        ids = [None] * world
+        dist.all_gather_object(ids, me)
+    keys = [i.get("uuid") or i.get("pci") or (i["host"], i["pid"]) for i in ids]
+    return {"world_size": world, "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist is not None else None,
+            "ranks": ids, "distinct_devices": len(set(map(str, keys)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["tvl1", "stereobm", "farneback", "surf"], default="tvl1")
@@ -742,9 +782,25 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--stop-slack", type=int, default=0, help="mi_tvl1_params.stop_slack (miflow extension; 0 = the reference's exact stopping point)")
     ap.add_argument("--cpu-iterations", type=int, default=None)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check only: bring the N ranks up, all-gather their identities, print the JSON line "
+                         "without touching a GPU (the CPU test of the --gpus N path uses it over gloo)")
     args = ap.parse_args()
     if args.defaults:
         args.iterations, args.epsilon = 300, 0.01
+    # --gpus N IS the number of ranks.  Started by a launcher (WORLD_SIZE in the environment: the driver's
+    # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) the two must agree; started bare with N > 1
+    # (`python bench.py --gpus 8`) this process becomes the launcher of N ranks, one per GPU, and relays their exit code.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        if args.gpus > 1:
+            return sys.exit(self_launch(args.gpus))
+    elif int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks; "
+                 f"refusing to report a line whose n_gpus is not what was asked for")
+    if args.workload != "tvl1" and args.gpus != 1:
+        sys.exit("bench.py: the secondary workloads are single-GPU lines (--gpus 1); the sharded metric is --workload tvl1")
     if args.workload == "stereobm":
         return print(json.dumps(bench_stereobm(args)))
     if args.workload == "surf":
@@ -758,7 +814,7 @@ def main():
 
     import numpy as np
     W, H, B = args.width, args.height, args.batch
-    base_pairs = gen_base_pairs(min(B, 16), H, W)   # forked workers: before torch touches the GPU
+    base_pairs = None if args.dry_run else gen_base_pairs(min(B, 16), H, W)   # forked workers: before torch touches the GPU
     import torch
 
     # one process per GPU; every rank runs its own batch of independent pairs (no data-path collective);
@@ -770,10 +826,23 @@ def main():
     # timing reduction over gloo on the CPU) -- exercises the multi-process control flow where no multi-GPU node is at hand
     backend = os.environ.get("MIFLOW_BENCH_BACKEND", "nccl")
     dist, rank, world, local = parallel.init_distributed(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
     if "MIFLOW_BENCH_DEVICE" in os.environ:
         local = int(os.environ["MIFLOW_BENCH_DEVICE"])
     dev = torch.device("cuda", local)
+    if args.dry_run:
+        ranks_info = gather_rank_identities(dist, world, backend, rank_identity(torch, dev, True))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "rccl_ranks": ranks_info}), flush=True)
+        return
     torch.cuda.set_device(dev)
+    ranks_info = gather_rank_identities(dist, world, backend, rank_identity(torch, dev, False))
+    if world > 1 and backend == "nccl" and ranks_info["distinct_devices"] != world:
+        sys.exit(f"bench.py: {world} ranks but only {ranks_info['distinct_devices']} distinct GPUs: {ranks_info['ranks']}")
     from opencv_contrib_amd import capi, cuda, synth
 
     I0, I1, base = make_inputs(B, H, W, dev, base=base_pairs)
@@ -941,6 +1010,7 @@ def main():
            # every rank's own rate (its batch over its own time, before the closing barrier): a slow GPU or link shows here, the
            # aggregate `value` is all pairs over the SLOWEST rank's time
            "per_rank_pairs_per_s": [B * args.steps / t_ for t_ in local_s],
+           "rccl_ranks": ranks_info,
            "whole_job_algorithmic_GBps": ab_pair * fps / 1e9,
            "whole_job_frac_of_hbm_peak": ab_pair * fps / 1e9 / HBM_PEAK_GBS,
            "epe_vs_analytic_flow_px": epe_gt,
@@ -973,6 +1043,7 @@ def main():
         th.join(float(os.environ.get("MIFLOW_BENCH_EXCHANGE_TIMEOUT", "180")))
         exchange_hung = th.is_alive()
         out["with_scatter_gather"] = {"error": "timed out (watchdog); skipped"} if exchange_hung else box.get("res")
+        out["gathered_flows_identical"] = (out["with_scatter_gather"] or {}).get("gathered_flows_identical")
 
     # the object of the timed run is released here: every variant below creates its own (a handle owns an internal stream, and
     # streams of live handles share the few hardware queues of the device)

@@ -10,6 +10,8 @@
 Also here: the kernels a default calc() is made of that round 2 added (fused-gradient warp, two-lane batches).
 """
 import numpy as np
+import os
+
 import pytest
 
 from opencv_contrib_amd import synth
@@ -268,6 +270,52 @@ def test_multi_device_host_entry_equals_calc_batch(gpu, devices, chunk):
     assert torch.equal(out, ref)
     out2 = multi.calc_batch(I0s[:3], I1s[:3])   # fewer pairs than workers x chunk: some workers idle
     assert torch.equal(out2, ref[:3])
+
+
+def test_multi_device_host_entry_over_distinct_devices(gpu):
+    """The same entry over DIFFERENT GPUs: real peer enable, per-device arena caches, xGMI
+    peer copies, one worker thread per device.  Needs a node with at least two visible devices; the one-GPU test box skips it
+    (the driver's multi-GPU node, if any, runs it).  Every pair's flow must be the bytes mi_tvl1_calc_batch produces on the
+    root device -- the kernels are deterministic and identical on every device."""
+    import torch
+    from opencv_contrib_amd import cuda
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    n = 13
+    pairs = [synth.flow_pair(120, 200, seed=300 + k)[:2] for k in range(n)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    alg = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0)
+    ref = alg.calc_batch(I0s, I1s)
+    torch.cuda.synchronize()
+    for devices, chunk in ((list(range(nd)), 2), ([nd - 1, 0], 16), ([0, 1, 1, 0], 3)):
+        multi = cuda.TVL1MultiDevice(alg, devices=devices, chunk=chunk)
+        assert multi.deviceCount() == len(devices)
+        for _ in range(2):    # the second call re-uses the workers' warm handles and staging slots
+            out = multi.calc_batch(I0s, I1s)
+            assert torch.equal(out, ref), (devices, chunk)
+        del multi
+    torch.cuda.set_device(gpu)
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(gpu):
+    """`python bench.py --gpus 2` on a node with two GPUs: two ranks on two distinct devices over RCCL, the scatter / gather leg
+    included, flows gathered on rank 0 identical to rank 0's own computation of every shard.  Skips on the one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"MIFLOW_BENCH_EXCHANGE_PAIRS": "8", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"]["distinct_devices"] == 2 and len(out["per_rank_pairs_per_s"]) == 2
+    assert out["gathered_flows_identical"] is True, out.get("with_scatter_gather")
 
 
 @pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class_rule", "cv_cuda_schedule"])

@@ -200,3 +200,33 @@ def test_multi_device_state_machine_on_a_fake_device_table(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "multi_sm_test: ok" in r.stdout, r.stderr
+
+
+def _bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+
+
+def test_bench_gpus_flag_is_the_rank_count_without_an_external_launcher():
+    """`python bench.py --gpus 2`, started bare, must BE a 2-rank job (it re-launches itself under
+    torch.distributed.run) -- here over gloo and without touching a GPU (--dry-run); the one JSON line names both ranks."""
+    import json
+    r = _bench(["--gpus", "2", "--dry-run"], {"MIFLOW_BENCH_BACKEND": "gloo", "MIFLOW_BENCH_DEVICE": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # only rank 0 owns stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gpus_arg"] == 2
+    assert out["rccl_ranks"]["world_size"] == 2 and [d["rank"] for d in out["rccl_ranks"]["ranks"]] == [0, 1]
+    assert len({d["pid"] for d in out["rccl_ranks"]["ranks"]}) == 2
+
+
+def test_bench_refuses_a_rank_count_that_is_not_what_gpus_asked_for():
+    """Under a launcher the flag and WORLD_SIZE must agree: a 1-rank group with --gpus 2 fails loudly instead of printing n_gpus 1."""
+    r = _bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+    r = _bench(["--gpus", "0", "--dry-run"])
+    assert r.returncode != 0
+    r = _bench(["--gpus", "2", "--workload", "stereobm"])
+    assert r.returncode != 0 and "single-GPU" in r.stderr
