@@ -574,16 +574,20 @@ def bench_surf(args):
            "config": {"workload": f"SURF_CUDA(400, 4 octaves, 2 layers, 64-d, oriented) on {W}x{H} CV_8UC1 blob image "
                                   f"(BASELINE configs[3]), {n} frames/step", "features": nf},
            "detect_only_frames_per_s": args.steps * n / el_det, "features_per_s": nf * args.steps * n / el,
-           "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el_det / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           # The detector is NOT under the HBM roofline (its tables are L2 / MALL resident): the HBM figures are kept as a view, the bound
+           # named is what the stage is made of -- dependent gathers from the integral table (octaves 1-3: 32 shared-corner taps per
+           # sample; octave 0 from LDS tiles) and the f64 box arithmetic
+           "roofline": {"bound": "gather_latency_and_f64_valu (not hbm)", "achieved": algo * args.steps * n / el_det / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s (HBM view)",
                         "frac": algo * args.steps * n / el_det / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("surf_det_trace")[0],
-                        "traffic_kernel": "k_det_trace, bytes per launch (one octave of one frame, mean over the octaves)",
+                        "traffic_kernel": "per-octave k_det_trace (MIFLOW_SURF_FUSED=0 form; the default path launches k_det_trace_all once per frame for all octaves), "
+                                          "bytes per launch, mean over the octaves",
                         "traffic_source": pmc_traffic("surf_det_trace")[1],
                         "note": "detector stage only; round 3: 32 shared-corner taps per sample with wave-uniform offsets, box sums in u32, "
                                 "division by the box area as reciprocal + one fma correction (exact), XCD-contiguous band order; the row "
                                 "scan of the non-maximum suppression split over 8 waves per 4K row (profiles/r03k: k_det_trace 159 -> 99 us, "
                                 "k_nms_flag 91 -> 54 us per octave launch).  Not HBM-bound (SURVEY 8d config 4): the integral table "
-                                "(33 MB) is L2 / MALL resident; what is left is the f64 arithmetic of the box sums and ~24 small launches "
-                                "per frame"}}
+                                "(33 MB) is L2 / MALL resident; what is left is the f64 arithmetic of the box sums and the dependent gathers; the fused "
+                                "all-octave path needs six launches per frame"}}
     # the descriptor half of a frame (k_orientation + k_descriptors / k_descriptors_staged on the keypoints just found): its bound is the
     # gather, not HBM and not VALU (r03l: halving the per-texel arithmetic changed nothing).  A patch sample of a feature of scale s reads
     # ~s x s texels of the ROTATED window.  Small features (s < 5): the 64 lanes of a wave sit in 64 different cells of the 21 x 21 patch, so
@@ -607,7 +611,7 @@ def bench_surf(args):
         torch.cuda.synchronize()
         el_desc = (time.perf_counter() - t0) / (args.steps * n)
         peak_lines = 256 * 2.4e9
-        out["descriptor_roofline"] = {"bound": "l1_gather_lines", "kernel": "k_descriptors / k_descriptors_staged (+ k_orientation, integral): orientation and 64-d "
+        out["descriptor_roofline"] = {"bound": "l1_gather_lines", "modelled": True, "kernel": "k_descriptors / k_descriptors_staged (+ k_orientation, integral): orientation and 64-d "
                                       "descriptors of the frame's keypoints (useProvidedKeypoints)",
                                       "achieved": lines / el_desc / 1e9, "peak": peak_lines / 1e9, "unit": "G lines/s",
                                       "frac": lines / el_desc / peak_lines, "texel_reads_per_frame": texels, "modelled_lines_per_frame": lines,

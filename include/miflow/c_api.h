@@ -121,7 +121,11 @@ typedef struct mi_tvl1_params {
                           * soon as every pair has stopped: the host waits inside calc() like the reference's own class does at each
                           * of its convergence checks (cudaoptflow/src/tvl1flow.cpp:362-368), about once per warp; larger batches stay
                           * fully stream-ordered.  -1 = never (no host wait inside calc()); 1 = for every single-lane call.  Results
-                          * do not depend on it. */
+                          * do not depend on it.  The wait also covers whatever the caller had queued earlier on that stream, and a
+                          * host thread driving several handles is serialised by it (use -1 there).  While `stream` is being captured
+                          * into a graph (hipStreamBeginCapture) the read-back is switched off whatever this field says: the calc is
+                          * then enqueued fully stream-ordered and the capture stays valid (handle warm, i.e. sized by an earlier
+                          * calc: allocations are not capturable). */
 } mi_tvl1_params;
 
 typedef struct mi_tvl1 mi_tvl1;

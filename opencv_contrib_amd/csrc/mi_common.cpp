@@ -28,7 +28,7 @@ const Tuning &tuning()
         // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip): 2 (default since r03w) = hand-over with one
         // workgroup barrier per stage, 1 = with tags and bounded waits, 0 = independent 64-column waves; all three bit-identical
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);
-        if (t.tb_jw < 0 || t.tb_jw > 3) t.tb_jw = 2;   // 3: eight joined waves (experiment)
+        if (t.tb_jw < 0 || t.tb_jw > 4) t.tb_jw = 2;   // 3: eight joined waves (experiment); 4: barrier form, branch-free publishes, mask-free interior blocks
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,
         // epsilon 0.01: 533 -> 593 pairs/s, the same flows
         t.tb_jw_spec = env_int("MIFLOW_TB_JW_SPEC", 1);
@@ -55,17 +55,27 @@ const Tuning &tuning()
 }
 
 namespace {
-struct BigBlock { void *p; size_t cap; int dev; };
+struct BigBlock { void *p; size_t cap; int dev; hipEvent_t ready; };   // ready: the previous owner's last work on the block (may be null)
 std::mutex g_big_mu;
 std::vector<BigBlock> g_big;
 const size_t kBigMaxBlocks = 4;   // PER DEVICE (two lanes of two handles): eight GPUs of a node each keep their own
-// upper bound of what the cache may hold; MIFLOW_CACHE_GB (0 = cache nothing) for hosts whose own allocator wants the memory back
+// upper bounds of what the cache may hold: MIFLOW_CACHE_GB per DEVICE (0 = cache nothing, for hosts whose own allocator wants the
+// memory back) and MIFLOW_CACHE_TOTAL_GB for the whole process (all devices together; default 4 x the per-device bound)
 size_t big_max_bytes()
 {
     static const size_t v = [] {
         const char *e = getenv("MIFLOW_CACHE_GB");
         const long long gb = e && *e ? atoll(e) : 24;
         return (size_t)(gb < 0 ? 0 : gb) << 30;
+    }();
+    return v;
+}
+size_t big_max_bytes_total()
+{
+    static const size_t v = [] {
+        const char *e = getenv("MIFLOW_CACHE_TOTAL_GB");
+        if (e && *e) { const long long gb = atoll(e); return (size_t)(gb < 0 ? 0 : gb) << 30; }
+        return 4 * big_max_bytes();
     }();
     return v;
 }
@@ -76,15 +86,29 @@ int big_alloc(void **p, size_t bytes, size_t *capacity)
     int dev = 0;
     MI_HIP_TRY(hipGetDevice(&dev));
     {
-        std::lock_guard<std::mutex> lk(g_big_mu);
-        int best = -1;
-        for (size_t i = 0; i < g_big.size(); ++i)
-            if (g_big[i].dev == dev && g_big[i].cap >= bytes && g_big[i].cap <= bytes + bytes / 2 + (64u << 20) &&
-                (best < 0 || g_big[i].cap < g_big[best].cap))
-                best = (int)i;
-        if (best >= 0) {
-            *p = g_big[best].p; *capacity = g_big[best].cap;
-            g_big.erase(g_big.begin() + best);
+        hipEvent_t ready = nullptr;
+        bool hit = false;
+        {
+            std::lock_guard<std::mutex> lk(g_big_mu);
+            int best = -1;
+            for (size_t i = 0; i < g_big.size(); ++i)
+                if (g_big[i].dev == dev && g_big[i].cap >= bytes && g_big[i].cap <= bytes + bytes / 2 + (64u << 20) &&
+                    (best < 0 || g_big[i].cap < g_big[best].cap))
+                    best = (int)i;
+            if (best >= 0) {
+                *p = g_big[best].p; *capacity = g_big[best].cap; ready = g_big[best].ready;
+                g_big.erase(g_big.begin() + best);
+                hit = true;
+            }
+        }
+        if (hit) {
+            // nothing the block's previous owner enqueued may still touch it: wait for ITS last work only (an event recorded when the
+            // block was returned) -- no device-wide synchronisation, other handles' streams keep running
+            if (ready) {
+                const hipError_t we = hipEventSynchronize(ready);
+                (void)hipEventDestroy(ready);
+                if (we != hipSuccess) { (void)hipFree(*p); *p = nullptr; set_error("cached block: %s", hipGetErrorString(we)); return MI_ERR_HIP; }
+            }
             return MI_OK;
         }
     }
@@ -98,7 +122,10 @@ int big_alloc(void **p, size_t bytes, size_t *capacity)
     return MI_OK;
 }
 
-void big_free(void *p, size_t capacity)
+// `streams`: every stream the owner may still have work on that touches the block (null entries are skipped; none = the owner
+// knows the block is idle).  One event after all of them marks the block's release; the next taker waits for that event.  Only when
+// an event cannot be recorded (e.g. the caller destroyed its stream before the handle) the device is synchronised instead.
+void big_free(void *p, size_t capacity, const hipStream_t *streams, int nstreams)
 {
     if (!p) return;
     int dev = 0;
@@ -107,25 +134,44 @@ void big_free(void *p, size_t capacity)
         hipPointerAttribute_t at;
         const int cur = dev;
         if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;
-        // a cached block may be handed to another handle / stream at once: nothing enqueued by its previous owner may still use it.
-        // hipFree synchronised the device implicitly; the cache keeps that guarantee explicitly (free_arena runs on destroy and on
-        // a change of the image size only, never in a steady-state calc).
         if (dev != cur) (void)hipSetDevice(dev);
-        const bool idle = hipDeviceSynchronize() == hipSuccess;
+        hipEvent_t ready = nullptr;
+        bool idle = true;
+        if (nstreams > 0) {
+            // one event on the first stream after it has been made to wait for the others
+            idle = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
+            for (int i = 1; idle && i < nstreams; ++i) {
+                if (streams[i] == streams[0]) continue;
+                hipEvent_t ev = nullptr;
+                idle = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, streams[i]) == hipSuccess &&
+                       hipStreamWaitEvent(streams[0], ev, 0) == hipSuccess;
+                if (ev) (void)hipEventDestroy(ev);
+            }
+            idle = idle && hipEventRecord(ready, streams[0]) == hipSuccess;
+            if (!idle) {
+                (void)hipGetLastError();
+                if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
+                idle = hipDeviceSynchronize() == hipSuccess;   // the fallback keeps the guarantee
+            }
+        }
         if (dev != cur) (void)hipSetDevice(cur);
         std::lock_guard<std::mutex> lk(g_big_mu);
-        size_t total = capacity, blocks = 0;
-        for (const BigBlock &b : g_big)
+        size_t total = capacity, all = capacity, blocks = 0;
+        for (const BigBlock &b : g_big) {
+            all += b.cap;
             if (b.dev == dev) { total += b.cap; ++blocks; }
-        if (idle && blocks < kBigMaxBlocks && total <= big_max_bytes()) {
-            g_big.push_back({p, capacity, dev});
+        }
+        if (idle && blocks < kBigMaxBlocks && total <= big_max_bytes() && all <= big_max_bytes_total()) {
+            g_big.push_back({p, capacity, dev, ready});
             return;
         }
+        if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }
         drop = p;
     } else {
         drop = p;
     }
-    (void)hipFree(drop);
+    const hipError_t fe = hipFree(drop);
+    if (fe != hipSuccess) set_error("hipFree of a %zu-byte arena failed: %s", capacity, hipGetErrorString(fe));
 }
 
 void big_trim()
@@ -137,7 +183,10 @@ void big_trim()
     }
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
-    for (const BigBlock &b : all) (void)hipFree(b.p);   // hipFree takes pointers of any device
+    for (const BigBlock &b : all) {
+        if (b.ready) { (void)hipEventSynchronize(b.ready); (void)hipEventDestroy(b.ready); }
+        (void)hipFree(b.p);   // hipFree takes pointers of any device
+    }
     if (have) (void)hipSetDevice(cur);
 }
 

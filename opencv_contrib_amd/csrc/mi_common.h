@@ -74,13 +74,14 @@ struct DevTmp {
     }
 };
 // Large device blocks (the per-lane TV-L1 arenas) come from a small process-wide cache: a block released by a handle is kept
-// (at most 4 blocks / MIFLOW_CACHE_GB = 24 GB PER DEVICE, after a device synchronisation: nothing of its previous owner is still
-// in flight when the next taker gets it) and handed to the next request of a similar size on the same device.  Measured on
+// (at most 4 blocks / MIFLOW_CACHE_GB = 24 GB PER DEVICE and MIFLOW_CACHE_TOTAL_GB = 4 x that per process; with an event behind
+// its previous owner's last work, which the next taker waits for: nothing of the previous owner is still in flight when the block is
+// used again, and no other handle's stream is stalled by a destroy) and handed to the next request of a similar size on the same device.  Measured on
 // MI355X / ROCm 7.2 (r02q): an arena obtained by hipMalloc right after a hipFree of the same size runs the same kernels 25 %
 // slower than the freed one did (390 vs 520 pairs/s, class defaults), i.e. create / destroy cycles of handles must not go
 // through the driver.  mi_release_cached_memory() returns everything to the driver.
 int big_alloc(void **p, size_t bytes, size_t *capacity);
-void big_free(void *p, size_t capacity);
+void big_free(void *p, size_t capacity, const hipStream_t *streams = nullptr, int nstreams = 0);
 void big_trim();
 int device_simds();
 

@@ -26,8 +26,11 @@ struct mi_surf {
     int sld = 0, vld = 0, dld = 0;
     // all octaves per launch (surf::detect_fused): region sizes and the per-(octave, layer) filter geometry on the device
     bool fused = false;
+    int lds_tiles = 0;   // octave 0 of the fused det / trace launch on LDS tiles: this handle's decision (MIFLOW_SURF_LDS=0 switches it off)
     int capO = 0;
     void *geo = nullptr;
+    std::vector<unsigned char> geo_host;   // source of the asynchronous upload: outlives the call
+    bool geo_dirty = false;
 };
 
 static int calc_size(int octave, int layer) { return (9 + 6 * layer) << octave; }
@@ -140,10 +143,12 @@ int mi_surf_max_features(const mi_surf *h, int rows, int cols, int *max_features
     return limits(h->P, rows, cols, max_features, &mc);
 }
 
-static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool need_mask)
+static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool need_mask, hipStream_t st)
 {
     const int octaves = h->P.n_octaves;
-    if (!(h->capR == rows && h->capC == cols && h->capL >= layers && h->capCand >= maxCand && h->capO == octaves)) {
+    // the plan (fused or not, region sizes, the geometry table) is that of EXACTLY this (size, octaves, layers): a handle whose
+    // nOctaveLayers was lowered re-plans instead of running on the larger plan's table
+    if (!(h->capR == rows && h->capC == cols && h->capL == layers && h->capCand >= maxCand && h->capO == octaves)) {
         free_scratch(h);
         h->sld = align_up(cols + 1, 64); h->vld = align_up(cols, 64); h->dld = align_up(cols, 64);
         // one launch per stage for all octaves where the kernel arguments hold them (surf::fused_supported), else octave by octave
@@ -152,7 +157,7 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
         {
             static const bool lds_ok = surf::lds_geometry_self_check();   // the LDS path's compile-time geometry against the host's
             const char *e = getenv("MIFLOW_SURF_LDS");
-            surf::set_lds_tiles(lds_ok && !(e && atoi(e) == 0));
+            h->lds_tiles = (lds_ok && !(e && atoi(e) == 0)) ? 1 : 0;
         }
         surf::FusedSizes z;
         z.plane_floats = (size_t)h->dld * rows * (layers + 2);
@@ -173,14 +178,18 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
         MI_HIP_TRY(hipMalloc((void **)&h->cand, sizeof(int4) * (size_t)maxCand * nlists));
         MI_HIP_TRY(hipMalloc(&h->itmp, surf::interp_tmp_bytes(maxCand) * nlists));
         if (h->fused) {
-            std::vector<unsigned char> g(z.geo_bytes);
-            surf::fused_geometry(h->sld, octaves, layers, g.data());
+            h->geo_host.assign(z.geo_bytes, 0);
+            surf::fused_geometry(h->sld, octaves, layers, h->geo_host.data());
             MI_HIP_TRY(hipMalloc(&h->geo, z.geo_bytes));
-            MI_HIP_TRY(hipMemcpy(h->geo, g.data(), z.geo_bytes, hipMemcpyHostToDevice));
+            h->geo_dirty = true;
         }
         h->capR = rows; h->capC = cols; h->capL = layers; h->capCand = maxCand; h->capO = octaves;
     }
     if (need_mask && !h->msum) MI_HIP_TRY(hipMalloc((void **)&h->msum, sizeof(unsigned) * (size_t)h->sld * (rows + 1)));
+    if (h->geo_dirty) {   // on the call's stream, not a blocking null-stream copy
+        MI_HIP_TRY(hipMemcpyAsync(h->geo, h->geo_host.data(), h->geo_host.size(), hipMemcpyHostToDevice, st));
+        h->geo_dirty = false;
+    }
     return MI_OK;
 }
 
@@ -214,7 +223,7 @@ int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *ke
     int maxF, maxC;
     if ((rc = limits(P, rows, cols, &maxF, &maxC))) return rc;
     if ((rc = check_kp(keypoints, maxF))) return rc;
-    if ((rc = ensure(h, rows, cols, P.n_octave_layers, maxC, use_mask))) return rc;
+    if ((rc = ensure(h, rows, cols, P.n_octave_layers, maxC, use_mask, st))) return rc;
     const int kld = (int)(keypoints->step / 4);
     float *kp = (float *)keypoints->data;
 
@@ -226,7 +235,7 @@ int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *ke
     if (h->fused) {                                                                                                  // :182-204, all octaves per launch
         if ((rc = surf::detect_fused(h->sum, use_mask ? h->msum : nullptr, h->sld, rows, cols, P.n_octaves, P.n_octave_layers,
                                      (float)P.hessian_threshold, h->det, h->trace, h->dld, h->bits, h->rowcnt, h->segcnt, h->cand, maxC,
-                                     h->counters + 1, h->itmp, h->geo, kp, kld, maxF, h->counters, st))) return rc;
+                                     h->counters + 1, h->itmp, h->geo, kp, kld, maxF, h->counters, h->lds_tiles, st))) return rc;
     } else
     for (int octave = 0; octave < P.n_octaves; ++octave) {                                                           // :182-204
         if ((rc = surf::det_trace(h->sum, h->sld, rows, cols, octave, P.n_octave_layers, h->det, h->trace, h->dld, st))) return rc;
@@ -264,7 +273,7 @@ int mi_surf_compute_orientation(mi_surf *h, const mi_mat *img, mi_mat *keypoints
     const int rows = img->rows, cols = img->cols;
     int maxF, maxC;
     if ((rc = limits(h->P, rows, cols, &maxF, &maxC))) return rc;
-    if ((rc = ensure(h, rows, cols, h->P.n_octave_layers, maxC, false))) return rc;
+    if ((rc = ensure(h, rows, cols, h->P.n_octave_layers, maxC, false, st))) return rc;
     if ((rc = surf::integral((const unsigned char *)img->data, (long long)img->step, rows, cols, false, h->V, h->BT, h->vld, h->sum, h->sld, st))) return rc;
     return surf::orientation(h->sum, h->sld, rows, cols, (float *)keypoints->data, (int)(keypoints->step / 4), nullptr, n_features,
                              h->P.upright != 0, h->apt, st);

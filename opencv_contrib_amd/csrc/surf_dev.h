@@ -21,11 +21,10 @@ struct FusedSizes { size_t plane_floats, bits_words, seg_counts, row_counts, geo
 bool fused_supported(int n_octaves, int nOctaveLayers);
 void fused_sizes(int rows, int cols, int dld, int n_octaves, int nOctaveLayers, FusedSizes *z);
 void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host);
-void set_lds_tiles(int on);          // octave 0 of the fused det / trace launch on LDS tiles (default on)
 bool lds_geometry_self_check();      // the compile-time tap geometry of that path equals haar_geo's
 int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int rows, int cols, int n_octaves, int nOctaveLayers, float thr,
                  float *det, float *trace, int dld, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
-                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s);
+                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, int lds_tiles, hipStream_t s);
 // tmp: interp_tmp_bytes(max_candidates) bytes of scratch
 int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, int max_candidates,
                 void *tmp, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s);

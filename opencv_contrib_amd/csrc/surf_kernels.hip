@@ -1190,14 +1190,13 @@ int interpolate(const float *det, int dld, int rows, int cols, int octave, const
 size_t interp_tmp_bytes(int max_candidates) { return sizeof(InterpOut) * (size_t)max_candidates; }
 
 // ---- all octaves per launch (k_*_all).  Sizes of the per-octave regions for a frame of rows x cols (the handle allocates them):
-static int g_surf_lds = 1;   // MIFLOW_SURF_LDS=0: octave 0 through the gather path like the other octaves
-void set_lds_tiles(int on) { g_surf_lds = on; }
-static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctaveLayers)
+// lds: octave 0 of the det / trace launch on LDS tiles (the HANDLE's decision, MIFLOW_SURF_LDS=0 switches it off: no process-global state)
+static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctaveLayers, int lds)
 {
     OctSet S;
     memset(&S, 0, sizeof(S));
     S.n = n_octaves; S.nlayers = nOctaveLayers; S.rows = rows; S.cols = cols; S.dld = dld;
-    S.lds0 = (nOctaveLayers + 2 <= kLdsLayers && g_surf_lds) ? 1 : 0;
+    S.lds0 = (nOctaveLayers + 2 <= kLdsLayers && lds) ? 1 : 0;
     long long plane = 0, bits = 0, seg = 0;
     int row = 0;
     for (int o = 0; o < n_octaves; ++o) {
@@ -1222,7 +1221,7 @@ static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctav
 bool fused_supported(int n_octaves, int nOctaveLayers) { return n_octaves <= kMaxFusedOctaves && nOctaveLayers + 2 <= kDetLayers; }
 void fused_sizes(int rows, int cols, int dld, int n_octaves, int nOctaveLayers, FusedSizes *z)
 {
-    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers);
+    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers, 0);   // the region sizes do not depend on the octave-0 path
     const int last = n_octaves - 1, lr = rows >> last;
     z->plane_floats = (size_t)(S.plane0[last] + (long long)(nOctaveLayers + 2) * lr * dld);
     z->bits_words = (size_t)(S.bits0[last] + (long long)nOctaveLayers * lr * S.chunks[last]);
@@ -1241,9 +1240,9 @@ void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host)
 // surf.cuda.cpp:182-204 for all octaves: six launches.  ncand: n_octaves counters; nfeat: the feature counter (zeroed by the caller)
 int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int rows, int cols, int n_octaves, int nOctaveLayers, float thr,
                  float *det, float *trace, int dld, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
-                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s)
+                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, int lds_tiles, hipStream_t s)
 {
-    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers);
+    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers, lds_tiles);
     SumTex t = {sum, sld, rows, cols};
     NmsArgs B;
     memset(&B, 0, sizeof(B));

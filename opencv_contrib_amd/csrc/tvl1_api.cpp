@@ -63,6 +63,8 @@ struct Lane {
     // internal stream of a concurrent lane + its completion event
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;   // the stream the lane's last calc was enqueued on (the caller's, or `stream`)
+    bool used = false;                   // a calc has been enqueued on the current arena
 };
 
 struct mi_tvl1 {
@@ -169,7 +171,11 @@ int mi_tvl1_get_params(const mi_tvl1 *h, mi_tvl1_params *p)
 
 static void free_arena(Lane &ln)
 {
-    if (ln.arena) big_free(ln.arena, ln.arena_bytes);
+    // the block goes back to the cache with an event behind the lane's last work (the stream its last calc ran on and its own internal
+    // stream): whoever takes it next waits for that event only -- destroying one handle no longer stalls the other handles' streams
+    const hipStream_t sts[2] = {ln.last_stream, ln.stream ? ln.stream : ln.last_stream};
+    if (ln.arena) big_free(ln.arena, ln.arena_bytes, sts, ln.used ? 2 : 0);
+    ln.used = false;
     ln.arena = nullptr;
     ln.L.clear();
 }
@@ -335,6 +341,7 @@ static int check_pair(const mi_mat *I0, const mi_mat *I1, const mi_mat *flow, co
 // The whole coarse-to-fine computation of n pairs on one stream (OpticalFlowDual_TVL1_Impl::calcImpl + procOneScale).
 static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, hipStream_t st, int *ns_out)
 {
+    struct Mark { Lane &l; hipStream_t s; ~Mark() { if (l.arena) { l.last_stream = s; l.used = true; } } } mark{ln, st};   // also on an error return: part of the calc may be in flight
     const mi_tvl1_params &P = h->P;
     const int W = I0s[0].cols, H = I0s[0].rows, B = n;
     int rc = ensure_arena(P, ln, W, H, B);
@@ -471,7 +478,11 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     int e_next = 0;           // next per-iteration error-sum index (speculative path)
     int q_settle_prev = -1, q_settle_scale = -1;   // settling launches of the previous warp / of the coarser scale's first warp
     // host feedback: only where the calc is one lane on the caller's stream (a wait inside lane k would hold up the enqueue of lane k+1)
-    const bool fb = spec && h->last_lanes == 1 && P.host_feedback >= 0 && (P.host_feedback == 1 || B <= 2);
+    // ... and never while the stream is being captured into a graph: an event synchronise on a capturing stream fails and
+    // invalidates the capture (hipGraph users get the fully stream-ordered enqueue, host_feedback = -1 behaviour)
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap_st) == hipSuccess && cap_st != hipStreamCaptureStatusNone;
+    const bool fb = spec && h->last_lanes == 1 && P.host_feedback >= 0 && (P.host_feedback == 1 || B <= 2) && !capturing;
     int fb_prev_warp = 2, fb_prev_scale = 2;   // launch index at which the previous warp / the coarser scale's first warp was found stopped
     ln.fb_waits = ln.fb_skipped = 0;
     if (fb) {

@@ -47,7 +47,10 @@ struct Slot {
 // (the scale doubles as the row mask); ownership of the column is applied once, when the accumulators are reduced.
 // JW (joined waves, see k_iterate_tbr): the lane without a source lane takes what the neighbouring wave handed over -- (xl1, xl2) =
 // p11, p21 of the column left of lane 0, (xr1, xr2) = u1, u2 of the column right of lane 63 -- instead of the zero fill.
-template <int PPL, bool ERR, int JW = 0>
+// MK = false (JW = 4, interior blocks): no stage of the block sees row 0 or row H, so the three border scalars are the constants
+// -1, 1 and taut and the masked forms reduce to the same operations without them -- fma(-1, b, a) and a - b, fma(x, 1, y) and
+// x + y round once, identically: the planes are bit-identical to the masked form's.
+template <int PPL, bool ERR, int JW = 0, bool MK = true>
 __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
                                         float m2, float taum2, float l_t, float theta, float taut, unsigned long long &acc, float es,
                                         float xl1 = 0.f, float xl2 = 0.f, float xr1 = 0.f, float xr2 = 0.f)
@@ -62,8 +65,8 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
         // ---- u_t(a)   (optflow/src/tvl1flow.cpp:989-1041, 1096-1112; TH written as clamp(-rho/grad, +-l_t))
-        const float div1 = dx1[j] + fmaf(negm1, B.p12[j], A.p12[j]);
-        const float div2 = dx2[j] + fmaf(negm1, B.p22[j], A.p22[j]);
+        const float div1 = dx1[j] + (MK ? fmaf(negm1, B.p12[j], A.p12[j]) : A.p12[j] - B.p12[j]);
+        const float div2 = dx2[j] + (MK ? fmaf(negm1, B.p22[j], A.p22[j]) : A.p22[j] - B.p22[j]);
         const float rho = fmaf(st.ix[j], A.u1[j], fmaf(st.iy[j], A.u2[j], st.rc[j]));
         const float fi = __builtin_amdgcn_fmed3f(-rho * st.rg[j], -l_t, l_t);
         const float nu1 = fmaf(theta, div1, fmaf(fi, st.ix[j], A.u1[j]));
@@ -75,14 +78,14 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
         const float u2x = right_ok[j] ? n2 - B.u2[j] : 0.f;
         const float d1 = nu1 - B.u1[j];
         const float d2 = nu2 - B.u2[j];
-        const float g1 = __builtin_amdgcn_sqrtf(fmaf(d1 * d1, m2, u1x * u1x));
-        const float g2 = __builtin_amdgcn_sqrtf(fmaf(d2 * d2, m2, u2x * u2x));
+        const float g1 = __builtin_amdgcn_sqrtf(MK ? fmaf(d1 * d1, m2, u1x * u1x) : d1 * d1 + u1x * u1x);
+        const float g2 = __builtin_amdgcn_sqrtf(MK ? fmaf(d2 * d2, m2, u2x * u2x) : d2 * d2 + u2x * u2x);
         const float q1 = __builtin_amdgcn_rcpf(fmaf(taut, g1, 1.0f));
         const float q2 = __builtin_amdgcn_rcpf(fmaf(taut, g2, 1.0f));
         B.p11[j] = fmaf(taut, u1x, B.p11[j]) * q1;
-        B.p12[j] = fmaf(taum2, d1, B.p12[j]) * q1;
+        B.p12[j] = fmaf(MK ? taum2 : taut, d1, B.p12[j]) * q1;
         B.p21[j] = fmaf(taut, u2x, B.p21[j]) * q2;
-        B.p22[j] = fmaf(taum2, d2, B.p22[j]) * q2;
+        B.p22[j] = fmaf(MK ? taum2 : taut, d2, B.p22[j]) * q2;
         if (ERR) {
             const float e1 = nu1 - A.u1[j], e2 = nu2 - A.u2[j];
             acc += (unsigned long long)__float2uint_rn(fmaf(e1, e1, e2 * e2) * es);   // v_cvt_u32_f32 saturates: a term >= 256 px^2 only under-counts
@@ -291,14 +294,26 @@ __device__ __forceinline__ void xwrite2(bool on, unsigned addr, float a, float b
         *reinterpret_cast<volatile MI_LDS f2 *>((lds_ptr)(unsigned long long)addr) = v;
     }
 }
+// JW == 4: the publish as an ORDINARY full-wave store -- the one lane that holds the boundary column writes to the neighbour's slot,
+// the other 63 to a dump area behind the hand-over areas (addresses prepared per lane once): no exec mask, no branch, so a whole
+// pipeline step stays ONE basic block and the scheduler may overlap the tail of a stage with the head of the next.
+__device__ __forceinline__ void xwrite2f(unsigned addr, float a, float b)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v; v.x = a; v.y = b;
+    *reinterpret_cast<volatile MI_LDS f2 *>((lds_ptr)(unsigned long long)addr) = v;
+}
+__host__ __device__ constexpr int xdump4_bytes(int T) { return 64 * 8 + 2 * xarea2_bytes(T) + 64; }   // per workgroup, shared by its waves
+__host__ __device__ constexpr bool jw_fast(int JW) { return JW == 4; }
 __device__ int g_jw_fault;   // sticky: a bounded wait on a neighbouring wave ran out (never expected; results are then invalid)
 
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, int k>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, int k>
 __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T], Xchg &x)
 {
+    constexpr bool JF = jw_fast(JW);
     constexpr int P = T + 1 + PF;
     constexpr int K = T > 2 ? T - 1 : 1;
     const int n = n0 + k;
@@ -308,8 +323,10 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     if (JW >= 2) {
         // the two hand-over base addresses live in VGPRs (a ds_* address operand is a VGPR: kept scalar they cost one v_mov per access)
         asm volatile("" : "+v"(x.own), "+v"(x.pub_l));
+        if (JF) asm volatile("" : "+v"(x.pub_r));
         // the row entering the pipeline: its p11, p21 of lane 63 are the right neighbour's stage-0 input of this step
-        xwrite2(x.on_r, x.own + xarea2_bytes(T), X[k].d.p11[0], X[k].d.p21[0]);
+        if (JF) xwrite2f(x.pub_r, X[k].d.p11[0], X[k].d.p21[0]);
+        else xwrite2(x.on_r, x.own + xarea2_bytes(T), X[k].d.p11[0], X[k].d.p21[0]);
     } else if (JW) {
         vtag_r = (unsigned)(n + 1); vtag_l = (unsigned)(n + 2);
         asm volatile("" : "+v"(vtag_r), "+v"(vtag_l), "+v"(x.own));   // one VGPR copy per step, not one v_mov per store
@@ -347,9 +364,9 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
 #endif
         const int a = r0 - t;   // row of the stage's input
         // wave-uniform masks, selected as INTEGERS so that they stay on the scalar unit (a float select is lowered to v_cndmask)
-        const float negm1 = __uint_as_float((a == 0) ? 0u : 0xbf800000u);
-        const float m2 = __uint_as_float((a == c.H) ? 0u : 0x3f800000u);
-        const float taum2 = __uint_as_float((a == c.H) ? 0u : __float_as_uint(c.taut));
+        const float negm1 = MK ? __uint_as_float((a == 0) ? 0u : 0xbf800000u) : -1.f;
+        const float m2 = MK ? __uint_as_float((a == c.H) ? 0u : 0x3f800000u) : 1.f;
+        const float taum2 = MK ? __uint_as_float((a == c.H) ? 0u : __float_as_uint(c.taut)) : c.taut;
         if (MODE == 1) {
             // speculative step: nit <= T active stages, each summing its error over the rows of this wave's band only (halo rows
             // belong to a neighbour).  A skipped stage writes nothing, which IS the identity of the rotating scheme: its output
@@ -371,6 +388,21 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         } else if (MODE == 2) {
             if constexpr (PPL == 1)
                 stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
+        } else if (JF) {
+            // hand-over values: read ONE STAGE EARLY wherever the interval rule allows it.  Stage g's left input was published in an
+            // earlier interval than stage g - 1 runs in, always; its right input (the neighbour's stage g - T) only if g is not the
+            // first stage of an interval (T = 2 XK: floor((g - T) / XK) + w + 1 < floor((g - 1) / XK) + w  <=>  g mod XK != 0) --
+            // stages that open an interval read after their barrier, as before.
+            constexpr int XKs = xk_stages(T);
+            if ((k * T + t) % XKs == 0) xbarrier();
+            if (t == 0 || (k * T + t) % XKs == 0) xread2(x.own + t * 2 * XS2, x.l1, x.l2, x.r1, x.r2);
+            const float l1 = x.l1, l2 = x.l2, r1 = x.r1, r2 = x.r2;
+            if (t + 1 < T && (k * T + t + 1) % XKs != 0) xread2(x.own + (t + 1) * 2 * XS2, x.l1, x.l2, x.r1, x.r2);
+            unsigned long long dummy = 0;
+            Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
+            stage_r<PPL, false, 1, MK>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, dummy, 0.f, l1, l2, r1, r2);
+            if (t + 1 < T) xwrite2f(x.pub_r + (t + 1) * 2 * XS2, SB.p11[0], SB.p21[0]);
+            xwrite2f(x.pub_l + t * 2 * XS2 + 8, SA.u1[0], SA.u2[0]);
         } else if (JW >= 2) {
             if ((k * T + t) % xk_stages(T) == 0) xbarrier();
             float l1, l2, r1, r2;
@@ -413,6 +445,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     }
     if (JW >= 2) {   // the slots of the other parity for the next step (the two parities of a stage are adjacent: one address bit)
         x.own ^= XS2; x.pub_l ^= XS2;
+        if (JF) x.pub_r ^= XS2;
     } else if (JW) {   // the other buffer for the next step
         const int d = (n & 1) ? -T * XS : T * XS;
         x.own += d; x.pub_r += d; x.pub_l -= d;   // pub_l addresses the left neighbour's buffer of the NEXT step: opposite phase
@@ -438,11 +471,11 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     }
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, int... Ks>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, int... Ks>
 __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
                                         Xchg &x, std::integer_sequence<int, Ks...>)
 {
-    (step_r<T, PPL, PZ, PF, MODE, JW, Ks>(c, X, n0, slot0, acc, x), ...);
+    (step_r<T, PPL, PZ, PF, MODE, JW, MK, Ks>(c, X, n0, slot0, acc, x), ...);
 }
 
 // MODE 0: T iterations, fixed work.
@@ -464,7 +497,7 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0>
 __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs A)
 {
-    static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW >= 2))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
+    static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW >= 2 && JW != 4))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
     static_assert(JW < 2 || (((T + 1 + PF) * T) % xk_stages(T) == 0 && T >= 2 * xk_stages(T)), "barrier intervals must tile the unrolled block and leave the right neighbour a full interval");
     constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
     constexpr int NW = jw_waves(JW);               // waves of a workgroup
@@ -512,6 +545,13 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
         x.pub_l = xb + (wave - 1) * XA + XS2;           // the left neighbour's slots of step 1 (parity 1); lane 0 of a wave with a left neighbour only
         x.on_r = has_right && c.lane == 63;
         x.on_l = has_left && c.lane == 0;
+        if (jw_fast(JW)) {
+            // per-lane publish addresses: the neighbour's slots for the one lane that holds the boundary column, the workgroup's dump
+            // area (never read; the parity bit and the stage offsets apply to it alike) for everybody else
+            const unsigned dump = xb + NW * XA + 32 + c.lane * 8;
+            x.pub_r = x.on_r ? x.own + XA : dump;
+            x.pub_l = x.on_l ? x.pub_l : dump;
+        }
         for (int i = c.lane; i < XA / 4; i += 64) reinterpret_cast<volatile MI_LDS unsigned *>((lds_ptr)(unsigned long long)x.own)[i] = 0u;
         __syncthreads();
         if (xw >= W) return;
@@ -579,7 +619,17 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
     for (int t = 0; t < T; ++t) acc[t] = 0;
     if (JW >= 2 && xk_stages(T) > 1)   // the skew: wave w starts w barrier intervals after wave 0 ...
         for (int i = 0; i < wave; ++i) xbarrier();
-    for (int n0 = 0; n0 < c.nsteps; n0 += P) steps_r<T, PPL, PZ, PF, MODE, JW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+    for (int n0 = 0; n0 < c.nsteps; n0 += P) {
+        if (jw_fast(JW)) {
+            // rows a = r0 - t seen by the stages of this block of P steps: [ystart + n0 - (T - 1), ystart + n0 + P - 1].  If neither row 0
+            // nor row H is among them the block runs the form without border masks (wave-uniform, and the same for the four waves of
+            // the workgroup: they share the band)
+            const int ra = c.ystart + n0 - (T - 1), rb = c.ystart + n0 + P - 1;
+            const bool plain = (ra > 0 || rb < 0) && (ra > c.H || rb < c.H);
+            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
+        }
+        steps_r<T, PPL, PZ, PF, MODE, JW, true>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+    }
     if (JW >= 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
         for (int i = wave; i < NW - 1; ++i) xbarrier();
     if (JW == 1 && x.budget < 0 && c.lane == 0) g_jw_fault = 1;
@@ -608,7 +658,7 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     // JW: a workgroup is one band of a 256-column strip; otherwise four consecutive bands of a 64-column strip
     const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
     constexpr size_t lds_bytes = (size_t)NW * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
-                                 (JW >= 2 ? NW * xarea2_bytes(T) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
+                                 (JW >= 2 ? NW * xarea2_bytes(T) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
         hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -646,7 +696,10 @@ static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 
                                      // barrier form (MIFLOW_TB_JW=2): no read-ahead registers, no dump area: four waves/SIMD and four workgroups/CU again
                                      {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2>, nullptr, 2},
                                      // eight joined waves (MIFLOW_TB_JW=3): 512-column strips, two workgroups of eight waves per CU
-                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 3>, nullptr, 3}};
+                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 3>, nullptr, 3},
+                                     // barrier form without exec-masked publishes and without border masks in interior blocks, hand-over
+                                     // values read a stage early (MIFLOW_TB_JW=4)
+                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 4>, nullptr, 4}};
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
@@ -743,7 +796,7 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
     int wps = e.PLAN;
     const int ring_slots = T > 2 ? T - 1 : 1;
     const int nw = e.JW ? jw_waves(e.JW) : 4;
-    int lds_blocks = (160 * 1024) / (ring_slots * nw * 256 * ppl * 4 + (e.JW >= 2 ? nw * xarea2_bytes(T) : e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
+    int lds_blocks = (160 * 1024) / (ring_slots * nw * 256 * ppl * 4 + (e.JW >= 2 ? nw * xarea2_bytes(T) + (jw_fast(e.JW) ? xdump4_bytes(T) : 0) : e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
     lds_blocks = lds_blocks * nw / 4;   // in units of four-wave workgroups (= waves per SIMD)
     if (wps > lds_blocks) wps = lds_blocks;
     if (tn.tb_plan_wps > 0) wps = tn.tb_plan_wps;
@@ -862,7 +915,19 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
 // sticky fault flag of the joined-wave kernels (0 = no wait ever ran out of its budget); reading clears nothing
 int tb_jw_fault(int *fault_host)
 {
-    MI_HIP_TRY(hipMemcpyFromSymbol(fault_host, HIP_SYMBOL(g_jw_fault), sizeof(int), 0, hipMemcpyDeviceToHost));
+    // the flag is a per-DEVICE symbol: a multi-device caller (mi_tvl1_multi) must see a fault raised on any of its GPUs
+    int cur = 0, n = 0, any = 0;
+    MI_HIP_TRY(hipGetDevice(&cur));
+    MI_HIP_TRY(hipGetDeviceCount(&n));
+    for (int d = 0; d < n; ++d) {
+        int f = 0;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        const hipError_t e = hipMemcpyFromSymbol(&f, HIP_SYMBOL(g_jw_fault), sizeof(int), 0, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { (void)hipSetDevice(cur); MI_HIP_TRY(e); }
+        any |= f;
+    }
+    MI_HIP_TRY(hipSetDevice(cur));
+    *fault_host = any;
     return MI_OK;
 }
 

@@ -1,7 +1,8 @@
 """Digest of what the blocked iteration kernel produces on a list of shapes (stage-level entry mi_tvl1_iterate, 10 fused iterations per
-launch, two launches) and of whole calcs: run once with MIFLOW_TB_JW=0, once with 1 and once with 2 (the switch is read once per
-process) and compare the outputs -- the joined-wave kernels must be bit-identical to the independent-wave kernel.
-Usage: MIFLOW_TB_JW=<0|1|2> python tools/jw_check.py > digest.txt"""
+launch, two launches) and of whole calcs: run once per value of MIFLOW_TB_JW (0 = independent waves, 1 = tags, 2 = barrier intervals,
+3 = eight joined waves, 4 = barrier intervals with branch-free publishes and mask-free interior blocks; the switch is read once per
+process) and compare the outputs -- every joined-wave kernel must be bit-identical to the independent-wave kernel.
+Usage: MIFLOW_TB_JW=<0|1|2|3|4> python tools/jw_check.py > digest.txt"""
 import ctypes as C
 import hashlib
 import os

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -28,6 +29,10 @@ __global__ __launch_bounds__(256) void k(float *out, Stamp *st, int iters, float
     unsigned long long msk = (threadIdx.x & 63) == 63 ? 0x8000000000000000ull : 0ull;
     msk = __builtin_amdgcn_readfirstlane((unsigned)(iters == 12345)) ? ~0ull : 0x8000000000000000ull;
     float4 q = make_float4(seed, seed, seed, seed);
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v pk[8];
+    for (int i = 0; i < 8; ++i) pk[i] = f2v{seed + i, seed - i};
+    const f2v pkb = {1.0f + seed * 1e-3f, 1.0f - seed * 1e-3f}, pkc = {seed * 1e-3f, -seed * 1e-3f};
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #define FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
@@ -91,10 +96,22 @@ __global__ __launch_bounds__(256) void k(float *out, Stamp *st, int iters, float
         // SALU result consumed by the next VALU
 #define SELF asm volatile("s_cmp_eq_u32 %1, %2\n s_cselect_b32 %0, %1, %2" : "=s"(s3) : "s"(s0), "s"(s2) : "scc");
 #define FMSG(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(s3), "v"(c));
+#define DSRF(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(la), "n"(i * 1024));
+        if (OP == 25) { DSRF(0) FMA(0) DSRF(1) FMA(1) DSRF(2) FMA(2) DSRF(3) FMA(3) DSRF(4) FMA(4) DSRF(5) FMA(5) DSRF(6) FMA(6) DSRF(7) FMA(7)
+                        DSRF(0) FMA(0) DSRF(1) FMA(1) DSRF(2) FMA(2) DSRF(3) FMA(3) DSRF(4) FMA(4) DSRF(5) FMA(5) DSRF(6) FMA(6) DSRF(7) FMA(7) WAIT0(0) }
+        if (OP == 26) { REP8(DPP) REP8(DPP) }
+        if (OP == 27) { REP8(SQRT) REP8(RCP) }
+#define PKF(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[i]) : "v"(pkb), "v"(pkc));
+        if (OP == 28) { REP8(PKF) REP8(PKF) }
+#define MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define ADD(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+        if (OP == 29) { REP8(MUL) REP8(MUL) }
+        if (OP == 30) { REP8(ADD) REP8(ADD) }
         if (OP == 24) { SELF FMSG(0) SELF FMSG(1) SELF FMSG(2) SELF FMSG(3) SELF FMSG(4) SELF FMSG(5) SELF FMSG(6) SELF FMSG(7) }   // 8 x (cmp, cselect, dependent fma)
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = q.x + q.y;
+    for (int i = 0; i < 8; ++i) s += pk[i].x + pk[i].y;
     for (int i = 0; i < 8; ++i) s += a[i];
     if (s == 123.456f || s0 == 77 || s3 == 99) out[threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c0, c1, r0, r1};
@@ -136,8 +153,63 @@ static void run(const char *name, int valu, int other)
     hipFree(out); hipFree(st);
 }
 
-int main()
+// sustained mode: `issue_mix sustain <op> <wps> <seconds>` keeps one stream on the chip long enough for the power management to settle;
+// poll rocm-smi beside it (tools/clock_poll.sh) for the socket power: energy per lane-instruction = (P - P_idle) / (lane-instructions / s)
+template <int OP>
+static void sustain(const char *name, int valu, int other, int wps, double seconds)
 {
+    float *out;
+    Stamp *st;
+    hipMalloc(&out, 4096);
+    hipMalloc(&st, sizeof(Stamp) * 256 * 8 * 4);
+    const int iters = 200000 * 16 / (valu + other);
+    const int blocks = 256 * wps;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 16384, 0, out, st, 64, 1.0f);
+    hipDeviceSynchronize();
+    double total_ms = 0; long launches = 0;
+    double ghz = 0;
+    while (total_ms < seconds * 1e3) {
+        hipEventRecord(e0);
+        for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 16384, 0, out, st, iters, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        total_ms += ms; launches += 4;
+    }
+    std::vector<Stamp> h(blocks * 4);
+    hipMemcpy(h.data(), st, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost);
+    double cyc = 0, rt = 0;
+    for (auto &s : h) { cyc += (double)(s.c1 - s.c0); rt += (double)(s.r1 - s.r0); }
+    ghz = cyc / (rt / 100e6) / 1e9;
+    const double winstr = (double)launches * blocks * 4 * iters * (valu + other);   // wave-instructions
+    printf("sustain %-30s wps%d: %.1f s, clock %.3f GHz (last launch), %.2f T lane-instr/s (%.2f T VALU lane-instr/s), %.2f cyc/instr per SIMD at that clock\n",
+           name, wps, total_ms * 1e-3, ghz, winstr * 64 / (total_ms * 1e-3) / 1e12, winstr * 64 * valu / (valu + other) / (total_ms * 1e-3) / 1e12,
+           (total_ms * 1e-3) * ghz * 1e9 * 1024 / winstr);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc >= 5 && !strcmp(argv[1], "sustain")) {
+        const int op = atoi(argv[2]), wps = atoi(argv[3]);
+        const double sec = atof(argv[4]);
+        switch (op) {
+        case 0: sustain<0>("16 fma, 8 chains", 16, 0, wps, sec); break;
+        case 2: sustain<2>("16 fma + 16 s_add", 16, 16, wps, sec); break;
+        case 7: sustain<7>("stage-like VALU", 44, 0, wps, sec); break;
+        case 8: sustain<8>("stage-like VALU + 24 SALU", 44, 24, wps, sec); break;
+        case 11: sustain<11>("16 s_add only", 0, 16, wps, sec); break;
+        case 25: sustain<25>("16 ds_read_b128 + 16 fma", 16, 16, wps, sec); break;
+        case 26: sustain<26>("16 v_mov_dpp", 16, 0, wps, sec); break;
+        case 27: sustain<27>("8 sqrt + 8 rcp", 16, 0, wps, sec); break;
+        case 28: sustain<28>("16 v_pk_fma_f32", 16, 0, wps, sec); break;
+        case 29: sustain<29>("16 v_mul_f32", 16, 0, wps, sec); break;
+        case 30: sustain<30>("16 v_add_f32", 16, 0, wps, sec); break;
+        default: printf("no such op\n");
+        }
+        return 0;
+    }
     run<0>("16 fma, 8 chains", 16, 0);
     run<6>("16 fma, ONE dependent chain", 16, 0);
     run<1>("16 fma + 8 s_add", 16, 8);
