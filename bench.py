@@ -214,6 +214,68 @@ def timed_cpu_baseline(cpu_calc, base, budget_s=12.0, hard_s=25.0, with_one_core
             "sweep": sweep, "one_core": one_core}
 
 
+class PowerPoll:
+    """rocm-smi polled from a thread while a leg runs: shader clock and socket power.  The TV-L1 step runs MI355X at its POWER limit
+    (about 1350 W; the shader clock settles near 2.05 GHz instead of 2.4), so the clock and the power belong next to any rate or
+    roofline fraction quoted against the 2.4 GHz peaks."""
+
+    def __init__(self, period=0.12):
+        import threading
+        self.samples, self._stop, self.period = [], False, period
+        self.th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o)
+                p_ = re.search(r"Power \(W\): ([\d.]+)", o)
+                if c and p_:
+                    self.samples.append((time.perf_counter(), int(c.group(1)), float(p_.group(1))))
+            except Exception:
+                return
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        self.th.join(timeout=6)
+
+    def mean(self, t0, t1):
+        s_ = [x for x in self.samples if t0 + 0.35 * (t1 - t0) <= x[0] <= t1]   # the settled part of the leg
+        if len(s_) < 2:
+            return None
+        return {"sclk_MHz": sum(x[1] for x in s_) / len(s_), "socket_power_W": sum(x[2] for x in s_) / len(s_), "samples": len(s_)}
+
+
+def power_leg(fn, units_per_call, seconds=2.5):
+    """Runs fn() back to back for `seconds` with the clock / power poll beside it; returns the settled means and the leg's own rate."""
+    import torch
+    try:
+        with PowerPoll() as poll:
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < seconds:
+                fn()
+                torch.cuda.synchronize()
+                n += 1
+            t1 = time.perf_counter()
+            m = poll.mean(t0, t1)
+        if not m:
+            return None
+        m.update({"rate_during_leg": n * units_per_call / (t1 - t0), "leg_s": t1 - t0})
+        return m
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def time_steps(alg, I0, I1, flows, steps, warmup, dist):
     import torch
     for _ in range(warmup):
@@ -784,6 +846,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the clock / socket-power leg (2.5 s of the same step with rocm-smi polled beside it)")
     ap.add_argument("--stop-slack", type=int, default=0, help="mi_tvl1_params.stop_slack (miflow extension; 0 = the reference's exact stopping point)")
     ap.add_argument("--cpu-iterations", type=int, default=None)
     ap.add_argument("--dry-run", action="store_true",
@@ -1020,6 +1083,32 @@ def main():
            "epe_vs_analytic_flow_px": epe_gt,
            "roofline": roof}
 
+    if world == 1 and not args.no_power:
+        # the same step held on the chip for a few seconds with rocm-smi polled beside it (untimed leg: the headline above is not touched)
+        pw = power_leg(lambda: alg.calc_batch(I0, I1, flows), float(B))
+        if pw and "sclk_MHz" in pw:
+            f_ghz = pw["sclk_MHz"] / 1e3
+            pw["note"] = ("shader clock and socket power while the step of `value` runs back to back (rocm-smi, settled part of the leg).  "
+                          "MI355X holds this workload at its power limit: the clock, not the kernels' issue or HBM efficiency, is what gives "
+                          "(DESIGN 4.1 round 4: a copy at 4.8 TB/s alone draws ~975 W, a pure v_fma stream at full rate ~980 W, idle ~270 W; "
+                          "removing 16 % of the iteration kernel's instructions changed nothing).  Peaks at the measured clock are given "
+                          "next to the 2.4 GHz spec peaks the fractions above use")
+            pw["valu_peak_at_measured_clock_T_lane_instr_per_s"] = VALU_PEAK_TLIPS * f_ghz / 2.4
+            if isinstance(roof.get("frac"), float) and roof.get("bound") == "valu_issue":
+                pw["roofline_frac_at_measured_clock"] = roof["achieved"] / (VALU_PEAK_TLIPS * f_ghz / 2.4)
+            pw["joules_per_pair"] = pw["socket_power_W"] / pw["rate_during_leg"]
+        out["power"] = pw
+    # whole-job HBM traffic: measured bytes per launch of the two dominant kernels (separate --pmc passes, profiles/pmc_traffic.json) x the
+    # launches of a step, over the wall time of a step -- the quantity north_star's "fraction of HBM roofline" bar is about
+    try:
+        if traffic and wtraffic and n_it and n_w:
+            tot = traffic * n_it + wtraffic * n_w
+            out["whole_job_hbm_traffic"] = {"bytes_per_step": tot, "GBps": tot / (el / args.steps) / 1e9, "frac_of_hbm_peak": tot / (el / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                            "frac_of_measured_copy_rate": tot / (el / args.steps) / 1e9 / 6290.0,
+                                            "GB_per_pair": tot / B / 1e9,
+                                            "note": "iteration + warp launches of one step (both lanes); resize / convert / pack (~4 % of the kernel time) not counted"}
+    except Exception as e:
+        out["whole_job_hbm_traffic"] = {"error": repr(e)[:200]}
     exchange_hung = False
     if world == 1 and os.environ.get("MIFLOW_BENCH_EXCHANGE_FORCE"):
         # development aid: the exchange leg on ONE GPU through a single-rank RCCL group (scatter / gather to self) -- exercises the

@@ -18,6 +18,7 @@ const Tuning &tuning()
         Tuning &t = g_tuning;
         const char *w = getenv("MIFLOW_WARP");
         t.warp_legacy = (w && w[0] == 'p') ? 1 : 0;
+        t.x_skip = env_int("MIFLOW_X_SKIP", 0);
         t.warp_tile = env_int("MIFLOW_WARP_TILE", 32);
         if (t.warp_tile != 64 && t.warp_tile != 32 && t.warp_tile != 16) t.warp_tile = 32;
         t.warp_lds = env_int("MIFLOW_WARP_LDS", 0);   // r02z3 at 1080p x 16: LDS-staged windows 1 140 vs 1 180 pairs/s with two lanes, 1 037 vs 1 012 with one
@@ -122,12 +123,13 @@ int big_alloc(void **p, size_t bytes, size_t *capacity)
     return MI_OK;
 }
 
-// `streams`: every stream the owner may still have work on that touches the block (null entries are skipped; none = the owner
-// knows the block is idle).  One event after all of them marks the block's release; the next taker waits for that event.  Only when
-// an event cannot be recorded (e.g. the caller destroyed its stream before the handle) the device is synchronised instead.
-void big_free(void *p, size_t capacity, const hipStream_t *streams, int nstreams)
+// `ready`: an event the owner recorded behind its last work on the block WHILE ITS STREAM WAS ALIVE (ownership passes to the cache; the
+// next taker waits for it and destroys it).  No event and `busy`: the owner cannot vouch for the block (e.g. its last calc was
+// enqueued under stream capture) -- the device is synchronised instead, which keeps the old guarantee.  Nothing here touches a
+// caller's stream: at destroy time it may no longer exist.
+void big_free(void *p, size_t capacity, hipEvent_t ready, bool busy)
 {
-    if (!p) return;
+    if (!p) { if (ready) (void)hipEventDestroy(ready); return; }
     int dev = 0;
     void *drop = nullptr;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -135,25 +137,8 @@ void big_free(void *p, size_t capacity, const hipStream_t *streams, int nstreams
         const int cur = dev;
         if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;
         if (dev != cur) (void)hipSetDevice(dev);
-        hipEvent_t ready = nullptr;
         bool idle = true;
-        if (nstreams > 0) {
-            // one event on the first stream after it has been made to wait for the others
-            idle = hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
-            for (int i = 1; idle && i < nstreams; ++i) {
-                if (streams[i] == streams[0]) continue;
-                hipEvent_t ev = nullptr;
-                idle = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, streams[i]) == hipSuccess &&
-                       hipStreamWaitEvent(streams[0], ev, 0) == hipSuccess;
-                if (ev) (void)hipEventDestroy(ev);
-            }
-            idle = idle && hipEventRecord(ready, streams[0]) == hipSuccess;
-            if (!idle) {
-                (void)hipGetLastError();
-                if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
-                idle = hipDeviceSynchronize() == hipSuccess;   // the fallback keeps the guarantee
-            }
-        }
+        if (!ready && busy) idle = hipDeviceSynchronize() == hipSuccess;
         if (dev != cur) (void)hipSetDevice(cur);
         std::lock_guard<std::mutex> lk(g_big_mu);
         size_t total = capacity, all = capacity, blocks = 0;

@@ -31,6 +31,7 @@ void set_error(const char *fmt, ...);
 // Tuning switches (environment, read ONCE for the process under std::call_once; DESIGN.md lists them).  None is needed
 // in production: every default is the measured best.
 struct Tuning {
+    int x_skip;              // MIFLOW_X_SKIP (timing experiments ONLY, wrong results): 1 = no warp launches after a level's first, 2 = no iteration launches
     int warp_legacy;         // MIFLOW_WARP=pk: packed-float4 gather warp (the round-1 kernel) instead of the fused-gradient one
     int warp_tile;           // MIFLOW_WARP_TILE: pixels of a wave along x in the warp kernels (64 | 32 | 16)
     int warp_lds;            // MIFLOW_WARP_LDS: windows of the fused-gradient warp read from an LDS-staged region of I1 (1) or gathered from global memory (0)
@@ -81,7 +82,7 @@ struct DevTmp {
 // slower than the freed one did (390 vs 520 pairs/s, class defaults), i.e. create / destroy cycles of handles must not go
 // through the driver.  mi_release_cached_memory() returns everything to the driver.
 int big_alloc(void **p, size_t bytes, size_t *capacity);
-void big_free(void *p, size_t capacity, const hipStream_t *streams = nullptr, int nstreams = 0);
+void big_free(void *p, size_t capacity, hipEvent_t ready = nullptr, bool busy = true);
 void big_trim();
 int device_simds();
 

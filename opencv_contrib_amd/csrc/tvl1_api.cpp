@@ -63,7 +63,8 @@ struct Lane {
     // internal stream of a concurrent lane + its completion event
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    hipStream_t last_stream = nullptr;   // the stream the lane's last calc was enqueued on (the caller's, or `stream`)
+    hipEvent_t idle_ev = nullptr;        // recorded behind the lane's last calc on the stream it ran on
+    bool idle_valid = false;             // ... and usable (not recorded under stream capture, no error)
     bool used = false;                   // a calc has been enqueued on the current arena
 };
 
@@ -171,10 +172,13 @@ int mi_tvl1_get_params(const mi_tvl1 *h, mi_tvl1_params *p)
 
 static void free_arena(Lane &ln)
 {
-    // the block goes back to the cache with an event behind the lane's last work (the stream its last calc ran on and its own internal
-    // stream): whoever takes it next waits for that event only -- destroying one handle no longer stalls the other handles' streams
-    const hipStream_t sts[2] = {ln.last_stream, ln.stream ? ln.stream : ln.last_stream};
-    if (ln.arena) big_free(ln.arena, ln.arena_bytes, sts, ln.used ? 2 : 0);
+    // the block goes back to the cache with the event the lane recorded behind its last calc (while that calc's stream was alive):
+    // whoever takes the block next waits for that event only -- destroying one handle no longer stalls the other handles' streams
+    if (ln.arena) {
+        big_free(ln.arena, ln.arena_bytes, ln.idle_valid ? ln.idle_ev : nullptr, ln.used);
+        if (ln.idle_valid) ln.idle_ev = nullptr;   // ownership went with the block
+    }
+    ln.idle_valid = false;
     ln.used = false;
     ln.arena = nullptr;
     ln.L.clear();
@@ -232,6 +236,7 @@ void mi_tvl1_destroy(mi_tvl1 *h)
     for (Lane &ln : h->lane) {
         for (hipEvent_t e : ln.ev_pool) (void)hipEventDestroy(e);
         free_arena(ln);
+        if (ln.idle_ev) { (void)hipEventDestroy(ln.idle_ev); ln.idle_ev = nullptr; }
         if (ln.tab_dev) (void)hipFree(ln.tab_dev);
         if (ln.S) (void)hipFree(ln.S);
         if (ln.E) (void)hipFree(ln.E);
@@ -341,7 +346,20 @@ static int check_pair(const mi_mat *I0, const mi_mat *I1, const mi_mat *flow, co
 // The whole coarse-to-fine computation of n pairs on one stream (OpticalFlowDual_TVL1_Impl::calcImpl + procOneScale).
 static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, hipStream_t st, int *ns_out)
 {
-    struct Mark { Lane &l; hipStream_t s; ~Mark() { if (l.arena) { l.last_stream = s; l.used = true; } } } mark{ln, st};   // also on an error return: part of the calc may be in flight
+    // behind everything this call enqueues for the lane (also on an error return: part of the calc may be in flight): the event the
+    // arena cache waits for before it hands the lane's block to somebody else
+    struct Mark {
+        Lane &l; hipStream_t s;
+        ~Mark()
+        {
+            if (!l.arena) return;
+            l.used = true; l.idle_valid = false;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+            if (!l.idle_ev && hipEventCreateWithFlags(&l.idle_ev, hipEventDisableTiming) != hipSuccess) { l.idle_ev = nullptr; (void)hipGetLastError(); return; }
+            if (hipEventRecord(l.idle_ev, s) == hipSuccess) l.idle_valid = true; else (void)hipGetLastError();
+        }
+    } mark{ln, st};
     const mi_tvl1_params &P = h->P;
     const int W = I0s[0].cols, H = I0s[0].rows, B = n;
     int rc = ensure_arena(P, ln, W, H, B);
@@ -531,7 +549,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 rc = next_event(&w0); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[w0], st));
             }
-            if (legacy_warp)
+            if (tuning().x_skip == 1 && wp > 0) rc = MI_OK;   // timing experiment: what a step costs without the warps' work and bytes
+            else if (legacy_warp)
                 rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             else
                 rc = warp_fused(sem, !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT)), -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
@@ -561,6 +580,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     if (mf && (rc = median_flow(mf, mu1, mu2, ln.scr[0], ln.scr[1], g, nullptr, cur, st))) return rc;
                     for (int k = 0; k < nb; ++k) {
                         ++nlaunch;
+                        if (tuning().x_skip == 2) { first_of_scale = false; continue; }   // timing experiment: the warps alone
                         rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
                         if (rc) return rc;
                         cur ^= 1;
