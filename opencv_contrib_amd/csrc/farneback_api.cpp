@@ -87,6 +87,15 @@ struct mi_farneback {
     std::vector<float *> pyr[2];
     std::vector<Plane> pyrg;
     float *pyr_base = nullptr;  // fast-pyramid levels of pair 0 (inside the pair block)
+    // Round 4: the frames' side of a level (blur, resize, polynomial expansion: farneback.cpp:434-454) does not depend on the flow, so
+    // it runs for ALL levels on an internal stream while the main stream iterates the coarser levels -- a single 640 x 480 pair is a
+    // chain of ~60 dependent launches of ~5 us, and this takes the 9 pyramid launches of the finer levels off that chain.  Needs the
+    // expansions of every level at once: Rall = per-level R[0] | R[1] regions (10 planes each, level-sized) inside the pair block.
+    float *Rall = nullptr;
+    long long Rall_floats = 0;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_level;
 };
 
 static int cv_round(double v) { return (int)std::lrint(v); }
@@ -148,6 +157,9 @@ void mi_farneback_destroy(mi_farneback *h)
 {
     if (!h) return;
     if (h->arena) (void)hipFree(h->arena);
+    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_level) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -158,16 +170,20 @@ static int ensure(mi_farneback *h, int W, int H, int B)
     h->arena = nullptr;
     const Plane g = plane_of(W, H);
     const size_t n = (size_t)g.ld * H;
-    // per pair: frames 2, blurred 1, lvl 2, R 2x5, M 5, bufM 5, flows 6 = 31 planes, + the fast-pyramid levels of both frames
-    // (sum over the half-size levels < 2/3 of a plane per frame: 2 planes reserved)
-    const size_t per_pair = n * 33;
+    // per pair: frames 2, blurred 2, lvl 2, R 2x5, M 5, bufM 5, flows 6 = 32 planes, + the fast-pyramid levels of both frames
+    // (sum over the half-size levels < 2/3 of a plane per frame: 2 planes reserved).  The two frames' planes of a kind are ADJACENT
+    // (frame 1 = frame 0 + one plane; R[1] = R[0] + five): the pyramid kernels run both frames in one launch
+    // + 16 planes of room for the per-level expansions (10 planes x sum of the level sizes: 13.3 planes at pyrScale 0.5; a pyramid
+    // that needs more runs level by level on the caller's stream as before)
+    const size_t per_pair = n * 50;
     MI_HIP_TRY(hipMalloc((void **)&h->arena, sizeof(float) * per_pair * (size_t)B));
     float *p = h->arena;
     auto take = [&](size_t k) { float *q = p; p += n * k; return q; };
-    h->frames[0] = take(1); h->frames[1] = take(1); h->blurred = take(1); h->lvl[0] = take(1); h->lvl[1] = take(1);
+    h->frames[0] = take(1); h->frames[1] = take(1); h->blurred = take(2); h->lvl[0] = take(1); h->lvl[1] = take(1);
     h->R[0] = take(5); h->R[1] = take(5); h->M = take(5); h->bufM = take(5);
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) h->flow[a][b] = take(1);
     h->pyr_base = take(2);
+    h->Rall = take(16); h->Rall_floats = (long long)n * 16;
     h->bs = (long long)per_pair;
     h->capW = W; h->capH = H; h->capB = B;
     return MI_OK;
@@ -266,8 +282,11 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         for (int i = 0; i <= P.win_size / 2; ++i) wk.k[i] = k[P.win_size / 2 + i];
     }
 
-    float *prevx = nullptr, *prevy = nullptr;
-    Plane gprev = g0;
+    // ---- per-level geometry (farneback.cpp:374-395)
+    struct Lv { Plane g; double sigma, scale; int smooth; float *R0; long long fsR; };
+    std::vector<Lv> lv(levels + 1);
+    const long long pn = (long long)g0.ld * H;   // one full-resolution plane: the distance between the two frames' planes of a kind
+    long long need = 0;
     for (int k = levels; k >= 0; k--) {
         scale = 1;
         for (int i = 0; i < k; i++) scale *= P.pyr_scale;
@@ -277,7 +296,73 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         int width = cv_round(W * scale), height = cv_round(H * scale);
         if (P.fast_pyramids) { width = h->pyrg[k].w; height = h->pyrg[k].h; }
         MI_REQUIRE(smoothSize / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "pyramid smoothing kernel too large (MAX_KSIZE_HALF)");
-        const Plane g = plane_of(width, height, bs, B);
+        lv[k].g = plane_of(width, height, bs, B); lv[k].sigma = sigma; lv[k].scale = scale; lv[k].smooth = smoothSize;
+        need += 10LL * lv[k].g.ld * lv[k].g.h;
+    }
+    // The frames' side of every level on the internal stream (see mi_farneback::Rall) when all expansions fit; MIFLOW_FB_ASYNC=0 or
+    // a pyramid that does not fit: level by level on the caller's stream, through the one full-size R pair.
+    bool async = need <= h->Rall_floats && tuning().fb_async != 0;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // not under stream capture: keep the captured graph a single chain
+        if (async && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) { (void)hipGetLastError(); async = false; }
+    }
+    {
+        long long off = 0;
+        for (int k = levels; k >= 0; k--) {
+            const long long lp = (long long)lv[k].g.ld * lv[k].g.h;
+            if (async) { lv[k].R0 = h->Rall + off; lv[k].fsR = 5 * lp; off += 10 * lp; }
+            else { lv[k].R0 = h->R[0]; lv[k].fsR = 5 * pn; }
+        }
+    }
+    // launch-latency-bound calls (a single pair or a few: every launch of the level loop underfills the device) take the forms with fewer
+    // launches: resize sampled inside the consumer kernels, the merge written by the last iteration.  MIFLOW_FB_FUSE=0 / 1 forces it.
+    const bool fuse_small = tuning().fb_fuse >= 0 ? tuning().fb_fuse != 0 : (long long)W * H * B <= 1500000;
+    // blur + resize + polynomial expansion of BOTH frames for level k (the reference's loop over the two frames, farneback.cpp:434-454,
+    // each stage once for both: 3 launches instead of 6)
+    auto pyramid_stage = [&](int k, hipStream_t sx) -> int {
+        const Plane &g = lv[k].g;
+        if (P.fast_pyramids)
+            return poly_exp(h->pyr[0][k], lv[k].R0, g, P.poly_n, C, sx, 2, h->pyr[1][k] - h->pyr[0][k], lv[k].fsR);
+        const int smoothSize = lv[k].smooth;
+        std::vector<float> gk(smoothSize);
+        gaussian_kernel(smoothSize, lv[k].sigma, gk.data());
+        Taps K;
+        memset(&K, 0, sizeof(K));
+        for (int i = 0; i <= smoothSize / 2; ++i) K.k[i] = gk[smoothSize / 2 + i];
+        int r;
+        if ((r = gaussian_blur(h->frames[0], h->blurred, g0, smoothSize / 2, K, MI_BORDER_REFLECT101, sx, 2, pn))) return r;
+        const float *src = h->blurred;
+        if (!(g.w == g0.w && g.h == g0.h)) {
+            // the level image = cuda::resize of the blurred frame (:447-448).  Few pairs: sampled inside the expansion kernel (same
+            // arithmetic, same bits, one launch less); many pairs: through the level planes (the expansion reads each sample 11 times)
+            if (fuse_small) return poly_exp(h->blurred, lv[k].R0, g, P.poly_n, C, sx, 2, pn, lv[k].fsR, &g0);
+            if ((r = resize2(h->blurred, h->blurred + pn, g0, h->lvl[0], h->lvl[1], g, 1.f, sx))) return r;
+            src = h->lvl[0];
+        }
+        return poly_exp(src, lv[k].R0, g, P.poly_n, C, sx, 2, pn, lv[k].fsR);
+    };
+    if (async) {
+        if (!h->aux) MI_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+        if (!h->ev_fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        while ((int)h->ev_level.size() <= levels) {
+            hipEvent_t e;
+            MI_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ev_level.push_back(e);
+        }
+        MI_HIP_TRY(hipEventRecord(h->ev_fork, st));             // the frames (and the fast pyramid) are complete here
+        MI_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        for (int k = levels; k >= 0; k--) {
+            if ((rc = pyramid_stage(k, h->aux))) { (void)hipStreamSynchronize(h->aux); return rc; }
+            MI_HIP_TRY(hipEventRecord(h->ev_level[k], h->aux));
+        }
+    }
+
+    float *prevx = nullptr, *prevy = nullptr;
+    Plane gprev = g0;
+    bool merged = false;
+    for (int k = levels; k >= 0; k--) {
+        scale = lv[k].scale;
+        const Plane g = lv[k].g;
         float *curx, *cury;
         if (k > 0) { curx = h->flow[1 + (k & 1)][0]; cury = h->flow[1 + (k & 1)][1]; }
         else { curx = fx0; cury = fy0; }
@@ -286,39 +371,47 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
                 if (k > 0 && (rc = resize2(fx0, fy0, g0, curx, cury, g, (float)scale, st))) return rc;
             } else {
                 const size_t bytes = sizeof(float) * (size_t)g.ld * g.h;
-                MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
-                MI_HIP_TRY(hipMemset2DAsync(cury, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
+                if (cury == curx + pn && bytes <= sizeof(float) * (size_t)pn) {   // the two planes are neighbours in the arena: one fill
+                    MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, sizeof(float) * (size_t)pn + bytes, (size_t)B, st));
+                } else {
+                    MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
+                    MI_HIP_TRY(hipMemset2DAsync(cury, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
+                }
             }
-        } else {              // :412-417
+        } else if (!(fuse_small && !(gprev.w == g.w && gprev.h == g.h))) {              // :412-417
             if ((rc = resize2(prevx, prevy, gprev, curx, cury, g, (float)(1. / P.pyr_scale), st))) return rc;
         }
-        if (P.fast_pyramids) {
-            if ((rc = poly_exp(h->pyr[0][k], h->R[0], g, P.poly_n, C, st))) return rc;
-            if ((rc = poly_exp(h->pyr[1][k], h->R[1], g, P.poly_n, C, st))) return rc;
-        } else {              // :434-454
-            std::vector<float> gk(smoothSize);
-            gaussian_kernel(smoothSize, sigma, gk.data());
-            Taps K;
-            memset(&K, 0, sizeof(K));
-            for (int i = 0; i <= smoothSize / 2; ++i) K.k[i] = gk[smoothSize / 2 + i];
-            for (int i = 0; i < 2; i++) {
-                if ((rc = gaussian_blur(h->frames[i], h->blurred, g0, smoothSize / 2, K, MI_BORDER_REFLECT101, st))) return rc;
-                const float *lv = h->blurred;
-                if (!(g.w == g0.w && g.h == g0.h)) {
-                    if ((rc = resize2(h->blurred, nullptr, g0, h->lvl[i], nullptr, g, 1.f, st))) return rc;
-                    lv = h->lvl[i];
-                }
-                if ((rc = poly_exp(lv, h->R[i], g, P.poly_n, C, st))) return rc;
-            }
-        }
+        if (async) MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_level[k], 0));
+        else if ((rc = pyramid_stage(k, st))) return rc;
+        const float *R0 = lv[k].R0, *R1 = lv[k].R0 + lv[k].fsR;
         float *M = h->M, *bufM = h->bufM;
-        if ((rc = update_matrices(curx, cury, h->R[0], h->R[1], M, g, st))) return rc;   // :458
+        if (prevx && fuse_small && !(gprev.w == g.w && gprev.h == g.h)) {   // the zoom of the coarser flow inside the first matrix update
+            if ((rc = update_matrices_resized(prevx, prevy, gprev, (float)(1. / P.pyr_scale), curx, cury, R0, R1, M, g, st))) return rc;
+        } else if ((rc = update_matrices(curx, cury, R0, R1, M, g, st))) return rc;   // :458
+        // levels whose 64 x 4 grid underfills the device: two iterations per launch (MIFLOW_FB_PAIR=0 / 1 forces the choice)
+        const bool pair_it = fuse_small && iterate2_supported(P.win_size) &&
+                             (tuning().fb_pair >= 0 ? tuning().fb_pair != 0 : (long long)div_up(g.w, 64) * div_up(g.h, 4) * B <= 2LL * (device_simds() / 4));
         for (int i = 0; i < P.num_iters; i++) {   // :465-471 -> :278-312, fused
-            if ((rc = iterate(M, h->R[0], h->R[1], curx, cury, bufM, g, P.win_size, gauss ? &wk : nullptr, i < P.num_iters - 1, st))) return rc;
+            if (pair_it && i + 1 < P.num_iters) {
+                const bool last2 = k == 0 && i + 1 == P.num_iters - 1 && B == 1;
+                bool dm2 = false;
+                if ((rc = iterate2(M, R0, R1, curx, cury, bufM, g, P.win_size, gauss ? &wk : nullptr, i + 1 < P.num_iters - 1, st,
+                                   last2 ? flows[0].data : nullptr, last2 ? (long long)flows[0].step : 0, &dm2))) return rc;
+                merged = merged || dm2;
+                std::swap(M, bufM);
+                ++i;
+                continue;
+            }
+            const bool last = k == 0 && i == P.num_iters - 1 && B == 1 && fuse_small;
+            bool dm = false;
+            if ((rc = iterate(M, R0, R1, curx, cury, bufM, g, P.win_size, gauss ? &wk : nullptr, i < P.num_iters - 1, st,
+                              last ? flows[0].data : nullptr, last ? (long long)flows[0].step : 0, &dm))) return rc;
+            merged = merged || dm;
             std::swap(M, bufM);
         }
         prevx = curx; prevy = cury; gprev = g;
     }
+    if (merged) return MI_OK;
     for (int b = 0; b < B; ++b)
         if ((rc = merge_flow(fx0 + b * bs, fy0 + b * bs, flows[b].data, (long long)flows[b].step, g0s, st))) return rc;   // cuda::merge :197-198
     return MI_OK;

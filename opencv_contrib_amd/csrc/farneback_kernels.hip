@@ -16,6 +16,7 @@
 // Planes are dense f32, `ld` floats per row (multiple of 64); 5-plane buffers are stacked vertically
 // (plane k at rows [k*h, (k+1)*h)) exactly like the reference's 5H x W matrices.
 #include "farneback_dev.h"
+#include "resize_dev.h"
 #include <cfloat>
 
 namespace mi {
@@ -82,10 +83,12 @@ __device__ __forceinline__ int gidx(int i, int n)
     return clampi(i, 0, n - 1);
 }
 template <int BORDER, bool FAST>
-__global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *dst, int w, int h, int ld, int kh, Taps K, long long bs)
+__global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *dst, int w, int h, int ld, int kh, Taps K, long long bs, int nf,
+                                                       long long fs)
 {
     extern __shared__ float row[];
-    src += (long long)blockIdx.z * bs; dst += (long long)blockIdx.z * bs;   // pair of the batch
+    // blockIdx.z = pair * nf + frame: nf = 2 runs both frames of every pair in one launch (frame f of a pair lies fs floats behind frame 0)
+    { const long long o = (long long)(blockIdx.z / nf) * bs + (long long)(blockIdx.z % nf) * fs; src += o; dst += o; }
     const int tx = threadIdx.x, y = blockIdx.y, x = blockIdx.x * 256 + tx;
     for (int i = tx; i < 256 + 2 * kh; i += 256) {
         // columns past w + kh feed no output (x < w below) but are loaded: keep them inside the range one mirror step covers
@@ -109,21 +112,34 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *
 
 // ------------------------------------------------------------------ polynomial expansion
 // farneback.cu:66-119: vertical pass (g, xg, xxg) into 3 LDS rows, horizontal pass -> 5 coefficient planes.
-template <int N>
-__global__ __launch_bounds__(256) void k_poly_exp(const float *src, float *dst, int w, int h, int ld, PolyC C, long long bs)
+// RS: `src` is the FULL-SIZE blurred frame (sw x sh, pitch sld) and the level image the expansion reads is its cuda::resize
+// (INTER_LINEAR, cudawarping/src/cuda/resize.cu:234-269) to w x h, sampled on the fly with the arithmetic of k_resize -- the same
+// bits as resizing into a plane first, one launch (and one plane round trip) less per level: what a single pair needs (round 4).
+struct RsSrc { int sw, sh, sld; double scx, scy; };
+template <int N, bool RS>
+__global__ __launch_bounds__(256) void k_poly_exp(const float *src, float *dst, int w, int h, int ld, PolyC C, long long bs, int nf, long long fs_src,
+                                                  long long fs_dst, RsSrc rs)
 {
     __shared__ float smem[3 * 256];
-    src += (long long)blockIdx.z * bs; dst += (long long)blockIdx.z * bs;
+    src += (long long)(blockIdx.z / nf) * bs + (long long)(blockIdx.z % nf) * fs_src;   // blockIdx.z = pair * nf + frame
+    dst += (long long)(blockIdx.z / nf) * bs + (long long)(blockIdx.z % nf) * fs_dst;
     const int tx = threadIdx.x, y = blockIdx.y;
     const int x = blockIdx.x * (256 - 2 * N) + tx - N;
     float *row = smem + tx;
     const int xw = clampi(x, 0, w - 1);
+    tvl1::RszX X;
+    if (RS) X = tvl1::resize_xside<MI_SEM_CUDA_COMPAT>(xw, rs.sw, rs.scx);
+    const auto at = [&](int yy) -> float {
+        if (!RS) return src[(long long)yy * ld + xw];
+        const tvl1::RszX Y = tvl1::resize_yside<MI_SEM_CUDA_COMPAT>(yy, rs.sh, rs.scy);
+        return tvl1::resize_combine<MI_SEM_CUDA_COMPAT>(src + (long long)Y.i0 * rs.sld, src + (long long)Y.i1 * rs.sld, X, Y);
+    };
     {
-        float a = src[(long long)y * ld + xw] * C.g[0], b = 0.f, c = 0.f;
+        float a = at(y) * C.g[0], b = 0.f, c = 0.f;
 #pragma unroll
         for (int k = 1; k <= N; ++k) {
-            const float t0 = src[(long long)max(y - k, 0) * ld + xw];
-            const float t1 = src[(long long)min(y + k, h - 1) * ld + xw];
+            const float t0 = at(max(y - k, 0));
+            const float t1 = at(min(y + k, h - 1));
             a += C.g[k] * (t0 + t1);
             b += C.xg[k] * (t1 - t0);
             c += C.xxg[k] * (t0 + t1);
@@ -159,8 +175,8 @@ __device__ __forceinline__ float border_w(int d)
     return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f);
 }
 
-__device__ __forceinline__ void update_matrices_px(int x, int y, int w, int h, int ld, float dx, float dy, const float *R0,
-                                                   const float *R1, float *M)
+__device__ __forceinline__ void update_matrices_vals(int x, int y, int w, int h, int ld, float dx, float dy, const float *R0,
+                                                     const float *R1, float (&m)[5])
 {
     const long long ps = (long long)ld * h;
     float fx = x + dx, fy = y + dy;
@@ -191,12 +207,21 @@ __device__ __forceinline__ void update_matrices_px(int x, int y, int w, int h, i
     r3 += r6 * dy + r5 * dx;
     const float scale = border_w(min(x, 5)) * border_w(min(y, 5)) * border_w(min(w - x - 1, 5)) * border_w(min(h - y - 1, 5));
     r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    M[o] = r4 * r4 + r6 * r6;
-    M[ps + o] = (r4 + r5) * r6;
-    M[2 * ps + o] = r5 * r5 + r6 * r6;
-    M[3 * ps + o] = r4 * r2 + r6 * r3;
-    M[4 * ps + o] = r6 * r2 + r5 * r3;
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
 }
+__device__ __forceinline__ void update_matrices_px(int x, int y, int w, int h, int ld, float dx, float dy, const float *R0,
+                                                   const float *R1, float *M)
+{
+    float m[5];
+    update_matrices_vals(x, y, w, h, ld, dx, dy, R0, R1, m);
+    const long long ps = (long long)ld * h, o = (long long)y * ld + x;
+    M[o] = m[0]; M[ps + o] = m[1]; M[2 * ps + o] = m[2]; M[3 * ps + o] = m[3]; M[4 * ps + o] = m[4];
+}
+
 
 __global__ __launch_bounds__(256) void k_update_matrices(const float *flowx, const float *flowy, const float *R0, const float *R1,
                                                          float *M, int w, int h, int ld, long long bs)
@@ -263,11 +288,18 @@ __global__ __launch_bounds__(256) void k_iterate(const float *M, const float *R0
 // ones, and (R + 2 KH) / R instead of 2 KH + 1 loads per output -- and forms the R sums in the reference's order (centre, then
 // the symmetric pairs outwards), so results are bit-identical to k_iterate.  (column, plane) tasks are dealt round-robin to the
 // threads: 5 x (256 + 2 KH) tasks in ceil(./256) rounds.
-template <bool GAUSS, int KH, int R>
+// TW = columns of a tile.  256: a thread owns one column and walks the R rows (large grids).  64 (R = 4: 64 x 4 outputs = one per
+// thread; round 4): for grids that do not fill the device -- a single 640 x 480 pair, the coarse levels of any pyramid -- where a launch
+// costs its LATENCY, not its work: the vertical pass is 2 rounds of independent loads instead of 6 and the horizontal pass + flow
+// solve + matrix update run once per thread instead of four times in a row (r08h: 9-10 us per launch whatever the level size).
+// The sums are formed in the same order: bit-identical planes.
+template <bool GAUSS, int KH, int R, int TW = 256>
 __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *R0, const float *R1, float *flowx, float *flowy,
-                                                   float *Mout, int w, int h, int ld, float boxAreaInv, int update, Taps K, long long bs, int swz)
+                                                   float *Mout, int w, int h, int ld, float boxAreaInv, int update, Taps K, long long bs, int swz,
+                                                   void *merged, long long merged_step)
 {
-    constexpr int SMW = 256 + 2 * KH;
+    static_assert(TW == 256 || TW * R == 256, "narrow tiles: one output per thread");
+    constexpr int SMW = TW + 2 * KH;
     __shared__ float smem[5][R][SMW];
     // workgroup -> (column tile, row tile, pair).  Consecutive workgroup ids go to different XCDs (8, each with its own L2), so
     // with the plain mapping the R + 2 KH rows a tile shares with its vertical neighbours are fetched from memory by several
@@ -284,11 +316,11 @@ __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *
         const long long po = (long long)bz * bs;
         M += po; R0 += po; R1 += po; flowx += po; flowy += po; Mout += po;
     }
-    const int tx = threadIdx.x, y0 = by * R, x = bx * 256 + tx;
+    const int tx = threadIdx.x, y0 = by * R, x = bx * TW + (TW == 256 ? tx : tx % TW);
     const long long ps = (long long)ld * h;
     for (int t = tx; t < 5 * SMW; t += 256) {
         const int k = t / SMW, i = t - k * SMW;
-        const int xe = clampi(bx * 256 + i - KH, 0, w - 1);
+        const int xe = clampi(bx * TW + i - KH, 0, w - 1);
         const float *P = M + k * ps + xe;
         float c[R + 2 * KH];
 #pragma unroll
@@ -307,13 +339,14 @@ __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *
     __syncthreads();
     if (x >= w) return;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int rr = 0; rr < (TW == 256 ? R : 1); ++rr) {
+        const int r = TW == 256 ? rr : tx / TW;
         const int y = y0 + r;
         if (y >= h) break;
         float res[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const float *q = &smem[k][r][tx + KH];
+            const float *q = &smem[k][r][(TW == 256 ? tx : tx % TW) + KH];
             float v = GAUSS ? q[0] * K.k[0] : q[0];
 #pragma unroll
             for (int i = 1; i <= KH; ++i) v += GAUSS ? (q[-i] + q[i]) * K.k[i] : q[-i] + q[i];
@@ -326,8 +359,117 @@ __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *
         const long long o = (long long)y * ld + x;
         flowx[o] = fx;
         flowy[o] = fy;
+        // the last iteration of the finest level of a single pair also writes the caller's CV_32FC2 flow (cuda::merge, farneback.cpp:197-198)
+        if (merged) ((float2 *)((char *)merged + (long long)y * merged_step))[x] = make_float2(fx, fy);
         if (update) update_matrices_px(x, y, w, h, ld, fx, fy, R0, R1, Mout);
     }
+}
+
+// TWO inner iterations in one launch (round 4; a single pair is a chain of ~5 us launches, 40 of them iterations): a workgroup still
+// owns a 64 x 4 tile of the SECOND iteration's output and recomputes what that needs of the first -- the flow and the updated
+// matrices M' on the tile grown by KH pixels on every side (E1: (64 + 2 KH) x (4 + 2 KH)), from M on the tile grown by 2 KH.  M' stays in
+// LDS; the second iteration blurs it exactly as the one-iteration kernel blurs the stored plane (replicated borders = clamped indices
+// into E1), so flow and Mout are BIT-IDENTICAL to two launches of k_iterate_t.  4.75 x the first iteration's work per tile: only for
+// levels whose grid underfills the device, where a launch costs its latency.  Input M and output Mout must be different buffers
+// (other workgroups still read M): the host swaps ONCE per fused pair.  1024 threads per workgroup: with 256 the E1 pass walked 4.75
+// pixels per thread one after the other, each with its own gather round trip, and the launch took longer than the two it replaces (r08i).
+template <bool GAUSS, int KH>
+__global__ __launch_bounds__(1024) void k_iterate2_t(const float *M, const float *R0, const float *R1, float *flowx, float *flowy, float *Mout, int w,
+                                                    int h, int ld, float boxAreaInv, int update, Taps K, long long bs, void *merged, long long merged_step)
+{
+    constexpr int TW = 64, TR = 4, EW = TW + 2 * KH, EH = TR + 2 * KH, SW = TW + 4 * KH, SH = TR + 4 * KH;
+    __shared__ float smemA[5][EH][SW];   // vertical sums of M for the rows of E1 (later reused for the second iteration's vertical sums)
+    __shared__ float smemM[5][EH][EW];   // M' on E1
+    static_assert(sizeof(float) * 5 * (EH * SW + EH * EW) <= 65536 && TR * EW <= EH * SW, "two-iteration tile must fit the static LDS");
+    {
+        const long long po = (long long)blockIdx.z * bs;
+        M += po; R0 += po; R1 += po; flowx += po; flowy += po; Mout += po;
+    }
+    const int tx = threadIdx.x, x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    const long long ps = (long long)ld * h;
+    // ---- first iteration, vertical pass: one (plane, column) task loads its SH rows once
+    for (int t = tx; t < 5 * SW; t += 1024) {
+        const int k = t / SW, i = t - k * SW;
+        const float *P = M + k * ps + clampi(x0 - 2 * KH + i, 0, w - 1);
+        float c[SH];
+#pragma unroll
+        for (int r = 0; r < SH; ++r) c[r] = P[(long long)clampi(y0 - 2 * KH + r, 0, h - 1) * ld];
+#pragma unroll
+        for (int e = 0; e < EH; ++e) {
+            float v = GAUSS ? c[e + KH] * K.k[0] : c[e + KH];
+#pragma unroll
+            for (int j = 1; j <= KH; ++j) {
+                const float sj = c[e + KH - j] + c[e + KH + j];
+                v += GAUSS ? sj * K.k[j] : sj;
+            }
+            smemA[k][e][i] = v;
+        }
+    }
+    __syncthreads();
+    // ---- first iteration, horizontal pass + flow + matrix update on E1 (pixels inside the image only)
+    for (int idx = tx; idx < EW * EH; idx += 1024) {
+        const int e = idx / EW, ci = idx - e * EW;
+        const int xc = x0 - KH + ci, ye = y0 - KH + e;
+        if (xc < 0 || xc >= w || ye < 0 || ye >= h) continue;
+        float res[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float *q = &smemA[k][e][ci + KH];
+            float v = GAUSS ? q[0] * K.k[0] : q[0];
+#pragma unroll
+            for (int i = 1; i <= KH; ++i) v += GAUSS ? (q[-i] + q[i]) * K.k[i] : q[-i] + q[i];
+            res[k] = GAUSS ? v : v * boxAreaInv;
+        }
+        const float g11 = res[0], g12 = res[1], g22 = res[2], h1 = res[3], h2 = res[4];
+        const float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
+        const float fx = (g11 * h2 - g12 * h1) * detInv;
+        const float fy = (g22 * h1 - g12 * h2) * detInv;
+        float m[5];
+        update_matrices_vals(xc, ye, w, h, ld, fx, fy, R0, R1, m);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) smemM[k][e][ci] = m[k];
+    }
+    __syncthreads();
+    // ---- second iteration, vertical pass over M' (clamped rows / columns = the replicated border of the stored plane)
+    float (*smemB)[TR][EW] = reinterpret_cast<float (*)[TR][EW]>(&smemA[0][0][0]);
+    for (int t = tx; t < 5 * EW; t += 1024) {
+        const int k = t / EW, ci = t - k * EW;
+        const int cc = clampi(x0 - KH + ci, 0, w - 1) - (x0 - KH);
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const int y = y0 + r;
+            const auto at = [&](int yy) { return smemM[k][clampi(yy, 0, h - 1) - (y0 - KH)][cc]; };
+            float v = GAUSS ? at(y) * K.k[0] : at(y);
+#pragma unroll
+            for (int j = 1; j <= KH; ++j) {
+                const float sj = at(y - j) + at(y + j);
+                v += GAUSS ? sj * K.k[j] : sj;
+            }
+            smemB[k][r][ci] = v;
+        }
+    }
+    __syncthreads();
+    // ---- second iteration, horizontal pass + flow (+ matrix update into Mout)
+    const int r = tx / TW, x = x0 + tx % TW, y = y0 + r;
+    if (tx >= TW * TR || x >= w || y >= h) return;
+    float res[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float *q = &smemB[k][r][tx % TW + KH];
+        float v = GAUSS ? q[0] * K.k[0] : q[0];
+#pragma unroll
+        for (int i = 1; i <= KH; ++i) v += GAUSS ? (q[-i] + q[i]) * K.k[i] : q[-i] + q[i];
+        res[k] = GAUSS ? v : v * boxAreaInv;
+    }
+    const float g11 = res[0], g12 = res[1], g22 = res[2], h1 = res[3], h2 = res[4];
+    const float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
+    const float fx = (g11 * h2 - g12 * h1) * detInv;
+    const float fy = (g22 * h1 - g12 * h2) * detInv;
+    const long long o = (long long)y * ld + x;
+    flowx[o] = fx;
+    flowy[o] = fy;
+    if (merged) ((float2 *)((char *)merged + (long long)y * merged_step))[x] = make_float2(fx, fy);
+    if (update) update_matrices_px(x, y, w, h, ld, fx, fy, R0, R1, Mout);
 }
 
 // 5-plane blur only / flow solve only (stage-level entry points and tests)
@@ -427,29 +569,70 @@ int merge_flow(const float *fx, const float *fy, void *flow, long long sf, const
     return MI_OK;
 }
 
-int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Taps &K, int border, hipStream_t s)
+int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Taps &K, int border, hipStream_t s, int nf, long long fs)
 {
     MI_REQUIRE(kh >= 0 && kh <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "Gaussian kernel half size out of range");
-    const dim3 grid(div_up(g.w, 256), g.h, g.batch);
+    const dim3 grid(div_up(g.w, 256), g.h, g.batch * nf);
     const size_t lds = sizeof(float) * (256 + 2 * kh);
     const bool fast = kh < g.w && kh < g.h && g.w >= 2 && g.h >= 2;
     if (border == MI_BORDER_REFLECT101) {
-        if (fast) hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
-        else hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, false>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
+        if (fast) hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
+        else hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, false>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
     } else if (border == MI_BORDER_REPLICATE)
-        hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REPLICATE, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs);
+        hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REPLICATE, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
     else { set_error("unsupported border mode %d", border); return MI_ERR_BAD_ARG; }   // farneback.cu:510-517: only these two
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
-int poly_exp(const float *src, float *dst5, const Plane &g, int polyN, const PolyC &C, hipStream_t s)
+int poly_exp(const float *src, float *dst5, const Plane &g, int polyN, const PolyC &C, hipStream_t s, int nf, long long fs_src, long long fs_dst,
+             const Plane *resize_from)
 {
-    if (polyN == 5)
-        hipLaunchKernelGGL(k_poly_exp<5>, dim3(div_up(g.w, 256 - 10), g.h, g.batch), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C, g.bs);
-    else if (polyN == 7)
-        hipLaunchKernelGGL(k_poly_exp<7>, dim3(div_up(g.w, 256 - 14), g.h, g.batch), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C, g.bs);
+    RsSrc rs;
+    memset(&rs, 0, sizeof(rs));
+    if (resize_from) {   // the scale factors exactly as tvl1::resize forms them for cv::cuda's semantics (cudawarping/src/resize.cpp:107)
+        rs.sw = resize_from->w; rs.sh = resize_from->h; rs.sld = resize_from->ld;
+        rs.scx = (double)(float)(1.0 / ((double)g.w / resize_from->w));
+        rs.scy = (double)(float)(1.0 / ((double)g.h / resize_from->h));
+    }
+#define MI_PE(N) do { if (resize_from) hipLaunchKernelGGL((k_poly_exp<N, true>), dim3(div_up(g.w, 256 - 2 * N), g.h, g.batch * nf), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C, g.bs, nf, fs_src, fs_dst, rs); \
+                     else hipLaunchKernelGGL((k_poly_exp<N, false>), dim3(div_up(g.w, 256 - 2 * N), g.h, g.batch * nf), dim3(256), 0, s, src, dst5, g.w, g.h, g.ld, C, g.bs, nf, fs_src, fs_dst, rs); } while (0)
+    if (polyN == 5) MI_PE(5);
+    else if (polyN == 7) MI_PE(7);
     else { set_error("polyN must be 5 or 7"); return MI_ERR_BAD_ARG; }   // CV_Assert, farneback.cpp:316
+#undef MI_PE
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// The zoom of the coarser level's flow (cuda::resize + the 1 / pyrScale multiply, farneback.cpp:412-417) and the first matrix update
+// of the level (:458) in one launch: the flow of a pixel is sampled with k_resize's arithmetic, stored, and used at once.
+__global__ __launch_bounds__(256) void k_update_matrices_rs(const float *px, const float *py, RsSrc rs, float alpha, float *flowx, float *flowy,
+                                                            const float *R0, const float *R1, float *M, int w, int h, int ld, long long bs)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const long long po = (long long)blockIdx.z * bs;
+    const tvl1::RszX X = tvl1::resize_xside<MI_SEM_CUDA_COMPAT>(x, rs.sw, rs.scx), Y = tvl1::resize_yside<MI_SEM_CUDA_COMPAT>(y, rs.sh, rs.scy);
+    float fx = tvl1::resize_combine<MI_SEM_CUDA_COMPAT>(px + po + (long long)Y.i0 * rs.sld, px + po + (long long)Y.i1 * rs.sld, X, Y);
+    float fy = tvl1::resize_combine<MI_SEM_CUDA_COMPAT>(py + po + (long long)Y.i0 * rs.sld, py + po + (long long)Y.i1 * rs.sld, X, Y);
+    if (alpha != 1.0f) { fx = fx * alpha; fy = fy * alpha; }
+    const long long o = (long long)y * ld + x;
+    flowx[po + o] = fx;
+    flowy[po + o] = fy;
+    update_matrices_px(x, y, w, h, ld, fx, fy, R0 + po, R1 + po, M + po);
+}
+int update_matrices_resized(const float *prevx, const float *prevy, const Plane &gprev, float alpha, float *flowx, float *flowy, const float *R0,
+                            const float *R1, float *M, const Plane &g, hipStream_t s)
+{
+    RsSrc rs;
+    rs.sw = gprev.w; rs.sh = gprev.h; rs.sld = gprev.ld;
+    rs.scx = (double)(float)(1.0 / ((double)g.w / gprev.w));
+    rs.scy = (double)(float)(1.0 / ((double)g.h / gprev.h));
+    dim3 grid = grid2d(g.w, g.h);
+    grid.z = g.batch;
+    hipLaunchKernelGGL(k_update_matrices_rs, grid, dim3(256), 0, s, prevx, prevy, rs, alpha, flowx, flowy, R0, R1, M, g.w, g.h, g.ld, g.bs);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -464,8 +647,9 @@ int update_matrices(const float *flowx, const float *flowy, const float *R0, con
 }
 
 int iterate(const float *M, const float *R0, const float *R1, float *flowx, float *flowy, float *Mout, const Plane &g, int ksize,
-            const Taps *gauss, bool update, hipStream_t s)
+            const Taps *gauss, bool update, hipStream_t s, void *merged, long long merged_step, bool *did_merge)
 {
+    if (did_merge) *did_merge = false;
     const int kh = ksize / 2;
     MI_REQUIRE(kh >= 0 && kh <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "winSize out of range");
     const dim3 grid(div_up(g.w, 256), g.h, g.batch);
@@ -474,15 +658,22 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
     Taps none;
     memset(&none, 0, sizeof(none));
     const int R = tuning().fb_rows, swz = tuning().fb_swz;
-    const dim3 tgrid(div_up(g.w, 256), div_up(g.h, R), g.batch);
+    dim3 tgrid(div_up(g.w, 256), div_up(g.h, R), g.batch);
     const Taps &K = gauss ? *gauss : none;
     const int upd = update ? 1 : 0;
-#define MI_FB_LAUNCH(G, KH, RR) hipLaunchKernelGGL((k_iterate_t<G, KH, RR>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs, swz)
+    // narrow tiles where the 256-column grid would leave most of the device idle (fewer workgroups than two per CU): the launch then
+    // costs its dependent steps, and a 64 x 4 tile has a third of them.  MIFLOW_FB_NARROW=0 / 1 forces the choice (tuning, tests).
+    const int narrow_env = tuning().fb_narrow;
+    const bool narrow = narrow_env >= 0 ? narrow_env != 0 : (long long)tgrid.x * tgrid.y * tgrid.z < 2LL * (device_simds() / 4);
+    if (narrow && R == 4) tgrid = dim3(div_up(g.w, 64), div_up(g.h, 4), g.batch);
+#define MI_FB_LAUNCH(G, KH, RR, TW) hipLaunchKernelGGL((k_iterate_t<G, KH, RR, TW>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs, swz, mg, merged_step)
 #define MI_FB_TILED(KH)                                                                  \
     case KH:                                                                             \
-        if (gauss) { if (R == 8) MI_FB_LAUNCH(true, KH, 8); else MI_FB_LAUNCH(true, KH, 4); }   \
-        else { if (R == 8) MI_FB_LAUNCH(false, KH, 8); else MI_FB_LAUNCH(false, KH, 4); }       \
+        if (gauss) { if (R == 8) MI_FB_LAUNCH(true, KH, 8, 256); else if (narrow) MI_FB_LAUNCH(true, KH, 4, 64); else MI_FB_LAUNCH(true, KH, 4, 256); }   \
+        else { if (R == 8) MI_FB_LAUNCH(false, KH, 8, 256); else if (narrow) MI_FB_LAUNCH(false, KH, 4, 64); else MI_FB_LAUNCH(false, KH, 4, 256); }       \
         break;
+    void *mg = (merged && g.batch == 1 && tuning().fb_tiled && (kh == 4 || kh == 6 || kh == 7 || kh == 10)) ? merged : nullptr;
+    if (did_merge) *did_merge = mg != nullptr;
     switch (tuning().fb_tiled ? kh : -1) {
         MI_FB_TILED(4) MI_FB_TILED(6) MI_FB_TILED(7) MI_FB_TILED(10)   // winSize 9, 13 (the default), 15, 21
     default:
@@ -491,6 +682,28 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
     }
 #undef MI_FB_TILED
 #undef MI_FB_LAUNCH
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// two fused iterations (k_iterate2_t); false when the window size has no instantiation (the caller then launches twice)
+bool iterate2_supported(int ksize) { const int kh = ksize / 2; return tuning().fb_tiled && (kh == 4 || kh == 6 || kh == 7); }
+int iterate2(const float *M, const float *R0, const float *R1, float *flowx, float *flowy, float *Mout, const Plane &g, int ksize, const Taps *gauss,
+             bool update, hipStream_t s, void *merged, long long merged_step, bool *did_merge)
+{
+    const int kh = ksize / 2;
+    MI_REQUIRE(iterate2_supported(ksize) && M != Mout, MI_ERR_BAD_ARG, "no two-iteration kernel for this window size");
+    const float inv = 1.f / ((1 + 2 * kh) * (1 + 2 * kh));
+    Taps none;
+    memset(&none, 0, sizeof(none));
+    const Taps &K = gauss ? *gauss : none;
+    void *mg = (merged && g.batch == 1) ? merged : nullptr;
+    if (did_merge) *did_merge = mg != nullptr;
+    const dim3 grid(div_up(g.w, 64), div_up(g.h, 4), g.batch);
+#define MI_FB2(KH) case KH: if (gauss) hipLaunchKernelGGL((k_iterate2_t<true, KH>), grid, dim3(1024), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, update ? 1 : 0, K, g.bs, mg, merged_step); \
+                            else hipLaunchKernelGGL((k_iterate2_t<false, KH>), grid, dim3(1024), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, update ? 1 : 0, K, g.bs, mg, merged_step); break;
+    switch (kh) { MI_FB2(4) MI_FB2(6) MI_FB2(7) }
+#undef MI_FB2
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

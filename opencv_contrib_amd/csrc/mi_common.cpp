@@ -50,6 +50,10 @@ const Tuning &tuning()
         t.exact_tb = env_int("MIFLOW_EXACT_TB", 1);
         t.fb_tiled = env_int("MIFLOW_FB_TILED", 1);
         t.fb_rows = env_int("MIFLOW_FB_ROWS", 4) == 8 ? 8 : 4;
+        t.fb_async = env_int("MIFLOW_FB_ASYNC", 0);   // r08i: the cross-stream events cost more than the 9 launches they take off the chain (2 718 vs 3 089 calc/s)
+        t.fb_fuse = env_int("MIFLOW_FB_FUSE", -1);
+        t.fb_pair = env_int("MIFLOW_FB_PAIR", -1);
+        t.fb_narrow = env_int("MIFLOW_FB_NARROW", -1);
         t.fb_swz = env_int("MIFLOW_FB_SWZ", 1);
     });
     return g_tuning;

@@ -52,6 +52,10 @@ struct Tuning {
     int exact_tb;            // MIFLOW_EXACT_TB: exact math, fixed work: fused blocks (1) or one launch per iteration (0)
     int spec;                // MIFLOW_SPEC: speculative blocked convergence path (1) or one launch per iteration (0)
     int fb_rows, fb_swz;     // MIFLOW_FB_ROWS (4 | 8 rows per workgroup), MIFLOW_FB_SWZ (XCD-contiguous tile order) of the tiled kernel
+    int fb_async;            // MIFLOW_FB_ASYNC: Farneback pyramid side of all levels on an internal stream beside the iterations (1) or in line (0, default: measured faster)
+    int fb_fuse;             // MIFLOW_FB_FUSE: Farneback few-launch forms (resize sampled inside poly_exp / update_matrices, merge in the last iteration): -1 = small calls (default), 0, 1
+    int fb_pair;             // MIFLOW_FB_PAIR: Farneback two iterations per launch (k_iterate2_t): -1 = levels that underfill the device (default), 0, 1
+    int fb_narrow;           // MIFLOW_FB_NARROW: Farneback iteration kernel on 64 x 4 tiles: -1 = where the 256-column grid underfills the device (default), 0 = never, 1 = always
     int fb_tiled;            // MIFLOW_FB_TILED: Farneback iteration kernel tiled over 4 rows (1) or one row per workgroup (0)
 };
 const Tuning &tuning();
