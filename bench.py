@@ -404,6 +404,22 @@ def bench_stereobm(args):
                         "hbm_algorithmic_GBps": algo_bytes * n / el / 1e9, "hbm_frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS,
                         "traffic": pmc_traffic("stereobm")[0], "traffic_kernel": "k_block_match, bytes per launch (one pair)",
                         "traffic_source": pmc_traffic("stereobm")[1]}}
+    # The 2-cycle issue peak holds for a short list of gfx950 VALU operations only (fma / mul / add / sub f32, add / sub u32, and / or /
+    # xor, right shift, mov); SDWA, DPP, selects, min / max, 24-bit multiplies, left shifts, conversions take 4.2 cycles per wave
+    # instruction (round 4: tools/ubench/issue_mix.hip, profiles/valu_rates_gfx950.json).  rate_weighted: the row loop's SIMD cycles if
+    # every instruction issued at ITS measured rate against the cycles the kernel's share of a pair actually takes -- what the kernel can
+    # still gain without changing its instruction mix.
+    try:
+        mixd = json.load(open(os.path.join(ROOT, "profiles", "static_mix_sbm.json")))
+        cyc = float(mixd["rate_weighted_cycles_per_output_pixel_and_disparity_lane"])   # SIMD cycles per (pixel, disparity) lane-unit x 64
+        simds, clk = 1024.0, 2.39e9   # StereoBM is not power-limited: the clock stays at 2.39 GHz (profiles/r08/pmc_sq_block_match.txt, r08j poll)
+        peak_pxd = simds * 64.0 * clk / cyc
+        out["roofline"]["rate_weighted"] = {"cycles_per_pixel_disparity_per_lane": cyc, "mix": mixd.get("rate_weighted"),
+                                            "peak_pixel_disparities_per_s": peak_pxd, "clock_GHz": clk / 1e9,
+                                            "frac_batched_executed": pxd * n / elb * halo_b / peak_pxd,
+                                            "frac_sequential_executed": pxd * n / el * halo_seq / peak_pxd}
+    except Exception as e:
+        out["roofline"]["rate_weighted"] = {"error": repr(e)[:200]}
     if batched["equals_single_compute"]:
         # `value` = the batched entry (block matching of the B pairs in one launch); the sequential compute() loop stays next to it
         out["sequential_compute_pairs_per_s"] = out["value"]

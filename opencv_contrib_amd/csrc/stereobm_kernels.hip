@@ -141,6 +141,10 @@ __global__ void k_dbg_wave_min(const unsigned *in, unsigned *out)
     if (threadIdx.x == 0) out[64] = (unsigned)pick_lane(mk);
 }
 
+// LDS pointers keep their address space (a generic pointer would turn the accesses into flat_load / flat_store)
+typedef __attribute__((address_space(3))) unsigned MI_LDSU;
+typedef unsigned mi_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) mi_u4 MI_LDSU4;
 // ------------------------------------------------------------------ block matching
 struct BmArgs {
     const unsigned char *left, *right;
@@ -171,7 +175,15 @@ struct Cfg {
 };
 
 // MODE 0: winner-take-all.  MODE 1: uniqueness verification of the pass-0 winner.
-template <int R, int MODE>
+// WT (MODE 0, packed windows R <= 12; round 4): winner-take-all through an LDS TRANSPOSITION instead of the transposed DPP reduction.
+// A lane (= disparity) writes the complemented window SSDs of the tile's columns to T[column][lane]; lane i then reads column i's 64
+// values and scans them with one v_lshl_or + v_max per disparity (the tie-break key is a compile-time constant of the scan position).
+// In groups of 16 columns (4.3 KB of LDS per wave; the whole tile at once cost the kernel its occupancy: 4 226 against 6 089 pairs/s,
+// r08j): lane (c, q) scans the 16 disparities of quarter q of column c -- 32 operations per group, 2 cross-row exchanges -- instead of
+// 49 shifts + 49 bit-ops to pack and 141 selects + 69 DPP / max operations to reduce (profiles/static_mix_sbm.json); same winners bit
+// for bit (same score, same key).  Row pitch of T = 68 dwords: the write of a column is 64 consecutive banks, a b128 read of 16
+// lanes covers the 64 banks once.
+template <int R, int MODE, bool WT = false>
 __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
 {
     if (A.tab) {
@@ -198,6 +210,10 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
     unsigned char *Ls = smem;
     unsigned char *Rs = smem + (size_t)(A.rb + 2 * R) * LS;
     unsigned *comb = reinterpret_cast<unsigned *>(Rs + (size_t)(A.rb + 2 * R) * RS);  // [2][nsets][2][64]
+    constexpr int TP = 68;                                                               // dwords per row of the transposition buffer
+    // WT: [16][TP] per wave (one group of 16 columns at a time), behind comb at the next 16-byte boundary (b128 reads)
+    unsigned *Tb = reinterpret_cast<unsigned *>(smem + (((size_t)(A.rb + 2 * R) * (LS + RS) + (size_t)2 * nsets * 128 * sizeof(unsigned) + 15) / 16 * 16)) +
+                   (WT ? (size_t)wset * 16 * TP : 0);
 
     // ---- stage the tile rows (byte copies; columns outside the image read as 0 and are never used
     //      by an active lane / valid column)
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
 
     // inactive lanes (d >= ndisp) carry a bias above any real SSD (max 51*51*255^2 < 2^28) so they never win
     const unsigned bias = active ? 0u : 0x40000000u;
+    const bool all_active = (A.ndisp & 63) == 0;   // wave-uniform: no lane of any set lies past the disparity range
     // wave-uniform facts about the tile
 #ifdef MI_STATIC_MIX_INTERIOR_TILES   // tools/static_mix.py sbm: count the row loop of a tile away from the right image edge
     const bool edge_tile = false;
@@ -301,6 +318,78 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
         unsigned resm = UINT_MAX, resd = 0;   // lane i collects the result of tile column i
         auto row_stage = [&](auto edge_tag) {
             constexpr bool EDGE = decltype(edge_tag)::value;
+            if (MODE == 0 && C::PACKED && WT) {
+                // ---- winner-take-all through LDS (see the kernel's header), 16 columns at a time: lane d writes the window values
+                //      of the group's columns to T[column][d]; lane (c = lane % 16, q = lane / 16) scans disparities 16 q .. 16 q + 15 of
+                //      column c with the same score as the DPP path, (2^26-1 - SSD) << 6 | (d ^ 0x38); the four quarters of a column are
+                //      combined across the rows of 16 lanes.  An inactive lane's value is written as 0, which no active lane's (> 0) ties.
+                const unsigned amask = active ? 0xffffffffu : 0u;
+                unsigned nw = 0x3ffffffu, nh = 0x3ffffffu;
+#pragma unroll
+                for (int c = 0; c < 2 * R; ++c) nw -= cs[c];
+                if (EDGE) {
+#pragma unroll
+                    for (int c = 0; c < R; ++c) nh -= cs[c];
+                }
+                MI_LDSU *tw = (MI_LDSU *)(Tb + lane);
+                const int sc = lane & 15, sq = lane >> 4;
+                const MI_LDSU4 *tr = (const MI_LDSU4 *)(Tb + sc * TP + sq * 16);
+                const unsigned kq = (unsigned)(sq * 16);
+                unsigned zr[TW / 16];
+                // window values of one group of 16 columns (registers); the sliding sums continue from group to group
+                auto group_vals = [&](int g, unsigned (&v)[16]) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = g * 16 + k;
+                        nw -= cs[i + 2 * R];
+                        unsigned val = nw;
+                        if (EDGE) {
+                            nh -= cs[i + R];
+                            const int X = X0 + i;
+                            const int t = (X - A.ndisp - R) & 127;
+                            val = (t < 128 - R && X + R >= A.cols - R) ? nh : nw;   // stereobm.cu:77-89
+                            nh += cs[i];
+                        }
+                        nw += cs[i];
+                        if (!all_active) val &= amask;
+                        v[k] = val;
+                    }
+                };
+                // Order of a row: write group g, issue its reads, compute group g + 1's values WHILE the reads are in flight, scan g.
+                // (LDS executes a wave's operations in order: the reads of group g see its writes, and the writes of group g + 1 -- same
+                // buffer -- come after them.)
+                unsigned cur[16], nxt[16];
+                group_vals(0, cur);
+#pragma unroll
+                for (int g = 0; g < TW / 16; ++g) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) tw[k * TP] = cur[k];
+                    mi_u4 rd[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rd[q] = tr[q];
+                    if (g + 1 < TW / 16) group_vals(g + 1, nxt);
+                    unsigned z = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        z = max(z, (rd[q].x << 6) | ((kq + 4 * q + 0) ^ 0x38u));
+                        z = max(z, (rd[q].y << 6) | ((kq + 4 * q + 1) ^ 0x38u));
+                        z = max(z, (rd[q].z << 6) | ((kq + 4 * q + 2) ^ 0x38u));
+                        z = max(z, (rd[q].w << 6) | ((kq + 4 * q + 3) ^ 0x38u));
+                    }
+                    z = max(z, (unsigned)__shfl_xor((int)z, 16));   // the four quarters of the column
+                    z = max(z, (unsigned)__shfl_xor((int)z, 32));
+                    zr[g] = z;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+                }
+                // lane i <- column i of the tile: row r of 16 lanes takes group r
+                unsigned z = zr[0];
+#pragma unroll
+                for (int g = 1; g < TW / 16; ++g) z = (lane >> 4) == g ? zr[g] : z;
+                resm = 0x3ffffffu - (z >> 6);
+                resd = (unsigned)(wset * 64) + ((z & 63u) ^ 0x38u);
+                return;
+            }
             if (MODE == 0 && C::PACKED) {
                 // ---- packed winner-take-all: score = (2^26-1 - SSD) << 6 | key, key = lane ^ 0x38 (earlier batch of 8
                 //      wins, then the LAST index inside the batch: stereobm.cu:120-125,349); inactive lanes score 0
@@ -595,10 +684,15 @@ static int launch_bm(const BmArgs &A, int mode, hipStream_t s)
 {
     using C = Cfg<R>;
     const int RS = (C::NC + A.nsets * 64 - 1 + 3) / 4 * 4 + 4;
-    const size_t lds = (size_t)(A.rb + 2 * R) * (C::LS + RS) + (size_t)2 * A.nsets * 128 * sizeof(unsigned);
+    size_t lds = (size_t)(A.rb + 2 * R) * (C::LS + RS) + (size_t)2 * A.nsets * 128 * sizeof(unsigned);
+    lds = (lds + 15) / 16 * 16;   // the transposition buffer behind it is read as b128
     const dim3 grid(div_up(A.cols - A.ndisp - 2 * R, C::TW), div_up(A.rows - 2 * R, A.rb), A.tab ? A.batch : 1);
     const dim3 block(64 * A.nsets);
-    if (mode == 0) {
+    if (mode == 0 && C::PACKED && tuning().sbm_wt) {
+        const size_t ldst = lds + (size_t)A.nsets * 16 * 68 * sizeof(unsigned);
+        (void)hipFuncSetAttribute((const void *)k_block_match<R, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
+        hipLaunchKernelGGL((k_block_match<R, 0, true>), grid, block, ldst, s, A);
+    } else if (mode == 0) {
         (void)hipFuncSetAttribute((const void *)k_block_match<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_block_match<R, 0>), grid, block, lds, s, A);
     } else {

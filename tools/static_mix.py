@@ -62,7 +62,28 @@ def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0):
     raise SystemExit("instantiation not found: " + pat)
 
 
-def mix_sbm(R=7, MODE=0):
+def rate_weighted_cycles(cnt):
+    """SIMD cycles of one trip of a loop if every VALU instruction issued at its measured gfx950 rate (profiles/valu_rates_gfx950.json): the
+    2-cycle 'spec' rate holds for a short list of operations only; SDWA, DPP, selects, min / max, 24-bit multiplies, left shifts, ...
+    take twice as long."""
+    r = json.load(open(os.path.join(ROOT, "profiles", "valu_rates_gfx950.json")))
+    full = set(r["full_rate_ops"])
+    c = r["cycles_per_wave64_instruction"]
+    nf = nh = nt = 0
+    for op, n in cnt.items():
+        if not op.startswith("v_"):
+            continue
+        base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+        if re.match(r"v_(rcp|sqrt|rsq|exp|log|sin|cos)", op):
+            nt += n
+        elif base in full and not op.endswith(("_sdwa", "_dpp")):
+            nf += n
+        else:
+            nh += n
+    return {"full_rate": nf, "half_rate": nh, "transcendental": nt, "cycles": nf * c["full_rate"] + nh * c["half_rate"] + nt * c["transcendental"]}
+
+
+def mix_sbm(R=7, MODE=0, WT=None):
     """Static instruction count of the row loop of k_block_match<R, MODE> (stereobm_kernels.hip): per trip a lane (= one disparity)
     slides the column sums of its NC = TW + 2R tile columns down one row and produces the TW window SSDs / winners of that row, so
     loop VALU / TW = lane-instructions per (output pixel, disparity) of a tile row.  Output of record: profiles/static_mix_sbm.json."""
@@ -74,7 +95,7 @@ def mix_sbm(R=7, MODE=0):
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-x", "hip", "-S", "--cuda-device-only", src,
                         "-o", out], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
-    name = f"_ZN2mi3sbm13k_block_matchILi{R}ELi{MODE}EEEvNS0_6BmArgsE"
+    name = f"_ZN2mi3sbm13k_block_matchILi{R}ELi{MODE}ELb{1 if WT else 0}EEEvNS0_6BmArgsE"
     i = txt.index("\n" + name + ":")
     lines = txt[i:txt.index(".Lfunc_end", i)].split("\n")
     labels = {m.group(1): k for k, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
@@ -102,7 +123,9 @@ def mix_sbm(R=7, MODE=0):
                 warm = c
     tw = 48 if R <= 12 else max(16, (64 - 2 * R) & ~3)
     valu = sum(n for o, n in cnt.items() if o.startswith("v_"))
-    return {"kernel": f"k_block_match<{R},{MODE}>", "row_loop_instructions": sum(cnt.values()), "row_loop_valu": valu,
+    rw = rate_weighted_cycles(cnt)
+    return {"kernel": f"k_block_match<{R},{MODE},{'true' if WT else 'false'}>", "row_loop_instructions": sum(cnt.values()), "row_loop_valu": valu,
+            "rate_weighted": rw, "rate_weighted_cycles_per_output_pixel_and_disparity_lane": round(rw["cycles"] / tw, 3),
             "warmup_row_valu": sum(n for o, n in (warm or {}).items() if o.startswith("v_")),
             "row_loop_salu": sum(n for o, n in cnt.items() if o.startswith("s_")), "row_loop_lds": sum(n for o, n in cnt.items() if o.startswith("ds_")),
             "tile_output_columns": tw, "valu_per_output_pixel_and_disparity": round(valu / tw, 3),
@@ -111,7 +134,7 @@ def mix_sbm(R=7, MODE=0):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sbm":   # python tools/static_mix.py sbm [R MODE]
-        print(json.dumps(mix_sbm(*[int(x) for x in sys.argv[2:4]]), indent=1))
+        print(json.dumps(mix_sbm(*[int(x) for x in sys.argv[2:5]]), indent=1))   # R MODE WT
     else:
         a = [int(x) for x in sys.argv[1:8]] or [10, 1, 0, 4, 2, 0, 0]
         print(json.dumps(mix(*a), indent=1))

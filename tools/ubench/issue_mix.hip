@@ -107,6 +107,46 @@ __global__ __launch_bounds__(256) void k(float *out, Stamp *st, int iters, float
 #define ADD(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
         if (OP == 29) { REP8(MUL) REP8(MUL) }
         if (OP == 30) { REP8(ADD) REP8(ADD) }
+        // integer / byte ops of the StereoBM row loop (each: 16 instructions over 8 independent registers)
+        unsigned *ia = (unsigned *)a;
+        const unsigned ib = __float_as_uint(b), ic = __float_as_uint(c);
+#define IOP(name, text) if (OP == name) { for (int rpt = 0; rpt < 2; ++rpt) { _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile(text : "+v"(ia[i]) : "v"(ib), "v"(ic), "s"(msk)); } }
+        IOP(40, "v_sub_u32_e32 %0, %0, %1")
+        IOP(41, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2")
+        IOP(42, "v_mad_i32_i24 %0, %0, %1, %2")
+        IOP(43, "v_mul_i32_i24_e32 %0, %0, %1")
+        IOP(44, "v_add_u32_e32 %0, %0, %1")
+        IOP(45, "v_lshl_or_b32 %0, %0, 6, %1")
+        IOP(46, "v_max_u32_e32 %0, %0, %1")
+        IOP(47, "v_max3_u32 %0, %0, %1, %2")
+        IOP(48, "v_alignbyte_b32 %0, %0, %1, 1")
+        IOP(49, "v_cndmask_b32_e64 %0, %0, %1, %3")
+        IOP(50, "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        IOP(51, "v_mad_u32_u24 %0, %0, %1, %2")
+        IOP(52, "v_and_b32_e32 %0, %0, %1")
+        IOP(53, "v_bfe_u32 %0, %0, 8, 8")
+        IOP(54, "v_perm_b32 %0, %0, %1, %2")
+        IOP(55, "v_dot4_u32_u8 %0, %0, %1, %2")
+        IOP(56, "v_sad_u8 %0, %0, %1, %2")
+        IOP(57, "v_pk_mul_lo_u16 %0, %0, %1")
+        IOP(58, "v_pk_sub_i16 %0, %0, %1")
+        IOP(59, "v_mad_u32_u16 %0, %0, %1, %2")
+        IOP(60, "v_cvt_f32_ubyte1 %0, %0")
+        IOP(61, "v_cvt_u32_f32_e32 %0, %0")
+        IOP(62, "v_lshrrev_b32_e32 %0, 8, %0")
+        IOP(63, "v_lshlrev_b32_e32 %0, 6, %0")
+        IOP(64, "v_or_b32_e32 %0, %0, %1")
+        IOP(65, "v_sub_f32_e32 %0, %0, %1")
+        IOP(66, "v_fma_f32 %0, -%0, %1, %2")
+        IOP(67, "v_cvt_f32_u32_e32 %0, %0")
+        IOP(68, "v_sub_f32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD")
+        IOP(69, "v_min_u32_e32 %0, %0, %1")
+        IOP(70, "v_cvt_f32_ubyte0_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2")
+        IOP(71, "v_mul_u32_u24_e32 %0, %0, %1")
+        IOP(72, "v_mul_lo_u32 %0, %0, %1")
+        IOP(73, "v_max_f32_e32 %0, %0, %1")
+        IOP(74, "v_xor_b32_e32 %0, %0, %1")
+        IOP(75, "v_subrev_u32_e32 %0, %0, %1")
         if (OP == 24) { SELF FMSG(0) SELF FMSG(1) SELF FMSG(2) SELF FMSG(3) SELF FMSG(4) SELF FMSG(5) SELF FMSG(6) SELF FMSG(7) }   // 8 x (cmp, cselect, dependent fma)
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -206,6 +246,14 @@ int main(int argc, char **argv)
         case 28: sustain<28>("16 v_pk_fma_f32", 16, 0, wps, sec); break;
         case 29: sustain<29>("16 v_mul_f32", 16, 0, wps, sec); break;
         case 30: sustain<30>("16 v_add_f32", 16, 0, wps, sec); break;
+#define SUS(n, nm) case n: sustain<n>(nm, 16, 0, wps, sec); break;
+        SUS(40, "v_sub_u32") SUS(41, "v_sub_u32_sdwa bytes") SUS(42, "v_mad_i32_i24") SUS(43, "v_mul_i32_i24") SUS(44, "v_add_u32") SUS(45, "v_lshl_or_b32")
+        SUS(46, "v_max_u32") SUS(47, "v_max3_u32") SUS(48, "v_alignbyte_b32") SUS(49, "v_cndmask_b32_e64 sgpr mask") SUS(50, "v_max_u32_dpp row_shr")
+        SUS(51, "v_mad_u32_u24") SUS(52, "v_and_b32") SUS(53, "v_bfe_u32") SUS(54, "v_perm_b32") SUS(55, "v_dot4_u32_u8") SUS(56, "v_sad_u8")
+        SUS(57, "v_pk_mul_lo_u16") SUS(58, "v_pk_sub_i16") SUS(59, "v_mad_u32_u16")
+        SUS(60, "v_cvt_f32_ubyte1") SUS(61, "v_cvt_u32_f32") SUS(62, "v_lshrrev_b32") SUS(63, "v_lshlrev_b32") SUS(64, "v_or_b32") SUS(65, "v_sub_f32")
+        SUS(66, "v_fma_f32 neg") SUS(67, "v_cvt_f32_u32") SUS(68, "v_sub_f32_sdwa dword") SUS(69, "v_min_u32") SUS(70, "v_cvt_f32_ubyte0_sdwa") SUS(71, "v_mul_u32_u24")
+        SUS(72, "v_mul_lo_u32") SUS(73, "v_max_f32") SUS(74, "v_xor_b32") SUS(75, "v_subrev_u32")
         default: printf("no such op\n");
         }
         return 0;
