@@ -745,6 +745,15 @@ def bench_surf(args):
     return out
 
 
+def static_mix_rate_weighted():
+    """SIMD cycles of one pipeline stage (one pixel row of one wave) of the T = 10 kernel at the measured per-operation issue rates."""
+    try:
+        jw = tbr_jw()
+        return float(json.load(open(os.path.join(ROOT, "profiles", "static_mix_tbr.json" if jw >= 2 else "static_mix_tbr_jw0.json")))["rate_weighted_per_stage"]["cycles"])
+    except Exception:
+        return 145.84
+
+
 def static_mix():
     """Per pipeline stage and pixel row of the T = 10 kernel that runs (tools/static_mix.py): profiles/static_mix_tbr.json = the default
     k_iterate_tbr<10, 1, ., 4, 2, 0, 2> (joined waves, barrier form), profiles/static_mix_tbr_jw0.json = the independent-wave form."""
@@ -1000,6 +1009,14 @@ def main():
                 "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it,
                 "iterations_per_launch_mean": mean_it * warps * len(its) * n_lanes_run / max(n_it, 1),
                 "traffic": traffic, "hbm": hbm_it,
+                # against the MEASURED issue rates (round 4, profiles/valu_rates_gfx950.json): only fma / mul / add / sub and a few integer
+                # operations issue in 2.4 cycles, DPP / selects / med3 take 4.2, v_rcp / v_sqrt 8.2: a stage costs 145.8 SIMD cycles, not the
+                # 115 of the spec-rate slot count.  wave_stages_per_s = executed (halo lanes included) rows x stages of 64 lanes.
+                "rate_weighted": {"cycles_per_wave_stage": static_mix_rate_weighted(),
+                                  "peak_wave_stages_per_s_at_2.4GHz": 1024 * 2.4e9 / static_mix_rate_weighted(),
+                                  "achieved_wave_stages_per_s": px_iter_timed / (ms_it * 1e-3) * lanes_per_px / 64.0,
+                                  "frac_at_2.4GHz": px_iter_timed / (ms_it * 1e-3) * lanes_per_px / 64.0 / (1024 * 2.4e9 / static_mix_rate_weighted()),
+                                  "note": "the same achieved rate against the stage's cycles at measured rates; the power leg's clock (power.sclk_MHz) scales the peak further"},
                 "note": "HIP events on the launch streams around each warp's iteration launch; with lanes = 2 the other half batch's "
                         "kernels share the GPU during these intervals (the rocprofv3 kernel trace shows the same durations)"}
     else:
@@ -1112,6 +1129,8 @@ def main():
             pw["valu_peak_at_measured_clock_T_lane_instr_per_s"] = VALU_PEAK_TLIPS * f_ghz / 2.4
             if isinstance(roof.get("frac"), float) and roof.get("bound") == "valu_issue":
                 pw["roofline_frac_at_measured_clock"] = roof["achieved"] / (VALU_PEAK_TLIPS * f_ghz / 2.4)
+                if "rate_weighted" in roof:
+                    pw["rate_weighted_frac_at_measured_clock"] = roof["rate_weighted"]["frac_at_2.4GHz"] * 2.4 / f_ghz
             pw["joules_per_pair"] = pw["socket_power_W"] / pw["rate_during_leg"]
         out["power"] = pw
     # whole-job HBM traffic: measured bytes per launch of the two dominant kernels (separate --pmc passes, profiles/pmc_traffic.json) x the

@@ -58,7 +58,11 @@ def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0):
             else:
                 cls["other"] += n
         stages = (T + 1 + PF) * T * PPL   # the loop body is unrolled P = T + 1 + PF steps of T stages
-        return {"kernel": pat, "loop_instructions": sum(cnt.values()), "per_stage_and_pixel": {k: round(v / stages, 3) for k, v in cls.items()}}
+        rw = rate_weighted_cycles(cnt)
+        return {"kernel": pat, "loop_instructions": sum(cnt.values()), "per_stage_and_pixel": {k: round(v / stages, 3) for k, v in cls.items()},
+                # SIMD cycles of a stage (one pixel row of one wave) at the MEASURED per-operation issue rates (profiles/valu_rates_gfx950.json)
+                "rate_weighted_per_stage": {"full_rate": round(rw["full_rate"] / stages, 3), "half_rate": round(rw["half_rate"] / stages, 3),
+                                            "transcendental": round(rw["transcendental"] / stages, 3), "cycles": round(rw["cycles"] / stages, 2)}}
     raise SystemExit("instantiation not found: " + pat)
 
 
