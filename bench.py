@@ -1217,7 +1217,10 @@ def main():
                     "frac": var["iterations10_eps0_one_lane"]["iterate_valu_issue_frac"],
                     "avg_launch_us": var["iterations10_eps0_one_lane"]["iterate_avg_launch_us"],
                     "pixel_iterations_per_s": var["iterations10_eps0_one_lane"]["iterate_pixel_iterations_per_s"],
-                    "sq_counters": "profiles/r02p/pmc_sq_summary.md (VALU active 0.46, issue-stalled 0.30, parked on waitcnt 0.07 of the wave cycles)"}
+                    "rate_weighted_frac_at_2.4GHz": var["iterations10_eps0_one_lane"]["iterate_pixel_iterations_per_s"] * lanes_per_px / 64.0 /
+                                                    (1024 * 2.4e9 / static_mix_rate_weighted()),
+                    "sq_counters": "profiles/r02p/pmc_sq_summary.md (VALU active 0.46, issue-stalled 0.30, parked on waitcnt 0.07 of the wave cycles)",
+                    "note": "one lane draws ~1 250 W at ~2.26 GHz (profiles/r08/poll_bench_one_lane.txt): divide the fractions by 0.94 for the measured clock"}
         except Exception as e:
             var["iterations10_eps0_one_lane"] = {"error": repr(e)[:200]}
         # other batch sizes of the same call (16 / 32 = the steps of the earlier records; 64 = the per-GPU share of BASELINE configs[4])
