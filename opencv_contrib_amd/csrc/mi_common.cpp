@@ -28,6 +28,8 @@ const Tuning &tuning()
         t.tb_swz = env_int("MIFLOW_TB_SWZ", 1);
         // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip): 2 (default since r03w) = hand-over with one
         // workgroup barrier per stage, 1 = with tags and bounded waits, 0 = independent 64-column waves; all three bit-identical
+        t.tb_nograd = env_int("MIFLOW_TB_NOGRAD", 1);
+        t.tb_skip_p = env_int("MIFLOW_TB_SKIP_P", 1);
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);
         if (t.tb_jw < 0 || t.tb_jw > 4) t.tb_jw = 2;   // 3: eight joined waves (experiment); 4: barrier form, branch-free publishes, mask-free interior blocks
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,

@@ -549,11 +549,27 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 rc = next_event(&w0); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[w0], st));
             }
+            // Round 4 byte cuts of the fixed-work blocked path: (1) where every pass of this warp is the default T = 10 kernel, the
+            // warp does not store |grad|^2 and the pass forms it from I1wx, I1wy (8 B/px per warp less through HBM, the same bits);
+            // (2) the last pass of a scale does not store p (the next scale starts from p = 0; 16 B/px per scale).
+            const bool blocked_w = !check && !P.exact_math && P.time_block != 1 && !gam;
+            std::vector<int> plan_w;
+            bool nograd = false;
+            if (blocked_w && !legacy_warp) {
+                const int mfw = P.median_filtering > 1 ? P.median_filtering : 0;
+                const int per = mfw ? P.inner_iterations : iters_per_warp;
+                plan_w.resize(per + 1);
+                plan_w.resize(tb_plan_level(g, per, P.time_block > 0 ? P.time_block : tb_max_block(), plan_w.data(), per));
+                nograd = !plan_w.empty();
+                for (int v : plan_w) nograd = nograd && tb_nograd_ok(v, g);
+            }
+            float *grad_w = nograd ? nullptr : grad;
+            pl.g = grad_w;
             if (tuning().x_skip == 1 && wp > 0) rc = MI_OK;   // timing experiment: what a step costs without the warps' work and bytes
             else if (legacy_warp)
                 rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             else
-                rc = warp_fused(sem, !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT)), -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
+                rc = warp_fused(sem, !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT)), -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad_w, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             if (rc) return rc;
             if (w0 >= 0) {
                 rc = next_event(&w1); if (rc) return rc;
@@ -581,7 +597,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     for (int k = 0; k < nb; ++k) {
                         ++nlaunch;
                         if (tuning().x_skip == 2) { first_of_scale = false; continue; }   // timing experiment: the warps alone
-                        rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st);
+                        const bool last_pass = tuning().tb_skip_p && wp == P.warps - 1 && no == nouter - 1 && k == nb - 1 && !mf;
+                        rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st, last_pass);
                         if (rc) return rc;
                         cur ^= 1;
                         first_of_scale = false;

@@ -88,8 +88,11 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 
 // Temporally blocked fast-math iteration (tvl1_tbr_kernels.hip): T fused iterations in one HBM pass,
 // set cur -> cur^1.  Supported T: 1,2,3,4,5,6,8,10.  rows_per_band <= 0: auto.
+// skip_p_out: the launch stores u only (the last pass of a scale: nobody reads its p).  pl.g == nullptr: no |grad|^2 plane, the kernel
+// forms it from I1wx, I1wy (only where tb_nograd_ok says so)
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
-               int cur, int rows_per_band, hipStream_t s);
+               int cur, int rows_per_band, hipStream_t s, bool skip_p_out = false);
+bool tb_nograd_ok(int T, const Geo &g);
 int tb_max_block();
 // Register-tile formulation of the same fused iterations for the small pyramid levels (tvl1_tile_kernels.hip): nit in
 // 1..tile_max_block() iterations per launch, bit-identical to iterate_tb.  variant < 0: default of the table.

@@ -45,6 +45,7 @@ struct TbArgs {
     int rows_per_band;
     int cur;  // input set
     int swz, nstrips;
+    int skip_p_out;   // MODE 0: the launch does not store p (last pass of a scale)
     CtlK ctl;   // speculative convergence path only (MODE 1): slot protocol of Ctl, e0 = first error-sum index of this launch's block
     int e0;
     SpecK sk;

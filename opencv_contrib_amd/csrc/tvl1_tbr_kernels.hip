@@ -179,7 +179,10 @@ __device__ __forceinline__ void str(float *rowp, unsigned xb, const float v[PPL]
     else *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int PPL, bool PZ>
+// NG (round 4): there is no |grad|^2 plane -- the warp did not store it and finish_static_ng forms it from the row's I1wx, I1wy when the
+// row is consumed, with the warp's own expression (two separately rounded products and their sum: the same bits).  8 B per pixel and
+// warp less through HBM; the step is power-limited and a byte costs ~13 f32 operations (profiles/r08/README.md).
+template <int PPL, bool PZ, bool NG = false>
 __device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const float *const u[2], const float *const p[4], int row,
                                            int H, unsigned xc)
 {
@@ -187,7 +190,7 @@ __device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const 
     asm volatile("" : "+v"(xc));
     ldr<PPL>(x.s.ix, A.pl.ix + ro, xc);
     ldr<PPL>(x.s.iy, A.pl.iy + ro, xc);
-    ldr<PPL>(x.s.rg, A.pl.g + ro, xc);   // RAW |grad|^2 until the row is consumed (finish_static)
+    if (!NG) ldr<PPL>(x.s.rg, A.pl.g + ro, xc);   // RAW |grad|^2 until the row is consumed (finish_static)
     ldr<PPL>(x.s.rc, A.pl.rc + ro, xc);
     ldr<PPL>(x.d.u1, u[0] + ro, xc);
     ldr<PPL>(x.d.u2, u[1] + ro, xc);
@@ -310,7 +313,7 @@ __device__ int g_jw_fault;   // sticky: a bounded wait on a neighbouring wave ra
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, int k>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, int k>
 __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T], Xchg &x)
 {
     constexpr bool JF = jw_fast(JW);
@@ -318,6 +321,10 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     constexpr int K = T > 2 ? T - 1 : 1;
     const int n = n0 + k;
     const int r0 = c.ystart + n;
+    if (NG) {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { const float ix2 = X[k].s.ix[j] * X[k].s.ix[j], iy2 = X[k].s.iy[j] * X[k].s.iy[j]; X[k].s.rg[j] = ix2 + iy2; }
+    }
     if (MODE != 2) finish_static<PPL>(X[k].s);
     unsigned xexpect = 0, vtag_r = 0, vtag_l = 0;
     if (JW >= 2) {
@@ -335,7 +342,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         xexpect = ((unsigned)(n + 1) & 0xffffu) * x.mul;
     }
 #ifndef TBR_X_NOLOAD   // timing experiments only (wrong results): no row loads after the prologue
-    load_row_r<PPL, PZ>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
+    load_row_r<PPL, PZ, NG>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
 #else
     X[(k + PF) % P] = X[k];
 #endif
@@ -463,19 +470,21 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             asm volatile("" : "+v"(xb));
             str<PPL>(c.uout[0] + ro, xb, r.u1);
             str<PPL>(c.uout[1] + ro, xb, r.u2);
-            str<PPL>(c.pout[0] + ro, xb, r.p11);
-            str<PPL>(c.pout[1] + ro, xb, r.p12);
-            str<PPL>(c.pout[2] + ro, xb, r.p21);
-            str<PPL>(c.pout[3] + ro, xb, r.p22);
+            if (!c.B.skip_p_out) {   // the last pass of a scale: nobody reads its p (the next scale starts from p = 0)
+                str<PPL>(c.pout[0] + ro, xb, r.p11);
+                str<PPL>(c.pout[1] + ro, xb, r.p12);
+                str<PPL>(c.pout[2] + ro, xb, r.p21);
+                str<PPL>(c.pout[3] + ro, xb, r.p22);
+            }
         }
     }
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, int... Ks>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, int... Ks>
 __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
                                         Xchg &x, std::integer_sequence<int, Ks...>)
 {
-    (step_r<T, PPL, PZ, PF, MODE, JW, MK, Ks>(c, X, n0, slot0, acc, x), ...);
+    (step_r<T, PPL, PZ, PF, MODE, JW, MK, NG, Ks>(c, X, n0, slot0, acc, x), ...);
 }
 
 // MODE 0: T iterations, fixed work.
@@ -494,7 +503,7 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 //   edges (236 of 256 lanes own a column instead of 44 of 64: 33 instead of 44 waves per 1080p row band).  At the three inner
 //   seams the neighbouring waves hand each other the two values a stage needs from across the seam through LDS (Xchg above).  The
 //   arithmetic of an owned pixel is the same operations on the same values as in the independent-wave form: bit-identical planes.
-template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0>
+template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0, bool NG = false>
 __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs A)
 {
     static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW >= 2 && JW != 4))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
 #pragma unroll
     for (int i = 0; i < 4; ++i) { c.pin[i] = A.pl.p[cur][i] + pb; c.pout[i] = A.pl.p[cur ^ 1][i] + pb; }
     c.B = A;
-    c.B.pl.ix += pb; c.B.pl.iy += pb; c.B.pl.g += pb; c.B.pl.rc += pb;
+    c.B.pl.ix += pb; c.B.pl.iy += pb; if (!NG) c.B.pl.g += pb; c.B.pl.rc += pb;
     c.l_t = A.l_t; c.theta = A.theta; c.taut = A.taut;
 
     Slot<PPL> X[P];
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
     c.ystart = c.y0 - T;
     c.nsteps = (c.y1 - c.y0) + 2 * T;
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
+    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ, NG>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
     int slot0 = 0;   // ring slot of the row entering at this step (= step mod K)
     unsigned long long acc[T];
 #pragma unroll
@@ -626,9 +635,9 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
             // the workgroup: they share the band)
             const int ra = c.ystart + n0 - (T - 1), rb = c.ystart + n0 + P - 1;
             const bool plain = (ra > 0 || rb < 0) && (ra > c.H || rb < c.H);
-            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
+            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false, NG>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
         }
-        steps_r<T, PPL, PZ, PF, MODE, JW, true>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+        steps_r<T, PPL, PZ, PF, MODE, JW, true, NG>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
     }
     if (JW >= 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
         for (int i = wave; i < NW - 1; ++i) xbarrier();
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
     }
 }
 
-template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0>
+template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0, bool NG = false>
 static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
@@ -661,23 +670,23 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
                                  (JW >= 2 ? NW * xarea2_bytes(T) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         return e;
     }();
     MI_HIP_TRY(attr_rc);
     if (tuning().tb_verbose) {
         static const int nb = [] {
             int n = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>, 64 * NW, lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG>, 64 * NW, lds_bytes);
             fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d jw=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, JW, lds_bytes, n);
             return n;
         }();
         (void)nb;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW>), grid, dim3(64 * NW), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW>), grid, dim3(64 * NW), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG>), grid, dim3(64 * NW), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG>), grid, dim3(64 * NW), lds_bytes, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -700,6 +709,8 @@ static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 
                                      // barrier form without exec-masked publishes and without border masks in interior blocks, hand-over
                                      // values read a stage early (MIFLOW_TB_JW=4)
                                      {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 4>, nullptr, 4}};
+// the default kernel without a |grad|^2 plane (tb_nograd_entry)
+static const TbrEntry g_tbr_ng = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true>, nullptr, 2};
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
@@ -839,15 +850,31 @@ int tb_query_plan(int T, const Geo &g, int *kernel, int *rows)
 }
 
 // T fused iterations, set cur -> cur^1.  Returns MI_ERR_BAD_ARG for unsupported T.
-int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
-               int cur, int rows_per_band, hipStream_t s)
+// The launch iterate_tb(T) would make can run without a |grad|^2 plane (pl.g == nullptr): the default joined-wave T = 10 kernel on a
+// level that does not take the register-tile kernel.  The caller (lane_calc) asks BEFORE the warp, which then does not store the plane.
+bool tb_nograd_ok(int T, const Geo &g)
 {
-    if (rows_per_band == 0 && tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force)
+    if (!tuning().tb_nograd || T != 10 || tuning().tb_jw != 2 || tuning().tb_ppl >= 0) return false;
+    if (tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force) return false;
+    return true;
+}
+
+int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
+               int cur, int rows_per_band, hipStream_t s, bool skip_p_out)
+{
+    if (rows_per_band == 0 && tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force) {
+        MI_REQUIRE(pl.g, MI_ERR_BAD_ARG, "the register-tile kernel needs the |grad|^2 plane");
         return iterate_tile(-1, T, pl, g, l_t, theta, taut, p_zero, cur, s);
+    }
     const TbrEntry *e = tbr_pick(T);
     if (!e) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
+    if (!pl.g) {
+        MI_REQUIRE(tb_nograd_ok(T, g), MI_ERR_BAD_ARG, "no |grad|^2 plane, but the kernel of this launch needs one");
+        e = &g_tbr_ng;
+    }
     TbArgs A;
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.swz = 0; A.nstrips = 0;
+    A.skip_p_out = skip_p_out ? 1 : 0;
     A.rows_per_band = rows_per_band > 0 ? rows_per_band : plan_band_rows(*e, g);
     if (tuning().tb_verbose) {
         static int shown = 0;
@@ -904,7 +931,7 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
     else { for (const TbrEntry &c : g_spec) if (c.T == T) e = &c; }
     if (!e) { set_error("no speculative kernel for time block %d", T); return MI_ERR_BAD_ARG; }
     TbArgs A;
-    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.swz = 0; A.nstrips = 0;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.swz = 0; A.nstrips = 0; A.skip_p_out = 0;
     A.rows_per_band = plan_band_rows(*e, g);
     A.ctl = make_ctlk(&ctl);
     A.e0 = e0;

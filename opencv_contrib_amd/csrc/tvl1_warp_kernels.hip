@@ -268,7 +268,7 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
     A.I1wy[o] = v2;
     // calcGradRho  optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163
     const float Ix2 = v1 * v1, Iy2 = v2 * v2;
-    A.grad[o] = Ix2 + Iy2;
+    if (A.grad) A.grad[o] = Ix2 + Iy2;   // null: the consumer (k_iterate_tbr NG) forms |grad|^2 from the two planes above itself
     A.rho[o] = (v0 - v1 * u1v - v2 * u2v - i0);
 }
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_warp_lds(Warp6Args A, CtlK ctl, int cur
         if (A.I1w) A.I1w[o] = v0;
         A.I1wx[o] = v1;
         A.I1wy[o] = v2;
-        A.grad[o] = v1 * v1 + v2 * v2;
+        if (A.grad) A.grad[o] = v1 * v1 + v2 * v2;
         A.rho[o] = (v0 - v1 * u1v[k] - v2 * u2v[k] - i0[k]);
     }
 }
