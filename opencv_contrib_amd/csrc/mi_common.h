@@ -38,6 +38,7 @@ struct Tuning {
     int warp_fast;           // MIFLOW_WARP_FAST: fast-math calcs form the warp's bicubic sums separably (1: +4.7 % pairs/s, 2-3 x the EPE against the oracle) or tap by tap in the reference's order (0); -1 (default): separably under MI_SEM_CUDA_COMPAT, whose map is not quantised (EPE 1.2e-5 either way), tap by tap under MI_SEM_CPU_REF
     int warp_np;             // MIFLOW_WARP_NP: patches a wave of the fused-gradient warp kernel walks (1 | 2 | 4)
     int tb_swz;             // MIFLOW_TB_SWZ: XCD-aware workgroup remap of the blocked iteration kernels
+    int warp_zoom;          // MIFLOW_WARP_ZOOM: the first warp of a scale zooms the coarser flow itself instead of a resize launch (1; default 0: measured slower)
     int tb_nograd;          // MIFLOW_TB_NOGRAD: the blocked pass forms |grad|^2 itself and the warp does not store the plane (1, default) / stored plane (0)
     int tb_skip_p;          // MIFLOW_TB_SKIP_P: the last pass of a scale does not store p (1, default)
     int tb_jw;              // MIFLOW_TB_JW: joined-wave form of the T = 10 blocked iteration kernel

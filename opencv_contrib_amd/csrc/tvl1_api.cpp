@@ -518,6 +518,10 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     ctl.S = ln.S; ctl.E = ln.E; ctl.Q = (int)ln.Q;
     ctl.P = ln.Pd; ctl.sched = (P.semantics == MI_SEM_CUDA_COMPAT) ? 1 : 0;   // cv::cuda's check schedule vs the CPU class's every-iteration check
 
+    WarpZoom zoom;
+    memset(&zoom, 0, sizeof(zoom));
+    bool have_zoom = false;
+    const bool zoom_path = !check && !P.exact_math && P.time_block != 1 && P.gamma == 0.0 && !legacy_warp && warp_zoom_ok() && tuning().x_skip == 0;
     for (int s = ns - 1; s >= 0; --s) {
         LevelBuf &Lv = ln.L[s];
         Geo g = Lv.g;
@@ -569,7 +573,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             else if (legacy_warp)
                 rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             else
-                rc = warp_fused(sem, !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT)), -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad_w, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
+                rc = warp_fused(sem, !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT)), -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad_w, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st,
+                                (wp == 0 && have_zoom) ? &zoom : nullptr);
             if (rc) return rc;
             if (w0 >= 0) {
                 rc = next_event(&w1); if (rc) return rc;
@@ -726,6 +731,18 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
         }
         // zoom the flow to the next finer scale and rescale it (tvl1flow.cpp:291-300)
         const Geo &gf = ln.L[s - 1].g;
+        have_zoom = false;
+        if (zoom_path && !dev_cur) {
+            // fixed-work blocked path: the finer scale's FIRST WARP samples this scale's flow itself (k_warp6 UP) -- no resize launch,
+            // no 8 B/px round trip of the zoomed flow
+            zoom.u1c = Lv.u[cur][0]; zoom.u2c = Lv.u[cur][1];
+            zoom.u1o = ln.L[s - 1].u[0][0]; zoom.u2o = ln.L[s - 1].u[0][1];
+            zoom.gc = g;
+            zoom.inv_scale_x = (double)gf.w / g.w; zoom.inv_scale_y = (double)gf.h / g.h;
+            zoom.post = (float)(1.0 / P.scale_step);
+            have_zoom = true;
+            continue;
+        }
         // u3 is zoomed too but NOT rescaled (tvl1flow.cpp:293-300; optflow tvl1flow.cpp:524-528)
         const float *us[3][2] = {{Lv.u[0][0], Lv.u[1][0]}, {Lv.u[0][1], Lv.u[1][1]}, {gam ? Lv.u[0][2] : nullptr, gam ? Lv.u[1][2] : nullptr}};
         float *ud[3] = {ln.L[s - 1].u[0][0], ln.L[s - 1].u[0][1], gam ? ln.L[s - 1].u[0][2] : nullptr};

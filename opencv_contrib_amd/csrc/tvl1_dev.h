@@ -78,9 +78,12 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
 // plane, half the gathered bytes, bit-identical results
 // fast: the three bicubic sums in separable form (rounding differs from the reference's tap-by-tap order; fast-math paths only)
 // lds: windows read from an LDS-staged region of I1 (1) or gathered from global memory (0); -1 = the tuning default
+// zoom: the first warp of a scale samples the coarser scale's flow itself (k_resize's arithmetic), writes it to (u1o, u2o) and uses it
+struct WarpZoom { const float *u1c, *u2c; float *u1o, *u2o; Geo gc; double inv_scale_x, inv_scale_y; float post; };
+bool warp_zoom_ok();
 int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
                float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
-               hipStream_t s);
+               hipStream_t s, const WarpZoom *zoom = nullptr);
 // one fused iteration (estimateU + estimateDualVariables), set cur -> set cur^1.
 // p_zero: p_in is known to be all-zero (first iteration of a scale) and is not read.
 int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut,

@@ -32,12 +32,24 @@ __device__ __forceinline__ int resolve_cur_k(const CtlK &c, int b, int cur_host)
     return s.x ^ (s.y & 1);
 }
 
+// The first warp of a scale may ZOOM the coarser scale's flow itself (round 4): its pixel's flow is sampled from the coarse planes with
+// k_resize's arithmetic (resize_dev.h), multiplied by 1 / scaleStep (tvl1flow.cpp:291-300), stored into the scale's own u planes (the
+// iteration pass reads them) and used at once -- the separate resize launch and its 8 B/px write + 8 B/px re-read are gone.
+struct WarpUp {
+    const float *u1c, *u2c;   // coarse planes (null: no zoom, the warp reads u1 / u2 of the scale)
+    float *u1o, *u2o;         // the scale's flow planes (set 0) the zoomed flow is written to
+    int cw, ch, cld;          // coarse geometry
+    long long cps;            // pair stride of the coarse planes
+    double scx, scy;          // scale factors as tvl1::resize forms them for the semantics
+    float post;
+};
 struct Warp6Args {
     const float *I0, *I1;
     const float *u1[2], *u2[2];
     float *I1w, *I1wx, *I1wy, *grad, *rho;
     const float *tab;  // 32x4 cubic phase table (CPU_REF)
     Geo g;
+    WarpUp up;
 };
 
 // pixels of a wave along x in the warp kernels (a 32 x 2 patch per wave measured best, profiles/r01u)

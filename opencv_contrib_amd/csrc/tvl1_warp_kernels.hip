@@ -17,6 +17,7 @@
 // texture, cudev/ptr2d/texture.hpp:228-232).
 #include "tvl1_dev.h"
 #include "tvl1_warp_dev.h"
+#include "resize_dev.h"
 
 namespace mi {
 namespace tvl1 {
@@ -275,7 +276,7 @@ __device__ __forceinline__ void warp_px(const Warp6Args &A, const float *s_tab, 
 // A wave owns NP consecutive TX x TY patches of a row band.  The flow and I0 of patch i + 1 are requested BEFORE the window
 // gathers of patch i are issued, so the two dependent memory phases of a pixel (flow -> addresses -> window) overlap across
 // patches: with one patch per wave the kernel ran at the latency bound of 2 phases x 2048 pixels in flight per CU (r02b).
-template <int SEM, int TX, int NP, bool FAST>
+template <int SEM, int TX, int NP, bool FAST, bool UP = false>
 __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_host)
 {
     __shared__ float s_tab[128];
@@ -295,7 +296,24 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
     const long long orow = pb + (long long)y * ld;
     const float *U1 = A.u1[cur] + orow, *U2 = A.u2[cur] + orow, *I0r = A.I0 + orow;
     const float *P = A.I1 + pb;
-    float u1n = U1[x0], u2n = U2[x0], i0n = I0r[x0];
+    // UP: the flow of pixel (xx, y) = the coarser scale's flow zoomed with k_resize's arithmetic x post (the same bits as the plane a
+    // resize launch would have written); it is stored for the iteration pass
+    const float *C1 = nullptr, *C2 = nullptr;
+    RszX Y;
+    if (UP) {
+        C1 = A.up.u1c + (long long)b * A.up.cps; C2 = A.up.u2c + (long long)b * A.up.cps;
+        Y = resize_yside<SEM>(y, A.up.ch, A.up.scy);
+    }
+    const auto flow_at = [&](int xx, float &a, float &c) {
+        if (!UP) { a = U1[xx]; c = U2[xx]; return; }
+        const RszX X = resize_xside<SEM>(xx, A.up.cw, A.up.scx);
+        a = resize_combine<SEM>(C1 + (long long)Y.i0 * A.up.cld, C1 + (long long)Y.i1 * A.up.cld, X, Y);
+        c = resize_combine<SEM>(C2 + (long long)Y.i0 * A.up.cld, C2 + (long long)Y.i1 * A.up.cld, X, Y);
+        if (A.up.post != 1.0f) { a = a * A.up.post; c = c * A.up.post; }
+        A.up.u1o[orow + xx] = a; A.up.u2o[orow + xx] = c;
+    };
+    float u1n, u2n, i0n = I0r[x0];
+    flow_at(x0, u1n, u2n);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int x = x0 + i * TX;
@@ -303,7 +321,8 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
         const float u1v = u1n, u2v = u2n, i0 = i0n;
         if (i + 1 < NP) {
             const int xn = min(x + TX, W - 1);   // clamped: the value of a patch past the right edge is never used
-            u1n = U1[xn]; u2n = U2[xn]; i0n = I0r[xn];
+            if (!UP || x + TX < W) flow_at(xn, u1n, u2n);
+            i0n = I0r[xn];
         }
         warp_px<SEM, FAST>(A, s_tab, P, x, y, orow + x, u1v, u2v, i0);
     }
@@ -409,11 +428,22 @@ __global__ __launch_bounds__(256) void k_warp_lds(Warp6Args A, CtlK ctl, int cur
     }
 }
 
+bool warp_zoom_ok() { return tuning().warp_zoom != 0 && tuning().warp_lds == 0 && warp_tile() == 32 && tuning().warp_np == 2; }
+
 int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
                float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
-               hipStream_t s)
+               hipStream_t s, const WarpZoom *zoom)
 {
     Warp6Args A;
+    memset(&A.up, 0, sizeof(A.up));
+    const bool up = zoom != nullptr;
+    if (up) {
+        MI_REQUIRE(warp_zoom_ok() && lds <= 0 && !ctl, MI_ERR_BAD_ARG, "the zooming warp needs the default patch shape and a host-known buffer set");
+        A.up.u1c = zoom->u1c; A.up.u2c = zoom->u2c; A.up.u1o = zoom->u1o; A.up.u2o = zoom->u2o;
+        A.up.cw = zoom->gc.w; A.up.ch = zoom->gc.h; A.up.cld = zoom->gc.ld; A.up.cps = zoom->gc.ps; A.up.post = zoom->post;
+        if (semantics == MI_SEM_CPU_REF) { A.up.scx = 1.0 / zoom->inv_scale_x; A.up.scy = 1.0 / zoom->inv_scale_y; }
+        else { A.up.scx = (double)(float)(1.0 / zoom->inv_scale_x); A.up.scy = (double)(float)(1.0 / zoom->inv_scale_y); }   // as tvl1::resize
+    }
     A.I0 = I0; A.I1 = I1;
     A.u1[0] = u1[0]; A.u1[1] = u1[1]; A.u2[0] = u2[0]; A.u2[1] = u2[1];
     A.I1w = I1w; A.I1wx = I1wx; A.I1wy = I1wy; A.grad = grad; A.rho = rho;
@@ -435,7 +465,10 @@ int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *
     const dim3 grid(div_up(g.w, tile * np), div_up(g.h, 4 * (64 / tile)), g.batch);
 #define LAUNCH_W6T(SEM, TX, NP)                                                                                          \
     do {                                                                                                                 \
-        if (fast) hipLaunchKernelGGL((k_warp6<SEM, TX, NP, true>), grid, dim3(256), 0, s, A, ck, cur_host);              \
+        if (up && TX == 32 && NP == 2) {   /* the zooming first warp of a scale: the default patch shape only */            \
+            if (fast) hipLaunchKernelGGL((k_warp6<SEM, 32, 2, true, true>), grid, dim3(256), 0, s, A, ck, cur_host);     \
+            else hipLaunchKernelGGL((k_warp6<SEM, 32, 2, false, true>), grid, dim3(256), 0, s, A, ck, cur_host);         \
+        } else if (fast) hipLaunchKernelGGL((k_warp6<SEM, TX, NP, true>), grid, dim3(256), 0, s, A, ck, cur_host);       \
         else hipLaunchKernelGGL((k_warp6<SEM, TX, NP, false>), grid, dim3(256), 0, s, A, ck, cur_host);                  \
     } while (0)
 #define LAUNCH_W6N(SEM, NP)                                                                                              \
