@@ -1381,6 +1381,19 @@ def main():
             del K0, K1, F4
         except Exception as e:
             var["tvl1_4k_3840x2160"] = {"error": repr(e)[:200]}
+        # opt-in storage of the dual variable as 16-bit fixed point between passes (MIFLOW_TB_P16=1; read once per process, hence the
+        # subprocess): changes results inside the stated tolerance (tools/p16_probe.py: mean EPE against the CPU-class oracle 1.6e-3 ->
+        # 3.2e-3 px at 1080p), NOT the default -- reported as the measure of what 16 B per pixel and pass boundary are worth
+        try:
+            import subprocess
+            env_ = dict(os.environ, MIFLOW_TB_P16="1")
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-variants", "--no-cpu", "--no-secondary", "--no-power", "--steps", str(max(4, hs)),
+                                 "--warmup", "2", "--batch", str(B)], capture_output=True, text=True, env=env_, timeout=300)
+            d_ = json.loads([l for l in r_.stdout.splitlines() if l.startswith("{")][-1])
+            var["p16_dual_storage_opt_in"] = {"pairs_per_s": d_["value"], "epe_vs_analytic_flow_px": d_.get("epe_vs_analytic_flow_px"),
+                                              "mean_epe_vs_cpu_oracle_px": "3.2e-3 (default path 1.6e-3; tools/p16_probe.py, tests/test_baseline_sizes.py)"}
+        except Exception as e:
+            var["p16_dual_storage_opt_in"] = {"error": repr(e)[:200]}
         out["variants"] = var
 
     if rank == 0 and world == 1 and not args.no_cpu:

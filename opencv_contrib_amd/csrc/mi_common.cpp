@@ -29,6 +29,7 @@ const Tuning &tuning()
         // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip): 2 (default since r03w) = hand-over with one
         // workgroup barrier per stage, 1 = with tags and bounded waits, 0 = independent 64-column waves; all three bit-identical
         t.warp_zoom = env_int("MIFLOW_WARP_ZOOM", 0);   // r08k: bit-identical, 1 388 against 1 406 pairs/s: the per-pixel (double precision) coordinates of cv::resize cost more than the resize launch and its 8 B/px
+        t.tb_p16 = env_int("MIFLOW_TB_P16", 0);
         t.tb_nograd = env_int("MIFLOW_TB_NOGRAD", 1);
         t.tb_skip_p = env_int("MIFLOW_TB_SKIP_P", 1);
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);

@@ -182,7 +182,11 @@ __device__ __forceinline__ void str(float *rowp, unsigned xb, const float v[PPL]
 // NG (round 4): there is no |grad|^2 plane -- the warp did not store it and finish_static_ng forms it from the row's I1wx, I1wy when the
 // row is consumed, with the warp's own expression (two separately rounded products and their sum: the same bits).  8 B per pixel and
 // warp less through HBM; the step is power-limited and a byte costs ~13 f32 operations (profiles/r08/README.md).
-template <int PPL, bool PZ, bool NG = false>
+// P16 (opt-in, MIFLOW_TB_P16=1; CHANGES RESULTS): between the passes of a scale the dual variable travels as signed 16-bit fixed point
+// (|p| <= 1 by construction of the dual update; v_cvt_pknorm_i16_f32, step 2^-15 ~ 3e-5): {p11, p12} in plane 0, {p21, p22} in plane
+// 2, 16 B per pixel and pass boundary less through HBM.  The raw dwords wait in the p11 / p21 registers of the set and are
+// unpacked when the row enters the pipeline (unpack_p16).
+template <int PPL, bool PZ, bool NG = false, bool P16 = false>
 __device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const float *const u[2], const float *const p[4], int row,
                                            int H, unsigned xc)
 {
@@ -194,7 +198,10 @@ __device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const 
     ldr<PPL>(x.s.rc, A.pl.rc + ro, xc);
     ldr<PPL>(x.d.u1, u[0] + ro, xc);
     ldr<PPL>(x.d.u2, u[1] + ro, xc);
-    if (!PZ) {
+    if (!PZ && P16) {
+        ldr<PPL>(x.d.p11, p[0] + ro, xc);
+        ldr<PPL>(x.d.p21, p[2] + ro, xc);
+    } else if (!PZ) {
         ldr<PPL>(x.d.p11, p[0] + ro, xc);
         ldr<PPL>(x.d.p12, p[1] + ro, xc);
         ldr<PPL>(x.d.p21, p[2] + ro, xc);
@@ -313,7 +320,7 @@ __device__ int g_jw_fault;   // sticky: a bounded wait on a neighbouring wave ra
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, int k>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int k>
 __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T], Xchg &x)
 {
     constexpr bool JF = jw_fast(JW);
@@ -321,6 +328,15 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     constexpr int K = T > 2 ? T - 1 : 1;
     const int n = n0 + k;
     const int r0 = c.ystart + n;
+    if (P16 && !PZ) {   // the entering row's p arrives packed: two snorm16 per dword
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int a = __float_as_int(X[k].d.p11[j]), b = __float_as_int(X[k].d.p21[j]);
+            const float sc = 1.0f / 32767.0f;
+            X[k].d.p11[j] = (float)(short)(a & 0xffff) * sc; X[k].d.p12[j] = (float)(a >> 16) * sc;
+            X[k].d.p21[j] = (float)(short)(b & 0xffff) * sc; X[k].d.p22[j] = (float)(b >> 16) * sc;
+        }
+    }
     if (NG) {
 #pragma unroll
         for (int j = 0; j < PPL; ++j) { const float ix2 = X[k].s.ix[j] * X[k].s.ix[j], iy2 = X[k].s.iy[j] * X[k].s.iy[j]; X[k].s.rg[j] = ix2 + iy2; }
@@ -342,7 +358,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         xexpect = ((unsigned)(n + 1) & 0xffffu) * x.mul;
     }
 #ifndef TBR_X_NOLOAD   // timing experiments only (wrong results): no row loads after the prologue
-    load_row_r<PPL, PZ, NG>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
+    load_row_r<PPL, PZ, NG, P16>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
 #else
     X[(k + PF) % P] = X[k];
 #endif
@@ -470,7 +486,18 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             asm volatile("" : "+v"(xb));
             str<PPL>(c.uout[0] + ro, xb, r.u1);
             str<PPL>(c.uout[1] + ro, xb, r.u2);
-            if (!c.B.skip_p_out) {   // the last pass of a scale: nobody reads its p (the next scale starts from p = 0)
+            if (P16 && !c.B.skip_p_out) {
+                float pa[PPL], pb2[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) {
+                    typedef short s2 __attribute__((ext_vector_type(2)));
+                    const s2 v1 = __builtin_amdgcn_cvt_pknorm_i16(r.p11[j], r.p12[j]), v2 = __builtin_amdgcn_cvt_pknorm_i16(r.p21[j], r.p22[j]);
+                    pa[j] = __int_as_float(((int)(unsigned short)v1.x) | ((int)v1.y << 16));
+                    pb2[j] = __int_as_float(((int)(unsigned short)v2.x) | ((int)v2.y << 16));
+                }
+                str<PPL>(c.pout[0] + ro, xb, pa);
+                str<PPL>(c.pout[2] + ro, xb, pb2);
+            } else if (!c.B.skip_p_out) {   // the last pass of a scale: nobody reads its p (the next scale starts from p = 0)
                 str<PPL>(c.pout[0] + ro, xb, r.p11);
                 str<PPL>(c.pout[1] + ro, xb, r.p12);
                 str<PPL>(c.pout[2] + ro, xb, r.p21);
@@ -480,11 +507,11 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     }
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, int... Ks>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int... Ks>
 __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
                                         Xchg &x, std::integer_sequence<int, Ks...>)
 {
-    (step_r<T, PPL, PZ, PF, MODE, JW, MK, NG, Ks>(c, X, n0, slot0, acc, x), ...);
+    (step_r<T, PPL, PZ, PF, MODE, JW, MK, NG, P16, Ks>(c, X, n0, slot0, acc, x), ...);
 }
 
 // MODE 0: T iterations, fixed work.
@@ -503,7 +530,7 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 //   edges (236 of 256 lanes own a column instead of 44 of 64: 33 instead of 44 waves per 1080p row band).  At the three inner
 //   seams the neighbouring waves hand each other the two values a stage needs from across the seam through LDS (Xchg above).  The
 //   arithmetic of an owned pixel is the same operations on the same values as in the independent-wave form: bit-identical planes.
-template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0, bool NG = false>
+template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false>
 __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs A)
 {
     static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW >= 2 && JW != 4))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
@@ -621,7 +648,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
     c.ystart = c.y0 - T;
     c.nsteps = (c.y1 - c.y0) + 2 * T;
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ, NG>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
+    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ, NG, P16>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
     int slot0 = 0;   // ring slot of the row entering at this step (= step mod K)
     unsigned long long acc[T];
 #pragma unroll
@@ -635,9 +662,9 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
             // the workgroup: they share the band)
             const int ra = c.ystart + n0 - (T - 1), rb = c.ystart + n0 + P - 1;
             const bool plain = (ra > 0 || rb < 0) && (ra > c.H || rb < c.H);
-            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false, NG>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
+            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false, NG, P16>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
         }
-        steps_r<T, PPL, PZ, PF, MODE, JW, true, NG>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+        steps_r<T, PPL, PZ, PF, MODE, JW, true, NG, P16>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
     }
     if (JW >= 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
         for (int i = wave; i < NW - 1; ++i) xbarrier();
@@ -654,7 +681,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
     }
 }
 
-template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0, bool NG = false>
+template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false>
 static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
@@ -670,23 +697,23 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
                                  (JW >= 2 ? NW * xarea2_bytes(T) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         return e;
     }();
     MI_HIP_TRY(attr_rc);
     if (tuning().tb_verbose) {
         static const int nb = [] {
             int n = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG>, 64 * NW, lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16>, 64 * NW, lds_bytes);
             fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d jw=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, JW, lds_bytes, n);
             return n;
         }();
         (void)nb;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG>), grid, dim3(64 * NW), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG>), grid, dim3(64 * NW), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16>), grid, dim3(64 * NW), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16>), grid, dim3(64 * NW), lds_bytes, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -711,6 +738,7 @@ static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 
                                      {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 4>, nullptr, 4}};
 // the default kernel without a |grad|^2 plane (tb_nograd_entry)
 static const TbrEntry g_tbr_ng = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true>, nullptr, 2};
+static const TbrEntry g_tbr_ng16 = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true, true>, nullptr, 2};   // + p as snorm16 between passes (opt-in)
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
@@ -870,7 +898,7 @@ int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta
     if (!e) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
     if (!pl.g) {
         MI_REQUIRE(tb_nograd_ok(T, g), MI_ERR_BAD_ARG, "no |grad|^2 plane, but the kernel of this launch needs one");
-        e = &g_tbr_ng;
+        e = tuning().tb_p16 ? &g_tbr_ng16 : &g_tbr_ng;
     }
     TbArgs A;
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.swz = 0; A.nstrips = 0;
