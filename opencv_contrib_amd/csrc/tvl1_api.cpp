@@ -567,6 +567,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 nograd = !plan_w.empty();
                 for (int v : plan_w) nograd = nograd && tb_nograd_ok(v, g);
             }
+            if (spec && !legacy_warp && !gam && P.median_filtering <= 1 && tb_spec_nograd_ok(g)) nograd = true;   // speculative steps: every block is a tbr launch
             float *grad_w = nograd ? nullptr : grad;
             pl.g = grad_w;
             if (tuning().x_skip == 1 && wp > 0) rc = MI_OK;   // timing experiment: what a step costs without the warps' work and bytes

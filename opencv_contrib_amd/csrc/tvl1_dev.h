@@ -96,6 +96,7 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s, bool skip_p_out = false);
 bool tb_nograd_ok(int T, const Geo &g);
+bool tb_spec_nograd_ok(const Geo &g);   // the same for the speculative steps of the convergence-checked path
 int tb_max_block();
 // Register-tile formulation of the same fused iterations for the small pyramid levels (tvl1_tile_kernels.hip): nit in
 // 1..tile_max_block() iterations per launch, bit-identical to iterate_tb.  variant < 0: default of the table.

@@ -753,6 +753,13 @@ static const TbrEntry g_tbr[] = {
 // lane's kernels fill the rest of the device (r02m at 1080p x 16, class defaults: 517 -> 545 pairs/s; fixed work loses 7 %).
 static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 2), TBRS(5, 1, 4, 2, 2)};
 static const TbrEntry g_spec_jw[] = {TBRSJ(10, 1, 3, 2, 2), TBRSJ(5, 1, 4, 2, 2)};   // MIFLOW_TB_JW >= 2 and MIFLOW_TB_JW_SPEC=1
+// ... and the same two without a |grad|^2 plane (round 4: the convergence-checked path re-reads the statics once per block)
+static const TbrEntry g_spec_jw_ng[] = {{10, 1, 3, 2, 2, nullptr, launch_tbr<10, 1, 3, 2, 1, 2, true>, 2}, {5, 1, 4, 2, 2, nullptr, launch_tbr<5, 1, 4, 2, 1, 2, true>, 2}};
+bool tb_spec_nograd_ok(const Geo &g)
+{
+    if (!tuning().tb_nograd || tuning().tb_jw < 2 || !tuning().tb_jw_spec) return false;
+    return !(tile_eligible(g) && tuning().tile_spec != 0);   // the register-tile kernel reads the stored plane
+}
 
 // Exact-math blocks (MODE 2; 1 px per lane).  The stage costs about four times the fast one (three IEEE divisions, two double
 // square roots), so short blocks already move the kernel from the HBM bound of the one-iteration kernel to the issue bound.
@@ -955,7 +962,10 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
     if (tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
         return iterate_tile_spec(T, pl, g, l_t, theta, taut, ctl, sk, e0, s);
     const TbrEntry *e = nullptr;
-    if (tuning().tb_jw >= 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }
+    if (!pl.g) {
+        MI_REQUIRE(tb_spec_nograd_ok(g), MI_ERR_BAD_ARG, "no |grad|^2 plane, but the speculative kernel of this launch needs one");
+        for (const TbrEntry &c : g_spec_jw_ng) if (c.T == T) e = &c;
+    } else if (tuning().tb_jw >= 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }
     else { for (const TbrEntry &c : g_spec) if (c.T == T) e = &c; }
     if (!e) { set_error("no speculative kernel for time block %d", T); return MI_ERR_BAD_ARG; }
     TbArgs A;
