@@ -400,7 +400,6 @@ def bench_stereobm(args):
                         "batched_frac": pxd * n / elb * vpd * halo_b / 1e12 / VALU_PEAK_TLIPS,
                         "valu_per_pixel_disparity": vpd, "executed_per_useful_row_work": {"sequential": halo_seq, "batched": halo_b},
                         "useful_frac_batched": pxd * n / elb * vpd / 1e12 / VALU_PEAK_TLIPS,
-                        "batched_frac_of_measured_plain_valu_peak": pxd * n / elb * vpd * halo_b / 1e12 / (VALU_PEAK_TLIPS * 2.0 / 3.1),
                         "hbm_algorithmic_GBps": algo_bytes * n / el / 1e9, "hbm_frac": algo_bytes * n / el / 1e9 / HBM_PEAK_GBS,
                         "traffic": pmc_traffic("stereobm")[0], "traffic_kernel": "k_block_match, bytes per launch (one pair)",
                         "traffic_source": pmc_traffic("stereobm")[1]}}
@@ -666,6 +665,18 @@ def bench_surf(args):
                                 "k_nms_flag 91 -> 54 us per octave launch).  Not HBM-bound (SURVEY 8d config 4): the integral table "
                                 "(33 MB) is L2 / MALL resident; what is left is the f64 arithmetic of the box sums and the dependent gathers; the fused "
                                 "all-octave path needs six launches per frame"}}
+    # Binding roofline of the detector and the descriptor kernels, MEASURED (round 4): tag lookups of the per-CU vector
+    # L1 (TCP_TOTAL_CACHE_ACCESSES, rocprofv3 --pmc, profiles/surf_counters.json) over the kernels' launch durations against one lookup
+    # per clock and CU.  k_det_trace_all runs at 0.73 of that rate, k_descriptors at 0.84, the LDS-staged large-feature kernel at 0.46
+    # (a quarter of its time the L1 is stalled on pending misses): the gathers, not HBM and not VALU, are what these kernels are made of.
+    try:
+        sc = json.load(open(os.path.join(ROOT, "profiles", "surf_counters.json")))
+        out["roofline"]["l1_tag_lookups"] = {"bound": "l1_tag_lookups", "peak_per_s": sc["peak_l1_tag_lookups_per_s"], "source": sc["source"],
+                                            "kernels": {k: {"frac": v["frac_of_l1_tag_peak"], "lookups_per_launch": v["tcp_total_cache_accesses"], "avg_launch_us": v["avg_us"],
+                                                            "lines_per_wave_load": v["lines_per_wave_load"], "l1_hit_rate": v["l1_hit_rate"]} for k, v in sc["kernels"].items()}}
+        out["roofline"]["binding"] = {"kernel": "k_det_trace_all", "bound": "l1_tag_lookups", "frac": sc["kernels"]["k_det_trace_all"]["frac_of_l1_tag_peak"]}
+    except Exception as e:
+        out["roofline"]["l1_tag_lookups"] = {"error": repr(e)[:200]}
     # the descriptor half of a frame (k_orientation + k_descriptors / k_descriptors_staged on the keypoints just found): its bound is the
     # gather, not HBM and not VALU (r03l: halving the per-texel arithmetic changed nothing).  A patch sample of a feature of scale s reads
     # ~s x s texels of the ROTATED window.  Small features (s < 5): the 64 lanes of a wave sit in 64 different cells of the 21 x 21 patch, so
@@ -689,7 +700,10 @@ def bench_surf(args):
         torch.cuda.synchronize()
         el_desc = (time.perf_counter() - t0) / (args.steps * n)
         peak_lines = 256 * 2.4e9
-        out["descriptor_roofline"] = {"bound": "l1_gather_lines", "modelled": True, "kernel": "k_descriptors / k_descriptors_staged (+ k_orientation, integral): orientation and 64-d "
+        out["descriptor_roofline"] = {"bound": "l1_gather_lines", "modelled": True,
+                                      "measured": "roofline.l1_tag_lookups: k_descriptors 0.84, k_descriptors_staged 0.46 of the L1 tag-lookup rate; the model below "
+                                                  "under-counts the staged kernel's lookups (42 measured per wave load against 14 modelled)",
+                                      "kernel": "k_descriptors / k_descriptors_staged (+ k_orientation, integral): orientation and 64-d "
                                       "descriptors of the frame's keypoints (useProvidedKeypoints)",
                                       "achieved": lines / el_desc / 1e9, "peak": peak_lines / 1e9, "unit": "G lines/s",
                                       "frac": lines / el_desc / peak_lines, "texel_reads_per_frame": texels, "modelled_lines_per_frame": lines,
@@ -1001,9 +1015,11 @@ def main():
                 ("four joined waves per 256-column strip, seam values handed over through LDS)" if jw else "independent 64-column waves)"),
                 "achieved": ach, "peak": VALU_PEAK_TLIPS, "unit": "T lane-instr/s", "frac": ach / VALU_PEAK_TLIPS,
                 "pixel_iterations_per_s": px_iter_timed / (ms_it * 1e-3),
-                # what a plain f32 VALU stream actually issues on this chip: 3.1 SIMD cycles per wave-instruction at 4 waves/SIMD
+                # what a plain f32 VALU stream issues on this chip with its clock MEASURED (round 4, s_memtime / s_memrealtime, tools/ubench/
+                # issue_mix.hip): 2.4 SIMD cycles per wave-instruction at 8 waves / SIMD and 2.33 GHz; the 3.1 "cycles" of the earlier rounds
+                # were wall time x a nominal 2.4 GHz
                 # (tools/ubench/valu_rates.hip, profiles/r01p/valu_rates.txt) against the 2 of the 157.3 TF figure
-                "peak_measured_plain_valu": VALU_PEAK_TLIPS * 2.0 / 3.1, "frac_of_measured_peak": ach / (VALU_PEAK_TLIPS * 2.0 / 3.1),
+                "peak_measured_plain_valu": 63.2, "frac_of_measured_peak": ach / 63.2,
                 "issue_slots_per_pixel_iteration": slots, "lanes_executed_per_owned_pixel": lanes_per_px,
                 "band_halo_rows_not_counted": True,
                 "avg_launch_us": 1e3 * ms_it / max(n_it, 1), "launches_timed": n_it,
@@ -1087,7 +1103,7 @@ def main():
             "executed_T_lane_instr_per_s": (it_exec + wp) / step_s / 1e12, "useful_T_lane_instr_per_s": (it_useful + wp) / step_s / 1e12,
             "peak": VALU_PEAK_TLIPS, "frac_executed": (it_exec + wp) / step_s / 1e12 / VALU_PEAK_TLIPS,
             "frac_useful": (it_useful + wp) / step_s / 1e12 / VALU_PEAK_TLIPS,
-            "frac_executed_of_measured_plain_valu_peak": (it_exec + wp) / step_s / 1e12 / (VALU_PEAK_TLIPS * 2.0 / 3.1),
+            "frac_executed_of_measured_plain_valu_peak": (it_exec + wp) / step_s / 1e12 / 63.2,   # 63.2 T lane-instr/s: a pure v_fma stream, clock measured
             "band_rows_finest_level": band_rows(W, H), "warp_valu_per_pixel": WARP_VALU_PER_PX,
             "note": "iteration kernel (static mix x pixel-iterations x halo factors) + warp kernel (static count x pixels) over the wall "
                     "time of a step; resize / convert / pack (4 % of the kernel time) not counted"}
