@@ -32,7 +32,7 @@ def test_tvl1_static_mix_of_record_matches_the_source():
 def test_stereobm_static_mix_of_record_matches_the_source():
     import static_mix
     rec = _load("static_mix_sbm.json")
-    now = static_mix.mix_sbm(7, 0)
+    now = static_mix.mix_sbm(7, 0, 1)   # the LDS-transposed winner-take-all is the kernel of record since round 4
     for k in ("row_loop_valu", "warmup_row_valu", "tile_output_columns"):
         assert now[k] == rec[k], f"{k}: regenerate profiles/static_mix_sbm.json (tools/static_mix.py sbm)"
     assert rec["warmup_row_valu"] < rec["row_loop_valu"] / 3
@@ -51,7 +51,7 @@ def test_bench_launch_plan_mirrors():
     # StereoBM rows per band: one 1080p / 128-disparity pair -> 16, a batch -> the 48-row cap
     assert bench.sbm_band_rows(1080, 1920, 128, 7, 1) == 16
     assert bench.sbm_band_rows(1080, 1920, 128, 7, 8) == 48
-    assert 15.0 < bench.sbm_valu_per_pxd() < 20.0
+    assert 12.0 < bench.sbm_valu_per_pxd() < 20.0
     assert 0.1 < bench.sbm_warmup_ratio() < 0.3
 
 
@@ -83,12 +83,14 @@ def test_blocked_kernels_keep_their_occupancy():
         return out
 
     tbr = usage("tvl1_tbr_kernels.hip")
-    rec = [v for k, v in tbr.items() if "k_iterate_tbrILi10ELi1ELb" in k and k.endswith("ELi4ELi2ELi0ELi2EEEvNS0_6TbArgsE")]
-    assert len(rec) == 2   # first pass of a warp (p = 0) and the others
+    # the kernel of record since round 4 forms |grad|^2 itself (NG): ...ELi2ELb1ELb0EE; the one that reads the plane stays for the stage API
+    rec = [v for k, v in tbr.items() if "k_iterate_tbrILi10ELi1ELb" in k and (k.endswith("ELi4ELi2ELi0ELi2ELb1ELb0EEEvNS0_6TbArgsE") or
+                                                                               k.endswith("ELi4ELi2ELi0ELi2ELb0ELb0EEEvNS0_6TbArgsE"))]
+    assert len(rec) == 4   # {no |grad|^2 plane, plane} x {first pass of a warp (p = 0), the others}
     for v in rec:
         assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["SGPRs Spill"] == 0 and v["Occupancy"] >= 4, v
     for k, v in tbr.items():
-        if k.endswith("ELi2EEEvNS0_6TbArgsE"):      # every joined-wave instantiation (fixed work and speculative steps)
+        if re.search(r"ELi2ELb[01]ELb[01]EEEvNS0_6TbArgsE$", k):      # every joined-wave instantiation (fixed work and speculative steps)
             assert v.get("VGPRs Spill", 0) == 0, k
     surf = usage("surf_kernels.hip")
     for k, v in surf.items():

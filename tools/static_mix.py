@@ -2,7 +2,7 @@
 stage and pixel row: compiles tvl1_tbr_kernels.hip to gfx950 assembly, finds the largest loop of the instantiation and counts its
 instructions by class.  bench.py's `roofline` (bound "valu_issue") uses these figures; the output of record is
 profiles/static_mix_tbr.json (the default kernel: joined waves, barrier form) and profiles/static_mix_tbr_jw0.json (independent waves).
-Usage: python tools/static_mix.py [T PPL PZ WPS PF MODE JW]  (default 10 1 0 4 2 0 0)"""
+Usage: python tools/static_mix.py [T PPL PZ WPS PF MODE JW [NG P16]]  (default 10 1 0 4 2 0 0; NG defaults to what a default calc runs)"""
 import collections
 import json
 import os
@@ -14,7 +14,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0):
+def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0, NG=None, P16=0):
+    # NG: the instantiation without a |grad|^2 plane -- what a default calc runs since round 4 for T = 10, JW = 2 (tb_nograd_ok)
+    if NG is None:
+        NG = 1 if (T == 10 and JW == 2 and MODE == 0) else 0
     src = os.path.join(ROOT, "opencv_contrib_amd", "csrc", "tvl1_tbr_kernels.hip")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
@@ -22,7 +25,7 @@ def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0):
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-x", "hip", "-S", "--cuda-device-only", src,
                         "-o", out], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
-    pat = f"k_iterate_tbrILi{T}ELi{PPL}ELb{PZ}ELi{WPS}ELi{PF}ELi{MODE}ELi{JW}EE"
+    pat = f"k_iterate_tbrILi{T}ELi{PPL}ELb{PZ}ELi{WPS}ELi{PF}ELi{MODE}ELi{JW}ELb{NG}ELb{P16}EE"
     for f in re.split(r"\n\s*\.globl\s+", txt):
         if pat not in f.split("\n", 1)[0]:
             continue
@@ -140,5 +143,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sbm":   # python tools/static_mix.py sbm [R MODE]
         print(json.dumps(mix_sbm(*[int(x) for x in sys.argv[2:5]]), indent=1))   # R MODE WT
     else:
-        a = [int(x) for x in sys.argv[1:8]] or [10, 1, 0, 4, 2, 0, 0]
+        a = [int(x) for x in sys.argv[1:10]] or [10, 1, 0, 4, 2, 0, 0]
         print(json.dumps(mix(*a), indent=1))
