@@ -191,6 +191,15 @@ pmc_secondary)
   cd $R
   python tools/pmc_secondary.py $O "profiles/$NAME" 2>&1 | tail -5; cp profiles/pmc_traffic.json $O/pmc_traffic.json
   find $O -type f -size +4M -delete ;;
+trace_secondary)
+  # kernel traces of the secondary workloads on the final tree (VERDICT r03 hygiene item)
+  cd /tmp
+  for wl in stereobm farneback surf; do
+    timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace_$wl -- python $R/bench.py --workload $wl --no-cpu --steps 3 --warmup 1 > $R/$O/trace_${wl}_bench.log 2>&1
+    for f in $(find $R/$O/trace_$wl -name "*kernel_stats.csv" | head -1); do cp $f $R/$O/kernel_stats_$wl.csv; echo "== $wl"; head -8 $f | cut -c1-170; done
+  done
+  cd $R
+  find $O -type f -size +4M -delete ;;
 spec_trace)
   (timeout 300 python tools/spec_trace.py --pairs 4 2>&1 | tail -120) > $O/spec_trace.log; head -70 $O/spec_trace.log ;;
 jw2)
