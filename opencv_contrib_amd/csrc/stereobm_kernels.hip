@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
                 //      of the group's columns to T[column][d]; lane (c = lane % 16, q = lane / 16) scans disparities 16 q .. 16 q + 15 of
                 //      column c with the same score as the DPP path, (2^26-1 - SSD) << 6 | (d ^ 0x38); the four quarters of a column are
                 //      combined across the rows of 16 lanes.  An inactive lane's value is written as 0, which no active lane's (> 0) ties.
-                const unsigned amask = active ? 0xffffffffu : 0u;
+                // per-lane constant mask (all ones for an active lane): ONE full-rate v_and per column -- a select on the wave-uniform
+                // "every lane is active" cost a half-rate v_cndmask per column on top of it
+                unsigned amask = active ? 0xffffffffu : 0u;
+                asm volatile("" : "+v"(amask));
                 unsigned nw = 0x3ffffffu, nh = 0x3ffffffu;
 #pragma unroll
                 for (int c = 0; c < 2 * R; ++c) nw -= cs[c];
@@ -351,8 +354,7 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
                             nh += cs[i];
                         }
                         nw += cs[i];
-                        if (!all_active) val &= amask;
-                        v[k] = val;
+                        v[k] = val & amask;
                     }
                 };
                 // Order of a row: write group g, issue its reads, compute group g + 1's values WHILE the reads are in flight, scan g.
