@@ -277,7 +277,24 @@ def power_leg(fn, units_per_call, seconds=2.5):
 
 
 def time_steps(alg, I0, I1, flows, steps, warmup, dist):
+    """I0 / I1: one batch, or a LIST of batches used in turn (step k computes batch k mod len -- the variant that measures the
+    convergence-checked path with its block-length history coming from OTHER pairs than the ones being computed)."""
     import torch
+    if isinstance(I0, (list, tuple)):
+        seq0, seq1 = list(I0), list(I1)
+        for k in range(warmup):
+            alg.calc_batch(seq0[k % len(seq0)], seq1[k % len(seq0)], flows)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            alg.calc_batch(seq0[(warmup + k) % len(seq0)], seq1[(warmup + k) % len(seq0)], flows)
+        torch.cuda.synchronize()
+        time_steps.local_s = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0
     for _ in range(warmup):
         alg.calc_batch(I0, I1, flows)
     if dist is not None:
@@ -1196,9 +1213,9 @@ def main():
         var = {}
         hs = max(1, args.steps // 2)
 
-        def vrun(name, it, eps, **kw):
+        def vrun(name, it, eps, inputs=None, warm=1, **kw):
             try:
-                e2, _, its2, _ = run(it, eps, hs, 1, **kw)
+                e2, _, its2, _ = run(it, eps, hs, warm, inputs=inputs, **kw)
                 m2 = float(np.mean(its2))
                 ab = algo_bytes_per_pair(W, H, warps, m2)
                 var[name] = {"pairs_per_s": B * hs / e2, "executed_iterations_per_warp_mean": m2, "algorithmic_GB_per_pair": ab / 1e9,
@@ -1210,7 +1227,28 @@ def main():
         vrun("iterations10_eps0.01_reference_test_setting", 10, 0.01)
         vrun("iterations2_eps0", 2, 0.0)
         vrun("iterations30_eps0", 30, 0.0)
-        vrun("class_defaults_300_eps0.01", 300, 0.01)                      # speculative blocks, device-decided stop
+        # Speculative blocks, device-decided stop.  Round 4: a warp's first block is as long as the same warp of the same pair slot
+        # needed in the handle's PREVIOUS calc (SpecK::h_in).  The plain variant repeats one batch, so its history is exact -- the
+        # best case of a video; `_history_from_other_pairs` alternates the batch with itself rolled by one and by two pairs, so
+        # every estimate comes from a different pair; `_no_history` (MIFLOW_TB_HIST=0, a subprocess: the switch is read once) is
+        # the first calc of a handle / the round-3 estimates.  Flows and iteration counts are identical in all three.
+        vrun("class_defaults_300_eps0.01", 300, 0.01, warm=2)
+        try:
+            import torch as _t
+            seqs = ([I0, _t.roll(I0, 1, 0).contiguous(), _t.roll(I0, 2, 0).contiguous()], [I1, _t.roll(I1, 1, 0).contiguous(), _t.roll(I1, 2, 0).contiguous()])
+            vrun("class_defaults_300_eps0.01_history_from_other_pairs", 300, 0.01, inputs=seqs, warm=2)
+            del seqs
+        except Exception as e:
+            var["class_defaults_300_eps0.01_history_from_other_pairs"] = {"error": repr(e)[:200]}
+        try:
+            import subprocess
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-variants", "--no-cpu", "--no-secondary", "--no-power", "--iterations", "300",
+                                 "--epsilon", "0.01", "--steps", str(max(2, hs)), "--warmup", "1", "--batch", str(B)], capture_output=True, text=True,
+                                env=dict(os.environ, MIFLOW_TB_HIST="0"), timeout=300)
+            d_ = json.loads([l for l in r_.stdout.splitlines() if l.startswith("{")][-1])
+            var["class_defaults_300_eps0.01_no_history"] = {"pairs_per_s": d_["value"]}
+        except Exception as e:
+            var["class_defaults_300_eps0.01_no_history"] = {"error": repr(e)[:200]}
         vrun("class_defaults_300_eps0.01_stop_slack1", 300, 0.01, stopSlack=1)   # miflow extension: up to one iteration past the reference's stop
         vrun("iterations10_eps0_exact_math", 10, 0.0, exactMath=True)
         vrun("iterations10_eps0_cuda_compat_semantics", 10, 0.0, semantics=1)

@@ -32,6 +32,8 @@ const Tuning &tuning()
         t.tb_p16 = env_int("MIFLOW_TB_P16", 0);
         t.tb_nograd = env_int("MIFLOW_TB_NOGRAD", 1);
         t.tb_skip_p = env_int("MIFLOW_TB_SKIP_P", 1);
+        t.tb_hist = env_int("MIFLOW_TB_HIST", 1);
+        t.fb_poll = env_int("MIFLOW_FB_POLL", 1);
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);
         if (t.tb_jw < 0 || t.tb_jw > 4) t.tb_jw = 2;   // 3: eight joined waves (experiment); 4: barrier form, branch-free publishes, mask-free interior blocks
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,

@@ -41,6 +41,8 @@ struct Tuning {
     int warp_zoom;          // MIFLOW_WARP_ZOOM: the first warp of a scale zooms the coarser flow itself instead of a resize launch (1; default 0: measured slower)
     int tb_p16;             // MIFLOW_TB_P16=1 (opt-in, CHANGES RESULTS within the fast path's tolerance): p between the passes of a scale as signed 16-bit fixed point
     int tb_nograd;          // MIFLOW_TB_NOGRAD: the blocked pass forms |grad|^2 itself and the warp does not store the plane (1, default) / stored plane (0)
+    int tb_hist;            // MIFLOW_TB_HIST: block lengths of the convergence-checked path from the handle's previous calc (1, default)
+    int fb_poll;            // MIFLOW_FB_POLL: host feedback through flags the deciding launch writes into pinned host memory when it STARTS (1, default) or a copy of the control slots behind the launch (0, round 3)
     int tb_skip_p;          // MIFLOW_TB_SKIP_P: the last pass of a scale does not store p (1, default)
     int tb_jw;              // MIFLOW_TB_JW: joined-wave form of the T = 10 blocked iteration kernel
     int tb_jw_spec;         // MIFLOW_TB_JW_SPEC: ... of the speculative steps as well

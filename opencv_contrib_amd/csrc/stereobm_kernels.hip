@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
 
     // inactive lanes (d >= ndisp) carry a bias above any real SSD (max 51*51*255^2 < 2^28) so they never win
     const unsigned bias = active ? 0u : 0x40000000u;
-    const bool all_active = (A.ndisp & 63) == 0;   // wave-uniform: no lane of any set lies past the disparity range
     // wave-uniform facts about the tile
 #ifdef MI_STATIC_MIX_INTERIOR_TILES   // tools/static_mix.py sbm: count the row loop of a tile away from the right image edge
     const bool edge_tile = false;

@@ -49,12 +49,21 @@ struct Lane {
     int4 *X = nullptr;      // per slot state of the speculative steps (SpecK::X)
     long long Q = 0;
     int ctlB = 0;
+    // iteration counts per (scale, warp, pair slot) of the previous calc, two parities (SpecK::h_in / h_out)
+    int *H = nullptr;
+    size_t H_cap = 0;             // ints per parity
+    unsigned long long H_sig = 0; // geometry / batch / loop shape the counts belong to (0: none)
+    int H_par = 0;                // parity the NEXT calc writes
     std::vector<SlotInfo> slots;
     int batch = 0;          // pairs of the last calc
     // host feedback (mi_tvl1_params.host_feedback): pinned landing area of the control slots read back between launches
     int2 *fb_host = nullptr;
     int fb_cap = 0;
     hipEvent_t fb_ev = nullptr;
+    int *fb_flag = nullptr;   // polled form (SpecK::fb_flag): {decision word, count} per pair, pinned
+    int fb_seq = 0;
+    std::vector<int> fb_hist;        // polled form: most iterations a (scale, warp) of the previous calc needed over its pairs (0: unknown)
+    unsigned long long fb_hist_sig = 0;
     long long fb_waits = 0, fb_skipped = 0;   // of the last calc: host waits, launches not enqueued
     // profiling (mi_tvl1_set_profiling)
     std::vector<hipEvent_t> ev_pool;
@@ -242,9 +251,11 @@ void mi_tvl1_destroy(mi_tvl1 *h)
         if (ln.E) (void)hipFree(ln.E);
         if (ln.Pd) (void)hipFree(ln.Pd);
         if (ln.X) (void)hipFree(ln.X);
+        if (ln.H) (void)hipFree(ln.H);
         if (ln.done) (void)hipEventDestroy(ln.done);
         if (ln.fb_ev) (void)hipEventDestroy(ln.fb_ev);
         if (ln.fb_host) (void)hipHostFree(ln.fb_host);
+        if (ln.fb_flag) (void)hipHostFree(ln.fb_flag);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (h->fork) (void)hipEventDestroy(h->fork);
@@ -436,6 +447,28 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
         MI_HIP_TRY(hipMemsetAsync(ln.E, 0, sizeof(unsigned long long) * (size_t)ln.Q * B, st));
         MI_HIP_TRY(hipMemsetAsync(ln.S, 0, sizeof(int2) * (size_t)ln.Q * B, st));
     }
+    // history of the previous calc of this lane (speculative steps only)
+    const size_t h_n = (size_t)ns * P.warps * B;
+    bool hist = spec && tuning().tb_hist != 0;
+    if (hist) {
+        unsigned long long sig = 1469598103934665603ull;
+        for (long long v : {(long long)W, (long long)H, (long long)B, (long long)ns, (long long)P.warps, (long long)iters_per_warp, (long long)I0s[0].type}) sig = (sig ^ (unsigned long long)v) * 1099511628211ull;
+        if (ln.H_cap < h_n) {
+            if (ln.H) (void)hipFree(ln.H);
+            ln.H = nullptr; ln.H_cap = 0; ln.H_sig = 0;
+            MI_HIP_TRY(hipMalloc((void **)&ln.H, sizeof(int) * 2 * h_n));
+            ln.H_cap = h_n;
+        }
+        if (ln.H_sig != sig) {   // counts of another geometry say nothing: start from none (0 = no estimate)
+            MI_HIP_TRY(hipMemsetAsync(ln.H, 0, sizeof(int) * 2 * ln.H_cap, st));
+            ln.H_sig = sig;
+        }
+        if (ln.fb_hist_sig != sig || ln.fb_hist.size() != (size_t)ns * P.warps) {
+            ln.fb_hist.assign((size_t)ns * P.warps, 0);
+            ln.fb_hist_sig = sig;
+        }
+        ln.H_par ^= 1;
+    }
     ln.slots.clear();
     ln.regions.clear();
     size_t ev_used = 0;
@@ -501,13 +534,17 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap_st) == hipSuccess && cap_st != hipStreamCaptureStatusNone;
     const bool fb = spec && h->last_lanes == 1 && P.host_feedback >= 0 && (P.host_feedback == 1 || B <= 2) && !capturing;
+    const bool fb_poll = fb && tuning().fb_poll != 0;
     int fb_prev_warp = 2, fb_prev_scale = 2;   // launch index at which the previous warp / the coarser scale's first warp was found stopped
     ln.fb_waits = ln.fb_skipped = 0;
     if (fb) {
         if (ln.fb_cap < B) {
             if (ln.fb_host) (void)hipHostFree(ln.fb_host);
-            ln.fb_host = nullptr; ln.fb_cap = 0;
+            if (ln.fb_flag) (void)hipHostFree(ln.fb_flag);
+            ln.fb_host = nullptr; ln.fb_flag = nullptr; ln.fb_cap = 0;
             MI_HIP_TRY(hipHostMalloc((void **)&ln.fb_host, 2 * sizeof(int2) * (size_t)B, hipHostMallocDefault));
+            MI_HIP_TRY(hipHostMalloc((void **)&ln.fb_flag, 2 * sizeof(int) * (size_t)B, hipHostMallocCoherent | hipHostMallocMapped));
+            memset(ln.fb_flag, 0, 2 * sizeof(int) * (size_t)B);
             ln.fb_cap = B;
         }
         if (!ln.fb_ev) MI_HIP_TRY(hipEventCreateWithFlags(&ln.fb_ev, hipEventDisableTiming));
@@ -627,7 +664,15 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // Speculative steps (k_iterate_tbr MODE 1): a launch runs a block of iterations recording their error sums; the next
                 // launch applies the reference's stopping rule to them and either builds on the block or replays the exact
                 // count from its input.  One settling launch ends the warp.  After convergence the remaining launches end at once.
-                const std::vector<int> &plan = spec_plan[(tile_eligible(g) && tuning().tile_spec != 0) ? 3 : wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
+                const bool on_tiles = tile_eligible(g) && tuning().tile_spec != 0;
+                std::vector<int> plan = spec_plan[on_tiles ? 3 : wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
+                if (on_tiles && fb_poll && hist && !plan.empty()) {
+                    // the previous calc's count for this warp is known on the host: a first block of at most 4 / 7 iterations runs on
+                    // tiles of that margin (k_iterate_tile M).  A count that turns out larger costs one more block, as any estimate does.
+                    int &hc = ln.fb_hist[(size_t)s * P.warps + wp];
+                    if (hc >= 1 && hc <= 7) plan[0] = hc <= 4 ? 4 : 7;
+                    hc = 0;   // known again once this warp's stop has been seen
+                }
                 int t_after = 0;
                 for (int v : plan) t_after += v;
                 SpecK sk;
@@ -640,6 +685,11 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 sk.hist_num = wp == 0 ? 7 : wp == 1 ? 9 : 4;
                 sk.hist_den = wp == 0 ? 10 : wp == 1 ? 20 : 5;
                 sk.slack = P.stop_slack;
+                if (hist) {
+                    const size_t o = ((size_t)s * P.warps + wp) * B;
+                    sk.h_in = ln.H + (size_t)(ln.H_par ^ 1) * ln.H_cap + o;
+                    sk.h_out = ln.H + (size_t)ln.H_par * ln.H_cap + o;
+                }
                 if (first_of_scale) {   // a replay of the scale's first block must see p = 0 in the input set as well
                     for (int j = 0; j < 4; ++j) MI_HIP_TRY(hipMemsetAsync(ln.pbuf[0][j], 0, sizeof(float) * (size_t)g.ps * B, st));
                 }
@@ -659,6 +709,11 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     Ctl a = ctl;
                     a.q = q; a.q_prev = q_last; a.first_of_warp = (k == 0); a.reset_cur = (k == 0 && first_of_scale); a.n = 0;
                     sk.e0_prev = e_prev; sk.final_launch = last ? 1 : 0; sk.t_after = t_after;
+                    int fb_seq_k = 0;
+                    if (fb_poll) {
+                        fb_seq_k = ln.fb_seq = (ln.fb_seq + 1) & 0x0fffffff;
+                        sk.fb_flag = ln.fb_flag; sk.fb_seq = fb_seq_k;
+                    }
                     rc = iterate_tb_spec(T, pl, g, l_t, theta, taut, false, a, sk, e_next, st);
                     if (rc) return rc;
                     ln.slots.push_back({s, wp});
@@ -667,18 +722,46 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     e_prev = e_next;
                     if (!last) e_next += T;
                     if (fb && !last && (int)k == fb_next) {
-                        // the slots of this launch and of the one before it (k >= 1), per pair
-                        MI_HIP_TRY(hipMemcpy2DAsync(ln.fb_host, 2 * sizeof(int2), ln.S + (q_last - 1), sizeof(int2) * (size_t)ln.Q, 2 * sizeof(int2),
-                                                    (size_t)B, hipMemcpyDeviceToHost, st));
-                        MI_HIP_TRY(hipEventRecord(ln.fb_ev, st));
-                        MI_HIP_TRY(hipEventSynchronize(ln.fb_ev));
-                        ++ln.fb_waits;
                         bool all = true, all_before = true;
-                        for (int b = 0; b < B; ++b) {
-                            all_before = all_before && (ln.fb_host[2 * b].y & MI_SLOT_DONE);
-                            all = all && (ln.fb_host[2 * b + 1].y & MI_SLOT_DONE);
+                        int n_most = 0;
+                        if (fb_poll) {
+                            // the launch just enqueued publishes its decision when it starts: wait for that word, not for the launch
+                            ++ln.fb_waits;
+                            for (int b = 0; b < B; ++b) {
+                                int v = 0;
+                                for (long long spin = 0;; ++spin) {
+                                    v = __atomic_load_n(ln.fb_flag + 2 * b, __ATOMIC_ACQUIRE);
+                                    if ((v >> 2) == fb_seq_k) break;
+                                    if ((spin & 1023) == 1023) {
+                                        // a failed launch never writes: the stream is idle (or in error) and the word is not there
+                                        const hipError_t qe = hipStreamQuery(st);
+                                        if (qe != hipErrorNotReady) {
+                                            v = __atomic_load_n(ln.fb_flag + 2 * b, __ATOMIC_ACQUIRE);
+                                            if ((v >> 2) == fb_seq_k) break;
+                                            MI_HIP_TRY(qe);
+                                            MI_REQUIRE(false, MI_ERR_HIP, "host feedback: launch finished without publishing its decision");
+                                        }
+                                    }
+                                    __builtin_ia32_pause();
+                                }
+                                all_before = all_before && (v & 2);
+                                all = all && (v & 1);
+                                n_most = std::max(n_most, ln.fb_flag[2 * b + 1]);
+                            }
+                        } else {
+                            // the slots of this launch and of the one before it (k >= 1), per pair
+                            MI_HIP_TRY(hipMemcpy2DAsync(ln.fb_host, 2 * sizeof(int2), ln.S + (q_last - 1), sizeof(int2) * (size_t)ln.Q, 2 * sizeof(int2),
+                                                        (size_t)B, hipMemcpyDeviceToHost, st));
+                            MI_HIP_TRY(hipEventRecord(ln.fb_ev, st));
+                            MI_HIP_TRY(hipEventSynchronize(ln.fb_ev));
+                            ++ln.fb_waits;
+                            for (int b = 0; b < B; ++b) {
+                                all_before = all_before && (ln.fb_host[2 * b].y & MI_SLOT_DONE);
+                                all = all && (ln.fb_host[2 * b + 1].y & MI_SLOT_DONE);
+                            }
                         }
                         if (all) {
+                            if (fb_poll && hist) ln.fb_hist[(size_t)s * P.warps + wp] = n_most;
                             ln.fb_skipped += (long long)plan.size() - (long long)k;
                             fb_done_at = all_before ? (int)k - 1 : (int)k;   // where the next warp's first read-back goes
                             break;

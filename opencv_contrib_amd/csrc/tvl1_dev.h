@@ -122,6 +122,16 @@ struct SpecK {
     int q_hist;         // slot whose X.x = iteration count of an earlier warp: the first block's estimate is
     int hist_num, hist_den;   //   floor(count * num / den), at least 1 (-1: none)
     int slack;          // mi_tvl1_params.stop_slack
+    // History of the handle's previous calc (same geometry and batch): the iterations THIS warp of THIS pair slot needed then --
+    // consecutive frame pairs of a video stop within an iteration of each other, so it is the best estimate of a block length
+    // there is.  Like every estimate it cannot change a result, only the number of passes.  Double-buffered by call parity (a
+    // launch's workgroups read h_in while its writer thread stores h_out).  nullptr: no usable history.
+    const int *h_in;
+    int *h_out;
+    // Host feedback without a copy: the launch's writer thread stores {fb_seq << 2 | was-done-before << 1 | done, iterations accepted
+    // so far} per pair into pinned host memory right after its decision, i.e. when the launch STARTS; the host polls it.  nullptr: none.
+    int *fb_flag;
+    int fb_seq;
 };
 
 int tb_spec_plan(int n, int warp_index, bool large_level, int *blocks, int max_blocks);

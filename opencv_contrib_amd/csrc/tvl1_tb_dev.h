@@ -63,7 +63,7 @@ __device__ __forceinline__ bool spec_settle(const CtlK &ck, const SpecK &sk, int
 {
     // (1) settle the block the previous launch of this warp ran speculatively (every workgroup, redundantly, from the same
     //     device data => the same decision); (2) pick this launch's work: replay, the next speculative block, or nothing.
-    int base = 0, done = 0, n = 0, replay = 0, accepted = 0, pbase = 0;
+    int base = 0, done = 0, n = 0, replay = 0, accepted = 0, pbase = 0, done_before = 0;
     double prev = 0.0;                    // cv::cuda's prevError
     float e_last = 0.f, e_before = 0.f;   // error / threshold of the last two accepted iterations (0: unknown)
     if (ck.q_prev >= 0) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ bool spec_settle(const CtlK &ck, const SpecK &sk, int
             n = px.x;
             e_last = __int_as_float(px.z);
             if (sl.y & MI_SLOT_DONE) {
-                done = 1;
+                done = 1; done_before = 1;
             } else if (px.y > 0) {
                 const int pn = px.y;
                 int kk = 0, conv = 0;
@@ -112,7 +112,10 @@ __device__ __forceinline__ bool spec_settle(const CtlK &ck, const SpecK &sk, int
         // avoids both a replay (too long) and extra passes (too short).  A pass costs nearly the same whatever its length
         // (it is bound by its 64 B/px), so what counts is the number of passes.
         int pred = T;
-        if (!ck.sched) {
+        const int hist = sk.h_in ? sk.h_in[b] : 0;   // what this warp of this slot needed in the handle's previous calc
+        if (!ck.sched && hist > n) {
+            pred = hist - n;
+        } else if (!ck.sched) {
             if (ck.first_of_warp) {
                 if (sk.q_hist >= 0) pred = (sk.X[(long long)b * ck.Q + sk.q_hist].x * sk.hist_num) / sk.hist_den;
             } else if (e_before > e_last && e_last > 1.f) {
@@ -130,6 +133,11 @@ __device__ __forceinline__ bool spec_settle(const CtlK &ck, const SpecK &sk, int
         ck.S[sq] = make_int2(replay ? pbase : base, (replay ? MI_SLOT_FLIP : 0) | (done ? MI_SLOT_DONE : 0) | (accepted << 8));
         ck.P[sq] = prev;
         sk.X[sq] = make_int4(n, record ? nit : 0, __float_as_int(e_last), 0);
+        if (sk.h_out) sk.h_out[b] = n;   // the warp's last launch leaves the final count
+        if (sk.fb_flag) {   // {decision word, iterations accepted so far} per pair; the word is the release
+            sk.fb_flag[2 * b + 1] = n;
+            __hip_atomic_store(sk.fb_flag + 2 * b, (sk.fb_seq << 2) | (done_before << 1) | done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (nit == 0) return false;
     cur = replay ? pbase : base;

@@ -47,10 +47,13 @@ constexpr int TILE_M = 10;   // validity margin per side = the most iterations o
 // SPEC: one speculative step of the convergence-checked path (k_iterate_tbr MODE 1 on register tiles): the block length comes from
 // the device-side settle logic, and every iteration's error sum(du1^2 + du2^2) over the tile's OWNED pixels is added -- as 2^-24
 // fixed-point integers, so the totals do not depend on the tiling -- to the per-iteration slots the next launch reads.
-template <int RW, int NW, bool PZ, bool SPEC>
+// M = margin of the tile per side = the most iterations the launch can run.  The speculative steps of a single pair know from the
+// handle's previous calc how many a warp will need (SpecK::h_in, and host-side Lane::fb_hist): a block of at most 4 iterations on
+// M = 4 tiles owns 56 x 56 of its 64 x 64 pixels instead of 44 x 44 -- 1.6 x fewer workgroups, loads and lane-iterations per pass.
+// Which margin a block ran on never shows: the arithmetic per pixel is the same and the error sums are exact integers.
+template <int RW, int NW, bool PZ, bool SPEC, int M = TILE_M>
 __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
 {
-    constexpr int M = TILE_M;
     constexpr int LW = 64;
     constexpr int STRIDE = LW - 2 * M;        // owned columns of the strips >= 1 (strip 0 owns LW - M)
     constexpr int BR = NW * RW - 2 * M;       // owned rows of a tile
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     __shared__ float xch[NW][4][64];
     // SPEC: per-iteration error sums of the workgroup; one global add per workgroup and iteration at the end (one per WAVE and
     // iteration -- 17 600 waves at 1080p -- made the launch 10 x slower: the adds of a slot serialise in L2)
-    __shared__ unsigned long long s_err[TILE_M];
+    __shared__ unsigned long long s_err[M];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     for (int r = 0; r < RW; ++r) rg[r] = __builtin_amdgcn_rcpf(fmaxf(rg[r], 1e-30f));   // finish_static
     xch[wave][2][lane] = p12[RW - 1];
     xch[wave][3][lane] = p22[RW - 1];
-    if (SPEC && threadIdx.x < TILE_M) s_err[threadIdx.x] = 0ull;
+    if (SPEC && threadIdx.x < M) s_err[threadIdx.x] = 0ull;
     __syncthreads();
 
     const float l_t = A.l_t, theta = A.theta, taut = A.taut;
@@ -192,14 +195,14 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     }
 }
 
-template <int RW, int NW, bool SPEC>
+template <int RW, int NW, bool SPEC, int M = TILE_M>
 static int launch_tile(const TileArgs &A, bool pz, hipStream_t s)
 {
-    constexpr int M = TILE_M, LW = 64, STRIDE = LW - 2 * M, BR = NW * RW - 2 * M;
+    constexpr int LW = 64, STRIDE = LW - 2 * M, BR = NW * RW - 2 * M;
     const int nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
     const dim3 grid(nstrips, div_up(A.g.h, BR), A.g.batch);
-    if (pz && !SPEC) hipLaunchKernelGGL((k_iterate_tile<RW, NW, true, false>), grid, dim3(NW * 64), 0, s, A);
-    else hipLaunchKernelGGL((k_iterate_tile<RW, NW, false, SPEC>), grid, dim3(NW * 64), 0, s, A);
+    if (pz && !SPEC) hipLaunchKernelGGL((k_iterate_tile<RW, NW, true, false, M>), grid, dim3(NW * 64), 0, s, A);
+    else hipLaunchKernelGGL((k_iterate_tile<RW, NW, false, SPEC, M>), grid, dim3(NW * 64), 0, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -207,9 +210,9 @@ static int launch_tile(const TileArgs &A, bool pz, hipStream_t s)
 typedef int (*TileLaunchFn)(const TileArgs &, bool, hipStream_t);
 struct TileEntry {
     int RW, NW;
-    TileLaunchFn launch, spec;
+    TileLaunchFn launch, spec, spec4, spec7;   // spec4 / spec7: blocks of at most 4 / 7 iterations on tiles of that margin
 };
-#define TILE(RW, NW) {RW, NW, launch_tile<RW, NW, false>, launch_tile<RW, NW, true>}
+#define TILE(RW, NW) {RW, NW, launch_tile<RW, NW, false>, launch_tile<RW, NW, true>, launch_tile<RW, NW, true, 4>, launch_tile<RW, NW, true, 7>}
 static const TileEntry g_tile[] = {TILE(4, 16), TILE(6, 16), TILE(8, 16), TILE(8, 8), TILE(6, 8), TILE(3, 16)};
 constexpr int kTileVariants = (int)(sizeof(g_tile) / sizeof(g_tile[0]));
 
@@ -260,7 +263,8 @@ int iterate_tile_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, floa
     A.ctl = make_ctlk(&ctl);
     A.sk = sk;
     A.e0 = e0;
-    return g_tile[variant].spec(A, false, s);
+    const TileEntry &e = g_tile[variant];
+    return (T <= 4 ? e.spec4 : T <= 7 ? e.spec7 : e.spec)(A, false, s);
 }
 
 }  // namespace tvl1

@@ -396,6 +396,39 @@ def test_host_feedback_never_changes_a_flow(gpu, iters, eps):
     assert np.array(counts).max() <= iters and (iters < 300 or np.array(counts).max() < 300)
 
 
+@pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class_rule", "cv_cuda_schedule"])
+def test_block_lengths_from_the_previous_calc_never_change_a_flow(gpu, sem):
+    """Round 4: the first block of a warp's speculative steps is as long as THIS warp of THIS pair slot needed in the handle's previous
+    calc (SpecK::h_in, tvl1_tb_dev.h spec_settle) -- on video the best estimate there is, and like every estimate only a matter of how
+    many passes run.  A handle whose history is exact (same pair again), misleading (another pair, a permuted batch, another size
+    in between) or absent (fresh handle) returns the same flows and the same per-(scale, warp) counts."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(200, 264, seed=140 + k)[:2] for k in range(4)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    small = synth.flow_pair(96, 128, seed=150)[:2]
+
+    def fresh(idx):
+        a = cuda.OpticalFlowDual_TVL1.create(semantics=sem, lanes=1)
+        f = a.calc_batch([I0s[i] for i in idx], [I1s[i] for i in idx])
+        torch.cuda.synchronize()
+        return f.clone(), [a.lastIterations(k) for k in range(len(idx))]
+
+    alg = cuda.OpticalFlowDual_TVL1.create(semantics=sem, lanes=1)
+    for idx in ([0, 1, 2, 3], [0, 1, 2, 3], [3, 2, 1, 0], [1, 1, 1, 1], [2, 0, 3, 1]):
+        want, counts = fresh(idx)
+        got = alg.calc_batch([I0s[i] for i in idx], [I1s[i] for i in idx])
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), idx
+        assert [alg.lastIterations(k) for k in range(4)] == counts, idx
+    alg.calc(T(small[0], gpu), T(small[1], gpu))              # another geometry in between: the counts are dropped, not misread
+    for k in (0, 0, 2):
+        want, counts = fresh([k])
+        assert torch.equal(alg.calc(I0s[k], I1s[k]), want[0]), k
+        assert alg.lastIterations(0) == counts[0]
+    assert (np.array(counts) < 300).any()
+
+
 @pytest.mark.parametrize("iters", [1, 2, 3, 5, 7, 12, 23])
 @pytest.mark.parametrize("shape", [(16, 16), (21, 37), (64, 9), (5, 300), (97, 131)])
 def test_speculative_steps_iteration_limits_and_small_images(gpu, oracle, shape, iters):
