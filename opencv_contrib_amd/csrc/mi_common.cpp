@@ -34,6 +34,7 @@ const Tuning &tuning()
         t.tb_skip_p = env_int("MIFLOW_TB_SKIP_P", 1);
         t.tb_hist = env_int("MIFLOW_TB_HIST", 1);
         t.fb_poll = env_int("MIFLOW_FB_POLL", 1);
+        t.fb_ahead = env_int("MIFLOW_FB_AHEAD", 1);
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);
         if (t.tb_jw < 0 || t.tb_jw > 4) t.tb_jw = 2;   // 3: eight joined waves (experiment); 4: barrier form, branch-free publishes, mask-free interior blocks
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,

@@ -580,6 +580,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
         const double se = P.epsilon * P.epsilon * (double)(g.w * g.h);
         ctl.thr = sem == MI_SEM_CPU_REF ? (double)(float)se : se;
 
+        bool pre_warped = false;   // this warp's kernel was enqueued ahead, behind the previous warp's last launch (host feedback)
         for (int wp = 0; wp < P.warps; ++wp) {
             Ctl wc = ctl;
             wc.q_prev = q_last;
@@ -607,7 +608,10 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             if (spec && !legacy_warp && !gam && P.median_filtering <= 1 && tb_spec_nograd_ok(g)) nograd = true;   // speculative steps: every block is a tbr launch
             float *grad_w = nograd ? nullptr : grad;
             pl.g = grad_w;
-            if (tuning().x_skip == 1 && wp > 0) rc = MI_OK;   // timing experiment: what a step costs without the warps' work and bytes
+            const bool warp_is_fused = !legacy_warp && tuning().x_skip == 0;
+            const bool fast_w = !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT));
+            if (pre_warped) { rc = MI_OK; pre_warped = false; }
+            else if (tuning().x_skip == 1 && wp > 0) rc = MI_OK;   // timing experiment: what a step costs without the warps' work and bytes
             else if (legacy_warp)
                 rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
             else
@@ -666,13 +670,16 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // count from its input.  One settling launch ends the warp.  After convergence the remaining launches end at once.
                 const bool on_tiles = tile_eligible(g) && tuning().tile_spec != 0;
                 std::vector<int> plan = spec_plan[on_tiles ? 3 : wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
-                if (on_tiles && fb_poll && hist && !plan.empty()) {
-                    // the previous calc's count for this warp is known on the host: a first block of at most 4 / 7 iterations runs on
-                    // tiles of that margin (k_iterate_tile M).  A count that turns out larger costs one more block, as any estimate does.
+                // the previous calc's count for this warp, where the host has seen it (polled host feedback): a first block of at most
+                // 4 / 7 iterations runs on tiles of that margin (k_iterate_tile M), and the first poll goes where that many iterations
+                // end.  A count that turns out different costs one more block or one more poll, as any estimate does.
+                int hprev = 0;
+                if (fb_poll && hist) {
                     int &hc = ln.fb_hist[(size_t)s * P.warps + wp];
-                    if (hc >= 1 && hc <= 7) plan[0] = hc <= 4 ? 4 : 7;
+                    hprev = hc;
                     hc = 0;   // known again once this warp's stop has been seen
                 }
+                if (on_tiles && hprev >= 1 && hprev <= 7 && !plan.empty()) plan[0] = hprev <= 4 ? 4 : 7;
                 int t_after = 0;
                 for (int v : plan) t_after += v;
                 SpecK sk;
@@ -691,7 +698,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     sk.h_out = ln.H + (size_t)ln.H_par * ln.H_cap + o;
                 }
                 if (first_of_scale) {   // a replay of the scale's first block must see p = 0 in the input set as well
-                    for (int j = 0; j < 4; ++j) MI_HIP_TRY(hipMemsetAsync(ln.pbuf[0][j], 0, sizeof(float) * (size_t)g.ps * B, st));
+                    rc = zero_planes4(ln.pbuf[0], (size_t)g.ps * B, st);
+                    if (rc) return rc;
                 }
                 int e_prev = 0;
                 // Host feedback (mi_tvl1_params.host_feedback): a call of one or two pairs reads the pairs' control slots back
@@ -701,6 +709,11 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // first warp did), then after every second launch.  The host waits like the reference's class does at each of its
                 // checks (cudaoptflow/src/tvl1flow.cpp:362-368); the flows do not depend on any of it.
                 int fb_next = fb ? std::max(1, wp > 0 ? fb_prev_warp : fb_prev_scale) : -1;
+                if (fb && hprev > 0) {   // the launch behind the block in which iteration hprev falls
+                    int kq = 0, sum = 0;
+                    while (kq < (int)plan.size() && (sum += plan[kq]) < hprev) ++kq;
+                    fb_next = std::max(1, std::min(kq + 1, (int)plan.size() - 1));
+                }
                 int fb_done_at = (int)plan.size();
                 for (size_t k = 0; k <= plan.size(); ++k) {
                     const bool last = k == plan.size();
@@ -724,6 +737,17 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     if (fb && !last && (int)k == fb_next) {
                         bool all = true, all_before = true;
                         int n_most = 0;
+                        // The next warp's kernel goes in BEHIND this launch before the host knows whether the warp has stopped: it
+                        // runs only for pairs whose slot says so (Ctl::need_done) and is enqueued again, unconditionally, where one
+                        // did not.  With the estimate right the device never waits for the host between two warps of a scale.
+                        bool ahead = false;
+                        if (fb_poll && tuning().fb_ahead != 0 && warp_is_fused && !h->profiling && wp + 1 < P.warps) {
+                            Ctl nc = ctl;
+                            nc.q_prev = q_last; nc.need_done = 1;
+                            rc = warp_fused(sem, fast_w, -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad_w, rho, h->cubic_tab, g, &nc, cur, st, nullptr);
+                            if (rc) return rc;
+                            ahead = true;
+                        }
                         if (fb_poll) {
                             // the launch just enqueued publishes its decision when it starts: wait for that word, not for the launch
                             ++ln.fb_waits;
@@ -761,6 +785,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                             }
                         }
                         if (all) {
+                            pre_warped = ahead;
                             if (fb_poll && hist) ln.fb_hist[(size_t)s * P.warps + wp] = n_most;
                             ln.fb_skipped += (long long)plan.size() - (long long)k;
                             fb_done_at = all_before ? (int)k - 1 : (int)k;   // where the next warp's first read-back goes

@@ -29,6 +29,8 @@ struct Ctl {
     double *P;       // per slot: prevError as seen by that launch (sched only)
     int sched;       // 0: check every iteration (CPU class), 1: the schedule above (MI_SEM_CUDA_COMPAT)
     int n;           // iteration index inside the warp
+    int need_done;   // warp kernels only: run only where slot q_prev says the previous warp has stopped (a launch enqueued AHEAD of
+                     // the host's knowledge of that, tvl1_api.cpp host feedback); elsewhere the launch leaves everything untouched
 };
 
 // (host code reads the flags too: mi_tvl1_last_iterations, the host feedback of tvl1_api.cpp)
@@ -55,6 +57,7 @@ struct IterPlanes {
 
 // type: MI_8UC1 (x1) or MI_32FC1 (x255)
 int convert(const PtrTab *tab_dev, int type, float *I0, float *I1, const Geo &g, hipStream_t s);
+int zero_planes4(float *const p[4], size_t n, hipStream_t s);   // four planes of n floats := 0, one launch
 // flow (MI_32FC2, tab.out) -> u1,u2
 int unpack_flow(const PtrTab *tab_dev, float *u1, float *u2, const Geo &g, hipStream_t s);
 // u (set resolved by ctl) -> flow (MI_32FC2)

@@ -12,7 +12,7 @@ struct CtlK {  // by-value copy for kernels (Ctl may be absent)
     int Q, q, q_prev, first_of_warp, reset_cur;
     double thr;
     double *P;
-    int sched, n;
+    int sched, n, need_done;
 };
 static inline CtlK make_ctlk(const Ctl *c)
 {
@@ -21,8 +21,14 @@ static inline CtlK make_ctlk(const Ctl *c)
     k.q_prev = -1;
     if (c) { k.S = c->S; k.E = c->E; k.Q = c->Q; k.q = c->q; k.q_prev = c->q_prev;
              k.first_of_warp = c->first_of_warp; k.reset_cur = c->reset_cur; k.thr = c->thr;
-             k.P = c->P; k.sched = c->sched; k.n = c->n; }
+             k.P = c->P; k.sched = c->sched; k.n = c->n; k.need_done = c->need_done; }
     return k;
+}
+// Ctl::need_done: false = this pair's previous warp has not stopped yet, the launch came too early for it
+__device__ __forceinline__ bool warp_gate_k(const CtlK &c, int b)
+{
+    if (!c.S || !c.need_done || c.q_prev < 0) return true;
+    return (c.S[(long long)b * c.Q + c.q_prev].y & MI_SLOT_DONE) != 0;
 }
 __device__ __forceinline__ int resolve_cur_k(const CtlK &c, int b, int cur_host)
 {

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
     const int b = blockIdx.z;
     const int W = A.g.w, H = A.g.h, ld = A.g.ld;
     if (x0 >= W || y >= H) return;
+    if (!warp_gate_k(ctl, b)) return;
     const int cur = resolve_cur_k(ctl, b, cur_host);
     const long long pb = (long long)b * A.g.ps;
     const long long orow = pb + (long long)y * ld;
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(256) void k_warp_lds(Warp6Args A, CtlK ctl, int cur
     const int x = blockIdx.x * WL_TW + lane;
     const int yb = blockIdx.y * WL_TH + wave * WL_PPT;
     const int b = blockIdx.z;
+    if (!warp_gate_k(ctl, b)) return;   // uniform over the workgroup
     const int cur = resolve_cur_k(ctl, b, cur_host);
     const long long pb = (long long)b * A.g.ps;
     const float *P = A.I1 + pb;
