@@ -50,7 +50,8 @@ const Tuning &tuning()
             const char *e = getenv("MIFLOW_TILE_MAXPX");
             t.tile_maxpx = e && *e ? atoll(e) : 2300000;   // the three coarsest levels of a 1080p pyramid at 8..16 pairs per lane
         }
-        t.tile_variant = env_int("MIFLOW_TILE_VARIANT", 0);
+        t.tile_variant = env_int("MIFLOW_TILE_VARIANT", -1);
+        t.tile_small_wgs = env_int("MIFLOW_TILE_SMALL_WGS", 1024);
         t.tile_spec = env_int("MIFLOW_TILE_SPEC", 1);
         t.lanes = env_int("MIFLOW_LANES", 0);
         t.spec = env_int("MIFLOW_SPEC", 1);
