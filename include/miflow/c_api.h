@@ -125,7 +125,11 @@ typedef struct mi_tvl1_params {
                           * host thread driving several handles is serialised by it (use -1 there).  While `stream` is being captured
                           * into a graph (hipStreamBeginCapture) the read-back is switched off whatever this field says: the calc is
                           * then enqueued fully stream-ordered and the capture stays valid (handle warm, i.e. sized by an earlier
-                          * calc: allocations are not capturable). */
+                          * calc: allocations are not capturable).
+                          * Round 4: the flags are words the deciding launch stores into pinned host memory when it starts and the
+                          * host polls them (no copy, no event); a handle also remembers, on the device, how many iterations each
+                          * warp of each pair slot needed in its previous calc and sizes the next calc's first blocks by that --
+                          * consecutive calcs of a video stream run one pass per warp.  Neither changes a flow or a count. */
 } mi_tvl1_params;
 
 typedef struct mi_tvl1 mi_tvl1;

@@ -1,1 +1,1 @@
-timeout 1500 python -m pytest tests/test_baseline_sizes.py tests/test_tvl1_gpu.py -m gpu -x -q 2>&1 | tail -3
+for p in -1 1 0; do echo FB_PAIR=$p; MIFLOW_FB_PAIR=$p timeout 100 python tools/fb_single.py 640 480 400; done
