@@ -419,7 +419,10 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // remaining (empty) launch -- the fewest launches: blocks of the kernel's margin
                 int kk = 0, sum = 0;
                 const int want = iters_per_warp + (iters_per_warp > 10 ? 30 : iters_per_warp > 1 ? 10 : 0);
-                while (sum < want && kk < (int)spec_plan[k].size()) { spec_plan[k][kk++] = tile_max_block(); sum += tile_max_block(); }
+                // one or two pairs (host feedback: launches behind the stop are never enqueued): shorter blocks on tiles of a
+                // smaller margin own more of their 64 columns x rows (MIFLOW_TILE_FB_BLOCK)
+                const int tb = (B <= 2 && tuning().tile_fb_block > 0) ? std::min(tuning().tile_fb_block, tile_max_block()) : tile_max_block();
+                while (sum < want && kk < (int)spec_plan[k].size()) { spec_plan[k][kk++] = tb; sum += tb; }
                 spec_plan[k].resize(kk);
             } else
             spec_plan[k].resize(tb_spec_plan(iters_per_warp, k == 2 ? 1 : 0, k == 0, spec_plan[k].data(), (int)spec_plan[k].size()));
@@ -679,7 +682,25 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                     hprev = hc;
                     hc = 0;   // known again once this warp's stop has been seen
                 }
-                if (on_tiles && hprev >= 1 && hprev <= 7 && !plan.empty()) plan[0] = hprev <= 4 ? 4 : 7;
+                if (on_tiles && hprev >= 1 && !plan.empty() && tuning().tile_fb_model != 0) {
+                    // Block length = tile margin for the whole warp, from a cost model fitted to the traces of profiles/r10:
+                    // a pass costs ~7 us (MIFLOW_TILE_FB_MODEL) of launch and hand-over plus (tile lanes) x (10.8 ps of loads and stores + 2.4 ps per
+                    // iteration); tile lanes = pixels x 64 / (64 - 2M) x TR / (TR - 2M) with TR = 48 or 64 rows (tile_rows_for).
+                    // Few iterations or a small level: one block of the margin that just holds them; many iterations on a
+                    // level that fills the device: more, shorter blocks whose tiles own more of their pixels.
+                    const double px = (double)g.w * g.h * B, TR = (double)tile_rows_for(g);
+                    int best = 10;
+                    double best_cost = 1e30;
+                    for (int bl : {4, 7, 10}) {
+                        const double passes = (double)((hprev + bl - 1) / bl);
+                        const double lanes = px * 64.0 / (64.0 - 2.0 * bl) * TR / (TR - 2.0 * bl);
+                        const double cost = passes * (double)tuning().tile_fb_model + lanes * (passes * 10.8e-6 + (double)hprev * 2.4e-6);
+                        if (cost < best_cost) { best_cost = cost; best = bl; }
+                    }
+                    int total = 0;
+                    for (int v : plan) total += v;
+                    plan.assign((size_t)((total + best - 1) / best), best);
+                } else if (on_tiles && hprev >= 1 && hprev <= 7 && !plan.empty()) plan[0] = hprev <= 4 ? 4 : 7;
                 int t_after = 0;
                 for (int v : plan) t_after += v;
                 SpecK sk;

@@ -107,6 +107,7 @@ int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float
                  hipStream_t s);
 int tile_max_block();
 int tile_owned_rows();   // rows a tile of the default variant owns
+int tile_rows_for(const Geo &g);   // rows (owned + margins) of the tiles level g runs on
 int tb_query_plan(int T, const Geo &g, int *kernel, int *rows);   // kernel 0 = streaming (band height), 1 = register tile
 int tile_variants();
 bool tile_eligible(const Geo &g);   // this level (pixels x pairs) runs on the register-tile kernel

@@ -230,6 +230,11 @@ static int auto_variant(const Geo &g)
     return wgs < tuning().tile_small_wgs ? 4 : 0;
 }
 int tile_max_block() { return TILE_M; }
+int tile_rows_for(const Geo &g)
+{
+    const TileEntry &e = g_tile[auto_variant(g)];
+    return e.RW * e.NW;
+}
 int tile_owned_rows()
 {
     int v = tuning().tile_variant;
