@@ -1407,7 +1407,10 @@ def main():
         # (300 iterations, epsilon 0.01), a 640 x 480 frame pair -- and the same at 1080p
         for (ww, hh, tag) in ((640, 480, "reference_perf_test_scenario_640x480_class_defaults_single_calc"), (W, H, "class_defaults_single_pair_calc_sequential")):
             try:
-                q0, q1, _ = make_inputs(1, hh, ww, dev, distinct=1)
+                # the same pair again and again, as the reference's TEST_CYCLE does -- since round 4 that is also the best case of the
+                # handle's block-length history (exact); `..._three_scenes_in_turn` cycles three DIFFERENT synthetic scenes through the
+                # handle, so every estimate comes from another scene (consecutive frames of a video lie between the two)
+                q0, q1, _ = make_inputs(3, hh, ww, dev, distinct=3)
                 a1 = cuda.OpticalFlowDual_TVL1.create()
                 one = torch.empty((hh, ww, 2), dtype=torch.float32, device=dev)
                 for _ in range(2):
@@ -1418,6 +1421,14 @@ def main():
                     a1.calc(q0[0], q1[0], one)
                 torch.cuda.synchronize()
                 var[tag] = {"calcs_per_s": 8 / (time.perf_counter() - t1), "executed_iterations_per_warp_mean": float(np.mean(a1.lastIterations(0)))}
+                for i in range(3):
+                    a1.calc(q0[i], q1[i], one)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(9):
+                    a1.calc(q0[i % 3], q1[i % 3], one)
+                torch.cuda.synchronize()
+                var[tag]["calcs_per_s_three_scenes_in_turn"] = 9 / (time.perf_counter() - t1)
                 del a1, one, q0, q1
             except Exception as e:
                 var[tag] = {"error": repr(e)[:200]}

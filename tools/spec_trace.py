@@ -1,6 +1,6 @@
 """Print the decisions of the speculative steps (k_iterate_tbr MODE 1) of a class-default TV-L1 calc: per (scale, warp) and
 pair, the sequence of launches as  <block length run>[+accepted by the next launch's settling | R<k> = replay of k].
-Usage (GPU box): python tools/spec_trace.py [--pairs 4] [--slack 0]"""
+Usage (GPU box): python tools/spec_trace.py [--pairs 4] [--slack 0] [--calls 2 [--roll 1]]"""
 import argparse
 import ctypes as C
 import os
@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=4)
     ap.add_argument("--slack", type=int, default=0)
     ap.add_argument("--size", default="1080x1920")
+    ap.add_argument("--calls", type=int, default=1, help="calcs on the handle before the traced one's slots are read (2: the traced calc has the first one's block-length history)")
+    ap.add_argument("--roll", type=int, default=0, help="with --calls > 1: roll the batch by this many pairs between calls (history from other pairs)")
     a = ap.parse_args()
     import torch
     from opencv_contrib_amd import capi, cuda, synth
@@ -25,7 +27,9 @@ def main():
     I0 = torch.stack([torch.from_numpy(p[0]) for p in prs]).to(dev)
     I1 = torch.stack([torch.from_numpy(p[1]) for p in prs]).to(dev)
     alg = cuda.OpticalFlowDual_TVL1.create(stopSlack=a.slack)
-    alg.calc_batch(I0, I1)
+    for c in range(max(a.calls, 1)):
+        sh = (a.calls - 1 - c) * a.roll
+        alg.calc_batch(torch.roll(I0, sh, 0).contiguous(), torch.roll(I1, sh, 0).contiguous())
     torch.cuda.synchronize()
     cap = 20000
     buf = (C.c_int * (8 * cap))()
