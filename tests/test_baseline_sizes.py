@@ -429,6 +429,31 @@ def test_block_lengths_from_the_previous_calc_never_change_a_flow(gpu, sem):
     assert (np.array(counts) < 300).any()
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (1080, 1920)], ids=["perf_test_640x480", "1080p"])
+def test_single_calcs_at_baseline_sizes_with_and_without_history(gpu, shape):
+    """The reference's own calling pattern at its perf test's size (cudaoptflow/perf/perf_optflow.cpp:283-311) and at 1080p: one pair per
+    calc(), class defaults, three scenes in turn through ONE handle (its block-length history, host-seen counts, tile margins and the
+    warp kernels enqueued ahead are then wrong as often as right) against a fresh handle per calc -- flows and counts identical, twice
+    round the scenes."""
+    import torch
+    from opencv_contrib_amd import cuda
+    h, w = shape
+    pairs = [synth.flow_pair(h, w, seed=1234 + k)[:2] for k in range(3)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    want = []
+    for k in range(3):
+        a = cuda.OpticalFlowDual_TVL1.create()
+        want.append((a.calc(I0s[k], I1s[k]).clone(), a.lastIterations(0)))
+        torch.cuda.synchronize()
+    alg = cuda.OpticalFlowDual_TVL1.create()
+    for rep in range(2):
+        for k in (0, 0, 1, 2, 2, 1):
+            f = alg.calc(I0s[k], I1s[k])
+            assert torch.equal(f, want[k][0]), (rep, k)
+            assert alg.lastIterations(0) == want[k][1], (rep, k)
+    assert (np.array(want[0][1]) < 300).any()
+
+
 @pytest.mark.parametrize("iters", [1, 2, 3, 5, 7, 12, 23])
 @pytest.mark.parametrize("shape", [(16, 16), (21, 37), (64, 9), (5, 300), (97, 131)])
 def test_speculative_steps_iteration_limits_and_small_images(gpu, oracle, shape, iters):
