@@ -143,7 +143,9 @@ int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right,
     // stereoBM_CUDA: memset disp = 0 (stereobm.cu:506); the 0xFF fill of minSSD (:507) is not needed -- the
     // kernel writes every element it later reads
     MI_HIP_TRY(hipMemset2DAsync(disp->data, disp->step, 0, (size_t)cols, (size_t)rows, st));
-    if ((rc = sbm::block_match(le, ls, ri, rs, (unsigned char *)disp->data, (long long)disp->step, h->minssd, h->step, rows, cols,
+    // the winners' SSDs are the uniqueness pass's input only: without that test nothing reads them and the kernel does not store them
+    // (8.3 of the 11.8 MB a 1080p pair's launch wrote, profiles/r10 StereoBM traffic)
+    if ((rc = sbm::block_match(le, ls, ri, rs, (unsigned char *)disp->data, (long long)disp->step, P.uniqueness_ratio > 0 ? h->minssd : nullptr, h->step, rows, cols,
                                P.num_disparities, P.block_size, P.uniqueness_ratio, P.emulate_cuda_edge, st)))
         return rc;
     if (P.texture_threshold > 0) {                                       // stereobm.cpp:189-190
@@ -208,7 +210,7 @@ int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const 
         h->tab_host[i] = {le, ri, (unsigned char *)disps[i].data, ls, rs, (long long)disps[i].step};
     }
     MI_HIP_TRY(hipMemcpyAsync(h->tab_dev, h->tab_host.data(), sizeof(sbm::BmPair) * n, hipMemcpyHostToDevice, st));
-    if ((rc = sbm::block_match_batch(h->tab_dev, n, h->minssd, h->step, pp, rows, cols, P.num_disparities, P.block_size, P.uniqueness_ratio,
+    if ((rc = sbm::block_match_batch(h->tab_dev, n, P.uniqueness_ratio > 0 ? h->minssd : nullptr, h->step, pp, rows, cols, P.num_disparities, P.block_size, P.uniqueness_ratio,
                                      P.emulate_cuda_edge, st)))
         return rc;
     if (P.texture_threshold > 0) {

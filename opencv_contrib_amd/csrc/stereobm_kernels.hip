@@ -157,6 +157,7 @@ struct BmArgs {
     int emulate_edge;
     float thresh_scale;    // (float)(1.0 + uniquenessRatio / 100.0f)  stereobm.cu:273
     int batch;
+    int swz;               // XCD-contiguous tile order (MIFLOW_SBM_SWZ, default 1)
     const BmPair *tab;     // batch: blockIdx.z = pair, image pointers from this device table, minssd advances by mpair elements
     long long mpair;
 };
@@ -186,10 +187,23 @@ struct Cfg {
 template <int R, int MODE, bool WT = false>
 __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
 {
+    // XCD-contiguous tile order (A.swz): workgroups are dealt round-robin over the 8 XCDs in launch order, so neighbouring tiles of
+    // a row band -- which read the same rows of both images -- used to sit behind eight different L2s and every L2 fetched nearly the
+    // whole pair (r10p: 25 MB per pair fetched for 4.1 MB of images).  XCD k now takes the k-th contiguous eighth of the
+    // (pair, y, x) tiles.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (A.swz) {
+        const unsigned nxy = gridDim.x * gridDim.y, nwg = nxy * gridDim.z, orig = (bz * gridDim.y + by) * gridDim.x + bx;
+        const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
+        const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        bz = lid / nxy;
+        const unsigned rem = lid - bz * nxy;
+        by = rem / gridDim.x; bx = rem - by * gridDim.x;
+    }
     if (A.tab) {
-        const BmPair p = A.tab[blockIdx.z];
+        const BmPair p = A.tab[bz];
         A.left = p.left; A.right = p.right; A.disp = p.disp; A.lstep = p.lstep; A.rstep = p.rstep; A.dstep = p.dstep;
-        if (A.minssd) A.minssd += (long long)blockIdx.z * A.mpair;
+        if (A.minssd) A.minssd += (long long)bz * A.mpair;
     }
     using C = Cfg<R>;
     constexpr int TW = C::TW, NC = C::NC, LS = C::LS, NLW = C::NLW, NRW = C::NRW;
@@ -200,8 +214,8 @@ __global__ __launch_bounds__(256) void k_block_match(BmArgs A)
     const int ndp = nsets * 64;                        // padded disparity range
     const int d = wset * 64 + lane;
     const bool active = d < A.ndisp;
-    const int X0 = A.ndisp + R + blockIdx.x * TW;      // first output column of the tile
-    const int Y0 = R + blockIdx.y * A.rb;              // first output row
+    const int X0 = A.ndisp + R + (int)bx * TW;         // first output column of the tile
+    const int Y0 = R + (int)by * A.rb;                 // first output row
     const int nrows = min(A.rb, A.rows - R - Y0);
     const int ncols = min(TW, A.cols - R - X0);        // valid output columns (X < cols - R)
     if (nrows <= 0 || ncols <= 0) return;
@@ -735,6 +749,8 @@ static int block_match_impl(BmArgs &A, int winsz, int uniqueness_ratio, int pair
     rb = rb > 48 ? 48 : rb;   // taller bands cost occupancy (LDS per workgroup grows with rb): r02w at 1080p x 16: 32 | 48 | 64 | 96 rows = 4990 | 5070 | . | 4575 pairs/s
     if (const char *e = getenv("MIFLOW_SBM_ROWS")) rb = atoi(e) > 0 ? atoi(e) : rb;
     A.rb = rb;
+    A.swz = tuning().sbm_swz != 0 ? 1 : 0;
+    MI_REQUIRE(uniqueness_ratio <= 0 || A.minssd, MI_ERR_BAD_ARG, "the uniqueness test needs the winners' SSD plane");
     int rc = g_bm[R](A, 0, s);
     if (rc) return rc;
     if (uniqueness_ratio > 0) rc = g_bm[R](A, 1, s);

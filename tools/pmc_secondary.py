@@ -21,6 +21,7 @@ def main():
     out = json.load(open(path)) if os.path.exists(path) else {}
     for wl, (key, pred) in KEYS.items():
         vals = {}
+        split = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             rows = []
             for p in glob.glob(os.path.join(d, f"pmc_{wl}_{counter}", "**", "*counter_collection.csv"), recursive=True):
@@ -34,12 +35,28 @@ def main():
             gmax = max(g for g, _ in rows)
             sel = [v for g, v in rows if g == gmax] if wl == "farneback" else [v for _, v in rows]
             vals[counter] = (sum(sel) / len(sel), len(sel))
+            if wl == "stereobm":
+                # the mean over ALL launches mixes compute() (one pair per launch) with compute_batch() (B pairs per
+                # launch, the largest grid); keep the two apart
+                gmin = min(g for g, _ in rows)
+                one = [v for g, v in rows if g == gmin]
+                many = [v for g, v in rows if g == gmax]
+                split[counter] = {"one_pair_launch": (sum(one) / len(one), len(one), gmin), "batched_launch": (sum(many) / len(many), len(many), gmax)}
         if len(vals) == 2:
             f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
             out[key] = {"hbm_bytes_per_launch": (2 * f + w) * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
                         "launches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]],
                         "source": f"{label}: two separate rocprofv3 --pmc passes of `python bench.py --workload {wl} --no-cpu --steps 2 --warmup 1`, "
                                   "(FETCH_SIZE x 2 + WRITE_SIZE) x 1024, mean over the launches"}
+            if len(split) == 2:
+                for kind in ("one_pair_launch", "batched_launch"):
+                    ff, nf, g = split["FETCH_SIZE"][kind]
+                    ww, nw, _ = split["WRITE_SIZE"][kind]
+                    out[key][kind] = {"fetch_bytes": 2 * ff * 1024, "write_bytes": ww * 1024, "hbm_bytes": (2 * ff + ww) * 1024, "launches": [nf, nw], "grid_size": g}
+                b = int(os.environ.get("PMC_SBM_BATCH", "0"))
+                if b > 0:
+                    out[key]["batched_launch"]["pairs"] = b
+                    out[key]["batched_launch"]["hbm_bytes_per_pair"] = out[key]["batched_launch"]["hbm_bytes"] / b
             print(key, out[key])
     json.dump(out, open(path, "w"), indent=1)
 
