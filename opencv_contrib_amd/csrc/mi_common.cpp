@@ -52,6 +52,8 @@ const Tuning &tuning()
         }
         t.tile_variant = env_int("MIFLOW_TILE_VARIANT", -1);
         t.tile_small_wgs = env_int("MIFLOW_TILE_SMALL_WGS", 1024);
+        t.tile_swz = env_int("MIFLOW_TILE_SWZ", 1);
+        t.warp_swz = env_int("MIFLOW_WARP_SWZ", 1);
         t.tile_fb_block = env_int("MIFLOW_TILE_FB_BLOCK", 10);
         t.tile_fb_model = env_int("MIFLOW_TILE_FB_MODEL", 7);
         t.tile_spec = env_int("MIFLOW_TILE_SPEC", 1);

@@ -57,6 +57,7 @@ struct Tuning {
     int tile_variant;        // MIFLOW_TILE_VARIANT: index into the (rows per wave, waves) table of tvl1_tile_kernels.hip; -1 (default) = by grid size
     int tile_fb_block;       // MIFLOW_TILE_FB_BLOCK: block length of the speculative steps of a one-or-two-pair calc on the register-tile kernel
     int tile_fb_model;       // MIFLOW_TILE_FB_MODEL: a one-or-two-pair calc picks each warp's block length / tile margin (4 | 7 | 10) from the previous calc's count by a cost model; the value = its microseconds per pass (7, default; 0 = off)
+    int tile_swz, warp_swz;  // MIFLOW_TILE_SWZ / MIFLOW_WARP_SWZ: XCD-contiguous tile order of the register-tile kernel / the fused-gradient warp kernel (1, default)
     int tile_small_wgs;      // MIFLOW_TILE_SMALL_WGS: grids of fewer 64-row tiles than this run on the 48-row / 8-wave variant (1024)
     int lanes;               // MIFLOW_LANES: internal streams a TV-L1 batch is split over (0: automatic)
     int exact_tb;            // MIFLOW_EXACT_TB: exact math, fixed work: fused blocks (1) or one launch per iteration (0)

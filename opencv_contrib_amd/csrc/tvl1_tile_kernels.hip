@@ -36,6 +36,7 @@ struct TileArgs {
     float l_t, theta, taut;
     int cur;   // input set
     int nit;   // iterations of this launch, 1..10 (SPEC: the most this launch may run; the device picks the count)
+    int swz;   // XCD-contiguous tile order (MIFLOW_TILE_SWZ, default 1)
     // SPEC only: slot protocol of the speculative steps (tvl1_tb_dev.h spec_settle), e0 = index of the first error sum of this block
     CtlK ctl;
     SpecK sk;
@@ -66,7 +67,29 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int strip = blockIdx.x, band = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.z;
+    const long long pb = (long long)b * A.g.ps;
+    int cur = A.cur, nit = A.nit;
+    bool record = false;
+    if (SPEC) {
+        // every thread takes the same decision from the same device data: the whole workgroup leaves or stays
+        // (before the tile order is worked out: most launches of a batch's plan end right here, and the index arithmetic below showed
+        // in their cost; the writer is tile (0, 0) in either order)
+        if (!spec_settle(A.ctl, A.sk, A.nit, b, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, cur, nit, record)) return;
+    }
+    // XCD-contiguous tile order (round 4): workgroups are dealt round-robin over the 8 XCDs in launch order, and a tile loads its
+    // margins -- its neighbours' pixels -- itself: with the neighbours behind seven other L2s every margin came from HBM a second
+    // time (x 1.3 .. 2.1 of the planes per pass).  One XCD takes a contiguous eighth of a pair's (band, strip) tiles.
+    int strip = blockIdx.x, band = blockIdx.y;
+    if (A.swz == 1 || (A.swz == 2 && (!SPEC || gridDim.z <= 2))) {   // MIFLOW_TILE_SWZ = 2: not for the speculative steps of a batch
+        // within the pair's own (band, strip) plane: the tiles of one pair stay spread over all XCDs (pairs of a batch stop at
+        // different launches; a pair per XCD left the other XCDs idle: r10 class defaults 1080p x 4 390 -> 374 pairs/s).  The residue
+        // class of the in-plane index is one XCD whatever the plane's offset in launch order.
+        const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
+        const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        band = (int)(lid / gridDim.x); strip = (int)(lid - (unsigned)band * gridDim.x);
+    }
     const int W = A.g.w, H = A.g.h, ld = A.g.ld;
     const int y0 = band * BR, y1 = min(y0 + BR, H);
     const int own_lo = strip == 0 ? 0 : (LW - M) + (strip - 1) * STRIDE;
@@ -77,13 +100,6 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     const unsigned xc = 4u * (unsigned)min(xl, ld - 1);    // clamped column of the unconditional loads, bytes
     const int ys = y0 - M + wave * RW;                     // image row of this wave's first register row
 
-    const long long pb = (long long)b * A.g.ps;
-    int cur = A.cur, nit = A.nit;
-    bool record = false;
-    if (SPEC) {
-        // every thread takes the same decision from the same device data: the whole workgroup leaves or stays
-        if (!spec_settle(A.ctl, A.sk, A.nit, b, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0, cur, nit, record)) return;
-    }
     const float *const uin[2] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb};
     const float *const pin[4] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb};
     const float *const stp[4] = {A.pl.ix + pb, A.pl.iy + pb, A.pl.g + pb, A.pl.rc + pb};
@@ -258,7 +274,7 @@ int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float
     if (variant < 0 || variant >= kTileVariants) { set_error("register-tile kernel: no variant %d", variant); return MI_ERR_BAD_ARG; }
     TileArgs A;
     memset(&A, 0, sizeof(A));
-    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.nit = nit;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.nit = nit; A.swz = tuning().tile_swz;
     if (tuning().tb_verbose) {
         static int shown = 0;
         if (shown++ < 40)
@@ -275,7 +291,7 @@ int iterate_tile_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, floa
     const int variant = auto_variant(g);
     TileArgs A;
     memset(&A, 0, sizeof(A));
-    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.nit = T;
+    A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.nit = T; A.swz = tuning().tile_swz;
     A.ctl = make_ctlk(&ctl);
     A.sk = sk;
     A.e0 = e0;

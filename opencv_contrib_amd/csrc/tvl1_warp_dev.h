@@ -56,6 +56,7 @@ struct Warp6Args {
     const float *tab;  // 32x4 cubic phase table (CPU_REF)
     Geo g;
     WarpUp up;
+    int swz;           // XCD-contiguous tile order (MIFLOW_WARP_SWZ, default 1)
 };
 
 // pixels of a wave along x in the warp kernels (a 32 x 2 patch per wave measured best, profiles/r01u)

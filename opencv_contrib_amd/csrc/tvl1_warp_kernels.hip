@@ -286,9 +286,18 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
     }
     constexpr int TY = 64 / TX;   // rows per wave: a TX x TY patch per wave keeps the gather footprint compact
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * (TX * NP) + (lane_ % TX);
-    const int y = blockIdx.y * (4 * TY) + wave_ * TY + lane_ / TX;
-    const int b = blockIdx.z;
+    // XCD-contiguous tile order (round 4): the 6 x 6 windows of vertically neighbouring tiles share most of their rows of I1; dealt
+    // round-robin over the 8 XCDs in launch order they sat behind different L2s and every tile's halo rows came from HBM again
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (A.swz) {
+        const unsigned nwg = gridDim.x * gridDim.y, orig = by * gridDim.x + bx;   // within the pair's plane (see k_iterate_tile)
+        const unsigned xcd = orig & 7u, qq = nwg >> 3, rr = nwg & 7u;
+        const unsigned lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        by = lid / gridDim.x; bx = lid - by * gridDim.x;
+    }
+    const int x0 = (int)bx * (TX * NP) + (lane_ % TX);
+    const int y = (int)by * (4 * TY) + wave_ * TY + lane_ / TX;
+    const int b = (int)bz;
     const int W = A.g.w, H = A.g.h, ld = A.g.ld;
     if (x0 >= W || y >= H) return;
     if (!warp_gate_k(ctl, b)) return;
@@ -446,7 +455,7 @@ int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *
         if (semantics == MI_SEM_CPU_REF) { A.up.scx = 1.0 / zoom->inv_scale_x; A.up.scy = 1.0 / zoom->inv_scale_y; }
         else { A.up.scx = (double)(float)(1.0 / zoom->inv_scale_x); A.up.scy = (double)(float)(1.0 / zoom->inv_scale_y); }   // as tvl1::resize
     }
-    A.I0 = I0; A.I1 = I1;
+    A.I0 = I0; A.I1 = I1; A.swz = tuning().warp_swz != 0 ? 1 : 0;
     A.u1[0] = u1[0]; A.u1[1] = u1[1]; A.u2[0] = u2[0]; A.u2[1] = u2[1];
     A.I1w = I1w; A.I1wx = I1wx; A.I1wy = I1wy; A.grad = grad; A.rho = rho;
     A.tab = cubic_tab_dev;

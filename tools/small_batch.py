@@ -1,5 +1,5 @@
 """Batches of small frames and the coarse levels of larger ones (the register-tile kernel's territory): pairs per second, fixed work
-(N = 10, epsilon 0) and class defaults.  usage: python tools/small_batch.py"""
+(N = 10, epsilon 0) and class defaults.  usage: python tools/small_batch.py [cd | fixed]"""
 import os
 import sys
 import time
@@ -16,7 +16,8 @@ for (w, h, n) in ((320, 240, 16), (320, 240, 64), (640, 480, 16), (1280, 720, 8)
     I1 = torch.stack([torch.from_numpy(pairs[k % len(pairs)][1]) for k in range(n)]).to(dev)
     out = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
     res = []
-    for (it, eps) in ((10, 0.0), (300, 0.01)):
+    modes = ((10, 0.0), (300, 0.01)) if len(sys.argv) < 2 else (((300, 0.01),) if sys.argv[1] == "cd" else ((10, 0.0),))
+    for (it, eps) in modes:
         alg = cuda.OpticalFlowDual_TVL1.create(iterations=it, epsilon=eps)
         for _ in range(3):
             alg.calc_batch(I0, I1, out)
@@ -27,4 +28,7 @@ for (w, h, n) in ((320, 240, 16), (320, 240, 64), (640, 480, 16), (1280, 720, 8)
             alg.calc_batch(I0, I1, out)
         torch.cuda.synchronize()
         res.append(n * steps / (time.perf_counter() - t0))
-    print(f"{w}x{h} x {n} pairs: N=10 eps=0 {res[0]:.0f} pairs/s, class defaults {res[1]:.0f} pairs/s", flush=True)
+    if len(res) == 2:
+        print(f"{w}x{h} x {n} pairs: N=10 eps=0 {res[0]:.0f} pairs/s, class defaults {res[1]:.0f} pairs/s", flush=True)
+    else:
+        print(f"{w}x{h} x {n} pairs ({sys.argv[1]}): {res[0]:.0f} pairs/s", flush=True)
