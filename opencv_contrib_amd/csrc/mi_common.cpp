@@ -63,6 +63,7 @@ const Tuning &tuning()
         t.fb_tiled = env_int("MIFLOW_FB_TILED", 1);
         t.sbm_wt = env_int("MIFLOW_SBM_WT", 1);
         t.sbm_swz = env_int("MIFLOW_SBM_SWZ", 1);
+        t.sbm_texfuse = env_int("MIFLOW_SBM_TEXFUSE", 1);
         t.fb_rows = env_int("MIFLOW_FB_ROWS", 4) == 8 ? 8 : 4;
         t.fb_async = env_int("MIFLOW_FB_ASYNC", 0);   // r08i: the cross-stream events cost more than the 9 launches they take off the chain (2 718 vs 3 089 calc/s)
         t.fb_fuse = env_int("MIFLOW_FB_FUSE", -1);

@@ -62,6 +62,7 @@ struct Tuning {
     int lanes;               // MIFLOW_LANES: internal streams a TV-L1 batch is split over (0: automatic)
     int exact_tb;            // MIFLOW_EXACT_TB: exact math, fixed work: fused blocks (1) or one launch per iteration (0)
     int spec;                // MIFLOW_SPEC: speculative blocked convergence path (1) or one launch per iteration (0)
+    int sbm_texfuse;         // MIFLOW_SBM_TEXFUSE: StereoBM textureness post-filter in one launch without the |Sobel| plane (1, default) or as two passes (0)
     int sbm_swz;             // MIFLOW_SBM_SWZ: StereoBM tiles in XCD-contiguous order (1, default)
     int sbm_wt;              // MIFLOW_SBM_WT: StereoBM winner-take-all through an LDS transposition (1, default) or the transposed DPP reduction (0)
     int fb_rows, fb_swz;     // MIFLOW_FB_ROWS (4 | 8 rows per workgroup), MIFLOW_FB_SWZ (XCD-contiguous tile order) of the tiled kernel

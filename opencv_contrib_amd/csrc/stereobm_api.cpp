@@ -148,7 +148,10 @@ int mi_stereobm_compute(mi_stereobm *h, const mi_mat *left, const mi_mat *right,
     if ((rc = sbm::block_match(le, ls, ri, rs, (unsigned char *)disp->data, (long long)disp->step, P.uniqueness_ratio > 0 ? h->minssd : nullptr, h->step, rows, cols,
                                P.num_disparities, P.block_size, P.uniqueness_ratio, P.emulate_cuda_edge, st)))
         return rc;
-    if (P.texture_threshold > 0) {                                       // stereobm.cpp:189-190
+    if (P.texture_threshold > 0 && tuning().sbm_texfuse != 0) {         // stereobm.cpp:189-190, one launch (k_textureness_fused)
+        rc = sbm::textureness_fused(le, ls, (unsigned char *)disp->data, (long long)disp->step, nullptr, 1, rows, cols, P.block_size,
+                                    P.texture_threshold, st);
+    } else if (P.texture_threshold > 0) {
         if (!h->tex) {
             int sld, sh;
             sbm::textureness_scratch_dims(h->cap_rows, h->cap_cols, &sld, &sh);
@@ -213,7 +216,9 @@ int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const 
     if ((rc = sbm::block_match_batch(h->tab_dev, n, P.uniqueness_ratio > 0 ? h->minssd : nullptr, h->step, pp, rows, cols, P.num_disparities, P.block_size, P.uniqueness_ratio,
                                      P.emulate_cuda_edge, st)))
         return rc;
-    if (P.texture_threshold > 0) {
+    if (P.texture_threshold > 0 && tuning().sbm_texfuse != 0) {   // the post-filter of all pairs in one launch (the block matcher's table)
+        if ((rc = sbm::textureness_fused(nullptr, 0, nullptr, 0, h->tab_dev, n, rows, cols, P.block_size, P.texture_threshold, st))) return rc;
+    } else if (P.texture_threshold > 0) {
         if (!h->tex) {
             int sld, sh;
             sbm::textureness_scratch_dims(h->cap_rows, h->cap_cols, &sld, &sh);
@@ -271,6 +276,9 @@ int mi_stereobm_textureness(const mi_mat *img, mi_mat *disp, int winsz, float av
     if ((rc = check_u8(img, "input")) || (rc = check_u8(disp, "disparity"))) return rc;
     MI_REQUIRE(img->rows == disp->rows && img->cols == disp->cols, MI_ERR_BAD_SIZE, "size mismatch");
     MI_REQUIRE(winsz % 2 == 1 && winsz / 2 <= 25, MI_ERR_BAD_ARG, "Unsupported window size");
+    if (tuning().sbm_texfuse != 0)
+        return sbm::textureness_fused((const unsigned char *)img->data, (long long)img->step, (unsigned char *)disp->data, (long long)disp->step,
+                                      nullptr, 1, img->rows, img->cols, winsz, avg_texture_threshold, (hipStream_t)stream);
     int sld, sh;
     sbm::textureness_scratch_dims(img->rows, img->cols, &sld, &sh);
     int *S = nullptr;

@@ -22,6 +22,8 @@ int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst
                    int cap, int winsize, hipStream_t s);
 // S: int scratch of textureness_scratch_dims() = sld x sh elements
 void textureness_scratch_dims(int rows, int cols, int *sld, int *sh);
+int textureness_fused(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, const BmPair *tab_dev, int pairs,
+                      int rows, int cols, int winsz, float avg_threshold, hipStream_t s);   // one launch, no scratch plane; bit-identical
 int textureness(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, int rows, int cols,
                 int winsz, float avg_threshold, int *S, hipStream_t s);
 int dbg_wave_min(const unsigned *in_dev, unsigned *out_dev, hipStream_t s);

@@ -693,6 +693,75 @@ __global__ __launch_bounds__(256) void k_textureness(const int *S, int sld, unsi
     }
 }
 
+// The two passes above in ONE launch and without the |Sobel| plane (round 4): the S plane cost 8.8 MB written and 28 MB read per 1080p
+// pair (its rows fetched once per XCD) and the post-filter two launches per pair -- 27 of the ~180 us a pair of a batch took.  A workgroup
+// owns 64 x 32 pixels: it forms B on the tile extended by W2 + 1 (texel-wise clamped reads, tex_box4), S = |x-Sobel of B| on the tile
+// extended by W2, both as 16-bit words in LDS (B <= 1020, S <= 4080), then every wave slides the column sums of its 8 rows exactly
+// as k_textureness does.  Integer arithmetic throughout: the same sums, the same comparison, the same disparities.  blockIdx.z = pair
+// of a batch (images and maps from the block matcher's table).
+#define TEXF_ROWS 32
+__global__ __launch_bounds__(256) void k_textureness_fused(const unsigned char *img, long long istep, unsigned char *disp, long long dstep,
+                                                           const BmPair *tab, int rows, int cols, int winsz, float threshold)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (tab) {
+        const BmPair p = tab[blockIdx.z];
+        img = p.left; istep = p.lstep; disp = p.disp; dstep = p.dstep;
+    }
+    const int W2 = winsz / 2;                          // <= 25
+    const int TC = 64 + 2 * W2, TRR = TEXF_ROWS + 2 * W2;   // S tile
+    const int BC = TC + 2, BR = TRR + 2;               // B tile
+    unsigned short *Bs = reinterpret_cast<unsigned short *>(smem);
+    unsigned short *Ss = Bs + BR * BC;
+    int *cs = reinterpret_cast<int *>(Ss + ((TRR * TC + 1) & ~1)) + (threadIdx.x >> 6) * 128;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TEXF_ROWS;
+    for (int i = threadIdx.x; i < BR * BC; i += 256) {
+        const int r = i / BC, c = i - r * BC;
+        Bs[i] = (unsigned short)tex_box4(img, istep, rows, cols, x0 - W2 - 1 + c, y0 - W2 - 1 + r);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TRR * TC; i += 256) {
+        const int r = i / TC, c = i - r * TC;
+        const unsigned short *b = Bs + r * BC + c;     // B(x - 1, y - 1) of S(x, y)
+        const int v = -(int)b[0] + (int)b[2] - 2 * (int)b[BC] + 2 * (int)b[BC + 2] - (int)b[2 * BC] + (int)b[2 * BC + 2];
+        Ss[i] = (unsigned short)abs(v);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = x0 + lane;
+    const int rb = wv * (TEXF_ROWS / 4);               // this wave's first row inside the tile
+    const int yb = y0 + rb;
+    if (yb >= rows) return;
+    const int ye = min(yb + TEXF_ROWS / 4, rows);
+    // column sums of S columns `lane` and `64 + lane` of the tile (the window of output column lane covers tile columns lane .. lane + 2 W2)
+    const bool has1 = 64 + lane < TC;
+    int s0 = 0, s1 = 0;
+    for (int i = 0; i <= 2 * W2; ++i) {
+        s0 += Ss[(rb + i) * TC + lane];
+        if (has1) s1 += Ss[(rb + i) * TC + 64 + lane];
+    }
+    for (int y = yb; y < ye; ++y) {
+        const int r = y - y0;
+        cs[lane] = s0;
+        cs[64 + lane] = s1;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (x < cols) {
+            const long long o = (long long)y * dstep + x;
+            if (disp[o]) {
+                long long sum = 0;
+                for (int j = 0; j <= 2 * W2; ++j) sum += cs[lane + j];
+                if ((float)sum * 0.25f < threshold) disp[o] = 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (y + 1 < ye) {
+            s0 += (int)Ss[(r + 1 + 2 * W2) * TC + lane] - (int)Ss[r * TC + lane];
+            if (has1) s1 += (int)Ss[(r + 1 + 2 * W2) * TC + 64 + lane] - (int)Ss[r * TC + 64 + lane];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host launchers
 template <int R>
 static int launch_bm(const BmArgs &A, int mode, hipStream_t s)
@@ -817,6 +886,22 @@ int textureness(const unsigned char *img, long long istep, unsigned char *disp, 
     hipLaunchKernelGGL(k_tex_sobel, dim3(div_up(sld, 64), div_up(sh, 4)), dim3(256), 0, s, img, istep, rows, cols, S, sld, sh);
     hipLaunchKernelGGL(k_textureness, dim3(div_up(cols, 64), div_up(div_up(rows, TEX_RPW), 4)), dim3(256), 0, s, (const int *)S, sld, disp,
                        dstep, rows, cols, winsz, threshold);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// the fused form (k_textureness_fused); tab_dev != null: `pairs` pairs of the block matcher's table in one launch
+int textureness_fused(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, const BmPair *tab_dev, int pairs,
+                      int rows, int cols, int winsz, float avg_threshold, hipStream_t s)
+{
+    const float threshold = avg_threshold * (float)(winsz * winsz);   // stereobm.cu:700
+    const int W2 = winsz / 2;
+    MI_REQUIRE(W2 >= 0 && W2 <= 25, MI_ERR_BAD_ARG, "Unsupported window size");
+    const int TC = 64 + 2 * W2, TRR = TEXF_ROWS + 2 * W2;
+    const size_t lds = sizeof(unsigned short) * ((size_t)(TRR + 2) * (TC + 2) + (((size_t)TRR * TC + 1) & ~(size_t)1)) + sizeof(int) * 4 * 128;
+    (void)hipFuncSetAttribute((const void *)k_textureness_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_textureness_fused, dim3(div_up(cols, 64), div_up(rows, TEXF_ROWS), tab_dev ? pairs : 1), dim3(256), lds, s, img, istep, disp,
+                       dstep, tab_dev, rows, cols, winsz, threshold);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

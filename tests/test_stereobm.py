@@ -220,7 +220,7 @@ def test_prefilters_and_textureness_bit_exact(gpu, oracle):
     img2 = np.rint(synth.texture(131, 203, 3, 4.0)).astype(np.uint8)
     img2[:, :70] = 120
     disp = rng.integers(1, 60, size=img2.shape).astype(np.uint8)
-    for ws, thr in ((9, 3.0), (19, 3.0), (15, 10.0)):
+    for ws, thr in ((9, 3.0), (19, 3.0), (15, 10.0), (51, 3.0), (5, 6.0), (33, 4.0)):   # 51: the largest window (round 4: the one-launch form's LDS tile)
         ref = oracle.sbm_textureness(img2, disp, ws, thr)
         assert (ref != disp).any() and (ref == disp).any()
         np.testing.assert_array_equal(N(cuda.stereobm_textureness(T(img2, gpu), T(disp, gpu), ws, thr)), ref)
