@@ -209,10 +209,10 @@ int mi_stereobm_compute_batch(mi_stereobm *h, int n, const mi_mat *lefts, const 
             }
             le = lb; ri = rb; ls = rs = h->step;
         }
-        MI_HIP_TRY(hipMemset2DAsync(disps[i].data, disps[i].step, 0, (size_t)cols, (size_t)rows, st));
         h->tab_host[i] = {le, ri, (unsigned char *)disps[i].data, ls, rs, (long long)disps[i].step};
     }
     MI_HIP_TRY(hipMemcpyAsync(h->tab_dev, h->tab_host.data(), sizeof(sbm::BmPair) * n, hipMemcpyHostToDevice, st));
+    if ((rc = sbm::zero_disp_batch(h->tab_dev, n, rows, cols, st))) return rc;   // stereobm.cu:506, all pairs in one launch
     if ((rc = sbm::block_match_batch(h->tab_dev, n, P.uniqueness_ratio > 0 ? h->minssd : nullptr, h->step, pp, rows, cols, P.num_disparities, P.block_size, P.uniqueness_ratio,
                                      P.emulate_cuda_edge, st)))
         return rc;

@@ -22,6 +22,7 @@ int prefilter_norm(const unsigned char *src, long long sstep, unsigned char *dst
                    int cap, int winsize, hipStream_t s);
 // S: int scratch of textureness_scratch_dims() = sld x sh elements
 void textureness_scratch_dims(int rows, int cols, int *sld, int *sh);
+int zero_disp_batch(const BmPair *tab_dev, int pairs, int rows, int cols, hipStream_t s);   // disp := 0 of every pair, one launch
 int textureness_fused(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, const BmPair *tab_dev, int pairs,
                       int rows, int cols, int winsz, float avg_threshold, hipStream_t s);   // one launch, no scratch plane; bit-identical
 int textureness(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, int rows, int cols,

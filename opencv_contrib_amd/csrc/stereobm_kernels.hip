@@ -890,6 +890,27 @@ int textureness(const unsigned char *img, long long istep, unsigned char *disp, 
     return MI_OK;
 }
 
+// disp := 0 for every pair of a batch in one launch (stereobm.cu:506 does it per pair; n small fills were n dependent launches)
+__global__ __launch_bounds__(256) void k_zero_disp_batch(const BmPair *tab, int rows, int cols)
+{
+    const BmPair p = tab[blockIdx.z];
+    const int y = blockIdx.y;
+    unsigned char *row = p.disp + (long long)y * p.dstep;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 16;
+    if (x4 >= cols) return;
+    if (x4 + 16 <= cols && ((reinterpret_cast<unsigned long long>(row + x4) & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(row + x4) = make_uint4(0, 0, 0, 0);
+    } else {
+        for (int k = 0; k < 16 && x4 + k < cols; ++k) row[x4 + k] = 0;
+    }
+}
+int zero_disp_batch(const BmPair *tab_dev, int pairs, int rows, int cols, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_zero_disp_batch, dim3(div_up(cols, 256 * 16), rows, pairs), dim3(256), 0, s, tab_dev, rows, cols);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 // the fused form (k_textureness_fused); tab_dev != null: `pairs` pairs of the block matcher's table in one launch
 int textureness_fused(const unsigned char *img, long long istep, unsigned char *disp, long long dstep, const BmPair *tab_dev, int pairs,
                       int rows, int cols, int winsz, float avg_threshold, hipStream_t s)
