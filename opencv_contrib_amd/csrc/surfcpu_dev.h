@@ -390,7 +390,8 @@ inline void make_tables(Tables &T)
         const double scale2 = -0.5 / (sigma * sigma);
         double w[64], sum = 0;
         for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = exp(scale2 * x * x); sum += w[i]; }
-        for (int i = 0; i < n; ++i) k[i] = (float)(w[i] / sum);
+        sum = 1. / sum;   // the main repo multiplies by the reciprocal (getGaussianKernelBitExact)
+        for (int i = 0; i < n; ++i) k[i] = (float)(w[i] * sum);
     };
     float g13[13], g20[PATCH_SZ];
     gauss(13, 2.5, g13);
@@ -398,7 +399,8 @@ inline void make_tables(Tables &T)
     for (int i = -6; i <= 6; ++i)
         for (int j = -6; j <= 6; ++j)
             if (i * i + j * j <= 36) { T.ax[n] = (signed char)i; T.ay[n] = (signed char)j; T.aw[n++] = g13[i + 6] * g13[j + 6]; }
-    gauss(PATCH_SZ, 3.3, g20);
+    gauss(PATCH_SZ, (double)3.3f, g20);   // SURF_DESC_SIGMA is a float constant (surf.cpp:121) promoted to double: 3.2999999523 (round 4: found by the
+                                          // verbatim build of the reference class, oracle/_ref/libref_surfcpu.so -- 3.3 was 1 ulp off in ~20 % of the entries)
     for (int i = 0; i < PATCH_SZ; ++i) for (int j = 0; j < PATCH_SZ; ++j) T.dw[i * PATCH_SZ + j] = g20[i] * g20[j];
 }
 

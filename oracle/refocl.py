@@ -39,7 +39,11 @@ def build(force: bool = False) -> bool:
 
 
 def available() -> bool:
-    return all(os.path.exists(p) for p in (lib_path(False), lib_path(True), cpu_lib_path(), os.path.join(_DIR, "libref_cu.so")))
+    return all(os.path.exists(p) for p in (lib_path(False), lib_path(True), cpu_lib_path(), os.path.join(_DIR, "libref_cu.so"), surfcpu_lib_path()))
+
+
+def surfcpu_lib_path() -> str:
+    return os.path.join(_DIR, "libref_surfcpu.so")
 
 
 def cpu_lib_path() -> str:
@@ -203,3 +207,46 @@ def cpu_tvl1_calc(I0, I1, tau=0.25, lambda_=0.15, theta=0.3, nscales=5, warps=5,
     if rc:
         raise ValueError(f"the reference class threw (rc {rc})")
     return flow, ns.value
+
+
+# ------------------------------------------------------------------------- the reference's CPU SURF class (surf.cpp, verbatim)
+_surfcpu = None
+
+
+def surfcpu_lib():
+    """oracle/_ref/libref_surfcpu.so: modules/xfeatures2d/src/surf.cpp compiled verbatim (with the reference's own surf.hpp / nonfree.hpp)
+    against the stub headers of oracle/refshim/cvsurf; integral / resize(INTER_AREA) / getGaussianKernel / phase / cvRound are the
+    restatements of oracle/surfcpu_ref.c (the main repo is not under /root/reference)."""
+    global _surfcpu
+    if _surfcpu is None:
+        if not os.path.exists(surfcpu_lib_path()):
+            build()
+        L = C.CDLL(surfcpu_lib_path())
+        L.ref_surfcpu_detect_and_compute.restype = C.c_int
+        L.ref_surfcpu_detect_and_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _surfcpu = L
+    return _surfcpu
+
+
+def surfcpu_detect_and_compute(img, hessian_threshold=100.0, n_octaves=4, n_octave_layers=3, extended=False, upright=False, mask=None,
+                               want_desc=True, keypoints=None, cap=65536):
+    """cv::xfeatures2d::SURF::create(...)->detectAndCompute(img, mask, keypoints, descriptors, useProvidedKeypoints) -- the reference
+    class itself.  keypoints (n x 7: x, y, size, angle, response, octave, class_id) given = useProvidedKeypoints.  Returns (keypoints,
+    descriptors or None)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    assert img.ndim == 2
+    kp = np.zeros((cap, 7), np.float32)
+    n_in = 0
+    if keypoints is not None:
+        n_in = len(keypoints)
+        kp[:n_in] = np.asarray(keypoints, np.float32)
+    dc = 128 if extended else 64
+    d = np.zeros((cap, dc), np.float32) if want_desc else None
+    m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+    n = surfcpu_lib().ref_surfcpu_detect_and_compute(img.ctypes.data, m.ctypes.data if m is not None else None, img.shape[0], img.shape[1],
+                                                     float(hessian_threshold), n_octaves, n_octave_layers, int(extended), int(upright),
+                                                     int(keypoints is not None), n_in, kp.ctypes.data, cap, d.ctypes.data if d is not None else None)
+    if n < 0:
+        raise RuntimeError(f"ref_surfcpu_detect_and_compute failed: {n}")
+    return kp[:n].copy(), (d[:n].copy() if d is not None else None)

@@ -60,7 +60,8 @@ static void gauss_kernel(int n, double sigma, float *k)   /* getGaussianKernel(n
     const double scale2 = -0.5 / (sigma * sigma);
     double w[64], sum = 0;
     for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; w[i] = exp(scale2 * x * x); sum += w[i]; }
-    for (int i = 0; i < n; ++i) k[i] = (float)(w[i] / sum);
+    sum = 1. / sum;   /* the main repo multiplies by the reciprocal (getGaussianKernelBitExact); so does refshim/cudahost's restatement */
+    for (int i = 0; i < n; ++i) k[i] = (float)(w[i] * sum);
 }
 
 static void integral_u8(const uint8_t *img, int rows, int cols, int *sum)   /* (rows+1) x (cols+1), CV_32S */
@@ -332,7 +333,8 @@ int orc_surfcpu_compute(const uint8_t *img, int rows, int cols, float *kp, int n
     for (int i = -ORI_RADIUS; i <= ORI_RADIUS; ++i)
         for (int j = -ORI_RADIUS; j <= ORI_RADIUS; ++j)
             if (i * i + j * j <= ORI_RADIUS * ORI_RADIUS) { aptx[n_ori] = i; apty[n_ori] = j; aptw[n_ori++] = g13[i + ORI_RADIUS] * g13[j + ORI_RADIUS]; }
-    gauss_kernel(PATCH_SZ, 3.3, g20);
+    gauss_kernel(PATCH_SZ, (double)3.3f, g20);   /* SURF_DESC_SIGMA is a FLOAT constant (surf.cpp:121) promoted to double: 3.2999999523.  Found by the
+                                                  * verbatim build of the class (libref_surfcpu.so): 3.3 gave descriptors 1 ulp off in ~20 % of the entries */
     for (int i = 0; i < PATCH_SZ; ++i) for (int j = 0; j < PATCH_SZ; ++j) DW[i * PATCH_SZ + j] = g20[i] * g20[j];
     static const int dx_s[2][5] = {{0, 0, 2, 4, -1}, {2, 0, 4, 4, 1}}, dy_s[2][5] = {{0, 0, 4, 2, 1}, {0, 2, 4, 4, -1}};
     int rc = 0;
@@ -450,4 +452,19 @@ int orc_surfcpu_compute(const uint8_t *img, int rows, int cols, float *kp, int n
     }
     free(sum);
     return rc;
+}
+
+/* ---- the restated main-repo functions, exported for oracle/refshim/cvsurf (libref_surfcpu.so: the reference's own surf.cpp compiled
+ * verbatim calls cv::integral / resize / getGaussianKernel / phase / cvRound, which are not under /root/reference) ---- */
+float orc_cv_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+void orc_cv_gauss_kernel(int n, double sigma, float *k) { gauss_kernel(n, sigma, k); }
+int orc_cv_round(double v) { return cv_round(v); }
+int orc_cv_resize_area_u8(const uint8_t *src, int n, uint8_t *dst, int m) { return resize_area_u8(src, n, dst, m); }
+void orc_cv_integral_u8(const uint8_t *img, long long step, int rows, int cols, int *sum)
+{
+    if (step == cols) { integral_u8(img, rows, cols, sum); return; }
+    uint8_t *dense = (uint8_t *)malloc((size_t)rows * cols);
+    for (int y = 0; y < rows; ++y) memcpy(dense + (size_t)y * cols, img + (size_t)y * step, (size_t)cols);
+    integral_u8(dense, rows, cols, sum);
+    free(dense);
 }

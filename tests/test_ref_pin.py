@@ -269,3 +269,60 @@ def test_hip_stages_against_reference_kernels(gpu, h, w, seed):
                                   float(l_t), float(theta), float(taut), niter=1, exact=True)
     for k, (name, g) in enumerate(zip(("u1", "u2", "p11", "p12", "p21", "p22"), uo + po)):
         assert np.abs(g.cpu().numpy() - r[1 + k]).max() <= 2e-6 * max(1.0, float(np.abs(r[1 + k]).max())), name
+
+
+# ------------------------------------------------------------------ the reference's CPU SURF class, verbatim (round 4)
+def _java_cross():
+    img = np.full((100, 100), 255, np.uint8)   # getTestImg() of the Java tests, see tests/test_zz_surf_cpu_class.py::java_cross
+    img[49:52, 20:80] = 100
+    img[20:80, 49:52] = 100
+    return img
+
+
+def test_surf_cpu_class_verbatim_reproduces_the_java_golden_vectors():
+    """oracle/_ref/libref_surfcpu.so = modules/xfeatures2d/src/surf.cpp compiled VERBATIM against oracle/refshim/cvsurf (VERDICT r03,
+    missing item 4): the class itself -- not a restatement -- gives the known answers of SURFFeatureDetectorTest.java:52-57,100-126 and
+    SURFDescriptorExtractorTest.java:38-69 within those tests' EPS."""
+    from oracle import refocl
+    from tests.test_zz_surf_cpu_class import JAVA_TRUTH, JAVA_DESCRIPTOR, EPS
+    kp, _ = refocl.surfcpu_detect_and_compute(_java_cross(), 8000, 3, 4, extended=True, upright=False, want_desc=False)
+    kp = kp[np.argsort(kp[:, 3])]
+    assert kp.shape == (4, 7)
+    np.testing.assert_allclose(kp[:, :5], JAVA_TRUTH[:, :5], rtol=0, atol=EPS)
+    np.testing.assert_array_equal(kp[:, 5:], JAVA_TRUTH[:, 5:])
+    mask = np.full((100, 100), 255, np.uint8)
+    mask[:, 50:] = 0
+    km, _ = refocl.surfcpu_detect_and_compute(_java_cross(), 8000, 3, 4, extended=True, upright=False, mask=mask, want_desc=False)
+    km = km[np.argsort(km[:, 3])]
+    np.testing.assert_allclose(km[:, :5], JAVA_TRUTH[1:3, :5], rtol=0, atol=EPS)
+    one = np.array([[55.775577545166016, 44.224422454833984, 16, 9.754629, 8617.863, 1, -1]], np.float32)
+    k2, d = refocl.surfcpu_detect_and_compute(_java_cross(), 100, 2, 4, extended=True, upright=False, keypoints=one)
+    assert d.shape == (1, 128) and np.abs(d[0] - JAVA_DESCRIPTOR).max() < 1e-6 and abs(k2[0, 3] - 350.24573) < EPS
+
+
+@pytest.mark.parametrize("shape,seed", [((240, 320), 7), ((300, 400), 11), ((480, 640), 3)])
+@pytest.mark.parametrize("extended,upright", [(False, False), (True, False), (False, True)])
+def test_surf_cpu_class_restatement_equals_the_verbatim_class(oracle, shape, seed, extended, upright):
+    """oracle/surfcpu_ref.c (what the GPU-side acceptance tests use as the CPU class) against the class itself on blob images, detector and
+    descriptors, also through a mask and for provided keypoints: BIT-identical keypoints (position, size, angle, response, octave,
+    Laplacian sign) and descriptors.  (This pin found the restatement's one deviation: the descriptor weights' sigma is the FLOAT
+    constant 3.3f promoted to double, surf.cpp:121,560 -- with 3.3 a fifth of the descriptor entries were 1 ulp off.)"""
+    from oracle import refocl
+    from opencv_contrib_amd import synth
+    img = synth.blob_image(shape[0], shape[1], seed=seed)
+    a_kp, a_d = refocl.surfcpu_detect_and_compute(img, 400, 4, 2, extended=extended, upright=upright)
+    b_kp, b_d = oracle.surfcpu_detect_and_compute(img, 400, 4, 2, extended=extended, upright=upright)
+    assert len(a_kp) > 30
+    np.testing.assert_array_equal(a_kp, b_kp)
+    np.testing.assert_array_equal(a_d, b_d)
+    mask = np.zeros(shape, np.uint8)
+    mask[shape[0] // 5:, : 3 * shape[1] // 4] = 255
+    m_kp, _ = refocl.surfcpu_detect_and_compute(img, 400, 4, 2, extended=extended, upright=upright, mask=mask, want_desc=False)
+    n_kp, _ = oracle.surfcpu_detect_and_compute(img, 400, 4, 2, extended=extended, upright=upright, mask=mask, want_desc=False)
+    assert 0 < len(m_kp) < len(a_kp)
+    np.testing.assert_array_equal(m_kp, n_kp)
+    p_kp, p_d = refocl.surfcpu_detect_and_compute(img, 400, 4, 2, extended=extended, upright=upright, keypoints=a_kp[::3])
+    q_kp, q_d = oracle.surfcpu_compute(img, a_kp[::3], extended=extended, upright=upright)
+    keep = q_kp[:, 2] > 0
+    np.testing.assert_array_equal(p_kp, q_kp[keep])
+    np.testing.assert_array_equal(p_d, q_d[keep])
