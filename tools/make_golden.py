@@ -108,6 +108,11 @@ def late_additions():
     img = synth.blob_image(160, 200, seed=7)
     kp = O.surfcpu_detect(img, 300.0, 3, 2)
     k2, d2 = O.surfcpu_compute(img, kp, True, False)
+    # round 4: keypoints and descriptors of this fixture are the output of the REFERENCE'S OWN class (oracle/_ref/libref_surfcpu.so =
+    # xfeatures2d/src/surf.cpp compiled verbatim), which the restatement equals bit for bit
+    from oracle import refocl
+    rk, rd = refocl.surfcpu_detect_and_compute(img, 300.0, 3, 2, extended=True, upright=False)
+    assert np.array_equal(rk, k2[k2[:, 2] > 0]) and np.array_equal(rd, d2[k2[:, 2] > 0])
     np.savez_compressed(os.path.join(OUT, "surfcpu_160x200_thr300_ext.npz"), img=img, detected=kp, keypoints=k2, descriptors=d2,
                         params=np.array(json.dumps(dict(hessian_threshold=300.0, n_octaves=3, n_octave_layers=2, extended=True, upright=False))))
     I0, I1, _ = synth.flow_pair(120, 160, seed=1234, dtype="u8")
