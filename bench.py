@@ -778,6 +778,22 @@ def bench_surf(args):
         ct = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / ct, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": f"1 frame {W}x{H}, {r['n']} features, {ct:.1f} s wall, oracle/surf_ref.c (OpenMP in det/trace and descriptors)"}
+        # round 4: the reference's OWN CPU class (xfeatures2d/src/surf.cpp compiled verbatim, oracle/_ref/libref_surfcpu.so; the stub's
+        # parallel_for_ runs its invokers on OpenMP stripes) on the same frame with the same octaves / layers -- the baseline of kind
+        # "reference"; the port above (the CUDA class's arithmetic on the host) stays beside it
+        try:
+            from oracle import refocl
+            if os.path.exists(refocl.surfcpu_lib_path()):
+                t0 = time.perf_counter()
+                kp_c, _ = refocl.surfcpu_detect_and_compute(img, 400.0, 4, 2, extended=False, upright=False)
+                cr = time.perf_counter() - t0
+                port = out["cpu_baseline"]
+                out["cpu_baseline"] = {"value": 1.0 / cr, "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference",
+                                       "sample": f"1 frame {W}x{H}, {len(kp_c)} features, {cr:.1f} s wall, cv::xfeatures2d::SURF (surf.cpp verbatim, stub core, "
+                                                 "OpenMP stripes), hessianThreshold 400, 4 octaves x 2 layers",
+                                       "port_of_the_cuda_class": port}
+        except Exception as e:
+            out["cpu_baseline"]["reference_cpu_class_error"] = repr(e)[:200]
     return out
 
 

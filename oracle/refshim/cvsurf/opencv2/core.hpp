@@ -15,6 +15,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define CV_EXPORTS
 #define CV_EXPORTS_W
@@ -233,8 +236,23 @@ public:
     virtual ~ParallelLoopBody() {}
     virtual void operator()(const Range &range) const = 0;
 };
-// serial: the class sorts its keypoints afterwards (KeypointGreater), so the order of execution does not show
-inline void parallel_for_(const Range &r, const ParallelLoopBody &body, double = -1.) { if (r.end > r.start) body(r); }
+// OpenMP stripes (the main repo's parallel_for_ runs the body on sub-ranges from a thread pool): the class guards its shared keypoint
+// vector with a Mutex and sorts it afterwards (KeypointGreater), so neither the striping nor the order of execution shows
+inline void parallel_for_(const Range &r, const ParallelLoopBody &body, double = -1.)
+{
+    const int n = r.end - r.start;
+    if (n <= 0) return;
+    int stripes = 1;
+#ifdef _OPENMP
+    stripes = std::min(n, 4 * omp_get_max_threads());
+#endif
+    if (stripes <= 1) { body(r); return; }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int k = 0; k < stripes; ++k) {
+        const int a = r.start + (int)((long long)n * k / stripes), b = r.start + (int)((long long)n * (k + 1) / stripes);
+        if (b > a) body(Range(a, b));
+    }
+}
 
 namespace ocl { inline bool useOpenCL() { return false; } }
 
