@@ -787,7 +787,9 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                                             MI_REQUIRE(false, MI_ERR_HIP, "host feedback: launch finished without publishing its decision");
                                         }
                                     }
+#if defined(__x86_64__) || defined(__i386__)
                                     __builtin_ia32_pause();
+#endif
                                 }
                                 all_before = all_before && (v & 2);
                                 all = all && (v & 1);
