@@ -130,3 +130,18 @@ def test_identical_frames_give_exactly_zero_flow(oracle, dtype):
         assert np.abs(oracle.pyrlk_dense(I0, I0)).max() == 0.0
         fb = np.abs(oracle.fb_calc(I0, I0)).max(-1)
         assert fb[12:-12, 12:-12].max() < 1e-3 and 0 < fb.max() < 0.5
+
+
+def test_xcd_contiguous_tile_order_is_a_permutation():
+    """The workgroup remap of k_iterate_tile / k_warp6 / k_block_match / k_iterate_tbr (round 4: `lid` from the launch-order index
+    `orig`; XCD = orig mod 8 takes a contiguous run of tiles): for every grid size it must be a bijection of [0, nwg) -- every tile
+    computed exactly once -- and the tiles of one XCD must be consecutive."""
+    import numpy as np
+    for nwg in list(range(1, 300)) + [1020, 1023, 1024, 1025, 4400, 35937]:
+        orig = np.arange(nwg, dtype=np.int64)
+        xcd, qq, rr = orig & 7, nwg >> 3, nwg & 7
+        lid = np.where(xcd < rr, xcd * (qq + 1), rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3)
+        assert np.array_equal(np.sort(lid), orig), nwg
+        for k in range(min(8, nwg)):
+            mine = np.sort(lid[xcd == k])
+            assert len(mine) == 0 or np.array_equal(mine, np.arange(mine[0], mine[0] + len(mine))), (nwg, k)
