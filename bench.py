@@ -14,7 +14,8 @@ unless --defaults is given (class defaults: 300 iterations, epsilon 0.01, data-d
 The JSON line carries N and the per-pair algorithmic bytes so the number can be read against
 BASELINE.md section 2.  Extra parameter sets are reported under "variants".
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints ONE compact JSON line (<= 4 KB, strict JSON: `compact_line`) as the only line on stdout; the long form
+(variants, secondary workloads, per-level tables, notes) goes to bench_full.json and to stderr.
 """
 from __future__ import annotations
 
@@ -797,6 +798,159 @@ def bench_surf(args):
     return out
 
 
+COMPACT_LIMIT = 4096   # bytes of the LAST stdout line (the driver's record keeps a bounded tail; r04's 21.9 KB line did not parse)
+
+
+def _finite(x):
+    """Strict JSON: non-finite floats become null; floats keep 6 significant digits in the compact line."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.6g" % x)
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def _s(x, n=110):
+    x = str(x)
+    return x if len(x) <= n else x[:n - 1] + "~"
+
+
+def _pick(d, *keys):
+    d = d or {}
+    return {k: d[k] for k in keys if k in d and d[k] is not None}
+
+
+def miflow_env():
+    """Every MIFLOW_* variable of the process environment (the library reads its switches from there): part of the record."""
+    return {k: _s(v, 40) for k, v in sorted(os.environ.items()) if k.startswith("MIFLOW_")}
+
+
+def compact_line(out, full_path=None):
+    """The one line the driver parses: at most COMPACT_LIMIT bytes of strict JSON with the contract's keys, the roofline and
+    cpu_baseline objects, the accuracy figures and the environment.  The long form (variants, secondary workloads, per-level
+    tables, notes) goes to `full_path` and to stderr.  Optional groups are dropped, last first, if the line would not fit."""
+    r = out.get("roofline") or {}
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config") or {}
+    c["config"] = _pick(cfg, "iterations", "epsilon", "warps", "nscales", "executed_iterations_per_warp_mean", "semantics", "math", "lanes",
+                        "algorithmic_GB_per_pair", "batch", "ndisp", "block_size", "width", "height")
+    c["config"]["workload"] = _s(cfg.get("workload", ""), 118)
+    if r:
+        roof = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_timed")
+        roof["kernel"] = _s(r.get("kernel", ""), 60)
+        h = r.get("hbm") or {}
+        roof.update({("hbm_" + k): h[k] for k in ("algorithmic_bytes_per_launch_mean", "traffic_GBps", "traffic_frac_of_hbm_peak") if h.get(k) is not None})
+        if isinstance(r.get("rate_weighted"), dict) and "frac_at_2.4GHz" in r["rate_weighted"]:
+            roof["rate_weighted_frac"] = r["rate_weighted"]["frac_at_2.4GHz"]
+        if isinstance(r.get("isolated_one_lane"), dict):
+            roof["alone_frac"] = r["isolated_one_lane"].get("frac")
+        c["roofline"] = roof
+    if out.get("cpu_baseline"):
+        cb = out["cpu_baseline"]
+        c["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "physical_cores")
+        c["cpu_baseline"]["sample"] = _s(cb.get("sample", ""), 118)
+    for k in ("epe_vs_cpu_ref_px", "ccorr_dissimilarity_vs_cpu_ref", "epe_vs_analytic_flow_px", "gathered_flows_identical"):
+        if out.get(k) is not None:
+            c[k] = out[k]
+    rr = out.get("rccl_ranks") or {}
+    if rr:
+        c["rccl_ranks"] = _pick(rr, "world_size", "distinct_devices")
+        c["rccl_ranks"]["backend"] = _s(rr.get("backend"), 40) if rr.get("backend") else None
+    if out.get("per_rank_pairs_per_s"):
+        c["per_rank_pairs_per_s"] = out["per_rank_pairs_per_s"]
+    c["env"] = miflow_env()
+    c["full"] = full_path
+    # optional groups, most important first; dropped from the end if the line would exceed the limit
+    opt = []
+    if isinstance(r.get("second_kernel"), dict):
+        sk = r["second_kernel"]
+        d = _pick(sk, "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic")
+        d["kernel"] = _s(sk.get("kernel", ""), 40)
+        opt.append(("second_kernel", d))
+    if isinstance(out.get("whole_job_hbm_traffic"), dict):
+        opt.append(("whole_job_hbm_traffic", _pick(out["whole_job_hbm_traffic"], "GB_per_pair", "GBps", "frac_of_hbm_peak")))
+    if isinstance(out.get("power"), dict):
+        opt.append(("power", _pick(out["power"], "sclk_MHz", "socket_power_W", "roofline_frac_at_measured_clock")))
+    if isinstance(out.get("with_scatter_gather"), dict):
+        opt.append(("with_scatter_gather", {k: (_s(v, 80) if isinstance(v, str) else v) for k, v in out["with_scatter_gather"].items()
+                                            if not isinstance(v, (dict, list))}))
+    sec = out.get("secondary") or {}
+    if sec:
+        d = {}
+        for name, e in sec.items():
+            if not isinstance(e, dict):
+                continue
+            if "error" in e:
+                d[name] = {"error": _s(e["error"], 60)}
+                continue
+            x = _pick(e, "value", "unit", "sequential_compute_pairs_per_s", "sequential_calc_pairs_per_s", "detect_only_frames_per_s")
+            rf = e.get("roofline") or {}
+            x.update({("roofline_" + k): (_s(rf[k], 30) if isinstance(rf[k], str) else rf[k]) for k in ("bound", "frac") if rf.get(k) is not None})
+            if isinstance(e.get("cpu_baseline"), dict):
+                x["cpu"] = e["cpu_baseline"].get("value")
+            d[name] = x
+        opt.append(("secondary", d))
+    var = out.get("variants") or {}
+    if var:
+        d = {}
+        for name, e in var.items():
+            if isinstance(e, dict):
+                v = e.get("pairs_per_s", e.get("calcs_per_s"))
+                if v is not None:
+                    d[_s(name, 60)] = v
+                for k2 in ("calcs_per_s_three_scenes_in_turn",):
+                    if e.get(k2) is not None:
+                        d[_s(name, 48) + ":3scenes"] = e[k2]
+        opt.append(("variants_pairs_per_s", d))
+    for k, v in opt:
+        c[k] = v
+    c = _finite(c)
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    while len(line.encode()) > COMPACT_LIMIT and opt:
+        k, _ = opt.pop()
+        c.pop(k, None)
+        c["dropped"] = c.get("dropped", []) + [k]
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line.encode()) > COMPACT_LIMIT:   # cannot happen with the bounded strings above; never print an over-long line
+        c = {k: c[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data", "roofline", "cpu_baseline", "full") if k in c}
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    return line
+
+
+def emit(out, name="bench_full.json"):
+    """Long form -> bench_full.json (+ gpurun_out/ when that scratch directory exists) and stderr; compact form = the ONLY stdout line."""
+    full_path = None
+    txt = json.dumps(_finite_keep(out))
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, name), "w") as f:
+                    f.write(txt + "\n")
+                full_path = full_path or os.path.relpath(os.path.join(d, name), ROOT)
+        except OSError:
+            pass
+    sys.stderr.write("bench.py full record: " + txt + "\n")
+    sys.stderr.flush()
+    print(compact_line(out, full_path), flush=True)
+
+
+def _finite_keep(x):
+    """The long form with full precision; only NaN / inf replaced (strict JSON)."""
+    if isinstance(x, float):
+        return None if (x != x or x in (float("inf"), float("-inf"))) else x
+    if isinstance(x, dict):
+        return {str(k): _finite_keep(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite_keep(v) for v in x]
+    return x
+
+
 def static_mix_rate_weighted():
     """SIMD cycles of one pipeline stage (one pixel row of one wave) of the T = 10 kernel at the measured per-operation issue rates."""
     try:
@@ -940,6 +1094,11 @@ def main():
     # (`python bench.py --gpus 8`) this process becomes the launcher of N ranks, one per GPU, and relays their exit code.
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
+    # a timed library that the environment can tell to skip work or to change results is not a benchmark: the release library does
+    # not read these switches at all (experiments build only); refuse them here as well so no record is ever made under them
+    for bad in ("MIFLOW_X_SKIP", "MIFLOW_TB_P16"):
+        if os.environ.get(bad, "0") not in ("", "0"):
+            sys.exit(f"bench.py: {bad} is set -- a work-skipping / result-changing experiment switch; refusing to time under it")
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         if args.gpus > 1:
             return sys.exit(self_launch(args.gpus))
@@ -949,15 +1108,15 @@ def main():
     if args.workload != "tvl1" and args.gpus != 1:
         sys.exit("bench.py: the secondary workloads are single-GPU lines (--gpus 1); the sharded metric is --workload tvl1")
     if args.workload == "stereobm":
-        return print(json.dumps(bench_stereobm(args)))
+        return emit(bench_stereobm(args), "bench_full_stereobm.json")
     if args.workload == "surf":
         if (args.width, args.height) == (1920, 1080):
             args.width, args.height = 3840, 2160
-        return print(json.dumps(bench_surf(args)))
+        return emit(bench_surf(args), "bench_full_surf.json")
     if args.workload == "farneback":
         if (args.width, args.height) == (1920, 1080):
             args.width, args.height = 640, 480
-        return print(json.dumps(bench_farneback(args)))
+        return emit(bench_farneback(args), "bench_full_farneback.json")
 
     import numpy as np
     W, H, B = args.width, args.height, args.batch
@@ -1470,19 +1629,6 @@ def main():
             del K0, K1, F4
         except Exception as e:
             var["tvl1_4k_3840x2160"] = {"error": repr(e)[:200]}
-        # opt-in storage of the dual variable as 16-bit fixed point between passes (MIFLOW_TB_P16=1; read once per process, hence the
-        # subprocess): changes results inside the stated tolerance (tools/p16_probe.py: mean EPE against the CPU-class oracle 1.6e-3 ->
-        # 3.2e-3 px at 1080p), NOT the default -- reported as the measure of what 16 B per pixel and pass boundary are worth
-        try:
-            import subprocess
-            env_ = dict(os.environ, MIFLOW_TB_P16="1")
-            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-variants", "--no-cpu", "--no-secondary", "--no-power", "--steps", str(max(4, hs)),
-                                 "--warmup", "2", "--batch", str(B)], capture_output=True, text=True, env=env_, timeout=300)
-            d_ = json.loads([l for l in r_.stdout.splitlines() if l.startswith("{")][-1])
-            var["p16_dual_storage_opt_in"] = {"pairs_per_s": d_["value"], "epe_vs_analytic_flow_px": d_.get("epe_vs_analytic_flow_px"),
-                                              "mean_epe_vs_cpu_oracle_px": "3.2e-3 (default path 1.6e-3; tools/p16_probe.py, tests/test_baseline_sizes.py)"}
-        except Exception as e:
-            var["p16_dual_storage_opt_in"] = {"error": repr(e)[:200]}
         out["variants"] = var
 
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -1528,7 +1674,7 @@ def main():
         dist.destroy_process_group()
     _flush_c_stdio()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if exchange_hung:
         os._exit(0)
 
