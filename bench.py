@@ -871,7 +871,7 @@ def compact_line(out, full_path=None):
         sk = r["second_kernel"]
         d = _pick(sk, "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic")
         d["kernel"] = _s(sk.get("kernel", ""), 40)
-        opt.append(("second_kernel", d))
+        roof["second_kernel"] = d   # part of the roofline object (bounded: ~250 bytes), not an optional group
     if isinstance(out.get("whole_job_hbm_traffic"), dict):
         opt.append(("whole_job_hbm_traffic", _pick(out["whole_job_hbm_traffic"], "GB_per_pair", "GBps", "frac_of_hbm_peak")))
     if isinstance(out.get("power"), dict):

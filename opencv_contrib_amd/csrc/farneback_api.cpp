@@ -175,7 +175,9 @@ static int ensure(mi_farneback *h, int W, int H, int B)
     // (frame 1 = frame 0 + one plane; R[1] = R[0] + five): the pyramid kernels run both frames in one launch
     // + 16 planes of room for the per-level expansions (10 planes x sum of the level sizes: 13.3 planes at pyrScale 0.5; a pyramid
     // that needs more runs level by level on the caller's stream as before)
-    const size_t per_pair = n * 50;
+    // -- the 16 planes exist only where the experiments build's MIFLOW_FB_ASYNC asks for that path (it measured slower and is off)
+    const bool want_rall = tuning().fb_async != 0;
+    const size_t per_pair = n * (want_rall ? 50 : 34);
     MI_HIP_TRY(hipMalloc((void **)&h->arena, sizeof(float) * per_pair * (size_t)B));
     float *p = h->arena;
     auto take = [&](size_t k) { float *q = p; p += n * k; return q; };
@@ -183,7 +185,7 @@ static int ensure(mi_farneback *h, int W, int H, int B)
     h->R[0] = take(5); h->R[1] = take(5); h->M = take(5); h->bufM = take(5);
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) h->flow[a][b] = take(1);
     h->pyr_base = take(2);
-    h->Rall = take(16); h->Rall_floats = (long long)n * 16;
+    h->Rall = want_rall ? take(16) : nullptr; h->Rall_floats = want_rall ? (long long)n * 16 : 0;
     h->bs = (long long)per_pair;
     h->capW = W; h->capH = H; h->capB = B;
     return MI_OK;

@@ -12,64 +12,75 @@ static int env_int(const char *name, int dflt)
     const char *e = getenv(name);
     return e && *e ? atoi(e) : dflt;
 }
+// Release builds read a handful of switches only (each one covered by a digest test); every other tuning variable --
+// all alternatives that lost their A/B, and the two that skip work (MIFLOW_X_SKIP) or change results (MIFLOW_TB_P16) -- exists in
+// the experiments build alone (MIFLOW_BUILD_VARIANT=exp MIFLOW_EXTRA_FLAGS=-DMIFLOW_EXPERIMENTS python -m opencv_contrib_amd.build):
+// in the shipped library the names are not even present as strings and the fields hold their defaults.
+#ifdef MIFLOW_EXPERIMENTS
+#define EXP_INT(name, dflt) env_int(name, dflt)
+#define EXP_ENV(name) getenv(name)
+#else
+#define EXP_INT(name, dflt) (dflt)
+#define EXP_ENV(name) ((const char *)nullptr)
+#endif
 const Tuning &tuning()
 {
     std::call_once(g_tuning_once, [] {
         Tuning &t = g_tuning;
-        const char *w = getenv("MIFLOW_WARP");
+        const char *w = EXP_ENV("MIFLOW_WARP");
         t.warp_legacy = (w && w[0] == 'p') ? 1 : 0;
-        t.x_skip = env_int("MIFLOW_X_SKIP", 0);
-        t.warp_tile = env_int("MIFLOW_WARP_TILE", 32);
+        t.x_skip = EXP_INT("MIFLOW_X_SKIP", 0);
+        t.warp_tile = EXP_INT("MIFLOW_WARP_TILE", 32);
         if (t.warp_tile != 64 && t.warp_tile != 32 && t.warp_tile != 16) t.warp_tile = 32;
-        t.warp_lds = env_int("MIFLOW_WARP_LDS", 0);   // r02z3 at 1080p x 16: LDS-staged windows 1 140 vs 1 180 pairs/s with two lanes, 1 037 vs 1 012 with one
-        t.warp_fast = env_int("MIFLOW_WARP_FAST", -1);   // -1: automatic = cv::cuda semantics only (window_sums, tvl1_warp_kernels.hip)
-        t.warp_np = env_int("MIFLOW_WARP_NP", 2);   // r02e at 1080p x 16: np 1 | 2 | 4 = 904 | 1042 | 1034 pairs/s
+        t.warp_lds = EXP_INT("MIFLOW_WARP_LDS", 0);   // r02z3 at 1080p x 16: LDS-staged windows 1 140 vs 1 180 pairs/s with two lanes, 1 037 vs 1 012 with one
+        t.warp_fast = EXP_INT("MIFLOW_WARP_FAST", -1);   // -1: automatic = cv::cuda semantics only (window_sums, tvl1_warp_kernels.hip)
+        t.warp_np = EXP_INT("MIFLOW_WARP_NP", 2);   // r02e at 1080p x 16: np 1 | 2 | 4 = 904 | 1042 | 1034 pairs/s
         if (t.warp_np != 1 && t.warp_np != 4) t.warp_np = 2;
-        t.tb_swz = env_int("MIFLOW_TB_SWZ", 1);
+        t.tb_swz = EXP_INT("MIFLOW_TB_SWZ", 1);
         // joined-wave form of the T = 10 blocked iteration kernel (tvl1_tbr_kernels.hip): 2 (default since r03w) = hand-over with one
         // workgroup barrier per stage, 1 = with tags and bounded waits, 0 = independent 64-column waves; all three bit-identical
-        t.warp_zoom = env_int("MIFLOW_WARP_ZOOM", 0);   // r08k: bit-identical, 1 388 against 1 406 pairs/s: the per-pixel (double precision) coordinates of cv::resize cost more than the resize launch and its 8 B/px
-        t.tb_p16 = env_int("MIFLOW_TB_P16", 0);
-        t.tb_nograd = env_int("MIFLOW_TB_NOGRAD", 1);
-        t.tb_skip_p = env_int("MIFLOW_TB_SKIP_P", 1);
+        t.warp_zoom = EXP_INT("MIFLOW_WARP_ZOOM", 0);   // r08k: bit-identical, 1 388 against 1 406 pairs/s: the per-pixel (double precision) coordinates of cv::resize cost more than the resize launch and its 8 B/px
+        t.tb_p16 = EXP_INT("MIFLOW_TB_P16", 0);
+        t.tb_nograd = EXP_INT("MIFLOW_TB_NOGRAD", 1);
+        t.tb_skip_p = EXP_INT("MIFLOW_TB_SKIP_P", 1);
         t.tb_hist = env_int("MIFLOW_TB_HIST", 1);
-        t.fb_poll = env_int("MIFLOW_FB_POLL", 1);
-        t.fb_ahead = env_int("MIFLOW_FB_AHEAD", 1);
+        t.fb_poll = EXP_INT("MIFLOW_FB_POLL", 1);
+        t.fb_ahead = EXP_INT("MIFLOW_FB_AHEAD", 1);
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);
         if (t.tb_jw < 0 || t.tb_jw > 4) t.tb_jw = 2;   // 3: eight joined waves (experiment); 4: barrier form, branch-free publishes, mask-free interior blocks
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,
         // epsilon 0.01: 533 -> 593 pairs/s, the same flows
-        t.tb_jw_spec = env_int("MIFLOW_TB_JW_SPEC", 1);
+        t.tb_jw_spec = EXP_INT("MIFLOW_TB_JW_SPEC", 1);
         t.tb_ppl = t.tb_wps = t.tb_pf = -1;
-        if (const char *v = getenv("MIFLOW_TB_VARIANT")) (void)sscanf(v, "%d,%d,%d", &t.tb_ppl, &t.tb_wps, &t.tb_pf);
-        t.tb_force = getenv("MIFLOW_TB_FORCE") != nullptr;
-        t.tb_plan_wps = env_int("MIFLOW_TB_WPS", 0);
-        t.tb_rows = env_int("MIFLOW_TB_ROWS", 0);
+        if (const char *v = EXP_ENV("MIFLOW_TB_VARIANT")) (void)sscanf(v, "%d,%d,%d", &t.tb_ppl, &t.tb_wps, &t.tb_pf);
+        t.tb_force = EXP_ENV("MIFLOW_TB_FORCE") != nullptr;
+        t.tb_plan_wps = EXP_INT("MIFLOW_TB_WPS", 0);
+        t.tb_rows = EXP_INT("MIFLOW_TB_ROWS", 0);
         t.tb_verbose = getenv("MIFLOW_TB_VERBOSE") != nullptr;
         {
             const char *e = getenv("MIFLOW_TILE_MAXPX");
             t.tile_maxpx = e && *e ? atoll(e) : 2300000;   // the three coarsest levels of a 1080p pyramid at 8..16 pairs per lane
         }
-        t.tile_variant = env_int("MIFLOW_TILE_VARIANT", -1);
-        t.tile_small_wgs = env_int("MIFLOW_TILE_SMALL_WGS", 1024);
-        t.tile_swz = env_int("MIFLOW_TILE_SWZ", 1);
-        t.warp_swz = env_int("MIFLOW_WARP_SWZ", 1);
-        t.tile_fb_block = env_int("MIFLOW_TILE_FB_BLOCK", 10);
-        t.tile_fb_model = env_int("MIFLOW_TILE_FB_MODEL", 7);
-        t.tile_spec = env_int("MIFLOW_TILE_SPEC", 1);
+        t.tile_variant = EXP_INT("MIFLOW_TILE_VARIANT", -1);
+        t.tile_small_wgs = EXP_INT("MIFLOW_TILE_SMALL_WGS", 1024);
+        t.tile_swz = EXP_INT("MIFLOW_TILE_SWZ", 1);
+        t.warp_swz = EXP_INT("MIFLOW_WARP_SWZ", 1);
+        t.tile_fb_block = EXP_INT("MIFLOW_TILE_FB_BLOCK", 10);
+        t.tile_fb_model = EXP_INT("MIFLOW_TILE_FB_MODEL", 7);
+        t.tile_spec = EXP_INT("MIFLOW_TILE_SPEC", 1);
         t.lanes = env_int("MIFLOW_LANES", 0);
-        t.spec = env_int("MIFLOW_SPEC", 1);
-        t.exact_tb = env_int("MIFLOW_EXACT_TB", 1);
-        t.fb_tiled = env_int("MIFLOW_FB_TILED", 1);
-        t.sbm_wt = env_int("MIFLOW_SBM_WT", 1);
-        t.sbm_swz = env_int("MIFLOW_SBM_SWZ", 1);
-        t.sbm_texfuse = env_int("MIFLOW_SBM_TEXFUSE", 1);
-        t.fb_rows = env_int("MIFLOW_FB_ROWS", 4) == 8 ? 8 : 4;
-        t.fb_async = env_int("MIFLOW_FB_ASYNC", 0);   // r08i: the cross-stream events cost more than the 9 launches they take off the chain (2 718 vs 3 089 calc/s)
+        t.spec = EXP_INT("MIFLOW_SPEC", 1);
+        t.exact_tb = EXP_INT("MIFLOW_EXACT_TB", 1);
+        t.fb_tiled = EXP_INT("MIFLOW_FB_TILED", 1);
+        t.sbm_wt = EXP_INT("MIFLOW_SBM_WT", 1);
+        t.sbm_swz = EXP_INT("MIFLOW_SBM_SWZ", 1);
+        t.sbm_texfuse = EXP_INT("MIFLOW_SBM_TEXFUSE", 1);
+        t.fb_rows = EXP_INT("MIFLOW_FB_ROWS", 4) == 8 ? 8 : 4;
+        t.fb_async = EXP_INT("MIFLOW_FB_ASYNC", 0);   // r08i: the cross-stream events cost more than the 9 launches they take off the chain (2 718 vs 3 089 calc/s)
         t.fb_fuse = env_int("MIFLOW_FB_FUSE", -1);
         t.fb_pair = env_int("MIFLOW_FB_PAIR", -1);
         t.fb_narrow = env_int("MIFLOW_FB_NARROW", -1);
-        t.fb_swz = env_int("MIFLOW_FB_SWZ", 1);
+        t.fb_swz = EXP_INT("MIFLOW_FB_SWZ", 1);
     });
     return g_tuning;
 }
@@ -127,9 +138,10 @@ int big_alloc(void **p, size_t bytes, size_t *capacity)
             if (ready) {
                 const hipError_t we = hipEventSynchronize(ready);
                 (void)hipEventDestroy(ready);
-                if (we != hipSuccess) { (void)hipFree(*p); *p = nullptr; set_error("cached block: %s", hipGetErrorString(we)); return MI_ERR_HIP; }
+                // a block whose previous owner's work cannot be vouched for is dropped; the request falls through to a fresh hipMalloc
+                if (we != hipSuccess) { (void)hipFree(*p); *p = nullptr; hit = false; }
             }
-            return MI_OK;
+            if (hit) return MI_OK;
         }
     }
     hipError_t e = hipMalloc(p, bytes);
@@ -172,6 +184,7 @@ void big_free(void *p, size_t capacity, hipEvent_t ready, bool busy)
         if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }
         drop = p;
     } else {
+        if (ready) (void)hipEventDestroy(ready);   // the cache does not take the block: its event goes with it
         drop = p;
     }
     const hipError_t fe = hipFree(drop);

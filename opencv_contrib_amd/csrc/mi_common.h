@@ -31,7 +31,7 @@ void set_error(const char *fmt, ...);
 // Tuning switches (environment, read ONCE for the process under std::call_once; DESIGN.md lists them).  None is needed
 // in production: every default is the measured best.
 struct Tuning {
-    int x_skip;              // MIFLOW_X_SKIP (timing experiments ONLY, wrong results): 1 = no warp launches after a level's first, 2 = no iteration launches
+    int x_skip;              // MIFLOW_X_SKIP (EXPERIMENTS BUILD ONLY; wrong results): 1 = no warp launches after a level's first, 2 = no iteration launches; always 0 in the release library
     int warp_legacy;         // MIFLOW_WARP=pk: packed-float4 gather warp (the round-1 kernel) instead of the fused-gradient one
     int warp_tile;           // MIFLOW_WARP_TILE: pixels of a wave along x in the warp kernels (64 | 32 | 16)
     int warp_lds;            // MIFLOW_WARP_LDS: windows of the fused-gradient warp read from an LDS-staged region of I1 (1) or gathered from global memory (0)
@@ -73,6 +73,12 @@ struct Tuning {
     int fb_tiled;            // MIFLOW_FB_TILED: Farneback iteration kernel tiled over 4 rows (1) or one row per workgroup (0)
 };
 const Tuning &tuning();
+// switches outside the Tuning table that only the experiments build reads (see mi_common.cpp)
+#ifdef MIFLOW_EXPERIMENTS
+#define MI_EXP_ENV(name) getenv(name)
+#else
+#define MI_EXP_ENV(name) ((const char *)nullptr)
+#endif
 
 // SIMDs of the current device (4 per CU; 1024 on MI355X), queried once per device
 // Temporary device buffers of the stage-level / self-test entry points: freed on every return path.

@@ -816,7 +816,7 @@ static int block_match_impl(BmArgs &A, int winsz, int uniqueness_ratio, int pair
     int rb = div_up(vrows, bands > 0 ? bands : 1);
     rb = rb < 2 * R + 2 ? 2 * R + 2 : rb;
     rb = rb > 48 ? 48 : rb;   // taller bands cost occupancy (LDS per workgroup grows with rb): r02w at 1080p x 16: 32 | 48 | 64 | 96 rows = 4990 | 5070 | . | 4575 pairs/s
-    if (const char *e = getenv("MIFLOW_SBM_ROWS")) rb = atoi(e) > 0 ? atoi(e) : rb;
+    if (const char *e = MI_EXP_ENV("MIFLOW_SBM_ROWS")) rb = atoi(e) > 0 ? atoi(e) : rb;
     A.rb = rb;
     A.swz = tuning().sbm_swz != 0 ? 1 : 0;
     MI_REQUIRE(uniqueness_ratio <= 0 || A.minssd, MI_ERR_BAD_ARG, "the uniqueness test needs the winners' SSD plane");

@@ -153,10 +153,10 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
         h->sld = align_up(cols + 1, 64); h->vld = align_up(cols, 64); h->dld = align_up(cols, 64);
         // one launch per stage for all octaves where the kernel arguments hold them (surf::fused_supported), else octave by octave
         // through one set of planes; the fused form keeps every octave's planes: ~4/3 of octave 0's
-        h->fused = surf::fused_supported(octaves, layers) && !(getenv("MIFLOW_SURF_FUSED") && atoi(getenv("MIFLOW_SURF_FUSED")) == 0);
+        h->fused = surf::fused_supported(octaves, layers) && !(MI_EXP_ENV("MIFLOW_SURF_FUSED") && atoi(MI_EXP_ENV("MIFLOW_SURF_FUSED")) == 0);
         {
             static const bool lds_ok = surf::lds_geometry_self_check();   // the LDS path's compile-time geometry against the host's
-            const char *e = getenv("MIFLOW_SURF_LDS");
+            const char *e = MI_EXP_ENV("MIFLOW_SURF_LDS");
             h->lds_tiles = (lds_ok && !(e && atoi(e) == 0)) ? 1 : 0;
         }
         surf::FusedSizes z;

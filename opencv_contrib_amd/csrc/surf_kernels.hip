@@ -1288,7 +1288,7 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
 {
     if (nfeat <= 0) return MI_OK;
     const float ss = surf_stage_s();
-    static const int kTileBytes = [] { const char *e = getenv("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 48; return (kb >= 16 && kb <= 150 ? kb : 48) * 1024; }();
+    static const int kTileBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 48; return (kb >= 16 && kb <= 150 ? kb : 48) * 1024; }();
     if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
     else hipLaunchKernelGGL(k_descriptors<false>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
     if (ss < 1e29f) {

@@ -8,11 +8,16 @@
 #include <algorithm>
 #include <cmath>
 #include <vector>
+#include <chrono>
+#include <sched.h>
+#include <time.h>
 
 using namespace mi;
 using namespace mi::tvl1;
 
 namespace {
+
+constexpr double kFeedbackWaitLimitUs = 30e6;   // polled host feedback: a decision word that has not arrived after 30 s never will
 
 struct LevelBuf {
     Geo g;
@@ -431,6 +436,9 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             e_max = std::max(e_max, t);
             l_max = std::max(l_max, (long long)spec_plan[k].size() + 1);
         }
+        // the cost-model plan of a one-or-two-pair calc (below) rounds a warp's total UP to a multiple of its block length, and the
+        // settling launch of a warp indexes one more block: a block of slack per warp (the launch loop checks the bound as well)
+        e_max += 2 * (long long)std::max(tile_max_block(), tb_max_block());
         Q = std::max((long long)ns * P.warps * e_max, (long long)ns * P.warps * l_max);
     }
     if (check) {
@@ -748,6 +756,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                         fb_seq_k = ln.fb_seq = (ln.fb_seq + 1) & 0x0fffffff;
                         sk.fb_flag = ln.fb_flag; sk.fb_seq = fb_seq_k;
                     }
+                    MI_REQUIRE((long long)e_next + T <= (long long)ln.Q && q < (int)ln.Q, MI_ERR_BAD_ARG,
+                               "speculative steps: error-sum slot %d + %d or launch slot %d beyond the %lld slots sized for this calc", e_next, T, q, (long long)ln.Q);
                     rc = iterate_tb_spec(T, pl, g, l_t, theta, taut, false, a, sk, e_next, st);
                     if (rc) return rc;
                     ln.slots.push_back({s, wp});
@@ -774,22 +784,34 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                             ++ln.fb_waits;
                             for (int b = 0; b < B; ++b) {
                                 int v = 0;
+                                // Bare spin (pause) for the first ~20 us -- the flag normally lands within a few microseconds of the launch
+                                // starting -- then the core is handed back between looks (sched_yield; a sleep of 50 us once 2 ms have
+                                // passed: earlier work queued on the caller's stream, or many handles waiting in many threads), so a
+                                // waiting calc() does not hold a core.  The stream is queried on the slow path only; a wall-clock bound ends
+                                // a wait no launch will ever answer.
+                                const auto t_wait0 = std::chrono::steady_clock::now();
                                 for (long long spin = 0;; ++spin) {
                                     v = __atomic_load_n(ln.fb_flag + 2 * b, __ATOMIC_ACQUIRE);
                                     if ((v >> 2) == fb_seq_k) break;
-                                    if ((spin & 1023) == 1023) {
-                                        // a failed launch never writes: the stream is idle (or in error) and the word is not there
-                                        const hipError_t qe = hipStreamQuery(st);
-                                        if (qe != hipErrorNotReady) {
-                                            v = __atomic_load_n(ln.fb_flag + 2 * b, __ATOMIC_ACQUIRE);
-                                            if ((v >> 2) == fb_seq_k) break;
-                                            MI_HIP_TRY(qe);
-                                            MI_REQUIRE(false, MI_ERR_HIP, "host feedback: launch finished without publishing its decision");
-                                        }
-                                    }
+                                    if ((spin & 63) != 63) {
 #if defined(__x86_64__) || defined(__i386__)
-                                    __builtin_ia32_pause();
+                                        __builtin_ia32_pause();
 #endif
+                                        continue;
+                                    }
+                                    const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_wait0).count();
+                                    if (waited_us < 20.0) continue;
+                                    // a failed launch never writes: the stream is idle (or in error) and the word is not there
+                                    const hipError_t qe = hipStreamQuery(st);
+                                    if (qe != hipErrorNotReady) {
+                                        v = __atomic_load_n(ln.fb_flag + 2 * b, __ATOMIC_ACQUIRE);
+                                        if ((v >> 2) == fb_seq_k) break;
+                                        MI_HIP_TRY(qe);
+                                        MI_REQUIRE(false, MI_ERR_HIP, "host feedback: launch finished without publishing its decision");
+                                    }
+                                    MI_REQUIRE(waited_us < kFeedbackWaitLimitUs, MI_ERR_HIP, "host feedback: no decision from the device within %.0f s", kFeedbackWaitLimitUs * 1e-6);
+                                    if (waited_us < 2000.0) sched_yield();
+                                    else { struct timespec ts_ = {0, 50000}; nanosleep(&ts_, nullptr); }
                                 }
                                 all_before = all_before && (v & 2);
                                 all = all && (v & 1);

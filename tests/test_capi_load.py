@@ -20,6 +20,21 @@ def test_exports_every_declared_symbol():
     assert not missing, f"declared in c_api.h but not exported: {missing}"
 
 
+RELEASE_SWITCHES = {"MIFLOW_BF_W", "MIFLOW_CACHE_GB", "MIFLOW_CACHE_TOTAL_GB", "MIFLOW_FB_FUSE", "MIFLOW_FB_NARROW", "MIFLOW_FB_PAIR",
+                    "MIFLOW_LANES", "MIFLOW_SURF_STAGE_S", "MIFLOW_TB_HIST", "MIFLOW_TB_JW", "MIFLOW_TB_VERBOSE", "MIFLOW_TILE_MAXPX"}
+
+
+def test_release_library_reads_no_experiment_switch():
+    """the shipped library does not contain the NAMES of the work-skipping (MIFLOW_X_SKIP), result-changing
+    (MIFLOW_TB_P16) or A/B-loser tuning variables -- they exist under -DMIFLOW_EXPERIMENTS only -- and the variables it does read are
+    exactly the documented set, each of which has a digest / behaviour test in the GPU suite."""
+    import re
+    blob = open(capi.LIB_PATH, "rb").read()
+    names = {m.decode() for m in re.findall(rb"MIFLOW_[A-Z0-9_]+", blob)}
+    assert "MIFLOW_X_SKIP" not in names and "MIFLOW_TB_P16" not in names
+    assert names == RELEASE_SWITCHES, sorted(names ^ RELEASE_SWITCHES)
+
+
 def test_binding_covers_header():
     L = capi.lib()
     for s in capi.declared_symbols():

@@ -316,8 +316,7 @@ def test_random_configuration_matches_oracle(gpu, oracle, cfg):
 def test_few_launch_forms_of_a_single_pair_are_bit_identical(gpu):
     """Round 4: a single pair is a chain of launch latencies, so small calls run forms with fewer / shorter
     launches -- 64 x 4 tiles (MIFLOW_FB_NARROW), the resize sampled inside poly_exp and the first matrix update + the merge written by
-    the last iteration (MIFLOW_FB_FUSE), two iterations per launch on the coarse levels (MIFLOW_FB_PAIR), the pyramid side on an
-    internal stream (MIFLOW_FB_ASYNC, off by default).  Every one of them performs the same operations in the same order: the flow
+    the last iteration (MIFLOW_FB_FUSE), two iterations per launch on the coarse levels (MIFLOW_FB_PAIR).  Every one of them performs the same operations in the same order: the flow
     of a whole calc must not change by a bit.  The switches are read once per process, hence the subprocesses."""
     import os
     import subprocess
@@ -325,11 +324,11 @@ def test_few_launch_forms_of_a_single_pair_are_bit_identical(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
     for name, env in (("plain", {"MIFLOW_FB_NARROW": "0", "MIFLOW_FB_FUSE": "0", "MIFLOW_FB_PAIR": "0"}), ("default", {}),
-                      ("all_on", {"MIFLOW_FB_NARROW": "1", "MIFLOW_FB_FUSE": "1", "MIFLOW_FB_PAIR": "1"}), ("async", {"MIFLOW_FB_ASYNC": "1"})):
+                      ("all_on", {"MIFLOW_FB_NARROW": "1", "MIFLOW_FB_FUSE": "1", "MIFLOW_FB_PAIR": "1"})):
         for (w, h) in ((640, 480), (333, 217)):
             r = subprocess.run([sys.executable, os.path.join(root, "tools", "fb_single.py"), str(w), str(h), "3"], capture_output=True, text=True,
                                env=dict(os.environ, **env), timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             digests[(name, w)] = [l.split("digest")[1].strip() for l in r.stdout.splitlines() if "digest" in l][0]
     for w in (640, 333):
-        assert digests[("plain", w)] == digests[("default", w)] == digests[("all_on", w)] == digests[("async", w)], digests
+        assert digests[("plain", w)] == digests[("default", w)] == digests[("all_on", w)], digests

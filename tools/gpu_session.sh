@@ -80,7 +80,10 @@ except Exception as e: print('ab $1 $2 failed', e); print(open('$O/ab_np$1_l$2.e
 PY
   done ;;
 bench)
-  (timeout 900 python bench.py 2>$O/bench.err | tail -1) > $O/bench.json; tail -c 3000 $O/bench.json; tail -5 $O/bench.err ;;
+  # stdout = the compact line the driver parses (bench_line.json); the long form is bench_full.json (copied as bench.json)
+  (timeout 900 python bench.py ${BENCH_ARGS:-} 2>$O/bench.err) > $O/bench_stdout.txt; tail -1 $O/bench_stdout.txt > $O/bench_line.json
+  echo "stdout lines: $(wc -l < $O/bench_stdout.txt), last line bytes: $(tail -1 $O/bench_stdout.txt | wc -c)"
+  cp bench_full.json $O/bench.json 2>/dev/null; cat $O/bench_line.json; grep -v "full record" $O/bench.err | tail -5 ;;
 trace)
   cd /tmp
   timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace -- python $R/bench.py --no-variants --no-cpu --no-secondary --steps 5 --warmup 2 > $R/$O/trace_bench.log 2>&1
