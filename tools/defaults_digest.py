@@ -1,4 +1,4 @@
-"""Digest + rate of a class-default (300 iterations, eps 0.01) 1080p batch: the speculative steps on the streaming kernel.  usage: python tools/defaults_digest.py [pairs]"""
+"""Digest + rate of a class-default (300 iterations, eps 0.01) 1080p batch: the speculative steps on the streaming kernel.  usage: python tools/defaults_digest.py [pairs] [both]   (both: also the fixed-work setting iterations=10, epsilon=0)"""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,3 +17,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 3
 print(f"class defaults 1080p x {B}: {B / dt:.1f} pairs/s digest {hashlib.sha256(F.cpu().numpy().tobytes()).hexdigest()[:16]} iterations {alg.lastIterations(0)[0][:5]}", flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "both":
+    a10 = cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0)
+    F10 = a10.calc_batch(I0, I1)
+    torch.cuda.synchronize()
+    print(f"iterations=10 epsilon=0 1080p x {B}: digest {hashlib.sha256(F10.cpu().numpy().tobytes()).hexdigest()[:16]}", flush=True)
