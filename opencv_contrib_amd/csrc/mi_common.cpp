@@ -46,6 +46,7 @@ const Tuning &tuning()
         t.tb_hist = env_int("MIFLOW_TB_HIST", 1);
         t.fb_poll = EXP_INT("MIFLOW_FB_POLL", 1);
         t.fb_ahead = EXP_INT("MIFLOW_FB_AHEAD", 1);
+        t.tb_fw = env_int("MIFLOW_TB_FW", 0);   // bit-identical; first form measured slower (r14b: 1 190 against 1 372 pairs/s at 64 pairs): off until it wins
         t.tb_jw = env_int("MIFLOW_TB_JW", 2);
         if (t.tb_jw < 0 || t.tb_jw > 4) t.tb_jw = 2;   // 3: eight joined waves (experiment); 4: barrier form, branch-free publishes, mask-free interior blocks
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,

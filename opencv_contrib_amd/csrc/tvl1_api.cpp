@@ -619,9 +619,15 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             if (spec && !legacy_warp && !gam && P.median_filtering <= 1 && tb_spec_nograd_ok(g)) nograd = true;   // speculative steps: every block is a tbr launch
             float *grad_w = nograd ? nullptr : grad;
             pl.g = grad_w;
+            // Round 5: a warp whose iterations are ONE pass of the default kernel runs inside that pass (producer waves, k_iterate_tbr
+            // FW) -- no warp launch, no static planes through HBM
+            const bool fast_w0 = !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT));
+            const bool fuse_w = blocked_w && !legacy_warp && nograd && plan_w.size() == 1 && P.median_filtering <= 1 && tuning().x_skip == 0 &&
+                                tuning().warp_lds == 0 && !(wp == 0 && have_zoom) && tb_fused_ok(plan_w[0], g, sem, fast_w0);
             const bool warp_is_fused = !legacy_warp && tuning().x_skip == 0;
             const bool fast_w = !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT));
             if (pre_warped) { rc = MI_OK; pre_warped = false; }
+            else if (fuse_w) rc = MI_OK;
             else if (tuning().x_skip == 1 && wp > 0) rc = MI_OK;   // timing experiment: what a step costs without the warps' work and bytes
             else if (legacy_warp)
                 rc = warp(sem, Lv.I0, ln.pack, u1v, u2v, nullptr, I1wx, I1wy, grad, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st);
@@ -629,7 +635,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 rc = warp_fused(sem, !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT)), -1, Lv.I0, Lv.I1, u1v, u2v, nullptr, I1wx, I1wy, grad_w, rho, h->cubic_tab, g, dev_cur ? &wc : nullptr, cur, st,
                                 (wp == 0 && have_zoom) ? &zoom : nullptr);
             if (rc) return rc;
-            if (w0 >= 0) {
+            if (w0 >= 0 && !fuse_w) {
                 rc = next_event(&w1); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[w1], st));
                 ln.regions.push_back({w0, w1, 1, 44.0 * g.w * g.h * B, 1, s});   // 44 B/px per warp
@@ -656,7 +662,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                         ++nlaunch;
                         if (tuning().x_skip == 2) { first_of_scale = false; continue; }   // timing experiment: the warps alone
                         const bool last_pass = tuning().tb_skip_p && wp == P.warps - 1 && no == nouter - 1 && k == nb - 1 && !mf;
-                        rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st, last_pass);
+                        if (fuse_w) rc = iterate_tb_fused(sem, Lv.I0, Lv.I1, h->cubic_tab, plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, st, last_pass);
+                        else rc = iterate_tb(plan[k], pl, g, l_t, theta, taut, first_of_scale, cur, 0, st, last_pass);
                         if (rc) return rc;
                         cur ^= 1;
                         first_of_scale = false;

@@ -99,6 +99,10 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s, bool skip_p_out = false);
 bool tb_nograd_ok(int T, const Geo &g);
+// the warp of a one-pass warp INSIDE that pass (k_iterate_tbr FW): no warp launch, no I1wx / I1wy / rho_c planes in HBM; bit-identical
+bool tb_fused_ok(int T, const Geo &g, int semantics, bool fast_warp);
+int iterate_tb_fused(int semantics, const float *I0, const float *I1, const float *cubic_tab_dev, int T, const IterPlanes &pl, const Geo &g,
+                     float l_t, float theta, float taut, bool p_zero, int cur, hipStream_t s, bool skip_p_out);
 bool tb_spec_nograd_ok(const Geo &g);   // the same for the speculative steps of the convergence-checked path
 int tb_max_block();
 // Register-tile formulation of the same fused iterations for the small pyramid levels (tvl1_tile_kernels.hip): nit in

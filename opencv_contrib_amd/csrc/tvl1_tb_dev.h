@@ -49,6 +49,9 @@ struct TbArgs {
     CtlK ctl;   // speculative convergence path only (MODE 1): slot protocol of Ctl, e0 = first error-sum index of this launch's block
     int e0;
     SpecK sk;
+    // fused warp (k_iterate_tbr FW): the frames of the level and the CPU class's cubic phase table -- the producer waves of a workgroup
+    // compute a row's I1wx, I1wy, rho_c from them (and from the flow the pass reads anyway); pl.ix / pl.iy / pl.rc are not touched
+    const float *fI0, *fI1, *ftab;
 };
 
 #define ERR_FIX_SCALE 16777216.0 /* 2^24 fixed point for the deterministic error sum */

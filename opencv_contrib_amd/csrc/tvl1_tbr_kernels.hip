@@ -25,6 +25,7 @@
 // Arithmetic: fast-math form (v_rcp / v_sqrt / fma; TH written as a clamp); parity against the oracle and the exact
 // kernel is tested with a stated tolerance (tests/test_tvl1_gpu.py).
 #include "tvl1_tb_dev.h"
+#include "tvl1_warp_px.h"
 #include <utility>
 #include <cstdlib>
 #include <cstdio>
@@ -186,16 +187,18 @@ __device__ __forceinline__ void str(float *rowp, unsigned xb, const float v[PPL]
 // (|p| <= 1 by construction of the dual update; v_cvt_pknorm_i16_f32, step 2^-15 ~ 3e-5): {p11, p12} in plane 0, {p21, p22} in plane
 // 2, 16 B per pixel and pass boundary less through HBM.  The raw dwords wait in the p11 / p21 registers of the set and are
 // unpacked when the row enters the pipeline (unpack_p16).
-template <int PPL, bool PZ, bool NG = false, bool P16 = false>
+template <int PPL, bool PZ, bool NG = false, bool P16 = false, int FW = 0>
 __device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const float *const u[2], const float *const p[4], int row,
                                            int H, unsigned xc)
 {
     const long long ro = (long long)min(max(row, 0), H - 1) * A.g.ld;   // wave-uniform
     asm volatile("" : "+v"(xc));
-    ldr<PPL>(x.s.ix, A.pl.ix + ro, xc);
-    ldr<PPL>(x.s.iy, A.pl.iy + ro, xc);
-    if (!NG) ldr<PPL>(x.s.rg, A.pl.g + ro, xc);   // RAW |grad|^2 until the row is consumed (finish_static)
-    ldr<PPL>(x.s.rc, A.pl.rc + ro, xc);
+    if (!FW) {   // FW: the row's statics come from the workgroup's producer wave through the LDS inbox (fw_inbox_get)
+        ldr<PPL>(x.s.ix, A.pl.ix + ro, xc);
+        ldr<PPL>(x.s.iy, A.pl.iy + ro, xc);
+        if (!NG) ldr<PPL>(x.s.rg, A.pl.g + ro, xc);   // RAW |grad|^2 until the row is consumed (finish_static)
+        ldr<PPL>(x.s.rc, A.pl.rc + ro, xc);
+    }
     ldr<PPL>(x.d.u1, u[0] + ro, xc);
     ldr<PPL>(x.d.u2, u[1] + ro, xc);
     if (!PZ && P16) {
@@ -219,6 +222,7 @@ struct CtxR {
     const float *uin[2], *pin[4];
     float *uout[2], *pout[4];
     float *ring;
+    float *inbox;   // FW: this wave's inbox (FW_RING slots of {I1wx | I1wy | rho_c} x 64 columns), written by its producer wave
     int lane, H, ld, y0, y1, ystart, nsteps;
     unsigned xc;
     bool st_ok, x0;   // x0: this lane holds column 0 (MODE 2)
@@ -317,10 +321,88 @@ __host__ __device__ constexpr int xdump4_bytes(int T) { return 64 * 8 + 2 * xare
 __host__ __device__ constexpr bool jw_fast(int JW) { return JW == 4; }
 __device__ int g_jw_fault;   // sticky: a bounded wait on a neighbouring wave ran out (never expected; results are then invalid)
 
+// ---- fused warp (FW; round 5): the warp INSIDE the pass kernel -- cudaoptflow/src/cuda/tvl1flow.cu:89-164 feeding :187-348 (CPU class:
+// optflow/src/tvl1flow.cpp:904-969 feeding :989-1181) without the HBM round trip of I1wx, I1wy, rho_c (12 B/px written by the warp
+// launch + 12 B/px read back by the pass, and the warp launch's own 8 B/px of flow).  A workgroup is the four joined CONSUMER waves of
+// the barrier form (JW = 2) plus four PRODUCER waves, one per consumer: producer j walks the rows of the band two rows ahead of the
+// pipeline and computes, for the 64 columns of consumer j, what k_warp6 computes for a pixel -- the same routines (tvl1_warp_px.h), the
+// same operations in the same order: the planes the consumer sees are bit-identical to the stored ones -- and writes the three values
+// into consumer j's LDS INBOX.  Eight waves of 128 VGPRs = two workgroups per CU: every SIMD runs two consumers and two producers.
+//
+// Synchronisation rides on the barriers the joined waves pass anyway (two per step at T = 10): all eight waves execute the same
+// sequence of s_barrier.  With global barrier numbers counted from the extra one that opens the pipeline: producer step n = barriers
+// 2n, 2n+1, consumer w's step n = barriers 2n+w, 2n+w+1 (the skew of the hand-over scheme).  The producer finishes row n+2 in its step
+// n, before barrier 2n+2; consumer w reads row n+1 after its barrier 2n+w >= 2n (written before barrier 2n) -- one step ahead of the use,
+// into the register set of that row; a slot of the four-row ring is overwritten (row n+2 over row n-2) after barrier 2n, and its last
+// reader (consumer 3 at its step n-3) finished before barrier 2n-2.  Rows above / below the image and columns right of it take the
+// clamped pixel's values -- what the clamped loads of the unfused kernel deliver; they are cut off from the image by the same masks.
+//
+// The producer's own latency is hidden by software pipelining: the window gathers of row m+1 and the flow / I0 loads of row m+2 are
+// issued when row m is finished, and consumed a whole pipeline step (~2 us) later.
+constexpr int FW_RING = 4;         // inbox slots (rows) per consumer wave: two rows of lead + the two steps of consumer skew
+constexpr int FW_SLOT = 3 * 64;    // floats per slot
+__host__ __device__ constexpr int fw_lds_floats(int NW) { return NW * FW_RING * FW_SLOT + 128; }   // inboxes + the cubic phase table
+template <int PPL>
+__device__ __forceinline__ void fw_inbox_get(const float *slot, int lane, Stat<PPL> &s)
+{
+    const float *q = slot + lane;   // (one pixel per lane: the kernel asserts it)
+    s.ix[0] = q[0]; s.iy[0] = q[64]; s.rc[0] = q[128];
+}
+template <int FW> struct FwSem { static constexpr int sem = FW == 2 ? MI_SEM_CUDA_COMPAT : MI_SEM_CPU_REF; static constexpr bool fast = FW == 2; };
+
+template <int FW, int NW>
+__device__ __forceinline__ void fw_produce(const TbArgs &A, float *inbox, const float *tab, int lane, int xw, int ystart, int nsteps_total,
+                                           long long pb, int cur)
+{
+    constexpr int SEM = FwSem<FW>::sem;
+    constexpr bool FAST = FwSem<FW>::fast;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    const int x = min(xw + lane, W - 1);
+    const float *U1 = A.pl.u[cur][0] + pb + x, *U2 = A.pl.u[cur][1] + pb + x, *I0 = A.fI0 + pb + x, *P = A.fI1 + pb;
+    // S: the row whose window is in flight; N: the row after it, whose flow / I0 loads are in flight
+    float u1s = 0.f, u2s = 0.f, i0s = 0.f, wx[4], wy[4], R[6][6];
+    int sx = 0, sy = 0;
+    bool inter = false;
+    float u1n, u2n, i0n;
+    const auto load_n = [&](int m) {
+        const long long ro = (long long)min(max(ystart + m, 0), H - 1) * ld;   // wave-uniform
+        u1n = U1[ro]; u2n = U2[ro]; i0n = I0[ro];
+    };
+    const auto issue_s = [&](int m) {   // N -> S: window origin and weights of row m, gathers issued
+        u1s = u1n; u2s = u2n; i0s = i0n;
+        warp_coords<SEM>(tab, x, min(max(ystart + m, 0), H - 1), u1s, u2s, sx, sy, wx, wy);
+        inter = window_interior(sx, sy, W, H);
+        if (inter) window_gather(R, P, ld, sx, sy);
+    };
+    const auto finish = [&](int m) {    // row m: sums, rho_c, hand-over; then the next row's requests
+        float v0, v1, v2;
+        if (inter) window_sums<SEM, FAST>(R, wx, wy, v0, v1, v2);
+        else window_border<SEM>(P, W, H, ld, sx, sy, wx, wy, v0, v1, v2);
+        float *q = inbox + (m & (FW_RING - 1)) * FW_SLOT + lane;
+        q[0] = v1; q[64] = v2;
+        q[128] = (v0 - v1 * u1s - v2 * u2s - i0s);   // calcGradRho, optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163 (warp_px)
+        issue_s(m + 1);
+        load_n(m + 2);
+    };
+    load_n(0);
+    issue_s(0);
+    load_n(1);
+    finish(0);
+    finish(1);
+    xbarrier();   // opens the pipeline: rows 0 and 1 are in the inbox
+#pragma unroll 1
+    for (int n = 0; n < nsteps_total; ++n) {
+        xbarrier();
+        finish(n + 2);
+        xbarrier();
+    }
+    for (int i = 0; i < NW - 1; ++i) xbarrier();   // the consumers' skew
+}
+
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int k>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int FW, int k>
 __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T], Xchg &x)
 {
     constexpr bool JF = jw_fast(JW);
@@ -358,7 +440,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         xexpect = ((unsigned)(n + 1) & 0xffffu) * x.mul;
     }
 #ifndef TBR_X_NOLOAD   // timing experiments only (wrong results): no row loads after the prologue
-    load_row_r<PPL, PZ, NG, P16>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
+    load_row_r<PPL, PZ, NG, P16, FW>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
 #else
     X[(k + PF) % P] = X[k];
 #endif
@@ -428,6 +510,9 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             xwrite2f(x.pub_l + t * 2 * XS2 + 8, SA.u1[0], SA.u2[0]);
         } else if (JW >= 2) {
             if ((k * T + t) % xk_stages(T) == 0) xbarrier();
+            // FW: the statics of the row that enters at the NEXT step, one step ahead of their use (the producer wave finished that row
+            // before the barrier just passed -- see fw_produce); they land in the register set that row's u, p already wait in
+            if constexpr (FW != 0) if (t == 0) fw_inbox_get<PPL>(c.inbox + ((n + 1) & (FW_RING - 1)) * FW_SLOT, c.lane, X[(k + 1) % P].s);
             float l1, l2, r1, r2;
             xread2(x.own + t * 2 * XS2, l1, l2, r1, r2);
             unsigned long long dummy = 0;
@@ -507,11 +592,11 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
     }
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int... Ks>
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int FW, int... Ks>
 __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
                                         Xchg &x, std::integer_sequence<int, Ks...>)
 {
-    (step_r<T, PPL, PZ, PF, MODE, JW, MK, NG, P16, Ks>(c, X, n0, slot0, acc, x), ...);
+    (step_r<T, PPL, PZ, PF, MODE, JW, MK, NG, P16, FW, Ks>(c, X, n0, slot0, acc, x), ...);
 }
 
 // MODE 0: T iterations, fixed work.
@@ -530,9 +615,10 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 //   edges (236 of 256 lanes own a column instead of 44 of 64: 33 instead of 44 waves per 1080p row band).  At the three inner
 //   seams the neighbouring waves hand each other the two values a stage needs from across the seam through LDS (Xchg above).  The
 //   arithmetic of an owned pixel is the same operations on the same values as in the independent-wave form: bit-identical planes.
-template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false>
-__global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs A)
+template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false, int FW = 0>
+__global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tbr(TbArgs A)
 {
+    static_assert(!FW || (JW == 2 && MODE == 0 && NG && !P16 && PPL == 1 && T == 10), "fused warp: the default joined-wave fixed-work kernel only");
     static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW >= 2 && JW != 4))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
     static_assert(JW < 2 || (((T + 1 + PF) * T) % xk_stages(T) == 0 && T >= 2 * xk_stages(T)), "barrier intervals must tile the unrolled block and leave the right neighbour a full interval");
     constexpr int M = (T + PPL - 1) / PPL * PPL;   // validity margin per side (px)
@@ -544,7 +630,10 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
     extern __shared__ __attribute__((aligned(16))) float lds[];
     CtxR<PPL> c;
     c.lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // FW: waves NW .. 2 NW - 1 are the producers of consumers 0 .. NW - 1 and share their geometry
+    const bool producer = FW && wave_id >= NW;
+    const int wave = producer ? wave_id - NW : wave_id;
     // block -> (strip, band group, pair); with swz the linear workgroup id is remapped so that each XCD (id % 8) owns a
     // contiguous run of strips: neighbouring strips share their halo columns through ONE L2
     int strip = blockIdx.x, bgrp = blockIdx.y, b = blockIdx.z;
@@ -581,6 +670,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
         x.pub_l = xb + (wave - 1) * XA + XS2;           // the left neighbour's slots of step 1 (parity 1); lane 0 of a wave with a left neighbour only
         x.on_r = has_right && c.lane == 63;
         x.on_l = has_left && c.lane == 0;
+        if (FW && threadIdx.x < 128) (lds + NW * (K * 256 * PPL) + NW * XA / 4 + NW * FW_RING * FW_SLOT)[threadIdx.x] = A.ftab[threadIdx.x];
         if (jw_fast(JW)) {
             // per-lane publish addresses: the neighbour's slots for the one lane that holds the boundary column, the workgroup's dump
             // area (never read; the parity bit and the stage offsets apply to it alike) for everybody else
@@ -618,6 +708,17 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
 
     const long long pb = (long long)b * A.g.ps;
     int cur = A.cur;
+    c.ystart = c.y0 - T;
+    c.nsteps = (c.y1 - c.y0) + 2 * T;
+    c.inbox = nullptr;
+    if constexpr (FW != 0) {
+        float *fw0 = lds + NW * (K * 256 * PPL) + NW * xarea2_bytes(T) / 4;
+        c.inbox = fw0 + wave * (FW_RING * FW_SLOT);
+        if (producer) {
+            fw_produce<FW, NW>(A, c.inbox, fw0 + NW * FW_RING * FW_SLOT, c.lane, xw, c.ystart, (c.nsteps + P - 1) / P * P, pb, cur);
+            return;
+        }
+    }
     c.nit = T;
     bool record = false;
     if (MODE == 1) {
@@ -632,7 +733,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
 #pragma unroll
     for (int i = 0; i < 4; ++i) { c.pin[i] = A.pl.p[cur][i] + pb; c.pout[i] = A.pl.p[cur ^ 1][i] + pb; }
     c.B = A;
-    c.B.pl.ix += pb; c.B.pl.iy += pb; if (!NG) c.B.pl.g += pb; c.B.pl.rc += pb;
+    if (!FW) { c.B.pl.ix += pb; c.B.pl.iy += pb; if (!NG) c.B.pl.g += pb; c.B.pl.rc += pb; }
     c.l_t = A.l_t; c.theta = A.theta; c.taut = A.taut;
 
     Slot<PPL> X[P];
@@ -645,10 +746,12 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
         }
     for (int k = 0; k < K; ++k) lds_put<PPL>(c.ring + k * (256 * PPL), c.lane, X[0].s);
 
-    c.ystart = c.y0 - T;
-    c.nsteps = (c.y1 - c.y0) + 2 * T;
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ, NG, P16>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
+    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ, NG, P16, FW>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
+    if constexpr (FW != 0) {   // the barrier that opens the pipeline (fw_produce): rows 0 and 1 are in the inbox; row 0 enters at step 0
+        xbarrier();
+        fw_inbox_get<PPL>(c.inbox, c.lane, X[0].s);
+    }
     int slot0 = 0;   // ring slot of the row entering at this step (= step mod K)
     unsigned long long acc[T];
 #pragma unroll
@@ -662,9 +765,9 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
             // the workgroup: they share the band)
             const int ra = c.ystart + n0 - (T - 1), rb = c.ystart + n0 + P - 1;
             const bool plain = (ra > 0 || rb < 0) && (ra > c.H || rb < c.H);
-            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false, NG, P16>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
+            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false, NG, P16, FW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
         }
-        steps_r<T, PPL, PZ, PF, MODE, JW, true, NG, P16>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+        steps_r<T, PPL, PZ, PF, MODE, JW, true, NG, P16, FW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
     }
     if (JW >= 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
         for (int i = wave; i < NW - 1; ++i) xbarrier();
@@ -681,7 +784,7 @@ __global__ __launch_bounds__(JW == 3 ? 512 : 256, WPS) void k_iterate_tbr(TbArgs
     }
 }
 
-template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false>
+template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false, int FW = 0>
 static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
@@ -694,26 +797,28 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     // JW: a workgroup is one band of a 256-column strip; otherwise four consecutive bands of a 64-column strip
     const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
     constexpr size_t lds_bytes = (size_t)NW * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
-                                 (JW >= 2 ? NW * xarea2_bytes(T) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0);
+                                 (JW >= 2 ? NW * xarea2_bytes(T) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0) +
+                                 (FW ? fw_lds_floats(NW) * sizeof(float) : 0);
+    constexpr int NTHREADS = 64 * NW * (FW ? 2 : 1);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         return e;
     }();
     MI_HIP_TRY(attr_rc);
     if (tuning().tb_verbose) {
         static const int nb = [] {
             int n = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16>, 64 * NW, lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW>, NTHREADS, lds_bytes);
             fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d jw=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, JW, lds_bytes, n);
             return n;
         }();
         (void)nb;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16>), grid, dim3(64 * NW), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16>), grid, dim3(64 * NW), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16, FW>), grid, dim3(NTHREADS), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW>), grid, dim3(NTHREADS), lds_bytes, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -738,6 +843,10 @@ static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 
                                      {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 4>, nullptr, 4}};
 // the default kernel without a |grad|^2 plane (tb_nograd_entry)
 static const TbrEntry g_tbr_ng = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true>, nullptr, 2};
+// ... and with the warp inside (FW: four producer waves beside the four joined consumers; two workgroups of eight waves per CU, i.e. two
+// CONSUMER waves per SIMD is what the band planner fills): [0] the CPU class's arithmetic, tap-by-tap sums; [1] cv::cuda's, separable sums
+static const TbrEntry g_tbr_fw[] = {{10, 1, 4, 2, 2, launch_tbr<10, 1, 4, 2, 0, 2, true, false, 1>, nullptr, 2},
+                                    {10, 1, 4, 2, 2, launch_tbr<10, 1, 4, 2, 0, 2, true, false, 2>, nullptr, 2}};
 static const TbrEntry g_tbr_ng16 = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true, true>, nullptr, 2};   // + p as snorm16 between passes (opt-in)
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
@@ -892,6 +1001,33 @@ bool tb_nograd_ok(int T, const Geo &g)
     if (!tuning().tb_nograd || T != 10 || tuning().tb_jw != 2 || tuning().tb_ppl >= 0) return false;
     if (tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force) return false;
     return true;
+}
+
+// A warp whose iterations are ONE pass of the default T = 10 kernel can run with the warp inside that pass (k_iterate_tbr FW): no warp
+// launch, no I1wx / I1wy / rho_c planes.  Which warp arithmetic: the two defaults (CPU class + tap-by-tap sums, cv::cuda + separable sums).
+bool tb_fused_ok(int T, const Geo &g, int semantics, bool fast_warp)
+{
+    if (!tuning().tb_fw || !tb_nograd_ok(T, g)) return false;
+    return (semantics == MI_SEM_CPU_REF && !fast_warp) || (semantics == MI_SEM_CUDA_COMPAT && fast_warp);
+}
+
+int iterate_tb_fused(int semantics, const float *I0, const float *I1, const float *cubic_tab_dev, int T, const IterPlanes &pl, const Geo &g,
+                     float l_t, float theta, float taut, bool p_zero, int cur, hipStream_t s, bool skip_p_out)
+{
+    MI_REQUIRE(T == 10 && tb_nograd_ok(T, g), MI_ERR_BAD_ARG, "fused warp: one pass of the default T = 10 kernel only");
+    const TbrEntry &e = g_tbr_fw[semantics == MI_SEM_CPU_REF ? 0 : 1];
+    TbArgs A;
+    memset(&A, 0, sizeof(A));
+    A.pl = pl; A.pl.ix = A.pl.iy = A.pl.g = A.pl.rc = nullptr;
+    A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur;
+    A.skip_p_out = skip_p_out ? 1 : 0;
+    A.fI0 = I0; A.fI1 = I1; A.ftab = cubic_tab_dev;
+    A.rows_per_band = plan_band_rows(e, g);
+    if (tuning().tb_verbose) {
+        static int shown = 0;
+        if (shown++ < 40) fprintf(stderr, "[tb] fused warp T=%d %dx%d batch=%d rows_per_band=%d\n", T, g.w, g.h, g.batch, A.rows_per_band);
+    }
+    return e.launch(A, p_zero, s);
 }
 
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
