@@ -337,8 +337,8 @@ __device__ int g_jw_fault;   // sticky: a bounded wait on a neighbouring wave ra
 // reader (consumer 3 at its step n-3) finished before barrier 2n-2.  Rows above / below the image and columns right of it take the
 // clamped pixel's values -- what the clamped loads of the unfused kernel deliver; they are cut off from the image by the same masks.
 //
-// The producer's own latency is hidden by software pipelining: the window gathers of row m+1 and the flow / I0 loads of row m+2 are
-// issued when row m is finished, and consumed a whole pipeline step (~2 us) later.
+// The producer's own latency is hidden by software pipelining: the window gathers of row m+2 and the flow / I0 loads of row m+4 are
+// issued when row m is finished, and consumed two whole pipeline steps later.
 constexpr int FW_RING = 4;         // inbox slots (rows) per consumer wave: two rows of lead + the two steps of consumer skew
 constexpr int FW_SLOT = 3 * 64;    // floats per slot
 __host__ __device__ constexpr int fw_lds_floats(int NW) { return NW * FW_RING * FW_SLOT + 128; }   // inboxes + the cubic phase table
@@ -350,6 +350,15 @@ __device__ __forceinline__ void fw_inbox_get(const float *slot, int lane, Stat<P
 }
 template <int FW> struct FwSem { static constexpr int sem = FW == 2 ? MI_SEM_CUDA_COMPAT : MI_SEM_CPU_REF; static constexpr bool fast = FW == 2; };
 
+#ifndef FW_X
+#define FW_X 0   // experiments build only: 1 = the producers write zeros (no loads, no arithmetic), 2 = arithmetic without loads -- wrong results
+#endif
+// A producer wave keeps FOUR rows in flight, all in registers with compile-time indices (the row loop is unrolled four times, so nothing
+// is ever copied: a copy of a register a load is still filling would make the wave wait for that load at once): the flow and I0 of rows
+// m .. m+3 in U[m & 3], the windows of rows m, m+1 in R[m & 1].  When row m is finished its window registers take the gathers of row
+// m+2 (whose flow arrived two steps ago) and its flow registers the loads of row m+4.
+struct FwU { float u1, u2, i0; };
+
 template <int FW, int NW>
 __device__ __forceinline__ void fw_produce(const TbArgs &A, float *inbox, const float *tab, int lane, int xw, int ystart, int nsteps_total,
                                            long long pb, int cur)
@@ -359,43 +368,75 @@ __device__ __forceinline__ void fw_produce(const TbArgs &A, float *inbox, const 
     const int W = A.g.w, H = A.g.h, ld = A.g.ld;
     const int x = min(xw + lane, W - 1);
     const float *U1 = A.pl.u[cur][0] + pb + x, *U2 = A.pl.u[cur][1] + pb + x, *I0 = A.fI0 + pb + x, *P = A.fI1 + pb;
-    // S: the row whose window is in flight; N: the row after it, whose flow / I0 loads are in flight
-    float u1s = 0.f, u2s = 0.f, i0s = 0.f, wx[4], wy[4], R[6][6];
-    int sx = 0, sy = 0;
-    bool inter = false;
-    float u1n, u2n, i0n;
-    const auto load_n = [&](int m) {
+    FwU U[4];
+    float R[2][6][6];
+    const auto load_u = [&](int m, FwU &u) {
         const long long ro = (long long)min(max(ystart + m, 0), H - 1) * ld;   // wave-uniform
-        u1n = U1[ro]; u2n = U2[ro]; i0n = I0[ro];
+#if FW_X == 0
+        u.u1 = U1[ro]; u.u2 = U2[ro]; u.i0 = I0[ro];
+#else
+        u.u1 = u.u2 = 0.25f; u.i0 = (float)ro;
+#endif
     };
-    const auto issue_s = [&](int m) {   // N -> S: window origin and weights of row m, gathers issued
-        u1s = u1n; u2s = u2n; i0s = i0n;
-        warp_coords<SEM>(tab, x, min(max(ystart + m, 0), H - 1), u1s, u2s, sx, sy, wx, wy);
-        inter = window_interior(sx, sy, W, H);
-        if (inter) window_gather(R, P, ld, sx, sy);
+    const auto gather = [&](int m, const FwU &u, float (&Rw)[6][6]) {   // window of row m, origin from its flow
+        int sx, sy;
+        float wx[4], wy[4];
+        warp_coords<SEM>(tab, x, min(max(ystart + m, 0), H - 1), u.u1, u.u2, sx, sy, wx, wy);
+#if FW_X == 0
+        // UNCONDITIONAL: a lane whose window touches the border (it takes window_border when the row is finished) gathers the nearest
+        // interior window instead and ignores it.  With the gathers under a branch the compiler cannot count the loads in flight and
+        // waits for nearly all of them at the head of every row (measured: the kernel then runs as slowly as warp + pass in sequence).
+        window_gather(Rw, P, ld, min(max(sx, 1), W - 5), min(max(sy, 1), H - 5));
+#else
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Rw[r][c] = u.u1 + (float)(r * 6 + c);
+#endif
     };
-    const auto finish = [&](int m) {    // row m: sums, rho_c, hand-over; then the next row's requests
+    // row m: sums, rho_c, hand-over (window origin and weights are a pure function of the pixel and its flow: recomputed here instead of
+    // being held for two steps -- twenty registers for twenty operations)
+    const auto sums = [&](int m, const FwU &u, const float (&Rw)[6][6]) {
         float v0, v1, v2;
-        if (inter) window_sums<SEM, FAST>(R, wx, wy, v0, v1, v2);
+#if FW_X == 1
+        v0 = v1 = v2 = 0.f;
+#else
+        int sx, sy;
+        float wx[4], wy[4];
+        warp_coords<SEM>(tab, x, min(max(ystart + m, 0), H - 1), u.u1, u.u2, sx, sy, wx, wy);
+#if FW_X == 2
+        window_sums<SEM, FAST>(Rw, wx, wy, v0, v1, v2);
+#else
+        if (window_interior(sx, sy, W, H)) window_sums<SEM, FAST>(Rw, wx, wy, v0, v1, v2);
         else window_border<SEM>(P, W, H, ld, sx, sy, wx, wy, v0, v1, v2);
+#endif
+#endif
         float *q = inbox + (m & (FW_RING - 1)) * FW_SLOT + lane;
         q[0] = v1; q[64] = v2;
-        q[128] = (v0 - v1 * u1s - v2 * u2s - i0s);   // calcGradRho, optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163 (warp_px)
-        issue_s(m + 1);
-        load_n(m + 2);
+        q[128] = (v0 - v1 * u.u1 - v2 * u.u2 - u.i0);   // calcGradRho, optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163 (warp_px)
     };
-    load_n(0);
-    issue_s(0);
-    load_n(1);
-    finish(0);
-    finish(1);
+#if FW_X == 1
+#define FW_ROW(m, k) do { sums((m), U[(k) & 3], R[(k) & 1]); } while (0)
+#else
+#define FW_ROW(m, k) do { sums((m), U[(k) & 3], R[(k) & 1]); gather((m) + 2, U[((k) + 2) & 3], R[(k) & 1]); load_u((m) + 4, U[(k) & 3]); } while (0)
+#endif
+    load_u(0, U[0]); load_u(1, U[1]); load_u(2, U[2]); load_u(3, U[3]);
+    gather(0, U[0], R[0]); gather(1, U[1], R[1]);
+    FW_ROW(0, 0);
+    FW_ROW(1, 1);
     xbarrier();   // opens the pipeline: rows 0 and 1 are in the inbox
+    // producer step n finishes row n + 2; four steps per trip (row n + 2 + k lives in U[(k + 2) & 3], R[k & 1]).  The trip is
+    // UNCONDITIONAL -- every path through the loop issues the same loads in the same order, so the compiler knows how many are in flight
+    // behind the one it waits for; the consumers' step count is a multiple of 13, the one to three steps left over run after the loop
+    int n = 0;
 #pragma unroll 1
-    for (int n = 0; n < nsteps_total; ++n) {
-        xbarrier();
-        finish(n + 2);
-        xbarrier();
+    for (; n + 4 <= nsteps_total; n += 4) {
+        xbarrier(); FW_ROW(n + 2, 2); xbarrier();
+        xbarrier(); FW_ROW(n + 3, 3); xbarrier();
+        xbarrier(); FW_ROW(n + 4, 0); xbarrier();
+        xbarrier(); FW_ROW(n + 5, 1); xbarrier();
     }
+    if (n < nsteps_total) { xbarrier(); FW_ROW(n + 2, 2); xbarrier(); }
+    if (n + 1 < nsteps_total) { xbarrier(); FW_ROW(n + 3, 3); xbarrier(); }
+    if (n + 2 < nsteps_total) { xbarrier(); FW_ROW(n + 4, 0); xbarrier(); }
+#undef FW_ROW
     for (int i = 0; i < NW - 1; ++i) xbarrier();   // the consumers' skew
 }
 
@@ -1007,7 +1048,7 @@ bool tb_nograd_ok(int T, const Geo &g)
 // launch, no I1wx / I1wy / rho_c planes.  Which warp arithmetic: the two defaults (CPU class + tap-by-tap sums, cv::cuda + separable sums).
 bool tb_fused_ok(int T, const Geo &g, int semantics, bool fast_warp)
 {
-    if (!tuning().tb_fw || !tb_nograd_ok(T, g)) return false;
+    if (!tuning().tb_fw || !tb_nograd_ok(T, g) || g.w < 6 || g.h < 6) return false;   // (the producers' unconditional window gather needs an interior)
     return (semantics == MI_SEM_CPU_REF && !fast_warp) || (semantics == MI_SEM_CUDA_COMPAT && fast_warp);
 }
 

@@ -318,6 +318,21 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(gpu):
     assert out["gathered_flows_identical"] is True, out.get("with_scatter_gather")
 
 
+def test_fused_warp_pass_is_bit_identical(gpu):
+    """Round 5: `MIFLOW_TB_FW=1` runs a warp whose iterations are one pass of the T = 10 kernel INSIDE that pass --
+    four producer waves per workgroup compute I1wx, I1wy, rho_c with the warp kernel's own per-pixel routines (tvl1_warp_px.h) and
+    hand them to the joined consumer waves through LDS; the three planes never reach HBM.  Same operations in the same order: the flows
+    of fixed-work calcs (both arithmetics, f32 and u8 frames, odd sizes, 8..64 pairs, one and two passes per warp) must not change by
+    a bit (tools/fw_check.py runs each setting in its own process: the switch is read once)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fw_check.py")], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert r.stdout.count("IDENTICAL") == 8 and "DIFFERENT" not in r.stdout, r.stdout[-3000:]
+    assert "fused warp" in r.stdout   # the fused kernel really ran in the MIFLOW_TB_FW=1 process (MIFLOW_TB_VERBOSE lines)
+
+
 def test_result_changing_switches_are_not_read_by_the_release_library(gpu):
     """Round 5: `MIFLOW_TB_P16=1` (dual variable as 16-bit fixed point between passes: changes results) and
     `MIFLOW_X_SKIP` (skips launches: wrong results) exist in the experiments build only.  With either set, the shipped library computes
