@@ -339,6 +339,13 @@ MI_API int mi_surf_max_features(const mi_surf *h, int rows, int cols, int *max_f
  * >= max_features columns.  Features come out in a deterministic order (octave, layer, row, column).
  * Synchronises `stream` once to return the count (the reference's keypoints.cols = featureCounter). */
 MI_API int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, int *n_features, void *stream);
+/* Replaces: SURF_CUDA::operator()(img, mask, keypoints, descriptors) = detectKeypoints + computeDescriptors,
+ * surf.cuda.cpp:380-397 (137-236) WITHOUT the read-back of keypoints.cols between the two (:205-209): the descriptor kernels read the
+ * feature count on the device.  keypoints as mi_surf_detect; descriptors: MI_32FC1, >= max_features rows x descriptorSize(); rows
+ * [0, *n_features) are written.  Synchronises `stream` once, at the end, to return the count.  Same keypoints and descriptors, bit
+ * for bit, as mi_surf_detect followed by mi_surf_compute_descriptors. */
+MI_API int mi_surf_detect_and_compute(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, mi_mat *descriptors,
+                                      int *n_features, void *stream);
 /* n frames through one handle; masks may be NULL.  keypoints[i] / n_features[i] as mi_surf_detect. */
 MI_API int mi_surf_detect_batch(mi_surf *h, int n, const mi_mat *imgs, const mi_mat *masks, mi_mat *keypoints, int *n_features, void *stream);
 /* Replaces: SURF_CUDA_Invoker::findOrientation for provided keypoints, surf.cuda.cpp:217-225,391-393 */

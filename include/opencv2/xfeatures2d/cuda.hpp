@@ -104,8 +104,27 @@ public:
     {
         push();
         mi_mat i = miMat(img);
-        if (!useProvidedKeypoints) (*this)(img, mask, keypoints);
-        else if (!upright) { mi_mat k = miMat(keypoints); miCheck(mi_surf_compute_orientation(h_, &i, &k, keypoints.cols, nullptr)); }
+        if (!useProvidedKeypoints) {
+            // one enqueue for the frame: the descriptor kernels read the feature count on the device (mi_surf_detect_and_compute),
+            // no read-back of keypoints.cols between detectKeypoints and computeDescriptors (surf.cuda.cpp:205-209)
+            int maxf = 0;
+            miCheck(mi_surf_max_features(h_, img.rows, img.cols, &maxf));
+            if (keypoints.rows != ROWS_COUNT || keypoints.cols < maxf || keypoints.type() != CV_32FC1) {
+                keypoints.release();
+                keypoints.create(ROWS_COUNT, maxf, CV_32FC1);
+            }
+            if (descriptors.rows < maxf || descriptors.cols != descriptorSize() || descriptors.type() != CV_32FC1) {
+                descriptors.release();
+                descriptors.create(maxf, descriptorSize(), CV_32FC1);
+            }
+            mi_mat m = miMat(mask), k = miMat(keypoints), d = miMat(descriptors);
+            int n = 0;
+            miCheck(mi_surf_detect_and_compute(h_, &i, mask.empty() ? nullptr : &m, &k, &d, &n, nullptr));
+            keypoints.cols = n;   // :209
+            if (n > 0) descriptors.rows = n; else descriptors.release();
+            return;
+        }
+        if (!upright) { mi_mat k = miMat(keypoints); miCheck(mi_surf_compute_orientation(h_, &i, &k, keypoints.cols, nullptr)); }
         const int n = keypoints.cols;
         if (n > 0) {
             if (descriptors.rows < n || descriptors.cols != descriptorSize() || descriptors.type() != CV_32FC1)

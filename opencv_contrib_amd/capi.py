@@ -167,6 +167,7 @@ def lib():
         "mi_surf_descriptor_size": (i, [vp]),
         "mi_surf_max_features": (i, [vp, i, i, C.POINTER(i)]),
         "mi_surf_detect": (i, [vp, PM, PM, PM, C.POINTER(i), vp]),
+        "mi_surf_detect_and_compute": (i, [vp, PM, PM, PM, PM, C.POINTER(i), vp]),
         "mi_surf_detect_batch": (i, [vp, i, PM, PM, PM, C.POINTER(i), vp]),
         "mi_surf_compute_orientation": (i, [vp, PM, PM, i, vp]),
         "mi_surf_compute_descriptors": (i, [vp, PM, PM, i, PM, vp]),

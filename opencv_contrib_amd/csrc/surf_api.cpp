@@ -207,10 +207,10 @@ static int check_kp(const mi_mat *kp, int min_cols)
     return MI_OK;
 }
 
-int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, int *n_features, void *stream)
+// Everything of SURF_CUDA_Invoker's detectKeypoints + findOrientation enqueued on `st`; the feature count stays on the device
+// (h->counters[0]).  *max_features = the bound the keypoint matrix was checked against.
+static int detect_enqueue(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, int *max_features, hipStream_t st)
 {
-    MI_REQUIRE(h && n_features, MI_ERR_BAD_ARG, "null argument");
-    hipStream_t st = (hipStream_t)stream;
     const mi_surf_params &P = h->P;
     int rc;
     if ((rc = check_img(img, "img"))) return rc;
@@ -244,11 +244,51 @@ int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *ke
         if ((rc = surf::interpolate(h->det, h->dld, rows, cols, octave, h->cand, h->counters + 1 + octave, maxC, h->itmp, kp, kld, maxF, h->counters, st))) return rc;
     }
     if ((rc = surf::orientation(h->sum, h->sld, rows, cols, kp, kld, h->counters, maxF, P.upright != 0, h->apt, st))) return rc;   // :211-214
+    *max_features = maxF;
+    return MI_OK;
+}
+
+static int read_count(mi_surf *h, int maxF, int *n_features, hipStream_t st)
+{
     unsigned nf = 0;
     MI_HIP_TRY(hipMemcpyAsync(&nf, h->counters, sizeof(unsigned), hipMemcpyDeviceToHost, st));                       // :205-207
     MI_HIP_TRY(hipStreamSynchronize(st));
     *n_features = (int)(nf < (unsigned)maxF ? nf : (unsigned)maxF);
     return MI_OK;
+}
+
+int mi_surf_detect(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, int *n_features, void *stream)
+{
+    MI_REQUIRE(h && n_features, MI_ERR_BAD_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int maxF = 0;
+    if (const int rc = detect_enqueue(h, img, mask, keypoints, &maxF, st)) return rc;
+    return read_count(h, maxF, n_features, st);
+}
+
+// detect + describe with the feature count left on the device between the two (round 5): the reference's operator()(img, mask,
+// keypoints, descriptors) reads keypoints.cols back before it launches compute_descriptors (surf.cuda.cpp:205-209, 227-236) -- a host
+// round trip in the middle of every frame.  Here the descriptor kernels read the count themselves; the one synchronisation that
+// returns it to the caller comes after everything is enqueued.  descriptors: at least max_features rows.
+int mi_surf_detect_and_compute(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_mat *keypoints, mi_mat *descriptors, int *n_features, void *stream)
+{
+    MI_REQUIRE(h && n_features, MI_ERR_BAD_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    int maxF = 0, rc;
+    if ((rc = check_img(img, "img"))) return rc;
+    {
+        int mc;
+        if ((rc = limits(h->P, img->rows, img->cols, &maxF, &mc))) return rc;
+    }
+    const int dsz = h->P.extended ? 128 : 64;
+    MI_REQUIRE(descriptors && descriptors->data && descriptors->type == MI_32FC1 && descriptors->rows >= maxF && descriptors->cols == dsz &&
+               descriptors->step % 4 == 0 && descriptors->step >= (size_t)dsz * 4, MI_ERR_BAD_ARG,
+               "descriptors must be CV_32FC1 with at least maxFeatures rows and descriptorSize() columns");
+    if ((rc = detect_enqueue(h, img, mask, keypoints, &maxF, st))) return rc;
+    if ((rc = surf::descriptors((const unsigned char *)img->data, (long long)img->step, img->rows, img->cols, (const float *)keypoints->data,
+                                (int)(keypoints->step / 4), maxF, h->P.extended != 0, (float *)descriptors->data,
+                                (long long)(descriptors->step / 4), h->dw, st, h->counters))) return rc;
+    return read_count(h, maxF, n_features, st);
 }
 
 // n frames through one handle (masks may be NULL, or hold NULL-data entries).  A 4K frame fills the device and the feature

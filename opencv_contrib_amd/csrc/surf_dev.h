@@ -32,8 +32,9 @@ size_t interp_tmp_bytes(int max_candidates);
 // nfeat_dev != nullptr: count read on the device (grid sized for n_or_max); else n_or_max features
 int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int kld, const unsigned *nfeat_dev, int n_or_max,
                 bool upright, const float *apt /* [3][113] x, y, w */, hipStream_t s);
+// nfeat_dev != nullptr: the count is read on the device and nfeat is its upper bound (desc must have that many rows)
 int descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp, int kld, int nfeat, bool extended,
-                float *desc, long long dstep_floats, const float *dw /* [400] */, hipStream_t s);
+                float *desc, long long dstep_floats, const float *dw /* [400] */, hipStream_t s, const unsigned *nfeat_dev = nullptr);
 int dbg_scan(const unsigned *in_dev, unsigned *out_dev, hipStream_t s);
 
 }  // namespace surf

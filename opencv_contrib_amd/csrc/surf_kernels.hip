@@ -21,6 +21,7 @@
 // Haar responses accumulate in double like the reference (u32 integral differences do not fit a float mantissa).
 #include "surf_dev.h"
 #include <cfloat>
+#include <algorithm>
 
 namespace mi {
 namespace surf {
@@ -779,25 +780,29 @@ __device__ __forceinline__ float desc_window(Win &w, const unsigned char *img, l
 // rotated window through global memory) -> desc_tail.  Features whose cell side s reaches s_stage are left to k_descriptors_staged.
 template <bool EXT>
 __global__ __launch_bounds__(512) void k_descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
-                                                     int kld, int nfeat, float *desc, long long dstep /* floats */, const float *dw, float s_stage,
-                                                     int tile_bytes)
+                                                     int kld, int nfeat_host, const unsigned *nfeat_dev, float *desc, long long dstep /* floats */, const float *dw,
+                                                     float s_stage, int tile_bytes)
 {
     __shared__ float P[21][21];
     __shared__ float D[128];
     __shared__ float part[4];
+    // nfeat_dev: the count is read on the device (detect + describe without a host round trip between them, round 5); nfeat_host then
+    // bounds it (maxFeatures) and the grid is a fixed number of workgroups that walk the features block-cyclically
+    const int nfeat = nfeat_dev ? min((int)*nfeat_dev, nfeat_host) : nfeat_host;
     // features are ordered by octave, i.e. by patch cost (441 x s^2 texel reads, s up to ~29 at 4 octaves): launch the
     // expensive ones first so they do not form the tail of the grid
-    const int f = nfeat - 1 - (int)blockIdx.x;
-    if (f < 0) return;
-    Win w;
-    const float s = desc_window(w, img, istep, rows, cols, kp, kld, f);
-    if (desc_staged(s, s_stage, tile_bytes)) return;
-    if (threadIdx.x < 441) {
-        const int tid = threadIdx.x, xl = tid % 21, yl = tid / 21;
-        P[yl][xl] = s > 1 ? area_filter(w, (float)xl, (float)yl, s) : linear_filter(w, yl * s, xl * s);
+    for (int f = nfeat - 1 - (int)blockIdx.x; f >= 0; f -= (int)gridDim.x) {
+        Win w;
+        const float s = desc_window(w, img, istep, rows, cols, kp, kld, f);
+        if (desc_staged(s, s_stage, tile_bytes)) continue;
+        if (threadIdx.x < 441) {
+            const int tid = threadIdx.x, xl = tid % 21, yl = tid / 21;
+            P[yl][xl] = s > 1 ? area_filter(w, (float)xl, (float)yl, s) : linear_filter(w, yl * s, xl * s);
+        }
+        __syncthreads();
+        desc_tail<EXT>(P, D, part, dw, desc + (long long)f * dstep);
+        __syncthreads();   // (a workgroup that walks several features: P, D, part are free again)
     }
-    __syncthreads();
-    desc_tail<EXT>(P, D, part, dw, desc + (long long)f * dstep);
 }
 
 // The same for LARGE features (round 3, r06w: the 908 octave-3 features of the 4K frame took 743 of the 1 146 us, 818 ns each -- a
@@ -843,56 +848,58 @@ __device__ __forceinline__ float area_filter_lds(const unsigned char *tile, int 
 }
 template <bool EXT>
 __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
-                                                            int kld, int nfeat, float *desc, long long dstep /* floats */, const float *dw, float s_stage,
-                                                            int tile_bytes)
+                                                            int kld, int nfeat_host, const unsigned *nfeat_dev, float *desc, long long dstep /* floats */,
+                                                            const float *dw, float s_stage, int tile_bytes)
 {
     __shared__ float P[21][21];
     __shared__ float D[128];
     __shared__ float part[4];
     extern __shared__ unsigned char tile[];
-    const int f = nfeat - 1 - (int)blockIdx.x;
-    if (f < 0) return;
-    Win w;
-    const float s = desc_window(w, img, istep, rows, cols, kp, kld, f);
-    if (!desc_staged(s, s_stage, tile_bytes)) return;
-    const int dxmax = (int)floorf(20.f * s + s);              // the largest sx2 of area_filter (x = 20)
-    const int nc = dxmax + 2;                                 // tile columns: dx = -1 .. dxmax
+    const int nfeat = nfeat_dev ? min((int)*nfeat_dev, nfeat_host) : nfeat_host;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ly = lane >> 3, lx = lane & 7;
-    const int nbc = (nc + 7) >> 3;
-    for (int ya = 0; ya < 21;) {
-        // the strip: patch rows ya .. yb - 1, as many as the tile holds (at least one: the host sizes the tile for that)
-        const int dy_lo = (int)ceilf((float)ya * s) - 1;
-        int yb = ya + 1;
-        while (yb < 21 && ((int)floorf((float)yb * s + s) - dy_lo + 1) * nc <= tile_bytes) ++yb;
-        const int nr = (int)floorf((float)(yb - 1) * s + s) - dy_lo + 1;
-        const int nblk = ((nr + 7) >> 3) * nbc;
-        // 8 x 8 blocks of the window lattice, block row / column carried along (no division per block); eight blocks per trip so that
-        // their loads are in flight together
-        int br = wv / nbc, bc = wv - br * nbc;
-        for (int blk = wv; blk < nblk; blk += 64) {
-            float v[8];
-            int rr[8], cc[8];
+    for (int f = nfeat - 1 - (int)blockIdx.x; f >= 0; f -= (int)gridDim.x) {
+        Win w;
+        const float s = desc_window(w, img, istep, rows, cols, kp, kld, f);
+        if (!desc_staged(s, s_stage, tile_bytes)) continue;
+        const int dxmax = (int)floorf(20.f * s + s);              // the largest sx2 of area_filter (x = 20)
+        const int nc = dxmax + 2;                                 // tile columns: dx = -1 .. dxmax
+        const int nbc = (nc + 7) >> 3;
+        for (int ya = 0; ya < 21;) {
+            // the strip: patch rows ya .. yb - 1, as many as the tile holds (at least one: the host sizes the tile for that)
+            const int dy_lo = (int)ceilf((float)ya * s) - 1;
+            int yb = ya + 1;
+            while (yb < 21 && ((int)floorf((float)yb * s + s) - dy_lo + 1) * nc <= tile_bytes) ++yb;
+            const int nr = (int)floorf((float)(yb - 1) * s + s) - dy_lo + 1;
+            const int nblk = ((nr + 7) >> 3) * nbc;
+            // 8 x 8 blocks of the window lattice, block row / column carried along (no division per block); eight blocks per trip so that
+            // their loads are in flight together
+            int br = wv / nbc, bc = wv - br * nbc;
+            for (int blk = wv; blk < nblk; blk += 64) {
+                float v[8];
+                int rr[8], cc[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                rr[u] = br * 8 + ly; cc[u] = bc * 8 + lx;
-                v[u] = (blk + 8 * u < nblk && rr[u] < nr && cc[u] < nc) ? win_get(w, dy_lo + rr[u], cc[u] - 1) : -1.f;
-                bc += 8;
-                while (bc >= nbc) { bc -= nbc; ++br; }
+                for (int u = 0; u < 8; ++u) {
+                    rr[u] = br * 8 + ly; cc[u] = bc * 8 + lx;
+                    v[u] = (blk + 8 * u < nblk && rr[u] < nr && cc[u] < nc) ? win_get(w, dy_lo + rr[u], cc[u] - 1) : -1.f;
+                    bc += 8;
+                    while (bc >= nbc) { bc -= nbc; ++br; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (v[u] >= 0.f) tile[rr[u] * nc + cc[u]] = (unsigned char)v[u];
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (v[u] >= 0.f) tile[rr[u] * nc + cc[u]] = (unsigned char)v[u];
+            __syncthreads();
+            const int nsmp = (yb - ya) * 21;
+            if ((int)threadIdx.x < nsmp) {
+                const int xl = threadIdx.x % 21, yl = ya + threadIdx.x / 21;
+                P[yl][xl] = area_filter_lds(tile, nc, dy_lo, (float)xl, (float)yl, s, w.win);
+            }
+            __syncthreads();
+            ya = yb;
         }
-        __syncthreads();
-        const int nsmp = (yb - ya) * 21;
-        if ((int)threadIdx.x < nsmp) {
-            const int xl = threadIdx.x % 21, yl = ya + threadIdx.x / 21;
-            P[yl][xl] = area_filter_lds(tile, nc, dy_lo, (float)xl, (float)yl, s, w.win);
-        }
-        __syncthreads();
-        ya = yb;
+        desc_tail<EXT>(P, D, part, dw, desc + (long long)f * dstep);
+        __syncthreads();   // (a workgroup that walks several features)
     }
-    desc_tail<EXT>(P, D, part, dw, desc + (long long)f * dstep);
 }
 
 // ------------------------------------------------------------------ octave 0 of the fused launch on an LDS tile (round 3)
@@ -1284,13 +1291,16 @@ static float surf_stage_s()
     return v;
 }
 int descriptors(const unsigned char *img, long long istep, int rows, int cols, const float *kp, int kld, int nfeat, bool extended,
-                float *desc, long long dstep_floats, const float *dw, hipStream_t s)
+                float *desc, long long dstep_floats, const float *dw, hipStream_t s, const unsigned *nfeat_dev)
 {
     if (nfeat <= 0) return MI_OK;
     const float ss = surf_stage_s();
     static const int kTileBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 48; return (kb >= 16 && kb <= 150 ? kb : 48) * 1024; }();
-    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
-    else hipLaunchKernelGGL(k_descriptors<false>, dim3(nfeat), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
+    // host-known count: one workgroup per feature.  Count on the device (nfeat = its upper bound, maxFeatures): a fixed grid of a few
+    // workgroups per CU walks the features block-cyclically, most expensive first -- no launch of tens of thousands of empty workgroups
+    const int grid = nfeat_dev ? std::min(nfeat, 16 * (device_simds() / 4)) : nfeat;
+    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(grid), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
+    else hipLaunchKernelGGL(k_descriptors<false>, dim3(grid), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
     if (ss < 1e29f) {
         static const hipError_t attr_rc = [] {
             hipError_t e = hipFuncSetAttribute((const void *)k_descriptors_staged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes);
@@ -1298,8 +1308,8 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
             return e;
         }();
         MI_HIP_TRY(attr_rc);
-        if (extended) hipLaunchKernelGGL(k_descriptors_staged<true>, dim3(nfeat), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
-        else hipLaunchKernelGGL(k_descriptors_staged<false>, dim3(nfeat), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, desc, dstep_floats, dw, ss, kTileBytes);
+        if (extended) hipLaunchKernelGGL(k_descriptors_staged<true>, dim3(grid), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
+        else hipLaunchKernelGGL(k_descriptors_staged<false>, dim3(grid), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
     }
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

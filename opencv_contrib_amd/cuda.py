@@ -1024,7 +1024,16 @@ class SURF_CUDA:
         import torch
         sp = C.c_void_p(stream) if stream is not None else capi.current_stream_ptr()
         if not useProvidedKeypoints:
-            keypoints = self.detect(img, mask, stream)
+            # one enqueue for the frame: the descriptor kernels read the feature count on the device (mi_surf_detect_and_compute)
+            mf = C.c_int()
+            capi.check(capi.lib().mi_surf_max_features(self._h, img.shape[0], img.shape[1], C.byref(mf)))
+            kp = torch.empty((7, mf.value), dtype=torch.float32, device=img.device)
+            desc = torch.empty((mf.value, self.descriptorSize()), dtype=torch.float32, device=img.device)
+            n = C.c_int()
+            mm = C.byref(capi.mat_from_tensor(mask)) if mask is not None else None
+            mk, md = capi.mat_from_tensor(kp), capi.mat_from_tensor(desc)
+            capi.check(capi.lib().mi_surf_detect_and_compute(self._h, C.byref(capi.mat_from_tensor(img)), mm, C.byref(mk), C.byref(md), C.byref(n), sp))
+            return kp[:, : n.value], desc[: n.value]
         elif not self._p.upright:
             capi.check(capi.lib().mi_surf_compute_orientation(self._h, C.byref(capi.mat_from_tensor(img)),
                                                               C.byref(capi.mat_from_tensor(keypoints)), keypoints.shape[1], sp))

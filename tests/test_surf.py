@@ -175,6 +175,31 @@ def test_detect_per_octave_and_all_octave_launch_plans_agree_with_the_oracle(gpu
 
 
 @gpu_mark
+@pytest.mark.parametrize("shape,thr,extended", [((300, 400), 100.0, False), ((1080, 1920), 400.0, False), ((720, 1283), 50.0, True)])
+def test_detect_and_compute_with_the_count_on_the_device_is_bit_identical(gpu, shape, thr, extended):
+    """Round 5: `mi_surf_detect_and_compute` leaves the feature count on the device between detectKeypoints and
+    computeDescriptors (the reference reads keypoints.cols back in between, surf.cuda.cpp:205-209) -- the descriptor kernels read it
+    themselves and a fixed grid walks the features.  Keypoints and descriptors must equal, bit for bit, detect() followed by
+    compute_descriptors with the host-known count (one workgroup per feature); overflow (tiny keypointsRatio) and a mask included."""
+    from opencv_contrib_amd import cuda
+    img = synth.blob_image(*shape, seed=31)
+    t = T(img, gpu)
+    for ratio, mask in ((0.05 if shape[0] < 1000 else 0.01, None), (0.0005, None), (0.05 if shape[0] < 1000 else 0.01, "m")):
+        m = None
+        if mask:
+            mm = np.zeros_like(img); mm[shape[0] // 8: shape[0] // 2, shape[1] // 6: shape[1] - 40] = 1
+            m = T(mm, gpu)
+        alg = cuda.SURF_CUDA.create(thr, 4, 2, extended, ratio, False)
+        kp1, d1 = alg.detectWithDescriptors(t, m)
+        kp0 = alg.detect(t, m)
+        assert kp0.shape == kp1.shape and kp0.shape[1] > 5
+        np.testing.assert_array_equal(N(kp0), N(kp1))
+        _, d0 = alg.detectWithDescriptors(t, None, kp0.clone(), True)   # provided keypoints: host-known count, one workgroup per feature
+        assert d0.shape == d1.shape == (kp0.shape[1], alg.descriptorSize())
+        np.testing.assert_array_equal(N(d0), N(d1))
+
+
+@gpu_mark
 def test_detect_mask_overflow_and_provided_keypoints(gpu, oracle):
     from opencv_contrib_amd import cuda
     img = synth.blob_image(260, 330, seed=13)
