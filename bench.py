@@ -148,6 +148,27 @@ def make_inputs(n, h, w, dev, distinct=16, base=None, **kw):
     return I0, I1, base
 
 
+def synth_sequence(n, h, w, dev, seed=4321):
+    """n consecutive frames (CV_32FC1 in [0, 1], on `dev`) of one synthetic sequence: a band-limited texture drifting along the smooth
+    field of synth.flow_field -- frame k samples the texture at p - k x F(p) (bicubic) -- so consecutive pairs have a smooth, slowly
+    varying flow of a few pixels, like neighbouring frames of a video."""
+    import numpy as np
+    import torch
+    from opencv_contrib_amd import synth
+    sc = max(1.0, w / 640.0)
+    tex = torch.from_numpy((synth.texture(h, w, seed, 2.0 * sc) / 255.0).astype(np.float32)).to(dev)[None, None]
+    u, v = synth.flow_field(h, w, 0.5 * sc)
+    u, v = torch.from_numpy(u.astype(np.float32)).to(dev), torch.from_numpy(v.astype(np.float32)).to(dev)
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+    out = []
+    for k in range(n):
+        gx = (xs - k * u) / (w - 1) * 2 - 1
+        gy = (ys - k * v) / (h - 1) * 2 - 1
+        f = torch.nn.functional.grid_sample(tex, torch.stack([gx, gy], -1)[None], mode="bicubic", padding_mode="reflection", align_corners=True)
+        out.append(f[0, 0].clamp(0, 1).contiguous())
+    return out
+
+
 def omp_set_threads(n):
     """Thread count of the OpenMP runtime the oracle libraries are linked against (libgomp)."""
     try:
@@ -993,7 +1014,7 @@ def secondary(args):
     configs[2] StereoBM 1080p/128/15, configs[3] SURF 4K; each with its bound, fraction and CPU baseline."""
     import copy
     out = {}
-    for name, fn, kw in (("stereobm_1080p_nd128_bs15", bench_stereobm, dict(width=1920, height=1080, batch=8, steps=3, warmup=1)),
+    for name, fn, kw in (("stereobm_1080p_nd128_bs15", bench_stereobm, dict(width=1920, height=1080, batch=64, steps=2, warmup=1)),
                          ("farneback_640x480", bench_farneback, dict(width=640, height=480, batch=16, steps=3, warmup=1)),
                          ("surf_4k_thr400", bench_surf, dict(width=3840, height=2160, batch=2, steps=3, warmup=1))):
         a = copy.copy(args)
@@ -1615,6 +1636,30 @@ def main():
                 del a1, one, q0, q1
             except Exception as e:
                 var[tag] = {"error": repr(e)[:200]}
+        # The convergence-checked path as a VIDEO caller uses it: 17 consecutive frames of one synthetic sequence
+        # (a texture drifting along a smooth flow field: frame k = the texture displaced by k x the field), ONE handle, class defaults,
+        # one pair (frame k, frame k + 1) per calc().  The handle's block-length history then comes from the PREVIOUS pair of the same
+        # scene -- between the repeat-same-pair figure (history exact) and three-scenes-in-turn (history from another scene) above.
+        for (ww, hh, tag) in ((640, 480, "video_sequence_640x480_class_defaults"), (W, H, "video_sequence_class_defaults")):
+            try:
+                frames = synth_sequence(17, hh, ww, dev)
+                a1 = cuda.OpticalFlowDual_TVL1.create()
+                one = torch.empty((hh, ww, 2), dtype=torch.float32, device=dev)
+                for _ in range(2):
+                    a1.calc(frames[0], frames[1], one)
+                torch.cuda.synchronize()
+                its_ = []
+                t1 = time.perf_counter()
+                for k in range(1, 16):
+                    a1.calc(frames[k], frames[k + 1], one)
+                torch.cuda.synchronize()
+                e_ = time.perf_counter() - t1
+                its_ = float(np.mean(a1.lastIterations(0)))
+                var[tag] = {"calcs_per_s": 15 / e_, "frames": 17, "executed_iterations_per_warp_mean_last_pair": its_,
+                            "mean_flow_px_last_pair": float(one.abs().mean().item())}
+                del a1, one, frames
+            except Exception as e:
+                var[tag] = {"error": repr(e)[:200]}
         # north_star "1080p/4K pairs": the same object on 3840x2160 pairs (B / 4 pairs per step = the pixels of the 1080p batch)
         try:
             # same motion in pixels as the 1080p pairs (flow_scale 3, texture sigma 6): five 0.8-scales cover it at either size
@@ -1662,6 +1707,11 @@ def main():
                                          f"iterations={cit}, epsilon={args.epsilon}; median {med:.2f} s, min {min(times):.2f} s per pair; "
                                          + ("cv::optflow::DualTVL1OpticalFlow (tvl1flow.cpp verbatim, stub core, OpenMP stripes)" if use_ref
                                             else "oracle/tvl1_ref.c (OpenMP rows)"),
+                               # the reference's class runs on OpenCV's parallel_for_; here its stripes run on the stub core's scheduler
+                               # (oracle/refshim/cvstub: OpenMP static stripes) -- `cores` is the best thread count of the sweep below,
+                               # not the machine: past ~16 threads the class's per-iteration serial parts and the stripes' barriers make
+                               # it slower, which OpenCV's own scheduler would likely hide better
+                               "scheduler": "stub parallel_for_ (OpenMP static stripes), best of the thread sweep",
                                "value_at_min": 1.0 / min(times), "physical_cores": phys, "logical_cpus": os.cpu_count(),
                                "thread_sweep_s_per_pair": {str(k): v for k, v in sweep.items()}, "one_core": one_core}
     if rank == 0 and world == 1 and not args.no_secondary:
