@@ -171,15 +171,19 @@ MI_API void mi_tvl1_destroy(mi_tvl1 *h);
 /* Batched-frames mode over the GPUs of one node (BASELINE configs[4]): independent pairs are cut into contiguous shards,
  * one per device, one host thread + handle + stream pair per device (the reference's multi-device idiom is cv::cuda::setDevice per
  * thread, cudaoptflow/test/test_optflow.cpp:62).  device_ids[0] is the ROOT device: the caller's I0 / I1 / flow matrices live
- * there; shards of the other devices travel peer-to-peer over xGMI (2-D copies, double buffered in chunks, overlapping the
- * compute), no collective.  device_ids == NULL: devices 0 .. n_devices - 1; n_devices <= 0: all.  The same id may be listed more
- * than once (several workers on one GPU).  calc_batch returns when every flow is in the caller's matrices; results are
- * bit-identical to mi_tvl1_calc_batch. */
+ * there; shards of the other devices travel over xGMI, double buffered in chunks, overlapping the compute -- as RCCL point-to-point
+ * messages (grouped ncclSend / ncclRecv on a two-rank communicator per worker, librccl bound at run time: the scatter / gather of
+ * north_star; no reduction, the pairs are independent) or, where RCCL is absent, switched off (MIFLOW_MULTI_RCCL=0), refuses the
+ * pair (the same GPU listed twice) or the matrix is pitched, as 2-D peer copies.  device_ids == NULL: devices 0 .. n_devices - 1;
+ * n_devices <= 0: all.  The same id may be listed more than once (several workers on one GPU).  calc_batch returns when every flow is
+ * in the caller's matrices; results are bit-identical to mi_tvl1_calc_batch. */
 typedef struct mi_tvl1_multi mi_tvl1_multi;
 MI_API int mi_tvl1_multi_create(const mi_tvl1_params *p, int n_devices, const int *device_ids, mi_tvl1_multi **out);
 MI_API int mi_tvl1_multi_device_count(const mi_tvl1_multi *m);
 MI_API int mi_tvl1_multi_set_chunk(mi_tvl1_multi *m, int pairs_per_chunk);   /* pairs staged per copy / compute step (default 16) */
 MI_API int mi_tvl1_multi_calc_batch(mi_tvl1_multi *m, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows);
+/* how the non-root workers are connected to the root: *rccl_links over RCCL, *peer_copy_links by peer copies (either may be NULL) */
+MI_API int mi_tvl1_multi_transport(const mi_tvl1_multi *m, int *rccl_links, int *peer_copy_links);
 MI_API void mi_tvl1_multi_destroy(mi_tvl1_multi *m);
 
 /* Stage-level entry points (dense or pitched MI_32FC1 planes) == the reference's internal

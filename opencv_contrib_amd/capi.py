@@ -125,12 +125,14 @@ def lib():
         "mi_tvl1_multi_device_count": (i, [vp]),
         "mi_tvl1_multi_set_chunk": (i, [vp, i]),
         "mi_tvl1_multi_calc_batch": (i, [vp, i, PM, PM, PM]),
+        "mi_tvl1_multi_transport": (i, [vp, C.POINTER(i), C.POINTER(i)]),
         "mi_tvl1_multi_destroy": (None, [vp]),
         "mi_tvl1_centered_gradient": (i, [PM, PM, PM, vp]),
         "mi_tvl1_warp_backward": (i, [i] + [PM] * 11),
         "mi_tvl1_iterate": (i, [i, i, i, PM, PM, PM, PM, PM, PM, PM, PM, f, f, f, C.POINTER(d), vp]),
         "mi_resize_linear": (i, [i, PM, PM, d, d, i, f, vp]),
         "miflow_selftest_lane_shift": (i, [C.POINTER(i)]),
+        "miflow_selftest_rccl_self_copy": (i, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(i)]),
         "miflow_selftest_jw_fault": (i, [C.POINTER(i)]),
         "miflow_selftest_tvl1_slots": (i, [vp, i, C.POINTER(i), i, vp]),
         "mi_stereobm_default_params": (None, [C.POINTER(StereoBMParams)]),

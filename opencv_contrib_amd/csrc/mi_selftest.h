@@ -23,6 +23,9 @@ MI_API int miflow_selftest_lane_shift(int *out_host /*[128]*/);
 /* *fault = 1 if a wave of a joined-wave blocked iteration kernel ever gave up waiting for its neighbour (never expected: the
  * results of that launch are invalid); synchronises the device */
 MI_API int miflow_selftest_jw_fault(int *fault);
+/* the RCCL binding of mi_tvl1_multi on one device: out_host = in_host after a grouped ncclSend / ncclRecv to self; *available = 0
+ * (and nothing copied) where librccl is absent */
+MI_API int miflow_selftest_rccl_self_copy(const unsigned char *in_host, unsigned char *out_host, size_t bytes, int *available);
 struct mi_tvl1;
 MI_API int miflow_selftest_tvl1_slots(struct mi_tvl1 *h, int pair, int *out_host, int cap_launches, void *stream);
 #ifdef __cplusplus

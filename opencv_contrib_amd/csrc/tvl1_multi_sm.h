@@ -17,6 +17,14 @@
 //   event_create(&e) / event_destroy(e) / event_record(e, s)
 //   dev_malloc(&p, bytes) / dev_free(p)
 //   copy2d_async(dst, dpitch, src, spitch, width_bytes, rows, stream)
+//   link_create(&link, root_dev, dev)                 -- the transport between the root and this worker's device, created by the worker's
+//                                                        thread (device `dev` current on entry and on return).  *link == nullptr: no
+//                                                        collective library / not usable for this pair -- the planes travel as peer copies
+//   link_destroy(link) / link_sync(link)              -- sync drains the link's ROOT-side stream
+//   link_begin(link) / link_end(link)                 -- bracket the planes of one chunk and direction (an RCCL group)
+//   link_plane(link, dst, dpitch, src, spitch, width_bytes, rows, to_worker, worker_stream)
+//                                                     -- one plane root -> worker (to_worker) or worker -> root, ordered on the
+//                                                        worker's stream like copy2d_async
 //   tvl1_create(&params, &h) / tvl1_destroy(h) / tvl1_calc_batch(h, n, I0s, I1s, flows, stream)
 //   last_error()                                      -- thread-local text of the calling thread's last failure
 #pragma once
@@ -45,6 +53,7 @@ public:
         bool is_root = false;
         void *h = nullptr;
         void *compute = nullptr, *copy = nullptr;
+        void *link = nullptr;   // RCCL transport to the root (nullptr: peer copies)
         Slot slot[2];
         int cap_chunk = 0, cap_w = 0, cap_h = 0, cap_type = -1;
         // per call
@@ -80,6 +89,8 @@ public:
 
     int device_count() const { return (int)W_.size(); }
     void set_chunk(int c) { chunk_ = c; }
+    void set_use_links(bool on) { use_links_ = on; }   // before init(): false = peer copies only
+    int link_count() const { int n = 0; for (const Worker &w : W_) n += w.link != nullptr; return n; }
     const std::string &error() const { return err_; }
     const Worker &worker(int i) const { return W_[i]; }
 
@@ -160,6 +171,9 @@ private:
         MI_MSM_TRY(B::tvl1_create(&P_, &w.h));
         MI_MSM_TRY(B::stream_create(&w.compute));
         MI_MSM_TRY(B::stream_create(&w.copy));
+        // north_star: "RCCL over xGMI for the scatter/gather only" -- a two-rank communicator per (root, worker) pair, owned by this
+        // worker's thread alone; absent library or an unusable pair (e.g. the same physical device twice) leave the peer copies
+        if (!w.is_root && use_links_) MI_MSM_TRY(B::link_create(&w.link, root, w.dev));
         for (Slot &s : w.slot) {
             MI_MSM_TRY(B::event_create(&s.in_done));
             MI_MSM_TRY(B::event_create(&s.calc_done));
@@ -184,6 +198,7 @@ private:
         (void)B::set_device(w.dev);
         if (w.copy) (void)B::stream_sync(w.copy);
         if (w.compute) (void)B::stream_sync(w.compute);
+        if (w.link) { (void)B::link_sync(w.link); (void)B::link_destroy(w.link); w.link = nullptr; }
         free_slots(w);
         for (Slot &s : w.slot) {
             if (s.in_done) (void)B::event_destroy(s.in_done);
@@ -232,11 +247,21 @@ private:
             Slot &s = w.slot[k & 1];
             const int c0 = k * chunk, n = std::min(chunk, w.count - c0);
             if (k >= 2) MI_MSM_TRY(B::stream_wait_event(w.copy, s.calc_done));   // the slot's previous compute has read its inputs
-            for (int j = 0; j < n; ++j) {
+            if (w.link) MI_MSM_TRY(B::link_begin(w.link));
+            int rc_planes = MI_OK;
+            for (int j = 0; j < n && !rc_planes; ++j) {
                 const mi_mat &m0 = I0s[w.first + c0 + j], &m1 = I1s[w.first + c0 + j];
-                MI_MSM_TRY(B::copy2d_async((char *)s.in0 + j * in_plane, in_pitch, m0.data, m0.step, in_pitch, (size_t)Ht, w.copy));
-                MI_MSM_TRY(B::copy2d_async((char *)s.in1 + j * in_plane, in_pitch, m1.data, m1.step, in_pitch, (size_t)Ht, w.copy));
+                if (w.link) {
+                    rc_planes = B::link_plane(w.link, (char *)s.in0 + j * in_plane, in_pitch, m0.data, m0.step, in_pitch, (size_t)Ht, 1, w.copy);
+                    if (!rc_planes) rc_planes = B::link_plane(w.link, (char *)s.in1 + j * in_plane, in_pitch, m1.data, m1.step, in_pitch, (size_t)Ht, 1, w.copy);
+                } else {
+                    rc_planes = B::copy2d_async((char *)s.in0 + j * in_plane, in_pitch, m0.data, m0.step, in_pitch, (size_t)Ht, w.copy);
+                    if (!rc_planes) rc_planes = B::copy2d_async((char *)s.in1 + j * in_plane, in_pitch, m1.data, m1.step, in_pitch, (size_t)Ht, w.copy);
+                }
             }
+            if (rc_planes) (void)fail(w, rc_planes);
+            if (w.link) { const int rc_end = B::link_end(w.link); if (!rc_planes) MI_MSM_TRY(rc_end); }   // a group once begun is always closed
+            if (rc_planes) return rc_planes;
             MI_MSM_TRY(B::event_record(s.in_done, w.copy));
             return MI_OK;
         };
@@ -255,10 +280,16 @@ private:
             MI_MSM_TRY(B::tvl1_calc_batch(w.h, n, a.data(), b.data(), f.data(), w.compute));
             MI_MSM_TRY(B::event_record(s.calc_done, w.compute));
             MI_MSM_TRY(B::stream_wait_event(w.copy, s.calc_done));
-            for (int j = 0; j < n; ++j) {
+            if (w.link) MI_MSM_TRY(B::link_begin(w.link));
+            int rc_planes = MI_OK;
+            for (int j = 0; j < n && !rc_planes; ++j) {
                 mi_mat &mf = flows[w.first + c0 + j];
-                MI_MSM_TRY(B::copy2d_async(mf.data, mf.step, (char *)s.out + j * out_plane, out_pitch, out_pitch, (size_t)Ht, w.copy));
+                rc_planes = w.link ? B::link_plane(w.link, mf.data, mf.step, (char *)s.out + j * out_plane, out_pitch, out_pitch, (size_t)Ht, 0, w.copy)
+                                   : B::copy2d_async(mf.data, mf.step, (char *)s.out + j * out_plane, out_pitch, out_pitch, (size_t)Ht, w.copy);
             }
+            if (rc_planes) (void)fail(w, rc_planes);
+            if (w.link) { const int rc_end = B::link_end(w.link); if (!rc_planes) MI_MSM_TRY(rc_end); }
+            if (rc_planes) return rc_planes;
             MI_MSM_TRY(B::event_record(s.out_done, w.copy));
         }
         return MI_OK;
@@ -272,9 +303,11 @@ private:
         if (w.count == 0) return MI_OK;
         const int rc = enqueue_shard(w, chunk, I0s, I1s, flows);
         const int s1 = B::stream_sync(w.copy), s2 = B::stream_sync(w.compute);
+        const int s3 = w.link ? B::link_sync(w.link) : MI_OK;   // the root side of the link: the flows it received are in the caller's matrices
         if (rc) return rc;
         MI_MSM_TRY(s1);
         MI_MSM_TRY(s2);
+        MI_MSM_TRY(s3);
         return MI_OK;
     }
 #undef MI_MSM_TRY
@@ -313,6 +346,7 @@ private:
 
     mi_tvl1_params P_{};
     int chunk_ = 16;
+    bool use_links_ = true;
     std::vector<Worker> W_;
     std::mutex mu_;
     std::condition_variable cv_job_, cv_done_;

@@ -156,7 +156,8 @@ class OpticalFlowDual_TVL1:
 
 class TVL1MultiDevice:
     """Batched-frames mode over the GPUs of one node through the C-ABI (mi_tvl1_multi_*): contiguous shards of independent pairs,
-    one host thread + handle + stream pair per device, peer-to-peer staging from / to the ROOT device (devices[0]), no collective.
+    one host thread + handle + stream pair per device, staging from / to the ROOT device (devices[0]) over RCCL point-to-point
+    messages (where librccl is present and the worker sits on another GPU) or peer-to-peer copies; no reduction.
     `alg` is an OpticalFlowDual_TVL1 whose parameters are used (create it with the reference's factory arguments).
     The same device id may appear several times (several workers on one GPU)."""
 
@@ -176,6 +177,12 @@ class TVL1MultiDevice:
 
     def deviceCount(self):
         return capi.lib().mi_tvl1_multi_device_count(self._h)
+
+    def transport(self):
+        """(workers linked to the root over RCCL, workers using peer copies)."""
+        a, b = C.c_int(), C.c_int()
+        capi.check(capi.lib().mi_tvl1_multi_transport(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def calc_batch(self, I0s, I1s, flows=None):
         """All tensors on the root device.  Synchronous: earlier work on the inputs must be complete (synchronised here)."""

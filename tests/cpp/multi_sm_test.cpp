@@ -46,7 +46,9 @@ struct World {
     std::mt19937 rng{1};
     // failure injection
     std::string fail_op; int fail_dev = -1; int fail_after = 0;   // fail the (fail_after+1)-th matching call
-    int live_streams = 0, live_events = 0, live_allocs = 0, live_handles = 0;
+    int live_streams = 0, live_events = 0, live_allocs = 0, live_handles = 0, live_links = 0;
+    bool links_enabled = false;   // the RCCL transport between the root and the other workers (off: peer copies)
+    long groups = 0, messages = 0, pitched_planes = 0;
 } G;
 
 static int maybe_fail(const char *op)
@@ -201,6 +203,99 @@ struct Backend {
         st->q.push_back(o);
         return MI_OK;
     }
+    // ---- the RCCL link of a (root, worker) pair.  Model: a dense plane is a MESSAGE of two halves, one on the worker's stream and one
+    // on the link's root-side stream.  The bytes move when the WORKER's half executes (a send does not complete before its data has
+    // left, a receive not before it has arrived, so the worker-side stream order is what protects the staging slots); the root's half
+    // is a marker behind it that somebody has to wait for (link_sync) before the call may return -- all_streams_idle() checks that.
+    // Pitched planes are peer copies on the worker's stream.
+    struct Link { int root, dev; Stream *root_stream; bool in_group = false; };
+    static int link_create(void **out, int root, int dev)
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        CHECK(t_dev == dev);
+        *out = nullptr;
+        if (!G.links_enabled || root == dev) return MI_OK;
+        if (int rc = maybe_fail("link_create")) return rc;
+        Stream *st = new Stream{root};
+        G.streams[root].push_back(st);
+        ++G.live_streams;
+        *out = new Link{root, dev, st};
+        ++G.live_links;
+        note("link_create");
+        return MI_OK;
+    }
+    static int link_destroy(void *l)
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        Link *L = (Link *)l;
+        CHECK(t_dev == L->dev && !L->in_group && L->root_stream->next == L->root_stream->q.size());
+        auto &v = G.streams[L->root];
+        v.erase(std::find(v.begin(), v.end(), L->root_stream));
+        delete L->root_stream;
+        --G.live_streams;
+        delete L;
+        --G.live_links;
+        return MI_OK;
+    }
+    static int link_sync(void *l)
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        Link *L = (Link *)l;
+        CHECK(t_dev == L->dev);
+        note("link_sync");
+        drain(L->root_stream);
+        return MI_OK;
+    }
+    static int link_begin(void *l)
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        Link *L = (Link *)l;
+        CHECK(t_dev == L->dev && !L->in_group);
+        if (int rc = maybe_fail("link_begin")) return rc;
+        L->in_group = true;
+        ++G.groups;
+        return MI_OK;
+    }
+    static int link_end(void *l)
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        Link *L = (Link *)l;
+        CHECK(t_dev == L->dev);
+        L->in_group = false;
+        return MI_OK;
+    }
+    static int link_plane(void *l, void *dst, size_t dpitch, const void *src, size_t spitch, size_t wbytes, size_t rows, int to_worker, void *ws)
+    {
+        std::lock_guard<std::mutex> lk(G.mu);
+        Link *L = (Link *)l;
+        Stream *st = (Stream *)ws;
+        CHECK(t_dev == L->dev && st->dev == L->dev && L->in_group);   // every plane of a chunk inside ONE bracket
+        if (int rc = maybe_fail("link_plane")) return rc;
+        const auto copy = [=] { for (size_t r = 0; r < rows; ++r) memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, wbytes); };
+        if (dpitch != wbytes || spitch != wbytes) {   // pitched: a peer copy on the worker's stream
+            ++G.pitched_planes;
+            Op o; o.run = copy;
+            st->q.push_back(o);
+            return MI_OK;
+        }
+        ++G.messages;
+        if (to_worker) {   // sender half (marker) on the root-side stream, receiver half on the worker's stream waits for it
+            const long t = L->root_stream->base + (long)L->root_stream->q.size();
+            L->root_stream->q.push_back(Op{});
+            Op o; o.run = copy; o.wait_stream = L->root_stream; o.wait_ticket = t;
+            st->q.push_back(o);
+            // the worker-side drain must be able to run the root-side marker: it lives on another device's stream list, so execute
+            // markers eagerly (a send has no precondition in this model: the caller's inputs are resident)
+            L->root_stream->next = L->root_stream->q.size();
+        } else {        // sender half (the bytes) on the worker's stream, receiver half on the root-side stream behind it
+            const long t = st->base + (long)st->q.size();
+            Op o; o.run = copy;
+            st->q.push_back(o);
+            Op r; r.wait_stream = st; r.wait_ticket = t;
+            L->root_stream->q.push_back(r);
+        }
+        return MI_OK;
+    }
     static int tvl1_create(const mi_tvl1_params *, void **h)
     {
         std::lock_guard<std::mutex> lk(G.mu);
@@ -247,18 +342,29 @@ struct Backend {
 
 using M = mi::multi::Machine<fake::Backend>;
 
+// every stream of every device has executed everything that was enqueued on it (a call that returned left nothing in flight)
+static bool all_streams_idle()
+{
+    std::lock_guard<std::mutex> lk(fake::G.mu);
+    for (auto &kv : fake::G.streams)
+        for (fake::Stream *s : kv.second)
+            if (s->next != s->q.size()) return false;
+    return true;
+}
+
 struct Batch {
     int n, rows, cols;
     size_t in_step, out_step;   // pitched "root device" matrices
     std::vector<std::vector<float>> I0, I1, F;
     std::vector<mi_mat> a, b, f;
-    Batch(int n_, int rows_, int cols_, unsigned seed) : n(n_), rows(rows_), cols(cols_)
+    int pi, po;   // pitch padding, in elements (0: dense matrices)
+    Batch(int n_, int rows_, int cols_, unsigned seed, bool dense = false) : n(n_), rows(rows_), cols(cols_), pi(dense ? 0 : 3), po(dense ? 0 : 5)
     {
-        in_step = (cols + 3) * 4; out_step = (cols + 5) * 8;
+        in_step = (cols + pi) * 4; out_step = (cols + po) * 8;
         std::mt19937 r(seed);
         I0.resize(n); I1.resize(n); F.resize(n); a.resize(n); b.resize(n); f.resize(n);
         for (int i = 0; i < n; ++i) {
-            I0[i].resize(rows * (cols + 3)); I1[i].resize(rows * (cols + 3)); F[i].assign(rows * (cols + 5) * 2, -7.f);
+            I0[i].resize(rows * (cols + pi)); I1[i].resize(rows * (cols + pi)); F[i].assign(rows * (cols + po) * 2, -7.f);
             for (float &v : I0[i]) v = (float)(r() % 1000);
             for (float &v : I1[i]) v = (float)(r() % 1000);
             a[i] = {I0[i].data(), in_step, rows, cols, MI_32FC1};
@@ -270,14 +376,14 @@ struct Batch {
     {
         for (int y = 0; y < rows; ++y)
             for (int x = 0; x < cols; ++x) {
-                const float v0 = I0[i][y * (cols + 3) + x], v1 = I1[i][y * (cols + 3) + x];
-                const float *o = &F[i][y * (cols + 5) * 2 + 2 * x];
+                const float v0 = I0[i][y * (cols + pi) + x], v1 = I1[i][y * (cols + pi) + x];
+                const float *o = &F[i][y * (cols + po) * 2 + 2 * x];
                 if (o[0] != v0 + 1.f || o[1] != 2.f * v1) return false;
             }
         // the pitch padding of the caller's flow matrices is never written
         for (int y = 0; y < rows; ++y)
-            for (int x = cols * 2; x < (cols + 5) * 2; ++x)
-                if (F[i][y * (cols + 5) * 2 + x] != -7.f) return false;
+            for (int x = cols * 2; x < (cols + po) * 2; ++x)
+                if (F[i][y * (cols + po) * 2 + x] != -7.f) return false;
         return true;
     }
 };
@@ -364,6 +470,65 @@ int main()
     }
     // 5. destruction released everything, each object on its own device (checked inside the fake)
     CHECK(fake::G.live_handles == 0 && fake::G.live_streams == 0 && fake::G.live_events == 0 && fake::G.live_allocs == 0);
+
+    // 5b. the RCCL transport (round 5): one link per non-root worker on a DIFFERENT device, every plane of a chunk and direction inside
+    //     one bracket (= one ncclGroup), dense planes as messages whose receiving half runs on the root-side stream for the flows --
+    //     so the results are only right if the root-side stream is drained after the worker's streams; pitched planes as peer copies;
+    //     a worker on the root's own device keeps its peer copies; failures inside a bracket close it and drain everything
+    {
+        fake::G.links_enabled = true;
+        M m;
+        CHECK(m.init(P, {5, 3, 6, 5}) == MI_OK);   // the fourth worker sits on the root's device
+        CHECK(m.link_count() == 2 && fake::G.live_links == 2 && count_log("3:link_create") == 1 && count_log("6:link_create") == 1);
+        CHECK(fake::G.live_streams == 8 + 2);      // two streams per worker + one root-side stream per link
+        int call = 0;
+        for (int chunk : {1, 3, 16})
+            for (int n : {2, 9, 23}) {
+                fake::G.rng.seed(2000 + call);
+                m.set_chunk(chunk);
+                // dense inputs and flows: messages
+                Batch B(n, 5, 9, 177 + call, true);
+                const long g0 = fake::G.groups, m0 = fake::G.messages, p0 = fake::G.pitched_planes;
+                CHECK(m.calc_batch(n, B.a.data(), B.b.data(), B.f.data()) == MI_OK);
+                CHECK(all_streams_idle());   // including the root-side halves of the flows' messages
+                for (int i = 0; i < n; ++i) CHECK(B.correct(i));
+                const int per = (n + 3) / 4, linked = std::max(0, std::min(per, n - per)) + std::max(0, std::min(per, n - 2 * per));   // pairs of workers 1 and 2
+                CHECK(fake::G.messages - m0 == 3L * linked && fake::G.pitched_planes == p0);
+                long want_groups = 0;
+                for (int wk = 1; wk <= 2; ++wk) { const int cnt = std::max(0, std::min(per, n - wk * per)); want_groups += 2L * ((cnt + chunk - 1) / chunk); }
+                CHECK(fake::G.groups - g0 == want_groups);
+                // pitched matrices through the same links: peer copies inside the brackets
+                Batch C(n, 5, 9, 277 + call);
+                CHECK(m.calc_batch(n, C.a.data(), C.b.data(), C.f.data()) == MI_OK);
+                for (int i = 0; i < n; ++i) CHECK(C.correct(i));
+                ++call;
+            }
+        for (const char *op : {"link_plane", "link_begin"}) {
+            m.set_chunk(2);
+            Batch B(16, 4, 6, 41, true);
+            fake::G.fail_op = op; fake::G.fail_dev = 6; fake::G.fail_after = 2;
+            const size_t before = fake::G.log.size();
+            CHECK(m.calc_batch(16, B.a.data(), B.b.data(), B.f.data()) == MI_ERR_HIP);
+            CHECK(m.error().find("device 6") != std::string::npos);
+            int syncs6 = 0, lsync6 = 0;
+            for (size_t i = before; i < fake::G.log.size(); ++i) { syncs6 += (fake::G.log[i] == "6:stream_sync"); lsync6 += (fake::G.log[i] == "6:link_sync"); }
+            CHECK(syncs6 == 2 && lsync6 == 1 && all_streams_idle());
+            for (int i = 0; i < 8; ++i) CHECK(B.correct(i));      // workers 0 and 1 (devices 5 and 3)
+            for (int i = 12; i < 16; ++i) CHECK(B.correct(i));    // worker 3 (device 5 again)
+            Batch C(16, 4, 6, 42, true);
+            CHECK(m.calc_batch(16, C.a.data(), C.b.data(), C.f.data()) == MI_OK);
+            for (int i = 0; i < 16; ++i) CHECK(C.correct(i));
+        }
+    }
+    CHECK(fake::G.live_handles == 0 && fake::G.live_streams == 0 && fake::G.live_events == 0 && fake::G.live_allocs == 0 && fake::G.live_links == 0);
+    {   // a failing link_create is a failing worker initialisation
+        M m;
+        fake::G.fail_op = "link_create"; fake::G.fail_dev = 6; fake::G.fail_after = 0;
+        CHECK(m.init(P, {5, 3, 6}) == MI_ERR_HIP);
+        CHECK(m.error().find("device 6") != std::string::npos);
+    }
+    CHECK(fake::G.live_handles == 0 && fake::G.live_streams == 0 && fake::G.live_links == 0);
+    fake::G.links_enabled = false;
 
     // 6. construction failures: a device without a peer link, and a failure in the middle of a later worker's initialisation --
     //    init reports the device and leaves nothing behind

@@ -272,6 +272,25 @@ def test_multi_device_host_entry_equals_calc_batch(gpu, devices, chunk):
     assert torch.equal(out2, ref[:3])
 
 
+def test_rccl_binding_of_the_multi_device_entry_on_one_gpu(gpu):
+    """Round 5: the C++ multi-GPU entry moves its shards as RCCL point-to-point messages (grouped ncclSend /
+    ncclRecv, librccl bound at run time).  A one-GPU box cannot open a two-rank communicator on two devices, but it can run the same
+    entry points with the same argument orders and constants: a one-rank communicator, a grouped send to self / receive from self.
+    Workers that share the root's GPU keep their peer copies (transport() says so) and still give the bytes of calc_batch."""
+    import ctypes as C
+    import torch
+    from opencv_contrib_amd import capi, cuda
+    torch.cuda.set_device(gpu)
+    src = bytes(np.random.default_rng(5).integers(0, 256, size=1 << 20, dtype=np.uint8))
+    dst = C.create_string_buffer(len(src))
+    avail = C.c_int(-1)
+    capi.check(capi.lib().miflow_selftest_rccl_self_copy(src, dst, len(src), C.byref(avail)))
+    assert avail.value == 1, "librccl.so of the ROCm installation was not found"
+    assert dst.raw == src
+    multi = cuda.TVL1MultiDevice(cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0), devices=[0, 0, 0], chunk=2)
+    assert multi.transport() == (0, 2)
+
+
 def test_multi_device_host_entry_over_distinct_devices(gpu):
     """The same entry over DIFFERENT GPUs: real peer enable, per-device arena caches, xGMI
     peer copies, one worker thread per device.  Needs a node with at least two visible devices; the one-GPU test box skips it
@@ -291,6 +310,7 @@ def test_multi_device_host_entry_over_distinct_devices(gpu):
     for devices, chunk in ((list(range(nd)), 2), ([nd - 1, 0], 16), ([0, 1, 1, 0], 3)):
         multi = cuda.TVL1MultiDevice(alg, devices=devices, chunk=chunk)
         assert multi.deviceCount() == len(devices)
+        assert multi.transport() == (sum(1 for d in devices[1:] if d != devices[0]), sum(1 for d in devices[1:] if d == devices[0]))   # RCCL between distinct GPUs
         for _ in range(2):    # the second call re-uses the workers' warm handles and staging slots
             out = multi.calc_batch(I0s, I1s)
             assert torch.equal(out, ref), (devices, chunk)
