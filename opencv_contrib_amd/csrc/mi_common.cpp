@@ -139,8 +139,14 @@ int big_alloc(void **p, size_t bytes, size_t *capacity)
             if (ready) {
                 const hipError_t we = hipEventSynchronize(ready);
                 (void)hipEventDestroy(ready);
-                // a block whose previous owner's work cannot be vouched for is dropped; the request falls through to a fresh hipMalloc
-                if (we != hipSuccess) { (void)hipFree(*p); *p = nullptr; hit = false; }
+                if (we != hipSuccess) {
+                    // The event could not be waited for.  Seen on ROCm 7.2 when the stream it was recorded on has since been
+                    // destroyed (hipErrorCapturedEvent: the runtime looks at the dead stream).  Clear the thread's sticky error -- it
+                    // would surface at the next hipGetLastError() after an unrelated launch -- and fall back to what vouches for the
+                    // block without the event: the whole device idle.  If even that fails the block is dropped for a fresh one.
+                    (void)hipGetLastError();
+                    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(*p); *p = nullptr; hit = false; }
+                }
             }
             if (hit) return MI_OK;
         }
