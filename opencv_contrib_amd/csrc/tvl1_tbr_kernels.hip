@@ -350,6 +350,9 @@ __device__ __forceinline__ void fw_inbox_get(const float *slot, int lane, Stat<P
 }
 template <int FW> struct FwSem { static constexpr int sem = FW == 2 ? MI_SEM_CUDA_COMPAT : MI_SEM_CPU_REF; static constexpr bool fast = FW == 2; };
 
+#ifndef FW_STAGE
+#define FW_STAGE 0   // 0 (default): the producers gather their windows (fw_produce); 1: they read them from a private LDS band of I1 (fw_produce_staged) -- bit-identical, measured no faster (r14g, r14h: 1 093 - 1 180 against 1 205 pairs/s): the fused form is bound by VALU issue, not by the gathers
+#endif
 #ifndef FW_X
 #define FW_X 0   // experiments build only: 1 = the producers write zeros (no loads, no arithmetic), 2 = arithmetic without loads -- wrong results
 #endif
@@ -437,6 +440,143 @@ __device__ __forceinline__ void fw_produce(const TbArgs &A, float *inbox, const 
     if (n + 1 < nsteps_total) { xbarrier(); FW_ROW(n + 3, 3); xbarrier(); }
     if (n + 2 < nsteps_total) { xbarrier(); FW_ROW(n + 4, 0); xbarrier(); }
 #undef FW_ROW
+    for (int i = 0; i < NW - 1; ++i) xbarrier();   // the consumers' skew
+}
+
+// ---- the producer with its OWN staged band of I1 (round 5, second form).  The gathering producer above is bound by its two windows in
+// flight (Little's law: 20 gather instructions per wave against ~2 us of latency under load): measured 1 205 pairs/s against 1 527 for the
+// same arithmetic without loads.  Here a producer wave keeps a private LDS ring of FWS_NR rows x FWS_CW columns of I1 around the place its
+// 64 columns look at: the columns of the wave shifted by the band's mean flow (ox, oy: measured once, on the band's middle row) +- FWS_D1,
+// the rows yu + oy - FWS_D2 - 2 .. yu + oy + FWS_D2 + 3 of output row yu.  One new row enters per step, streamed four steps ahead with two
+// coalesced dword loads per lane (two registers per row in flight instead of thirty-two), and a pixel's window is thirty-two ds_read_b32
+// with immediate offsets.  I1 is read from HBM once per strip (+ the column margins) instead of six times through L2.  A lane whose window
+// leaves the staged band (flow further than FWS_D from the band's mean, e.g. across a motion boundary) gathers it from global memory as
+// before, synchronously: same values, same sums -- bit-identical whichever path a pixel takes.
+constexpr int FWS_D1 = 5, FWS_D2 = 8;
+constexpr int FWS_CW = 64 + 2 * FWS_D1 + 6;    // 80 columns (with 88 the workgroup needs exactly 80 KB of LDS and only one fits a CU)
+constexpr int FWS_NR = 2 * FWS_D2 + 6;         // 22 rows: the six window rows of every flow within +- FWS_D2 of the band's mean
+__host__ __device__ constexpr int fws_lds_floats(int NW) { return NW * FWS_NR * FWS_CW; }
+
+template <int FW, int NW>
+__device__ __forceinline__ void fw_produce_staged(const TbArgs &A, float *inbox, const float *tab, float *ring, int lane, int xw, int ystart,
+                                                  int nsteps_total, int y_mid, long long pb, int cur)
+{
+    constexpr int SEM = FwSem<FW>::sem;
+    constexpr bool FAST = FwSem<FW>::fast;
+    const int W = A.g.w, H = A.g.h, ld = A.g.ld;
+    const int x = min(xw + lane, W - 1);
+    const float *U1 = A.pl.u[cur][0] + pb + x, *U2 = A.pl.u[cur][1] + pb + x, *I0 = A.fI0 + pb + x, *P = A.fI1 + pb;
+    // the band's mean flow, rounded: wave-uniform offsets of the staged band
+    int ox, oy;
+    {
+        const long long ro = (long long)min(max(y_mid, 0), H - 1) * ld;
+        float a = U1[ro], b = U2[ro];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        ox = __builtin_amdgcn_readfirstlane(__float2int_rn(fminf(fmaxf(a * (1.0f / 64.0f), -30000.f), 30000.f)));
+        oy = __builtin_amdgcn_readfirstlane(__float2int_rn(fminf(fmaxf(b * (1.0f / 64.0f), -30000.f), 30000.f)));
+    }
+    const int cb = xw + ox - FWS_D1 - 3;                                     // image column of ring column 0
+    // the two columns this lane streams per row: cb + lane and (lanes < FWS_CW - 64) cb + 64 + lane, clamped into the image
+    const int ca = min(max(cb + lane, 0), W - 1), cbb = min(max(cb + 64 + lane, 0), W - 1);
+    const bool second = lane < FWS_CW - 64;
+    FwU U[4];
+    float ST[4][2];
+    const auto load_u = [&](int m, FwU &u) {
+        const long long ro = (long long)min(max(ystart + m, 0), H - 1) * ld;   // wave-uniform
+        u.u1 = U1[ro]; u.u2 = U2[ro]; u.i0 = I0[ro];
+    };
+    // row of I1 entering the band at output row index m: rtop(m) = ystart + m + oy + FWS_D2 + 3; ring slot of image row r = r mod FWS_NR
+    // kept incrementally (wave-uniform): slot_top = slot of rtop(m)
+    const auto load_row = [&](int r, float (&st)[2]) {
+        const float *q = P + (long long)min(max(r, 0), H - 1) * ld;
+        st[0] = q[ca];
+        st[1] = q[cbb];   // (lanes >= 24 load a duplicate they never store: one instruction for the wave either way)
+    };
+    const auto store_row = [&](int slot, const float (&st)[2]) {
+        float *q = ring + slot * FWS_CW + lane;
+        q[0] = st[0];
+        if (second) q[64] = st[1];
+    };
+    int rlow = ystart + oy - FWS_D2 - 2;                   // image row of the band's first row at m = 0
+    int slot_low = ((rlow % FWS_NR) + FWS_NR) % FWS_NR;    // its ring slot
+    // prologue: the 22 rows of m = 0 (rlow .. rlow + 21), four at a time through ST
+    for (int r0 = 0; r0 < FWS_NR; r0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (r0 + k < FWS_NR) load_row(rlow + r0 + k, ST[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (r0 + k < FWS_NR) { int sl = slot_low + r0 + k; sl -= sl >= FWS_NR ? FWS_NR : 0; store_row(sl, ST[k]); }
+    }
+    // rows entering at m = 1 .. 4 in flight (the row entering at step m is rlow + m + FWS_NR - 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_row(rlow + FWS_NR + k, ST[k]);   // ST[k]: enters at m = k + 1
+    load_u(0, U[0]); load_u(1, U[1]); load_u(2, U[2]); load_u(3, U[3]);
+
+    // one output row: m = its index, u = its flow / I0, slot_lo = ring slot of image row rlow_m = ystart + m + oy - FWS_D2 - 2
+    const auto row = [&](int m, const FwU &u, int rlow_m, int slot_lo) {
+        const int yu = ystart + m;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, rc = 0.f;
+        if (yu >= 0 && yu < H) {   // wave-uniform; rows outside the image hand over zeros: they are cut off from the image by the masks
+            int sx, sy;
+            float wx[4], wy[4];
+            warp_coords<SEM>(tab, x, yu, u.u1, u.u2, sx, sy, wx, wy);
+            const int dc = sx - 1 - cb, dr = sy - 1 - rlow_m;
+            const bool inter = window_interior(sx, sy, W, H);
+            const bool staged = inter && (unsigned)dc <= (unsigned)(FWS_CW - 6) && (unsigned)dr <= (unsigned)(FWS_NR - 6);
+            if (staged) {
+                float Rw[6][6];
+                unsigned t = (unsigned)(slot_lo + dr);
+                t = min(t, t - (unsigned)FWS_NR);   // wrap: t < NR stays (t - NR is huge as unsigned), otherwise t - NR
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const float *q = ring + t * FWS_CW + dc;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)
+                        if (!((r == 0 || r == 5) && (c == 0 || c == 5))) Rw[r][c] = q[c];
+                    ++t;
+                    t = min(t, t - (unsigned)FWS_NR);
+                }
+                window_sums<SEM, FAST>(Rw, wx, wy, v0, v1, v2);
+            } else if (inter) {
+                float Rw[6][6];
+                window_gather(Rw, P, ld, sx, sy);
+                window_sums<SEM, FAST>(Rw, wx, wy, v0, v1, v2);
+            } else {
+                window_border<SEM>(P, W, H, ld, sx, sy, wx, wy, v0, v1, v2);
+            }
+            rc = (v0 - v1 * u.u1 - v2 * u.u2 - u.i0);   // calcGradRho, optflow/src/tvl1flow.cpp:918-944 == tvl1flow.cu:151-163 (warp_px)
+        }
+        float *q = inbox + (m & (FW_RING - 1)) * FW_SLOT + lane;
+        q[0] = v1; q[64] = v2; q[128] = rc;
+    };
+    // step of output row m (k = m & 3): [m >= 1: the row that enters the band replaces the one that left] -> row -> next requests
+    // (unconditional: every path through the row loop issues the same loads in the same order -- see fw_produce)
+#define FWS_STEP(m, k)                                                                               \
+    do {                                                                                             \
+        store_row(slot_low, ST[((k) + 3) & 3]);   /* the slot of the row that just left the band */  \
+        asm volatile("" ::: "memory");                                                               \
+        load_row(rlow + FWS_NR + 4, ST[((k) + 3) & 3]);   /* enters four steps from now */           \
+        ++rlow;                                                                                      \
+        slot_low = slot_low + 1 == FWS_NR ? 0 : slot_low + 1;                                        \
+        row((m), U[(k) & 3], rlow, slot_low);                                                        \
+        load_u((m) + 4, U[(k) & 3]);                                                                 \
+    } while (0)
+    row(0, U[0], rlow, slot_low);
+    load_u(4, U[0]);
+    FWS_STEP(1, 1);
+    xbarrier();   // opens the pipeline: rows 0 and 1 are in the inbox
+    int n = 0;
+#pragma unroll 1
+    for (; n + 4 <= nsteps_total; n += 4) {
+        xbarrier(); FWS_STEP(n + 2, 2); xbarrier();
+        xbarrier(); FWS_STEP(n + 3, 3); xbarrier();
+        xbarrier(); FWS_STEP(n + 4, 0); xbarrier();
+        xbarrier(); FWS_STEP(n + 5, 1); xbarrier();
+    }
+    if (n < nsteps_total) { xbarrier(); FWS_STEP(n + 2, 2); xbarrier(); }
+    if (n + 1 < nsteps_total) { xbarrier(); FWS_STEP(n + 3, 3); xbarrier(); }
+    if (n + 2 < nsteps_total) { xbarrier(); FWS_STEP(n + 4, 0); xbarrier(); }
+#undef FWS_STEP
     for (int i = 0; i < NW - 1; ++i) xbarrier();   // the consumers' skew
 }
 
@@ -756,7 +896,12 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
         float *fw0 = lds + NW * (K * 256 * PPL) + NW * xarea2_bytes(T) / 4;
         c.inbox = fw0 + wave * (FW_RING * FW_SLOT);
         if (producer) {
+#if FW_STAGE
+            fw_produce_staged<FW, NW>(A, c.inbox, fw0 + NW * FW_RING * FW_SLOT, fw0 + fw_lds_floats(NW) + wave * (FWS_NR * FWS_CW), c.lane, xw, c.ystart,
+                                      (c.nsteps + P - 1) / P * P, (c.y0 + c.y1) >> 1, pb, cur);
+#else
             fw_produce<FW, NW>(A, c.inbox, fw0 + NW * FW_RING * FW_SLOT, c.lane, xw, c.ystart, (c.nsteps + P - 1) / P * P, pb, cur);
+#endif
             return;
         }
     }
@@ -839,7 +984,7 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
     constexpr size_t lds_bytes = (size_t)NW * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
                                  (JW >= 2 ? NW * xarea2_bytes(T) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0) +
-                                 (FW ? fw_lds_floats(NW) * sizeof(float) : 0);
+                                 (FW ? (fw_lds_floats(NW) + (FW_STAGE ? fws_lds_floats(NW) : 0)) * sizeof(float) : 0);
     constexpr int NTHREADS = 64 * NW * (FW ? 2 : 1);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
