@@ -18,7 +18,7 @@ struct mi_surf {
     int capR = 0, capC = 0, capL = 0, capCand = 0;
     unsigned *sum = nullptr, *msum = nullptr, *V = nullptr, *BT = nullptr;
     float *det = nullptr, *trace = nullptr;
-    unsigned long long *bits = nullptr;
+    unsigned long long *bits = nullptr, *sbits = nullptr;
     unsigned *rowcnt = nullptr, *segcnt = nullptr;
     int4 *cand = nullptr;
     void *itmp = nullptr;   // per-candidate interpolation results
@@ -97,9 +97,9 @@ int mi_surf_get_params(const mi_surf *h, mi_surf_params *p) { MI_REQUIRE(h && p,
 
 static void free_scratch(mi_surf *h)
 {
-    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->rowcnt, h->segcnt, h->cand, h->itmp, h->geo};
+    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->sbits, h->rowcnt, h->segcnt, h->cand, h->itmp, h->geo};
     for (void *p : ps) if (p) (void)hipFree(p);
-    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->rowcnt = nullptr; h->segcnt = nullptr; h->cand = nullptr; h->itmp = nullptr; h->geo = nullptr;
+    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->sbits = nullptr; h->rowcnt = nullptr; h->segcnt = nullptr; h->cand = nullptr; h->itmp = nullptr; h->geo = nullptr;
     h->capR = h->capC = h->capL = h->capCand = h->capO = 0;
 }
 
@@ -158,6 +158,12 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
             static const bool lds_ok = surf::lds_geometry_self_check();   // the LDS path's compile-time geometry against the host's
             const char *e = MI_EXP_ENV("MIFLOW_SURF_LDS");
             h->lds_tiles = (lds_ok && !(e && atoi(e) == 0)) ? 1 : 0;
+            // round 5 experiment, kept as a tested opt-in (MIFLOW_SURF_NMS0=1): octave 0's maxima flagged inside the det kernel, no det /
+            // trace planes for three quarters of the samples.  Bit-identical, but SLOWER on MI355X (r14j, 4K frame: k_det_nms0 180 us
+            // against 103 + 65 us for the tile kernel + the flag launch -- the 18 % of overlapping samples cost more than the planes'
+            // 265 MB -- and the refinement's 27 re-evaluations per candidate 143 us against 15): 736 against 826 frames/s
+            const char *n0 = getenv("MIFLOW_SURF_NMS0");
+            if (h->lds_tiles && n0 && *n0 && atoi(n0) != 0) h->lds_tiles = 2;
         }
         surf::FusedSizes z;
         z.plane_floats = (size_t)h->dld * rows * (layers + 2);
@@ -173,6 +179,7 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
         MI_HIP_TRY(hipMalloc((void **)&h->det, sizeof(float) * z.plane_floats));
         MI_HIP_TRY(hipMalloc((void **)&h->trace, sizeof(float) * z.plane_floats));
         MI_HIP_TRY(hipMalloc((void **)&h->bits, sizeof(unsigned long long) * z.bits_words));
+        MI_HIP_TRY(hipMalloc((void **)&h->sbits, sizeof(unsigned long long) * z.bits_words));
         MI_HIP_TRY(hipMalloc((void **)&h->rowcnt, sizeof(unsigned) * z.row_counts));
         MI_HIP_TRY(hipMalloc((void **)&h->segcnt, sizeof(unsigned) * z.seg_counts));
         MI_HIP_TRY(hipMalloc((void **)&h->cand, sizeof(int4) * (size_t)maxCand * nlists));
@@ -235,7 +242,7 @@ static int detect_enqueue(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_
     if (h->fused) {                                                                                                  // :182-204, all octaves per launch
         if ((rc = surf::detect_fused(h->sum, use_mask ? h->msum : nullptr, h->sld, rows, cols, P.n_octaves, P.n_octave_layers,
                                      (float)P.hessian_threshold, h->det, h->trace, h->dld, h->bits, h->rowcnt, h->segcnt, h->cand, maxC,
-                                     h->counters + 1, h->itmp, h->geo, kp, kld, maxF, h->counters, h->lds_tiles, st))) return rc;
+                                     h->counters + 1, h->itmp, h->geo, kp, kld, maxF, h->counters, h->lds_tiles, st, h->sbits))) return rc;
     } else
     for (int octave = 0; octave < P.n_octaves; ++octave) {                                                           // :182-204
         if ((rc = surf::det_trace(h->sum, h->sld, rows, cols, octave, P.n_octave_layers, h->det, h->trace, h->dld, st))) return rc;

@@ -24,7 +24,8 @@ void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host);
 bool lds_geometry_self_check();      // the compile-time tap geometry of that path equals haar_geo's
 int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int rows, int cols, int n_octaves, int nOctaveLayers, float thr,
                  float *det, float *trace, int dld, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
-                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, int lds_tiles, hipStream_t s);
+                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, int lds_tiles, hipStream_t s,
+                 unsigned long long *sbits = nullptr);   // lds_tiles: 0 = global taps, 1 = octave 0 on LDS tiles, 2 (needs sbits: as many words as octave 0's bits) = ... and its maxima flagged there
 // tmp: interp_tmp_bytes(max_candidates) bytes of scratch
 int interpolate(const float *det, int dld, int rows, int cols, int octave, const int4 *cand, const unsigned *ncand, int max_candidates,
                 void *tmp, float *kp, int kld, int max_features, unsigned *nfeat, hipStream_t s);

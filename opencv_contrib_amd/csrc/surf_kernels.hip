@@ -303,6 +303,7 @@ struct NmsArgs {
     float thr;
     SumTex mask;                            // mask.s == nullptr: no mask
     unsigned long long *bits;               // [nlayers][layer_rows][chunks] ballot of the maxima
+    const unsigned long long *sbits;        // octave 0 of the all-octave plan with the maxima flagged inside the det kernel (fuse0): sign bit of the trace at each maximum (same layout); else nullptr: nms_write_row reads the trace plane
     unsigned *rowcnt;                       // [nlayers * layer_rows (+1)]  exclusive offsets of the rows (k_scan_counts), total at the end
     unsigned *segcnt;                       // [nlayers * layer_rows][nseg]  maxima per row segment (k_nms_flag)
     int chunks, nseg;                       // 64-sample chunks per row; row segments of kNmsSeg chunks
@@ -420,7 +421,8 @@ __device__ __forceinline__ void nms_write_row(const NmsArgs &A, int r, int4 *can
             const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
             if (idx < (unsigned)max_candidates) {
                 const int j = c * 64 + lane;
-                const int lap = (int)copysignf(1.0f, A.trace[(long long)(layer * layer_rows + i) * A.dld + j]);
+                const int lap = A.sbits ? (((A.sbits[(long long)r * A.chunks + c] >> lane) & 1ull) ? -1 : 1)
+                                        : (int)copysignf(1.0f, A.trace[(long long)(layer * layer_rows + i) * A.dld + j]);
                 cand[idx] = make_int4(j, i, layer, lap);
             }
         }
@@ -456,13 +458,25 @@ __device__ __forceinline__ bool solve3x3(const float A[3][3], const float b[3], 
 // appends the accepted features in candidate order behind the features of the previous octaves.
 struct InterpOut { float px, py, psize, hess; int lap, ok; };
 
+// RECOMPUTE (octave 0 with the maxima flagged inside the det kernel): there is no det plane -- the 27 values are evaluated again from the
+// integral image (det0_at: the same taps, the same box_div, the same order as the tile kernel: the same bits)
+__device__ float det0_at(const SumTex &t, int layer, int ii, int jj);
 __device__ __forceinline__ bool interp_eval_one(const float *det, int dld, int rows, int cols, int octave, const int4 *cand,
-                                                const unsigned *ncand_p, InterpOut *tmp, int c)
+                                                const unsigned *ncand_p, InterpOut *tmp, int c, const SumTex *recompute = nullptr)
 {
     if (c >= (int)*ncand_p) return false;
     const int layer_rows = rows >> octave;
     const int4 mp = cand[c];
     float N9[3][3][3];
+    if (recompute) {
+#pragma unroll 1
+        for (int z = 0; z < 3; ++z)
+#pragma unroll 1
+            for (int y = 0; y < 3; ++y)
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+                    N9[z][y][x] = det0_at(*recompute, mp.z - 1 + z, mp.y - 1 + y, mp.x - 1 + x);
+    } else {
 #pragma unroll
     for (int z = 0; z < 3; ++z)
 #pragma unroll
@@ -470,6 +484,7 @@ __device__ __forceinline__ bool interp_eval_one(const float *det, int dld, int r
 #pragma unroll
             for (int x = 0; x < 3; ++x)
                 N9[z][y][x] = det[(long long)(layer_rows * (mp.z - 1 + z) + mp.y - 1 + y) * dld + mp.x - 1 + x];
+    }
     float dD[3], H[3][3], xs[3];
     dD[0] = -0.5f * (N9[1][1][2] - N9[1][1][0]);
     dD[1] = -0.5f * (N9[1][2][1] - N9[1][0][1]);
@@ -972,6 +987,137 @@ __device__ __forceinline__ void haar_det_trace_lds(const unsigned *q, float &d, 
     d = dx * dy - 0.81f * dxy * dxy;
     tr = dx + dy;
 }
+// The same sample evaluated from the integral image itself (stride sld): p = the word of the sample's top-left corner.  The taps are
+// LdsGeo<L>'s edges with the image's stride instead of the patch's -- same integers, same box_div, same order: the same bits.
+template <int L>
+__device__ __forceinline__ void haar_det_trace_g0(const unsigned *p, int sld, float &d, float &tr)
+{
+    typedef LdsGeo<L> G;
+    const auto Q = [&](int ey, int ex) { return p[ey * sld + ex]; };
+    const auto E4 = [](int i) { return G::e(i == 0 ? 1 : i == 1 ? 4 : i == 2 ? 5 : 8); };
+    unsigned cxx[4][2], cyy[2][4], cxy[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { cxx[a][b] = Q(G::e(b ? 7 : 2), G::e(3 * a)); cyy[b][a] = Q(G::e(3 * a), G::e(b ? 7 : 2)); }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cxy[a][b] = Q(E4(a), E4(b));
+    const double wxx[3] = {1.0, -2.0, 1.0};
+    double sx = 0, sy = 0, sxy = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sx += box_div(cxx[k][0] - cxx[k][1] - cxx[k + 1][0] + cxx[k + 1][1], wxx[k], G::axx(k), 1.0 / G::axx(k));
+        sy += box_div(cyy[0][k] - cyy[0][k + 1] - cyy[1][k] + cyy[1][k + 1], wxx[k], G::axx(k), 1.0 / G::axx(k));
+    }
+    sxy += box_div(cxy[0][0] - cxy[1][0] - cxy[0][1] + cxy[1][1], 1.0, G::a6, 1.0 / G::a6);
+    sxy += box_div(cxy[0][2] - cxy[1][2] - cxy[0][3] + cxy[1][3], -1.0, G::a7, 1.0 / G::a7);
+    sxy += box_div(cxy[2][0] - cxy[3][0] - cxy[2][1] + cxy[3][1], -1.0, G::a7, 1.0 / G::a7);
+    sxy += box_div(cxy[2][2] - cxy[3][2] - cxy[2][3] + cxy[3][3], 1.0, G::a9, 1.0 / G::a9);
+    const float dx = (float)sx, dy = (float)sy, dxy = (float)sxy;
+    d = dx * dy - 0.81f * dxy * dxy;
+    tr = dx + dy;
+}
+template <int L>
+__device__ __forceinline__ float det0_layer(const SumTex &t, int ii, int jj)
+{
+    constexpr int size = 9 + 6 * L, m = size >> 1;
+    const int samples_i = 1 + (t.rows - size), samples_j = 1 + (t.cols - size);
+    const int i = ii - m, j = jj - m;
+    float d = 0.f, tr = 0.f;
+    if (size <= t.rows && size <= t.cols && i >= 0 && j >= 0 && i < samples_i && j < samples_j)
+        haar_det_trace_g0<L>(t.s + (long long)i * t.sld + j, t.sld, d, tr);
+    return d;
+}
+__device__ float det0_at(const SumTex &t, int layer, int ii, int jj)
+{
+    switch (layer) {
+    case 0: return det0_layer<0>(t, ii, jj);
+    case 1: return det0_layer<1>(t, ii, jj);
+    case 2: return det0_layer<2>(t, ii, jj);
+    default: return det0_layer<3>(t, ii, jj);
+    }
+}
+
+// ---- octave 0 with the maxima flagged INSIDE the det kernel (round 5; surf.cu:205-222 feeding :263-355 without the planes): a
+// workgroup's 16 x 64 tile of det values, all layers, stays in LDS; the 26 strict comparisons of the 14 x 62 interior samples of the
+// middle layers read their neighbours there, and what leaves the kernel is the flag word of each (layer, row) -- OR-ed into the
+// 64-column chunk words the scan and the candidate writer expect (a tile's 62 columns straddle two of them) -- with the sign of the
+// trace at each maximum beside it.  Tiles overlap by one sample on every side (stride 14 x 62): 18 % more samples evaluated, and the
+// 265 MB of octave-0 det / trace planes of a 4K frame are neither written nor read again.  The sub-pixel refinement evaluates its 27
+// values from the integral image (det0_at).
+constexpr int kFuseTY = kLdsTY - 2, kFuseTX = kLdsTX - 2;
+struct Fuse0Args {
+    float thr;
+    SumTex mask;                       // mask.s == nullptr: none
+    unsigned long long *bits, *sbits;  // octave 0's regions (offset 0), zeroed by the caller
+    unsigned *segcnt;
+    int chunks, nseg;
+};
+template <int L>
+__device__ __forceinline__ void fuse_layer(const SumTex &t, const unsigned *patch, int ii0, int jj0, int w4, int lane, float (*detT)[kLdsTY][kLdsTX],
+                                           unsigned long long (*sgn)[kLdsTY])
+{
+    constexpr int size = 9 + 6 * L, m = size >> 1, mmax = kLdsSMax >> 1;
+    const int samples_i = 1 + (t.rows - size), samples_j = 1 + (t.cols - size);
+    const int j = jj0 + lane - m;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int il = w4 * 4 + r4, i = ii0 + il - m;
+        float d = 0.f, tr = 0.f;
+        if (size <= t.rows && size <= t.cols && i >= 0 && j >= 0 && i < samples_i && j < samples_j)
+            haar_det_trace_lds<L>(patch + (il + mmax - m) * kLdsPW + (lane + mmax - m), d, tr);
+        detT[L][il][lane] = d;
+        const unsigned long long sm = __ballot((__float_as_uint(tr) >> 31) != 0u);
+        if (lane == 0) sgn[L][il] = sm;
+    }
+}
+__device__ __forceinline__ void fuse_nms(const SumTex &t, const Fuse0Args &F, int nlayers, int ii0, int jj0, int w4, int lane,
+                                         const float (*detT)[kLdsTY][kLdsTX], const unsigned long long (*sgn)[kLdsTY])
+{
+    const int lm = max(lane - 1, 0), lp = min(lane + 1, kLdsTX - 1);
+    const int jj = jj0 + lane;
+    for (int q = w4; q < nlayers * kFuseTY; q += 4) {
+        const int layer = q / kFuseTY + 1, il = q % kFuseTY + 1, ii = ii0 + il;
+        if (ii >= t.rows) continue;   // wave-uniform
+        const int size = calc_size(0, layer);
+        const int margin = (calc_size(0, layer + 1) >> 1) + 1;
+        const float v = detT[layer][il][lane];
+        bool ismax = lane >= 1 && lane <= kFuseTX && ii >= margin && ii < t.rows - margin && jj >= margin && jj < t.cols - margin && v > F.thr;
+        if (ismax && F.mask.s) ismax = mask_check(F.mask, ii - (size >> 1), jj - (size >> 1), size);
+        if (__ballot(ismax) != 0ull) {
+            if (ismax) {
+                const float *c0 = detT[layer][il];
+                ismax = v > c0[lm] && v > c0[lp];
+#pragma unroll
+                for (int di = -1; di <= 1; di += 2) { const float *c = detT[layer][il + di]; ismax = ismax && v > c[lm] && v > c[lane] && v > c[lp]; }
+#pragma unroll
+                for (int dl = -1; dl <= 1; dl += 2)
+#pragma unroll
+                    for (int di = -1; di <= 1; ++di) { const float *c = detT[layer + dl][il + di]; ismax = ismax && v > c[lm] && v > c[lane] && v > c[lp]; }
+            }
+        }
+        const unsigned long long m = __ballot(ismax);
+        if (m == 0ull || lane != 0) continue;
+        // lane k of the tile row = column jj0 + k (jj0 >= -1): chunk words c_lo (bits from s on) and c_lo + 1
+        const int c_lo = ((jj0 + 64) >> 6) - 1, s = jj0 - 64 * c_lo;
+        const long long r = (long long)(layer - 1) * t.rows + ii;
+        const unsigned long long sg = sgn[layer][il] & m;
+        const unsigned long long lo = m << s, hi = s ? m >> (64 - s) : 0ull;
+        if (lo && c_lo >= 0) {
+            atomicOr(F.bits + r * F.chunks + c_lo, lo);
+            if (sg << s) atomicOr(F.sbits + r * F.chunks + c_lo, sg << s);
+            atomicAdd(F.segcnt + r * F.nseg + c_lo / kNmsSeg, (unsigned)__popcll(lo));
+        }
+        if (hi && c_lo + 1 < F.chunks) {
+            atomicOr(F.bits + r * F.chunks + c_lo + 1, hi);
+            if (s && (sg >> (64 - s))) atomicOr(F.sbits + r * F.chunks + c_lo + 1, sg >> (64 - s));
+            atomicAdd(F.segcnt + r * F.nseg + (c_lo + 1) / kNmsSeg, (unsigned)__popcll(hi));
+        }
+    }
+}
+
 // one layer of the tile: the four sample rows of this wave
 template <int L>
 __device__ __forceinline__ void lds_layer(const SumTex &t, const unsigned *patch, int ii0, int jj, int w4, int lane, float *det, float *trace, long long plane0,
@@ -1014,6 +1160,7 @@ struct OctSet {
     int blk_wr[kMaxFusedOctaves + 1];        //   ... of k_nms_write_all (row groups)
     int nbx[kMaxFusedOctaves], nby[kMaxFusedOctaves], nseg[kMaxFusedOctaves], chunks[kMaxFusedOctaves];
     int lds0;                                // octave 0 of k_det_trace_all on LDS tiles (all its layers per workgroup): nby[0] counts 16-row tiles
+    int fuse0;                               // ... and its maxima flagged in that kernel (no planes; tiles of 14 x 62 interior samples; no k_nms_flag_all workgroups)
 };
 __device__ __forceinline__ int find_octave(const int *cum, int n, int id)
 {
@@ -1022,13 +1169,44 @@ __device__ __forceinline__ int find_octave(const int *cum, int n, int id)
     for (int k = 1; k < kMaxFusedOctaves; ++k) o += (k < n && id >= cum[k]) ? 1 : 0;
     return o;
 }
-__global__ __launch_bounds__(256) void k_det_trace_all(SumTex t, float *det, float *trace, OctSet S, const HaarGeo *geo)
+// Octave 0 with its maxima flagged in the kernel (fuse0): its own launch, so that the 32 KB of LDS a tile needs do not cost the
+// latency-bound global-tap workgroups of the other octaves their occupancy (r14i: in one launch the frame was 8 % slower).
+__global__ __launch_bounds__(256) void k_det_nms0(SumTex t, OctSet S, Fuse0Args F)
+{
+    const int nbx = S.nbx[0], nl2 = S.nlayers + 2;
+    const unsigned q = (unsigned)blockIdx.x, nwg = (unsigned)S.blk_dt[1];   // nwg % 8 == 0; XCD-contiguous tile order as in k_det_trace_all
+    const int loc = (int)((q & 7u) * (nwg >> 3) + (q >> 3));
+    __shared__ unsigned patch[kLdsPH * kLdsPW];
+    {
+        __shared__ float detT[kLdsLayers][kLdsTY][kLdsTX];
+        __shared__ unsigned long long sgn[kLdsLayers][kLdsTY];
+        if (loc >= nbx * S.nby[0]) return;   // padding (the whole workgroup)
+        const int bx = __builtin_amdgcn_readfirstlane(loc % nbx), by = __builtin_amdgcn_readfirstlane(loc / nbx);
+        const int lane = threadIdx.x & 63, w4 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int ii0 = by * kFuseTY - 1, jj0 = bx * kFuseTX - 1, mmax = kLdsSMax >> 1;
+        for (int r = w4; r < kLdsPH; r += 4) {
+            const unsigned *row = t.s + (long long)min(max(ii0 - mmax + r, 0), t.rows) * t.sld;
+            for (int c = lane; c < kLdsPW; c += 64) patch[r * kLdsPW + c] = row[min(max(jj0 - mmax + c, 0), t.cols)];
+        }
+        __syncthreads();
+        fuse_layer<0>(t, patch, ii0, jj0, w4, lane, detT, sgn);
+        fuse_layer<1>(t, patch, ii0, jj0, w4, lane, detT, sgn);
+        if (nl2 > 2) fuse_layer<2>(t, patch, ii0, jj0, w4, lane, detT, sgn);
+        if (nl2 > 3) fuse_layer<3>(t, patch, ii0, jj0, w4, lane, detT, sgn);
+        __syncthreads();
+        fuse_nms(t, F, S.nlayers, ii0, jj0, w4, lane, detT, sgn);
+        return;
+    }
+}
+
+// (blk0: workgroups of octave 0 that run in k_det_nms0 instead -- fuse0 -- and are not part of this launch's grid)
+__global__ __launch_bounds__(256) void k_det_trace_all(SumTex t, float *det, float *trace, OctSet S, const HaarGeo *geo, int blk0)
 {
     // Everything derived from the workgroup id is wave-uniform.  The octave comes from the ORIGINAL id (every octave's range is padded
     // to a multiple of 8 workgroups), the XCD-contiguous remap is applied INSIDE the octave: a sample of octave o costs up to 10 x one of
     // octave 0 (its 64 lanes read taps 4 << o bytes apart: 4 .. 32 cache lines per wave load), so an order that hands whole octaves
     // to single XCDs leaves the other six idle (r03o / r03p: 1 285 us against 395 us for the four per-octave launches)
-    const int orig = blockIdx.x;
+    const int orig = blockIdx.x + blk0;
     const int octave = __builtin_amdgcn_readfirstlane(find_octave(S.blk_dt, S.n, orig));
     const int nbx = S.nbx[octave], nl2 = S.nlayers + 2;
     const unsigned q = (unsigned)(orig - S.blk_dt[octave]), nwg = (unsigned)(S.blk_dt[octave + 1] - S.blk_dt[octave]);   // nwg % 8 == 0
@@ -1085,6 +1263,7 @@ __device__ __forceinline__ NmsArgs oct_args(const NmsArgs &B, const OctSet &S, i
     A.octave = octave;
     A.det = B.det + S.plane0[octave]; A.trace = B.trace + S.plane0[octave];
     A.bits = B.bits + S.bits0[octave];
+    A.sbits = (octave == 0 && S.fuse0) ? B.sbits : nullptr;
     A.rowcnt = B.rowcnt + S.row0[octave] + octave;            // one extra entry (the total) per octave
     A.segcnt = B.segcnt + S.seg0[octave];
     A.chunks = S.chunks[octave]; A.nseg = S.nseg[octave];
@@ -1109,11 +1288,11 @@ __global__ __launch_bounds__(256) void k_nms_write_all(NmsArgs B, OctSet S, int4
                   max_candidates, ncand + octave);
 }
 __global__ __launch_bounds__(256) void k_interp_eval_all(const float *det, OctSet S, const int4 *cand, const unsigned *ncand, InterpOut *tmp,
-                                                         int max_candidates, unsigned *okcnt)
+                                                         int max_candidates, unsigned *okcnt, SumTex t0)
 {
     const int octave = blockIdx.y;
     const bool ok = interp_eval_one(det + S.plane0[octave], S.dld, S.rows, S.cols, octave, cand + (long long)octave * max_candidates, ncand + octave,
-                                    tmp + (long long)octave * max_candidates, blockIdx.x * 256 + threadIdx.x);
+                                    tmp + (long long)octave * max_candidates, blockIdx.x * 256 + threadIdx.x, (octave == 0 && S.fuse0) ? &t0 : nullptr);
     // accepted candidates of the octave (one atomic per wave): k_interp_compact_all's workgroup of octave o starts at the sum over o' < o
     const unsigned long long m = __ballot(ok);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(okcnt + octave, (unsigned)__popcll(m));
@@ -1204,6 +1383,7 @@ static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctav
     memset(&S, 0, sizeof(S));
     S.n = n_octaves; S.nlayers = nOctaveLayers; S.rows = rows; S.cols = cols; S.dld = dld;
     S.lds0 = (nOctaveLayers + 2 <= kLdsLayers && lds) ? 1 : 0;
+    S.fuse0 = (S.lds0 && lds >= 2) ? 1 : 0;   // lds = 2: octave 0's maxima flagged inside the det kernel
     long long plane = 0, bits = 0, seg = 0;
     int row = 0;
     for (int o = 0; o < n_octaves; ++o) {
@@ -1211,12 +1391,15 @@ static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctav
         S.plane0[o] = plane; S.bits0[o] = bits; S.row0[o] = row; S.seg0[o] = seg;
         S.chunks[o] = div_up(lc, 64); S.nseg[o] = div_up(S.chunks[o], kNmsSeg);
         S.nbx[o] = div_up(lc, 64); S.nby[o] = div_up(lr, 4);
-        if (o == 0 && S.lds0) {   // one workgroup per 16 x 64 tile and ALL layers
+        if (o == 0 && S.fuse0) {   // one workgroup per 14 x 62 tile of interior samples (16 x 64 evaluated) and ALL layers
+            S.nbx[0] = div_up(lc, kFuseTX); S.nby[0] = div_up(lr, kFuseTY);
+            S.blk_dt[1] = align_up(S.nbx[0] * S.nby[0], 8);
+        } else if (o == 0 && S.lds0) {   // one workgroup per 16 x 64 tile and ALL layers
             S.nby[0] = div_up(lr, kLdsTY);
             S.blk_dt[1] = align_up(S.nbx[0] * S.nby[0], 8);
         } else
         S.blk_dt[o + 1] = S.blk_dt[o] + align_up(S.nbx[o] * S.nby[o] * (nOctaveLayers + 2), 8);   // padded: see k_det_trace_all
-        S.blk_nms[o + 1] = S.blk_nms[o] + div_up(nOctaveLayers * lr, 4) * S.nseg[o];
+        S.blk_nms[o + 1] = S.blk_nms[o] + ((o == 0 && S.fuse0) ? 0 : div_up(nOctaveLayers * lr, 4) * S.nseg[o]);
         S.blk_wr[o + 1] = S.blk_wr[o] + div_up(nOctaveLayers * lr, 4);
         plane += (long long)(nOctaveLayers + 2) * lr * dld;
         bits += (long long)nOctaveLayers * lr * S.chunks[o];
@@ -1247,21 +1430,35 @@ void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host)
 // surf.cuda.cpp:182-204 for all octaves: six launches.  ncand: n_octaves counters; nfeat: the feature counter (zeroed by the caller)
 int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int rows, int cols, int n_octaves, int nOctaveLayers, float thr,
                  float *det, float *trace, int dld, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
-                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, int lds_tiles, hipStream_t s)
+                 unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, int lds_tiles, hipStream_t s,
+                 unsigned long long *sbits)
 {
-    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers, lds_tiles);
+    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers, (lds_tiles >= 2 && !sbits) ? 1 : lds_tiles);
     SumTex t = {sum, sld, rows, cols};
     NmsArgs B;
     memset(&B, 0, sizeof(B));
     B.det = det; B.trace = trace; B.dld = dld; B.rows = rows; B.cols = cols; B.nlayers = nOctaveLayers; B.thr = thr;
     B.mask.s = mask_sum; B.mask.sld = sld; B.mask.rows = rows; B.mask.cols = cols;
-    B.bits = bits; B.rowcnt = rowcnt; B.segcnt = segcnt;
-    hipLaunchKernelGGL(k_det_trace_all, dim3(S.blk_dt[n_octaves]), dim3(256), 0, s, t, det, trace, S, (const HaarGeo *)geo_dev);
+    B.bits = bits; B.sbits = sbits; B.rowcnt = rowcnt; B.segcnt = segcnt;
+    Fuse0Args F;
+    memset(&F, 0, sizeof(F));
+    if (S.fuse0) {
+        // octave 0's flag words, sign words and segment counts are accumulated by atomics: zero them (2 x 2 MB + 0.1 MB at 4K)
+        const size_t words = (size_t)nOctaveLayers * rows * S.chunks[0];
+        MI_HIP_TRY(hipMemsetAsync(bits, 0, sizeof(unsigned long long) * words, s));
+        MI_HIP_TRY(hipMemsetAsync(sbits, 0, sizeof(unsigned long long) * words, s));
+        MI_HIP_TRY(hipMemsetAsync(segcnt, 0, sizeof(unsigned) * (size_t)nOctaveLayers * rows * S.nseg[0], s));
+        F.thr = thr; F.mask = B.mask; F.bits = bits; F.sbits = sbits; F.segcnt = segcnt; F.chunks = S.chunks[0]; F.nseg = S.nseg[0];
+    }
+    const int blk0 = S.fuse0 ? S.blk_dt[1] : 0;
+    if (S.fuse0) hipLaunchKernelGGL(k_det_nms0, dim3(blk0), dim3(256), 0, s, t, S, F);
+    if (S.blk_dt[n_octaves] > blk0)
+        hipLaunchKernelGGL(k_det_trace_all, dim3(S.blk_dt[n_octaves] - blk0), dim3(256), 0, s, t, det, trace, S, (const HaarGeo *)geo_dev, blk0);
     hipLaunchKernelGGL(k_nms_flag_all, dim3(S.blk_nms[n_octaves]), dim3(256), 0, s, B, S);
     hipLaunchKernelGGL(k_scan_counts_all, dim3(n_octaves), dim3(1024), 0, s, B, S);
     hipLaunchKernelGGL(k_nms_write_all, dim3(S.blk_wr[n_octaves]), dim3(256), 0, s, B, S, cand, max_candidates, ncand);
     hipLaunchKernelGGL(k_interp_eval_all, dim3(div_up(max_candidates, 256), n_octaves), dim3(256), 0, s, (const float *)det, S, (const int4 *)cand,
-                       (const unsigned *)ncand, (InterpOut *)tmp, max_candidates, nfeat + 32);   // counters[32 + octave]: zeroed with the others
+                       (const unsigned *)ncand, (InterpOut *)tmp, max_candidates, nfeat + 32, t);   // counters[32 + octave]: zeroed with the others
     hipLaunchKernelGGL(k_interp_compact_all, dim3(n_octaves), dim3(1024), 0, s, (const InterpOut *)tmp, (const unsigned *)ncand, n_octaves, max_candidates, kp,
                        kld, max_features, nfeat, (const unsigned *)(nfeat + 32));
     MI_HIP_TRY(hipGetLastError());

@@ -13,6 +13,8 @@ xfeatures2d/test/test_surf.cuda.cpp:102-107,166-173).
 """
 import os
 
+import os
+
 import numpy as np
 import pytest
 
@@ -197,6 +199,27 @@ def test_detect_and_compute_with_the_count_on_the_device_is_bit_identical(gpu, s
         _, d0 = alg.detectWithDescriptors(t, None, kp0.clone(), True)   # provided keypoints: host-known count, one workgroup per feature
         assert d0.shape == d1.shape == (kp0.shape[1], alg.descriptorSize())
         np.testing.assert_array_equal(N(d0), N(d1))
+
+
+@gpu_mark
+def test_maxima_flagged_inside_the_det_kernel_are_bit_identical(gpu):
+    """Round 5: octave 0's det / trace values stay in the LDS tile of the kernel that computes them, the 26
+    comparisons run there and only the flag words (+ the sign of the trace at each maximum) leave it; the sub-pixel refinement
+    evaluates its 27 values from the integral image (MIFLOW_SURF_NMS0=1: an opt-in -- measured slower than the plane form, see
+    surf_api.cpp).  Keypoints (order included) and descriptors must not change by a bit against the default plane form -- 4K at the BASELINE setting, small and odd sizes, one
+    layer, a mask, the overflow of the candidate list.  The switch is read once per process, hence the subprocesses."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env in (("fused", {"MIFLOW_SURF_NMS0": "1"}), ("planes", {})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "surf_digest.py")], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = re.findall(r"n=(\d+) digest ([0-9a-f]{16})", r.stdout)
+        assert len(out[tag]) == 5 and all(int(n) > 5 for n, _ in out[tag]), r.stdout
+    assert out["fused"] == out["planes"], out
 
 
 @gpu_mark
