@@ -353,6 +353,26 @@ def test_fused_warp_pass_is_bit_identical(gpu):
     assert "fused warp" in r.stdout   # the fused kernel really ran in the MIFLOW_TB_FW=1 process (MIFLOW_TB_VERBOSE lines)
 
 
+def test_scheduling_switches_of_the_release_library_do_not_change_results(gpu):
+    """The release switches that only move WORK AROUND -- `MIFLOW_LANES` (internal streams of a batch), `MIFLOW_TB_HIST` (block lengths
+    of the convergence-checked path from the handle's previous calc), `MIFLOW_TB_JW=0` (independent instead of joined waves),
+    `MIFLOW_TB_FW=1` (warp inside the pass) -- must leave the flows of a fixed-work batch and of a class-default batch bit-identical
+    (each setting in its own process: the switches are read once)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dig = {}
+    for tag, env in (("default", {}), ("lanes1", {"MIFLOW_LANES": "1"}), ("lanes3", {"MIFLOW_LANES": "3"}), ("nohist", {"MIFLOW_TB_HIST": "0"}),
+                     ("jw0", {"MIFLOW_TB_JW": "0"}), ("fw1", {"MIFLOW_TB_FW": "1"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "defaults_digest.py"), "6", "both"], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        dig[tag] = re.findall(r"digest ([0-9a-f]{16})", r.stdout)
+        assert len(dig[tag]) == 2, r.stdout
+    assert all(v == dig["default"] for v in dig.values()), dig
+
+
 def test_result_changing_switches_are_not_read_by_the_release_library(gpu):
     """Round 5: `MIFLOW_TB_P16=1` (dual variable as 16-bit fixed point between passes: changes results) and
     `MIFLOW_X_SKIP` (skips launches: wrong results) exist in the experiments build only.  With either set, the shipped library computes
