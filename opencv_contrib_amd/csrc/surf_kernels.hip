@@ -861,6 +861,10 @@ __device__ __forceinline__ float area_filter_lds(const unsigned char *tile, int 
     if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + T(sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
     return sat_u8(out);
 }
+#ifndef MI_SURF_STAGE_U
+#define MI_SURF_STAGE_U 8   // r14n: 16 and 24 in flight change nothing (818 / 816 against 820 frames/s): the staging is not bound by its depth
+#endif
+constexpr int kStageU = MI_SURF_STAGE_U;   // staged texel loads in flight per lane
 template <bool EXT>
 __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
                                                             int kld, int nfeat_host, const unsigned *nfeat_dev, float *desc, long long dstep /* floats */,
@@ -886,22 +890,24 @@ __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char 
             while (yb < 21 && ((int)floorf((float)yb * s + s) - dy_lo + 1) * nc <= tile_bytes) ++yb;
             const int nr = (int)floorf((float)(yb - 1) * s + s) - dy_lo + 1;
             const int nblk = ((nr + 7) >> 3) * nbc;
-            // 8 x 8 blocks of the window lattice, block row / column carried along (no division per block); eight blocks per trip so that
-            // their loads are in flight together
+            // 8 x 8 blocks of the window lattice, block row / column carried along (no division per block); kStageU blocks per trip so that
+            // their loads are in flight together (the staging is a chain of gather round trips: 8 per trip until round 5)
             int br = wv / nbc, bc = wv - br * nbc;
-            for (int blk = wv; blk < nblk; blk += 64) {
-                float v[8];
-                int rr[8], cc[8];
+            for (int blk = wv; blk < nblk; blk += 8 * kStageU) {
+                float v[kStageU];
+                int ti[kStageU];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    rr[u] = br * 8 + ly; cc[u] = bc * 8 + lx;
-                    v[u] = (blk + 8 * u < nblk && rr[u] < nr && cc[u] < nc) ? win_get(w, dy_lo + rr[u], cc[u] - 1) : -1.f;
+                for (int u = 0; u < kStageU; ++u) {
+                    const int rr = br * 8 + ly, cc = bc * 8 + lx;
+                    const bool in = blk + 8 * u < nblk && rr < nr && cc < nc;
+                    ti[u] = in ? rr * nc + cc : -1;
+                    v[u] = in ? win_get(w, dy_lo + rr, cc - 1) : 0.f;
                     bc += 8;
                     while (bc >= nbc) { bc -= nbc; ++br; }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (v[u] >= 0.f) tile[rr[u] * nc + cc[u]] = (unsigned char)v[u];
+                for (int u = 0; u < kStageU; ++u)
+                    if (ti[u] >= 0) tile[ti[u]] = (unsigned char)v[u];
             }
             __syncthreads();
             const int nsmp = (yb - ya) * 21;

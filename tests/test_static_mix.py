@@ -83,14 +83,21 @@ def test_blocked_kernels_keep_their_occupancy():
         return out
 
     tbr = usage("tvl1_tbr_kernels.hip")
-    # the kernel of record since round 4 forms |grad|^2 itself (NG): ...ELi2ELb1ELb0EE; the one that reads the plane stays for the stage API
-    rec = [v for k, v in tbr.items() if "k_iterate_tbrILi10ELi1ELb" in k and (k.endswith("ELi4ELi2ELi0ELi2ELb1ELb0EEEvNS0_6TbArgsE") or
-                                                                               k.endswith("ELi4ELi2ELi0ELi2ELb0ELb0EEEvNS0_6TbArgsE"))]
+    # the kernel of record since round 4 forms |grad|^2 itself (NG): ...ELi2ELb1ELb0ELi0EE (the last argument, round 5: FW = 0, the warp as
+    # its own launch); the one that reads the plane stays for the stage API
+    rec = [v for k, v in tbr.items() if "k_iterate_tbrILi10ELi1ELb" in k and (k.endswith("ELi4ELi2ELi0ELi2ELb1ELb0ELi0EEEvNS0_6TbArgsE") or
+                                                                               k.endswith("ELi4ELi2ELi0ELi2ELb0ELb0ELi0EEEvNS0_6TbArgsE"))]
     assert len(rec) == 4   # {no |grad|^2 plane, plane} x {first pass of a warp (p = 0), the others}
     for v in rec:
         assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["SGPRs Spill"] == 0 and v["Occupancy"] >= 4, v
+    # the fused-warp instantiations (FW = 1, 2: four producer waves beside the four consumers; opt-in) must fit the same budget: eight
+    # waves per workgroup at 128 VGPRs = two workgroups per CU
+    fw = [v for k, v in tbr.items() if re.search(r"k_iterate_tbrILi10ELi1ELb[01]ELi4ELi2ELi0ELi2ELb1ELb0ELi[12]EEEvNS0_6TbArgsE$", k)]
+    assert len(fw) == 4
+    for v in fw:
+        assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["Occupancy"] >= 4, v
     for k, v in tbr.items():
-        if re.search(r"ELi2ELb[01]ELb[01]EEEvNS0_6TbArgsE$", k):      # every joined-wave instantiation (fixed work and speculative steps)
+        if re.search(r"ELi2ELb[01]ELb[01]ELi[012]EEEvNS0_6TbArgsE$", k):      # every joined-wave instantiation (fixed work and speculative steps)
             assert v.get("VGPRs Spill", 0) == 0, k
     surf = usage("surf_kernels.hip")
     for k, v in surf.items():
