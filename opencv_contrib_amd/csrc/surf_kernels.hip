@@ -584,13 +584,15 @@ __global__ __launch_bounds__(256) void k_orientation(SumTex t, float *kp, int kl
     const float c_NX[2][5] = {{0, 0, 2, 4, -1}, {2, 0, 4, 4, 1}};   // surf.cu:524-525
     const float c_NY[2][5] = {{0, 0, 4, 2, 1}, {0, 2, 4, 4, -1}};
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int f = blockIdx.x * 4 + wv;
-    const int nfeat = nfeat_p ? (int)*nfeat_p : n_fixed;
-    if (f >= nfeat) return;
+    const int nfeat = nfeat_p ? min((int)*nfeat_p, n_fixed) : n_fixed;
+    // a wave walks the features grid-cyclically (round 5: with the count on the device the grid is a fixed few workgroups per CU instead of
+    // maxFeatures / 4 workgroups, four fifths of them empty at 4K); a wave's LDS operations execute in order, so its rows of sh / best
+    // are free again when the next feature's stores issue
+    for (int f = blockIdx.x * 4 + wv; f < nfeat; f += (int)gridDim.x * 4) {
     const float fx = kp[f], fy = kp[kld + f], fsz = kp[4 * kld + f];
     const float s = fsz * 1.2f / 9.0f;
     const int grad_wav_size = 2 * rn(2.0f * s);
-    if ((t.rows + 1) < grad_wav_size || (t.cols + 1) < grad_wav_size) return;   // the reference returns without writing
+    if ((t.rows + 1) < grad_wav_size || (t.cols + 1) < grad_wav_size) continue;   // the reference returns without writing
     float *sX = sh[wv][0], *sY = sh[wv][1], *sA = sh[wv][2];
     for (int tid = lane; tid < 128; tid += 64) {
         float X = 0.f, Y = 0.f, angle = 0.f;
@@ -647,6 +649,7 @@ __global__ __launch_bounds__(256) void k_orientation(SumTex t, float *kp, int kl
         kp_dir = 360.0f - kp_dir;
         if (fabsf(kp_dir - 360.f) < FLT_EPSILON) kp_dir = 0.f;
         kp[5 * kld + f] = kp_dir;
+    }
     }
 }
 
@@ -861,6 +864,9 @@ __device__ __forceinline__ float area_filter_lds(const unsigned char *tile, int 
     if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + T(sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
     return sat_u8(out);
 }
+#ifndef MI_SURF_DESC_WGS_PER_CU
+#define MI_SURF_DESC_WGS_PER_CU 16   // workgroups per CU of the descriptor launch when the feature count is on the device (r15c at 4K: 3 | 6 | 16 | 48 = 818 | 841 | 905 | 902 frames/s)
+#endif
 #ifndef MI_SURF_STAGE_U
 #define MI_SURF_STAGE_U 8   // r14n: 16 and 24 in flight change nothing (818 / 816 against 820 frames/s): the staging is not bound by its depth
 #endif
@@ -879,7 +885,18 @@ __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char 
     for (int f = nfeat - 1 - (int)blockIdx.x; f >= 0; f -= (int)gridDim.x) {
         Win w;
         const float s = desc_window(w, img, istep, rows, cols, kp, kld, f);
-        if (!desc_staged(s, s_stage, tile_bytes)) continue;
+        if (!desc_staged(s, s_stage, tile_bytes)) {
+            // round 5: ONE launch builds every feature's patch -- a small feature straight from global memory (k_descriptors' body), a
+            // large one through the tile -- so that the two kinds share the grid (no second launch waiting for the first one's tail)
+            if (threadIdx.x < 441) {
+                const int tid = threadIdx.x, xl = tid % 21, yl = tid / 21;
+                P[yl][xl] = s > 1 ? area_filter(w, (float)xl, (float)yl, s) : linear_filter(w, yl * s, xl * s);
+            }
+            __syncthreads();
+            desc_tail<EXT>(P, D, part, dw, desc + (long long)f * dstep);
+            __syncthreads();
+            continue;
+        }
         const int dxmax = (int)floorf(20.f * s + s);              // the largest sx2 of area_filter (x = 20)
         const int nc = dxmax + 2;                                 // tile columns: dx = -1 .. dxmax
         const int nbc = (nc + 7) >> 3;
@@ -1479,7 +1496,8 @@ int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int
         hipLaunchKernelGGL(k_fill_angle, dim3(div_up(n_or_max, 256)), dim3(256), 0, s, kp, kld, nfeat_dev, n_or_max, 360.0f - 90.0f);
     } else {
         SumTex t = {sum, sld, rows, cols};
-        hipLaunchKernelGGL(k_orientation, dim3(div_up(n_or_max, 4)), dim3(256), 0, s, t, kp, kld, nfeat_dev, n_or_max, apt);
+        const int grid = nfeat_dev ? std::min(div_up(n_or_max, 4), 8 * (device_simds() / 4)) : div_up(n_or_max, 4);
+        hipLaunchKernelGGL(k_orientation, dim3(grid), dim3(256), 0, s, t, kp, kld, nfeat_dev, n_or_max, apt);
     }
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
@@ -1501,10 +1519,11 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
     static const int kTileBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 48; return (kb >= 16 && kb <= 150 ? kb : 48) * 1024; }();
     // host-known count: one workgroup per feature.  Count on the device (nfeat = its upper bound, maxFeatures): a fixed grid of a few
     // workgroups per CU walks the features block-cyclically, most expensive first -- no launch of tens of thousands of empty workgroups
-    const int grid = nfeat_dev ? std::min(nfeat, 16 * (device_simds() / 4)) : nfeat;
-    if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(grid), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
-    else hipLaunchKernelGGL(k_descriptors<false>, dim3(grid), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
-    if (ss < 1e29f) {
+    const int grid = nfeat_dev ? std::min(nfeat, MI_SURF_DESC_WGS_PER_CU * (device_simds() / 4)) : nfeat;
+    if (!(ss < 1e29f)) {   // staging switched off (MIFLOW_SURF_STAGE_S=0): every patch straight from global memory
+        if (extended) hipLaunchKernelGGL(k_descriptors<true>, dim3(grid), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
+        else hipLaunchKernelGGL(k_descriptors<false>, dim3(grid), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
+    } else {
         static const hipError_t attr_rc = [] {
             hipError_t e = hipFuncSetAttribute((const void *)k_descriptors_staged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_descriptors_staged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes);
