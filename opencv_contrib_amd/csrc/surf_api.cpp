@@ -16,7 +16,7 @@ struct mi_surf {
     float *apt = nullptr, *dw = nullptr;
     // scratch sized for (rows, cols, layers)
     int capR = 0, capC = 0, capL = 0, capCand = 0;
-    unsigned *sum = nullptr, *msum = nullptr, *V = nullptr, *BT = nullptr;
+    unsigned *sum = nullptr, *msum = nullptr, *V = nullptr, *BT = nullptr, *poly = nullptr;
     float *det = nullptr, *trace = nullptr;
     unsigned long long *bits = nullptr, *sbits = nullptr;
     unsigned *rowcnt = nullptr, *segcnt = nullptr;
@@ -26,6 +26,7 @@ struct mi_surf {
     int sld = 0, vld = 0, dld = 0;
     // all octaves per launch (surf::detect_fused): region sizes and the per-(octave, layer) filter geometry on the device
     bool fused = false;
+    bool use_poly = false;
     int lds_tiles = 0;   // octave 0 of the fused det / trace launch on LDS tiles: this handle's decision (MIFLOW_SURF_LDS=0 switches it off)
     int capO = 0;
     void *geo = nullptr;
@@ -97,9 +98,9 @@ int mi_surf_get_params(const mi_surf *h, mi_surf_params *p) { MI_REQUIRE(h && p,
 
 static void free_scratch(mi_surf *h)
 {
-    void *ps[] = {h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->sbits, h->rowcnt, h->segcnt, h->cand, h->itmp, h->geo};
+    void *ps[] = {h->poly, h->sum, h->msum, h->V, h->BT, h->det, h->trace, h->bits, h->sbits, h->rowcnt, h->segcnt, h->cand, h->itmp, h->geo};
     for (void *p : ps) if (p) (void)hipFree(p);
-    h->sum = h->msum = h->V = h->BT = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->sbits = nullptr; h->rowcnt = nullptr; h->segcnt = nullptr; h->cand = nullptr; h->itmp = nullptr; h->geo = nullptr;
+    h->sum = h->msum = h->V = h->BT = h->poly = nullptr; h->det = h->trace = nullptr; h->bits = nullptr; h->sbits = nullptr; h->rowcnt = nullptr; h->segcnt = nullptr; h->cand = nullptr; h->itmp = nullptr; h->geo = nullptr;
     h->capR = h->capC = h->capL = h->capCand = h->capO = 0;
 }
 
@@ -164,13 +165,18 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
             // 265 MB -- and the refinement's 27 re-evaluations per candidate 143 us against 15): 736 against 826 frames/s
             const char *n0 = getenv("MIFLOW_SURF_NMS0");
             if (h->lds_tiles && n0 && *n0 && atoi(n0) != 0) h->lds_tiles = 2;
+            // round 5: octaves >= 1 read their taps from polyphase planes of the integral image (consecutive lanes = consecutive words
+            // instead of words 2^o apart); MIFLOW_SURF_POLY=0 keeps the strided gathers (bit-identical either way)
+            const char *pp = getenv("MIFLOW_SURF_POLY");
+            h->use_poly = h->fused && octaves > 1 && !(pp && *pp && atoi(pp) == 0);
+            if (h->use_poly) h->lds_tiles |= 4;
         }
         surf::FusedSizes z;
         z.plane_floats = (size_t)h->dld * rows * (layers + 2);
         z.bits_words = (size_t)layers * rows * div_up(cols, 64);
         z.row_counts = (size_t)layers * rows + 1;
         z.seg_counts = (size_t)layers * rows * surf::nms_segments(cols);
-        z.geo_bytes = 0;
+        z.geo_bytes = 0; z.poly_words = 0;
         if (h->fused) surf::fused_sizes(rows, cols, h->dld, octaves, layers, &z);
         const size_t nlists = h->fused ? (size_t)octaves : 1;
         MI_HIP_TRY(hipMalloc((void **)&h->sum, sizeof(unsigned) * (size_t)h->sld * (rows + 1)));
@@ -186,7 +192,8 @@ static int ensure(mi_surf *h, int rows, int cols, int layers, int maxCand, bool 
         MI_HIP_TRY(hipMalloc(&h->itmp, surf::interp_tmp_bytes(maxCand) * nlists));
         if (h->fused) {
             h->geo_host.assign(z.geo_bytes, 0);
-            surf::fused_geometry(h->sld, octaves, layers, h->geo_host.data());
+            surf::fused_geometry(h->sld, octaves, layers, h->geo_host.data(), rows, cols, h->use_poly);
+            if (h->use_poly) MI_HIP_TRY(hipMalloc((void **)&h->poly, sizeof(unsigned) * z.poly_words));
             MI_HIP_TRY(hipMalloc(&h->geo, z.geo_bytes));
             h->geo_dirty = true;
         }
@@ -242,7 +249,7 @@ static int detect_enqueue(mi_surf *h, const mi_mat *img, const mi_mat *mask, mi_
     if (h->fused) {                                                                                                  // :182-204, all octaves per launch
         if ((rc = surf::detect_fused(h->sum, use_mask ? h->msum : nullptr, h->sld, rows, cols, P.n_octaves, P.n_octave_layers,
                                      (float)P.hessian_threshold, h->det, h->trace, h->dld, h->bits, h->rowcnt, h->segcnt, h->cand, maxC,
-                                     h->counters + 1, h->itmp, h->geo, kp, kld, maxF, h->counters, h->lds_tiles, st, h->sbits))) return rc;
+                                     h->counters + 1, h->itmp, h->geo, kp, kld, maxF, h->counters, h->lds_tiles, st, h->sbits, h->poly))) return rc;
     } else
     for (int octave = 0; octave < P.n_octaves; ++octave) {                                                           // :182-204
         if ((rc = surf::det_trace(h->sum, h->sld, rows, cols, octave, P.n_octave_layers, h->det, h->trace, h->dld, st))) return rc;

@@ -191,7 +191,9 @@ struct HaarGeo {       // per layer: tap offsets (elements, relative to the samp
     double ry[10], area[10];   // boxes: Dxx 0..2, Dyy 3..5, Dxy 6..9
 };
 // host side (the geometry of a layer does not depend on the sample): rintf = round-half-even = __float2int_rn of the device code
-static HaarGeo haar_geo(int size, int sld)
+constexpr int kMaxFusedOctaves = 6;
+template <class Off>   // off(ey, ex): word offset of the tap (ey rows, ex columns) from the sample's top-left corner
+static HaarGeo haar_geo_off(int size, Off off)
 {
     HaarGeo g;
     const float ratio = (float)size / 9;
@@ -200,9 +202,9 @@ static HaarGeo haar_geo(int size, int sld)
     const int e27[2] = {rnh(ratio * 2.f), rnh(ratio * 7.f)};
     const int e1458[4] = {rnh(ratio * 1.f), rnh(ratio * 4.f), rnh(ratio * 5.f), rnh(ratio * 8.f)};
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 2; ++j) { g.xx[i][j] = e27[j] * sld + e0369[i]; g.yy[j][i] = e0369[i] * sld + e27[j]; }
+        for (int j = 0; j < 2; ++j) { g.xx[i][j] = off(e27[j], e0369[i]); g.yy[j][i] = off(e0369[i], e27[j]); }
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) g.xy[i][j] = e1458[i] * sld + e1458[j];
+        for (int j = 0; j < 4; ++j) g.xy[i][j] = off(e1458[i], e1458[j]);
     for (int k = 0; k < 3; ++k) {
         g.area[k] = (double)((e0369[k + 1] - e0369[k]) * (e27[1] - e27[0]));
         g.area[3 + k] = g.area[k];   // Dyy is Dxx transposed: the same edge differences
@@ -213,6 +215,43 @@ static HaarGeo haar_geo(int size, int sld)
     g.area[9] = (double)((e1458[3] - e1458[2]) * (e1458[3] - e1458[2]));
     for (int k = 0; k < 10; ++k) g.ry[k] = 1.0 / g.area[k];
     return g;
+}
+static HaarGeo haar_geo(int size, int sld) { return haar_geo_off(size, [sld](int ey, int ex) { return ey * sld + ex; }); }
+
+// ---- polyphase copies of the integral image for octaves >= 1 (round 5).  A sample of octave o sits at S[(i << o)][(j << o)] and its
+// taps at fixed offsets (ey, ex) from there: the 64 lanes of a wave (consecutive j) read words 2^o apart -- 8 .. 32 lines of 64 B per
+// load, the L1 tag-lookup rate that bounds the gather path (profiles/surf_counters.json).  With the integral image also stored as 4^o
+// PHASE PLANES per octave, plane (y & m, x & m) holding S[y][x] at (y >> o, x >> o), the same tap is
+//     plane(ey & m, ex & m)[i + (ey >> o)][j + (ex >> o)]
+// i.e. consecutive lanes read CONSECUTIVE words (4-5 lines per load), and the tap is still "lane offset + wave-uniform offset": only the
+// geometry table and the lane offset change, the integers read -- and with them every det / trace value -- are the same.
+struct PolyGeo { int prows, pld; long long plane_words, base; };   // per octave (octave 0: unused)
+static PolyGeo poly_geo(int rows, int cols, int o, long long base)
+{
+    PolyGeo g;
+    g.prows = (rows >> o) + 2; g.pld = align_up((cols >> o) + 2, 64);
+    g.plane_words = (long long)g.prows * g.pld; g.base = base;
+    return g;
+}
+static long long poly_total_words(int rows, int cols, int n_octaves)
+{
+    long long w = 0;
+    for (int o = 1; o < n_octaves; ++o) w += poly_geo(rows, cols, o, 0).plane_words << (2 * o);
+    return w;
+}
+struct PolyArgs { int n; int prows[kMaxFusedOctaves], pld[kMaxFusedOctaves]; long long plane_words[kMaxFusedOctaves], base[kMaxFusedOctaves]; };
+// one thread per word of the integral image: coalesced read, one store per octave (runs of 64 >> o consecutive words per plane)
+__global__ __launch_bounds__(256) void k_poly_build(SumTex t, unsigned *poly, PolyArgs A)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x > t.cols || y > t.rows) return;
+    const unsigned v = t.s[(long long)y * t.sld + x];
+#pragma unroll
+    for (int o = 1; o < kMaxFusedOctaves; ++o) {
+        if (o >= A.n) break;
+        const int m = (1 << o) - 1;
+        poly[A.base[o] + (long long)(((y & m) << o) + (x & m)) * A.plane_words[o] + (long long)(y >> o) * A.pld[o] + (x >> o)] = v;
+    }
 }
 constexpr int kDetLayers = 6;   // layers of one launch (nOctaveLayers + 2 <= 6; more layers: several launches)
 struct HaarGeoSet { HaarGeo l[kDetLayers]; };
@@ -312,7 +351,10 @@ struct NmsArgs {
 // surf.cu:263-355: one wave per (layer, row); flags per 64-column chunk.  The centre values of four chunks are loaded together (the
 // round-2 loop issued one load per chunk and waited for it: 60 dependent round trips per 4K row, 176 us per octave-0 launch for
 // 66 MB); a chunk without a value above the threshold -- nearly all -- costs nothing more.
-constexpr int kNmsSeg = 8;   // chunks of one wave: a 4K row is 8 waves (one wave per row left the loop at 60 dependent round trips)
+#ifndef MI_SURF_NMS_SEG
+#define MI_SURF_NMS_SEG 8
+#endif
+constexpr int kNmsSeg = MI_SURF_NMS_SEG;   // chunks of one wave: a 4K row is 8 waves (one wave per row left the loop at 60 dependent round trips)
 __device__ __forceinline__ void nms_flag_row(const NmsArgs &A, int r, int seg)
 {
     const int lane = threadIdx.x & 63;
@@ -1169,7 +1211,6 @@ __device__ __forceinline__ void lds_layer(const SumTex &t, const unsigned *patch
 // 0's samples and took 1/6 of its time).  Here every stage covers all octaves: the planes, flag words, counts and candidate lists of
 // an octave live at their own offsets (OctSet), a workgroup finds its octave from the cumulative workgroup counts, and the last
 // stage walks the octaves in order so that the features of octave o still follow those of octave o - 1 (deterministic order).
-constexpr int kMaxFusedOctaves = 6;
 struct OctSet {
     int n;                                   // octaves
     int nlayers;                             // nOctaveLayers
@@ -1183,6 +1224,9 @@ struct OctSet {
     int blk_wr[kMaxFusedOctaves + 1];        //   ... of k_nms_write_all (row groups)
     int nbx[kMaxFusedOctaves], nby[kMaxFusedOctaves], nseg[kMaxFusedOctaves], chunks[kMaxFusedOctaves];
     int lds0;                                // octave 0 of k_det_trace_all on LDS tiles (all its layers per workgroup): nby[0] counts 16-row tiles
+    int poly;                                // octaves >= 1 read their taps from the polyphase planes (pld / pbase per octave; geometry table built for them)
+    int pld[kMaxFusedOctaves];
+    long long pbase[kMaxFusedOctaves];
     int fuse0;                               // ... and its maxima flagged in that kernel (no planes; tiles of 14 x 62 interior samples; no k_nms_flag_all workgroups)
 };
 __device__ __forceinline__ int find_octave(const int *cum, int n, int id)
@@ -1223,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_det_nms0(SumTex t, OctSet S, Fuse0Args 
 }
 
 // (blk0: workgroups of octave 0 that run in k_det_nms0 instead -- fuse0 -- and are not part of this launch's grid)
-__global__ __launch_bounds__(256) void k_det_trace_all(SumTex t, float *det, float *trace, OctSet S, const HaarGeo *geo, int blk0)
+__global__ __launch_bounds__(256) void k_det_trace_all(SumTex t, float *det, float *trace, OctSet S, const HaarGeo *geo, int blk0, const unsigned *poly)
 {
     // Everything derived from the workgroup id is wave-uniform.  The octave comes from the ORIGINAL id (every octave's range is padded
     // to a multiple of 8 workgroups), the XCD-contiguous remap is applied INSIDE the octave: a sample of octave o costs up to 10 x one of
@@ -1270,9 +1314,17 @@ __global__ __launch_bounds__(256) void k_det_trace_all(SumTex t, float *det, flo
         // read-only for the life of the launch and wave-uniform: through the constant address space = scalar loads (s_load_dwordx16)
         typedef const __attribute__((address_space(4))) HaarGeo cgeo_t;
         cgeo_t &g = *((cgeo_t *)(unsigned long long)geo + (octave * kDetLayers + layer));
+        if (S.poly && octave >= 1) {   // taps from the octave's phase planes: consecutive lanes read consecutive words (octave 0 without its LDS tiles keeps the image itself: stride 1 already)
+            SumTex tp = t;
+            tp.s = poly + S.pbase[octave];
+            unsigned voff = 4u * ((unsigned)i * (unsigned)S.pld[octave] + (unsigned)j);
+            asm volatile("" : "+v"(voff));
+            haar_det_trace(tp, g, voff, d, tr);
+        } else {
         unsigned voff = 4u * ((unsigned)(i << octave) * (unsigned)t.sld + (unsigned)(j << octave));
         asm volatile("" : "+v"(voff));
         haar_det_trace(t, g, voff, d, tr);
+        }
     }
     const long long o = S.plane0[octave] + (long long)(layer * layer_rows + ii) * S.dld + jj;
     det[o] = d;
@@ -1405,8 +1457,17 @@ static OctSet make_octset(int rows, int cols, int dld, int n_octaves, int nOctav
     OctSet S;
     memset(&S, 0, sizeof(S));
     S.n = n_octaves; S.nlayers = nOctaveLayers; S.rows = rows; S.cols = cols; S.dld = dld;
-    S.lds0 = (nOctaveLayers + 2 <= kLdsLayers && lds) ? 1 : 0;
-    S.fuse0 = (S.lds0 && lds >= 2) ? 1 : 0;   // lds = 2: octave 0's maxima flagged inside the det kernel
+    S.lds0 = (nOctaveLayers + 2 <= kLdsLayers && (lds & 3)) ? 1 : 0;
+    S.fuse0 = (S.lds0 && (lds & 3) >= 2) ? 1 : 0;   // lds & 3 = 2: octave 0's maxima flagged inside the det kernel
+    S.poly = (lds & 4) && n_octaves > 1 ? 1 : 0;     // lds & 4: octaves >= 1 on the polyphase planes
+    {
+        long long base = 0;
+        for (int o = 1; o < n_octaves; ++o) {
+            const PolyGeo pg = poly_geo(rows, cols, o, base);
+            S.pld[o] = pg.pld; S.pbase[o] = base;
+            base += pg.plane_words << (2 * o);
+        }
+    }
     long long plane = 0, bits = 0, seg = 0;
     int row = 0;
     for (int o = 0; o < n_octaves; ++o) {
@@ -1441,22 +1502,34 @@ void fused_sizes(int rows, int cols, int dld, int n_octaves, int nOctaveLayers, 
     z->seg_counts = (size_t)(S.seg0[last] + (long long)nOctaveLayers * lr * S.nseg[last]);
     z->row_counts = (size_t)(S.row0[last] + nOctaveLayers * lr + n_octaves);
     z->geo_bytes = sizeof(HaarGeo) * (size_t)n_octaves * kDetLayers;
+    z->poly_words = (size_t)poly_total_words(rows, cols, n_octaves);
 }
 // geometry of every (octave, layer) of the frame size: uploaded by the handle when the size changes
-void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host)
+void fused_geometry(int sld, int n_octaves, int nOctaveLayers, void *geo_host, int rows, int cols, bool poly)
 {
     HaarGeo *g = (HaarGeo *)geo_host;
     memset(g, 0, sizeof(HaarGeo) * (size_t)n_octaves * kDetLayers);
     for (int o = 0; o < n_octaves; ++o)
-        for (int l = 0; l < nOctaveLayers + 2; ++l) g[o * kDetLayers + l] = haar_geo(calc_size(o, l), sld);
+        for (int l = 0; l < nOctaveLayers + 2; ++l) {
+            if (poly && o >= 1) {   // tap (ey, ex) of octave o = phase plane (ey & m, ex & m), position shifted by (ey >> o, ex >> o)
+                const PolyGeo pg = poly_geo(rows, cols, o, 0);
+                const int m = (1 << o) - 1;
+                g[o * kDetLayers + l] = haar_geo_off(calc_size(o, l), [&](int ey, int ex) {
+                    return (int)((long long)(((ey & m) << o) + (ex & m)) * pg.plane_words + (long long)(ey >> o) * pg.pld + (ex >> o));
+                });
+            } else g[o * kDetLayers + l] = haar_geo(calc_size(o, l), sld);
+        }
 }
 // surf.cuda.cpp:182-204 for all octaves: six launches.  ncand: n_octaves counters; nfeat: the feature counter (zeroed by the caller)
 int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int rows, int cols, int n_octaves, int nOctaveLayers, float thr,
                  float *det, float *trace, int dld, unsigned long long *bits, unsigned *rowcnt, unsigned *segcnt, int4 *cand, int max_candidates,
                  unsigned *ncand, void *tmp, const void *geo_dev, float *kp, int kld, int max_features, unsigned *nfeat, int lds_tiles, hipStream_t s,
-                 unsigned long long *sbits)
+                 unsigned long long *sbits, unsigned *poly)
 {
-    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers, (lds_tiles >= 2 && !sbits) ? 1 : lds_tiles);
+    int ldsf = lds_tiles;
+    if ((ldsf & 3) >= 2 && !sbits) ldsf = (ldsf & ~3) | 1;
+    if (!poly) ldsf &= ~4;
+    const OctSet S = make_octset(rows, cols, dld, n_octaves, nOctaveLayers, ldsf);
     SumTex t = {sum, sld, rows, cols};
     NmsArgs B;
     memset(&B, 0, sizeof(B));
@@ -1473,10 +1546,20 @@ int detect_fused(const unsigned *sum, const unsigned *mask_sum, int sld, int row
         MI_HIP_TRY(hipMemsetAsync(segcnt, 0, sizeof(unsigned) * (size_t)nOctaveLayers * rows * S.nseg[0], s));
         F.thr = thr; F.mask = B.mask; F.bits = bits; F.sbits = sbits; F.segcnt = segcnt; F.chunks = S.chunks[0]; F.nseg = S.nseg[0];
     }
+    if (S.poly) {
+        PolyArgs PA;
+        memset(&PA, 0, sizeof(PA));
+        PA.n = n_octaves;
+        for (int o = 1; o < n_octaves; ++o) {
+            const PolyGeo pg = poly_geo(rows, cols, o, S.pbase[o]);
+            PA.prows[o] = pg.prows; PA.pld[o] = pg.pld; PA.plane_words[o] = pg.plane_words; PA.base[o] = pg.base;
+        }
+        hipLaunchKernelGGL(k_poly_build, dim3(div_up(cols + 1, 256), rows + 1), dim3(256), 0, s, t, poly, PA);
+    }
     const int blk0 = S.fuse0 ? S.blk_dt[1] : 0;
     if (S.fuse0) hipLaunchKernelGGL(k_det_nms0, dim3(blk0), dim3(256), 0, s, t, S, F);
     if (S.blk_dt[n_octaves] > blk0)
-        hipLaunchKernelGGL(k_det_trace_all, dim3(S.blk_dt[n_octaves] - blk0), dim3(256), 0, s, t, det, trace, S, (const HaarGeo *)geo_dev, blk0);
+        hipLaunchKernelGGL(k_det_trace_all, dim3(S.blk_dt[n_octaves] - blk0), dim3(256), 0, s, t, det, trace, S, (const HaarGeo *)geo_dev, blk0, (const unsigned *)poly);
     hipLaunchKernelGGL(k_nms_flag_all, dim3(S.blk_nms[n_octaves]), dim3(256), 0, s, B, S);
     hipLaunchKernelGGL(k_scan_counts_all, dim3(n_octaves), dim3(1024), 0, s, B, S);
     hipLaunchKernelGGL(k_nms_write_all, dim3(S.blk_wr[n_octaves]), dim3(256), 0, s, B, S, cand, max_candidates, ncand);

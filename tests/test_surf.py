@@ -213,13 +213,15 @@ def test_maxima_flagged_inside_the_det_kernel_are_bit_identical(gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for tag, env in (("fused", {"MIFLOW_SURF_NMS0": "1"}), ("planes", {})):
+    for tag, env in (("fused", {"MIFLOW_SURF_NMS0": "1"}), ("planes", {}), ("strided", {"MIFLOW_SURF_POLY": "0"})):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "surf_digest.py")], capture_output=True, text=True,
                            env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = re.findall(r"n=(\d+) digest ([0-9a-f]{16})", r.stdout)
         assert len(out[tag]) == 5 and all(int(n) > 5 for n, _ in out[tag]), r.stdout
-    assert out["fused"] == out["planes"], out
+    # ... and the polyphase planes of the integral image (octaves >= 1 read consecutive words, the default since round 5) against the
+    # strided gathers (MIFLOW_SURF_POLY=0): the same integers, the same det / trace values
+    assert out["fused"] == out["planes"] == out["strided"], out
 
 
 @gpu_mark
