@@ -366,35 +366,45 @@ __device__ __forceinline__ void nms_flag_row(const NmsArgs &A, int r, int seg)
     const int margin = ((calc_size(A.octave, layer + 1) >> 1) >> A.octave) + 1;
     unsigned cnt = 0;
     const bool row_ok = i >= margin && i < layer_rows - margin;
-#define DET(l, ii, jj) A.det[(long long)((l) * layer_rows + clampi(ii, 0, A.rows - 1)) * A.dld + clampi(jj, 0, A.cols - 1)]
     constexpr int CB = 4;
+    const float *row = A.det + (long long)(layer * layer_rows + min(i, layer_rows - 1)) * A.dld;   // the centre row of this wave's samples
     for (int c0 = cbeg; c0 < cend; c0 += CB) {
         float v[CB];
         bool in[CB];
+        // Round 5: every lane loads ITS OWN centre value, candidate or not (columns up to dld - 1 lie inside the row's allocation; what
+        // is there beyond the layer's samples is compared by nobody), plus the two values left and right of the group: the in-row
+        // neighbours of a candidate are then the neighbouring LANES' registers -- the first of the four stages below costs no load
+        // and no round trip (it ends nearly every chunk: in-plane maxima are rare), where it used to cost one per chunk.
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
             const int j = (c0 + k) * 64 + lane;
             in[k] = row_ok && c0 + k < cend && j >= margin && j < layer_cols - margin;
-            v[k] = in[k] ? DET(layer, i, j) : -FLT_MAX;
+            v[k] = (row_ok && c0 + k < cend) ? row[j] : -FLT_MAX;
         }
+        const float eL = (row_ok && c0 > 0) ? row[c0 * 64 - 1] : -FLT_MAX;
+        const float eR = (row_ok && c0 + CB < A.chunks) ? row[(c0 + CB) * 64] : -FLT_MAX;
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
             if (c0 + k >= cend) break;
             const int j = (c0 + k) * 64 + lane;
             // The 26 strict comparisons of surf.cu:316-343 in FOUR wave-uniform stages -- same row, the two other rows of the layer, the
             // layer below, the layer above -- each entered only while some lane of the chunk is still a candidate.  On a textured
-            // frame most chunks hold values above the threshold (r06c) but in-plane maxima are rare: the two loads of the first stage
-            // end nearly every chunk, where the one-stage form issued all 26 loads for every chunk with one value above the threshold.
+            // frame most chunks hold values above the threshold (r06c) but in-plane maxima are rare: the first stage ends nearly
+            // every chunk, where the one-stage form issued all 26 loads for every chunk with one value above the threshold.
             // margin >= 1 and 1 <= layer <= nlayers keep every neighbour inside the planes: nine row pointers, immediate column offsets.
             bool ismax = in[k] && v[k] > A.thr;
             if (ismax && A.mask.s) {
                 const int sum_i = (i - ((size >> 1) >> A.octave)) << A.octave, sum_j = (j - ((size >> 1) >> A.octave)) << A.octave;
                 ismax = mask_check(A.mask, sum_i, sum_j, size);
             }
-            const float *ctr = A.det + (long long)(layer * layer_rows + i) * A.dld + j;
+            const float *ctr = row + j;
             const float vk = v[k];
+            // ctr[-1], ctr[1]: the neighbouring lanes' values; lane 0 / lane 63 take the previous / next chunk's edge lane (or eL / eR)
+            const float fromL = k > 0 ? __shfl(v[k > 0 ? k - 1 : 0], 63) : eL, fromR = k + 1 < CB ? __shfl(v[k + 1 < CB ? k + 1 : k], 0) : eR;
+            const float up = __shfl_up(vk, 1), dn = __shfl_down(vk, 1);
+            const float left = lane == 0 ? fromL : up, right = lane == 63 ? fromR : dn;
             if (__ballot(ismax) != 0ull) {
-                if (ismax) ismax = vk > ctr[-1] && vk > ctr[1];
+                if (ismax) ismax = vk > left && vk > right;
                 if (__ballot(ismax) != 0ull) {
                     if (ismax) {
                         const float *qa = ctr - A.dld, *qb = ctr + A.dld;
