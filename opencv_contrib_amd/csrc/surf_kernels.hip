@@ -383,47 +383,74 @@ __device__ __forceinline__ void nms_flag_row(const NmsArgs &A, int r, int seg)
         }
         const float eL = (row_ok && c0 > 0) ? row[c0 * 64 - 1] : -FLT_MAX;
         const float eR = (row_ok && c0 + CB < A.chunks) ? row[(c0 + CB) * 64] : -FLT_MAX;
+        // The 26 strict comparisons of surf.cu:316-343 in FOUR stages -- same row, the two other rows of the layer, the layer below, the
+        // layer above -- STAGE-MAJOR over the group's chunks (round 5): a stage's loads of all four chunks are issued together and a
+        // stage is entered only while some lane of some chunk is still a candidate.  In-row maxima are common on a textured frame (one
+        // sample in five to ten), so chunk-major order -- the round-3 form -- made three to four dependent round trips PER CHUNK.
+        // margin >= 1 and 1 <= layer <= nlayers keep every neighbour inside the planes.
+        bool ismax[CB];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) {
+            const int j = (c0 + k) * 64 + lane;
+            ismax[k] = in[k] && v[k] > A.thr;
+            if (ismax[k] && A.mask.s) {
+                const int sum_i = (i - ((size >> 1) >> A.octave)) << A.octave, sum_j = (j - ((size >> 1) >> A.octave)) << A.octave;
+                ismax[k] = mask_check(A.mask, sum_i, sum_j, size);
+            }
+            // ctr[-1], ctr[1]: the neighbouring lanes' values; lane 0 / lane 63 take the previous / next chunk's edge lane (or eL / eR)
+            const float fromL = k > 0 ? __shfl(v[k > 0 ? k - 1 : 0], 63) : eL, fromR = k + 1 < CB ? __shfl(v[k + 1 < CB ? k + 1 : k], 0) : eR;
+            const float up = __shfl_up(v[k], 1), dn = __shfl_down(v[k], 1);
+            const float left = lane == 0 ? fromL : up, right = lane == 63 ? fromR : dn;
+            ismax[k] = ismax[k] && v[k] > left && v[k] > right;
+            any = any || ismax[k];
+        }
+        if (__ballot(any) != 0ull) {
+            // the two other rows of the layer: six values per candidate, all chunks' loads in flight together
+            float n[CB][6];
+#pragma unroll
+            for (int k = 0; k < CB; ++k)
+                if (ismax[k]) {
+                    const float *ctr = row + (c0 + k) * 64 + lane, *qa = ctr - A.dld, *qb = ctr + A.dld;
+                    n[k][0] = qa[-1]; n[k][1] = qa[0]; n[k][2] = qa[1]; n[k][3] = qb[-1]; n[k][4] = qb[0]; n[k][5] = qb[1];
+                }
+            any = false;
+#pragma unroll
+            for (int k = 0; k < CB; ++k) {
+                if (ismax[k]) ismax[k] = v[k] > n[k][0] && v[k] > n[k][1] && v[k] > n[k][2] && v[k] > n[k][3] && v[k] > n[k][4] && v[k] > n[k][5];
+                any = any || ismax[k];
+            }
+#pragma unroll
+            for (int dl = -1; dl <= 1; dl += 2) {   // the layer below, then the layer above: nine values per candidate
+                if (__ballot(any) == 0ull) break;
+                float q9[CB][9];
+#pragma unroll
+                for (int k = 0; k < CB; ++k)
+                    if (ismax[k]) {
+                        const float *ctr = row + (c0 + k) * 64 + lane;
+#pragma unroll
+                        for (int di = -1; di <= 1; ++di) {
+                            const float *q = ctr + (long long)(dl * layer_rows + di) * A.dld;
+                            q9[k][3 * (di + 1) + 0] = q[-1]; q9[k][3 * (di + 1) + 1] = q[0]; q9[k][3 * (di + 1) + 2] = q[1];
+                        }
+                    }
+                any = false;
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    if (ismax[k]) {
+                        bool m = true;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) m = m && v[k] > q9[k][e];
+                        ismax[k] = m;
+                    }
+                    any = any || ismax[k];
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < CB; ++k) {
             if (c0 + k >= cend) break;
-            const int j = (c0 + k) * 64 + lane;
-            // The 26 strict comparisons of surf.cu:316-343 in FOUR wave-uniform stages -- same row, the two other rows of the layer, the
-            // layer below, the layer above -- each entered only while some lane of the chunk is still a candidate.  On a textured
-            // frame most chunks hold values above the threshold (r06c) but in-plane maxima are rare: the first stage ends nearly
-            // every chunk, where the one-stage form issued all 26 loads for every chunk with one value above the threshold.
-            // margin >= 1 and 1 <= layer <= nlayers keep every neighbour inside the planes: nine row pointers, immediate column offsets.
-            bool ismax = in[k] && v[k] > A.thr;
-            if (ismax && A.mask.s) {
-                const int sum_i = (i - ((size >> 1) >> A.octave)) << A.octave, sum_j = (j - ((size >> 1) >> A.octave)) << A.octave;
-                ismax = mask_check(A.mask, sum_i, sum_j, size);
-            }
-            const float *ctr = row + j;
-            const float vk = v[k];
-            // ctr[-1], ctr[1]: the neighbouring lanes' values; lane 0 / lane 63 take the previous / next chunk's edge lane (or eL / eR)
-            const float fromL = k > 0 ? __shfl(v[k > 0 ? k - 1 : 0], 63) : eL, fromR = k + 1 < CB ? __shfl(v[k + 1 < CB ? k + 1 : k], 0) : eR;
-            const float up = __shfl_up(vk, 1), dn = __shfl_down(vk, 1);
-            const float left = lane == 0 ? fromL : up, right = lane == 63 ? fromR : dn;
-            if (__ballot(ismax) != 0ull) {
-                if (ismax) ismax = vk > left && vk > right;
-                if (__ballot(ismax) != 0ull) {
-                    if (ismax) {
-                        const float *qa = ctr - A.dld, *qb = ctr + A.dld;
-                        ismax = vk > qa[-1] && vk > qa[0] && vk > qa[1] && vk > qb[-1] && vk > qb[0] && vk > qb[1];
-                    }
-#pragma unroll
-                    for (int dl = -1; dl <= 1; dl += 2) {
-                        if (__ballot(ismax) == 0ull) break;
-                        if (ismax) {
-#pragma unroll
-                            for (int di = -1; di <= 1; ++di) {
-                                const float *q = ctr + (long long)(dl * layer_rows + di) * A.dld;
-                                ismax = ismax && vk > q[-1] && vk > q[0] && vk > q[1];
-                            }
-                        }
-                    }
-                }
-            }
-            const unsigned long long m = __ballot(ismax);
+            const unsigned long long m = __ballot(ismax[k]);
             if (lane == 0) A.bits[(long long)r * A.chunks + c0 + k] = m;
             cnt += __popcll(m);
         }
@@ -440,7 +467,17 @@ __device__ __forceinline__ void scan_counts_body(unsigned *cnt, const unsigned *
     const int per = (n + 1023) / 1024;
     const int b = threadIdx.x * per, e = min(b + per, n);
     const auto row_total = [&](int k) { unsigned c = 0; for (int q = 0; q < nseg; ++q) c += seg[(long long)k * nseg + q]; return c; };
+    // a thread's row totals are kept for the second pass when they fit (8 rows per thread: every frame up to 4096 rows x 2 layers);
+    // all their loads are issued before the first add (round 5: the two dependent passes over global memory were most of the launch)
+    constexpr int kKeep = 8;
+    unsigned keep[kKeep];
     unsigned s = 0;
+    if (per <= kKeep) {
+#pragma unroll
+        for (int q = 0; q < kKeep; ++q) keep[q] = (b + q < e) ? row_total(b + q) : 0u;
+#pragma unroll
+        for (int q = 0; q < kKeep; ++q) s += keep[q];
+    } else
     for (int k = b; k < e; ++k) s += row_total(k);
     part[threadIdx.x] = s;
     __syncthreads();
@@ -451,6 +488,10 @@ __device__ __forceinline__ void scan_counts_body(unsigned *cnt, const unsigned *
         __syncthreads();
     }
     unsigned run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+    if (per <= kKeep) {
+#pragma unroll
+        for (int q = 0; q < kKeep; ++q) if (b + q < e) { cnt[b + q] = run; run += keep[q]; }
+    } else
     for (int k = b; k < e; ++k) { const unsigned c = row_total(k); cnt[k] = run; run += c; }
     if (threadIdx.x == 1023) cnt[n] = part[1023];
 }
@@ -466,19 +507,32 @@ __device__ __forceinline__ void nms_write_row(const NmsArgs &A, int r, int4 *can
     if (r >= nrows) return;
     const int layer = r / layer_rows + 1, i = r % layer_rows;
     unsigned base = A.rowcnt[r];
-    for (int c = 0; c < A.chunks; ++c) {
-        const unsigned long long m = A.bits[(long long)r * A.chunks + c];
-        if (!m) continue;
-        if ((m >> lane) & 1ull) {
-            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            if (idx < (unsigned)max_candidates) {
-                const int j = c * 64 + lane;
-                const int lap = A.sbits ? (((A.sbits[(long long)r * A.chunks + c] >> lane) & 1ull) ? -1 : 1)
-                                        : (int)copysignf(1.0f, A.trace[(long long)(layer * layer_rows + i) * A.dld + j]);
-                cand[idx] = make_int4(j, i, layer, lap);
+    // 64 chunk words per trip: lane c holds word c0 + c, a wave-wide exclusive sum of the popcounts gives every word's first index, and
+    // only the non-empty words (few) are walked (round 5: the row's words were read one after the other, 60 dependent loads at 4K)
+    for (int c0 = 0; c0 < A.chunks; c0 += 64) {
+        const unsigned long long mine = (c0 + lane < A.chunks) ? A.bits[(long long)r * A.chunks + c0 + lane] : 0ull;
+        const unsigned pc = (unsigned)__popcll(mine);
+        unsigned incl = pc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const unsigned excl = incl - pc;
+        unsigned long long nz = __ballot(pc != 0u);
+        while (nz) {
+            const int cl = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            const unsigned long long m = __shfl(mine, cl);
+            const unsigned wbase = base + __shfl(excl, cl);
+            if ((m >> lane) & 1ull) {
+                const unsigned idx = wbase + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (idx < (unsigned)max_candidates) {
+                    const int c = c0 + cl, j = c * 64 + lane;
+                    const int lap = A.sbits ? (((A.sbits[(long long)r * A.chunks + c] >> lane) & 1ull) ? -1 : 1)
+                                            : (int)copysignf(1.0f, A.trace[(long long)(layer * layer_rows + i) * A.dld + j]);
+                    cand[idx] = make_int4(j, i, layer, lap);
+                }
             }
         }
-        base += (unsigned)__popcll(m);
+        base += __shfl(incl, 63);
     }
 }
 __global__ __launch_bounds__(256) void k_nms_write(NmsArgs A, int4 *cand, int max_candidates, unsigned *ncand)
