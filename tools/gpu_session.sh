@@ -186,6 +186,17 @@ for k, v in agg.items():
 PY
   tail -1 $O/pmc_sq.log | cut -c1-200
   find $O -type f -size +4M -delete ;;
+surf_counters)
+  # vector-L1 counters + kernel stats of the SURF frame -> profiles/surf_counters.json (tools/surf_counters.py)
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VMEM_RD SQ_INSTS_LDS -f csv -d $R/$O/pmc_surf_l1 -- python $R/bench.py --workload surf --no-cpu --steps 2 --warmup 1 > $R/$O/pmc_surf_l1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace_surf2 -- python $R/bench.py --workload surf --no-cpu --steps 3 --warmup 1 > $R/$O/trace_surf2.log 2>&1
+  cd $R
+  for f in $(find $O/trace_surf2 -name "*kernel_stats.csv" | head -1); do cp $f $O/kernel_stats_surf.csv; done
+  python tools/surf_counters.py $O/pmc_surf_l1 $O/kernel_stats_surf.csv "profiles/$NAME: rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VMEM_RD SQ_INSTS_LDS and --kernel-trace --stats of python bench.py --workload surf --no-cpu (per-launch means)" 2>&1 | tail -10
+  cp profiles/surf_counters.json $O/surf_counters.json
+  python tools/surf_timeline.py $O/trace_surf2 > $O/surf_timeline.txt 2>&1
+  find $O -type f -size +4M -delete ;;
 pmc_secondary)
   cd /tmp
   for wl in stereobm farneback surf; do for c in FETCH_SIZE WRITE_SIZE; do
