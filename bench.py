@@ -929,7 +929,7 @@ def compact_line(out, full_path=None):
             if isinstance(e, dict):
                 v = e.get("pairs_per_s", e.get("calcs_per_s"))
                 if v is not None:
-                    d[_s(name, 60)] = v
+                    d[_s(name, 50)] = v
                 for k2 in ("calcs_per_s_three_scenes_in_turn",):
                     if e.get(k2) is not None:
                         d[_s(name, 48) + ":3scenes"] = e[k2]
