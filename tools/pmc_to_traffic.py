@@ -39,7 +39,7 @@ def main():
 
     # the fixed-work T = 10 kernel: MODE 0 is the sixth template argument, the seventh (JW: 0 / 1 / 2 / 3) the wave arrangement
     import re
-    for key, pred in (("tbr", lambda k: re.search(r"k_iterate_tbr<10, 1, (true|false), \d+, \d+, 0(, \d+)?(, (true|false), (true|false))?>\(mi::tvl1::TbArgs\)", k) is not None),
+    for key, pred in (("tbr", lambda k: re.search(r"k_iterate_tbr<10, 1, (true|false), \d+, \d+, 0(, \d+)?(, (true|false), (true|false))?(, 0)?>\(mi::tvl1::TbArgs\)", k) is not None),
                       ("warp6", lambda k: "k_warp6<" in k), ("convert", lambda k: "k_convert" in k)):
         f, nf = mean(pred, "FETCH_SIZE")
         w, nw = mean(pred, "WRITE_SIZE")
