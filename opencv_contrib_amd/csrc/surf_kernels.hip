@@ -970,6 +970,9 @@ __device__ __forceinline__ float area_filter_lds(const unsigned char *tile, int 
     if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + T(sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
     return sat_u8(out);
 }
+#ifndef MI_SURF_ORI_WGS_PER_CU
+#define MI_SURF_ORI_WGS_PER_CU 8
+#endif
 #ifndef MI_SURF_DESC_WGS_PER_CU
 #define MI_SURF_DESC_WGS_PER_CU 16   // workgroups per CU of the descriptor launch when the feature count is on the device (r15c at 4K: 3 | 6 | 16 | 48 = 818 | 841 | 905 | 902 frames/s)
 #endif
@@ -1643,7 +1646,7 @@ int orientation(const unsigned *sum, int sld, int rows, int cols, float *kp, int
         hipLaunchKernelGGL(k_fill_angle, dim3(div_up(n_or_max, 256)), dim3(256), 0, s, kp, kld, nfeat_dev, n_or_max, 360.0f - 90.0f);
     } else {
         SumTex t = {sum, sld, rows, cols};
-        const int grid = nfeat_dev ? std::min(div_up(n_or_max, 4), 8 * (device_simds() / 4)) : div_up(n_or_max, 4);
+        const int grid = nfeat_dev ? std::min(div_up(n_or_max, 4), MI_SURF_ORI_WGS_PER_CU * (device_simds() / 4)) : div_up(n_or_max, 4);
         hipLaunchKernelGGL(k_orientation, dim3(grid), dim3(256), 0, s, t, kp, kld, nfeat_dev, n_or_max, apt);
     }
     MI_HIP_TRY(hipGetLastError());
