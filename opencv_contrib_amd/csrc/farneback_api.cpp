@@ -245,6 +245,20 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
 
     // flowx0/flowy0 (level-0 flow planes; also the caller's initial flow)
     float *fx0 = h->flow[0][0], *fy0 = h->flow[0][1];
+    if (B > 1) {   // one launch per 64 pairs (blockIdx.z = pair) instead of one per pair
+        for (int b0 = 0; b0 < B; b0 += kFmtPairs) {
+            const int nb = std::min(kFmtPairs, B - b0);
+            FmtTab T;
+            memset(&T, 0, sizeof(T));
+            for (int j = 0; j < nb; ++j) {
+                T.a[j] = I0s[b0 + j].data; T.sa[j] = (long long)I0s[b0 + j].step;
+                T.b[j] = I1s[b0 + j].data; T.sb[j] = (long long)I1s[b0 + j].step;
+            }
+            if ((rc = convert_batch(T, nb, I0s[0].type, h->frames[0] + b0 * bs, h->frames[1] + b0 * bs, bs, g0s, st))) return rc;
+        }
+        for (int b = 0; b < B && use_init; ++b)
+            if ((rc = split_flow(flows[b].data, (long long)flows[b].step, fx0 + b * bs, fy0 + b * bs, g0s, st))) return rc;
+    } else
     for (int b = 0; b < B; ++b) {
         if ((rc = convert(I0s[b].data, (long long)I0s[b].step, I1s[b].data, (long long)I1s[b].step, I0s[b].type, h->frames[0] + b * bs,
                           h->frames[1] + b * bs, g0s, st))) return rc;
@@ -386,10 +400,26 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         if (async) MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_level[k], 0));
         else if ((rc = pyramid_stage(k, st))) return rc;
         const float *R0 = lv[k].R0, *R1 = lv[k].R0 + lv[k].fsR;
-        float *M = h->M, *bufM = h->bufM;
+        // Pair GROUPS (round 5).  An iteration of a level streams 22 planes per pair (M in and out, both expansions, the flow); with the
+        // whole batch per launch a 640 x 480 level of 32 pairs is 0.9 GB per iteration -- every iteration comes from HBM.  Run group by
+        // group instead: the matrix update and ALL iterations of a few pairs whose planes fit the 256 MB last-level cache, then the next
+        // group.  The same launches on the same data in the same order per pair: bit-identical.  Small calls (one launch chain per
+        // level, few-launch forms) keep the whole batch.
+        int G = B;
+        if (B > 1 && !fuse_small && tuning().fb_group_mb > 0) {
+            const long long per_pair = 22LL * (long long)g.ld * g.h * (long long)sizeof(float);
+            G = (int)std::max(1LL, std::min((long long)B, ((long long)tuning().fb_group_mb << 20) / per_pair));
+        }
+        for (int b0 = 0; b0 < B; b0 += G) {
+        const long long goff = (long long)b0 * bs;
+        Plane gg = g;
+        gg.batch = std::min(G, B - b0);
+        float *M = h->M + goff, *bufM = h->bufM + goff;
+        float *gx = curx + goff, *gy = cury + goff;
+        const float *gR0 = R0 + goff, *gR1 = R1 + goff;
         if (prevx && fuse_small && !(gprev.w == g.w && gprev.h == g.h)) {   // the zoom of the coarser flow inside the first matrix update
             if ((rc = update_matrices_resized(prevx, prevy, gprev, (float)(1. / P.pyr_scale), curx, cury, R0, R1, M, g, st))) return rc;
-        } else if ((rc = update_matrices(curx, cury, R0, R1, M, g, st))) return rc;   // :458
+        } else if ((rc = update_matrices(gx, gy, gR0, gR1, M, gg, st))) return rc;   // :458
         // levels whose 64 x 4 grid underfills the device: two iterations per launch (MIFLOW_FB_PAIR=0 / 1 forces the choice)
         const bool pair_it = fuse_small && iterate2_supported(P.win_size) &&
                              (tuning().fb_pair >= 0 ? tuning().fb_pair != 0 : (long long)div_up(g.w, 64) * div_up(g.h, 4) * B <= 2LL * (device_simds() / 4));
@@ -397,7 +427,7 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
             if (pair_it && i + 1 < P.num_iters) {
                 const bool last2 = k == 0 && i + 1 == P.num_iters - 1 && B == 1;
                 bool dm2 = false;
-                if ((rc = iterate2(M, R0, R1, curx, cury, bufM, g, P.win_size, gauss ? &wk : nullptr, i + 1 < P.num_iters - 1, st,
+                if ((rc = iterate2(M, gR0, gR1, gx, gy, bufM, gg, P.win_size, gauss ? &wk : nullptr, i + 1 < P.num_iters - 1, st,
                                    last2 ? flows[0].data : nullptr, last2 ? (long long)flows[0].step : 0, &dm2))) return rc;
                 merged = merged || dm2;
                 std::swap(M, bufM);
@@ -406,14 +436,25 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
             }
             const bool last = k == 0 && i == P.num_iters - 1 && B == 1 && fuse_small;
             bool dm = false;
-            if ((rc = iterate(M, R0, R1, curx, cury, bufM, g, P.win_size, gauss ? &wk : nullptr, i < P.num_iters - 1, st,
+            if ((rc = iterate(M, gR0, gR1, gx, gy, bufM, gg, P.win_size, gauss ? &wk : nullptr, i < P.num_iters - 1, st,
                               last ? flows[0].data : nullptr, last ? (long long)flows[0].step : 0, &dm))) return rc;
             merged = merged || dm;
             std::swap(M, bufM);
         }
+        }
         prevx = curx; prevy = cury; gprev = g;
     }
     if (merged) return MI_OK;
+    if (B > 1) {
+        for (int b0 = 0; b0 < B; b0 += kFmtPairs) {
+            const int nb = std::min(kFmtPairs, B - b0);
+            FmtTab T;
+            memset(&T, 0, sizeof(T));
+            for (int j = 0; j < nb; ++j) { T.a[j] = flows[b0 + j].data; T.sa[j] = (long long)flows[b0 + j].step; }
+            if ((rc = merge_flow_batch(fx0 + b0 * bs, fy0 + b0 * bs, T, nb, bs, g0s, st))) return rc;   // cuda::merge :197-198
+        }
+        return MI_OK;
+    }
     for (int b = 0; b < B; ++b)
         if ((rc = merge_flow(fx0 + b * bs, fy0 + b * bs, flows[b].data, (long long)flows[b].step, g0s, st))) return rc;   // cuda::merge :197-198
     return MI_OK;

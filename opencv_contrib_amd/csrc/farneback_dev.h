@@ -18,6 +18,11 @@ struct PolyC { float g[8], xg[8], xxg[8]; float ig11, ig03, ig33, ig55; };
 
 inline Plane plane_of(int w, int h, long long bs = 0, int batch = 1) { Plane p; p.w = w; p.h = h; p.ld = align_up(w, 64); p.bs = bs; p.batch = batch; return p; }
 
+// by-value table of the caller's matrices for the batched format steps (blockIdx.z = pair)
+constexpr int kFmtPairs = 64;
+struct FmtTab { const void *a[kFmtPairs], *b[kFmtPairs]; long long sa[kFmtPairs], sb[kFmtPairs]; };
+int convert_batch(const FmtTab &T, int n, int type, float *A, float *B, long long bs, const Plane &g, hipStream_t s);   // A, B: pair 0's planes
+int merge_flow_batch(const float *fx, const float *fy, const FmtTab &T, int n, long long bs, const Plane &g, hipStream_t s);   // T.a / T.sa: the flow matrices
 int convert(const void *a, long long sa, const void *b, long long sb, int type, float *A, float *B, const Plane &g, hipStream_t s);
 int split_flow(const void *flow, long long sf, float *fx, float *fy, const Plane &g, hipStream_t s);
 int merge_flow(const float *fx, const float *fy, void *flow, long long sf, const Plane &g, hipStream_t s);

@@ -550,6 +550,51 @@ __global__ __launch_bounds__(256) void k_pyr_down(const float *src, int sw, int 
 // ------------------------------------------------------------------ host launchers
 static inline dim3 grid2d(int w, int h) { return dim3(div_up(w, 64), div_up(h, 4)); }
 
+// ---- the per-pair format steps of a BATCH in one launch each (round 5: a 32-pair batch spent 64 launches of ~5 us on them, 7 % of its
+// time): blockIdx.z = pair, the caller's matrices arrive as a by-value table of up to kFmtPairs entries per launch
+__global__ __launch_bounds__(256) void k_convert_batch(FmtTab T, int type, float *A, float *B, long long bs, int w, int h, int ld)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int p = blockIdx.z;
+    const void *a = T.a[p], *b = T.b[p];
+    const long long sa = T.sa[p], sb = T.sb[p];
+    const long long o = (long long)p * bs + (long long)y * ld + x;
+    if (type == MI_8UC1) {   // convertTo(CV_32F), farneback.cpp:342-345 (no scaling)
+        A[o] = (float)((const unsigned char *)a)[(long long)y * sa + x];
+        B[o] = (float)((const unsigned char *)b)[(long long)y * sb + x];
+    } else {
+        A[o] = ((const float *)((const char *)a + (long long)y * sa))[x];
+        B[o] = ((const float *)((const char *)b + (long long)y * sb))[x];
+    }
+}
+__global__ __launch_bounds__(256) void k_merge_flow_batch(const float *fx, const float *fy, FmtTab T, long long bs, int w, int h, int ld)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int p = blockIdx.z;
+    const long long o = (long long)p * bs + (long long)y * ld + x;
+    ((float2 *)((char *)const_cast<void *>(T.a[p]) + (long long)y * T.sa[p]))[x] = make_float2(fx[o], fy[o]);   // cuda::merge, farneback.cpp:197-198
+}
+int convert_batch(const FmtTab &T, int n, int type, float *A, float *B, long long bs, const Plane &g, hipStream_t s)
+{
+    dim3 grid = grid2d(g.w, g.h);
+    grid.z = n;
+    hipLaunchKernelGGL(k_convert_batch, grid, dim3(256), 0, s, T, type, A, B, bs, g.w, g.h, g.ld);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+int merge_flow_batch(const float *fx, const float *fy, const FmtTab &T, int n, long long bs, const Plane &g, hipStream_t s)
+{
+    dim3 grid = grid2d(g.w, g.h);
+    grid.z = n;
+    hipLaunchKernelGGL(k_merge_flow_batch, grid, dim3(256), 0, s, fx, fy, T, bs, g.w, g.h, g.ld);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 int convert(const void *a, long long sa, const void *b, long long sb, int type, float *A, float *B, const Plane &g, hipStream_t s)
 {
     hipLaunchKernelGGL(k_convert, grid2d(g.w, g.h), dim3(256), 0, s, a, sa, b, sb, type, A, B, g.w, g.h, g.ld);

@@ -78,6 +78,7 @@ const Tuning &tuning()
         t.sbm_texfuse = EXP_INT("MIFLOW_SBM_TEXFUSE", 1);
         t.fb_rows = EXP_INT("MIFLOW_FB_ROWS", 4) == 8 ? 8 : 4;
         t.fb_async = EXP_INT("MIFLOW_FB_ASYNC", 0);   // r08i: the cross-stream events cost more than the 9 launches they take off the chain (2 718 vs 3 089 calc/s)
+        t.fb_group_mb = env_int("MIFLOW_FB_GROUP_MB", 200);   // r15j / r15k at 640 x 480 x 32 pairs: 0 | 48 | 96 | 160 | 200 | 240 | 320 | 480 MB = 7 190 | 6 100 | 7 110 | 7 400-7 560 | 7 755 | 7 540 | 7 185 | 7 005 pairs/s
         t.fb_fuse = env_int("MIFLOW_FB_FUSE", -1);
         t.fb_pair = env_int("MIFLOW_FB_PAIR", -1);
         t.fb_narrow = env_int("MIFLOW_FB_NARROW", -1);

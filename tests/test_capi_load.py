@@ -20,7 +20,7 @@ def test_exports_every_declared_symbol():
     assert not missing, f"declared in c_api.h but not exported: {missing}"
 
 
-RELEASE_SWITCHES = {"MIFLOW_BF_W", "MIFLOW_CACHE_GB", "MIFLOW_CACHE_TOTAL_GB", "MIFLOW_FB_FUSE", "MIFLOW_FB_NARROW", "MIFLOW_FB_PAIR",
+RELEASE_SWITCHES = {"MIFLOW_BF_W", "MIFLOW_CACHE_GB", "MIFLOW_CACHE_TOTAL_GB", "MIFLOW_FB_FUSE", "MIFLOW_FB_GROUP_MB", "MIFLOW_FB_NARROW", "MIFLOW_FB_PAIR",
                     "MIFLOW_LANES", "MIFLOW_MULTI_RCCL", "MIFLOW_SURF_NMS0", "MIFLOW_SURF_POLY", "MIFLOW_SURF_STAGE_S", "MIFLOW_TB_FW", "MIFLOW_TB_HIST", "MIFLOW_TB_JW", "MIFLOW_TB_VERBOSE", "MIFLOW_TILE_MAXPX"}
 
 

@@ -276,6 +276,31 @@ def test_calc_batch_equals_single_calcs(gpu, oracle, kw):
     assert torch.equal(again[1], singles[1])
 
 
+@gpu_mark
+@pytest.mark.parametrize("kw", [dict(), dict(flags=4, fastPyramids=True)], ids=["defaults", "initial_flow_fast_pyramids"])
+def test_large_batch_runs_in_cache_sized_groups_and_equals_single_calcs(gpu, kw):
+    """Round 5: a large batch walks the level loop in groups of pairs whose planes fit the last-level cache (MIFLOW_FB_GROUP_MB,
+    farneback_api.cpp calc) and converts / merges 64 pairs per launch.  70 pairs of 240 x 320 are three groups with a ragged last one
+    and two convert launches with a ragged second one: every pair still equals its single calc() bit for bit."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(240, 320, seed=80 + k, dtype="u8")[:2] for k in range(5)]
+    I0s, I1s = [T(p[0], gpu) for p in pairs], [T(p[1], gpu) for p in pairs]
+    alg, one = cuda.FarnebackOpticalFlow.create(**kw), cuda.FarnebackOpticalFlow.create(**kw)
+    B, flows = 70, None
+    if kw.get("flags", 0) & 4:
+        rng = np.random.default_rng(5)
+        init = [torch.from_numpy((rng.standard_normal((240, 320, 2)) * 0.5).astype(np.float32)).to(gpu) for _ in range(5)]
+        flows = torch.stack([init[k % 5] for k in range(B)]).clone()
+        singles = [one.calc(I0s[k], I1s[k], init[k].clone()).clone() for k in range(5)]
+    else:
+        singles = [one.calc(I0s[k], I1s[k]).clone() for k in range(5)]
+    out = alg.calc_batch([I0s[k % 5] for k in range(B)], [I1s[k % 5] for k in range(B)], flows)
+    torch.cuda.synchronize()
+    for k in range(B):
+        assert torch.equal(out[k], singles[k % 5]), f"pair {k}"
+
+
 def _random_fb_configs():
     rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "7702")))
     out = []
