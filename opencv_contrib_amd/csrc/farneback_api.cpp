@@ -387,7 +387,9 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
                 if (k > 0 && (rc = resize2(fx0, fy0, g0, curx, cury, g, (float)scale, st))) return rc;
             } else {
                 const size_t bytes = sizeof(float) * (size_t)g.ld * g.h;
-                if (cury == curx + pn && bytes <= sizeof(float) * (size_t)pn) {   // the two planes are neighbours in the arena: one fill
+                // the two planes are neighbours in the arena: one fill over both and the gap between them while that gap is small (a single
+                // pair: one launch less); a batch would clear B full-size planes for two coarse ones (r16d: 57 us of a 32-pair calc)
+                if (cury == curx + pn && bytes <= sizeof(float) * (size_t)pn && sizeof(float) * (size_t)pn * B <= (8u << 20)) {
                     MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, sizeof(float) * (size_t)pn + bytes, (size_t)B, st));
                 } else {
                     MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
@@ -409,6 +411,7 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         if (B > 1 && !fuse_small && tuning().fb_group_mb > 0) {
             const long long per_pair = 22LL * (long long)g.ld * g.h * (long long)sizeof(float);
             G = (int)std::max(1LL, std::min((long long)B, ((long long)tuning().fb_group_mb << 20) / per_pair));
+            if ((long long)B * 8 <= (long long)G * 9) G = B;   // no one- or two-pair tail group for a budget missed by an eighth (r16g: 31 + 1 pairs at 320 x 240)
         }
         for (int b0 = 0; b0 < B; b0 += G) {
         const long long goff = (long long)b0 * bs;

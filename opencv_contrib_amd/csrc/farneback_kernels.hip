@@ -110,6 +110,53 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *
     }
 }
 
+// The same blur, tiled (round 5), for compile-time half sizes: a workgroup owns RB rows x 256 columns.  The one-row kernel above
+// fetches the 2 kh + 1 rows of a column per OUTPUT row, a chain of dependent loads for 256 outputs per workgroup: 147 us per 64 planes
+// of 640 x 480 whatever the kernel size, against ~35 us of plane traffic.  Here a thread loads the RB + 2 KH rows of its column ONCE,
+// all in flight together (RB in 8..14 so that RB + 2 KH is a multiple of eight), forms the RB vertical sums from registers and
+// leaves them in the LDS for the horizontal pass; the 2 KH columns beside the tile are a second, short round of wave 0.  Rows and
+// columns go through the border rule when they are loaded and the sums are formed in the same order: bit-identical planes.
+template <int KH> struct BlurTile { static constexpr int RB = (2 * KH) % 8 ? 16 - (2 * KH) % 8 : 8; };
+template <int BORDER, int KH>
+__global__ __launch_bounds__(256) void k_gaussian_blur_t(const float *src, float *dst, int w, int h, int ld, Taps K, long long bs, int nf, long long fs)
+{
+    constexpr int RB = BlurTile<KH>::RB, W2 = 256 + 2 * KH, NL = RB + 2 * KH;
+    __shared__ float vs[RB][W2];
+    { const long long o = (long long)(blockIdx.z / nf) * bs + (long long)(blockIdx.z % nf) * fs; src += o; dst += o; }
+    const int tx = threadIdx.x, y0 = blockIdx.y * RB, x0 = blockIdx.x * 256;
+    float k[KH + 1];
+#pragma unroll
+    for (int j = 0; j <= KH; ++j) k[j] = K.k[j];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int i = tx + 256 * pass;
+        if (i >= W2) break;
+        const float *P = src + gidx<BORDER, true>(min(x0 + i - KH, w - 1 + KH), w);
+        float c[NL];
+#pragma unroll
+        for (int r = 0; r < NL; ++r) c[r] = P[(long long)gidx<BORDER, true>(min(y0 - KH + r, h - 1 + KH), h) * ld];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            float v = c[r + KH] * k[0];
+#pragma unroll
+            for (int j = 1; j <= KH; ++j) v += (c[r + KH - j] + c[r + KH + j]) * k[j];
+            vs[r][i] = v;
+        }
+    }
+    __syncthreads();
+    const int x = x0 + tx;
+    if (x >= w) return;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        if (y0 + r >= h) break;
+        const float *q = &vs[r][tx + KH];
+        float res = q[0] * k[0];
+#pragma unroll
+        for (int i = 1; i <= KH; ++i) res += (q[-i] + q[i]) * k[i];
+        dst[(long long)(y0 + r) * ld + x] = res;
+    }
+}
+
 // ------------------------------------------------------------------ polynomial expansion
 // farneback.cu:66-119: vertical pass (g, xg, xxg) into 3 LDS rows, horizontal pass -> 5 coefficient planes.
 // RS: `src` is the FULL-SIZE blurred frame (sw x sh, pitch sld) and the level image the expansion reads is its cuda::resize
@@ -175,34 +222,53 @@ __device__ __forceinline__ float border_w(int d)
     return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f);
 }
 
-__device__ __forceinline__ void update_matrices_vals(int x, int y, int w, int h, int ld, float dx, float dy, const float *R0,
-                                                     const float *R1, float (&m)[5])
+// The per-pixel update in two steps so that a caller can put the loads of SEVERAL pixels in flight before it uses any of them (round 5:
+// a thread of the tiled iteration walked its four rows one after the other, each with three dependent round trips -- three planes of R0,
+// the gather, two more planes of R0).  um_load issues the 5 + 20 loads of a pixel unconditionally: the 2 x 2 window's origin is clamped
+// into the plane, so the addresses are valid whether the displaced position is inside (then they are the reference's) or not (then the
+// values are not used).  um_finish is the arithmetic of farneback.cu:176-239 on those values, operation for operation.
+struct UmTaps { float r0[5], p00[5], p01[5], p10[5], p11[5]; };
+__device__ __forceinline__ void um_load(int x, int y, int w, int h, int ld, float dx, float dy, const float *R0, const float *R1, UmTaps &T)
 {
     const long long ps = (long long)ld * h;
+    const int x1 = (int)floorf(x + dx), y1 = (int)floorf(y + dy);
+    // column + 1 of a one-column plane stays inside its row (ld is a multiple of 64, plane_of); row + 1 of a one-row plane would not.
+    // The two columns of a window row are adjacent words: one 8-byte load, half the L1 tag lookups of two.
+    const long long oy = h > 1 ? ld : 0;
+    const float *P = R1 + (long long)clampi(y1, 0, max(h - 2, 0)) * ld + clampi(x1, 0, max(w - 2, 0));
+    const float *Q = R0 + (long long)y * ld + x;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float *Pb = P + oy;
+        T.p00[k] = P[0]; T.p01[k] = P[1]; T.p10[k] = Pb[0]; T.p11[k] = Pb[1];
+        T.r0[k] = Q[0];
+        P += ps; Q += ps;
+    }
+}
+__device__ __forceinline__ void um_finish(int x, int y, int w, int h, float dx, float dy, const UmTaps &T, float (&m)[5])
+{
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= x1; fy -= y1;
-    const long long o = (long long)y * ld + x;
     float r2, r3, r4, r5, r6;
     if (x1 >= 0 && y1 >= 0 && x1 < w - 1 && y1 < h - 1) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float *P = R1 + (long long)y1 * ld + x1;
-        r2 = a00 * P[0] + a01 * P[1] + a10 * P[ld] + a11 * P[ld + 1]; P += ps;
-        r3 = a00 * P[0] + a01 * P[1] + a10 * P[ld] + a11 * P[ld + 1]; P += ps;
-        r4 = a00 * P[0] + a01 * P[1] + a10 * P[ld] + a11 * P[ld + 1]; P += ps;
-        r5 = a00 * P[0] + a01 * P[1] + a10 * P[ld] + a11 * P[ld + 1]; P += ps;
-        r6 = a00 * P[0] + a01 * P[1] + a10 * P[ld] + a11 * P[ld + 1];
-        r4 = (R0[2 * ps + o] + r4) * 0.5f;
-        r5 = (R0[3 * ps + o] + r5) * 0.5f;
-        r6 = (R0[4 * ps + o] + r6) * 0.25f;
+        r2 = a00 * T.p00[0] + a01 * T.p01[0] + a10 * T.p10[0] + a11 * T.p11[0];
+        r3 = a00 * T.p00[1] + a01 * T.p01[1] + a10 * T.p10[1] + a11 * T.p11[1];
+        r4 = a00 * T.p00[2] + a01 * T.p01[2] + a10 * T.p10[2] + a11 * T.p11[2];
+        r5 = a00 * T.p00[3] + a01 * T.p01[3] + a10 * T.p10[3] + a11 * T.p11[3];
+        r6 = a00 * T.p00[4] + a01 * T.p01[4] + a10 * T.p10[4] + a11 * T.p11[4];
+        r4 = (T.r0[2] + r4) * 0.5f;
+        r5 = (T.r0[3] + r5) * 0.5f;
+        r6 = (T.r0[4] + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[2 * ps + o];
-        r5 = R0[3 * ps + o];
-        r6 = R0[4 * ps + o] * 0.5f;
+        r4 = T.r0[2];
+        r5 = T.r0[3];
+        r6 = T.r0[4] * 0.5f;
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[ps + o] - r3) * 0.5f;
+    r2 = (T.r0[0] - r2) * 0.5f;
+    r3 = (T.r0[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     const float scale = border_w(min(x, 5)) * border_w(min(y, 5)) * border_w(min(w - x - 1, 5)) * border_w(min(h - y - 1, 5));
@@ -212,6 +278,13 @@ __device__ __forceinline__ void update_matrices_vals(int x, int y, int w, int h,
     m[2] = r5 * r5 + r6 * r6;
     m[3] = r4 * r2 + r6 * r3;
     m[4] = r6 * r2 + r5 * r3;
+}
+__device__ __forceinline__ void update_matrices_vals(int x, int y, int w, int h, int ld, float dx, float dy, const float *R0,
+                                                     const float *R1, float (&m)[5])
+{
+    UmTaps T;
+    um_load(x, y, w, h, ld, dx, dy, R0, R1, T);
+    um_finish(x, y, w, h, dx, dy, T, m);
 }
 __device__ __forceinline__ void update_matrices_px(int x, int y, int w, int h, int ld, float dx, float dy, const float *R0,
                                                    const float *R1, float *M)
@@ -293,6 +366,12 @@ __global__ __launch_bounds__(256) void k_iterate(const float *M, const float *R0
 // costs its LATENCY, not its work: the vertical pass is 2 rounds of independent loads instead of 6 and the horizontal pass + flow
 // solve + matrix update run once per thread instead of four times in a row (r08h: 9-10 us per launch whatever the level size).
 // The sums are formed in the same order: bit-identical planes.
+#ifndef MI_FB_VB
+#define MI_FB_VB 2   // rounds of the vertical pass in flight together
+#endif
+#ifndef MI_FB_UB
+#define MI_FB_UB 2   // rows of a thread whose matrix-update loads are in flight together
+#endif
 template <bool GAUSS, int KH, int R, int TW = 256>
 __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *R0, const float *R1, float *flowx, float *flowy,
                                                    float *Mout, int w, int h, int ld, float boxAreaInv, int update, Taps K, long long bs, int swz,
@@ -318,31 +397,47 @@ __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *
     }
     const int tx = threadIdx.x, y0 = by * R, x = bx * TW + (TW == 256 ? tx : tx % TW);
     const long long ps = (long long)ld * h;
-    for (int t = tx; t < 5 * SMW; t += 256) {
-        const int k = t / SMW, i = t - k * SMW;
-        const int xe = clampi(bx * TW + i - KH, 0, w - 1);
-        const float *P = M + k * ps + xe;
-        float c[R + 2 * KH];
+    // vertical pass: the (column, plane) tasks in rounds of 256, VB rounds' loads in flight together (round 5: the rounds used to wait for
+    // each other, six dependent round trips per 256-column tile).  A thread past the last task repeats it (same value to the same LDS word).
+    constexpr int NT = 5 * SMW, NRND = (NT + 255) / 256, VB = MI_FB_VB < NRND ? MI_FB_VB : NRND;
 #pragma unroll
-        for (int r = 0; r < R + 2 * KH; ++r) c[r] = P[(long long)clampi(y0 + r - KH, 0, h - 1) * ld];
+    for (int q0 = 0; q0 < NRND; q0 += VB) {
+        float c[VB][R + 2 * KH];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float v = GAUSS ? c[r + KH] * K.k[0] : c[r + KH];
+        for (int v = 0; v < VB; ++v) {
+            if (q0 + v >= NRND) break;
+            const int t = min(tx + 256 * (q0 + v), NT - 1);
+            const int k = t / SMW, i = t - k * SMW;
+            const float *P = M + k * ps + clampi(bx * TW + i - KH, 0, w - 1);
 #pragma unroll
-            for (int j = 1; j <= KH; ++j) {
-                const float sj = c[r + KH - j] + c[r + KH + j];
-                v += GAUSS ? sj * K.k[j] : sj;
+            for (int r = 0; r < R + 2 * KH; ++r) c[v][r] = P[(long long)clampi(y0 + r - KH, 0, h - 1) * ld];
+        }
+#pragma unroll
+        for (int v = 0; v < VB; ++v) {
+            if (q0 + v >= NRND) break;
+            const int t = min(tx + 256 * (q0 + v), NT - 1);   // (a conditional store would pull this round's loads into the branch, behind the others)
+            const int k = t / SMW, i = t - k * SMW;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float u = GAUSS ? c[v][r + KH] * K.k[0] : c[v][r + KH];
+#pragma unroll
+                for (int j = 1; j <= KH; ++j) {
+                    const float sj = c[v][r + KH - j] + c[v][r + KH + j];
+                    u += GAUSS ? sj * K.k[j] : sj;
+                }
+                smem[k][r][i] = u;
             }
-            smem[k][r][i] = v;
         }
     }
     __syncthreads();
     if (x >= w) return;
+    // horizontal pass + 2 x 2 solve of every row of the thread, then the matrix update of those rows with all their loads in flight together
+    constexpr int NR = TW == 256 ? R : 1;
+    float fxs[NR], fys[NR];
 #pragma unroll
-    for (int rr = 0; rr < (TW == 256 ? R : 1); ++rr) {
+    for (int rr = 0; rr < NR; ++rr) {
         const int r = TW == 256 ? rr : tx / TW;
         const int y = y0 + r;
-        if (y >= h) break;
         float res[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -356,12 +451,37 @@ __global__ __launch_bounds__(256) void k_iterate_t(const float *M, const float *
         const float detInv = 1.f / (g11 * g22 - g12 * g12 + 1e-3f);
         const float fx = (g11 * h2 - g12 * h1) * detInv;
         const float fy = (g22 * h1 - g12 * h2) * detInv;
-        const long long o = (long long)y * ld + x;
-        flowx[o] = fx;
-        flowy[o] = fy;
-        // the last iteration of the finest level of a single pair also writes the caller's CV_32FC2 flow (cuda::merge, farneback.cpp:197-198)
-        if (merged) ((float2 *)((char *)merged + (long long)y * merged_step))[x] = make_float2(fx, fy);
-        if (update) update_matrices_px(x, y, w, h, ld, fx, fy, R0, R1, Mout);
+        fxs[rr] = fx; fys[rr] = fy;
+        if (y < h) {
+            const long long o = (long long)y * ld + x;
+            flowx[o] = fx;
+            flowy[o] = fy;
+            // the last iteration of the finest level of a single pair also writes the caller's CV_32FC2 flow (cuda::merge, farneback.cpp:197-198)
+            if (merged) ((float2 *)((char *)merged + (long long)y * merged_step))[x] = make_float2(fx, fy);
+        }
+    }
+    if (!update) return;
+    constexpr int UB = MI_FB_UB < NR ? MI_FB_UB : NR;   // rows whose gathers are in flight together
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += UB) {
+        UmTaps T[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (r0 + u >= NR) break;
+            const int y = min(y0 + (TW == 256 ? r0 + u : tx / TW), h - 1);   // a row past the image (last tile) loads the last row's and stores nothing
+            um_load(x, y, w, h, ld, fxs[r0 + u], fys[r0 + u], R0, R1, T[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (r0 + u >= NR) break;
+            const int y = y0 + (TW == 256 ? r0 + u : tx / TW);
+            if (y >= h) continue;
+            float m[5];
+            um_finish(x, y, w, h, fxs[r0 + u], fys[r0 + u], T[u], m);
+            const long long o = (long long)y * ld + x;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) Mout[k * ps + o] = m[k];
+        }
     }
 }
 
@@ -620,12 +740,19 @@ int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Ta
     const dim3 grid(div_up(g.w, 256), g.h, g.batch * nf);
     const size_t lds = sizeof(float) * (256 + 2 * kh);
     const bool fast = kh < g.w && kh < g.h && g.w >= 2 && g.h >= 2;
-    if (border == MI_BORDER_REFLECT101) {
+    if (border != MI_BORDER_REFLECT101 && border != MI_BORDER_REPLICATE) { set_error("unsupported border mode %d", border); return MI_ERR_BAD_ARG; }   // farneback.cu:510-517: only these two
+    // tiled form for the half sizes the pyramid of pyrScale 0.5 (1, 1, 4, 9, 19) and its neighbours use
+    if (fast && tuning().fb_blur_tiled && (kh == 1 || kh == 2 || kh == 3 || kh == 4 || kh == 9 || kh == 19)) {
+#define MI_FB_BLUR(KH) case KH: { const dim3 tg(div_up(g.w, 256), div_up(g.h, BlurTile<KH>::RB), g.batch * nf);                                  \
+        if (border == MI_BORDER_REFLECT101) hipLaunchKernelGGL((k_gaussian_blur_t<MI_BORDER_REFLECT101, KH>), tg, dim3(256), 0, s, src, dst, g.w, g.h, g.ld, K, g.bs, nf, fs); \
+        else hipLaunchKernelGGL((k_gaussian_blur_t<MI_BORDER_REPLICATE, KH>), tg, dim3(256), 0, s, src, dst, g.w, g.h, g.ld, K, g.bs, nf, fs); } break;
+        switch (kh) { MI_FB_BLUR(1) MI_FB_BLUR(2) MI_FB_BLUR(3) MI_FB_BLUR(4) MI_FB_BLUR(9) MI_FB_BLUR(19) }
+#undef MI_FB_BLUR
+    } else if (border == MI_BORDER_REFLECT101) {
         if (fast) hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
         else hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, false>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
-    } else if (border == MI_BORDER_REPLICATE)
+    } else
         hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REPLICATE, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
-    else { set_error("unsupported border mode %d", border); return MI_ERR_BAD_ARG; }   // farneback.cu:510-517: only these two
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

@@ -83,6 +83,7 @@ const Tuning &tuning()
         t.fb_pair = env_int("MIFLOW_FB_PAIR", -1);
         t.fb_narrow = env_int("MIFLOW_FB_NARROW", -1);
         t.fb_swz = EXP_INT("MIFLOW_FB_SWZ", 1);
+        t.fb_blur_tiled = EXP_INT("MIFLOW_FB_BLUR_TILED", 1);   // r16e: pyramid pre-blur on 8-14 row tiles from the LDS (0: one row per workgroup)
     });
     return g_tuning;
 }
