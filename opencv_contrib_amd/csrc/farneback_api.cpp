@@ -94,7 +94,7 @@ struct mi_farneback {
     float *Rall = nullptr;
     long long Rall_floats = 0;
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_level;
 };
 
@@ -159,6 +159,7 @@ void mi_farneback_destroy(mi_farneback *h)
     if (h->arena) (void)hipFree(h->arena);
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t e : h->ev_level) (void)hipEventDestroy(e);
     delete h;
 }
@@ -335,10 +336,14 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
     const bool fuse_small = tuning().fb_fuse >= 0 ? tuning().fb_fuse != 0 : (long long)W * H * B <= 1500000;
     // blur + resize + polynomial expansion of BOTH frames for level k (the reference's loop over the two frames, farneback.cpp:434-454,
     // each stage once for both: 3 launches instead of 6)
-    auto pyramid_stage = [&](int k, hipStream_t sx) -> int {
-        const Plane &g = lv[k].g;
+    // (pairs b0 .. b0 + nb - 1 of the batch: a pair group of the level loop below runs its own stage, so that the expansions it is
+    // about to iterate on are still in the last-level cache)
+    auto pyramid_stage = [&](int k, hipStream_t sx, int b0, int nb) -> int {
+        const long long po = (long long)b0 * bs;
+        Plane g = lv[k].g, gf = g0;
+        g.batch = nb; gf.batch = nb;
         if (P.fast_pyramids)
-            return poly_exp(h->pyr[0][k], lv[k].R0, g, P.poly_n, C, sx, 2, h->pyr[1][k] - h->pyr[0][k], lv[k].fsR);
+            return poly_exp(h->pyr[0][k] + po, lv[k].R0 + po, g, P.poly_n, C, sx, 2, h->pyr[1][k] - h->pyr[0][k], lv[k].fsR);
         const int smoothSize = lv[k].smooth;
         std::vector<float> gk(smoothSize);
         gaussian_kernel(smoothSize, lv[k].sigma, gk.data());
@@ -346,16 +351,16 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         memset(&K, 0, sizeof(K));
         for (int i = 0; i <= smoothSize / 2; ++i) K.k[i] = gk[smoothSize / 2 + i];
         int r;
-        if ((r = gaussian_blur(h->frames[0], h->blurred, g0, smoothSize / 2, K, MI_BORDER_REFLECT101, sx, 2, pn))) return r;
-        const float *src = h->blurred;
-        if (!(g.w == g0.w && g.h == g0.h)) {
+        if ((r = gaussian_blur(h->frames[0] + po, h->blurred + po, gf, smoothSize / 2, K, MI_BORDER_REFLECT101, sx, 2, pn))) return r;
+        const float *src = h->blurred + po;
+        if (!(g.w == gf.w && g.h == gf.h)) {
             // the level image = cuda::resize of the blurred frame (:447-448).  Few pairs: sampled inside the expansion kernel (same
             // arithmetic, same bits, one launch less); many pairs: through the level planes (the expansion reads each sample 11 times)
-            if (fuse_small) return poly_exp(h->blurred, lv[k].R0, g, P.poly_n, C, sx, 2, pn, lv[k].fsR, &g0);
-            if ((r = resize2(h->blurred, h->blurred + pn, g0, h->lvl[0], h->lvl[1], g, 1.f, sx))) return r;
-            src = h->lvl[0];
+            if (fuse_small) return poly_exp(h->blurred + po, lv[k].R0 + po, g, P.poly_n, C, sx, 2, pn, lv[k].fsR, &gf);
+            if ((r = resize2(h->blurred + po, h->blurred + po + pn, gf, h->lvl[0] + po, h->lvl[1] + po, g, 1.f, sx))) return r;
+            src = h->lvl[0] + po;
         }
-        return poly_exp(src, lv[k].R0, g, P.poly_n, C, sx, 2, pn, lv[k].fsR);
+        return poly_exp(src, lv[k].R0 + po, g, P.poly_n, C, sx, 2, pn, lv[k].fsR);
     };
     if (async) {
         if (!h->aux) MI_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
@@ -368,7 +373,7 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         MI_HIP_TRY(hipEventRecord(h->ev_fork, st));             // the frames (and the fast pyramid) are complete here
         MI_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
         for (int k = levels; k >= 0; k--) {
-            if ((rc = pyramid_stage(k, h->aux))) { (void)hipStreamSynchronize(h->aux); return rc; }
+            if ((rc = pyramid_stage(k, h->aux, 0, B))) { (void)hipStreamSynchronize(h->aux); return rc; }
             MI_HIP_TRY(hipEventRecord(h->ev_level[k], h->aux));
         }
     }
@@ -396,11 +401,7 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
                     MI_HIP_TRY(hipMemset2DAsync(cury, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
                 }
             }
-        } else if (!(fuse_small && !(gprev.w == g.w && gprev.h == g.h))) {              // :412-417
-            if ((rc = resize2(prevx, prevy, gprev, curx, cury, g, (float)(1. / P.pyr_scale), st))) return rc;
         }
-        if (async) MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_level[k], 0));
-        else if ((rc = pyramid_stage(k, st))) return rc;
         const float *R0 = lv[k].R0, *R1 = lv[k].R0 + lv[k].fsR;
         // Pair GROUPS (round 5).  An iteration of a level streams 22 planes per pair (M in and out, both expansions, the flow); with the
         // whole batch per launch a 640 x 480 level of 32 pairs is 0.9 GB per iteration -- every iteration comes from HBM.  Run group by
@@ -408,18 +409,55 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         // group.  The same launches on the same data in the same order per pair: bit-identical.  Small calls (one launch chain per
         // level, few-launch forms) keep the whole batch.
         int G = B;
+        const bool zoom = prevx && !(fuse_small && !(gprev.w == g.w && gprev.h == g.h));   // :412-417 as its own launch
         if (B > 1 && !fuse_small && tuning().fb_group_mb > 0) {
             const long long per_pair = 22LL * (long long)g.ld * g.h * (long long)sizeof(float);
             G = (int)std::max(1LL, std::min((long long)B, ((long long)tuning().fb_group_mb << 20) / per_pair));
             if ((long long)B * 8 <= (long long)G * 9) G = B;   // no one- or two-pair tail group for a budget missed by an eighth (r16g: 31 + 1 pairs at 320 x 240)
         }
-        for (int b0 = 0; b0 < B; b0 += G) {
+        // Groups are independent chains of launches (their pairs' planes only): two of them run side by side, the second on the handle's
+        // internal stream, each half the size -- the launches of a chain wait for each other's last workgroups (r16g: 37 us per level-0
+        // iteration of 7 pairs against 25 us of vector issue), and the other chain fills those tails.
+        // a level in groups: the zoom of the coarser flow and the frames' side go group by group too (what they write is what the group
+        // reads next); otherwise once for the batch, as the reference orders them
+        const bool staged = G < B && !async;
+        if (!staged) {
+            if (zoom && (rc = resize2(prevx, prevy, gprev, curx, cury, g, (float)(1. / P.pyr_scale), st))) return rc;
+            if (async) MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_level[k], 0));
+            else if ((rc = pyramid_stage(k, st, 0, B))) return rc;
+        }
+        bool two = false;
+        if (G < B && tuning().fb_group_streams == 2) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            two = !(hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone);
+            if (!two) (void)hipGetLastError();
+        }
+        if (two) {
+            G = std::max(1, G / 2);
+            const int n = (div_up(B, G) + 1) & ~1;   // an even number of groups of (almost) equal size: both chains end together
+            G = div_up(B, n);
+            if (!h->aux) MI_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+            if (!h->ev_fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            if (!h->ev_join) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            MI_HIP_TRY(hipEventRecord(h->ev_fork, st));
+            MI_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+        }
+        hipStream_t const caller_st = st;
+        int gi = 0;
+        for (int b0 = 0; b0 < B; b0 += G, ++gi) {
+        hipStream_t st = (two && (gi & 1)) ? h->aux : caller_st;   // this group's chain
         const long long goff = (long long)b0 * bs;
         Plane gg = g;
         gg.batch = std::min(G, B - b0);
         float *M = h->M + goff, *bufM = h->bufM + goff;
         float *gx = curx + goff, *gy = cury + goff;
         const float *gR0 = R0 + goff, *gR1 = R1 + goff;
+        if (staged) {
+            Plane gp = gprev;
+            gp.batch = gg.batch;
+            if (zoom && (rc = resize2(prevx + goff, prevy + goff, gp, gx, gy, gg, (float)(1. / P.pyr_scale), st))) return rc;
+            if ((rc = pyramid_stage(k, st, b0, gg.batch))) return rc;
+        }
         if (prevx && fuse_small && !(gprev.w == g.w && gprev.h == g.h)) {   // the zoom of the coarser flow inside the first matrix update
             if ((rc = update_matrices_resized(prevx, prevy, gprev, (float)(1. / P.pyr_scale), curx, cury, R0, R1, M, g, st))) return rc;
         } else if ((rc = update_matrices(gx, gy, gR0, gR1, M, gg, st))) return rc;   // :458
@@ -444,6 +482,10 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
             merged = merged || dm;
             std::swap(M, bufM);
         }
+        }
+        if (two) {
+            MI_HIP_TRY(hipEventRecord(h->ev_join, h->aux));
+            MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
         }
         prevx = curx; prevy = cury; gprev = g;
     }

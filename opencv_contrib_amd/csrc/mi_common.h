@@ -72,6 +72,8 @@ struct Tuning {
     int fb_fuse;             // MIFLOW_FB_FUSE: Farneback few-launch forms (resize sampled inside poly_exp / update_matrices, merge in the last iteration): -1 = small calls (default), 0, 1
     int fb_pair;             // MIFLOW_FB_PAIR: Farneback two iterations per launch (k_iterate2_t): -1 = levels that underfill the device (default), 0, 1
     int fb_narrow;           // MIFLOW_FB_NARROW: Farneback iteration kernel on 64 x 4 tiles: -1 = where the 256-column grid underfills the device (default), 0 = never, 1 = always
+    int fb_group_streams;    // MIFLOW_FB_GROUP_STREAMS (experiments build): the pair groups of a batched Farneback level run as two chains on two streams (2) or one after the other (1)
+    int fb_poly_tiled;       // MIFLOW_FB_POLY_TILED (experiments build): Farneback polynomial expansion on 8-row tiles (1) or one row per workgroup (0)
     int fb_blur_tiled;       // MIFLOW_FB_BLUR_TILED (experiments build): Farneback pyramid pre-blur tiled over 8-14 rows (1) or one row per workgroup (0)
     int fb_tiled;            // MIFLOW_FB_TILED: Farneback iteration kernel tiled over 4 rows (1) or one row per workgroup (0)
 };
