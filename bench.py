@@ -578,8 +578,8 @@ def bench_farneback(args):
            "batched_calc_batch": batched,
            "roofline": {"bound": "hbm", "achieved": algo * args.steps * n / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo * args.steps * n / el / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("farneback_iterate_level0_batch")[0],
-                        "traffic_kernel": "k_iterate_t, finest level of the batched calc: bytes per launch (32 pairs x 640 x 480 px; "
-                                          "algorithmic 88 B/px = 865 MB)",
+                        "traffic_kernel": (lambda q: f"k_iterate_t, finest level of the batched calc: bytes per launch ({q} pairs x 640 x 480 px; "
+                                                     f"algorithmic 88 B/px = {q * 640 * 480 * 88 / 1e6:.0f} MB)")(pmc_pairs("farneback_iterate_level0_batch", 32)),
                         "traffic_source": pmc_traffic("farneback_iterate_level0_batch")[1],
                         "note": "sequential calc() of ONE small pair: launch-latency bound (about 70 launches of 5-50 us); bytes = "
                                 "fused-iteration accounting"}}
@@ -593,8 +593,9 @@ def bench_farneback(args):
         out["config"]["workload"] += f"; value = calc_batch of {batched['batch']} pairs"
         out["roofline"]["achieved"] = algo * batched["pairs_per_s"] / 1e9
         out["roofline"]["frac"] = algo * batched["pairs_per_s"] / 1e9 / HBM_PEAK_GBS
-        out["roofline"]["note"] = ("batched calc (blockIdx.z = pair): bytes = fused-iteration accounting (SURVEY 8d); the finest-level "
-                                   "iteration kernel alone moves 0.94 GB per launch in 213 us = 4.4 TB/s (profiles/r02u)")
+        out["roofline"]["note"] = ("batched calc (blockIdx.z = pair): bytes = fused-iteration accounting (SURVEY 8d); pair groups of 4 on two "
+                                   "streams keep a level's 22 planes per pair in the last-level cache; the level-0 iteration launch is vector-issue "
+                                   "bound (about 6 wave instructions per pixel, profiles/r16)")
     # four independent objects on four streams (distinct handles share nothing: the reference's constant-memory race does not exist
     # here): a 640 x 480 pair alone cannot fill 256 CUs, concurrent pairs can
     try:
@@ -1013,6 +1014,14 @@ def pmc_traffic(key, pairs_per_launch=None, sub=None):
         return v, tj[key].get("source")
     except Exception:
         return None, None
+
+
+def pmc_pairs(key, default):
+    """Pairs per launch the PMC figure of `key` was collected at (profiles/pmc_traffic.json)."""
+    try:
+        return int(json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key].get("pairs_per_launch", default))
+    except Exception:
+        return default
 
 
 def secondary(args):

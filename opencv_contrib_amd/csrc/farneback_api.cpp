@@ -409,10 +409,14 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         // group.  The same launches on the same data in the same order per pair: bit-identical.  Small calls (one launch chain per
         // level, few-launch forms) keep the whole batch.
         int G = B;
-        const bool zoom = prevx && !(fuse_small && !(gprev.w == g.w && gprev.h == g.h));   // :412-417 as its own launch
+        // :412-417.  A level of another size than the coarser one: sampled inside the first matrix update (same arithmetic, same bits; one
+        // launch and one round trip of the flow planes less -- round 4 for small calls, round 5 for every call); same size: a copy
+        const bool zoom_fused = prevx && !(gprev.w == g.w && gprev.h == g.h) && tuning().fb_fuse != 0;
+        const bool zoom = prevx && !zoom_fused;
         if (B > 1 && !fuse_small && tuning().fb_group_mb > 0) {
             const long long per_pair = 22LL * (long long)g.ld * g.h * (long long)sizeof(float);
             G = (int)std::max(1LL, std::min((long long)B, ((long long)tuning().fb_group_mb << 20) / per_pair));
+            if (G < 2) G = B;                                  // not even two pairs' planes fit (1080p): whole-batch launches, nothing would stay cached (r16l)
             if ((long long)B * 8 <= (long long)G * 9) G = B;   // no one- or two-pair tail group for a budget missed by an eighth (r16g: 31 + 1 pairs at 320 x 240)
         }
         // Groups are independent chains of launches (their pairs' planes only): two of them run side by side, the second on the handle's
@@ -458,8 +462,10 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
             if (zoom && (rc = resize2(prevx + goff, prevy + goff, gp, gx, gy, gg, (float)(1. / P.pyr_scale), st))) return rc;
             if ((rc = pyramid_stage(k, st, b0, gg.batch))) return rc;
         }
-        if (prevx && fuse_small && !(gprev.w == g.w && gprev.h == g.h)) {   // the zoom of the coarser flow inside the first matrix update
-            if ((rc = update_matrices_resized(prevx, prevy, gprev, (float)(1. / P.pyr_scale), curx, cury, R0, R1, M, g, st))) return rc;
+        if (zoom_fused) {
+            Plane gp = gprev;
+            gp.batch = gg.batch;
+            if ((rc = update_matrices_resized(prevx + goff, prevy + goff, gp, (float)(1. / P.pyr_scale), gx, gy, gR0, gR1, M, gg, st))) return rc;
         } else if ((rc = update_matrices(gx, gy, gR0, gR1, M, gg, st))) return rc;   // :458
         // levels whose 64 x 4 grid underfills the device: two iterations per launch (MIFLOW_FB_PAIR=0 / 1 forces the choice)
         const bool pair_it = fuse_small && iterate2_supported(P.win_size) &&
