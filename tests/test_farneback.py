@@ -301,6 +301,28 @@ def test_large_batch_runs_in_cache_sized_groups_and_equals_single_calcs(gpu, kw)
         assert torch.equal(out[k], singles[k % 5]), f"pair {k}"
 
 
+@pytest.mark.gpu
+def test_pair_group_budget_never_changes_a_flow(gpu):
+    """MIFLOW_FB_GROUP_MB (read once per process, hence the subprocesses) only decides how many pairs a launch of a large level covers
+    and on which of the handle's two streams a group's chain runs: whole-batch launches (0), the default and a budget that leaves one
+    pair per group give the same bytes for a 12-pair 640 x 480 batch."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for mb in ("0", None, "30"):
+        env = dict(os.environ)
+        env.pop("MIFLOW_FB_GROUP_MB", None)
+        if mb is not None:
+            env["MIFLOW_FB_GROUP_MB"] = mb
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fb_batch.py"), "12", "1", "640", "480"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[mb] = re.search(r"digest ([0-9a-f]+)", r.stdout).group(1)
+    assert len(set(digests.values())) == 1, digests
+
+
 def _random_fb_configs():
     rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "7702")))
     out = []

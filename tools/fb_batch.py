@@ -8,9 +8,9 @@ dev = torch.device("cuda:0")
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (640, 480)
-I0, I1, _ = synth.flow_pair(H, W, seed=1234, dtype="u8")
-b0 = [torch.from_numpy(I0).to(dev) for _ in range(nb)]
-b1 = [torch.from_numpy(I1).to(dev) for _ in range(nb)]
+P = [synth.flow_pair(H, W, seed=1234 + k, dtype="u8") for k in range(min(nb, 4))]   # four distinct scenes in turn
+b0 = [torch.from_numpy(P[i % len(P)][0]).to(dev) for i in range(nb)]
+b1 = [torch.from_numpy(P[i % len(P)][1]).to(dev) for i in range(nb)]
 flows = torch.empty((nb, H, W, 2), dtype=torch.float32, device=dev)
 alg = cuda.FarnebackOpticalFlow.create()
 alg.calc_batch(b0, b1, flows)
