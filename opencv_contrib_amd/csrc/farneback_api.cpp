@@ -2,6 +2,7 @@
 // FarnebackOpticalFlowImpl (modules/cudaoptflow/src/farneback.cpp:96-492), ordered on ONE stream (the
 // reference fans out over 5 streams and blocks the host once per level, :319-324,366,456).
 #include "farneback_dev.h"
+#include "fb_groups.h"
 #include "tvl1_dev.h"   // tvl1::resize == cuda::resize(INTER_LINEAR) on dense f32 planes
 #include <cfloat>
 #include <cmath>
@@ -408,20 +409,23 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         // group instead: the matrix update and ALL iterations of a few pairs whose planes fit the 256 MB last-level cache, then the next
         // group.  The same launches on the same data in the same order per pair: bit-identical.  Small calls (one launch chain per
         // level, few-launch forms) keep the whole batch.
-        int G = B;
         // :412-417.  A level of another size than the coarser one: sampled inside the first matrix update (same arithmetic, same bits; one
         // launch and one round trip of the flow planes less -- round 4 for small calls, round 5 for every call); same size: a copy
         const bool zoom_fused = prevx && !(gprev.w == g.w && gprev.h == g.h) && tuning().fb_fuse != 0;
         const bool zoom = prevx && !zoom_fused;
-        if (B > 1 && !fuse_small && tuning().fb_group_mb > 0) {
-            const long long per_pair = 22LL * (long long)g.ld * g.h * (long long)sizeof(float);
-            G = (int)std::max(1LL, std::min((long long)B, ((long long)tuning().fb_group_mb << 20) / per_pair));
-            if (G < 2) G = B;                                  // not even two pairs' planes fit (1080p): whole-batch launches, nothing would stay cached (r16l)
-            if ((long long)B * 8 <= (long long)G * 9) G = B;   // no one- or two-pair tail group for a budget missed by an eighth (r16g: 31 + 1 pairs at 320 x 240)
-        }
         // Groups are independent chains of launches (their pairs' planes only): two of them run side by side, the second on the handle's
         // internal stream, each half the size -- the launches of a chain wait for each other's last workgroups (r16g: 37 us per level-0
-        // iteration of 7 pairs against 25 us of vector issue), and the other chain fills those tails.
+        // iteration of 7 pairs against 25 us of vector issue), and the other chain fills those tails.  Not while the caller's stream is
+        // being captured (the graph stays one chain).  The plan itself: fb_groups.h.
+        int chains = tuning().fb_group_streams == 2 ? 2 : 1;
+        if (chains == 2) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); chains = 1; }
+        }
+        GroupPlan gp_ = {B, 1, false};
+        if (!fuse_small) gp_ = plan_pair_groups(B, 22LL * (long long)g.ld * g.h * (long long)sizeof(float), tuning().fb_group_mb, chains);
+        const int G = gp_.pairs;
+        const bool two = gp_.two;
         // a level in groups: the zoom of the coarser flow and the frames' side go group by group too (what they write is what the group
         // reads next); otherwise once for the batch, as the reference orders them
         const bool staged = G < B && !async;
@@ -430,16 +434,7 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
             if (async) MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_level[k], 0));
             else if ((rc = pyramid_stage(k, st, 0, B))) return rc;
         }
-        bool two = false;
-        if (G < B && tuning().fb_group_streams == 2) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            two = !(hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone);
-            if (!two) (void)hipGetLastError();
-        }
         if (two) {
-            G = std::max(1, G / 2);
-            const int n = (div_up(B, G) + 1) & ~1;   // an even number of groups of (almost) equal size: both chains end together
-            G = div_up(B, n);
             if (!h->aux) MI_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
             if (!h->ev_fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             if (!h->ev_join) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));

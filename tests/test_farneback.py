@@ -301,6 +301,20 @@ def test_large_batch_runs_in_cache_sized_groups_and_equals_single_calcs(gpu, kw)
         assert torch.equal(out[k], singles[k % 5]), f"pair {k}"
 
 
+def test_pair_group_plan_host_arithmetic(tmp_path):
+    """tests/cpp/fb_groups_test.cpp: the plan of the batched level loop (csrc/fb_groups.h -- pairs per launch group, one or two chains)
+    for the bench's shape, the sizes where no groups are formed, and its invariants over a sweep (groups cover the batch, the groups in
+    flight stay inside the cache budget).  Plain C++, no device."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fb_groups_test")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "opencv_contrib_amd", "csrc"),
+                        os.path.join(root, "tests", "cpp", "fb_groups_test.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "fb_groups_test: ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_pair_group_budget_never_changes_a_flow(gpu):
     """MIFLOW_FB_GROUP_MB (read once per process, hence the subprocesses) only decides how many pairs a launch of a large level covers
