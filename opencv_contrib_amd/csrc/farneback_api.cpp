@@ -247,25 +247,27 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
 
     // flowx0/flowy0 (level-0 flow planes; also the caller's initial flow)
     float *fx0 = h->flow[0][0], *fy0 = h->flow[0][1];
-    if (B > 1) {   // one launch per 64 pairs (blockIdx.z = pair) instead of one per pair
-        for (int b0 = 0; b0 < B; b0 += kFmtPairs) {
-            const int nb = std::min(kFmtPairs, B - b0);
-            FmtTab T;
-            memset(&T, 0, sizeof(T));
-            for (int j = 0; j < nb; ++j) {
-                T.a[j] = I0s[b0 + j].data; T.sa[j] = (long long)I0s[b0 + j].step;
-                T.b[j] = I1s[b0 + j].data; T.sb[j] = (long long)I1s[b0 + j].step;
+    // convertTo(CV_32F), farneback.cpp:342-345; the caller's initial flow split into planes
+    auto convert_frames = [&]() -> int {
+        if (B > 1) {   // one launch per 64 pairs (blockIdx.z = pair) instead of one per pair
+            for (int b0 = 0; b0 < B; b0 += kFmtPairs) {
+                const int nb = std::min(kFmtPairs, B - b0);
+                FmtTab T;
+                memset(&T, 0, sizeof(T));
+                for (int j = 0; j < nb; ++j) {
+                    T.a[j] = I0s[b0 + j].data; T.sa[j] = (long long)I0s[b0 + j].step;
+                    T.b[j] = I1s[b0 + j].data; T.sb[j] = (long long)I1s[b0 + j].step;
+                }
+                const int r = convert_batch(T, nb, I0s[0].type, h->frames[0] + b0 * bs, h->frames[1] + b0 * bs, bs, g0s, st);
+                if (r) return r;
             }
-            if ((rc = convert_batch(T, nb, I0s[0].type, h->frames[0] + b0 * bs, h->frames[1] + b0 * bs, bs, g0s, st))) return rc;
+            return MI_OK;
         }
-        for (int b = 0; b < B && use_init; ++b)
-            if ((rc = split_flow(flows[b].data, (long long)flows[b].step, fx0 + b * bs, fy0 + b * bs, g0s, st))) return rc;
-    } else
-    for (int b = 0; b < B; ++b) {
-        if ((rc = convert(I0s[b].data, (long long)I0s[b].step, I1s[b].data, (long long)I1s[b].step, I0s[b].type, h->frames[0] + b * bs,
-                          h->frames[1] + b * bs, g0s, st))) return rc;
-        if (use_init && (rc = split_flow(flows[b].data, (long long)flows[b].step, fx0 + b * bs, fy0 + b * bs, g0s, st))) return rc;
-    }
+        return convert(I0s[0].data, (long long)I0s[0].step, I1s[0].data, (long long)I1s[0].step, I0s[0].type, h->frames[0], h->frames[1], g0s, st);
+    };
+    if (P.fast_pyramids && (rc = convert_frames())) return rc;   // the fast pyramid is built from the converted frames, below
+    for (int b = 0; b < B && use_init; ++b)
+        if ((rc = split_flow(flows[b].data, (long long)flows[b].step, fx0 + b * bs, fy0 + b * bs, g0s, st))) return rc;
 
     // crop unnecessary levels, farneback.cpp:330-340
     double scale = 1;
@@ -317,6 +319,11 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         lv[k].g = plane_of(width, height, bs, B); lv[k].sigma = sigma; lv[k].scale = scale; lv[k].smooth = smoothSize;
         need += 10LL * lv[k].g.ld * lv[k].g.h;
     }
+    // The frames as f32 planes -- unless every level's pre-blur can read the caller's matrices itself (`direct`, round 5: the tiled blur
+    // has an instantiation for every level's kernel size): then the conversion pass and its planes are not needed at all.
+    bool direct = !P.fast_pyramids && tuning().fb_direct != 0;
+    for (int k = 0; k <= levels && direct; ++k) direct = gaussian_blur_tab_ok(g0, lv[k].smooth / 2);
+    if (!P.fast_pyramids && !direct && (rc = convert_frames())) return rc;
     // The frames' side of every level on the internal stream (see mi_farneback::Rall) when all expansions fit; MIFLOW_FB_ASYNC=0 or
     // a pyramid that does not fit: level by level on the caller's stream, through the one full-size R pair.
     bool async = need <= h->Rall_floats && tuning().fb_async != 0;
@@ -352,7 +359,19 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         memset(&K, 0, sizeof(K));
         for (int i = 0; i <= smoothSize / 2; ++i) K.k[i] = gk[smoothSize / 2 + i];
         int r;
-        if ((r = gaussian_blur(h->frames[0] + po, h->blurred + po, gf, smoothSize / 2, K, MI_BORDER_REFLECT101, sx, 2, pn))) return r;
+        if (direct) {
+            for (int c0 = 0; c0 < nb; c0 += kFmtPairs) {
+                FmtTab T;
+                memset(&T, 0, sizeof(T));
+                Plane gc = gf;
+                gc.batch = std::min(kFmtPairs, nb - c0);
+                for (int j = 0; j < gc.batch; ++j) {
+                    T.a[j] = I0s[b0 + c0 + j].data; T.sa[j] = (long long)I0s[b0 + c0 + j].step;
+                    T.b[j] = I1s[b0 + c0 + j].data; T.sb[j] = (long long)I1s[b0 + c0 + j].step;
+                }
+                if ((r = gaussian_blur_tab(T, I0s[0].type, h->blurred + po + (long long)c0 * bs, gc, smoothSize / 2, K, sx, pn))) return r;
+            }
+        } else if ((r = gaussian_blur(h->frames[0] + po, h->blurred + po, gf, smoothSize / 2, K, MI_BORDER_REFLECT101, sx, 2, pn))) return r;
         const float *src = h->blurred + po;
         if (!(g.w == gf.w && g.h == gf.h)) {
             // the level image = cuda::resize of the blurred frame (:447-448).  Few pairs: sampled inside the expansion kernel (same

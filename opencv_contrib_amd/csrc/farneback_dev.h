@@ -28,6 +28,9 @@ int split_flow(const void *flow, long long sf, float *fx, float *fy, const Plane
 int merge_flow(const float *fx, const float *fy, void *flow, long long sf, const Plane &g, hipStream_t s);
 // nf = 2: both frames of every pair in one launch (blockIdx.z = pair * 2 + frame; frame 1 lies fs floats behind frame 0 in src / dst)
 int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Taps &K, int border, hipStream_t s, int nf = 1, long long fs = 0);
+// the same (REFLECT101, both frames of g.batch <= kFmtPairs pairs) reading the caller's CV_8UC1 / CV_32FC1 matrices T.a / T.b instead of converted planes
+bool gaussian_blur_tab_ok(const Plane &g, int kh);
+int gaussian_blur_tab(const FmtTab &T, int type, float *dst, const Plane &g, int kh, const Taps &K, hipStream_t s, long long fs);
 // resize_from: src is a plane of that (larger) geometry and the expansion reads its cuda::resize to g, sampled on the fly
 int poly_exp(const float *src, float *dst5, const Plane &g, int polyN, const PolyC &C, hipStream_t s, int nf = 1, long long fs_src = 0, long long fs_dst = 0,
              const Plane *resize_from = nullptr);

@@ -117,12 +117,12 @@ __global__ __launch_bounds__(256) void k_gaussian_blur(const float *src, float *
 // leaves them in the LDS for the horizontal pass; the 2 KH columns beside the tile are a second, short round of wave 0.  Rows and
 // columns go through the border rule when they are loaded and the sums are formed in the same order: bit-identical planes.
 template <int KH> struct BlurTile { static constexpr int RB = (2 * KH) % 8 ? 16 - (2 * KH) % 8 : 8; };
-template <int BORDER, int KH>
-__global__ __launch_bounds__(256) void k_gaussian_blur_t(const float *src, float *dst, int w, int h, int ld, Taps K, long long bs, int nf, long long fs)
+// (the tile's arithmetic; `at(row, column)` reads a source pixel as float)
+template <int BORDER, int KH, class At>
+__device__ __forceinline__ void blur_tile(At at, float *dst, int w, int h, int ld, const Taps &K)
 {
     constexpr int RB = BlurTile<KH>::RB, W2 = 256 + 2 * KH, NL = RB + 2 * KH;
     __shared__ float vs[RB][W2];
-    { const long long o = (long long)(blockIdx.z / nf) * bs + (long long)(blockIdx.z % nf) * fs; src += o; dst += o; }
     const int tx = threadIdx.x, y0 = blockIdx.y * RB, x0 = blockIdx.x * 256;
     float k[KH + 1];
 #pragma unroll
@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void k_gaussian_blur_t(const float *src, float
     for (int pass = 0; pass < 2; ++pass) {
         const int i = tx + 256 * pass;
         if (i >= W2) break;
-        const float *P = src + gidx<BORDER, true>(min(x0 + i - KH, w - 1 + KH), w);
+        const int xc = gidx<BORDER, true>(min(x0 + i - KH, w - 1 + KH), w);
         float c[NL];
 #pragma unroll
-        for (int r = 0; r < NL; ++r) c[r] = P[(long long)gidx<BORDER, true>(min(y0 - KH + r, h - 1 + KH), h) * ld];
+        for (int r = 0; r < NL; ++r) c[r] = at(gidx<BORDER, true>(min(y0 - KH + r, h - 1 + KH), h), xc);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             float v = c[r + KH] * k[0];
@@ -155,6 +155,25 @@ __global__ __launch_bounds__(256) void k_gaussian_blur_t(const float *src, float
         for (int i = 1; i <= KH; ++i) res += (q[-i] + q[i]) * k[i];
         dst[(long long)(y0 + r) * ld + x] = res;
     }
+}
+template <int BORDER, int KH>
+__global__ __launch_bounds__(256) void k_gaussian_blur_t(const float *src, float *dst, int w, int h, int ld, Taps K, long long bs, int nf, long long fs)
+{
+    { const long long o = (long long)(blockIdx.z / nf) * bs + (long long)(blockIdx.z % nf) * fs; src += o; dst += o; }
+    blur_tile<BORDER, KH>([&](int r, int c) { return src[(long long)r * ld + c]; }, dst, w, h, ld, K);
+}
+// ... reading the CALLER's matrices (round 5): blockIdx.z = pair * 2 + frame, frame 0 / 1 of pair p = T.a[p] / T.b[p] with row steps T.sa / T.sb
+// in bytes; CV_8UC1 converted on the fly (convertTo(CV_32F), farneback.cpp:342-345: exact) or CV_32FC1.  The conversion pass and its
+// two planes per pair are gone, and the four blurs of an 8-bit pair read a quarter of the bytes.
+template <int BORDER, int KH, bool U8>
+__global__ __launch_bounds__(256) void k_gaussian_blur_tab(FmtTab T, float *dst, int w, int h, int ld, Taps K, long long bs, long long fs)
+{
+    const int p = blockIdx.z >> 1, f = blockIdx.z & 1;
+    dst += (long long)p * bs + (long long)f * fs;
+    const char *base = (const char *)(f ? T.b[p] : T.a[p]);
+    const long long step = f ? T.sb[p] : T.sa[p];
+    if (U8) blur_tile<BORDER, KH>([&](int r, int c) { return (float)((const unsigned char *)(base + (long long)r * step))[c]; }, dst, w, h, ld, K);
+    else blur_tile<BORDER, KH>([&](int r, int c) { return ((const float *)(base + (long long)r * step))[c]; }, dst, w, h, ld, K);
 }
 
 // ------------------------------------------------------------------ polynomial expansion
@@ -809,6 +828,24 @@ int gaussian_blur(const float *src, float *dst, const Plane &g, int kh, const Ta
         else hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REFLECT101, false>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
     } else
         hipLaunchKernelGGL((k_gaussian_blur<MI_BORDER_REPLICATE, true>), grid, dim3(256), lds, s, src, dst, g.w, g.h, g.ld, kh, K, g.bs, nf, fs);
+    MI_HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+// the tiled blur straight from the caller's matrices (both frames of g.batch <= kFmtPairs pairs); false: no instantiation for this case
+bool gaussian_blur_tab_ok(const Plane &g, int kh)
+{
+    const bool fast = kh < g.w && kh < g.h && g.w >= 2 && g.h >= 2;
+    return fast && tuning().fb_blur_tiled && (kh == 1 || kh == 2 || kh == 3 || kh == 4 || kh == 9 || kh == 19);
+}
+int gaussian_blur_tab(const FmtTab &T, int type, float *dst, const Plane &g, int kh, const Taps &K, hipStream_t s, long long fs)
+{
+    MI_REQUIRE(gaussian_blur_tab_ok(g, kh) && g.batch <= kFmtPairs && (type == MI_8UC1 || type == MI_32FC1), MI_ERR_BAD_ARG, "no direct-source blur for this case");
+#define MI_FB_BLUR(KH) case KH: { const dim3 tg(div_up(g.w, 256), div_up(g.h, BlurTile<KH>::RB), g.batch * 2);                                  \
+        if (type == MI_8UC1) hipLaunchKernelGGL((k_gaussian_blur_tab<MI_BORDER_REFLECT101, KH, true>), tg, dim3(256), 0, s, T, dst, g.w, g.h, g.ld, K, g.bs, fs); \
+        else hipLaunchKernelGGL((k_gaussian_blur_tab<MI_BORDER_REFLECT101, KH, false>), tg, dim3(256), 0, s, T, dst, g.w, g.h, g.ld, K, g.bs, fs); } break;
+    switch (kh) { MI_FB_BLUR(1) MI_FB_BLUR(2) MI_FB_BLUR(3) MI_FB_BLUR(4) MI_FB_BLUR(9) MI_FB_BLUR(19) }
+#undef MI_FB_BLUR
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }

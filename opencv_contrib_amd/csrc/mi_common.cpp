@@ -85,6 +85,7 @@ const Tuning &tuning()
         t.fb_swz = EXP_INT("MIFLOW_FB_SWZ", 1);
         t.fb_group_streams = EXP_INT("MIFLOW_FB_GROUP_STREAMS", 2);   // pair groups of a batched level as two chains on two streams (1: one chain)
         t.fb_poly_tiled = EXP_INT("MIFLOW_FB_POLY_TILED", 1);   // polynomial expansion on 8-row tiles (0: one row per workgroup)
+        t.fb_direct = EXP_INT("MIFLOW_FB_DIRECT", 1);   // pyramid pre-blur reads the caller's matrices (0: through converted f32 planes)
         t.fb_blur_tiled = EXP_INT("MIFLOW_FB_BLUR_TILED", 1);   // r16e: pyramid pre-blur on 8-14 row tiles from the LDS (0: one row per workgroup)
     });
     return g_tuning;

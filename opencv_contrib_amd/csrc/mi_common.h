@@ -74,6 +74,7 @@ struct Tuning {
     int fb_narrow;           // MIFLOW_FB_NARROW: Farneback iteration kernel on 64 x 4 tiles: -1 = where the 256-column grid underfills the device (default), 0 = never, 1 = always
     int fb_group_streams;    // MIFLOW_FB_GROUP_STREAMS (experiments build): the pair groups of a batched Farneback level run as two chains on two streams (2) or one after the other (1)
     int fb_poly_tiled;       // MIFLOW_FB_POLY_TILED (experiments build): Farneback polynomial expansion on 8-row tiles (1) or one row per workgroup (0)
+    int fb_direct;           // MIFLOW_FB_DIRECT (experiments build): the Farneback pre-blur reads the caller's CV_8UC1 / CV_32FC1 matrices (1) or converted f32 planes (0)
     int fb_blur_tiled;       // MIFLOW_FB_BLUR_TILED (experiments build): Farneback pyramid pre-blur tiled over 8-14 rows (1) or one row per workgroup (0)
     int fb_tiled;            // MIFLOW_FB_TILED: Farneback iteration kernel tiled over 4 rows (1) or one row per workgroup (0)
 };
