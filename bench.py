@@ -594,8 +594,8 @@ def bench_farneback(args):
         out["roofline"]["achieved"] = algo * batched["pairs_per_s"] / 1e9
         out["roofline"]["frac"] = algo * batched["pairs_per_s"] / 1e9 / HBM_PEAK_GBS
         out["roofline"]["note"] = ("batched calc (blockIdx.z = pair): bytes = fused-iteration accounting (SURVEY 8d); pair groups of 4 on two "
-                                   "streams keep a level's 22 planes per pair in the last-level cache; the level-0 iteration launch is vector-issue "
-                                   "bound (about 6 wave instructions per pixel, profiles/r16)")
+                                   "streams keep a level's 22 planes per pair in the last-level cache; the level-0 iteration launch moves 1.02 x its "
+                                   "compulsory bytes past the L2, at 4.5-5 TB/s (profiles/r16, r17z)")
     # four independent objects on four streams (distinct handles share nothing: the reference's constant-memory race does not exist
     # here): a 640 x 480 pair alone cannot fill 256 CUs, concurrent pairs can
     try:

@@ -407,9 +407,12 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         float *curx, *cury;
         if (k > 0) { curx = h->flow[1 + (k & 1)][0]; cury = h->flow[1 + (k & 1)][1]; }
         else { curx = fx0; cury = fy0; }
+        bool zero_flow = false;
         if (!prevx) {
             if (use_init) {   // :398-404
                 if (k > 0 && (rc = resize2(fx0, fy0, g0, curx, cury, g, (float)scale, st))) return rc;
+            } else if (P.num_iters > 0) {
+                zero_flow = true;   // the first matrix update takes the flow as zero and the iterations write every pixel of both planes: no fill
             } else {
                 const size_t bytes = sizeof(float) * (size_t)g.ld * g.h;
                 // the two planes are neighbours in the arena: one fill over both and the gap between them while that gap is small (a single
@@ -480,7 +483,7 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
             Plane gp = gprev;
             gp.batch = gg.batch;
             if ((rc = update_matrices_resized(prevx + goff, prevy + goff, gp, (float)(1. / P.pyr_scale), gx, gy, gR0, gR1, M, gg, st))) return rc;
-        } else if ((rc = update_matrices(gx, gy, gR0, gR1, M, gg, st))) return rc;   // :458
+        } else if ((rc = update_matrices(zero_flow ? nullptr : gx, zero_flow ? nullptr : gy, gR0, gR1, M, gg, st))) return rc;   // :458
         // levels whose 64 x 4 grid underfills the device: two iterations per launch (MIFLOW_FB_PAIR=0 / 1 forces the choice)
         const bool pair_it = fuse_small && iterate2_supported(P.win_size) &&
                              (tuning().fb_pair >= 0 ? tuning().fb_pair != 0 : (long long)div_up(g.w, 64) * div_up(g.h, 4) * B <= 2LL * (device_simds() / 4));

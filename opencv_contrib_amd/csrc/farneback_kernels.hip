@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *flowx, con
     if (x >= w || y >= h) return;
     const long long po = (long long)blockIdx.z * bs;
     const long long o = (long long)y * ld + x;
-    update_matrices_px(x, y, w, h, ld, flowx[po + o], flowy[po + o], R0 + po, R1 + po, M + po);
+    // flowx == nullptr: the zero flow the coarsest level starts from (farneback.cpp:405-409) without a cleared plane to read it from
+    update_matrices_px(x, y, w, h, ld, flowx ? flowx[po + o] : 0.f, flowx ? flowy[po + o] : 0.f, R0 + po, R1 + po, M + po);
 }
 
 // ------------------------------------------------------------------ fused inner iteration

@@ -199,7 +199,7 @@ surf_counters)
   find $O -type f -size +4M -delete ;;
 pmc_secondary)
   cd /tmp
-  for wl in stereobm farneback surf; do for c in FETCH_SIZE WRITE_SIZE; do
+  for wl in ${PMC_WLS:-stereobm farneback surf}; do for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $c -f csv -d $R/$O/pmc_${wl}_$c -- python $R/bench.py --workload $wl --no-cpu --steps 2 --warmup 1 > $R/$O/pmc_${wl}_$c.log 2>&1
   done; done
   cd $R
