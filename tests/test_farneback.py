@@ -337,6 +337,21 @@ def test_pair_group_budget_never_changes_a_flow(gpu):
     assert len(set(digests.values())) == 1, digests
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mb", ["6", "20"])
+def test_random_batches_in_many_small_pair_groups_equal_single_calcs(gpu, mb):
+    """tools/fb_stress.py under a pair-group budget of a few MB (every level of every call is cut into many groups on two streams): random
+    sizes, 2..40 pairs, 8-bit / float frames, pitched ROI inputs (the pre-blur reads them in place), window sizes, pyramid parameters, the fast
+    pyramid -- each batch equals the single calc()s of its pairs bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fb_stress.py"), "8", mb], capture_output=True, text=True,
+                       env=dict(os.environ, MIFLOW_FB_GROUP_MB=mb), timeout=900)
+    assert r.returncode == 0 and "fb_stress: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def _random_fb_configs():
     rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "7702")))
     out = []
