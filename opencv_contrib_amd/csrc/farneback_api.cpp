@@ -463,6 +463,11 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
             MI_HIP_TRY(hipEventRecord(h->ev_fork, st));
             MI_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
         }
+        // an error return from inside the group loop still orders the caller's stream behind whatever the internal one was given
+        struct ChainJoin {
+            hipStream_t st, aux; hipEvent_t ev; bool armed;
+            ~ChainJoin() { if (armed) { (void)hipEventRecord(ev, aux); (void)hipStreamWaitEvent(st, ev, 0); } }
+        } chain_join = {st, h->aux, h->ev_join, two};
         hipStream_t const caller_st = st;
         int gi = 0;
         for (int b0 = 0; b0 < B; b0 += G, ++gi) {
@@ -507,6 +512,7 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
         }
         }
         if (two) {
+            chain_join.armed = false;
             MI_HIP_TRY(hipEventRecord(h->ev_join, h->aux));
             MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
         }
