@@ -291,7 +291,11 @@ MI_API int mi_farneback_get_params(const mi_farneback *h, mi_farneback_params *p
  * I0,I1: MI_8UC1 or MI_32FC1 (convertTo(CV_32F), no scaling), same size/type; flow: MI_32FC2 of the frame size,
  * read as the initial flow when MI_OPTFLOW_USE_INITIAL_FLOW.  One stream, no host synchronisation. */
 MI_API int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream);
-/* n independent pairs of identical size and type in one pass (blockIdx.z = pair in every kernel of the level loop). */
+/* n independent pairs of identical size and type in one pass (blockIdx.z = pair in every kernel of the level loop).  Ordered on
+ * `stream` like calc(): a level whose planes exceed the last-level cache runs group by group of pairs, every second group on a stream the
+ * handle owns, forked from and joined back into `stream` inside the call (not while `stream` is being captured: one chain then).  The
+ * frames and flows must stay valid until the work enqueued on `stream` has run -- the pyramid reads the caller's matrices in place at
+ * every level.  Results are the bytes of n calc()s. */
 MI_API int mi_farneback_calc_batch(mi_farneback *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream);
 MI_API void mi_farneback_destroy(mi_farneback *h);
 
