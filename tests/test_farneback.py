@@ -352,6 +352,39 @@ def test_random_batches_in_many_small_pair_groups_equal_single_calcs(gpu, mb):
     assert r.returncode == 0 and "fb_stress: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@gpu_mark
+@pytest.mark.parametrize("batch", [1, 12], ids=["one_pair", "batch_in_groups"])
+def test_calc_captured_into_a_graph_by_the_caller_replays_the_same_flow(gpu, batch):
+    """A caller may capture calc() / calc_batch() into a HIP graph (torch.cuda.CUDAGraph here) and replay it: no call of the level loop
+    synchronises or allocates once the handle has its arena, and a batch whose levels run in pair groups stays ONE chain while its
+    stream is being captured (the second chain lives on a stream of the handle's own, which a capture must not touch).  The replay
+    writes the bytes of the plain call."""
+    import torch
+    from opencv_contrib_amd import cuda
+    pairs = [synth.flow_pair(480, 640, seed=300 + k, dtype="u8")[:2] for k in range(min(batch, 3))]
+    I0 = [T(pairs[i % len(pairs)][0], gpu) for i in range(batch)]
+    I1 = [T(pairs[i % len(pairs)][1], gpu) for i in range(batch)]
+    alg = cuda.FarnebackOpticalFlow.create()
+    run = (lambda out: alg.calc(I0[0], I1[0], out)) if batch == 1 else (lambda out: alg.calc_batch(I0, I1, out))
+    out = run(None)
+    torch.cuda.synchronize()
+    ref = out.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(out)                      # the handle's arena and streams exist before the capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        run(out)
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
 def _random_fb_configs():
     rng = np.random.default_rng(int(os.environ.get("MIFLOW_SWEEP_SEED", "7702")))
     out = []
