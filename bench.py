@@ -1469,6 +1469,11 @@ def main():
         except Exception as e:
             var["class_defaults_300_eps0.01_no_history"] = {"error": repr(e)[:200]}
         vrun("class_defaults_300_eps0.01_stop_slack1", 300, 0.01, stopSlack=1)   # miflow extension: up to one iteration past the reference's stop
+        # the other half of the reference's own test matrix: Gamma(1.0) (test_optflow.cpp:451,530-532) -- since round 6 on the blocked
+        # kernel with the illumination channel (k_iterate_tbr GAM: u3, p31, p32 ride through the same pipeline); the algorithmic
+        # bytes of an iteration are 96 B/px there (three u, six p) against the 64 the two-channel figure below is computed with
+        vrun("iterations10_eps0_gamma1", 10, 0.0, gamma=1.0)
+        vrun("class_defaults_300_eps0.01_gamma1", 300, 0.01, gamma=1.0, warm=2)
         vrun("iterations10_eps0_exact_math", 10, 0.0, exactMath=True)
         vrun("iterations10_eps0_cuda_compat_semantics", 10, 0.0, semantics=1)
         # one lane: the whole batch on the caller's stream -- the two dominant kernels timed WITHOUT the other half batch's kernels

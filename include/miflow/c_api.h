@@ -184,6 +184,9 @@ MI_API int mi_tvl1_multi_set_chunk(mi_tvl1_multi *m, int pairs_per_chunk);   /* 
 MI_API int mi_tvl1_multi_calc_batch(mi_tvl1_multi *m, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows);
 /* how the non-root workers are connected to the root: *rccl_links over RCCL, *peer_copy_links by peer copies (either may be NULL) */
 MI_API int mi_tvl1_multi_transport(const mi_tvl1_multi *m, int *rccl_links, int *peer_copy_links);
+/* why the most recent link of this process fell back to peer copies (the RCCL error text, "librccl.so not found", "MIFLOW_MULTI_RCCL=0");
+ * "" if none did.  Valid until the calling thread's next call. */
+MI_API const char *mi_tvl1_multi_transport_why(void);
 MI_API void mi_tvl1_multi_destroy(mi_tvl1_multi *m);
 
 /* Stage-level entry points (dense or pitched MI_32FC1 planes) == the reference's internal

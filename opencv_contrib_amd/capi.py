@@ -126,6 +126,7 @@ def lib():
         "mi_tvl1_multi_set_chunk": (i, [vp, i]),
         "mi_tvl1_multi_calc_batch": (i, [vp, i, PM, PM, PM]),
         "mi_tvl1_multi_transport": (i, [vp, C.POINTER(i), C.POINTER(i)]),
+        "mi_tvl1_multi_transport_why": (C.c_char_p, []),
         "mi_tvl1_multi_destroy": (None, [vp]),
         "mi_tvl1_centered_gradient": (i, [PM, PM, PM, vp]),
         "mi_tvl1_warp_backward": (i, [i] + [PM] * 11),

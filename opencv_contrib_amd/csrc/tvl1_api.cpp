@@ -410,7 +410,8 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
     const int iters_per_warp = P.iterations * P.inner_iterations;
     const bool check = P.epsilon > 0.0 && iters_per_warp > 0;
     // convergence-checked path in fast math: speculative blocks (k_iterate_tbr MODE 1 / 2) instead of one launch per iteration
-    const bool spec = check && !P.exact_math && P.time_block != 1 && P.gamma == 0.0 && P.median_filtering <= 1 && tuning().spec != 0;
+    // (gamma != 0 -- round 6: the illumination channel runs the same speculative steps on its own kernels, tvl1_tbr_kernels.hip GAM)
+    const bool spec = check && !P.exact_math && P.time_block != 1 && P.median_filtering <= 1 && tuning().spec != 0;
     // control slots per pair: one per launch (S, P, X) and one error sum per iteration (E); both index spaces fit max(.,.)
     long long Q = (long long)ns * P.warps * iters_per_warp;
     std::vector<int> spec_plan[4];   // kernel block sizes of the speculative steps: first warp of a large level / of a small one / later warps / levels on the register-tile kernel
@@ -605,24 +606,24 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
             // Round 4 byte cuts of the fixed-work blocked path: (1) where every pass of this warp is the default T = 10 kernel, the
             // warp does not store |grad|^2 and the pass forms it from I1wx, I1wy (8 B/px per warp less through HBM, the same bits);
             // (2) the last pass of a scale does not store p (the next scale starts from p = 0; 16 B/px per scale).
-            const bool blocked_w = !check && !P.exact_math && P.time_block != 1 && !gam;
+            const bool blocked_w = !check && !P.exact_math && P.time_block != 1;
             std::vector<int> plan_w;
             bool nograd = false;
             if (blocked_w && !legacy_warp) {
                 const int mfw = P.median_filtering > 1 ? P.median_filtering : 0;
                 const int per = mfw ? P.inner_iterations : iters_per_warp;
                 plan_w.resize(per + 1);
-                plan_w.resize(tb_plan_level(g, per, P.time_block > 0 ? P.time_block : tb_max_block(), plan_w.data(), per));
+                plan_w.resize(tb_plan_level(g, per, P.time_block > 0 ? P.time_block : tb_max_block(), plan_w.data(), per, gam));
                 nograd = !plan_w.empty();
-                for (int v : plan_w) nograd = nograd && tb_nograd_ok(v, g);
+                for (int v : plan_w) nograd = nograd && (gam || tb_nograd_ok(v, g));   // the illumination channel's kernels never read the plane
             }
-            if (spec && !legacy_warp && !gam && P.median_filtering <= 1 && tb_spec_nograd_ok(g)) nograd = true;   // speculative steps: every block is a tbr launch
+            if (spec && !legacy_warp && P.median_filtering <= 1 && (gam || tb_spec_nograd_ok(g))) nograd = true;   // speculative steps: every block is a tbr launch
             float *grad_w = nograd ? nullptr : grad;
             pl.g = grad_w;
             // Round 5: a warp whose iterations are ONE pass of the default kernel runs inside that pass (producer waves, k_iterate_tbr
             // FW) -- no warp launch, no static planes through HBM
             const bool fast_w0 = !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT));
-            const bool fuse_w = blocked_w && !legacy_warp && nograd && plan_w.size() == 1 && P.median_filtering <= 1 && tuning().x_skip == 0 &&
+            const bool fuse_w = blocked_w && !gam && !legacy_warp && nograd && plan_w.size() == 1 && P.median_filtering <= 1 && tuning().x_skip == 0 &&
                                 tuning().warp_lds == 0 && !(wp == 0 && have_zoom) && tb_fused_ok(plan_w[0], g, sem, fast_w0);
             const bool warp_is_fused = !legacy_warp && tuning().x_skip == 0;
             const bool fast_w = !P.exact_math && (tuning().warp_fast > 0 || (tuning().warp_fast < 0 && sem == MI_SEM_CUDA_COMPAT));
@@ -645,7 +646,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 rc = next_event(&e0); if (rc) return rc;
                 MI_HIP_TRY(hipEventRecord(ln.ev_pool[e0], st));
             }
-            const bool blocked = !check && !P.exact_math && P.time_block != 1 && !gam;
+            const bool blocked = !check && !P.exact_math && P.time_block != 1;
             const bool exact_blocked = !check && P.exact_math && P.time_block != 1 && !gam && P.median_filtering <= 1 && tuning().exact_tb != 0;
             long long nlaunch = 0;
             const int mf = P.median_filtering > 1 ? P.median_filtering : 0;
@@ -655,7 +656,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // filter sits between outer iterations, so blocks never span more than inner_iterations
                 const int per = mf ? P.inner_iterations : iters_per_warp, nouter = mf ? P.iterations : 1;
                 std::vector<int> plan(per + 1);
-                const int nb = tb_plan_level(g, per, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), per);
+                const int nb = tb_plan_level(g, per, P.time_block > 0 ? P.time_block : tb_max_block(), plan.data(), per, gam);
                 for (int no = 0; no < nouter; ++no) {
                     if (mf && (rc = median_flow(mf, mu1, mu2, ln.scr[0], ln.scr[1], g, nullptr, cur, st))) return rc;
                     for (int k = 0; k < nb; ++k) {
@@ -686,7 +687,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // Speculative steps (k_iterate_tbr MODE 1): a launch runs a block of iterations recording their error sums; the next
                 // launch applies the reference's stopping rule to them and either builds on the block or replays the exact
                 // count from its input.  One settling launch ends the warp.  After convergence the remaining launches end at once.
-                const bool on_tiles = tile_eligible(g) && tuning().tile_spec != 0;
+                const bool on_tiles = !gam && tile_eligible(g) && tuning().tile_spec != 0;   // (the illumination channel has no register-tile kernel)
                 std::vector<int> plan = spec_plan[on_tiles ? 3 : wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
                 // the previous calc's count for this warp, where the host has seen it (polled host feedback): a first block of at most
                 // 4 / 7 iterations runs on tiles of that margin (k_iterate_tile M), and the first poll goes where that many iterations
@@ -736,6 +737,11 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 if (first_of_scale) {   // a replay of the scale's first block must see p = 0 in the input set as well
                     rc = zero_planes4(ln.pbuf[0], (size_t)g.ps * B, st);
                     if (rc) return rc;
+                    if (gam) {
+                        float *const p3[4] = {ln.pbuf[0][4], ln.pbuf[0][5], ln.pbuf[0][4], ln.pbuf[0][5]};
+                        rc = zero_planes4(p3, (size_t)g.ps * B, st);
+                        if (rc) return rc;
+                    }
                 }
                 int e_prev = 0;
                 // Host feedback (mi_tvl1_params.host_feedback): a call of one or two pairs reads the pairs' control slots back

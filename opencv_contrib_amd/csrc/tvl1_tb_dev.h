@@ -33,6 +33,13 @@ template <int PPL>
 struct Dyn {
     float u1[PPL], u2[PPL], p11[PPL], p12[PPL], p21[PPL], p22[PPL];
 };
+// gamma != 0 (illumination channel; cudaoptflow/src/cuda/tvl1flow.cu:209-288 u3 terms, :313-348 p31 / p32; CPU class
+// optflow/src/tvl1flow.cpp:1011-1038, 1105-1110, 1172-1178): the third component of a stage's state.  Kernels without the channel never
+// touch it and the registers do not exist.
+template <int PPL>
+struct Dyn3 {
+    float u3[PPL], p31[PPL], p32[PPL];
+};
 template <int PPL>
 struct Stat {  // static planes of one row: I1wx, I1wy, 1/grad, rho_c
     float ix[PPL], iy[PPL], rg[PPL], rc[PPL];

@@ -34,11 +34,20 @@
 namespace mi {
 namespace tvl1 {
 
-template <int PPL>
+template <int PPL, bool GAM = false>
 struct Slot {
     Dyn<PPL> d;
     Stat<PPL> s;
 };
+template <int PPL>
+struct Slot<PPL, true> {   // gamma != 0: the illumination channel's third component (GAM kernels)
+    Dyn<PPL> d;
+    Stat<PPL> s;
+    Dyn3<PPL> g;
+};
+// the third component of a register set, or nullptr in a kernel without the channel (the stage never dereferences it there)
+template <int PPL> __device__ __forceinline__ Dyn3<PPL> *g3(Slot<PPL, true> &x) { return &x.g; }
+template <int PPL> __device__ __forceinline__ Dyn3<PPL> *g3(Slot<PPL, false> &) { return nullptr; }
 
 // In-place stage.  negm1 = -(a != 0), m2 = (a != H), taum2 = taut * m2 are wave-uniform scalars.
 // ERR: also accumulate this iteration level's convergence error sum(du1^2 + du2^2) (optflow/src/tvl1flow.cpp:1096-1112 ==
@@ -51,24 +60,38 @@ struct Slot {
 // MK = false (JW = 4, interior blocks): no stage of the block sees row 0 or row H, so the three border scalars are the constants
 // -1, 1 and taut and the masked forms reduce to the same operations without them -- fma(-1, b, a) and a - b, fma(x, 1, y) and
 // x + y round once, identically: the planes are bit-identical to the masked form's.
-template <int PPL, bool ERR, int JW = 0, bool MK = true>
+// GAM (round 6): the illumination channel of gamma != 0 rides along -- A3 / B3 are the u3, p31, p32 of the same two register sets, G.gamma
+// the weight, G.eu3 = 1 where the convergence error includes (du3)^2 (CPU class, optflow/src/tvl1flow.cpp:1110) and 0 under cv::cuda's
+// rule (tvl1flow.cu:276-283), (xl3, xr3) the hand-over values of the joined form.  The threshold test keeps |grad|^2 = I1wx^2 + I1wy^2
+// (both references: no gamma^2 term), so fi is shared by the three components.
+struct GamK { float gamma, eu3, xl3, xr3; };
+template <int PPL, bool ERR, int JW = 0, bool MK = true, bool GAM = false>
 __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
                                         float m2, float taum2, float l_t, float theta, float taut, unsigned long long &acc, float es,
-                                        float xl1 = 0.f, float xl2 = 0.f, float xr1 = 0.f, float xr2 = 0.f)
+                                        float xl1 = 0.f, float xl2 = 0.f, float xr1 = 0.f, float xr2 = 0.f, Dyn3<PPL> *A3 = nullptr,
+                                        Dyn3<PPL> *B3 = nullptr, const GamK G = GamK{0.f, 0.f, 0.f, 0.f})
 {
-    float dx1[PPL], dx2[PPL];
+    float dx1[PPL], dx2[PPL], dx3[PPL];
     dx1[0] = A.p11[0] - (JW ? dpp_from_prev_fill(A.p11[PPL - 1], xl1) : dpp_from_prev(A.p11[PPL - 1]));
     dx2[0] = A.p21[0] - (JW ? dpp_from_prev_fill(A.p21[PPL - 1], xl2) : dpp_from_prev(A.p21[PPL - 1]));
+    if constexpr (GAM) dx3[0] = A3->p31[0] - (JW ? dpp_from_prev_fill(A3->p31[PPL - 1], G.xl3) : dpp_from_prev(A3->p31[PPL - 1]));
 #pragma unroll
-    for (int j = 1; j < PPL; ++j) { dx1[j] = A.p11[j] - A.p11[j - 1]; dx2[j] = A.p21[j] - A.p21[j - 1]; }
+    for (int j = 1; j < PPL; ++j) {
+        dx1[j] = A.p11[j] - A.p11[j - 1]; dx2[j] = A.p21[j] - A.p21[j - 1];
+        if constexpr (GAM) dx3[j] = A3->p31[j] - A3->p31[j - 1];
+    }
     const float r1 = JW ? dpp_from_next_fill(B.u1[0], xr1) : dpp_from_next(B.u1[0]);
     const float r2 = JW ? dpp_from_next_fill(B.u2[0], xr2) : dpp_from_next(B.u2[0]);
+    float r3 = 0.f;
+    if constexpr (GAM) r3 = JW ? dpp_from_next_fill(B3->u3[0], G.xr3) : dpp_from_next(B3->u3[0]);
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
         // ---- u_t(a)   (optflow/src/tvl1flow.cpp:989-1041, 1096-1112; TH written as clamp(-rho/grad, +-l_t))
         const float div1 = dx1[j] + (MK ? fmaf(negm1, B.p12[j], A.p12[j]) : A.p12[j] - B.p12[j]);
         const float div2 = dx2[j] + (MK ? fmaf(negm1, B.p22[j], A.p22[j]) : A.p22[j] - B.p22[j]);
-        const float rho = fmaf(st.ix[j], A.u1[j], fmaf(st.iy[j], A.u2[j], st.rc[j]));
+        float rho0 = st.rc[j];
+        if constexpr (GAM) rho0 = fmaf(G.gamma, A3->u3[j], rho0);   // optflow tvl1flow.cpp:1011 == tvl1flow.cu:233
+        const float rho = fmaf(st.ix[j], A.u1[j], fmaf(st.iy[j], A.u2[j], rho0));
         const float fi = __builtin_amdgcn_fmed3f(-rho * st.rg[j], -l_t, l_t);
         const float nu1 = fmaf(theta, div1, fmaf(fi, st.ix[j], A.u1[j]));
         const float nu2 = fmaf(theta, div2, fmaf(fi, st.iy[j], A.u2[j]));
@@ -87,9 +110,25 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
         B.p12[j] = fmaf(MK ? taum2 : taut, d1, B.p12[j]) * q1;
         B.p21[j] = fmaf(taut, u2x, B.p21[j]) * q2;
         B.p22[j] = fmaf(MK ? taum2 : taut, d2, B.p22[j]) * q2;
+        float e3sq = 0.f;
+        if constexpr (GAM) {
+            // the same update for (u3, p31, p32): d3 = fi * gamma (:1020-1033 == tvl1flow.cu:243-262), the dual step :1172-1178 == :341-346
+            const float div3 = dx3[j] + (MK ? fmaf(negm1, B3->p32[j], A3->p32[j]) : A3->p32[j] - B3->p32[j]);
+            const float nu3 = fmaf(theta, div3, fmaf(fi, G.gamma, A3->u3[j]));
+            const float n3 = (j + 1 < PPL) ? B3->u3[j + 1 < PPL ? j + 1 : j] : r3;
+            const float u3x = right_ok[j] ? n3 - B3->u3[j] : 0.f;
+            const float d3 = nu3 - B3->u3[j];
+            const float g3 = __builtin_amdgcn_sqrtf(MK ? fmaf(d3 * d3, m2, u3x * u3x) : d3 * d3 + u3x * u3x);
+            const float q3 = __builtin_amdgcn_rcpf(fmaf(taut, g3, 1.0f));
+            B3->p31[j] = fmaf(taut, u3x, B3->p31[j]) * q3;
+            B3->p32[j] = fmaf(MK ? taum2 : taut, d3, B3->p32[j]) * q3;
+            if (ERR) { const float e3 = nu3 - A3->u3[j]; e3sq = e3 * e3 * G.eu3; }
+            A3->u3[j] = nu3;
+        }
         if (ERR) {
             const float e1 = nu1 - A.u1[j], e2 = nu2 - A.u2[j];
-            acc += (unsigned long long)__float2uint_rn(fmaf(e1, e1, e2 * e2) * es);   // v_cvt_u32_f32 saturates: a term >= 256 px^2 only under-counts
+            const float et = GAM ? fmaf(e1, e1, e2 * e2) + e3sq : fmaf(e1, e1, e2 * e2);
+            acc += (unsigned long long)__float2uint_rn(et * es);   // v_cvt_u32_f32 saturates: a term >= 256 px^2 only under-counts
         }
         A.u1[j] = nu1;
         A.u2[j] = nu2;
@@ -187,8 +226,8 @@ __device__ __forceinline__ void str(float *rowp, unsigned xb, const float v[PPL]
 // (|p| <= 1 by construction of the dual update; v_cvt_pknorm_i16_f32, step 2^-15 ~ 3e-5): {p11, p12} in plane 0, {p21, p22} in plane
 // 2, 16 B per pixel and pass boundary less through HBM.  The raw dwords wait in the p11 / p21 registers of the set and are
 // unpacked when the row enters the pipeline (unpack_p16).
-template <int PPL, bool PZ, bool NG = false, bool P16 = false, int FW = 0>
-__device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const float *const u[2], const float *const p[4], int row,
+template <int PPL, bool PZ, bool NG = false, bool P16 = false, int FW = 0, bool GAM = false>
+__device__ __forceinline__ void load_row_r(Slot<PPL, GAM> &x, const TbArgs &A, const float *const u[3], const float *const p[6], int row,
                                            int H, unsigned xc)
 {
     const long long ro = (long long)min(max(row, 0), H - 1) * A.g.ld;   // wave-uniform
@@ -213,14 +252,24 @@ __device__ __forceinline__ void load_row_r(Slot<PPL> &x, const TbArgs &A, const 
 #pragma unroll
         for (int j = 0; j < PPL; ++j) x.d.p11[j] = x.d.p12[j] = x.d.p21[j] = x.d.p22[j] = 0.f;
     }
+    if constexpr (GAM) {
+        ldr<PPL>(x.g.u3, u[2] + ro, xc);
+        if (!PZ) {
+            ldr<PPL>(x.g.p31, p[4] + ro, xc);
+            ldr<PPL>(x.g.p32, p[5] + ro, xc);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) x.g.p31[j] = x.g.p32[j] = 0.f;
+        }
+    }
 }
 
 // Wave-constant context of the row loop (all scalars after inlining).
 template <int PPL>
 struct CtxR {
     TbArgs B;                 // plane pointers already offset to the pair
-    const float *uin[2], *pin[4];
-    float *uout[2], *pout[4];
+    const float *uin[3], *pin[6];     // [2], [4], [5]: the illumination channel (GAM kernels)
+    float *uout[3], *pout[6];
     float *ring;
     float *inbox;   // FW: this wave's inbox (FW_RING slots of {I1wx | I1wy | rho_c} x 64 columns), written by its producer wave
     int lane, H, ld, y0, y1, ystart, nsteps;
@@ -228,6 +277,7 @@ struct CtxR {
     bool st_ok, x0;   // x0: this lane holds column 0 (MODE 2)
     bool right_ok[PPL];
     float l_t, theta, taut;
+    float gamma, eu3;   // GAM: the channel's weight; 1 / 0 = the error sum includes (du3)^2 (CPU class) or not (cv::cuda)
     int nit;        // active stages (MODE 1: the length of the speculative block or of the replay; otherwise T)
 };
 
@@ -282,6 +332,9 @@ __device__ __forceinline__ void xwrite(unsigned slot, int data_off, int tag_off,
 // 38.2 KB of LDS per workgroup = four workgroups per CU like the independent-wave kernel).  s_waitcnt lgkmcnt(0) + s_barrier, NOT
 // __syncthreads: the latter also waits for the row prefetches and stores in flight (vmcnt).
 constexpr int XS2 = 16;
+// GAM: a slot is 32 bytes {p11, p21, u1, u2 | p31, u3, -, -}: the third component's two hand-over values behind the sixteen bytes of the
+// two-channel form (one more ds_read_b64 per stage, one more exec-masked ds_write_b32 per publish)
+__host__ __device__ constexpr int xs2_bytes(bool gam) { return gam ? 32 : XS2; }
 // waves of a joined group: JW = 1, 2: four (a 256-column strip); JW = 3: eight (512 columns: 492 owned instead of 2 x 236), barrier form
 __host__ __device__ constexpr int jw_waves(int JW) { return JW == 3 ? 8 : 4; }
 // Stages per barrier interval.  With a constant SKEW of XK stages between neighbouring waves (wave w runs XK * w stages behind wave 0:
@@ -292,7 +345,7 @@ __host__ __device__ constexpr int jw_waves(int JW) { return JW == 3 ? 8 : 4; }
 // its global index is a multiple of XK; the step index enters through the compile-time phase k of the unrolled block (the block's
 // first step n0 is a multiple of P, and P * T is a multiple of XK: checked in the kernel).
 __host__ __device__ constexpr int xk_stages(int T) { return T >= 10 && T % 5 == 0 ? 5 : T >= 4 ? 2 : 1; }
-__host__ __device__ constexpr int xarea2_bytes(int T) { return 2 * T * XS2; }
+__host__ __device__ constexpr int xarea2_bytes(int T, bool gam = false) { return 2 * T * xs2_bytes(gam); }
 __device__ __forceinline__ void xbarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void xread2(unsigned slot, float &l1, float &l2, float &r1, float &r2)
 {
@@ -307,6 +360,17 @@ __device__ __forceinline__ void xwrite2(bool on, unsigned addr, float a, float b
         f2 v; v.x = a; v.y = b;
         *reinterpret_cast<volatile MI_LDS f2 *>((lds_ptr)(unsigned long long)addr) = v;
     }
+}
+// GAM: the third component's pair {p31 from the left | u3 from the right} at +16 of the slot
+__device__ __forceinline__ void xread1g(unsigned slot, float &l3, float &r3)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = *reinterpret_cast<volatile MI_LDS f2 *>((lds_ptr)(unsigned long long)(slot + 16));
+    l3 = v.x; r3 = v.y;
+}
+__device__ __forceinline__ void xwrite1(bool on, unsigned addr, float a)
+{
+    if (on) *reinterpret_cast<volatile MI_LDS float *>((lds_ptr)(unsigned long long)addr) = a;
 }
 // JW == 4: the publish as an ORDINARY full-wave store -- the one lane that holds the boundary column writes to the neighbour's slot,
 // the other 63 to a dump area behind the hand-over areas (addresses prepared per lane once): no exec mask, no branch, so a whole
@@ -583,10 +647,12 @@ __device__ __forceinline__ void fw_produce_staged(const TbArgs &A, float *inbox,
 // Pipeline step with phase k (= step index mod P): every register-set index below is a compile-time constant.
 // No early exit inside the unrolled block (an exit per step keeps every register set alive across P merge points): the last
 // block may run up to P-1 steps past the band end; those rows are clamped loads whose results are never stored.
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int FW, int k>
-__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T], Xchg &x)
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int FW, bool GAM, int k>
+__device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL, GAM> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T], Xchg &x)
 {
     constexpr bool JF = jw_fast(JW);
+    constexpr int XSg = xs2_bytes(GAM);          // bytes per hand-over slot and parity (barrier forms)
+    constexpr int XAg = xarea2_bytes(T, GAM);    // bytes per wave's hand-over area
     constexpr int P = T + 1 + PF;
     constexpr int K = T > 2 ? T - 1 : 1;
     const int n = n0 + k;
@@ -612,7 +678,8 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         if (JF) asm volatile("" : "+v"(x.pub_r));
         // the row entering the pipeline: its p11, p21 of lane 63 are the right neighbour's stage-0 input of this step
         if (JF) xwrite2f(x.pub_r, X[k].d.p11[0], X[k].d.p21[0]);
-        else xwrite2(x.on_r, x.own + xarea2_bytes(T), X[k].d.p11[0], X[k].d.p21[0]);
+        else xwrite2(x.on_r, x.own + XAg, X[k].d.p11[0], X[k].d.p21[0]);
+        if constexpr (GAM) xwrite1(x.on_r, x.own + XAg + 16, X[k].g.p31[0]);
     } else if (JW) {
         vtag_r = (unsigned)(n + 1); vtag_l = (unsigned)(n + 2);
         asm volatile("" : "+v"(vtag_r), "+v"(vtag_l), "+v"(x.own));   // one VGPR copy per step, not one v_mov per store
@@ -621,7 +688,7 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
         xexpect = ((unsigned)(n + 1) & 0xffffu) * x.mul;
     }
 #ifndef TBR_X_NOLOAD   // timing experiments only (wrong results): no row loads after the prologue
-    load_row_r<PPL, PZ, NG, P16, FW>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
+    load_row_r<PPL, PZ, NG, P16, FW, GAM>(X[(k + PF) % P], c.B, c.uin, c.pin, r0 + PF, c.H, c.xc);
 #else
     X[(k + PF) % P] = X[k];
 #endif
@@ -663,14 +730,22 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
                 // pair, i.e. of the whole workgroup); a skipped stage hands over what it holds -- its unmodified input
                 if ((k * T + t) % xk_stages(T) == 0) xbarrier();
                 float l1, l2, r1, r2;
-                xread2(x.own + t * 2 * XS2, l1, l2, r1, r2);
+                GamK G{c.gamma, c.eu3, 0.f, 0.f};
+                xread2(x.own + t * 2 * XSg, l1, l2, r1, r2);
+                if constexpr (GAM) xread1g(x.own + t * 2 * XSg, G.xl3, G.xr3);
                 Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
-                if (t < c.nit) stage_r<PPL, true, 1>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, acc[t], es, l1, l2, r1, r2);
-                if (t + 1 < T) xwrite2(x.on_r, x.own + xarea2_bytes(T) + (t + 1) * 2 * XS2, SB.p11[0], SB.p21[0]);
-                xwrite2(x.on_l, x.pub_l + t * 2 * XS2 + 8, SA.u1[0], SA.u2[0]);
+                Dyn3<PPL> *const SA3 = g3(X[(k - t + P) % P]), *const SB3 = g3(X[(k - t - 1 + 2 * P) % P]);
+                if (t < c.nit) stage_r<PPL, true, 1, true, GAM>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, acc[t], es, l1, l2, r1, r2, SA3, SB3, G);
+                if (t + 1 < T) xwrite2(x.on_r, x.own + XAg + (t + 1) * 2 * XSg, SB.p11[0], SB.p21[0]);
+                xwrite2(x.on_l, x.pub_l + t * 2 * XSg + 8, SA.u1[0], SA.u2[0]);
+                if constexpr (GAM) {
+                    if (t + 1 < T) xwrite1(x.on_r, x.own + XAg + (t + 1) * 2 * XSg + 16, SB3->p31[0]);
+                    xwrite1(x.on_l, x.pub_l + t * 2 * XSg + 20, SA3->u3[0]);
+                }
             } else if (t < c.nit)
-                stage_r<PPL, true>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
-                                   c.taut, acc[t], es);
+                stage_r<PPL, true, 0, true, GAM>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
+                                                 c.taut, acc[t], es, 0.f, 0.f, 0.f, 0.f, g3(X[(k - t + P) % P]), g3(X[(k - t - 1 + 2 * P) % P]),
+                                                 GamK{c.gamma, c.eu3, 0.f, 0.f});
         } else if (MODE == 2) {
             if constexpr (PPL == 1)
                 stage_r_exact(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok[0], c.x0, a == 0, a == c.H, c.l_t, c.theta, c.taut);
@@ -695,14 +770,21 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             // before the barrier just passed -- see fw_produce); they land in the register set that row's u, p already wait in
             if constexpr (FW != 0) if (t == 0) fw_inbox_get<PPL>(c.inbox + ((n + 1) & (FW_RING - 1)) * FW_SLOT, c.lane, X[(k + 1) % P].s);
             float l1, l2, r1, r2;
-            xread2(x.own + t * 2 * XS2, l1, l2, r1, r2);
+            GamK G{c.gamma, 0.f, 0.f, 0.f};
+            xread2(x.own + t * 2 * XSg, l1, l2, r1, r2);
+            if constexpr (GAM) xread1g(x.own + t * 2 * XSg, G.xl3, G.xr3);
             unsigned long long dummy = 0;
             Dyn<PPL> &SA = X[(k - t + P) % P].d, &SB = X[(k - t - 1 + 2 * P) % P].d;
-            stage_r<PPL, false, 1>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, dummy, 0.f, l1, l2, r1, r2);
+            Dyn3<PPL> *const SA3 = g3(X[(k - t + P) % P]), *const SB3 = g3(X[(k - t - 1 + 2 * P) % P]);
+            stage_r<PPL, false, 1, true, GAM>(SA, SB, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta, c.taut, dummy, 0.f, l1, l2, r1, r2, SA3, SB3, G);
             // p_t(row a-1) of lane 63 -> stage t+1 of the right neighbour (the next area), this step; u_t(row a) of lane 0 -> stage t
             // of the left neighbour, NEXT step (pub_l points at its slots of the other parity)
-            if (t + 1 < T) xwrite2(x.on_r, x.own + xarea2_bytes(T) + (t + 1) * 2 * XS2, SB.p11[0], SB.p21[0]);
-            xwrite2(x.on_l, x.pub_l + t * 2 * XS2 + 8, SA.u1[0], SA.u2[0]);
+            if (t + 1 < T) xwrite2(x.on_r, x.own + XAg + (t + 1) * 2 * XSg, SB.p11[0], SB.p21[0]);
+            xwrite2(x.on_l, x.pub_l + t * 2 * XSg + 8, SA.u1[0], SA.u2[0]);
+            if constexpr (GAM) {
+                if (t + 1 < T) xwrite1(x.on_r, x.own + XAg + (t + 1) * 2 * XSg + 16, SB3->p31[0]);
+                xwrite1(x.on_l, x.pub_l + t * 2 * XSg + 20, SA3->u3[0]);
+            }
         } else if (JW) {
             // consume the slot read ahead for this stage (re-read until both writers have delivered), read ahead for the next one
             // (stage 0 of the next step lives in the other buffer), compute, hand the new boundary values over
@@ -728,13 +810,14 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
             xwrite(x.pub_l + t * XS, 8, 18, SA.u1[0], SA.u2[0], vtag_l);
         } else {
             unsigned long long dummy = 0;
-            stage_r<PPL, false>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
-                                c.taut, dummy, 0.f);
+            stage_r<PPL, false, 0, true, GAM>(X[(k - t + P) % P].d, X[(k - t - 1 + 2 * P) % P].d, st, c.right_ok, negm1, m2, taum2, c.l_t, c.theta,
+                                              c.taut, dummy, 0.f, 0.f, 0.f, 0.f, 0.f, g3(X[(k - t + P) % P]), g3(X[(k - t - 1 + 2 * P) % P]),
+                                              GamK{c.gamma, 0.f, 0.f, 0.f});
         }
     }
     if (JW >= 2) {   // the slots of the other parity for the next step (the two parities of a stage are adjacent: one address bit)
-        x.own ^= XS2; x.pub_l ^= XS2;
-        if (JF) x.pub_r ^= XS2;
+        x.own ^= XSg; x.pub_l ^= XSg;
+        if (JF) x.pub_r ^= XSg;
     } else if (JW) {   // the other buffer for the next step
         const int d = (n & 1) ? -T * XS : T * XS;
         x.own += d; x.pub_r += d; x.pub_l -= d;   // pub_l addresses the left neighbour's buffer of the NEXT step: opposite phase
@@ -769,15 +852,23 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 
                 str<PPL>(c.pout[2] + ro, xb, r.p21);
                 str<PPL>(c.pout[3] + ro, xb, r.p22);
             }
+            if constexpr (GAM) {
+                const Dyn3<PPL> &r3 = X[(k - T + 2 * P) % P].g;
+                str<PPL>(c.uout[2] + ro, xb, r3.u3);
+                if (!c.B.skip_p_out) {
+                    str<PPL>(c.pout[4] + ro, xb, r3.p31);
+                    str<PPL>(c.pout[5] + ro, xb, r3.p32);
+                }
+            }
         }
     }
     slot0 = (slot0 + 1 == K) ? 0 : slot0 + 1;
 }
-template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int FW, int... Ks>
-__device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
+template <int T, int PPL, bool PZ, int PF, int MODE, int JW, bool MK, bool NG, bool P16, int FW, bool GAM, int... Ks>
+__device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL, GAM> (&X)[T + 1 + PF], int n0, int &slot0, unsigned long long (&acc)[T],
                                         Xchg &x, std::integer_sequence<int, Ks...>)
 {
-    (step_r<T, PPL, PZ, PF, MODE, JW, MK, NG, P16, FW, Ks>(c, X, n0, slot0, acc, x), ...);
+    (step_r<T, PPL, PZ, PF, MODE, JW, MK, NG, P16, FW, GAM, Ks>(c, X, n0, slot0, acc, x), ...);
 }
 
 // MODE 0: T iterations, fixed work.
@@ -796,9 +887,12 @@ __device__ __forceinline__ void steps_r(const CtxR<PPL> &c, Slot<PPL> (&X)[T + 1
 //   edges (236 of 256 lanes own a column instead of 44 of 64: 33 instead of 44 waves per 1080p row band).  At the three inner
 //   seams the neighbouring waves hand each other the two values a stage needs from across the seam through LDS (Xchg above).  The
 //   arithmetic of an owned pixel is the same operations on the same values as in the independent-wave form: bit-identical planes.
-template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false, int FW = 0>
+// GAM (round 6): gamma != 0 -- the illumination channel (u3, p31, p32) rides through the same pipeline: nine instead of six dynamic
+//   registers per set, 32-byte hand-over slots, three more loads and stores per row; always without a |grad|^2 plane (NG).
+template <int T, int PPL, bool PZ, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false, int FW = 0, bool GAM = false>
 __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tbr(TbArgs A)
 {
+    static_assert(!GAM || (NG && !P16 && !FW && (JW == 0 || JW == 2) && MODE != 2), "illumination channel: independent or barrier-joined waves, fast math, no |grad|^2 plane");
     static_assert(!FW || (JW == 2 && MODE == 0 && NG && !P16 && PPL == 1 && T == 10), "fused warp: the default joined-wave fixed-work kernel only");
     static_assert(!JW || (PPL == 1 && T > 2 && (MODE == 0 || (MODE == 1 && JW >= 2 && JW != 4))), "joined waves: 1 px per lane; the speculative steps in the barrier form only");
     static_assert(JW < 2 || (((T + 1 + PF) * T) % xk_stages(T) == 0 && T >= 2 * xk_stages(T)), "barrier intervals must tile the unrolled block and leave the right neighbour a full interval");
@@ -844,11 +938,11 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
         // behind the NW rings: 4 areas of T stages x 2 parities (of the step) x 16 bytes, all zero at the start: a wave without a left
         // / right neighbour keeps reading zeros there -- the fill of the independent-wave form -- and parity 0 holds the all-zero u of
         // "step -1".  Slot of (stage t, parity q) = area + t * 32 + q * 16: the step's parity is ONE address bit (areas are 32-byte aligned)
-        constexpr int XA = xarea2_bytes(T);
+        constexpr int XA = xarea2_bytes(T, GAM);
         const unsigned xb = (unsigned)(unsigned long long)(lds_ptr)(lds + NW * (K * 256 * PPL));
         const bool has_left = wave > 0, has_right = wave < NW - 1 && xw + 64 < W;
         x.own = xb + wave * XA;                         // parity 0; the right neighbour's area is own + XA (lane 63 of a wave that has one)
-        x.pub_l = xb + (wave - 1) * XA + XS2;           // the left neighbour's slots of step 1 (parity 1); lane 0 of a wave with a left neighbour only
+        x.pub_l = xb + (wave - 1) * XA + xs2_bytes(GAM);   // the left neighbour's slots of step 1 (parity 1); lane 0 of a wave with a left neighbour only
         x.on_r = has_right && c.lane == 63;
         x.on_l = has_left && c.lane == 0;
         if (FW && threadIdx.x < 128) (lds + NW * (K * 256 * PPL) + NW * XA / 4 + NW * FW_RING * FW_SLOT)[threadIdx.x] = A.ftab[threadIdx.x];
@@ -918,22 +1012,31 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
     c.uout[0] = A.pl.u[cur ^ 1][0] + pb; c.uout[1] = A.pl.u[cur ^ 1][1] + pb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { c.pin[i] = A.pl.p[cur][i] + pb; c.pout[i] = A.pl.p[cur ^ 1][i] + pb; }
+    c.uin[2] = nullptr; c.uout[2] = nullptr; c.pin[4] = c.pin[5] = nullptr; c.pout[4] = c.pout[5] = nullptr;
+    c.gamma = 0.f; c.eu3 = 0.f;
+    if constexpr (GAM) {
+        c.uin[2] = A.pl.u[cur][2] + pb; c.uout[2] = A.pl.u[cur ^ 1][2] + pb;
+#pragma unroll
+        for (int i = 4; i < 6; ++i) { c.pin[i] = A.pl.p[cur][i] + pb; c.pout[i] = A.pl.p[cur ^ 1][i] + pb; }
+        c.gamma = A.pl.gamma; c.eu3 = A.pl.err_u3 ? 1.f : 0.f;
+    }
     c.B = A;
     if (!FW) { c.B.pl.ix += pb; c.B.pl.iy += pb; if (!NG) c.B.pl.g += pb; c.B.pl.rc += pb; }
     c.l_t = A.l_t; c.theta = A.theta; c.taut = A.taut;
 
-    Slot<PPL> X[P];
+    Slot<PPL, GAM> X[P];
 #pragma unroll
     for (int i = 0; i < P; ++i)
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
             X[i].d.u1[j] = X[i].d.u2[j] = X[i].d.p11[j] = X[i].d.p12[j] = X[i].d.p21[j] = X[i].d.p22[j] = 0.f;
             X[i].s.ix[j] = X[i].s.iy[j] = X[i].s.rg[j] = X[i].s.rc[j] = 0.f;
+            if constexpr (GAM) X[i].g.u3[j] = X[i].g.p31[j] = X[i].g.p32[j] = 0.f;
         }
     for (int k = 0; k < K; ++k) lds_put<PPL>(c.ring + k * (256 * PPL), c.lane, X[0].s);
 
 #pragma unroll
-    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ, NG, P16, FW>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
+    for (int k = 0; k < PF; ++k) load_row_r<PPL, PZ, NG, P16, FW, GAM>(X[k], c.B, c.uin, c.pin, c.ystart + k, c.H, c.xc);
     if constexpr (FW != 0) {   // the barrier that opens the pipeline (fw_produce): rows 0 and 1 are in the inbox; row 0 enters at step 0
         xbarrier();
         fw_inbox_get<PPL>(c.inbox, c.lane, X[0].s);
@@ -951,9 +1054,9 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
             // the workgroup: they share the band)
             const int ra = c.ystart + n0 - (T - 1), rb = c.ystart + n0 + P - 1;
             const bool plain = (ra > 0 || rb < 0) && (ra > c.H || rb < c.H);
-            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false, NG, P16, FW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
+            if (plain) { steps_r<T, PPL, PZ, PF, MODE, JW, false, NG, P16, FW, GAM>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{}); continue; }
         }
-        steps_r<T, PPL, PZ, PF, MODE, JW, true, NG, P16, FW>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
+        steps_r<T, PPL, PZ, PF, MODE, JW, true, NG, P16, FW, GAM>(c, X, n0, slot0, acc, x, std::make_integer_sequence<int, P>{});
     }
     if (JW >= 2 && xk_stages(T) > 1)   // ... and keeps the others company for as many at the end (every live wave passes the same number)
         for (int i = wave; i < NW - 1; ++i) xbarrier();
@@ -970,7 +1073,7 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
     }
 }
 
-template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false, int FW = 0>
+template <int T, int PPL, int WPS, int PF, int MODE, int JW = 0, bool NG = false, bool P16 = false, int FW = 0, bool GAM = false>
 static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
 {
     constexpr int M = (T + PPL - 1) / PPL * PPL;
@@ -983,28 +1086,28 @@ static int launch_tbr(const TbArgs &A0, bool pz, hipStream_t s)
     // JW: a workgroup is one band of a 256-column strip; otherwise four consecutive bands of a 64-column strip
     const dim3 grid(A.nstrips, JW ? div_up(A.g.h, A.rows_per_band) : div_up(div_up(A.g.h, A.rows_per_band), 4), A.g.batch);
     constexpr size_t lds_bytes = (size_t)NW * (T > 2 ? T - 1 : 1) * 256 * PPL * sizeof(float) +
-                                 (JW >= 2 ? NW * xarea2_bytes(T) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0) +
+                                 (JW >= 2 ? NW * xarea2_bytes(T, GAM) + (jw_fast(JW) ? xdump4_bytes(T) : 0) : JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0) +
                                  (FW ? (fw_lds_floats(NW) + (FW_STAGE ? fws_lds_floats(NW) : 0)) * sizeof(float) : 0);
     constexpr int NTHREADS = 64 * NW * (FW ? 2 : 1);
     // once per instantiation (thread-safe function-local static), result checked on every launch
     static const hipError_t attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16, FW, GAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            e = hipFuncSetAttribute((const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW, GAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         return e;
     }();
     MI_HIP_TRY(attr_rc);
     if (tuning().tb_verbose) {
         static const int nb = [] {
             int n = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW>, NTHREADS, lds_bytes);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW, GAM>, NTHREADS, lds_bytes);
             fprintf(stderr, "[tbr] T=%d ppl=%d wps=%d pf=%d jw=%d lds=%zu B/block -> %d resident blocks/CU\n", T, PPL, WPS, PF, JW, lds_bytes, n);
             return n;
         }();
         (void)nb;
     }
-    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16, FW>), grid, dim3(NTHREADS), lds_bytes, s, A);
-    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW>), grid, dim3(NTHREADS), lds_bytes, s, A);
+    if (pz) hipLaunchKernelGGL((k_iterate_tbr<T, PPL, true, WPS, PF, MODE, JW, NG, P16, FW, GAM>), grid, dim3(NTHREADS), lds_bytes, s, A);
+    else hipLaunchKernelGGL((k_iterate_tbr<T, PPL, false, WPS, PF, MODE, JW, NG, P16, FW, GAM>), grid, dim3(NTHREADS), lds_bytes, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -1016,6 +1119,7 @@ struct TbrEntry {
     int T, PPL, WPS, PF, PLAN;
     TbLaunchFn launch, spec;
     int JW;   // 1 / 2: joined waves (a workgroup = one band of a 256-column strip), hand-over by tags / by one barrier per stage
+    bool GAM; // the kernel carries the illumination channel (gamma != 0)
 };
 #define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr, 0}
 // joined waves: the hand-over registers cost 14 VGPRs (3 waves/SIMD), rings + hand-over areas 40.7 KB of LDS = 3 workgroups per CU
@@ -1033,6 +1137,17 @@ static const TbrEntry g_tbr_ng = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, 
 // CONSUMER waves per SIMD is what the band planner fills): [0] the CPU class's arithmetic, tap-by-tap sums; [1] cv::cuda's, separable sums
 static const TbrEntry g_tbr_fw[] = {{10, 1, 4, 2, 2, launch_tbr<10, 1, 4, 2, 0, 2, true, false, 1>, nullptr, 2},
                                     {10, 1, 4, 2, 2, launch_tbr<10, 1, 4, 2, 0, 2, true, false, 2>, nullptr, 2}};
+// gamma != 0 (round 6): the blocked kernel with the illumination channel -- nine dynamic registers per set (T = 10:
+// three waves/SIMD), always without a |grad|^2 plane.  Blocks of 10 and 5 as joined waves, 2 and 1 as independent waves (any iteration
+// count decomposes greedily: tb_plan_gam)
+// (T = 10 with ONE prefetched row: 163 VGPRs = three waves/SIMD without scratch; with two it is 168 + 12 spilled dwords)
+static const TbrEntry g_tbr_gam[] = {{10, 1, 3, 1, 3, launch_tbr<10, 1, 3, 1, 0, 2, true, false, 0, true>, nullptr, 2, true},
+                                     {5, 1, 4, 2, 3, launch_tbr<5, 1, 4, 2, 0, 2, true, false, 0, true>, nullptr, 2, true},
+                                     {2, 1, 6, 2, 6, launch_tbr<2, 1, 6, 2, 0, 0, true, false, 0, true>, nullptr, 0, true},
+                                     {1, 1, 8, 2, 8, launch_tbr<1, 1, 8, 2, 0, 0, true, false, 0, true>, nullptr, 0, true}};
+// ... and its speculative steps (convergence-checked path)
+static const TbrEntry g_spec_gam[] = {{10, 1, 2, 2, 2, nullptr, launch_tbr<10, 1, 2, 2, 1, 2, true, false, 0, true>, 2, true},
+                                      {5, 1, 3, 2, 2, nullptr, launch_tbr<5, 1, 3, 2, 1, 2, true, false, 0, true>, 2, true}};
 static const TbrEntry g_tbr_ng16 = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true, true>, nullptr, 2};   // + p as snorm16 between passes (opt-in)
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
@@ -1112,8 +1227,22 @@ int tb_plan(int n, int cap, int *blocks, int max_blocks)
     return k;
 }
 
-int tb_plan_level(const Geo &g, int n, int cap, int *blocks, int max_blocks)
+// gamma != 0: greedy blocks of the four lengths the channel's kernels exist in (g_tbr_gam)
+int tb_plan_gam(int n, int cap, int *blocks, int max_blocks)
 {
+    int k = 0;
+    for (int left = n; left > 0 && k < max_blocks;) {
+        int t = 1;
+        for (const TbrEntry &e : g_tbr_gam) if (e.T <= left && e.T <= cap && e.T > t) t = e.T;
+        blocks[k++] = t;
+        left -= t;
+    }
+    return k;
+}
+
+int tb_plan_level(const Geo &g, int n, int cap, int *blocks, int max_blocks, bool gam)
+{
+    if (gam) return tb_plan_gam(n, cap, blocks, max_blocks);   // the channel has no register-tile kernel: every level streams
     if (!tile_eligible(g) || tuning().tb_force) return tb_plan(n, cap, blocks, max_blocks);
     // register-tile kernel: any block length up to its margin costs one launch; fewest launches win
     int k = 0;
@@ -1137,7 +1266,7 @@ static int plan_band_rows(const TbrEntry &e, const Geo &g)
     int wps = e.PLAN;
     const int ring_slots = T > 2 ? T - 1 : 1;
     const int nw = e.JW ? jw_waves(e.JW) : 4;
-    int lds_blocks = (160 * 1024) / (ring_slots * nw * 256 * ppl * 4 + (e.JW >= 2 ? nw * xarea2_bytes(T) + (jw_fast(e.JW) ? xdump4_bytes(T) : 0) : e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
+    int lds_blocks = (160 * 1024) / (ring_slots * nw * 256 * ppl * 4 + (e.JW >= 2 ? nw * xarea2_bytes(T, e.GAM) + (jw_fast(e.JW) ? xdump4_bytes(T) : 0) : e.JW ? 4 * (xarea_bytes(T) + xdump_bytes(T)) : 0));
     lds_blocks = lds_blocks * nw / 4;   // in units of four-wave workgroups (= waves per SIMD)
     if (wps > lds_blocks) wps = lds_blocks;
     if (tn.tb_plan_wps > 0) wps = tn.tb_plan_wps;
@@ -1219,6 +1348,18 @@ int iterate_tb_fused(int semantics, const float *I0, const float *I1, const floa
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s, bool skip_p_out)
 {
+    if (pl.gamma != 0.f) {   // the illumination channel: its own kernels (no |grad|^2 plane read, whether or not the warp stored one)
+        const TbrEntry *e = nullptr;
+        for (const TbrEntry &c : g_tbr_gam) if (c.T == T) e = &c;
+        if (!e) { set_error("gamma != 0: unsupported time block %d", T); return MI_ERR_BAD_ARG; }
+        MI_REQUIRE(pl.u[0][2] && pl.u[1][2] && pl.p[0][4] && pl.p[0][5] && pl.p[1][4] && pl.p[1][5], MI_ERR_BAD_ARG, "gamma != 0 needs the u3 / p31 / p32 planes");
+        TbArgs A;
+        memset(&A, 0, sizeof(A));
+        A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur;
+        A.skip_p_out = skip_p_out ? 1 : 0;
+        A.rows_per_band = rows_per_band > 0 ? rows_per_band : plan_band_rows(*e, g);
+        return e->launch(A, p_zero, s);
+    }
     if (rows_per_band == 0 && tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force) {
         MI_REQUIRE(pl.g, MI_ERR_BAD_ARG, "the register-tile kernel needs the |grad|^2 plane");
         return iterate_tile(-1, T, pl, g, l_t, theta, taut, p_zero, cur, s);
@@ -1281,10 +1422,12 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
 {
     // small levels: the same step on register tiles (serial depth of a launch = its iterations, not the image height); integer
     // error sums and identical per-pixel arithmetic => the same decisions and the same flows as the streaming kernel
-    if (tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
+    if (pl.gamma == 0.f && tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
         return iterate_tile_spec(T, pl, g, l_t, theta, taut, ctl, sk, e0, s);
     const TbrEntry *e = nullptr;
-    if (!pl.g) {
+    if (pl.gamma != 0.f) {
+        for (const TbrEntry &c : g_spec_gam) if (c.T == T) e = &c;
+    } else if (!pl.g) {
         MI_REQUIRE(tb_spec_nograd_ok(g), MI_ERR_BAD_ARG, "no |grad|^2 plane, but the speculative kernel of this launch needs one");
         for (const TbrEntry &c : g_spec_jw_ng) if (c.T == T) e = &c;
     } else if (tuning().tb_jw >= 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }

@@ -184,6 +184,11 @@ class TVL1MultiDevice:
         capi.check(capi.lib().mi_tvl1_multi_transport(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    @staticmethod
+    def transportWhy():
+        """Why the most recent link of this process fell back to peer copies ("" if none did)."""
+        return (capi.lib().mi_tvl1_multi_transport_why() or b"").decode()
+
     def calc_batch(self, I0s, I1s, flows=None):
         """All tensors on the root device.  Synchronous: earlier work on the inputs must be complete (synchronised here)."""
         import torch

@@ -75,6 +75,27 @@ def test_tvl1_1080p_cuda_semantics_against_its_oracle(gpu, oracle):
     assert synth.ccorr_dissimilarity(flow, ref) <= 1e-4
 
 
+@pytest.mark.parametrize("sem", [0, 1], ids=["cpu_class", "cuda_class"])
+def test_tvl1_1080p_gamma1_against_oracle(gpu, oracle, sem):
+    """The other half of the reference's TV-L1 test matrix -- Gamma(1.0), cudaoptflow/test/test_optflow.cpp:451,530-532 -- at the
+    BASELINE size on the path a default-constructed object runs since round 6: the blocked kernel with the illumination channel
+    (k_iterate_tbr GAM; tvl1flow.cu:209-288 u3 terms, :313-348 p31 / p32).  A brightness change between the frames exercises u3."""
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(1080, 1920, seed=1234)
+    I1 = np.clip(I1 * 1.05 + 0.02, 0, 1).astype(np.float32)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0, gamma=1.0, semantics=sem))
+    ref0 = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=10, epsilon=0.0, gamma=0.0, semantics=sem))
+    assert np.sqrt(((ref - ref0) ** 2).sum(-1)).mean() > 1e-2, "gamma has no effect on this input"
+    flow = N(cuda.OpticalFlowDual_TVL1.create(iterations=10, epsilon=0.0, gamma=1.0, semantics=sem).calc(T(I0, gpu), T(I1, gpu)))
+    assert np.isfinite(flow).all()
+    d = np.sqrt(((flow - ref) ** 2).sum(-1))
+    assert d.mean() <= 5e-3, d.mean()
+    assert synth.ccorr_dissimilarity(flow, ref) <= 1e-4       # the reference accepts 4e-3 (test_optflow.cpp:465)
+    assert (d <= 0.02).mean() >= 0.985
+    # gamma = 1 with the illumination change modelled recovers the analytic field better than gamma = 0 does on the same frames
+    assert synth.epe(flow, gt) < synth.epe(ref0, gt) + 0.02
+
+
 def test_tvl1_batch_of_64_equals_64_single_calcs(gpu):
     """configs[4]: one GPU's share of the 512-pair batch.  64 distinct 1080p pairs (4 generated pairs under flips and rolls)
     through ONE calc_batch (two internal lanes of 32) against 64 calc() calls of another object: bit-identical flows."""

@@ -17,6 +17,14 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 RECORDS = [os.path.join(ROOT, "profiles", d, "bench.json") for d in ("r11z", "r12z")]
 
 
+def _last_record():
+    """The newest tracked bench record; the tests that need one SKIP where profiles/ did not travel with the tree."""
+    have = [p for p in RECORDS if os.path.exists(p)]
+    if not have:
+        pytest.skip("no tracked bench record under profiles/ (measurement files absent)")
+    return json.load(open(have[-1]))
+
+
 def _strict(line):
     def bad(x):
         raise ValueError("non-finite constant " + x)
@@ -54,7 +62,7 @@ def test_compact_line_of_a_real_record(path):
 
 
 def test_compact_line_survives_a_hostile_record(monkeypatch):
-    out = json.load(open([p for p in RECORDS if os.path.exists(p)][-1]))
+    out = _last_record()
     out["variants"] = {("variant_%03d_" % i) + "x" * 80: {"pairs_per_s": float(i)} for i in range(400)}
     out["secondary"]["surf_4k_thr400"]["roofline"]["bound"] = "y" * 5000
     out["roofline"]["kernel"] = "k" * 10000
@@ -72,7 +80,7 @@ def test_compact_line_survives_a_hostile_record(monkeypatch):
 
 
 def test_emit_prints_exactly_one_stdout_line_and_writes_the_long_form(tmp_path, monkeypatch):
-    out = json.load(open([p for p in RECORDS if os.path.exists(p)][-1]))
+    out = _last_record()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     so, se = io.StringIO(), io.StringIO()
     with redirect_stdout(so), redirect_stderr(se):
