@@ -64,11 +64,8 @@ int nccl_rc(int e, const char *what)
 // root's half of every send / recv pair is enqueued on, and the worker's device for restoring the thread's device.  One thread -- the
 // worker's -- drives both ranks, so both halves of a chunk's transfers sit in ONE ncclGroup (the documented single-thread,
 // multi-device pattern).
-// Every link shares the ROOT device: communicator creation on it, and the ncclGroupStart .. ncclGroupEnd brackets that enqueue on its
-// per-link streams, are serialised process-wide (RCCL makes no progress guarantee for concurrent ncclCommInitAll on one device, nor for
-// concurrent groups from several threads that all contain that device).  Only the ENQUEUE is serialised -- a bracket returns as soon as the
-// transfers are queued; the transfers of different links still overlap on their own streams.
-std::mutex g_root_mu;
+// (Every link shares the ROOT device: link_create and the ncclGroupStart .. ncclGroupEnd brackets are serialised process-wide by the
+// state machine, tvl1_multi_sm.h root_mu -- ADVICE r05.)
 // why the most recent link fell back to peer copies ("" = none did); mi_tvl1_multi_transport_why
 std::mutex g_why_mu;
 std::string g_link_why;
@@ -127,7 +124,6 @@ struct HipBackend {
         L->root = root; L->dev = dev;
         void *comms[2] = {nullptr, nullptr};
         const int devs[2] = {root, dev};
-        std::lock_guard<std::mutex> lk(g_root_mu);   // one communicator at a time on the root device
         if (const int e = R.CommInitAll(comms, 2, devs)) {   // not fatal: the pair keeps its peer copies; the reason is kept (mi_tvl1_multi_transport_why)
             char buf[256];
             snprintf(buf, sizeof buf, "ncclCommInitAll({%d, %d}) failed: %s", root, dev, R.GetErrorString ? R.GetErrorString(e) : "RCCL error");
@@ -164,25 +160,13 @@ struct HipBackend {
         const int rc2 = HB(hipSetDevice(L->dev));
         return rc ? rc : rc2;
     }
-    // the bracket holds g_root_mu from GroupStart to GroupEnd (same thread: the worker's); link_end is called for every link_begin that
-    // returned MI_OK, whatever happened to the planes in between (tvl1_multi_sm.h)
-    static int link_begin(void *l)
-    {
-        Link *L = (Link *)l;
-        g_root_mu.lock();
-        const int rc = NB(rccl().GroupStart());
-        L->in_group = rc == MI_OK;
-        if (!L->in_group) g_root_mu.unlock();
-        return rc;
-    }
+    static int link_begin(void *l) { Link *L = (Link *)l; const int rc = NB(rccl().GroupStart()); L->in_group = rc == MI_OK; return rc; }
     static int link_end(void *l)
     {
         Link *L = (Link *)l;
         if (!L->in_group) return MI_OK;
         L->in_group = false;
-        const int rc = NB(rccl().GroupEnd());
-        g_root_mu.unlock();
-        return rc;
+        return NB(rccl().GroupEnd());
     }
     static int link_plane(void *l, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t rows, int to_worker, void *worker_stream)
     {

@@ -147,6 +147,8 @@ public:
 
 private:
     static int fail(Worker &w, int rc) { if (rc && w.err.empty()) w.err = B::last_error(); return rc; }
+    // one per backend type and process: all machines of a process share the root devices' RCCL state
+    static std::mutex &root_mu() { static std::mutex m; return m; }
 #define MI_MSM_TRY(expr) do { const int _rc = (expr); if (_rc) return fail(w, _rc); } while (0)
 
     int worker_init(Worker &w)
@@ -173,7 +175,14 @@ private:
         MI_MSM_TRY(B::stream_create(&w.copy));
         // north_star: "RCCL over xGMI for the scatter/gather only" -- a two-rank communicator per (root, worker) pair, owned by this
         // worker's thread alone; absent library or an unusable pair (e.g. the same physical device twice) leave the peer copies
-        if (!w.is_root && use_links_) MI_MSM_TRY(B::link_create(&w.link, root, w.dev));
+        // Every link shares the ROOT device: communicator creation on it, and the brackets that enqueue on its per-link streams, are
+        // serialised process-wide (root_mu: RCCL guarantees no progress for concurrent communicator creation on one device, nor for
+        // concurrent groups from several threads that all contain it).  Only the ENQUEUE is serialised -- the transfers of different
+        // links still overlap on their own streams.
+        if (!w.is_root && use_links_) {
+            std::lock_guard<std::mutex> lk(root_mu());
+            MI_MSM_TRY(B::link_create(&w.link, root, w.dev));
+        }
         for (Slot &s : w.slot) {
             MI_MSM_TRY(B::event_create(&s.in_done));
             MI_MSM_TRY(B::event_create(&s.calc_done));
@@ -247,7 +256,8 @@ private:
             Slot &s = w.slot[k & 1];
             const int c0 = k * chunk, n = std::min(chunk, w.count - c0);
             if (k >= 2) MI_MSM_TRY(B::stream_wait_event(w.copy, s.calc_done));   // the slot's previous compute has read its inputs
-            if (w.link) MI_MSM_TRY(B::link_begin(w.link));
+            std::unique_lock<std::mutex> bracket(root_mu(), std::defer_lock);   // held from link_begin to link_end (see worker_init)
+            if (w.link) { bracket.lock(); MI_MSM_TRY(B::link_begin(w.link)); }
             int rc_planes = MI_OK;
             for (int j = 0; j < n && !rc_planes; ++j) {
                 const mi_mat &m0 = I0s[w.first + c0 + j], &m1 = I1s[w.first + c0 + j];
@@ -260,7 +270,7 @@ private:
                 }
             }
             if (rc_planes) (void)fail(w, rc_planes);
-            if (w.link) { const int rc_end = B::link_end(w.link); if (!rc_planes) MI_MSM_TRY(rc_end); }   // a group once begun is always closed
+            if (w.link) { const int rc_end = B::link_end(w.link); bracket.unlock(); if (!rc_planes) MI_MSM_TRY(rc_end); }   // a group once begun is always closed
             if (rc_planes) return rc_planes;
             MI_MSM_TRY(B::event_record(s.in_done, w.copy));
             return MI_OK;
@@ -280,7 +290,8 @@ private:
             MI_MSM_TRY(B::tvl1_calc_batch(w.h, n, a.data(), b.data(), f.data(), w.compute));
             MI_MSM_TRY(B::event_record(s.calc_done, w.compute));
             MI_MSM_TRY(B::stream_wait_event(w.copy, s.calc_done));
-            if (w.link) MI_MSM_TRY(B::link_begin(w.link));
+            std::unique_lock<std::mutex> bracket(root_mu(), std::defer_lock);
+            if (w.link) { bracket.lock(); MI_MSM_TRY(B::link_begin(w.link)); }
             int rc_planes = MI_OK;
             for (int j = 0; j < n && !rc_planes; ++j) {
                 mi_mat &mf = flows[w.first + c0 + j];
@@ -288,7 +299,7 @@ private:
                                    : B::copy2d_async(mf.data, mf.step, (char *)s.out + j * out_plane, out_pitch, out_pitch, (size_t)Ht, w.copy);
             }
             if (rc_planes) (void)fail(w, rc_planes);
-            if (w.link) { const int rc_end = B::link_end(w.link); if (!rc_planes) MI_MSM_TRY(rc_end); }
+            if (w.link) { const int rc_end = B::link_end(w.link); bracket.unlock(); if (!rc_planes) MI_MSM_TRY(rc_end); }
             if (rc_planes) return rc_planes;
             MI_MSM_TRY(B::event_record(s.out_done, w.copy));
         }

@@ -64,7 +64,7 @@ template <int PPL> __device__ __forceinline__ Dyn3<PPL> *g3(Slot<PPL, false> &) 
 // the weight, G.eu3 = 1 where the convergence error includes (du3)^2 (CPU class, optflow/src/tvl1flow.cpp:1110) and 0 under cv::cuda's
 // rule (tvl1flow.cu:276-283), (xl3, xr3) the hand-over values of the joined form.  The threshold test keeps |grad|^2 = I1wx^2 + I1wy^2
 // (both references: no gamma^2 term), so fi is shared by the three components.
-struct GamK { float gamma, eu3, xl3, xr3; };
+struct GamK { float gamma, eu3, xl3, xr3, rmask = 1.f; };
 template <int PPL, bool ERR, int JW = 0, bool MK = true, bool GAM = false>
 __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
                                         float m2, float taum2, float l_t, float theta, float taut, unsigned long long &acc, float es,
@@ -98,8 +98,12 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
         // ---- p_t(a-1)  (:1140-1181)
         const float n1 = (j + 1 < PPL) ? B.u1[j + 1 < PPL ? j + 1 : j] : r1;
         const float n2 = (j + 1 < PPL) ? B.u2[j + 1 < PPL ? j + 1 : j] : r2;
+#ifdef TBR_X_RMUL   // tuning experiment: the right-border cut as a full-rate multiply by the lane's 0 / 1 mask instead of a half-rate v_cndmask
+        const float u1x = (n1 - B.u1[j]) * G.rmask, u2x = (n2 - B.u2[j]) * G.rmask;
+#else
         const float u1x = right_ok[j] ? n1 - B.u1[j] : 0.f;
         const float u2x = right_ok[j] ? n2 - B.u2[j] : 0.f;
+#endif
         const float d1 = nu1 - B.u1[j];
         const float d2 = nu2 - B.u2[j];
         const float g1 = __builtin_amdgcn_sqrtf(MK ? fmaf(d1 * d1, m2, u1x * u1x) : d1 * d1 + u1x * u1x);
@@ -277,6 +281,7 @@ struct CtxR {
     bool st_ok, x0;   // x0: this lane holds column 0 (MODE 2)
     bool right_ok[PPL];
     float l_t, theta, taut;
+    float rmask;        // (TBR_X_RMUL experiment) 1 where the lane has a right neighbour inside the image, else 0
     float gamma, eu3;   // GAM: the channel's weight; 1 / 0 = the error sum includes (du3)^2 (CPU class) or not (cv::cuda)
     int nit;        // active stages (MODE 1: the length of the speculative block or of the replay; otherwise T)
 };
@@ -771,6 +776,9 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL, GAM> (&X)[T
             if constexpr (FW != 0) if (t == 0) fw_inbox_get<PPL>(c.inbox + ((n + 1) & (FW_RING - 1)) * FW_SLOT, c.lane, X[(k + 1) % P].s);
             float l1, l2, r1, r2;
             GamK G{c.gamma, 0.f, 0.f, 0.f};
+#ifdef TBR_X_RMUL
+            G.rmask = c.rmask;
+#endif
             xread2(x.own + t * 2 * XSg, l1, l2, r1, r2);
             if constexpr (GAM) xread1g(x.own + t * 2 * XSg, G.xl3, G.xr3);
             unsigned long long dummy = 0;
@@ -902,6 +910,9 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
     constexpr int STRIDE = LW - 2 * M;             // owned columns of the strips >= 1 (strip 0 owns LW - M)
     constexpr int P = T + 1 + PF;                  // register sets
     constexpr int K = T > 2 ? T - 1 : 1;           // LDS ring slots: the row of step n is read by stages 2..T-1 at steps n+2..n+T-1
+#ifdef TBR_X_PRIO   // tuning experiment: static wave priority of the pass kernel against whatever shares its SIMDs (the other lane's warp kernel)
+    __builtin_amdgcn_s_setprio(TBR_X_PRIO);
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     CtxR<PPL> c;
     c.lane = threadIdx.x & 63;
@@ -977,6 +988,7 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
     }
 #pragma unroll
     for (int j = 0; j < PPL; ++j) c.right_ok[j] = (xl + j + 1 < W);
+    c.rmask = c.right_ok[0] ? 1.f : 0.f;
     c.st_ok = xl >= own_lo && xl < own_hi;
     c.x0 = xl == 0;
     c.xc = 4u * (unsigned)min(xl, c.ld - PPL);   // clamped column of the unconditional loads, bytes

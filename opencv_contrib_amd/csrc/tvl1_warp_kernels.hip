@@ -29,6 +29,9 @@ namespace tvl1 {
 template <int SEM, int TX, int NP, bool FAST, bool UP = false>
 __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_host)
 {
+#ifdef WARP_X_PRIO   // tuning experiment: static wave priority of the warp kernel (it is the latency-bound one of the two that share the chip)
+    __builtin_amdgcn_s_setprio(WARP_X_PRIO);
+#endif
     __shared__ float s_tab[128];
     if (SEM == MI_SEM_CPU_REF) {
         if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];

@@ -38,7 +38,7 @@ static thread_local std::string t_err;
 
 struct World {
     std::mutex mu;
-    std::set<int> valid{3, 5, 6, 9};
+    std::set<int> valid{0, 1, 2, 3, 4, 5, 6, 7, 9};
     std::map<std::pair<int, int>, int> peer_enabled;   // (device, peer) -> count
     std::map<void *, int> owner;                       // allocation -> device
     std::vector<std::string> log;                      // "dev:op"
@@ -49,6 +49,7 @@ struct World {
     int live_streams = 0, live_events = 0, live_allocs = 0, live_handles = 0, live_links = 0;
     bool links_enabled = false;   // the RCCL transport between the root and the other workers (off: peer copies)
     long groups = 0, messages = 0, pitched_planes = 0;
+    int open_brackets = 0, max_open_brackets = 0;   // brackets (RCCL groups) open right now / the most ever open at once
 } G;
 
 static int maybe_fail(const char *op)
@@ -216,6 +217,7 @@ struct Backend {
         *out = nullptr;
         if (!G.links_enabled || root == dev) return MI_OK;
         if (int rc = maybe_fail("link_create")) return rc;
+        CHECK(G.open_brackets == 0);   // communicator creation on the root device does not overlap a group either
         Stream *st = new Stream{root};
         G.streams[root].push_back(st);
         ++G.live_streams;
@@ -252,6 +254,10 @@ struct Backend {
         Link *L = (Link *)l;
         CHECK(t_dev == L->dev && !L->in_group);
         if (int rc = maybe_fail("link_begin")) return rc;
+        // what the real RCCL groups need: never two brackets open at once that contain the same root device
+        CHECK(G.open_brackets == 0);
+        ++G.open_brackets;
+        G.max_open_brackets = std::max(G.max_open_brackets, G.open_brackets);
         L->in_group = true;
         ++G.groups;
         return MI_OK;
@@ -261,6 +267,7 @@ struct Backend {
         std::lock_guard<std::mutex> lk(G.mu);
         Link *L = (Link *)l;
         CHECK(t_dev == L->dev);
+        if (L->in_group) --G.open_brackets;
         L->in_group = false;
         return MI_OK;
     }
@@ -519,6 +526,39 @@ int main()
             CHECK(m.calc_batch(16, C.a.data(), C.b.data(), C.f.data()) == MI_OK);
             for (int i = 0; i < 16; ++i) CHECK(C.correct(i));
         }
+    }
+    CHECK(fake::G.live_handles == 0 && fake::G.live_streams == 0 && fake::G.live_events == 0 && fake::G.live_allocs == 0 && fake::G.live_links == 0);
+    // 5c. a full node: eight workers, SEVEN links that all contain the root device.  The worker threads run
+    //     concurrently; the brackets (the real backend's ncclGroupStart .. ncclGroupEnd) must never overlap -- the fake checks that in
+    //     link_begin -- while the copies themselves still interleave on the per-link streams.  Ragged shards, several chunk sizes.
+    {
+        fake::G.max_open_brackets = 0;
+        M m;
+        CHECK(m.init(P, {5, 0, 1, 2, 3, 4, 6, 7}) == MI_OK);
+        CHECK(m.link_count() == 7 && fake::G.live_links == 7);
+        int call = 0;
+        for (int chunk : {1, 2, 16})
+            for (int n : {8, 37, 64}) {
+                fake::G.rng.seed(3000 + call);
+                m.set_chunk(chunk);
+                Batch B(n, 5, 9, 400 + call, true);
+                const long g0 = fake::G.groups;
+                CHECK(m.calc_batch(n, B.a.data(), B.b.data(), B.f.data()) == MI_OK);
+                CHECK(all_streams_idle());
+                for (int i = 0; i < n; ++i) CHECK(B.correct(i));
+                CHECK(fake::G.groups > g0);
+                ++call;
+            }
+        CHECK(fake::G.max_open_brackets == 1 && fake::G.open_brackets == 0);
+        // a failure inside one worker's bracket releases the serialisation: the other six links finish, the machine stays usable
+        m.set_chunk(2);
+        Batch B(64, 4, 6, 51, true);
+        fake::G.fail_op = "link_plane"; fake::G.fail_dev = 3; fake::G.fail_after = 1;
+        CHECK(m.calc_batch(64, B.a.data(), B.b.data(), B.f.data()) == MI_ERR_HIP);
+        CHECK(m.error().find("device 3") != std::string::npos && fake::G.open_brackets == 0 && all_streams_idle());
+        Batch C(64, 4, 6, 52, true);
+        CHECK(m.calc_batch(64, C.a.data(), C.b.data(), C.f.data()) == MI_OK);
+        for (int i = 0; i < 64; ++i) CHECK(C.correct(i));
     }
     CHECK(fake::G.live_handles == 0 && fake::G.live_streams == 0 && fake::G.live_events == 0 && fake::G.live_allocs == 0 && fake::G.live_links == 0);
     {   // a failing link_create is a failing worker initialisation

@@ -457,20 +457,24 @@ def test_calc_gamma_illumination_channel_matches_oracle(gpu, oracle, sem, fast):
 
 @pytest.mark.parametrize("sem", [0, 1])
 @pytest.mark.parametrize("iters,shape", [(10, (240, 320)), (7, (135, 531)), (23, (300, 700)), (1, (64, 100))])
-def test_gamma_blocked_kernel_matches_one_iteration_launches(gpu, sem, iters, shape):
+def test_gamma_blocked_kernel_matches_oracle_and_one_iteration_launches(gpu, oracle, sem, iters, shape):
     """gamma != 0 on the temporally blocked kernel (round 6; VERDICT r05 item 2: half of the reference's own test matrix runs
     Gamma(1.0), cudaoptflow/test/test_optflow.cpp:451,530-532; kernels tvl1flow.cu:209-288 u3 terms, :313-348 p31 / p32).  The
-    blocked path (k_iterate_tbr GAM: blocks of 10 / 5 / 2 / 1, joined and independent waves, several strips and bands) against
-    timeBlock = 1 (one launch per iteration, k_iterate<.., GAMMA>) -- the same fast-math formulas, different fusion: the flows
-    agree far inside the parity bound."""
+    blocked path (k_iterate_tbr GAM: blocks of 10 / 5 / 2 / 1, joined and independent waves, several strips and bands) against the
+    oracle with the fast path's bound, and against timeBlock = 1 (one launch per iteration, k_iterate<.., GAMMA>: the same
+    formulas in another fast-math form -- a 3-way branch where the blocked stage clamps -- so the two differ by about what each
+    differs from the oracle)."""
     I0, I1, _ = synth.flow_pair(*shape, seed=31 + iters)
     I1 = np.clip(I1 * 1.06 + 0.015, 0, 1).astype(np.float32)
     kw = dict(iterations=iters, epsilon=0.0, gamma=1.0, semantics=sem, exactMath=False)
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(iterations=iters, epsilon=0.0, gamma=1.0, semantics=sem))
     fb, _ = _run(gpu, I0, I1, **kw)
     f1, _ = _run(gpu, I0, I1, timeBlock=1, **kw)
     f0, _ = _run(gpu, I0, I1, **dict(kw, gamma=0.0))
     assert np.sqrt(((fb - f0) ** 2).sum(-1)).mean() > 1e-3, "gamma has no effect on this input"
-    _assert_flow_close(fb, f1, mean_epe=1e-3, ccorr=1e-6, frac_within=(0.02, 0.99))
+    # the cv::cuda semantics' separable warp sums (the default there) round differently from the oracle's tap order: its own bound
+    _assert_flow_close(fb, ref, mean_epe=5e-3 if sem == 0 else 2e-2, ccorr=1e-4, frac_within=(0.05, 0.97))
+    _assert_flow_close(fb, f1, mean_epe=1.2e-2 if sem == 0 else 3e-2, ccorr=1e-4, frac_within=(0.08, 0.97))
 
 
 def test_gamma_blocked_batch_equals_single_calcs(gpu):
