@@ -934,10 +934,15 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
     const bool narrow = narrow_env >= 0 ? narrow_env != 0 : (long long)tgrid.x * tgrid.y * tgrid.z < 2LL * (device_simds() / 4);
     if (narrow && R == 4) tgrid = dim3(div_up(g.w, 64), div_up(g.h, 4), g.batch);
 #define MI_FB_LAUNCH(G, KH, RR, TW) hipLaunchKernelGGL((k_iterate_t<G, KH, RR, TW>), tgrid, dim3(256), 0, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, inv, upd, K, g.bs, swz, mg, merged_step)
+#ifdef MIFLOW_EXPERIMENTS   // 8-row tiles (MIFLOW_FB_ROWS=8) lost their A/B: experiments build only
+#define MI_FB_R8(G, KH) if (R == 8) MI_FB_LAUNCH(G, KH, 8, 256); else
+#else
+#define MI_FB_R8(G, KH)
+#endif
 #define MI_FB_TILED(KH)                                                                  \
     case KH:                                                                             \
-        if (gauss) { if (R == 8) MI_FB_LAUNCH(true, KH, 8, 256); else if (narrow) MI_FB_LAUNCH(true, KH, 4, 64); else MI_FB_LAUNCH(true, KH, 4, 256); }   \
-        else { if (R == 8) MI_FB_LAUNCH(false, KH, 8, 256); else if (narrow) MI_FB_LAUNCH(false, KH, 4, 64); else MI_FB_LAUNCH(false, KH, 4, 256); }       \
+        if (gauss) { MI_FB_R8(true, KH) if (narrow) MI_FB_LAUNCH(true, KH, 4, 64); else MI_FB_LAUNCH(true, KH, 4, 256); }   \
+        else { MI_FB_R8(false, KH) if (narrow) MI_FB_LAUNCH(false, KH, 4, 64); else MI_FB_LAUNCH(false, KH, 4, 256); }       \
         break;
     void *mg = (merged && g.batch == 1 && tuning().fb_tiled && (kh == 4 || kh == 6 || kh == 7 || kh == 10)) ? merged : nullptr;
     if (did_merge) *did_merge = mg != nullptr;
@@ -948,6 +953,7 @@ int iterate(const float *M, const float *R0, const float *R1, float *flowx, floa
         else hipLaunchKernelGGL(k_iterate<false>, grid, dim3(256), lds, s, M, R0, R1, flowx, flowy, Mout, g.w, g.h, g.ld, kh, inv, upd, K, g.bs);
     }
 #undef MI_FB_TILED
+#undef MI_FB_R8
 #undef MI_FB_LAUNCH
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -2,6 +2,8 @@
 #include "mi_common.h"
 #include <vector>
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
 #include <mutex>
 
 namespace mi {
@@ -23,10 +25,36 @@ static int env_int(const char *name, int dflt)
 #define EXP_INT(name, dflt) (dflt)
 #define EXP_ENV(name) ((const char *)nullptr)
 #endif
+#ifndef MIFLOW_EXPERIMENTS
+// A deployment that sets a variable only the experiments build reads would be ignored silently: say so, once, on stderr.
+// (The names this library does read are listed; anything else that starts with the prefix is reported.)
+extern "C" char **environ;
+static void warn_unread_switches()
+{
+    static const char *const known[] = {"MIFLOW_BF_W", "MIFLOW_CACHE_GB", "MIFLOW_CACHE_TOTAL_GB", "MIFLOW_FB_FUSE", "MIFLOW_FB_GROUP_MB", "MIFLOW_FB_NARROW",
+                                        "MIFLOW_FB_PAIR", "MIFLOW_LANES", "MIFLOW_MULTI_RCCL", "MIFLOW_SURF_NMS0", "MIFLOW_SURF_POLY", "MIFLOW_SURF_STAGE_S",
+                                        "MIFLOW_TB_HIST", "MIFLOW_TB_VERBOSE", "MIFLOW_TILE_MAXPX"};
+    // read by the Python side, the bench, the tests or the build -- not by the library
+    static const char *const foreign[] = {"MIFLOW_LIB", "MIFLOW_BENCH_", "MIFLOW_SWEEP_", "MIFLOW_BUILD_", "MIFLOW_EXTRA_", "MIFLOW_SLP_"};
+    if (!environ) return;
+    for (char **e = environ; *e; ++e) {
+        if (strncmp(*e, "MIFLOW_", 7) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        const size_t n = eq ? (size_t)(eq - *e) : strlen(*e);
+        bool ok = false;
+        for (const char *k : known) ok = ok || (strlen(k) == n && strncmp(k, *e, n) == 0);
+        for (const char *k : foreign) ok = ok || strncmp(k, *e, strlen(k)) == 0;
+        if (!ok) fprintf(stderr, "miflow: %.*s is not read by this library (tuning experiments exist in the -DMIFLOW_EXPERIMENTS build only); ignored\n", (int)n, *e);
+    }
+}
+#endif
 const Tuning &tuning()
 {
     std::call_once(g_tuning_once, [] {
         Tuning &t = g_tuning;
+#ifndef MIFLOW_EXPERIMENTS
+        warn_unread_switches();
+#endif
         const char *w = EXP_ENV("MIFLOW_WARP");
         t.warp_legacy = (w && w[0] == 'p') ? 1 : 0;
         t.x_skip = EXP_INT("MIFLOW_X_SKIP", 0);
@@ -46,8 +74,8 @@ const Tuning &tuning()
         t.tb_hist = env_int("MIFLOW_TB_HIST", 1);
         t.fb_poll = EXP_INT("MIFLOW_FB_POLL", 1);
         t.fb_ahead = EXP_INT("MIFLOW_FB_AHEAD", 1);
-        t.tb_fw = env_int("MIFLOW_TB_FW", 0);   // bit-identical; first form measured slower (r14b: 1 190 against 1 372 pairs/s at 64 pairs): off until it wins
-        t.tb_jw = env_int("MIFLOW_TB_JW", 2);
+        t.tb_fw = EXP_INT("MIFLOW_TB_FW", 0);   // bit-identical; measured slower (r14b: 1 190 against 1 372 pairs/s at 64 pairs): experiments build only since round 6
+        t.tb_jw = EXP_INT("MIFLOW_TB_JW", 2);   // the release library contains the barrier form (2) only
         if (t.tb_jw < 0 || t.tb_jw > 4) t.tb_jw = 2;   // 3: eight joined waves (experiment); 4: barrier form, branch-free publishes, mask-free interior blocks
         // the speculative steps (MODE 1, class defaults) as joined waves too (barrier form only): r04a at 1080p x 32, 300 iterations,
         // epsilon 0.01: 533 -> 593 pairs/s, the same flows
@@ -247,7 +275,11 @@ void set_error(const char *fmt, ...)
 extern "C" {
 
 const char *mi_last_error(void) { return mi::g_err; }
+#ifdef MIFLOW_EXPERIMENTS
+const char *mi_version(void) { return "miflow 0.1 (gfx950) +experiments"; }   // the tuning variants are compiled in (tests that exercise them ask)
+#else
 const char *mi_version(void) { return "miflow 0.1 (gfx950)"; }
+#endif
 
 int mi_device_count(void)
 {

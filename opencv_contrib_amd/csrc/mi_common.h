@@ -45,8 +45,8 @@ struct Tuning {
     int fb_poll;            // MIFLOW_FB_POLL: host feedback through flags the deciding launch writes into pinned host memory when it STARTS (1, default) or a copy of the control slots behind the launch (0, round 3)
     int fb_ahead;           // MIFLOW_FB_AHEAD: polled host feedback enqueues the next warp's kernel (gated on the device) before it polls (1, default)
     int tb_skip_p;          // MIFLOW_TB_SKIP_P: the last pass of a scale does not store p (1, default)
-    int tb_fw;              // MIFLOW_TB_FW: a warp whose iterations are one pass of the T = 10 kernel runs INSIDE that pass (producer waves; 1, default) or as its own launch (0)
-    int tb_jw;              // MIFLOW_TB_JW: joined-wave form of the T = 10 blocked iteration kernel
+    int tb_fw;              // MIFLOW_TB_FW (experiments build): 1 = a warp whose iterations are one pass of the T = 10 kernel runs INSIDE that pass (producer waves); 0 (default, and always in the release library) = its own launch
+    int tb_jw;              // MIFLOW_TB_JW (experiments build): joined-wave form of the T = 10 blocked iteration kernel; the release library holds form 2 only
     int tb_jw_spec;         // MIFLOW_TB_JW_SPEC: ... of the speculative steps as well
     int tb_ppl, tb_wps, tb_pf;   // MIFLOW_TB_VARIANT=ppl,wps,pf (-1: table default)
     int tb_force;            // MIFLOW_TB_FORCE: greedy blocks of exactly the cap (tuning sweeps)

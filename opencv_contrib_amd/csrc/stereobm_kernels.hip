@@ -772,13 +772,27 @@ static int launch_bm(const BmArgs &A, int mode, hipStream_t s)
     lds = (lds + 15) / 16 * 16;   // the transposition buffer behind it is read as b128
     const dim3 grid(div_up(A.cols - A.ndisp - 2 * R, C::TW), div_up(A.rows - 2 * R, A.rb), A.tab ? A.batch : 1);
     const dim3 block(64 * A.nsets);
-    if (mode == 0 && C::PACKED && tuning().sbm_wt) {
-        const size_t ldst = lds + (size_t)A.nsets * 16 * 68 * sizeof(unsigned);
-        (void)hipFuncSetAttribute((const void *)k_block_match<R, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
-        hipLaunchKernelGGL((k_block_match<R, 0, true>), grid, block, ldst, s, A);
+    // one first-pass kernel per radius in the release library: the transposed winner-take-all where the column sums are packed (C::PACKED),
+    // the plain form elsewhere; the experiments build keeps both for MIFLOW_SBM_WT
+#ifdef MIFLOW_EXPERIMENTS
+    const bool wt = C::PACKED && tuning().sbm_wt;
+#else
+    constexpr bool wt = C::PACKED;
+#endif
+    if (mode == 0 && wt) {
+        if constexpr (C::PACKED) {
+            const size_t ldst = lds + (size_t)A.nsets * 16 * 68 * sizeof(unsigned);
+            (void)hipFuncSetAttribute((const void *)k_block_match<R, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
+            hipLaunchKernelGGL((k_block_match<R, 0, true>), grid, block, ldst, s, A);
+        }
     } else if (mode == 0) {
-        (void)hipFuncSetAttribute((const void *)k_block_match<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_block_match<R, 0>), grid, block, lds, s, A);
+#ifndef MIFLOW_EXPERIMENTS
+        if constexpr (!C::PACKED)
+#endif
+        {
+            (void)hipFuncSetAttribute((const void *)k_block_match<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_block_match<R, 0>), grid, block, lds, s, A);
+        }
     } else {
         (void)hipFuncSetAttribute((const void *)k_block_match<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_block_match<R, 1>), grid, block, lds, s, A);

@@ -96,8 +96,9 @@ int iterate(bool exact, const IterPlanes &pl, const Geo &g, float l_t, float the
 // set cur -> cur^1.  Supported T: 1,2,3,4,5,6,8,10.  rows_per_band <= 0: auto.
 // skip_p_out: the launch stores u only (the last pass of a scale: nobody reads its p).  pl.g == nullptr: no |grad|^2 plane, the kernel
 // forms it from I1wx, I1wy (only where tb_nograd_ok says so)
+// independent_waves (test hook of the stage-level entry): the kernel whose waves each own a 64-column strip, never the joined form
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
-               int cur, int rows_per_band, hipStream_t s, bool skip_p_out = false);
+               int cur, int rows_per_band, hipStream_t s, bool skip_p_out = false, bool independent_waves = false);
 bool tb_nograd_ok(int T, const Geo &g);
 // the warp of a one-pass warp INSIDE that pass (k_iterate_tbr FW): no warp launch, no I1wx / I1wy / rho_c planes in HBM; bit-identical
 bool tb_fused_ok(int T, const Geo &g, int semantics, bool fast_warp);

@@ -799,13 +799,15 @@ int warp(int semantics, const float *I0, const float *pk, const float *u1[2], co
     A.g = g;
     const CtlK ck = make_ctlk(ctl);
     if (semantics == MI_SEM_CPU_REF) {
+#ifdef MIFLOW_EXPERIMENTS
         const int tile = warp_tile();   // r01u: 32 x 2 patch per wave +2 % on the bench (64: 881, 32: 902, 16: 878 pairs/s)
         if (tile == 16)
             hipLaunchKernelGGL((k_warp<MI_SEM_CPU_REF, 16>), dim3(div_up(g.w, 16), div_up(g.h, 16), g.batch), dim3(256), 0, s, A, ck, cur_host);
-        else if (tile == 32)
-            hipLaunchKernelGGL((k_warp<MI_SEM_CPU_REF, 32>), dim3(div_up(g.w, 32), div_up(g.h, 8), g.batch), dim3(256), 0, s, A, ck, cur_host);
-        else
+        else if (tile == 64)
             hipLaunchKernelGGL((k_warp<MI_SEM_CPU_REF, 64>), grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
+        else
+#endif
+            hipLaunchKernelGGL((k_warp<MI_SEM_CPU_REF, 32>), dim3(div_up(g.w, 32), div_up(g.h, 8), g.batch), dim3(256), 0, s, A, ck, cur_host);
     } else
         hipLaunchKernelGGL(k_warp<MI_SEM_CUDA_COMPAT>, grid2d(g, g.batch), dim3(256), 0, s, A, ck, cur_host);
     MI_HIP_TRY(hipGetLastError());

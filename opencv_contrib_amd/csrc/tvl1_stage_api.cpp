@@ -128,6 +128,10 @@ int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1w
 {
     hipStream_t st = (hipStream_t)stream;
     MI_REQUIRE(niter >= 1, MI_ERR_BAD_ARG, "niter must be >= 1");
+    // test hook: time_block = 100 + T runs the INDEPENDENT-wave kernel of block length T (every wave its own 64-column strip) where
+    // T alone runs the kernel of record (T = 10: four joined waves per 256-column strip) -- the two must agree bit for bit
+    const bool indep = !exact_math && time_block >= 100;
+    if (indep) time_block -= 100;
     const bool tiled = !exact_math && time_block < 0;   // test hook: register-tile kernel, variant -time_block - 1
     MI_REQUIRE(!tiled || -time_block - 1 < tile_variants(), MI_ERR_BAD_ARG, "no such register-tile variant");
     const bool blocked = (!exact_math && time_block > 0) || tiled;
@@ -169,7 +173,7 @@ int mi_tvl1_iterate(int exact_math, int time_block, int niter, const mi_mat *I1w
         if (blocked) {
             const int T = tb_pick_block(niter - it, time_block);
             // rows_per_band = -1: always the streaming kernel (the tile kernel is compared against it)
-            TRY(iterate_tb(T, pl, g, l_t, theta, taut, false, cur, -1, st));
+            TRY(iterate_tb(T, pl, g, l_t, theta, taut, false, cur, -1, st, false, indep));
             it += T;
             cur ^= 1;
             continue;

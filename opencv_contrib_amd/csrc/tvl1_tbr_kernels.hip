@@ -64,7 +64,7 @@ template <int PPL> __device__ __forceinline__ Dyn3<PPL> *g3(Slot<PPL, false> &) 
 // the weight, G.eu3 = 1 where the convergence error includes (du3)^2 (CPU class, optflow/src/tvl1flow.cpp:1110) and 0 under cv::cuda's
 // rule (tvl1flow.cu:276-283), (xl3, xr3) the hand-over values of the joined form.  The threshold test keeps |grad|^2 = I1wx^2 + I1wy^2
 // (both references: no gamma^2 term), so fi is shared by the three components.
-struct GamK { float gamma, eu3, xl3, xr3, rmask = 1.f; };
+struct GamK { float gamma, eu3, xl3, xr3; };
 template <int PPL, bool ERR, int JW = 0, bool MK = true, bool GAM = false>
 __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL> &st, const bool right_ok[PPL], float negm1,
                                         float m2, float taum2, float l_t, float theta, float taut, unsigned long long &acc, float es,
@@ -98,12 +98,9 @@ __device__ __forceinline__ void stage_r(Dyn<PPL> &A, Dyn<PPL> &B, const Stat<PPL
         // ---- p_t(a-1)  (:1140-1181)
         const float n1 = (j + 1 < PPL) ? B.u1[j + 1 < PPL ? j + 1 : j] : r1;
         const float n2 = (j + 1 < PPL) ? B.u2[j + 1 < PPL ? j + 1 : j] : r2;
-#ifdef TBR_X_RMUL   // tuning experiment: the right-border cut as a full-rate multiply by the lane's 0 / 1 mask instead of a half-rate v_cndmask
-        const float u1x = (n1 - B.u1[j]) * G.rmask, u2x = (n2 - B.u2[j]) * G.rmask;
-#else
+        // (r19b: the cut as a full-rate multiply by a 0 / 1 lane mask instead of the half-rate v_cndmask changes nothing: 1 414 against 1 416 pairs/s)
         const float u1x = right_ok[j] ? n1 - B.u1[j] : 0.f;
         const float u2x = right_ok[j] ? n2 - B.u2[j] : 0.f;
-#endif
         const float d1 = nu1 - B.u1[j];
         const float d2 = nu2 - B.u2[j];
         const float g1 = __builtin_amdgcn_sqrtf(MK ? fmaf(d1 * d1, m2, u1x * u1x) : d1 * d1 + u1x * u1x);
@@ -281,7 +278,6 @@ struct CtxR {
     bool st_ok, x0;   // x0: this lane holds column 0 (MODE 2)
     bool right_ok[PPL];
     float l_t, theta, taut;
-    float rmask;        // (TBR_X_RMUL experiment) 1 where the lane has a right neighbour inside the image, else 0
     float gamma, eu3;   // GAM: the channel's weight; 1 / 0 = the error sum includes (du3)^2 (CPU class) or not (cv::cuda)
     int nit;        // active stages (MODE 1: the length of the speculative block or of the replay; otherwise T)
 };
@@ -776,9 +772,6 @@ __device__ __forceinline__ void step_r(const CtxR<PPL> &c, Slot<PPL, GAM> (&X)[T
             if constexpr (FW != 0) if (t == 0) fw_inbox_get<PPL>(c.inbox + ((n + 1) & (FW_RING - 1)) * FW_SLOT, c.lane, X[(k + 1) % P].s);
             float l1, l2, r1, r2;
             GamK G{c.gamma, 0.f, 0.f, 0.f};
-#ifdef TBR_X_RMUL
-            G.rmask = c.rmask;
-#endif
             xread2(x.own + t * 2 * XSg, l1, l2, r1, r2);
             if constexpr (GAM) xread1g(x.own + t * 2 * XSg, G.xl3, G.xr3);
             unsigned long long dummy = 0;
@@ -910,9 +903,7 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
     constexpr int STRIDE = LW - 2 * M;             // owned columns of the strips >= 1 (strip 0 owns LW - M)
     constexpr int P = T + 1 + PF;                  // register sets
     constexpr int K = T > 2 ? T - 1 : 1;           // LDS ring slots: the row of step n is read by stages 2..T-1 at steps n+2..n+T-1
-#ifdef TBR_X_PRIO   // tuning experiment: static wave priority of the pass kernel against whatever shares its SIMDs (the other lane's warp kernel)
-    __builtin_amdgcn_s_setprio(TBR_X_PRIO);
-#endif
+    // (r19b: a static s_setprio 1 here changes nothing -- 1 412 against 1 416 pairs/s --, s_setprio 2 on the warp kernel costs 2.5 %)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     CtxR<PPL> c;
     c.lane = threadIdx.x & 63;
@@ -988,7 +979,6 @@ __global__ __launch_bounds__((JW == 3 || FW) ? 512 : 256, WPS) void k_iterate_tb
     }
 #pragma unroll
     for (int j = 0; j < PPL; ++j) c.right_ok[j] = (xl + j + 1 < W);
-    c.rmask = c.right_ok[0] ? 1.f : 0.f;
     c.st_ok = xl >= own_lo && xl < own_hi;
     c.x0 = xl == 0;
     c.xc = 4u * (unsigned)min(xl, c.ld - PPL);   // clamped column of the unconditional loads, bytes
@@ -1134,21 +1124,30 @@ struct TbrEntry {
     bool GAM; // the kernel carries the illumination channel (gamma != 0)
 };
 #define TBR(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, launch_tbr<T, PPL, WPS, PF, 0>, nullptr, 0}
-// joined waves: the hand-over registers cost 14 VGPRs (3 waves/SIMD), rings + hand-over areas 40.7 KB of LDS = 3 workgroups per CU
-static const TbrEntry g_tbr_jw[] = {{10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 1>, nullptr, 1},
-                                     // barrier form (MIFLOW_TB_JW=2): no read-ahead registers, no dump area: four waves/SIMD and four workgroups/CU again
-                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2>, nullptr, 2},
+// Ship what is used: the release library instantiates the kernels a release build can reach -- the barrier form of
+// the joined waves (JW = 2), the independent-wave blocks of the other lengths, the exact-math blocks, the illumination channel.  The
+// forms that lost their A/B (tags, eight joined waves, branch-free publishes, the fused warp, 16-bit dual storage, alternative register
+// shapes, MIFLOW_TB_JW = 0) exist under -DMIFLOW_EXPERIMENTS only (libmiflow_exp.so), where the digest tests of their bit-identity run.
+static const TbrEntry g_tbr_jw[] = {
+#ifdef MIFLOW_EXPERIMENTS
+                                     // joined waves with tags: the hand-over registers cost 14 VGPRs (3 waves/SIMD), rings + hand-over areas 40.7 KB of LDS = 3 workgroups per CU
+                                     {10, 1, 3, 2, 3, launch_tbr<10, 1, 3, 2, 0, 1>, nullptr, 1},
                                      // eight joined waves (MIFLOW_TB_JW=3): 512-column strips, two workgroups of eight waves per CU
                                      {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 3>, nullptr, 3},
                                      // barrier form without exec-masked publishes and without border masks in interior blocks, hand-over
                                      // values read a stage early (MIFLOW_TB_JW=4)
-                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 4>, nullptr, 4}};
+                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 4>, nullptr, 4},
+#endif
+                                     // barrier form (MIFLOW_TB_JW=2, the default): no read-ahead registers, no dump area: four waves/SIMD and four workgroups/CU
+                                     {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2>, nullptr, 2}};
 // the default kernel without a |grad|^2 plane (tb_nograd_entry)
 static const TbrEntry g_tbr_ng = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true>, nullptr, 2};
 // ... and with the warp inside (FW: four producer waves beside the four joined consumers; two workgroups of eight waves per CU, i.e. two
 // CONSUMER waves per SIMD is what the band planner fills): [0] the CPU class's arithmetic, tap-by-tap sums; [1] cv::cuda's, separable sums
+#ifdef MIFLOW_EXPERIMENTS
 static const TbrEntry g_tbr_fw[] = {{10, 1, 4, 2, 2, launch_tbr<10, 1, 4, 2, 0, 2, true, false, 1>, nullptr, 2},
                                     {10, 1, 4, 2, 2, launch_tbr<10, 1, 4, 2, 0, 2, true, false, 2>, nullptr, 2}};
+#endif
 // gamma != 0 (round 6): the blocked kernel with the illumination channel -- nine dynamic registers per set (T = 10:
 // three waves/SIMD), always without a |grad|^2 plane.  Blocks of 10 and 5 as joined waves, 2 and 1 as independent waves (any iteration
 // count decomposes greedily: tb_plan_gam)
@@ -1160,21 +1159,29 @@ static const TbrEntry g_tbr_gam[] = {{10, 1, 3, 1, 3, launch_tbr<10, 1, 3, 1, 0,
 // ... and its speculative steps (convergence-checked path)
 static const TbrEntry g_spec_gam[] = {{10, 1, 2, 2, 2, nullptr, launch_tbr<10, 1, 2, 2, 1, 2, true, false, 0, true>, 2, true},
                                       {5, 1, 3, 2, 2, nullptr, launch_tbr<5, 1, 3, 2, 1, 2, true, false, 0, true>, 2, true}};
-static const TbrEntry g_tbr_ng16 = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true, true>, nullptr, 2};   // + p as snorm16 between passes (opt-in)
+#ifdef MIFLOW_EXPERIMENTS
+static const TbrEntry g_tbr_ng16 = {10, 1, 4, 2, 3, launch_tbr<10, 1, 4, 2, 0, 2, true, true>, nullptr, 2};   // + p as snorm16 between passes (changes results)
+#endif
 static const TbrEntry g_tbr[] = {
     // first entry of each T = default (r01s sweep, G px-iter/s at 1080p x 16: T10 394 | T8 353 | T6 271 | T5 256 | T4 215 | T3 152 | T2 106 | T1 64)
     TBR(10, 1, 4, 2, 3), TBR(8, 2, 2, 2, 2), TBR(6, 1, 5, 2, 3), TBR(5, 2, 3, 2, 3), TBR(4, 2, 3, 2, 3), TBR(3, 1, 7, 2, 6), TBR(2, 1, 8, 2, 8),
     TBR(1, 1, 8, 2, 8),
+#ifdef MIFLOW_EXPERIMENTS
     // alternatives (tuning sweeps, MIFLOW_TB_VARIANT)
     TBR(10, 2, 2, 2, 2), TBR(8, 1, 4, 2, 2), TBR(6, 2, 3, 2, 3),
+#endif
 };
 // The speculative steps (MODE 1: T accumulator registers more, hence one wave/SIMD less than MODE 0 at T = 10).
 #define TBRS(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1>, 0}
 #define TBRSJ(T, PPL, WPS, PF, PLAN) {T, PPL, WPS, PF, PLAN, nullptr, launch_tbr<T, PPL, WPS, PF, 1, 2>, 2}
 // PLAN = 2: the bands are cut for two waves per SIMD -- fewer, taller bands (less halo) than the fixed-work kernels use; the other
 // lane's kernels fill the rest of the device (r02m at 1080p x 16, class defaults: 517 -> 545 pairs/s; fixed work loses 7 %).
+// (a release build runs the speculative steps of a level either on the register tiles or, without a |grad|^2 plane, on g_spec_jw_ng:
+// the two tables below are reachable through experiment switches only)
+#ifdef MIFLOW_EXPERIMENTS
 static const TbrEntry g_spec[] = {TBRS(10, 1, 3, 2, 2), TBRS(5, 1, 4, 2, 2)};
 static const TbrEntry g_spec_jw[] = {TBRSJ(10, 1, 3, 2, 2), TBRSJ(5, 1, 4, 2, 2)};   // MIFLOW_TB_JW >= 2 and MIFLOW_TB_JW_SPEC=1
+#endif
 // ... and the same two without a |grad|^2 plane (round 4: the convergence-checked path re-reads the statics once per block)
 static const TbrEntry g_spec_jw_ng[] = {{10, 1, 3, 2, 2, nullptr, launch_tbr<10, 1, 3, 2, 1, 2, true>, 2}, {5, 1, 4, 2, 2, nullptr, launch_tbr<5, 1, 4, 2, 1, 2, true>, 2}};
 bool tb_spec_nograd_ok(const Geo &g)
@@ -1334,13 +1341,23 @@ bool tb_nograd_ok(int T, const Geo &g)
 // launch, no I1wx / I1wy / rho_c planes.  Which warp arithmetic: the two defaults (CPU class + tap-by-tap sums, cv::cuda + separable sums).
 bool tb_fused_ok(int T, const Geo &g, int semantics, bool fast_warp)
 {
+#ifndef MIFLOW_EXPERIMENTS
+    (void)T; (void)g; (void)semantics; (void)fast_warp;
+    return false;   // measured slower (profiles/r14): the fused form is built into the experiments library only
+#else
     if (!tuning().tb_fw || !tb_nograd_ok(T, g) || g.w < 6 || g.h < 6) return false;   // (the producers' unconditional window gather needs an interior)
     return (semantics == MI_SEM_CPU_REF && !fast_warp) || (semantics == MI_SEM_CUDA_COMPAT && fast_warp);
+#endif
 }
 
 int iterate_tb_fused(int semantics, const float *I0, const float *I1, const float *cubic_tab_dev, int T, const IterPlanes &pl, const Geo &g,
                      float l_t, float theta, float taut, bool p_zero, int cur, hipStream_t s, bool skip_p_out)
 {
+#ifndef MIFLOW_EXPERIMENTS
+    (void)semantics; (void)I0; (void)I1; (void)cubic_tab_dev; (void)T; (void)pl; (void)g; (void)l_t; (void)theta; (void)taut; (void)p_zero; (void)cur; (void)s; (void)skip_p_out;
+    set_error("the warp fused into the pass kernel exists in the experiments build only (-DMIFLOW_EXPERIMENTS)");
+    return MI_ERR_NOT_IMPL;
+#else
     MI_REQUIRE(T == 10 && tb_nograd_ok(T, g), MI_ERR_BAD_ARG, "fused warp: one pass of the default T = 10 kernel only");
     const TbrEntry &e = g_tbr_fw[semantics == MI_SEM_CPU_REF ? 0 : 1];
     TbArgs A;
@@ -1355,10 +1372,11 @@ int iterate_tb_fused(int semantics, const float *I0, const float *I1, const floa
         if (shown++ < 40) fprintf(stderr, "[tb] fused warp T=%d %dx%d batch=%d rows_per_band=%d\n", T, g.w, g.h, g.batch, A.rows_per_band);
     }
     return e.launch(A, p_zero, s);
+#endif
 }
 
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
-               int cur, int rows_per_band, hipStream_t s, bool skip_p_out)
+               int cur, int rows_per_band, hipStream_t s, bool skip_p_out, bool independent_waves)
 {
     if (pl.gamma != 0.f) {   // the illumination channel: its own kernels (no |grad|^2 plane read, whether or not the warp stored one)
         const TbrEntry *e = nullptr;
@@ -1377,10 +1395,18 @@ int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta
         return iterate_tile(-1, T, pl, g, l_t, theta, taut, p_zero, cur, s);
     }
     const TbrEntry *e = tbr_pick(T);
+    if (independent_waves) {   // test hook: the first independent-wave entry of this block length
+        e = nullptr;
+        for (const TbrEntry &c : g_tbr) if (c.T == T && !e) e = &c;
+    }
     if (!e) { set_error("unsupported time block %d", T); return MI_ERR_BAD_ARG; }
     if (!pl.g) {
         MI_REQUIRE(tb_nograd_ok(T, g), MI_ERR_BAD_ARG, "no |grad|^2 plane, but the kernel of this launch needs one");
+#ifdef MIFLOW_EXPERIMENTS
         e = tuning().tb_p16 ? &g_tbr_ng16 : &g_tbr_ng;
+#else
+        e = &g_tbr_ng;
+#endif
     }
     TbArgs A;
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = cur; A.swz = 0; A.nstrips = 0;
@@ -1442,8 +1468,13 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
     } else if (!pl.g) {
         MI_REQUIRE(tb_spec_nograd_ok(g), MI_ERR_BAD_ARG, "no |grad|^2 plane, but the speculative kernel of this launch needs one");
         for (const TbrEntry &c : g_spec_jw_ng) if (c.T == T) e = &c;
-    } else if (tuning().tb_jw >= 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }
+    }
+#ifdef MIFLOW_EXPERIMENTS
+    else if (tuning().tb_jw >= 2 && tuning().tb_jw_spec) { for (const TbrEntry &c : g_spec_jw) if (c.T == T) e = &c; }
     else { for (const TbrEntry &c : g_spec) if (c.T == T) e = &c; }
+#else
+    else for (const TbrEntry &c : g_spec_jw_ng) if (c.T == T) e = &c;   // (the same kernel forms |grad|^2 itself and ignores the stored plane)
+#endif
     if (!e) { set_error("no speculative kernel for time block %d", T); return MI_ERR_BAD_ARG; }
     TbArgs A;
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.swz = 0; A.nstrips = 0; A.skip_p_out = 0;

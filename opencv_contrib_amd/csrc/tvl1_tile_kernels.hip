@@ -229,7 +229,13 @@ struct TileEntry {
     TileLaunchFn launch, spec, spec4, spec7;   // spec4 / spec7: blocks of at most 4 / 7 iterations on tiles of that margin
 };
 #define TILE(RW, NW) {RW, NW, launch_tile<RW, NW, false>, launch_tile<RW, NW, true>, launch_tile<RW, NW, true, 4>, launch_tile<RW, NW, true, 7>}
-static const TileEntry g_tile[] = {TILE(4, 16), TILE(6, 16), TILE(8, 16), TILE(8, 8), TILE(6, 8), TILE(3, 16)};
+// [0] = the large-grid shape (64-row tiles of 16 waves), [1] = the small-grid shape (48-row tiles of 8 waves x 6 rows): what a release
+// build runs (auto_variant).  The other shapes of the r02 / r10 sweeps exist in the experiments build only.
+static const TileEntry g_tile[] = {TILE(4, 16), TILE(6, 8),
+#ifdef MIFLOW_EXPERIMENTS
+                                   TILE(6, 16), TILE(8, 16), TILE(8, 8), TILE(3, 16),
+#endif
+};
 constexpr int kTileVariants = (int)(sizeof(g_tile) / sizeof(g_tile[0]));
 
 int tile_variants() { return kTileVariants; }
@@ -243,7 +249,7 @@ static int auto_variant(const Geo &g)
     constexpr int M = TILE_M, LW = 64, STRIDE = LW - 2 * M;
     const long long nstrips = g.w <= LW - M ? 1 : 1 + div_up(g.w - (LW - M), STRIDE);
     const long long wgs = nstrips * div_up(g.h, 64 - 2 * M) * g.batch;
-    return wgs < tuning().tile_small_wgs ? 4 : 0;
+    return wgs < tuning().tile_small_wgs ? 1 : 0;
 }
 int tile_max_block() { return TILE_M; }
 int tile_rows_for(const Geo &g)

@@ -29,9 +29,6 @@ namespace tvl1 {
 template <int SEM, int TX, int NP, bool FAST, bool UP = false>
 __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_host)
 {
-#ifdef WARP_X_PRIO   // tuning experiment: static wave priority of the warp kernel (it is the latency-bound one of the two that share the chip)
-    __builtin_amdgcn_s_setprio(WARP_X_PRIO);
-#endif
     __shared__ float s_tab[128];
     if (SEM == MI_SEM_CPU_REF) {
         if (threadIdx.x < 128) s_tab[threadIdx.x] = A.tab[threadIdx.x];
@@ -100,6 +97,7 @@ __global__ __launch_bounds__(256) void k_warp6(Warp6Args A, CtlK ctl, int cur_ho
 // (about 2 floats per pixel), and every interior window is read from LDS.  Pixels whose window touches the image border, or
 // tiles whose flow is so wild that the region exceeds the buffer, take the global path of k_warp6 (same arithmetic).
 // Tap values, weights and the accumulation order are those of warp_px: bit-identical planes.
+#ifdef MIFLOW_EXPERIMENTS   // measured slower under the two-lane overlap (r02z3): experiments build only (ship what is used)
 constexpr int WL_TW = 64, WL_TH = 16, WL_PPT = 4;   // tile; rows per thread (wave w owns rows 4w .. 4w+3, lane = column)
 constexpr int WL_RW = 96, WL_RH = 40;               // staged region capacity, floats x rows (15 KB)
 
@@ -192,7 +190,13 @@ __global__ __launch_bounds__(256) void k_warp_lds(Warp6Args A, CtlK ctl, int cur
     }
 }
 
+#endif   // MIFLOW_EXPERIMENTS (k_warp_lds)
+
+#ifdef MIFLOW_EXPERIMENTS
 bool warp_zoom_ok() { return tuning().warp_zoom != 0 && tuning().warp_lds == 0 && warp_tile() == 32 && tuning().warp_np == 2; }
+#else
+bool warp_zoom_ok() { return false; }   // the zooming first warp (k_warp6<.., UP>) lost its A/B (r08k): experiments build only
+#endif
 
 int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *I1, const float *u1[2], const float *u2[2], float *I1w, float *I1wx,
                float *I1wy, float *grad, float *rho, const float *cubic_tab_dev, const Geo &g, const Ctl *ctl, int cur_host,
@@ -216,6 +220,10 @@ int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *
     const CtlK ck = make_ctlk(ctl);
     const bool cpu = semantics == MI_SEM_CPU_REF;
     if (lds < 0 ? tuning().warp_lds != 0 : lds != 0) {
+#ifndef MIFLOW_EXPERIMENTS
+        set_error("the LDS-staged warp (k_warp_lds) exists in the experiments build only (-DMIFLOW_EXPERIMENTS)");
+        return MI_ERR_NOT_IMPL;
+#else
         const dim3 grid(div_up(g.w, WL_TW), div_up(g.h, WL_TH), g.batch);
         if (cpu && fast) hipLaunchKernelGGL((k_warp_lds<MI_SEM_CPU_REF, true>), grid, dim3(256), 0, s, A, ck, cur_host);
         else if (cpu) hipLaunchKernelGGL((k_warp_lds<MI_SEM_CPU_REF, false>), grid, dim3(256), 0, s, A, ck, cur_host);
@@ -223,7 +231,21 @@ int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *
         else hipLaunchKernelGGL((k_warp_lds<MI_SEM_CUDA_COMPAT, false>), grid, dim3(256), 0, s, A, ck, cur_host);
         MI_HIP_TRY(hipGetLastError());
         return MI_OK;
+#endif
     }
+#ifndef MIFLOW_EXPERIMENTS
+    // the shipped shape: 32 x 2 patches, two per wave (r01u / r02e sweeps); the other patch shapes and the zooming form are tuning variants
+    MI_REQUIRE(!up, MI_ERR_NOT_IMPL, "the zooming warp exists in the experiments build only");
+    {
+        const dim3 grid(div_up(g.w, 32 * 2), div_up(g.h, 4 * 2), g.batch);
+        if (cpu && fast) hipLaunchKernelGGL((k_warp6<MI_SEM_CPU_REF, 32, 2, true>), grid, dim3(256), 0, s, A, ck, cur_host);
+        else if (cpu) hipLaunchKernelGGL((k_warp6<MI_SEM_CPU_REF, 32, 2, false>), grid, dim3(256), 0, s, A, ck, cur_host);
+        else if (fast) hipLaunchKernelGGL((k_warp6<MI_SEM_CUDA_COMPAT, 32, 2, true>), grid, dim3(256), 0, s, A, ck, cur_host);
+        else hipLaunchKernelGGL((k_warp6<MI_SEM_CUDA_COMPAT, 32, 2, false>), grid, dim3(256), 0, s, A, ck, cur_host);
+        MI_HIP_TRY(hipGetLastError());
+        return MI_OK;
+    }
+#else
     const int tile = warp_tile();
     const int np = tuning().warp_np;   // patches per wave (MIFLOW_WARP_NP = 1 | 2 | 4, default 2)
     const dim3 grid(div_up(g.w, tile * np), div_up(g.h, 4 * (64 / tile)), g.batch);
@@ -250,6 +272,7 @@ int warp_fused(int semantics, bool fast, int lds, const float *I0, const float *
 #undef LAUNCH_W6
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
+#endif
 }
 
 }  // namespace tvl1

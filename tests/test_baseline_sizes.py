@@ -359,8 +359,8 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(gpu):
     assert out["gathered_flows_identical"] is True, out.get("with_scatter_gather")
 
 
-def test_fused_warp_pass_is_bit_identical(gpu):
-    """Round 5: `MIFLOW_TB_FW=1` runs a warp whose iterations are one pass of the T = 10 kernel INSIDE that pass --
+def test_fused_warp_pass_is_bit_identical(gpu, exp_env):
+    """(Experiments build: the fused form lost its A/B, profiles/r14, and is not in the release library since round 6.)  Round 5: `MIFLOW_TB_FW=1` runs a warp whose iterations are one pass of the T = 10 kernel INSIDE that pass --
     four producer waves per workgroup compute I1wx, I1wy, rho_c with the warp kernel's own per-pixel routines (tvl1_warp_px.h) and
     hand them to the joined consumer waves through LDS; the three planes never reach HBM.  Same operations in the same order: the flows
     of fixed-work calcs (both arithmetics, f32 and u8 frames, odd sizes, 8..64 pairs, one and two passes per warp) must not change by
@@ -368,7 +368,7 @@ def test_fused_warp_pass_is_bit_identical(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fw_check.py")], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fw_check.py")], capture_output=True, text=True, timeout=1200, env=exp_env)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert r.stdout.count("IDENTICAL") == 8 and "DIFFERENT" not in r.stdout, r.stdout[-3000:]
     assert "fused warp" in r.stdout   # the fused kernel really ran in the MIFLOW_TB_FW=1 process (MIFLOW_TB_VERBOSE lines)
@@ -376,16 +376,21 @@ def test_fused_warp_pass_is_bit_identical(gpu):
 
 def test_scheduling_switches_of_the_release_library_do_not_change_results(gpu):
     """The release switches that only move WORK AROUND -- `MIFLOW_LANES` (internal streams of a batch), `MIFLOW_TB_HIST` (block lengths
-    of the convergence-checked path from the handle's previous calc), `MIFLOW_TB_JW=0` (independent instead of joined waves),
-    `MIFLOW_TB_FW=1` (warp inside the pass) -- must leave the flows of a fixed-work batch and of a class-default batch bit-identical
-    (each setting in its own process: the switches are read once)."""
+    of the convergence-checked path from the handle's previous calc) -- must leave the flows of a fixed-work batch and of a
+    class-default batch bit-identical (each setting in its own process: the switches are read once).  Where the experiments build is in
+    the tree, its `MIFLOW_TB_JW=0` (independent instead of joined waves) and `MIFLOW_TB_FW=1` (warp inside the pass) must give the
+    release library's digests as well -- two other formulations of the same arithmetic."""
     import re
     import subprocess
     import sys
+    from conftest import experiments_lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dig = {}
-    for tag, env in (("default", {}), ("lanes1", {"MIFLOW_LANES": "1"}), ("lanes3", {"MIFLOW_LANES": "3"}), ("nohist", {"MIFLOW_TB_HIST": "0"}),
-                     ("jw0", {"MIFLOW_TB_JW": "0"}), ("fw1", {"MIFLOW_TB_FW": "1"})):
+    settings = [("default", {}), ("lanes1", {"MIFLOW_LANES": "1"}), ("lanes3", {"MIFLOW_LANES": "3"}), ("nohist", {"MIFLOW_TB_HIST": "0"})]
+    if experiments_lib():
+        settings += [("exp", {"MIFLOW_LIB": experiments_lib()}), ("exp_jw0", {"MIFLOW_LIB": experiments_lib(), "MIFLOW_TB_JW": "0"}),
+                     ("exp_fw1", {"MIFLOW_LIB": experiments_lib(), "MIFLOW_TB_FW": "1"})]
+    for tag, env in settings:
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "defaults_digest.py"), "6", "both"], capture_output=True, text=True,
                            env=dict(os.environ, **env), timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -648,10 +653,13 @@ def test_fused_warp_equals_gather_warp(gpu, oracle, sem, amp):
 @pytest.mark.parametrize("amp", [0.0, 2.5, 12.0, 400.0])
 @pytest.mark.parametrize("shape", [(130, 203), (6, 9), (97, 640)])
 def test_fused_warp_lds_staged_equals_gather(gpu, sem, amp, shape):
-    """k_warp_lds (windows read from an LDS-staged region of I1 found from the tile's own flows; fallback to the global path
+    """(Experiments build only since round 6: the LDS-staged warp lost its A/B under the two-lane overlap, r02z3.)  k_warp_lds (windows read from an LDS-staged region of I1 found from the tile's own flows; fallback to the global path
     for border windows and for tiles whose flow spreads the windows beyond the buffer: amp 12 and 400) and k_warp6 (global
     gather) are bit-identical, in exact and in fast (separable sums) form."""
     from opencv_contrib_amd import cuda
+    from conftest import loaded_library_is_experiments_build
+    if not loaded_library_is_experiments_build():
+        pytest.skip("k_warp_lds is compiled into the experiments build only (run the suite with MIFLOW_LIB=libmiflow_exp.so)")
     h, w = shape
     rng = np.random.default_rng(sem * 7 + int(amp) + h)
     I0 = (rng.random((h, w)) * 255).astype(np.float32)
