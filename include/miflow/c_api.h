@@ -298,7 +298,10 @@ MI_API int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1
  * `stream` like calc(): a level whose planes exceed the last-level cache runs group by group of pairs, every second group on a stream the
  * handle owns, forked from and joined back into `stream` inside the call (not while `stream` is being captured: one chain then).  The
  * frames and flows must stay valid until the work enqueued on `stream` has run -- the pyramid reads the caller's matrices in place at
- * every level.  Results are the bytes of n calc()s. */
+ * every level.  Results are the bytes of n calc()s.
+ * ONE calc in flight per handle: a handle owns its scratch planes AND the internal stream / events of the pair groups, so calls on one
+ * handle must be ordered -- the same `stream`, or a synchronisation between calls on different streams or from different host threads
+ * (the reference's object has the same rule: its GpuMat members are per-object scratch).  Use one handle per concurrent caller. */
 MI_API int mi_farneback_calc_batch(mi_farneback *h, int n, const mi_mat *I0s, const mi_mat *I1s, mi_mat *flows, void *stream);
 MI_API void mi_farneback_destroy(mi_farneback *h);
 

@@ -135,6 +135,7 @@ def lib():
         "miflow_selftest_lane_shift": (i, [C.POINTER(i)]),
         "miflow_selftest_rccl_self_copy": (i, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(i)]),
         "miflow_selftest_jw_fault": (i, [C.POINTER(i)]),
+        "miflow_selftest_farneback_poison": (i, [vp, vp]),
         "miflow_selftest_tvl1_slots": (i, [vp, i, C.POINTER(i), i, vp]),
         "mi_stereobm_default_params": (None, [C.POINTER(StereoBMParams)]),
         "mi_stereobm_create": (i, [C.POINTER(StereoBMParams), C.POINTER(vp)]),

@@ -3,6 +3,8 @@
 // reference fans out over 5 streams and blocks the host once per level, :319-324,366,456).
 #include "farneback_dev.h"
 #include "fb_groups.h"
+#include "fb_plan.h"
+#include "mi_selftest.h"
 #include "tvl1_dev.h"   // tvl1::resize == cuda::resize(INTER_LINEAR) on dense f32 planes
 #include <cfloat>
 #include <cmath>
@@ -88,15 +90,10 @@ struct mi_farneback {
     std::vector<float *> pyr[2];
     std::vector<Plane> pyrg;
     float *pyr_base = nullptr;  // fast-pyramid levels of pair 0 (inside the pair block)
-    // Round 4: the frames' side of a level (blur, resize, polynomial expansion: farneback.cpp:434-454) does not depend on the flow, so
-    // it runs for ALL levels on an internal stream while the main stream iterates the coarser levels -- a single 640 x 480 pair is a
-    // chain of ~60 dependent launches of ~5 us, and this takes the 9 pyramid launches of the finer levels off that chain.  Needs the
-    // expansions of every level at once: Rall = per-level R[0] | R[1] regions (10 planes each, level-sized) inside the pair block.
-    float *Rall = nullptr;
-    long long Rall_floats = 0;
+    // internal stream + events of the two-chain pair groups (enqueue_level).  ONE calc in flight per handle: a handle used from two host
+    // threads, or on two streams without a synchronisation in between, races on the arena AND on this stream's ordering (c_api.h).
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_level;
 };
 
 static int cv_round(double v) { return (int)std::lrint(v); }
@@ -161,7 +158,6 @@ void mi_farneback_destroy(mi_farneback *h)
     if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    for (hipEvent_t e : h->ev_level) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -175,11 +171,8 @@ static int ensure(mi_farneback *h, int W, int H, int B)
     // per pair: frames 2, blurred 2, lvl 2, R 2x5, M 5, bufM 5, flows 6 = 32 planes, + the fast-pyramid levels of both frames
     // (sum over the half-size levels < 2/3 of a plane per frame: 2 planes reserved).  The two frames' planes of a kind are ADJACENT
     // (frame 1 = frame 0 + one plane; R[1] = R[0] + five): the pyramid kernels run both frames in one launch
-    // + 16 planes of room for the per-level expansions (10 planes x sum of the level sizes: 13.3 planes at pyrScale 0.5; a pyramid
-    // that needs more runs level by level on the caller's stream as before)
-    // -- the 16 planes exist only where the experiments build's MIFLOW_FB_ASYNC asks for that path (it measured slower and is off)
-    const bool want_rall = tuning().fb_async != 0;
-    const size_t per_pair = n * (want_rall ? 50 : 34);
+    // (round 4's all-levels-at-once expansion planes and the internal-stream pyramid they served measured slower, r08i, and are gone)
+    const size_t per_pair = n * 34;
     MI_HIP_TRY(hipMalloc((void **)&h->arena, sizeof(float) * per_pair * (size_t)B));
     float *p = h->arena;
     auto take = [&](size_t k) { float *q = p; p += n * k; return q; };
@@ -187,7 +180,6 @@ static int ensure(mi_farneback *h, int W, int H, int B)
     h->R[0] = take(5); h->R[1] = take(5); h->M = take(5); h->bufM = take(5);
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 2; ++b) h->flow[a][b] = take(1);
     h->pyr_base = take(2);
-    h->Rall = want_rall ? take(16) : nullptr; h->Rall_floats = want_rall ? (long long)n * 16 : 0;
     h->bs = (long long)per_pair;
     h->capW = W; h->capH = H; h->capB = B;
     return MI_OK;
@@ -222,6 +214,171 @@ static int check_pair(const mi_mat *I0, const mi_mat *I1, const mi_mat *flow, co
     MI_REQUIRE(flow->step % 8 == 0 && ((uintptr_t)flow->data % 8) == 0, MI_ERR_BAD_ARG, "flow must be 8-byte aligned");
     if (I0->type == MI_32FC1) MI_REQUIRE(I0->step % 4 == 0 && I1->step % 4 == 0, MI_ERR_BAD_ARG, "float frames must be 4-byte aligned");
     MI_REQUIRE(I0->rows == ref->rows && I0->cols == ref->cols && I0->type == ref->type, MI_ERR_BAD_SIZE, "all pairs of a batch must share size and type");
+    return MI_OK;
+}
+
+// ---- one mi_farneback_calc_batch call: what the level loop needs besides the plan, and the state it carries from level to level
+struct FbCall {
+    mi_farneback *h;
+    const FbPlan *plan;
+    int B;
+    long long bs, pn;          // floats between consecutive pairs' blocks / in one full-resolution plane (= the distance between the two frames' planes of a kind)
+    Plane g0;                  // full-resolution geometry of the batch
+    const mi_mat *I0s, *I1s;
+    mi_mat *flows;
+    hipStream_t st;            // the caller's stream
+    bool gauss, direct;        // OPTFLOW_FARNEBACK_GAUSSIAN; the pre-blur reads the caller's matrices itself
+    PolyC C;
+    Taps wk;                   // the Gaussian window of the iterations (gauss)
+    float *fx0, *fy0;          // level-0 flow planes (and the caller's initial flow)
+    float *prevx = nullptr, *prevy = nullptr;   // the coarser level's flow
+    Plane gprev;
+    bool merged = false;       // the last iteration wrote the caller's flow matrix itself
+};
+
+// blur + resize + polynomial expansion of BOTH frames for level k (the reference's loop over the two frames, farneback.cpp:434-454,
+// each stage once for both: 3 launches instead of 6), for pairs b0 .. b0 + nb - 1 of the batch: a pair group of the level runs its own
+// stage, so that the expansions it is about to iterate on are still in the last-level cache
+static int pyramid_stage(const FbCall &c, int k, hipStream_t sx, int b0, int nb)
+{
+    mi_farneback *h = c.h;
+    const mi_farneback_params &P = h->P;
+    const FbLevel &L = c.plan->lv[k];
+    const long long po = (long long)b0 * c.bs, pn = c.pn;
+    Plane g = plane_of(L.w, L.h, c.bs, nb), gf = c.g0;
+    gf.batch = nb;
+    float *const R0 = h->R[0] + po;
+    const long long fsR = 5 * pn;   // R[1] = R[0] + five full-size planes
+    if (P.fast_pyramids)
+        return poly_exp(h->pyr[0][k] + po, R0, g, P.poly_n, c.C, sx, 2, h->pyr[1][k] - h->pyr[0][k], fsR);
+    const int smoothSize = L.smooth;
+    std::vector<float> gk(smoothSize);
+    gaussian_kernel(smoothSize, L.sigma, gk.data());
+    Taps K;
+    memset(&K, 0, sizeof(K));
+    for (int i = 0; i <= smoothSize / 2; ++i) K.k[i] = gk[smoothSize / 2 + i];
+    int r;
+    if (c.direct) {
+        for (int c0 = 0; c0 < nb; c0 += kFmtPairs) {
+            FmtTab T;
+            memset(&T, 0, sizeof(T));
+            Plane gc = gf;
+            gc.batch = std::min(kFmtPairs, nb - c0);
+            for (int j = 0; j < gc.batch; ++j) {
+                T.a[j] = c.I0s[b0 + c0 + j].data; T.sa[j] = (long long)c.I0s[b0 + c0 + j].step;
+                T.b[j] = c.I1s[b0 + c0 + j].data; T.sb[j] = (long long)c.I1s[b0 + c0 + j].step;
+            }
+            if ((r = gaussian_blur_tab(T, c.I0s[0].type, h->blurred + po + (long long)c0 * c.bs, gc, smoothSize / 2, K, sx, pn))) return r;
+        }
+    } else if ((r = gaussian_blur(h->frames[0] + po, h->blurred + po, gf, smoothSize / 2, K, MI_BORDER_REFLECT101, sx, 2, pn))) return r;
+    const float *src = h->blurred + po;
+    if (!(g.w == gf.w && g.h == gf.h)) {
+        // the level image = cuda::resize of the blurred frame (:447-448).  Few pairs: sampled inside the expansion kernel (same
+        // arithmetic, same bits, one launch less); many pairs: through the level planes (the expansion reads each sample 11 times)
+        if (c.plan->fuse_small) return poly_exp(h->blurred + po, R0, g, P.poly_n, c.C, sx, 2, pn, fsR, &gf);
+        if ((r = resize2(h->blurred + po, h->blurred + po + pn, gf, h->lvl[0] + po, h->lvl[1] + po, g, 1.f, sx))) return r;
+        src = h->lvl[0] + po;
+    }
+    return poly_exp(src, R0, g, P.poly_n, c.C, sx, 2, pn, fsR);
+}
+
+// Level k of the plan: the flow planes' start, then -- for the whole batch or pair group by pair group (fb_groups.h) -- the frames' side,
+// the first matrix update and the iterations (farneback.cpp:396-471; updateFlow_boxFilter / _gaussianBlur :278-312 fused into `iterate`).
+static int enqueue_level(FbCall &c, int k)
+{
+    mi_farneback *h = c.h;
+    const mi_farneback_params &P = h->P;
+    const FbLevel &L = c.plan->lv[k];
+    const int B = c.B;
+    const long long bs = c.bs, pn = c.pn;
+    hipStream_t const caller_st = c.st;
+    const Plane g = plane_of(L.w, L.h, bs, B);
+    float *curx, *cury;
+    if (k > 0) { curx = h->flow[1 + (k & 1)][0]; cury = h->flow[1 + (k & 1)][1]; }
+    else { curx = c.fx0; cury = c.fy0; }
+    int rc;
+    if (L.init_resize) {   // :398-404
+        if ((rc = resize2(c.fx0, c.fy0, c.g0, curx, cury, g, (float)L.scale, caller_st))) return rc;
+    } else if (L.clear_flow) {
+        const size_t bytes = sizeof(float) * (size_t)g.ld * g.h;
+        // the two planes are neighbours in the arena: one fill over both and the gap between them while that gap is small (a single
+        // pair: one launch less); a batch would clear B full-size planes for two coarse ones (r16d: 57 us of a 32-pair calc)
+        if (cury == curx + pn && bytes <= sizeof(float) * (size_t)pn && sizeof(float) * (size_t)pn * B <= (8u << 20)) {
+            MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, sizeof(float) * (size_t)pn + bytes, (size_t)B, caller_st));
+        } else {
+            MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, caller_st));
+            MI_HIP_TRY(hipMemset2DAsync(cury, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, caller_st));
+        }
+    }   // (L.zero_flow: no fill -- the first matrix update takes the flow as zero and the iterations write every pixel of both planes;
+        //  tests/test_farneback.py poisons the arena to hold every iterate variant to that)
+    const float *R0 = h->R[0], *R1 = h->R[0] + 5 * pn;
+    // Pair GROUPS (round 5; the plan: fb_groups.h).  An iteration of a level streams 22 planes per pair (M in and out, both expansions,
+    // the flow); with the whole batch per launch a 640 x 480 level of 32 pairs is 0.9 GB per iteration -- every iteration comes from
+    // HBM.  Group by group instead: the matrix update and ALL iterations of a few pairs whose planes fit the 256 MB last-level cache,
+    // then the next group.  The same launches on the same data in the same order per pair: bit-identical.  Groups are independent
+    // chains of launches: two of them run side by side, the second on the handle's internal stream, each half the size -- the
+    // launches of a chain wait for each other's last workgroups (r16g), and the other chain fills those tails.
+    const int G = L.groups.pairs;
+    const bool two = L.groups.two;
+    if (!L.staged) {   // once for the batch, as the reference orders them
+        if (L.zoom && (rc = resize2(c.prevx, c.prevy, c.gprev, curx, cury, g, (float)(1. / P.pyr_scale), caller_st))) return rc;
+        if ((rc = pyramid_stage(c, k, caller_st, 0, B))) return rc;
+    }
+    if (two) {
+        if (!h->aux) MI_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+        if (!h->ev_fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        if (!h->ev_join) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        MI_HIP_TRY(hipEventRecord(h->ev_fork, caller_st));
+        MI_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    }
+    // an error return from inside the group loop still orders the caller's stream behind whatever the internal one was given
+    struct ChainJoin {
+        hipStream_t st, aux; hipEvent_t ev; bool armed;
+        ~ChainJoin() { if (armed) { (void)hipEventRecord(ev, aux); (void)hipStreamWaitEvent(st, ev, 0); } }
+    } chain_join = {caller_st, h->aux, h->ev_join, two};
+    int gi = 0;
+    for (int b0 = 0; b0 < B; b0 += G, ++gi) {
+        hipStream_t st = (two && (gi & 1)) ? h->aux : caller_st;   // this group's chain
+        const long long goff = (long long)b0 * bs;
+        Plane gg = g;
+        gg.batch = std::min(G, B - b0);
+        float *M = h->M + goff, *bufM = h->bufM + goff;
+        float *gx = curx + goff, *gy = cury + goff;
+        const float *gR0 = R0 + goff, *gR1 = R1 + goff;
+        Plane gp = c.gprev;
+        gp.batch = gg.batch;
+        if (L.staged) {
+            if (L.zoom && (rc = resize2(c.prevx + goff, c.prevy + goff, gp, gx, gy, gg, (float)(1. / P.pyr_scale), st))) return rc;
+            if ((rc = pyramid_stage(c, k, st, b0, gg.batch))) return rc;
+        }
+        if (L.zoom_fused) {
+            if ((rc = update_matrices_resized(c.prevx + goff, c.prevy + goff, gp, (float)(1. / P.pyr_scale), gx, gy, gR0, gR1, M, gg, st))) return rc;
+        } else if ((rc = update_matrices(L.zero_flow ? nullptr : gx, L.zero_flow ? nullptr : gy, gR0, gR1, M, gg, st))) return rc;   // :458
+        for (int i = 0; i < P.num_iters; i++) {   // :465-471 -> :278-312, fused
+            if (L.pair_it && i + 1 < P.num_iters) {
+                const bool last2 = k == 0 && i + 1 == P.num_iters - 1 && B == 1;
+                bool dm2 = false;
+                if ((rc = iterate2(M, gR0, gR1, gx, gy, bufM, gg, P.win_size, c.gauss ? &c.wk : nullptr, i + 1 < P.num_iters - 1, st,
+                                   last2 ? c.flows[0].data : nullptr, last2 ? (long long)c.flows[0].step : 0, &dm2))) return rc;
+                c.merged = c.merged || dm2;
+                std::swap(M, bufM);
+                ++i;
+                continue;
+            }
+            const bool last = k == 0 && i == P.num_iters - 1 && B == 1 && c.plan->fuse_small;
+            bool dm = false;
+            if ((rc = iterate(M, gR0, gR1, gx, gy, bufM, gg, P.win_size, c.gauss ? &c.wk : nullptr, i < P.num_iters - 1, st,
+                              last ? c.flows[0].data : nullptr, last ? (long long)c.flows[0].step : 0, &dm))) return rc;
+            c.merged = c.merged || dm;
+            std::swap(M, bufM);
+        }
+    }
+    if (two) {
+        chain_join.armed = false;
+        MI_HIP_TRY(hipEventRecord(h->ev_join, h->aux));
+        MI_HIP_TRY(hipStreamWaitEvent(caller_st, h->ev_join, 0));
+    }
+    c.prevx = curx; c.prevy = cury; c.gprev = g;
     return MI_OK;
 }
 
@@ -269,17 +426,30 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
     for (int b = 0; b < B && use_init; ++b)
         if ((rc = split_flow(flows[b].data, (long long)flows[b].step, fx0 + b * bs, fy0 + b * bs, g0s, st))) return rc;
 
-    // crop unnecessary levels, farneback.cpp:330-340
-    double scale = 1;
-    int levels = 0;
-    for (; levels < P.num_levels; levels++) {
-        scale *= P.pyr_scale;
-        if (W * scale < 32 || H * scale < 32) break;   // MIN_SIZE :54
+    // ---- the plan (fb_plan.h: pure arithmetic over the call's shape and the tuning knobs, unit-tested without a device)
+    FbKnobs knobs;
+    knobs.fuse = tuning().fb_fuse; knobs.pair = tuning().fb_pair; knobs.group_mb = tuning().fb_group_mb;
+    knobs.chains = tuning().fb_group_streams == 2 ? 2 : 1;
+    {   // groups alternate over two streams only while the caller's stream is NOT being captured (a captured graph stays one chain);
+        // asked once per call
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (knobs.chains == 2 && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) { (void)hipGetLastError(); knobs.chains = 1; }
     }
+    knobs.simds = device_simds();
+    knobs.iterate2_ok = iterate2_supported(P.win_size);
+    const FbShape shape = {W, H, B, P.num_levels, P.pyr_scale, P.fast_pyramids != 0, P.num_iters, use_init};
+    const FbPlan plan = fb_make_plan(shape, knobs);
+    const int levels = plan.levels;
+    for (int k = 0; k <= levels; ++k)
+        MI_REQUIRE(plan.lv[k].smooth / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "pyramid smoothing kernel too large (MAX_KSIZE_HALF)");
+
+    FbCall c;
+    c.h = h; c.plan = &plan; c.B = B; c.bs = bs; c.g0 = g0; c.pn = (long long)g0.ld * H;
+    c.I0s = I0s; c.I1s = I1s; c.flows = flows; c.st = st; c.gauss = gauss;
+    c.fx0 = fx0; c.fy0 = fy0; c.gprev = g0;
     if (P.fast_pyramids) {   // :346-359
         std::vector<Plane> pg(levels + 1);
-        pg[0] = g0;
-        for (int i = 1; i <= levels; ++i) pg[i] = plane_of((pg[i - 1].w + 1) / 2, (pg[i - 1].h + 1) / 2, bs, B);
+        for (int i = 0; i <= levels; ++i) pg[i] = plane_of(plan.lv[i].w, plan.lv[i].h, bs, B);
         h->pyrg = pg;
         for (int f = 0; f < 2; ++f) {
             h->pyr[f].assign(levels + 1, nullptr);
@@ -292,232 +462,22 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
                 if ((rc = pyr_down(h->pyr[f][i - 1], pg[i - 1], h->pyr[f][i], pg[i], st))) return rc;
             }
     }
-    PolyC C;
-    if ((rc = prepare_gaussian(P.poly_n, P.poly_sigma, &C))) return rc;   // setPolynomialExpansionConsts :361
-    Taps wk;
-    memset(&wk, 0, sizeof(wk));
+    if ((rc = prepare_gaussian(P.poly_n, P.poly_sigma, &c.C))) return rc;   // setPolynomialExpansionConsts :361
+    memset(&c.wk, 0, sizeof(c.wk));
     if (gauss) {   // :460-464
         std::vector<float> k(P.win_size);
         gaussian_kernel(P.win_size, (double)(P.win_size / 2 * 0.3f), k.data());
-        for (int i = 0; i <= P.win_size / 2; ++i) wk.k[i] = k[P.win_size / 2 + i];
-    }
-
-    // ---- per-level geometry (farneback.cpp:374-395)
-    struct Lv { Plane g; double sigma, scale; int smooth; float *R0; long long fsR; };
-    std::vector<Lv> lv(levels + 1);
-    const long long pn = (long long)g0.ld * H;   // one full-resolution plane: the distance between the two frames' planes of a kind
-    long long need = 0;
-    for (int k = levels; k >= 0; k--) {
-        scale = 1;
-        for (int i = 0; i < k; i++) scale *= P.pyr_scale;
-        const double sigma = (1. / scale - 1) * 0.5;
-        int smoothSize = cv_round(sigma * 5) | 1;
-        smoothSize = smoothSize > 3 ? smoothSize : 3;
-        int width = cv_round(W * scale), height = cv_round(H * scale);
-        if (P.fast_pyramids) { width = h->pyrg[k].w; height = h->pyrg[k].h; }
-        MI_REQUIRE(smoothSize / 2 <= MI_FB_MAX_KSIZE_HALF, MI_ERR_BAD_ARG, "pyramid smoothing kernel too large (MAX_KSIZE_HALF)");
-        lv[k].g = plane_of(width, height, bs, B); lv[k].sigma = sigma; lv[k].scale = scale; lv[k].smooth = smoothSize;
-        need += 10LL * lv[k].g.ld * lv[k].g.h;
+        for (int i = 0; i <= P.win_size / 2; ++i) c.wk.k[i] = k[P.win_size / 2 + i];
     }
     // The frames as f32 planes -- unless every level's pre-blur can read the caller's matrices itself (`direct`, round 5: the tiled blur
     // has an instantiation for every level's kernel size): then the conversion pass and its planes are not needed at all.
-    bool direct = !P.fast_pyramids && tuning().fb_direct != 0;
-    for (int k = 0; k <= levels && direct; ++k) direct = gaussian_blur_tab_ok(g0, lv[k].smooth / 2);
-    if (!P.fast_pyramids && !direct && (rc = convert_frames())) return rc;
-    // The frames' side of every level on the internal stream (see mi_farneback::Rall) when all expansions fit; MIFLOW_FB_ASYNC=0 or
-    // a pyramid that does not fit: level by level on the caller's stream, through the one full-size R pair.
-    bool async = need <= h->Rall_floats && tuning().fb_async != 0;
-    {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // not under stream capture: keep the captured graph a single chain
-        if (async && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) { (void)hipGetLastError(); async = false; }
-    }
-    {
-        long long off = 0;
-        for (int k = levels; k >= 0; k--) {
-            const long long lp = (long long)lv[k].g.ld * lv[k].g.h;
-            if (async) { lv[k].R0 = h->Rall + off; lv[k].fsR = 5 * lp; off += 10 * lp; }
-            else { lv[k].R0 = h->R[0]; lv[k].fsR = 5 * pn; }
-        }
-    }
-    // launch-latency-bound calls (a single pair or a few: every launch of the level loop underfills the device) take the forms with fewer
-    // launches: resize sampled inside the consumer kernels, the merge written by the last iteration.  MIFLOW_FB_FUSE=0 / 1 forces it.
-    const bool fuse_small = tuning().fb_fuse >= 0 ? tuning().fb_fuse != 0 : (long long)W * H * B <= 1500000;
-    // blur + resize + polynomial expansion of BOTH frames for level k (the reference's loop over the two frames, farneback.cpp:434-454,
-    // each stage once for both: 3 launches instead of 6)
-    // (pairs b0 .. b0 + nb - 1 of the batch: a pair group of the level loop below runs its own stage, so that the expansions it is
-    // about to iterate on are still in the last-level cache)
-    auto pyramid_stage = [&](int k, hipStream_t sx, int b0, int nb) -> int {
-        const long long po = (long long)b0 * bs;
-        Plane g = lv[k].g, gf = g0;
-        g.batch = nb; gf.batch = nb;
-        if (P.fast_pyramids)
-            return poly_exp(h->pyr[0][k] + po, lv[k].R0 + po, g, P.poly_n, C, sx, 2, h->pyr[1][k] - h->pyr[0][k], lv[k].fsR);
-        const int smoothSize = lv[k].smooth;
-        std::vector<float> gk(smoothSize);
-        gaussian_kernel(smoothSize, lv[k].sigma, gk.data());
-        Taps K;
-        memset(&K, 0, sizeof(K));
-        for (int i = 0; i <= smoothSize / 2; ++i) K.k[i] = gk[smoothSize / 2 + i];
-        int r;
-        if (direct) {
-            for (int c0 = 0; c0 < nb; c0 += kFmtPairs) {
-                FmtTab T;
-                memset(&T, 0, sizeof(T));
-                Plane gc = gf;
-                gc.batch = std::min(kFmtPairs, nb - c0);
-                for (int j = 0; j < gc.batch; ++j) {
-                    T.a[j] = I0s[b0 + c0 + j].data; T.sa[j] = (long long)I0s[b0 + c0 + j].step;
-                    T.b[j] = I1s[b0 + c0 + j].data; T.sb[j] = (long long)I1s[b0 + c0 + j].step;
-                }
-                if ((r = gaussian_blur_tab(T, I0s[0].type, h->blurred + po + (long long)c0 * bs, gc, smoothSize / 2, K, sx, pn))) return r;
-            }
-        } else if ((r = gaussian_blur(h->frames[0] + po, h->blurred + po, gf, smoothSize / 2, K, MI_BORDER_REFLECT101, sx, 2, pn))) return r;
-        const float *src = h->blurred + po;
-        if (!(g.w == gf.w && g.h == gf.h)) {
-            // the level image = cuda::resize of the blurred frame (:447-448).  Few pairs: sampled inside the expansion kernel (same
-            // arithmetic, same bits, one launch less); many pairs: through the level planes (the expansion reads each sample 11 times)
-            if (fuse_small) return poly_exp(h->blurred + po, lv[k].R0 + po, g, P.poly_n, C, sx, 2, pn, lv[k].fsR, &gf);
-            if ((r = resize2(h->blurred + po, h->blurred + po + pn, gf, h->lvl[0] + po, h->lvl[1] + po, g, 1.f, sx))) return r;
-            src = h->lvl[0] + po;
-        }
-        return poly_exp(src, lv[k].R0 + po, g, P.poly_n, C, sx, 2, pn, lv[k].fsR);
-    };
-    if (async) {
-        if (!h->aux) MI_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-        if (!h->ev_fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        while ((int)h->ev_level.size() <= levels) {
-            hipEvent_t e;
-            MI_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            h->ev_level.push_back(e);
-        }
-        MI_HIP_TRY(hipEventRecord(h->ev_fork, st));             // the frames (and the fast pyramid) are complete here
-        MI_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        for (int k = levels; k >= 0; k--) {
-            if ((rc = pyramid_stage(k, h->aux, 0, B))) { (void)hipStreamSynchronize(h->aux); return rc; }
-            MI_HIP_TRY(hipEventRecord(h->ev_level[k], h->aux));
-        }
-    }
+    c.direct = !P.fast_pyramids && tuning().fb_direct != 0;
+    for (int k = 0; k <= levels && c.direct; ++k) c.direct = gaussian_blur_tab_ok(g0, plan.lv[k].smooth / 2);
+    if (!P.fast_pyramids && !c.direct && (rc = convert_frames())) return rc;
 
-    float *prevx = nullptr, *prevy = nullptr;
-    Plane gprev = g0;
-    bool merged = false;
-    for (int k = levels; k >= 0; k--) {
-        scale = lv[k].scale;
-        const Plane g = lv[k].g;
-        float *curx, *cury;
-        if (k > 0) { curx = h->flow[1 + (k & 1)][0]; cury = h->flow[1 + (k & 1)][1]; }
-        else { curx = fx0; cury = fy0; }
-        bool zero_flow = false;
-        if (!prevx) {
-            if (use_init) {   // :398-404
-                if (k > 0 && (rc = resize2(fx0, fy0, g0, curx, cury, g, (float)scale, st))) return rc;
-            } else if (P.num_iters > 0) {
-                zero_flow = true;   // the first matrix update takes the flow as zero and the iterations write every pixel of both planes: no fill
-            } else {
-                const size_t bytes = sizeof(float) * (size_t)g.ld * g.h;
-                // the two planes are neighbours in the arena: one fill over both and the gap between them while that gap is small (a single
-                // pair: one launch less); a batch would clear B full-size planes for two coarse ones (r16d: 57 us of a 32-pair calc)
-                if (cury == curx + pn && bytes <= sizeof(float) * (size_t)pn && sizeof(float) * (size_t)pn * B <= (8u << 20)) {
-                    MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, sizeof(float) * (size_t)pn + bytes, (size_t)B, st));
-                } else {
-                    MI_HIP_TRY(hipMemset2DAsync(curx, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
-                    MI_HIP_TRY(hipMemset2DAsync(cury, sizeof(float) * (size_t)bs, 0, bytes, (size_t)B, st));
-                }
-            }
-        }
-        const float *R0 = lv[k].R0, *R1 = lv[k].R0 + lv[k].fsR;
-        // Pair GROUPS (round 5).  An iteration of a level streams 22 planes per pair (M in and out, both expansions, the flow); with the
-        // whole batch per launch a 640 x 480 level of 32 pairs is 0.9 GB per iteration -- every iteration comes from HBM.  Run group by
-        // group instead: the matrix update and ALL iterations of a few pairs whose planes fit the 256 MB last-level cache, then the next
-        // group.  The same launches on the same data in the same order per pair: bit-identical.  Small calls (one launch chain per
-        // level, few-launch forms) keep the whole batch.
-        // :412-417.  A level of another size than the coarser one: sampled inside the first matrix update (same arithmetic, same bits; one
-        // launch and one round trip of the flow planes less -- round 4 for small calls, round 5 for every call); same size: a copy
-        const bool zoom_fused = prevx && !(gprev.w == g.w && gprev.h == g.h) && tuning().fb_fuse != 0;
-        const bool zoom = prevx && !zoom_fused;
-        // Groups are independent chains of launches (their pairs' planes only): two of them run side by side, the second on the handle's
-        // internal stream, each half the size -- the launches of a chain wait for each other's last workgroups (r16g: 37 us per level-0
-        // iteration of 7 pairs against 25 us of vector issue), and the other chain fills those tails.  Not while the caller's stream is
-        // being captured (the graph stays one chain).  The plan itself: fb_groups.h.
-        int chains = tuning().fb_group_streams == 2 ? 2 : 1;
-        if (chains == 2) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); chains = 1; }
-        }
-        GroupPlan gp_ = {B, 1, false};
-        if (!fuse_small) gp_ = plan_pair_groups(B, 22LL * (long long)g.ld * g.h * (long long)sizeof(float), tuning().fb_group_mb, chains);
-        const int G = gp_.pairs;
-        const bool two = gp_.two;
-        // a level in groups: the zoom of the coarser flow and the frames' side go group by group too (what they write is what the group
-        // reads next); otherwise once for the batch, as the reference orders them
-        const bool staged = G < B && !async;
-        if (!staged) {
-            if (zoom && (rc = resize2(prevx, prevy, gprev, curx, cury, g, (float)(1. / P.pyr_scale), st))) return rc;
-            if (async) MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_level[k], 0));
-            else if ((rc = pyramid_stage(k, st, 0, B))) return rc;
-        }
-        if (two) {
-            if (!h->aux) MI_HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-            if (!h->ev_fork) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            if (!h->ev_join) MI_HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-            MI_HIP_TRY(hipEventRecord(h->ev_fork, st));
-            MI_HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-        }
-        // an error return from inside the group loop still orders the caller's stream behind whatever the internal one was given
-        struct ChainJoin {
-            hipStream_t st, aux; hipEvent_t ev; bool armed;
-            ~ChainJoin() { if (armed) { (void)hipEventRecord(ev, aux); (void)hipStreamWaitEvent(st, ev, 0); } }
-        } chain_join = {st, h->aux, h->ev_join, two};
-        hipStream_t const caller_st = st;
-        int gi = 0;
-        for (int b0 = 0; b0 < B; b0 += G, ++gi) {
-        hipStream_t st = (two && (gi & 1)) ? h->aux : caller_st;   // this group's chain
-        const long long goff = (long long)b0 * bs;
-        Plane gg = g;
-        gg.batch = std::min(G, B - b0);
-        float *M = h->M + goff, *bufM = h->bufM + goff;
-        float *gx = curx + goff, *gy = cury + goff;
-        const float *gR0 = R0 + goff, *gR1 = R1 + goff;
-        if (staged) {
-            Plane gp = gprev;
-            gp.batch = gg.batch;
-            if (zoom && (rc = resize2(prevx + goff, prevy + goff, gp, gx, gy, gg, (float)(1. / P.pyr_scale), st))) return rc;
-            if ((rc = pyramid_stage(k, st, b0, gg.batch))) return rc;
-        }
-        if (zoom_fused) {
-            Plane gp = gprev;
-            gp.batch = gg.batch;
-            if ((rc = update_matrices_resized(prevx + goff, prevy + goff, gp, (float)(1. / P.pyr_scale), gx, gy, gR0, gR1, M, gg, st))) return rc;
-        } else if ((rc = update_matrices(zero_flow ? nullptr : gx, zero_flow ? nullptr : gy, gR0, gR1, M, gg, st))) return rc;   // :458
-        // levels whose 64 x 4 grid underfills the device: two iterations per launch (MIFLOW_FB_PAIR=0 / 1 forces the choice)
-        const bool pair_it = fuse_small && iterate2_supported(P.win_size) &&
-                             (tuning().fb_pair >= 0 ? tuning().fb_pair != 0 : (long long)div_up(g.w, 64) * div_up(g.h, 4) * B <= 2LL * (device_simds() / 4));
-        for (int i = 0; i < P.num_iters; i++) {   // :465-471 -> :278-312, fused
-            if (pair_it && i + 1 < P.num_iters) {
-                const bool last2 = k == 0 && i + 1 == P.num_iters - 1 && B == 1;
-                bool dm2 = false;
-                if ((rc = iterate2(M, gR0, gR1, gx, gy, bufM, gg, P.win_size, gauss ? &wk : nullptr, i + 1 < P.num_iters - 1, st,
-                                   last2 ? flows[0].data : nullptr, last2 ? (long long)flows[0].step : 0, &dm2))) return rc;
-                merged = merged || dm2;
-                std::swap(M, bufM);
-                ++i;
-                continue;
-            }
-            const bool last = k == 0 && i == P.num_iters - 1 && B == 1 && fuse_small;
-            bool dm = false;
-            if ((rc = iterate(M, gR0, gR1, gx, gy, bufM, gg, P.win_size, gauss ? &wk : nullptr, i < P.num_iters - 1, st,
-                              last ? flows[0].data : nullptr, last ? (long long)flows[0].step : 0, &dm))) return rc;
-            merged = merged || dm;
-            std::swap(M, bufM);
-        }
-        }
-        if (two) {
-            chain_join.armed = false;
-            MI_HIP_TRY(hipEventRecord(h->ev_join, h->aux));
-            MI_HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-        }
-        prevx = curx; prevy = cury; gprev = g;
-    }
+    for (int k = levels; k >= 0; k--)
+        if ((rc = enqueue_level(c, k))) return rc;
+    const bool merged = c.merged;
     if (merged) return MI_OK;
     if (B > 1) {
         for (int b0 = 0; b0 < B; b0 += kFmtPairs) {
@@ -537,6 +497,14 @@ int mi_farneback_calc_batch(mi_farneback *h, int nb, const mi_mat *I0s, const mi
 int mi_farneback_calc(mi_farneback *h, const mi_mat *I0, const mi_mat *I1, mi_mat *flow, void *stream)
 {
     return mi_farneback_calc_batch(h, 1, I0, I1, flow, stream);
+}
+
+// test hook (mi_selftest.h): NaNs over the whole arena
+int miflow_selftest_farneback_poison(mi_farneback *h, void *stream)
+{
+    MI_REQUIRE(h && h->arena, MI_ERR_BAD_ARG, "no arena yet: run a calc first");
+    MI_HIP_TRY(hipMemsetAsync(h->arena, 0xff, sizeof(float) * (size_t)h->bs * (size_t)h->capB, (hipStream_t)stream));
+    return MI_OK;
 }
 
 }  // extern "C"

@@ -105,7 +105,6 @@ const Tuning &tuning()
         t.sbm_swz = EXP_INT("MIFLOW_SBM_SWZ", 1);
         t.sbm_texfuse = EXP_INT("MIFLOW_SBM_TEXFUSE", 1);
         t.fb_rows = EXP_INT("MIFLOW_FB_ROWS", 4) == 8 ? 8 : 4;
-        t.fb_async = EXP_INT("MIFLOW_FB_ASYNC", 0);   // r08i: the cross-stream events cost more than the 9 launches they take off the chain (2 718 vs 3 089 calc/s)
         t.fb_group_mb = env_int("MIFLOW_FB_GROUP_MB", 240);   // 640 x 480 x 32 pairs, two chains (r16i / r16j): 160 | 200 | 240 | 270 | 300 | 330 | 440 MB = 9 630 | 9 630-9 740 | 10 030-10 170 | 9 370 | 9 300 | 8 890 | 8 560 pairs/s; one chain (r15k): 0 | 200 | 320 = 7 190 | 7 755 | 7 185
         t.fb_fuse = env_int("MIFLOW_FB_FUSE", -1);
         t.fb_pair = env_int("MIFLOW_FB_PAIR", -1);

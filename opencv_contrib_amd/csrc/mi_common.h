@@ -68,7 +68,6 @@ struct Tuning {
     int sbm_wt;              // MIFLOW_SBM_WT: StereoBM winner-take-all through an LDS transposition (1, default) or the transposed DPP reduction (0)
     int fb_rows, fb_swz;     // MIFLOW_FB_ROWS (4 | 8 rows per workgroup), MIFLOW_FB_SWZ (XCD-contiguous tile order) of the tiled kernel
     int fb_group_mb;         // MIFLOW_FB_GROUP_MB: a batched Farneback level runs its matrix update + all iterations group by group of pairs whose 22 planes fit this many MB (the last-level cache; 0 = whole batch per launch)
-    int fb_async;            // MIFLOW_FB_ASYNC: Farneback pyramid side of all levels on an internal stream beside the iterations (1) or in line (0, default: measured faster)
     int fb_fuse;             // MIFLOW_FB_FUSE: Farneback few-launch forms (resize sampled inside poly_exp / update_matrices, merge in the last iteration): -1 = small calls (default), 0, 1
     int fb_pair;             // MIFLOW_FB_PAIR: Farneback two iterations per launch (k_iterate2_t): -1 = levels that underfill the device (default), 0, 1
     int fb_narrow;           // MIFLOW_FB_NARROW: Farneback iteration kernel on 64 x 4 tiles: -1 = where the 256-column grid underfills the device (default), 0 = never, 1 = always

@@ -26,6 +26,11 @@ MI_API int miflow_selftest_jw_fault(int *fault);
 /* the RCCL binding of mi_tvl1_multi on one device: out_host = in_host after a grouped ncclSend / ncclRecv to self; *available = 0
  * (and nothing copied) where librccl is absent */
 MI_API int miflow_selftest_rccl_self_copy(const unsigned char *in_host, unsigned char *out_host, size_t bytes, int *available);
+/* fills the handle's whole scratch arena (every plane of every pair slot it was sized for) with NaNs on `stream`: a calc that reads a
+ * plane it has not written first -- e.g. the coarsest level's flow, which is never cleared (zero_flow, csrc/fb_plan.h) -- then shows it.
+ * MI_ERR_BAD_ARG before the handle's first calc (no arena yet). */
+struct mi_farneback;
+MI_API int miflow_selftest_farneback_poison(struct mi_farneback *h, void *stream);
 struct mi_tvl1;
 MI_API int miflow_selftest_tvl1_slots(struct mi_tvl1 *h, int pair, int *out_host, int cap_launches, void *stream);
 #ifdef __cplusplus

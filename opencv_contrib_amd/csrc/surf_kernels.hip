@@ -970,6 +970,65 @@ __device__ __forceinline__ float area_filter_lds(const unsigned char *tile, int 
     if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + T(sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
     return sat_u8(out);
 }
+// ---- row-coalesced staging of a strip (round 6).  Until round 5 the lattice tile was filled by one byte
+// gather per lattice point -- 8 x 8 blocks of the rotated window lattice, 41 L1 tag lookups per wave load for 64 useful bytes, the kernel
+// at 0.84 of the L1 lookup rate (profiles/surf_counters.json).  Now a strip is staged in two steps: (1) the image rows the strip's
+// lattice touches are copied into an IMAGE tile with aligned dword loads along the rows -- per image row only the segment the rotated
+// strip covers (a conservative x-range from the strip's four corners), all segments at one pitch: a wave load touches 4-5 lines for 256
+// useful bytes; (2) every lattice point takes its texel from that tile (LDS -> LDS), with win_get's own coordinate expression.  A texel
+// the conservative range should ever miss is read from global memory instead: the lattice tile holds the same bytes as before whatever
+// the geometry code does, and area_filter_lds / desc_tail are untouched -- bit-identical descriptors by construction.
+constexpr int kStripRowsMax = 1024;   // image rows one strip may touch (a strip that touches more takes the per-texel gather)
+struct StripRows { int y0, nrows; };
+// texel rows the lattice region i in [i0, i1], j in [j0, j1] touches: py is monotone in i and in j (also in float arithmetic: every
+// operation of win_get's expression is monotone), so its extremes sit at the four corners
+__device__ __forceinline__ StripRows strip_rows(const Win &w, int i0, int i1, int j0, int j1)
+{
+    float lo = 3.0e38f, hi = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = (k & 1) ? i1 : i0, j = (k & 2) ? j1 : j0;
+        const float py = w.cy - (w.off + j) * w.s + (w.off + i) * w.c;
+        lo = fminf(lo, py); hi = fmaxf(hi, py);
+    }
+    StripRows r;
+    r.y0 = clampi(__float2int_rd(fmaxf(lo, -1.0e6f)), 0, w.rows - 1);
+    r.nrows = clampi(__float2int_rd(fminf(hi, 1.0e6f)), 0, w.rows - 1) - r.y0 + 1;
+    return r;
+}
+// conservative range [xl, xr] of the texel columns the region touches on texel row y (clamped to the image like win_get clamps):
+// extremes of px over (rectangle of the region) x (band py in [y, y + 1), widened by 0.05; open-ended at the first / last image row,
+// where clamped rows collect) = over the rectangle's corners inside the band and its edges' crossings of the band's two lines
+__device__ __forceinline__ void strip_row_range(const Win &w, int i0, int i1, int j0, int j1, int y, int &xl, int &xr)
+{
+    const float blo = y == 0 ? -3.0e38f : (float)y - 0.05f, bhi = y == w.rows - 1 ? 3.0e38f : (float)y + 1.05f;
+    float cx[4], cy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // corners in cyclic order: (i0, j0), (i0, j1), (i1, j1), (i1, j0)
+        const int i = (k == 0 || k == 1) ? i0 : i1, j = (k == 1 || k == 2) ? j1 : j0;
+        cx[k] = w.cx + (w.off + j) * w.c + (w.off + i) * w.s;
+        cy[k] = w.cy - (w.off + j) * w.s + (w.off + i) * w.c;
+    }
+    float lo = 3.0e38f, hi = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int n = (k + 1) & 3;
+        if (cy[k] >= blo && cy[k] <= bhi) { lo = fminf(lo, cx[k]); hi = fmaxf(hi, cx[k]); }
+        const float dy = cy[n] - cy[k];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float Y = e ? bhi : blo;
+            if (fabsf(Y) < 1.0e37f && dy != 0.f && (cy[k] - Y) * (cy[n] - Y) <= 0.f) {
+                const float x = cx[k] + (Y - cy[k]) / dy * (cx[n] - cx[k]);
+                lo = fminf(lo, x); hi = fmaxf(hi, x);
+            }
+        }
+    }
+    if (lo > hi) { xl = 0; xr = -1; return; }   // the region does not touch this row
+    xl = clampi(__float2int_rd(fmaxf(lo, -1.0e6f)) - 1, 0, w.cols - 1);
+    xr = clampi(__float2int_rd(fminf(hi, 1.0e6f)) + 1, 0, w.cols - 1);
+}
+
 #ifndef MI_SURF_ORI_WGS_PER_CU
 #define MI_SURF_ORI_WGS_PER_CU 8
 #endif
@@ -983,12 +1042,15 @@ constexpr int kStageU = MI_SURF_STAGE_U;   // staged texel loads in flight per l
 template <bool EXT>
 __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
                                                             int kld, int nfeat_host, const unsigned *nfeat_dev, float *desc, long long dstep /* floats */,
-                                                            const float *dw, float s_stage, int tile_bytes)
+                                                            const float *dw, float s_stage, int tile_bytes, int img_bytes)
 {
     __shared__ float P[21][21];
     __shared__ float D[128];
     __shared__ float part[4];
-    extern __shared__ unsigned char tile[];
+    __shared__ int rowx0[kStripRowsMax];   // first staged column of each image row of the strip (its address is 4-byte aligned)
+    __shared__ int s_pitch;                // bytes staged per row (the longest row's), before rounding up to dwords
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];   // [0, tile_bytes): the lattice tile; behind it the image tile
+    unsigned char *const itile = tile + tile_bytes;
     const int nfeat = nfeat_dev ? min((int)*nfeat_dev, nfeat_host) : nfeat_host;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ly = lane >> 3, lx = lane & 7;
     for (int f = nfeat - 1 - (int)blockIdx.x; f >= 0; f -= (int)gridDim.x) {
@@ -1016,8 +1078,66 @@ __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char 
             while (yb < 21 && ((int)floorf((float)yb * s + s) - dy_lo + 1) * nc <= tile_bytes) ++yb;
             const int nr = (int)floorf((float)(yb - 1) * s + s) - dy_lo + 1;
             const int nblk = ((nr + 7) >> 3) * nbc;
+            // (1) the image rows of the strip -> the image tile, row-coalesced
+            const StripRows SR = strip_rows(w, dy_lo, dy_lo + nr - 1, -1, dxmax);
+            const bool rows_fit = img_bytes > 0 && SR.nrows <= kStripRowsMax;
+            if (threadIdx.x == 0) s_pitch = 0;
+            __syncthreads();
+            if (rows_fit) {
+                for (int r = threadIdx.x; r < SR.nrows; r += 512) {
+                    int xl, xr;
+                    strip_row_range(w, dy_lo, dy_lo + nr - 1, -1, dxmax, SR.y0 + r, xl, xr);
+                    // start the row's segment where its ADDRESS is dword aligned (the caller's matrix may be a ROI at any byte offset)
+                    const int a = (int)((unsigned long long)(img + (long long)(SR.y0 + r) * istep + xl) & 3ull);
+                    rowx0[r] = xl - a;
+                    if (xr >= xl) atomicMax(&s_pitch, xr - (xl - a) + 1);
+                }
+            }
+            __syncthreads();
+            const int pitch4 = (s_pitch + 3) >> 2;   // dwords per staged row
+            const bool staged = rows_fit && pitch4 > 0 && (long long)SR.nrows * pitch4 * 4 <= (long long)img_bytes;   // workgroup-uniform
+            if (staged) {
+                unsigned *const it4 = reinterpret_cast<unsigned *>(itile);
+                const int ndw = SR.nrows * pitch4;
+                int r = (int)threadIdx.x / pitch4, k = (int)threadIdx.x - r * pitch4;
+                const int dr = 512 / pitch4, dk = 512 - dr * pitch4;
+                for (int id = threadIdx.x; id < ndw; id += 512) {
+                    const int y = SR.y0 + r, x = rowx0[r] + 4 * k;
+                    const unsigned char *q = img + (long long)y * istep;
+                    unsigned v;
+                    if (x >= 0 && x + 3 < cols) v = *reinterpret_cast<const unsigned *>(q + x);   // aligned by the choice of rowx0
+                    else   // the segment's head before column 0 / its tail beyond the last column: the clamped bytes (never looked up)
+                        v = (unsigned)q[clampi(x, 0, cols - 1)] | ((unsigned)q[clampi(x + 1, 0, cols - 1)] << 8) |
+                            ((unsigned)q[clampi(x + 2, 0, cols - 1)] << 16) | ((unsigned)q[clampi(x + 3, 0, cols - 1)] << 24);
+                    it4[id] = v;
+                    r += dr; k += dk;
+                    if (k >= pitch4) { k -= pitch4; ++r; }
+                }
+                __syncthreads();
+                // (2) the lattice tile from the image tile: win_get's coordinates, the texel's byte from LDS (from global memory should the
+                //     conservative ranges ever miss it)
+                const int npt = nr * nc, pitch = pitch4 * 4;
+                int rr = (int)threadIdx.x / nc, cc = (int)threadIdx.x - rr * nc;
+                const int drr = 512 / nc, dcc = 512 - drr * nc;
+                for (int ti = threadIdx.x; ti < npt; ti += 512) {
+                    const int i = dy_lo + rr, j = cc - 1;
+                    const float px = w.cx + (w.off + j) * w.c + (w.off + i) * w.s;
+                    const float py = w.cy - (w.off + j) * w.s + (w.off + i) * w.c;
+                    const int x = clampi(__float2int_rd(px), 0, w.cols - 1), y = clampi(__float2int_rd(py), 0, w.rows - 1);
+                    const int ry = y - SR.y0;
+                    unsigned char v;
+                    if ((unsigned)ry < (unsigned)SR.nrows) {
+                        const int o = x - rowx0[ry];
+                        v = (unsigned)o < (unsigned)pitch ? itile[ry * pitch + o] : w.img[(long long)y * w.step + x];
+                    } else
+                        v = w.img[(long long)y * w.step + x];
+                    tile[ti] = v;
+                    rr += drr; cc += dcc;
+                    if (cc >= nc) { cc -= nc; ++rr; }
+                }
+            } else {
             // 8 x 8 blocks of the window lattice, block row / column carried along (no division per block); kStageU blocks per trip so that
-            // their loads are in flight together (the staging is a chain of gather round trips: 8 per trip until round 5)
+            // their loads are in flight together (the per-texel gather of rounds 3-5: strips whose rows do not fit the image tile)
             int br = wv / nbc, bc = wv - br * nbc;
             for (int blk = wv; blk < nblk; blk += 8 * kStageU) {
                 float v[kStageU];
@@ -1034,6 +1154,7 @@ __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char 
 #pragma unroll
                 for (int u = 0; u < kStageU; ++u)
                     if (ti[u] >= 0) tile[ti[u]] = (unsigned char)v[u];
+            }
             }
             __syncthreads();
             const int nsmp = (yb - ya) * 21;
@@ -1666,7 +1787,11 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
 {
     if (nfeat <= 0) return MI_OK;
     const float ss = surf_stage_s();
-    static const int kTileBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 48; return (kb >= 16 && kb <= 150 ? kb : 48) * 1024; }();
+    // dynamic LDS of the staged kernel: the lattice tile of a strip (kTileBytes) and, behind it, the image tile its rows are staged into
+    // with row-coalesced loads (kImgBytes: a rotated strip's row segments at one pitch take up to ~2 x the lattice's bytes; 0 = the
+    // per-texel gather of rounds 3-5).  24 + 40 KB + 7 KB static = two workgroups of eight waves per CU.
+    static const int kTileBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 24; return (kb >= 16 && kb <= 100 ? kb : 24) * 1024; }();
+    static const int kImgBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_IMG_KB"); const int kb = e ? atoi(e) : 40; return (kb >= 0 && kb <= 100 ? kb : 40) * 1024; }();
     // host-known count: one workgroup per feature.  Count on the device (nfeat = its upper bound, maxFeatures): a fixed grid of a few
     // workgroups per CU walks the features block-cyclically, most expensive first -- no launch of tens of thousands of empty workgroups
     const int grid = nfeat_dev ? std::min(nfeat, MI_SURF_DESC_WGS_PER_CU * (device_simds() / 4)) : nfeat;
@@ -1675,13 +1800,13 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
         else hipLaunchKernelGGL(k_descriptors<false>, dim3(grid), dim3(512), 0, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
     } else {
         static const hipError_t attr_rc = [] {
-            hipError_t e = hipFuncSetAttribute((const void *)k_descriptors_staged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_descriptors_staged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes);
+            hipError_t e = hipFuncSetAttribute((const void *)k_descriptors_staged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes + kImgBytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_descriptors_staged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kTileBytes + kImgBytes);
             return e;
         }();
         MI_HIP_TRY(attr_rc);
-        if (extended) hipLaunchKernelGGL(k_descriptors_staged<true>, dim3(grid), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
-        else hipLaunchKernelGGL(k_descriptors_staged<false>, dim3(grid), dim3(512), kTileBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes);
+        if (extended) hipLaunchKernelGGL(k_descriptors_staged<true>, dim3(grid), dim3(512), kTileBytes + kImgBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes, kImgBytes);
+        else hipLaunchKernelGGL(k_descriptors_staged<false>, dim3(grid), dim3(512), kTileBytes + kImgBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes, kImgBytes);
     }
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

@@ -301,6 +301,48 @@ def test_large_batch_runs_in_cache_sized_groups_and_equals_single_calcs(gpu, kw)
         assert torch.equal(out[k], singles[k % 5]), f"pair {k}"
 
 
+def test_call_plan_host_arithmetic(tmp_path):
+    """tests/cpp/fb_plan_test.cpp: the plan of a mi_farneback_calc_batch call (csrc/fb_plan.h, round 6 -- the level crop and geometry of
+    cudaoptflow/src/farneback.cpp:330-395, how each level's flow starts, fused / plain zoom, pair groups, two iterations per launch) for
+    the class defaults, the bench's batch, the initial-flow and zero-iteration cases, fast pyramids, forced switches, and its invariants
+    over a sweep of shapes.  The level loop (enqueue_level) only executes a plan.  Plain C++, no device."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fb_plan_test")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "opencv_contrib_amd", "csrc"),
+                        os.path.join(root, "tests", "cpp", "fb_plan_test.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "fb_plan_test: ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(winSize=9), dict(winSize=15), dict(winSize=21), dict(winSize=11), dict(winSize=5, numIters=1),
+                                dict(flags=256), dict(polyN=7, polySigma=1.5), dict(fastPyramids=True), dict(numLevels=1), dict(pyrScale=0.8, numLevels=8)],
+                         ids=["defaults_win13", "win9", "win15", "win21", "win11_generic", "win5_one_iteration", "gaussian", "poly7", "fast_pyramids",
+                              "one_level", "scale0.8"])
+@pytest.mark.parametrize("shape,B", [((120, 160), 1), ((97, 203), 3), ((480, 640), 1), ((240, 320), 40)])
+def test_no_plane_is_read_before_it_is_written(gpu, kw, shape, B):
+    """the coarsest level's flow planes are never cleared -- the first matrix update takes the flow as zero and every iterate
+    variant (tiled, narrow 64 x 4 tiles, two iterations per launch, the generic window sizes, Gaussian windows, pair groups on two
+    streams) must write all w x h pixels of both planes before anything reads them.  A calc whose scratch arena was filled with NaNs
+    (miflow_selftest_farneback_poison) must give the bytes of the calc before it: a stale read would turn up as NaNs or as a changed flow."""
+    import torch
+    from opencv_contrib_amd import capi, cuda
+    pairs = [synth.flow_pair(*shape, seed=600 + k, dtype="u8")[:2] for k in range(min(B, 4))]
+    I0s = [torch.from_numpy(pairs[k % len(pairs)][0]).to(gpu) for k in range(B)]
+    I1s = [torch.from_numpy(pairs[k % len(pairs)][1]).to(gpu) for k in range(B)]
+    alg = cuda.FarnebackOpticalFlow.create(**kw)
+    run = (lambda: alg.calc(I0s[0], I1s[0]).clone()) if B == 1 else (lambda: alg.calc_batch(I0s, I1s).clone())
+    a = run()
+    torch.cuda.synchronize()
+    capi.check(capi.lib().miflow_selftest_farneback_poison(alg._h, capi.current_stream_ptr()))
+    b = run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(b).all()
+    assert torch.equal(a, b)
+
+
 def test_pair_group_plan_host_arithmetic(tmp_path):
     """tests/cpp/fb_groups_test.cpp: the plan of the batched level loop (csrc/fb_groups.h -- pairs per launch group, one or two chains)
     for the bench's shape, the sizes where no groups are formed, and its invariants over a sweep (groups cover the batch, the groups in
