@@ -970,7 +970,12 @@ __device__ __forceinline__ float area_filter_lds(const unsigned char *tile, int 
     if ((sy2 < fsy2) && (sx1 > fsx1)) out = out + T(sy2, sx1 - 1) * ((fsy2 - sy2) * (sx1 - fsx1) * scale);
     return sat_u8(out);
 }
-// ---- row-coalesced staging of a strip (round 6).  Until round 5 the lattice tile was filled by one byte
+#ifdef MIFLOW_EXPERIMENTS
+// ---- row-coalesced staging of a strip (round 6) -- BUILT, bit-identical, and SLOWER: experiments build
+// only (MIFLOW_SURF_COAL_S = the cell side from which a feature takes it; profiles/r19/README.md: at 4K 907 frames/s with the per-texel
+// gather against 831 / 788 / 736 with this path from cell side 24 / 16 / 8 on, although it issues a fifteenth of the L1 tag lookups --
+// the descriptor launch is bound by the dependent phases of a feature's strips, five barriers each here against two, not by lookups).
+// Until round 5 the lattice tile was filled by one byte
 // gather per lattice point -- 8 x 8 blocks of the rotated window lattice, 41 L1 tag lookups per wave load for 64 useful bytes, the kernel
 // at 0.84 of the L1 lookup rate (profiles/surf_counters.json).  Now a strip is staged in two steps: (1) the image rows the strip's
 // lattice touches are copied into an IMAGE tile with aligned dword loads along the rows -- per image row only the segment the rotated
@@ -1028,6 +1033,7 @@ __device__ __forceinline__ void strip_row_range(const Win &w, int i0, int i1, in
     xl = clampi(__float2int_rd(fmaxf(lo, -1.0e6f)) - 1, 0, w.cols - 1);
     xr = clampi(__float2int_rd(fminf(hi, 1.0e6f)) + 1, 0, w.cols - 1);
 }
+#endif   // MIFLOW_EXPERIMENTS
 
 #ifndef MI_SURF_ORI_WGS_PER_CU
 #define MI_SURF_ORI_WGS_PER_CU 8
@@ -1042,15 +1048,19 @@ constexpr int kStageU = MI_SURF_STAGE_U;   // staged texel loads in flight per l
 template <bool EXT>
 __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char *img, long long istep, int rows, int cols, const float *kp,
                                                             int kld, int nfeat_host, const unsigned *nfeat_dev, float *desc, long long dstep /* floats */,
-                                                            const float *dw, float s_stage, int tile_bytes, int img_bytes)
+                                                            const float *dw, float s_stage, int tile_bytes, int img_bytes, float s_coal)
 {
     __shared__ float P[21][21];
     __shared__ float D[128];
     __shared__ float part[4];
+#ifdef MIFLOW_EXPERIMENTS
     __shared__ int rowx0[kStripRowsMax];   // first staged column of each image row of the strip (its address is 4-byte aligned)
     __shared__ int s_pitch;                // bytes staged per row (the longest row's), before rounding up to dwords
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char tile[];   // [0, tile_bytes): the lattice tile; behind it the image tile
+#ifdef MIFLOW_EXPERIMENTS
     unsigned char *const itile = tile + tile_bytes;
+#endif
     const int nfeat = nfeat_dev ? min((int)*nfeat_dev, nfeat_host) : nfeat_host;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ly = lane >> 3, lx = lane & 7;
     for (int f = nfeat - 1 - (int)blockIdx.x; f >= 0; f -= (int)gridDim.x) {
@@ -1075,15 +1085,25 @@ __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char 
             // the strip: patch rows ya .. yb - 1, as many as the tile holds (at least one: the host sizes the tile for that)
             const int dy_lo = (int)ceilf((float)ya * s) - 1;
             int yb = ya + 1;
-            while (yb < 21 && ((int)floorf((float)yb * s + s) - dy_lo + 1) * nc <= tile_bytes) ++yb;
+            // features from cell side s_coal on stage their strips row-coalesced (lattice tile + image tile); smaller ones -- a strip or two
+            // per feature, bound by the latency of their phases, not by L1 lookups -- keep the per-texel gather into ONE tile of both sizes
+#ifdef MIFLOW_EXPERIMENTS
+            const bool coal = img_bytes > 0 && s >= s_coal;
+#else
+            constexpr bool coal = false;   // (the release library passes img_bytes = 0: one lattice tile)
+#endif
+            const int tile_cap = coal ? tile_bytes : tile_bytes + img_bytes;
+            while (yb < 21 && ((int)floorf((float)yb * s + s) - dy_lo + 1) * nc <= tile_cap) ++yb;
             const int nr = (int)floorf((float)(yb - 1) * s + s) - dy_lo + 1;
             const int nblk = ((nr + 7) >> 3) * nbc;
+#ifdef MIFLOW_EXPERIMENTS
             // (1) the image rows of the strip -> the image tile, row-coalesced
             const StripRows SR = strip_rows(w, dy_lo, dy_lo + nr - 1, -1, dxmax);
-            const bool rows_fit = img_bytes > 0 && SR.nrows <= kStripRowsMax;
-            if (threadIdx.x == 0) s_pitch = 0;
-            __syncthreads();
-            if (rows_fit) {
+            const bool rows_fit = coal && SR.nrows <= kStripRowsMax;
+            int pitch4 = 0;   // dwords per staged row
+            if (rows_fit) {   // (workgroup-uniform)
+                if (threadIdx.x == 0) s_pitch = 0;
+                __syncthreads();
                 for (int r = threadIdx.x; r < SR.nrows; r += 512) {
                     int xl, xr;
                     strip_row_range(w, dy_lo, dy_lo + nr - 1, -1, dxmax, SR.y0 + r, xl, xr);
@@ -1092,49 +1112,88 @@ __global__ __launch_bounds__(512) void k_descriptors_staged(const unsigned char 
                     rowx0[r] = xl - a;
                     if (xr >= xl) atomicMax(&s_pitch, xr - (xl - a) + 1);
                 }
+                __syncthreads();
+                pitch4 = (s_pitch + 3) >> 2;
             }
-            __syncthreads();
-            const int pitch4 = (s_pitch + 3) >> 2;   // dwords per staged row
             const bool staged = rows_fit && pitch4 > 0 && (long long)SR.nrows * pitch4 * 4 <= (long long)img_bytes;   // workgroup-uniform
+#else
+            constexpr bool staged = false;
+            (void)coal;
+#endif
             if (staged) {
+#ifdef MIFLOW_EXPERIMENTS
                 unsigned *const it4 = reinterpret_cast<unsigned *>(itile);
                 const int ndw = SR.nrows * pitch4;
-                int r = (int)threadIdx.x / pitch4, k = (int)threadIdx.x - r * pitch4;
-                const int dr = 512 / pitch4, dk = 512 - dr * pitch4;
-                for (int id = threadIdx.x; id < ndw; id += 512) {
-                    const int y = SR.y0 + r, x = rowx0[r] + 4 * k;
-                    const unsigned char *q = img + (long long)y * istep;
-                    unsigned v;
-                    if (x >= 0 && x + 3 < cols) v = *reinterpret_cast<const unsigned *>(q + x);   // aligned by the choice of rowx0
-                    else   // the segment's head before column 0 / its tail beyond the last column: the clamped bytes (never looked up)
-                        v = (unsigned)q[clampi(x, 0, cols - 1)] | ((unsigned)q[clampi(x + 1, 0, cols - 1)] << 8) |
-                            ((unsigned)q[clampi(x + 2, 0, cols - 1)] << 16) | ((unsigned)q[clampi(x + 3, 0, cols - 1)] << 24);
-                    it4[id] = v;
-                    r += dr; k += dk;
-                    if (k >= pitch4) { k -= pitch4; ++r; }
+                {
+                    // kStageU dwords in flight per lane (a trip's row starts are read first, then its loads are issued together, then stored:
+                    // one load per trip made the staging a chain of LDS + memory round trips, r19d: 687 against 900 frames/s)
+                    int r = (int)threadIdx.x / pitch4, k = (int)threadIdx.x - r * pitch4;
+                    const int dr = 512 / pitch4, dk = 512 - dr * pitch4;
+                    for (int id = threadIdx.x; id < ndw; id += 512 * kStageU) {
+                        const unsigned char *q[kStageU];
+                        int x[kStageU];
+                        bool ok[kStageU], fast[kStageU];
+                        unsigned v[kStageU];
+#pragma unroll
+                        for (int u = 0; u < kStageU; ++u) {
+                            ok[u] = id + 512 * u < ndw;
+                            const int ru = ok[u] ? r : 0;
+                            x[u] = rowx0[ru] + 4 * k;
+                            q[u] = img + (long long)(SR.y0 + ru) * istep;
+                            fast[u] = ok[u] && x[u] >= 0 && x[u] + 3 < cols;
+                            r += dr; k += dk;
+                            if (k >= pitch4) { k -= pitch4; ++r; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < kStageU; ++u)   // aligned by the choice of rowx0; a lane without a full dword inside the row loads row 0's first
+                            v[u] = *reinterpret_cast<const unsigned *>(fast[u] ? q[u] + x[u] : img);
+#pragma unroll
+                        for (int u = 0; u < kStageU; ++u) {
+                            if (ok[u] && !fast[u])   // the segment's head before column 0 / its tail beyond the last column: the clamped bytes (never looked up)
+                                v[u] = (unsigned)q[u][clampi(x[u], 0, cols - 1)] | ((unsigned)q[u][clampi(x[u] + 1, 0, cols - 1)] << 8) |
+                                       ((unsigned)q[u][clampi(x[u] + 2, 0, cols - 1)] << 16) | ((unsigned)q[u][clampi(x[u] + 3, 0, cols - 1)] << 24);
+                            if (ok[u]) it4[id + 512 * u] = v[u];
+                        }
+                    }
                 }
                 __syncthreads();
                 // (2) the lattice tile from the image tile: win_get's coordinates, the texel's byte from LDS (from global memory should the
-                //     conservative ranges ever miss it)
+                //     conservative ranges ever miss it); kGatherU points per trip so that their two dependent LDS reads overlap
+                constexpr int kGatherU = 8;
                 const int npt = nr * nc, pitch = pitch4 * 4;
                 int rr = (int)threadIdx.x / nc, cc = (int)threadIdx.x - rr * nc;
                 const int drr = 512 / nc, dcc = 512 - drr * nc;
-                for (int ti = threadIdx.x; ti < npt; ti += 512) {
-                    const int i = dy_lo + rr, j = cc - 1;
-                    const float px = w.cx + (w.off + j) * w.c + (w.off + i) * w.s;
-                    const float py = w.cy - (w.off + j) * w.s + (w.off + i) * w.c;
-                    const int x = clampi(__float2int_rd(px), 0, w.cols - 1), y = clampi(__float2int_rd(py), 0, w.rows - 1);
-                    const int ry = y - SR.y0;
-                    unsigned char v;
-                    if ((unsigned)ry < (unsigned)SR.nrows) {
-                        const int o = x - rowx0[ry];
-                        v = (unsigned)o < (unsigned)pitch ? itile[ry * pitch + o] : w.img[(long long)y * w.step + x];
-                    } else
-                        v = w.img[(long long)y * w.step + x];
-                    tile[ti] = v;
-                    rr += drr; cc += dcc;
-                    if (cc >= nc) { cc -= nc; ++rr; }
+                for (int ti = threadIdx.x; ti < npt; ti += 512 * kGatherU) {
+                    int xs[kGatherU], ys[kGatherU], o[kGatherU];
+                    bool ok[kGatherU], in[kGatherU];
+                    unsigned char v[kGatherU];
+#pragma unroll
+                    for (int u = 0; u < kGatherU; ++u) {
+                        ok[u] = ti + 512 * u < npt;
+                        const int i = dy_lo + rr, j = cc - 1;
+                        const float px = w.cx + (w.off + j) * w.c + (w.off + i) * w.s;
+                        const float py = w.cy - (w.off + j) * w.s + (w.off + i) * w.c;
+                        xs[u] = clampi(__float2int_rd(px), 0, w.cols - 1); ys[u] = clampi(__float2int_rd(py), 0, w.rows - 1);
+                        rr += drr; cc += dcc;
+                        if (cc >= nc) { cc -= nc; ++rr; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGatherU; ++u) {
+                        const int ry = ys[u] - SR.y0;
+                        const bool rin = (unsigned)ry < (unsigned)SR.nrows;
+                        o[u] = xs[u] - rowx0[rin ? ry : 0];
+                        in[u] = rin && (unsigned)o[u] < (unsigned)pitch;
+                        o[u] = in[u] ? ry * pitch + o[u] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGatherU; ++u) v[u] = itile[o[u]];
+#pragma unroll
+                    for (int u = 0; u < kGatherU; ++u) {
+                        if (ok[u] && !in[u]) v[u] = w.img[(long long)ys[u] * w.step + xs[u]];
+                        if (ok[u]) tile[ti + 512 * u] = v[u];
+                    }
                 }
+#endif
             } else {
             // 8 x 8 blocks of the window lattice, block row / column carried along (no division per block); kStageU blocks per trip so that
             // their loads are in flight together (the per-texel gather of rounds 3-5: strips whose rows do not fit the image tile)
@@ -1787,11 +1846,16 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
 {
     if (nfeat <= 0) return MI_OK;
     const float ss = surf_stage_s();
-    // dynamic LDS of the staged kernel: the lattice tile of a strip (kTileBytes) and, behind it, the image tile its rows are staged into
-    // with row-coalesced loads (kImgBytes: a rotated strip's row segments at one pitch take up to ~2 x the lattice's bytes; 0 = the
-    // per-texel gather of rounds 3-5).  24 + 40 KB + 7 KB static = two workgroups of eight waves per CU.
-    static const int kTileBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 24; return (kb >= 16 && kb <= 100 ? kb : 24) * 1024; }();
-    static const int kImgBytes = [] { const char *e = MI_EXP_ENV("MIFLOW_SURF_IMG_KB"); const int kb = e ? atoi(e) : 40; return (kb >= 0 && kb <= 100 ? kb : 40) * 1024; }();
+    // dynamic LDS of the staged kernel: the lattice tile of a strip.  (Experiments build: behind it the image tile of the row-coalesced
+    // staging, MIFLOW_SURF_TILE_KB / _IMG_KB / _COAL_S; the release library runs the per-texel gather into one 48 KB tile.)
+#ifdef MIFLOW_EXPERIMENTS
+    static const int kTileBytes = [] { const char *e = getenv("MIFLOW_SURF_TILE_KB"); const int kb = e ? atoi(e) : 48; return (kb >= 8 && kb <= 100 ? kb : 48) * 1024; }();
+    static const int kImgBytes = [] { const char *e = getenv("MIFLOW_SURF_IMG_KB"); const int kb = e ? atoi(e) : 0; return (kb >= 0 && kb <= 100 ? kb : 0) * 1024; }();
+    static const float kCoalS = [] { const char *e = getenv("MIFLOW_SURF_COAL_S"); return e ? (float)atof(e) : 16.0f; }();
+#else
+    constexpr int kTileBytes = 48 * 1024, kImgBytes = 0;
+    constexpr float kCoalS = 1e30f;
+#endif
     // host-known count: one workgroup per feature.  Count on the device (nfeat = its upper bound, maxFeatures): a fixed grid of a few
     // workgroups per CU walks the features block-cyclically, most expensive first -- no launch of tens of thousands of empty workgroups
     const int grid = nfeat_dev ? std::min(nfeat, MI_SURF_DESC_WGS_PER_CU * (device_simds() / 4)) : nfeat;
@@ -1805,8 +1869,8 @@ int descriptors(const unsigned char *img, long long istep, int rows, int cols, c
             return e;
         }();
         MI_HIP_TRY(attr_rc);
-        if (extended) hipLaunchKernelGGL(k_descriptors_staged<true>, dim3(grid), dim3(512), kTileBytes + kImgBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes, kImgBytes);
-        else hipLaunchKernelGGL(k_descriptors_staged<false>, dim3(grid), dim3(512), kTileBytes + kImgBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes, kImgBytes);
+        if (extended) hipLaunchKernelGGL(k_descriptors_staged<true>, dim3(grid), dim3(512), kTileBytes + kImgBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes, kImgBytes, kCoalS);
+        else hipLaunchKernelGGL(k_descriptors_staged<false>, dim3(grid), dim3(512), kTileBytes + kImgBytes, s, img, istep, rows, cols, kp, kld, nfeat, nfeat_dev, desc, dstep_floats, dw, ss, kTileBytes, kImgBytes, kCoalS);
     }
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;

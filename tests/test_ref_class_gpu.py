@@ -30,10 +30,17 @@ def N(t):
     ((120, 160), 3, "f32", dict(iterations=10, epsilon=0.0)),          # the headline setting under cv::cuda's semantics
     ((96, 128), 5, "u8", dict(iterations=10)),                           # the reference test's literal setting: epsilon stays 0.01
     ((64, 88), 7, "f32", dict()),                                        # class defaults: 300 iterations, epsilon 0.01, sparse check schedule
+    # Gamma(1.0), the other half of the reference's test matrix (cudaoptflow/test/test_optflow.cpp:451,530-532): the blocked kernel with the
+    # illumination channel (round 6) against the reference class's own estimateU / estimateDualVariables (tvl1flow.cu:209-348)
+    ((240, 320), 9, "f32", dict(iterations=10, epsilon=0.0, gamma=1.0)),
+    ((96, 128), 11, "u8", dict(iterations=10, gamma=1.0)),               # ... convergence-checked: speculative blocks with the channel
+    ((64, 88), 13, "f32", dict(gamma=0.5)),
 ])
 def test_tvl1_hip_vs_the_reference_cuda_class(gpu, shape, seed, dtype, kw):
     from opencv_contrib_amd import capi, cuda
     I0, I1, _ = synth.flow_pair(shape[0], shape[1], seed=seed, dtype=dtype)
+    if kw.get("gamma"):   # a brightness change between the frames, so that u3 is exercised
+        I1 = np.clip(I1.astype(np.float32) * 1.05 + (3 if dtype == "u8" else 0.012), 0, 255 if dtype == "u8" else 1).astype(I1.dtype)
     ref, _ = refcu.cuda_class_tvl1_calc(I0, I1, **kw)
     alg = cuda.OpticalFlowDual_TVL1.create(semantics=capi.MI_SEM_CUDA_COMPAT, **kw)
     flow = N(alg.calc(T(I0, gpu), T(I1, gpu)))
