@@ -84,16 +84,31 @@ public:
         descriptorsGPU.download(descriptors.data(), (size_t)descriptorsGPU.cols * 4);
     }
 
+    // ensureSizeIsEnough on the ALLOCATION, not on the header: a call hands `m` back with cols / rows cut to the feature count,
+    // so a test of the header would free and re-create the buffers on every frame (up to 33 MB of hipFree + hipMalloc, each a device
+    // synchronisation).  The buffer a previous call created -- its pitch and extent are still in step / datastart / dataend -- is reused
+    // whenever it holds rows x cols elements of the type; the header is restored to that size.
+    static bool holds(const GpuMat &m, int rows, int cols, int type)
+    {
+        static const int dsz[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+        const size_t es = (size_t)dsz[type & 7] * (size_t)CV_MAT_CN(type);
+        return m.data && m.data == m.datastart && m.type() == (type & 0xFFF) && m.step >= (size_t)cols * es &&
+               (size_t)(m.dataend - m.datastart) >= m.step * (size_t)(rows - 1) + (size_t)cols * es;
+    }
+    static void ensureCapacity(GpuMat &m, int rows, int cols, int type)
+    {
+        if (holds(m, rows, cols, type)) { m.rows = rows; m.cols = cols; return; }
+        m.release();
+        m.create(rows, cols, type);
+    }
+
     //! finds the keypoints (surf.cuda.cpp:369-378)
     void operator()(const GpuMat &img, const GpuMat &mask, GpuMat &keypoints)
     {
         push();
         int maxf = 0;
         miCheck(mi_surf_max_features(h_, img.rows, img.cols, &maxf));
-        if (keypoints.rows != ROWS_COUNT || keypoints.cols < maxf || keypoints.type() != CV_32FC1) {
-            keypoints.release();
-            keypoints.create(ROWS_COUNT, maxf, CV_32FC1);   // ensureSizeIsEnough(ROWS_COUNT, maxFeatures) :179
-        }
+        ensureCapacity(keypoints, ROWS_COUNT, maxf, CV_32FC1);   // ensureSizeIsEnough(ROWS_COUNT, maxFeatures) :179
         mi_mat i = miMat(img), m = miMat(mask), k = miMat(keypoints);
         int n = 0;
         miCheck(mi_surf_detect(h_, &i, mask.empty() ? nullptr : &m, &k, &n, nullptr));
@@ -109,31 +124,31 @@ public:
             // no read-back of keypoints.cols between detectKeypoints and computeDescriptors (surf.cuda.cpp:205-209)
             int maxf = 0;
             miCheck(mi_surf_max_features(h_, img.rows, img.cols, &maxf));
-            if (keypoints.rows != ROWS_COUNT || keypoints.cols < maxf || keypoints.type() != CV_32FC1) {
-                keypoints.release();
-                keypoints.create(ROWS_COUNT, maxf, CV_32FC1);
-            }
-            if (descriptors.rows < maxf || descriptors.cols != descriptorSize() || descriptors.type() != CV_32FC1) {
-                descriptors.release();
-                descriptors.create(maxf, descriptorSize(), CV_32FC1);
-            }
-            mi_mat m = miMat(mask), k = miMat(keypoints), d = miMat(descriptors);
+            ensureCapacity(keypoints, ROWS_COUNT, maxf, CV_32FC1);
+            // the count is not known before the enqueue: the descriptors of up to maxFeatures keypoints are written into the caller's matrix
+            // where its ALLOCATION holds them (the matrix a previous frame got back, cut to its count), else into a new one that replaces
+            // it.  No keypoint: the caller's matrix is left as it was, as computeDescriptors leaves it (surf.cuda.cpp:227-236).
+            const bool fits = holds(descriptors, maxf, descriptorSize(), CV_32FC1);
+            const int rows0 = descriptors.rows, cols0 = descriptors.cols;
+            GpuMat fresh;
+            if (fits) { descriptors.rows = maxf; descriptors.cols = descriptorSize(); } else fresh.create(maxf, descriptorSize(), CV_32FC1);
+            GpuMat &dst = fits ? descriptors : fresh;
+            mi_mat m = miMat(mask), k = miMat(keypoints), d = miMat(dst);
             int n = 0;
             miCheck(mi_surf_detect_and_compute(h_, &i, mask.empty() ? nullptr : &m, &k, &d, &n, nullptr));
             keypoints.cols = n;   // :209
-            if (n > 0) descriptors.rows = n; else descriptors.release();
+            if (n > 0) { if (!fits) descriptors = fresh; descriptors.rows = n; }
+            else if (fits) { descriptors.rows = rows0; descriptors.cols = cols0; }
             return;
         }
         if (!upright) { mi_mat k = miMat(keypoints); miCheck(mi_surf_compute_orientation(h_, &i, &k, keypoints.cols, nullptr)); }
         const int n = keypoints.cols;
         if (n > 0) {
-            if (descriptors.rows < n || descriptors.cols != descriptorSize() || descriptors.type() != CV_32FC1)
-                { descriptors.release(); descriptors.create(n, descriptorSize(), CV_32FC1); }
-            descriptors.rows = n;
+            ensureCapacity(descriptors, n, descriptorSize(), CV_32FC1);   // ensureSizeIsEnough(nFeatures, descriptorSize) :232
             mi_mat k = miMat(keypoints), d = miMat(descriptors);
             miCheck(mi_surf_compute_descriptors(h_, &i, &k, n, &d, nullptr));
             miCheck(mi_stream_synchronize(nullptr));   // SURF_CUDA has no stream parameter: every wrapper ends synchronised (surf.cu:923,928)
-        } else descriptors.release();
+        }   // (no keypoint: descriptors stay as they were, surf.cuda.cpp:229-235)
     }
     void detect(const GpuMat &img, const GpuMat &mask, GpuMat &keypoints) { (*this)(img, mask, keypoints); }
     void detectWithDescriptors(const GpuMat &img, const GpuMat &mask, GpuMat &keypoints, GpuMat &descriptors, bool useProvidedKeypoints = false)

@@ -63,6 +63,23 @@ int main(int argc, char **argv)
         fwrite(desc.data(), 4, desc.size(), o);
         if (desc.size() != (size_t)nk * 64) return 7;
         fclose(o);
+        {   // frame after frame through the GpuMat overload the buffers are REUSED (a header cut to the feature count must not
+            // look too small: that was a hipFree + hipMalloc of up to 33 MB per frame), and a frame without keypoints leaves the caller's
+            // descriptors untouched, as the reference's computeDescriptors does (surf.cuda.cpp:227-236)
+            cuda::GpuMat kg, dg;
+            surf(d0, cuda::GpuMat(), kg, dg);
+            if (kg.cols != nk || dg.rows != nk || dg.cols != 64) return 10;
+            const void *kp0 = kg.data, *dp0 = dg.data;
+            surf(d0, cuda::GpuMat(), kg, dg);
+            if (kg.data != kp0 || dg.data != dp0 || kg.cols != nk || dg.rows != nk) return 10;
+            std::vector<float> d2((size_t)nk * 64);
+            if (nk > 0) { dg.download(d2.data(), 64 * sizeof(float)); if (d2 != desc) return 10; }
+            cuda::SURF_CUDA none(1e12, 3, 2, false, 0.05f);   // a threshold nothing passes
+            none(d0, cuda::GpuMat(), kg, dg);
+            if (kg.cols != 0 || dg.data != dp0 || dg.rows != nk) return 10;
+            surf(d0, cuda::GpuMat(), kg);                       // detect only: the same keypoint buffer again
+            if (kg.data != kp0 || kg.cols != nk) return 10;
+        }
         // superres adapters (the in-tree caller of the flow classes): planar flow == split of the class's own result
         if (argc > 3) {
             Ptr<superres::DualTVL1OpticalFlow> sr = superres::createOptFlow_DualTVL1_CUDA();
