@@ -48,5 +48,10 @@ def exp_env():
 
 
 def loaded_library_is_experiments_build():
-    from opencv_contrib_amd import capi
-    return b"+experiments" in (capi.lib().mi_version() or b"")
+    """True where the library this process loads (MIFLOW_LIB) is the experiments build.  Usable at collection time (no GPU needed); False
+    where no library has been built yet."""
+    try:
+        from opencv_contrib_amd import capi
+        return b"+experiments" in (capi.lib().mi_version() or b"")
+    except Exception:
+        return False

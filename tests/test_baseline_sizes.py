@@ -649,7 +649,11 @@ def test_fused_warp_equals_gather_warp(gpu, oracle, sem, amp):
         np.testing.assert_array_equal(N(x), N(y), err_msg=name)
 
 
-@pytest.mark.parametrize("sem", [0, 1])
+from conftest import loaded_library_is_experiments_build  # noqa: E402
+
+
+# (collected where the loaded library is the experiments build: tests/test_tvl1_gpu.py::test_experiment_only_kernels_under_the_experiments_build)
+@pytest.mark.parametrize("sem", [0, 1] if loaded_library_is_experiments_build() else [])
 @pytest.mark.parametrize("amp", [0.0, 2.5, 12.0, 400.0])
 @pytest.mark.parametrize("shape", [(130, 203), (6, 9), (97, 640)])
 def test_fused_warp_lds_staged_equals_gather(gpu, sem, amp, shape):
@@ -657,9 +661,6 @@ def test_fused_warp_lds_staged_equals_gather(gpu, sem, amp, shape):
     for border windows and for tiles whose flow spreads the windows beyond the buffer: amp 12 and 400) and k_warp6 (global
     gather) are bit-identical, in exact and in fast (separable sums) form."""
     from opencv_contrib_amd import cuda
-    from conftest import loaded_library_is_experiments_build
-    if not loaded_library_is_experiments_build():
-        pytest.skip("k_warp_lds is compiled into the experiments build only (run the suite with MIFLOW_LIB=libmiflow_exp.so)")
     h, w = shape
     rng = np.random.default_rng(sem * 7 + int(amp) + h)
     I0 = (rng.random((h, w)) * 255).astype(np.float32)

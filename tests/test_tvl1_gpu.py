@@ -179,6 +179,21 @@ def test_joined_wave_kernel_is_bit_identical_to_the_independent_wave_kernel(gpu,
     assert outs[0] == outs[4]
 
 
+def test_experiment_only_kernels_under_the_experiments_build(gpu, exp_env):
+    """The kernels that exist in the experiments build only and are tested IN PROCESS (the tile shapes 2..5 against the streaming kernel,
+    the LDS-staged warp against the gather) are collected where that library is the one loaded: run those tests here, in a pytest
+    subprocess with MIFLOW_LIB = libmiflow_exp.so.  (The variants selected by environment switches have their own subprocess tests.)"""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_tvl1_gpu.py"), os.path.join(root, "tests", "test_baseline_sizes.py"),
+                        "-m", "gpu", "-q", "-p", "no:cacheprovider", "-k", "iterate_tile_equals_streaming_kernel or fused_warp_lds_staged_equals_gather"],
+                       capture_output=True, text=True, env=exp_env, timeout=1500, cwd=root)
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert r.returncode == 0 and m and int(m.group(1)) == 18 + 24, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 @pytest.mark.parametrize("shape", [(70, 100), (64, 64), (135, 257), (300, 531), (97, 1000), (540, 960)])
 def test_release_joined_wave_kernel_equals_independent_waves(gpu, shape):
     """The kernel of record (four joined waves per 256-column strip, seam values handed over through LDS, barrier intervals) against
@@ -212,7 +227,13 @@ def test_iterate_blocked_matches_exact(gpu, T, shape):
             np.testing.assert_allclose(N(b), N(a), rtol=0, atol=2e-5 * niter, err_msg=f"{nm} T={T} niter={niter}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+# tile shapes 0 and 1 are what a release build runs; 2..5 are compiled into the experiments build only and are
+# collected where that library is the one loaded -- test_experiment_only_kernels_under_the_experiments_build runs them that way
+from conftest import loaded_library_is_experiments_build  # noqa: E402
+TILE_VARIANTS = [0, 1, 2, 3, 4, 5] if loaded_library_is_experiments_build() else [0, 1]
+
+
+@pytest.mark.parametrize("variant", TILE_VARIANTS)
 @pytest.mark.parametrize("shape", [(68, 120), (135, 240), (300, 531)])
 def test_iterate_tile_equals_streaming_kernel(gpu, variant, shape):
     """The register-tile formulation of the fused iterations (tvl1_tile_kernels.hip, the small pyramid levels) against the
@@ -220,9 +241,6 @@ def test_iterate_tile_equals_streaming_kernel(gpu, variant, shape):
     runs on never changes a flow.  Shapes: the two coarsest 1080p levels, and one spanning several strips and row tiles;
     niter 10 = one launch, 7 = a short launch, 23 = 10 + 10 + 3."""
     from opencv_contrib_amd import cuda
-    from conftest import loaded_library_is_experiments_build
-    if variant >= 2 and not loaded_library_is_experiments_build():
-        pytest.skip("tile shapes 2..5 are compiled into the experiments build only (the release library runs shapes 0 and 1)")
     I1wx, I1wy, grad, rho, u, p = _iter_inputs(*shape, seed=11)
     args = [T_(a, gpu) for a in (I1wx, I1wy, grad, rho)] + [[T_(a, gpu) for a in u], [T_(a, gpu) for a in p],
                                                             0.045, 0.3, 0.25 / 0.3]

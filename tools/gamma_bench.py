@@ -1,6 +1,6 @@
 """gamma != 0 (the illumination channel): pairs per second of the blocked path (k_iterate_tbr GAM, round 6) against one launch per
 iteration (timeBlock = 1, the only fast-math path before round 6) and against gamma = 0, at 1080p.
-usage: python tools/gamma_bench.py [pairs] [steps]"""
+usage: python tools/gamma_bench.py [pairs] [steps] [only: substring of a case name, e.g. "blocked" for profiler runs]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ from opencv_contrib_amd import cuda, synth
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 h, w = 1080, 1920
 pairs = [synth.flow_pair(h, w, seed=1234 + k)[:2] for k in range(4)]
 I0 = torch.stack([torch.from_numpy(pairs[k % 4][0]) for k in range(n)]).to(dev)
@@ -26,6 +27,8 @@ for name, kw in (("gamma0 N=10", dict(iterations=10, epsilon=0.0)),
                  ("gamma1 N=10 cuda semantics", dict(iterations=10, epsilon=0.0, gamma=1.0, semantics=1)),
                  ("gamma0 class defaults", dict()),
                  ("gamma1 class defaults", dict(gamma=1.0))):
+    if only and only not in name:
+        continue
     alg = cuda.OpticalFlowDual_TVL1.create(**kw)
     for _ in range(2):
         alg.calc_batch(I0, I1, out)

@@ -205,6 +205,29 @@ pmc_secondary)
   cd $R
   python tools/pmc_secondary.py $O "profiles/$NAME" 2>&1 | tail -5; cp profiles/pmc_traffic.json $O/pmc_traffic.json
   find $O -type f -size +4M -delete ;;
+trace_gamma)
+  # gamma != 0 on the blocked kernel (round 6): rates of tools/gamma_bench.py, kernel trace and HBM traffic of the N = 10 case
+  (timeout 600 python tools/gamma_bench.py 64 4 > $O/gamma_bench.log 2>&1); grep -v amdgpu.ids $O/gamma_bench.log
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/trace_gamma -- python $R/tools/gamma_bench.py 64 3 blocked > $R/$O/trace_gamma.log 2>&1
+  for f in $(find $R/$O/trace_gamma -name "*kernel_stats.csv" | head -1); do cp $f $R/$O/kernel_stats_gamma.csv; head -6 $f | cut -c1-200; done
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -f csv -d $R/$O/pmc_gamma_$c -- python $R/tools/gamma_bench.py 64 1 blocked > $R/$O/pmc_gamma_$c.log 2>&1
+  done
+  cd $R
+  python - <<PY | tee $O/pmc_gamma_summary.md
+import csv, glob, collections
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob('$O/pmc_gamma_%s/*/*counter_collection.csv' % c):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != c: continue
+            k = r['Kernel_Name'].split('(')[0][-70:]
+            agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
+    for k, (v, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:4]:
+        print(f"| {c} | {k} | launches {n} | mean per launch {v / max(n, 1):.1f} (counter units: KB; FETCH_SIZE x 2 on gfx950) |")
+PY
+  find $O -type f -size +4M -delete ;;
 trace_secondary)
   # kernel traces of the secondary workloads on the final tree (VERDICT r03 hygiene item)
   cd /tmp
