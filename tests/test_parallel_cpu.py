@@ -41,7 +41,8 @@ res = torch.full((len(parallel.shard_range(7, world, rank)), 2), float(rank))
 g = parallel.gather_to_rank0(dist, rank, world, res)
 out = {"rank": rank, "wall": wall, "total": total, "calls": len(done), "shard": done[0],
        "gathered": g.tolist() if g is not None else None}
-print("RESULT " + json.dumps(out), flush=True)
+# one write per rank (the two ranks share the launcher's stdout pipe: a line written in pieces can interleave with the other rank's)
+os.write(1, ("RESULT " + json.dumps(out) + "\n").encode())
 dist.destroy_process_group()
 '''
 
@@ -93,7 +94,7 @@ if rank == 0:
             exp0 = parts[r][:, 0] * 2 + r
             exp1 = parts[r][:, 1] - parts[r][:, 0]
             ok = ok and bool(torch.equal(root_out[b][r][..., 0], exp0)) and bool(torch.equal(root_out[b][r][..., 1], exp1))
-print("RESULT " + json.dumps({"rank": rank, "wall": wall, "rounds": len(seen), "first": seen[0], "ok": ok}), flush=True)
+os.write(1, ("RESULT " + json.dumps({"rank": rank, "wall": wall, "rounds": len(seen), "first": seen[0], "ok": ok}) + "\n").encode())   # one write per rank
 dist.destroy_process_group()
 '''
 
@@ -158,7 +159,7 @@ ref = torch.empty(3, 6, 8, 2)
 if rank == 0:
     FakeAlg().calc_batch(I0, I1, ref)
 res = bench.bench_exchange(args, parallel, dist, rank, world, "cpu", I0, I1, ref)
-print("RESULT " + json.dumps({"rank": rank, "res": res}), flush=True)
+os.write(1, ("RESULT " + json.dumps({"rank": rank, "res": res}) + "\n").encode())   # one write per rank
 dist.destroy_process_group()
 '''
 

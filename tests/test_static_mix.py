@@ -83,22 +83,27 @@ def test_blocked_kernels_keep_their_occupancy():
         return out
 
     tbr = usage("tvl1_tbr_kernels.hip")
-    # the kernel of record since round 4 forms |grad|^2 itself (NG): ...ELi2ELb1ELb0ELi0EE (the last argument, round 5: FW = 0, the warp as
-    # its own launch); the one that reads the plane stays for the stage API
-    rec = [v for k, v in tbr.items() if "k_iterate_tbrILi10ELi1ELb" in k and (k.endswith("ELi4ELi2ELi0ELi2ELb1ELb0ELi0EEEvNS0_6TbArgsE") or
-                                                                               k.endswith("ELi4ELi2ELi0ELi2ELb0ELb0ELi0EEEvNS0_6TbArgsE"))]
+    # template arguments <T, PPL, PZ, WPS, PF, MODE, JW, NG, P16, FW, GAM>.  The kernel of record since round 4 forms |grad|^2 itself (NG):
+    # ...ELi2ELb1ELb0ELi0ELb0EE (FW = 0: the warp as its own launch; GAM = 0: no illumination channel); the one that reads the plane stays
+    # for the stage API
+    rec = [v for k, v in tbr.items() if "k_iterate_tbrILi10ELi1ELb" in k and (k.endswith("ELi4ELi2ELi0ELi2ELb1ELb0ELi0ELb0EEEvNS0_6TbArgsE") or
+                                                                               k.endswith("ELi4ELi2ELi0ELi2ELb0ELb0ELi0ELb0EEEvNS0_6TbArgsE"))]
     assert len(rec) == 4   # {no |grad|^2 plane, plane} x {first pass of a warp (p = 0), the others}
     for v in rec:
         assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["SGPRs Spill"] == 0 and v["Occupancy"] >= 4, v
-    # the fused-warp instantiations (FW = 1, 2: four producer waves beside the four consumers; opt-in) must fit the same budget: eight
-    # waves per workgroup at 128 VGPRs = two workgroups per CU
-    fw = [v for k, v in tbr.items() if re.search(r"k_iterate_tbrILi10ELi1ELb[01]ELi4ELi2ELi0ELi2ELb1ELb0ELi[12]EEEvNS0_6TbArgsE$", k)]
-    assert len(fw) == 4
-    for v in fw:
+    # round 6, gamma != 0 (GAM = 1): the T = 10 pass with ONE prefetched row must keep three waves per SIMD without scratch (163 VGPRs;
+    # with two rows it is 168 + 12 spilled dwords), the T = 5 pass four, and no GAM kernel of the joined form may spill VGPRs
+    gam10 = [v for k, v in tbr.items() if re.search(r"k_iterate_tbrILi10ELi1ELb[01]ELi3ELi1ELi0ELi2ELb1ELb0ELi0ELb1EEEvNS0_6TbArgsE$", k)]
+    gam5 = [v for k, v in tbr.items() if re.search(r"k_iterate_tbrILi5ELi1ELb[01]ELi4ELi2ELi0ELi2ELb1ELb0ELi0ELb1EEEvNS0_6TbArgsE$", k)]
+    assert len(gam10) == 2 and len(gam5) == 2
+    for v in gam10:
+        assert v["VGPRs"] <= 168 and v["VGPRs Spill"] == 0 and v["Occupancy"] >= 3, v
+    for v in gam5:
         assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["Occupancy"] >= 4, v
     for k, v in tbr.items():
-        if re.search(r"ELi2ELb[01]ELb[01]ELi[012]EEEvNS0_6TbArgsE$", k):      # every joined-wave instantiation (fixed work and speculative steps)
+        if re.search(r"ELi2ELb[01]ELb[01]ELi[012]ELb[01]EEEvNS0_6TbArgsE$", k):      # every joined-wave instantiation (fixed work and speculative steps)
             assert v.get("VGPRs Spill", 0) == 0, k
+    # (the fused-warp instantiations -- FW = 1, 2 -- are compiled into the experiments build only since round 6)
     surf = usage("surf_kernels.hip")
     for k, v in surf.items():
         if "k_det_trace_all" in k or "k_descriptors" in k or "k_nms_flag_all" in k:

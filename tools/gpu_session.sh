@@ -185,6 +185,7 @@ for k, v in agg.items():
     print(k, {n: round(x / w, 3) for n, x in v.items()}, 'wave_cycles', w)
 PY
   tail -1 $O/pmc_sq.log | cut -c1-200
+  for f in $(find $O/pmc_sq -name "*counter_collection.csv" | head -1); do gzip -9 -c $f > $O/pmc_sq_counter_collection.csv.gz; done
   find $O -type f -size +4M -delete ;;
 surf_counters)
   # vector-L1 counters + kernel stats of the SURF frame -> profiles/surf_counters.json (tools/surf_counters.py)
@@ -195,6 +196,8 @@ surf_counters)
   for f in $(find $O/trace_surf2 -name "*kernel_stats.csv" | head -1); do cp $f $O/kernel_stats_surf.csv; done
   python tools/surf_counters.py $O/pmc_surf_l1 $O/kernel_stats_surf.csv "profiles/$NAME: rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VMEM_RD SQ_INSTS_LDS and --kernel-trace --stats of python bench.py --workload surf --no-cpu (per-launch means)" 2>&1 | tail -10
   cp profiles/surf_counters.json $O/surf_counters.json
+  # the raw per-dispatch counters the JSON is derived from, compressed (the file itself is larger than what this script keeps)
+  for f in $(find $O/pmc_surf_l1 -name "*counter_collection.csv" | head -1); do gzip -9 -c $f > $O/surf_counter_collection.csv.gz; done
   python tools/surf_timeline.py $O/trace_surf2 > $O/surf_timeline.txt 2>&1
   find $O -type f -size +4M -delete ;;
 pmc_secondary)

@@ -14,7 +14,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0, NG=None, P16=0, FW=0):
+def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0, NG=None, P16=0, FW=0, GAM=0):
     # NG: the instantiation without a |grad|^2 plane -- what a default calc runs since round 4 for T = 10, JW = 2 (tb_nograd_ok)
     if NG is None:
         NG = 1 if (T == 10 and JW == 2 and MODE == 0) else 0
@@ -25,7 +25,7 @@ def mix(T=10, PPL=1, PZ=0, WPS=4, PF=2, MODE=0, JW=0, NG=None, P16=0, FW=0):
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-x", "hip", "-S", "--cuda-device-only", src,
                         "-o", out], check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
-    pat = f"k_iterate_tbrILi{T}ELi{PPL}ELb{PZ}ELi{WPS}ELi{PF}ELi{MODE}ELi{JW}ELb{NG}ELb{P16}ELi{FW}EE"   # FW (round 5): 0 = the warp as its own launch
+    pat = f"k_iterate_tbrILi{T}ELi{PPL}ELb{PZ}ELi{WPS}ELi{PF}ELi{MODE}ELi{JW}ELb{NG}ELb{P16}ELi{FW}ELb{GAM}EE"   # FW (round 5): 0 = the warp as its own launch; GAM (round 6): 1 = with the illumination channel
     for f in re.split(r"\n\s*\.globl\s+", txt):
         if pat not in f.split("\n", 1)[0]:
             continue
