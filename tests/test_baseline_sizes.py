@@ -653,9 +653,11 @@ from conftest import loaded_library_is_experiments_build  # noqa: E402
 
 
 # (collected where the loaded library is the experiments build: tests/test_tvl1_gpu.py::test_experiment_only_kernels_under_the_experiments_build)
-@pytest.mark.parametrize("sem", [0, 1] if loaded_library_is_experiments_build() else [])
-@pytest.mark.parametrize("amp", [0.0, 2.5, 12.0, 400.0])
-@pytest.mark.parametrize("shape", [(130, 203), (6, 9), (97, 640)])
+LDS_WARP_CASES = [(sem, amp, shape) for sem in (0, 1) for amp in (0.0, 2.5, 12.0, 400.0) for shape in ((130, 203), (6, 9), (97, 640))] \
+    if loaded_library_is_experiments_build() else []
+
+
+@pytest.mark.parametrize("sem,amp,shape", LDS_WARP_CASES)
 def test_fused_warp_lds_staged_equals_gather(gpu, sem, amp, shape):
     """(Experiments build only since round 6: the LDS-staged warp lost its A/B under the two-lane overlap, r02z3.)  k_warp_lds (windows read from an LDS-staged region of I1 found from the tile's own flows; fallback to the global path
     for border windows and for tiles whose flow spreads the windows beyond the buffer: amp 12 and 400) and k_warp6 (global
