@@ -519,6 +519,36 @@ def test_gamma_blocked_kernel_matches_oracle_and_one_iteration_launches(gpu, ora
     _assert_flow_close(fb, f1, mean_epe=1.5e-2 if sem == 0 else 3e-2, ccorr=1e-4, frac_within=(0.08, 0.96))
 
 
+@pytest.mark.parametrize("kw", [dict(innerIterations=6, iterations=4, medianFiltering=5), dict(iterations=10, timeBlock=5), dict(iterations=9, timeBlock=3),
+                                dict(iterations=10, useInitialFlow=True), dict(iterations=12, nscales=3, warps=2, scaleStep=0.5)],
+                         ids=["median5_inner6", "blocks_of_5", "blocks_of_2_and_1", "initial_flow", "other_pyramid"])
+def test_gamma_blocked_kernel_with_the_other_knobs(gpu, oracle, kw):
+    """The illumination channel on the blocked kernel next to the knobs that change the launch sequence around it: the CPU class's median
+    filter between outer iterations (optflow/src/tvl1flow.cpp:1381-1384: u1, u2 only), forced block lengths (5 + 5; 2 + 1 ...), the
+    caller's initial flow (u3 starts at zero on the coarsest scale either way), another pyramid.  Against the oracle, fast-path bounds."""
+    import torch
+    from opencv_contrib_amd import cuda
+    I0, I1, gt = synth.flow_pair(200, 280, seed=91)
+    I1 = np.clip(I1 * 1.05 + 0.01, 0, 1).astype(np.float32)
+    okw = dict(epsilon=0.0, gamma=1.0)
+    for a, b in (("iterations", "iterations"), ("innerIterations", "inner_iterations"), ("medianFiltering", "median_filtering"), ("nscales", "nscales"),
+                 ("warps", "warps"), ("scaleStep", "scale_step")):
+        if a in kw:
+            okw[b] = kw[a]
+    if "innerIterations" in kw:
+        okw["outer_iterations"] = okw.pop("iterations")
+    init = None
+    if kw.get("useInitialFlow"):
+        init = (gt * 0.8).astype(np.float32)
+        okw["use_initial_flow"] = 1
+    ref = oracle.tvl1_calc(I0, I1, oracle.tvl1_params(**okw), init_flow=init) if init is not None else oracle.tvl1_calc(I0, I1, oracle.tvl1_params(**okw))
+    alg = _create(epsilon=0.0, gamma=1.0, exactMath=False, **kw)
+    flow = torch.from_numpy(init.copy()).to(gpu) if init is not None else None
+    out = N(alg.calc(T(I0, gpu), T(I1, gpu), flow))
+    # (the median SELECTS among neighbouring values: a last-bit change can swap the selected sample -- the bound of the gamma = 0 median test)
+    _assert_flow_close(out, ref, mean_epe=1e-2, ccorr=1e-4, frac_within=(0.05, 0.96))
+
+
 def test_gamma_blocked_batch_equals_single_calcs(gpu):
     """The illumination channel's kernels keep the batch contract: a batch, two lanes or one, is bit-identical to single calcs."""
     import torch
