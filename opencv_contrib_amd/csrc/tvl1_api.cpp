@@ -687,7 +687,7 @@ static int lane_calc(mi_tvl1 *h, Lane &ln, int n, const mi_mat *I0s, const mi_ma
                 // Speculative steps (k_iterate_tbr MODE 1): a launch runs a block of iterations recording their error sums; the next
                 // launch applies the reference's stopping rule to them and either builds on the block or replays the exact
                 // count from its input.  One settling launch ends the warp.  After convergence the remaining launches end at once.
-                const bool on_tiles = !gam && tile_eligible(g) && tuning().tile_spec != 0;   // (the illumination channel has no register-tile kernel)
+                const bool on_tiles = tile_eligible(g) && tuning().tile_spec != 0;
                 std::vector<int> plan = spec_plan[on_tiles ? 3 : wp > 0 ? 2 : ((double)g.w * g.h * B >= kLargeLevel ? 0 : 1)];
                 // the previous calc's count for this warp, where the host has seen it (polled host feedback): a first block of at most
                 // 4 / 7 iterations runs on tiles of that margin (k_iterate_tile M), and the first poll goes where that many iterations

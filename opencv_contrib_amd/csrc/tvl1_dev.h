@@ -152,7 +152,7 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
 // cost-model decomposition of n iterations into supported blocks (largest first); returns the count
 int tb_plan(int n, int cap, int *blocks, int max_blocks);
 // the same for level g: greedy blocks of tile_max_block() where the level runs on the register-tile kernel
-int tb_plan_level(const Geo &g, int n, int cap, int *blocks, int max_blocks, bool gam = false);   // gam: the illumination channel's block set (10, 5, 2, 1; never the tile kernel)
+int tb_plan_level(const Geo &g, int n, int cap, int *blocks, int max_blocks, bool gam = false);   // gam: the illumination channel's block set on streaming levels (10, 5, 2, 1)
 // largest supported block <= n (n >= 1)
 inline int tb_pick_block(int n, int cap)
 {

@@ -1261,7 +1261,7 @@ int tb_plan_gam(int n, int cap, int *blocks, int max_blocks)
 
 int tb_plan_level(const Geo &g, int n, int cap, int *blocks, int max_blocks, bool gam)
 {
-    if (gam) return tb_plan_gam(n, cap, blocks, max_blocks);   // the channel has no register-tile kernel: every level streams
+    if (gam && (!tile_eligible(g) || tuning().tb_force)) return tb_plan_gam(n, cap, blocks, max_blocks);   // the channel's streaming kernels: blocks of 10 / 5 / 2 / 1
     if (!tile_eligible(g) || tuning().tb_force) return tb_plan(n, cap, blocks, max_blocks);
     // register-tile kernel: any block length up to its margin costs one launch; fewest launches win
     int k = 0;
@@ -1378,6 +1378,8 @@ int iterate_tb_fused(int semantics, const float *I0, const float *I1, const floa
 int iterate_tb(int T, const IterPlanes &pl, const Geo &g, float l_t, float theta, float taut, bool p_zero,
                int cur, int rows_per_band, hipStream_t s, bool skip_p_out, bool independent_waves)
 {
+    if (pl.gamma != 0.f && rows_per_band == 0 && tile_eligible(g) && T <= tile_max_block() && !tuning().tb_force)
+        return iterate_tile(-1, T, pl, g, l_t, theta, taut, p_zero, cur, s);   // small levels: the register tile with the channel (bit-identical)
     if (pl.gamma != 0.f) {   // the illumination channel: its own kernels (no |grad|^2 plane read, whether or not the warp stored one)
         const TbrEntry *e = nullptr;
         for (const TbrEntry &c : g_tbr_gam) if (c.T == T) e = &c;
@@ -1460,7 +1462,7 @@ int iterate_tb_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, float 
 {
     // small levels: the same step on register tiles (serial depth of a launch = its iterations, not the image height); integer
     // error sums and identical per-pixel arithmetic => the same decisions and the same flows as the streaming kernel
-    if (pl.gamma == 0.f && tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
+    if (tile_eligible(g) && T <= tile_max_block() && !p_zero && tuning().tile_spec != 0)
         return iterate_tile_spec(T, pl, g, l_t, theta, taut, ctl, sk, e0, s);
     const TbrEntry *e = nullptr;
     if (pl.gamma != 0.f) {

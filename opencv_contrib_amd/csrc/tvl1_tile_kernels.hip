@@ -52,7 +52,10 @@ constexpr int TILE_M = 10;   // validity margin per side = the most iterations o
 // handle's previous calc how many a warp will need (SpecK::h_in, and host-side Lane::fb_hist): a block of at most 4 iterations on
 // M = 4 tiles owns 56 x 56 of its 64 x 64 pixels instead of 44 x 44 -- 1.6 x fewer workgroups, loads and lane-iterations per pass.
 // Which margin a block ran on never shows: the arithmetic per pixel is the same and the error sums are exact integers.
-template <int RW, int NW, bool PZ, bool SPEC, int M = TILE_M>
+// GAM (round 6): gamma != 0 -- the illumination channel (u3, p31, p32; tvl1flow.cu:209-288,313-348) on the register tile, the operations of
+// stage_r<.., GAM> in its order: bit-identical to the streaming kernel with the channel.  Like that kernel it forms |grad|^2 from I1wx, I1wy
+// itself (the warp's own expression: two separately rounded products and their sum) -- with gamma != 0 the warp never stores the plane.
+template <int RW, int NW, bool PZ, bool SPEC, int M = TILE_M, bool GAM = false>
 __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
 {
     constexpr int LW = 64;
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
     constexpr int BR = NW * RW - 2 * M;       // owned rows of a tile
     static_assert(BR > 0, "tile too small for its margin");
     // [wave][0,1: u1,u2 of the wave's first row (after the U phase)  2,3: p12,p22 of its last row][lane]
-    __shared__ float xch[NW][4][64];
+    // GAM: 4: u3 of the first row, 5: p32 of the last row
+    __shared__ float xch[NW][GAM ? 6 : 4][64];
     // SPEC: per-iteration error sums of the workgroup; one global add per workgroup and iteration at the end (one per WAVE and
     // iteration -- 17 600 waves at 1080p -- made the launch 10 x slower: the adds of a slot serialise in L2)
     __shared__ unsigned long long s_err[M];
@@ -102,25 +106,37 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
 
     const float *const uin[2] = {A.pl.u[cur][0] + pb, A.pl.u[cur][1] + pb};
     const float *const pin[4] = {A.pl.p[cur][0] + pb, A.pl.p[cur][1] + pb, A.pl.p[cur][2] + pb, A.pl.p[cur][3] + pb};
-    const float *const stp[4] = {A.pl.ix + pb, A.pl.iy + pb, A.pl.g + pb, A.pl.rc + pb};
+    const float *const stp[4] = {A.pl.ix + pb, A.pl.iy + pb, GAM ? nullptr : A.pl.g + pb, A.pl.rc + pb};
+    const float *const u3in = GAM ? A.pl.u[cur][2] + pb : nullptr;
+    const float *const p3in[2] = {GAM ? A.pl.p[cur][4] + pb : nullptr, GAM ? A.pl.p[cur][5] + pb : nullptr};
+    const float gamma = A.pl.gamma, eu3 = A.pl.err_u3 ? 1.f : 0.f;
 
     float u1[RW], u2[RW], p11[RW], p12[RW], p21[RW], p22[RW];
     float ix[RW], iy[RW], rg[RW], rc[RW];
+    float u3[RW], p31[RW], p32[RW];   // GAM only
     // rows above / below the image are loaded from clamped addresses (finite data); the four border cuts below isolate the
     // valid region from them exactly as in stage_r
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         const long long ro = (long long)min(max(ys + r, 0), H - 1) * ld;   // wave-uniform
         const auto ldv = [&](const float *plane) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(plane + ro) + xc); };
-        ix[r] = ldv(stp[0]); iy[r] = ldv(stp[1]); rg[r] = ldv(stp[2]); rc[r] = ldv(stp[3]);
+        ix[r] = ldv(stp[0]); iy[r] = ldv(stp[1]); rc[r] = ldv(stp[3]);
+        if constexpr (GAM) { const float ix2 = ix[r] * ix[r], iy2 = iy[r] * iy[r]; rg[r] = ix2 + iy2; }   // (step_r NG: the warp's expression)
+        else rg[r] = ldv(stp[2]);
         u1[r] = ldv(uin[0]); u2[r] = ldv(uin[1]);
         if (!PZ) { p11[r] = ldv(pin[0]); p12[r] = ldv(pin[1]); p21[r] = ldv(pin[2]); p22[r] = ldv(pin[3]); }
         else p11[r] = p12[r] = p21[r] = p22[r] = 0.f;
+        if constexpr (GAM) {
+            u3[r] = ldv(u3in);
+            if (!PZ) { p31[r] = ldv(p3in[0]); p32[r] = ldv(p3in[1]); }
+            else p31[r] = p32[r] = 0.f;
+        } else u3[r] = p31[r] = p32[r] = 0.f;
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) rg[r] = __builtin_amdgcn_rcpf(fmaxf(rg[r], 1e-30f));   // finish_static
     xch[wave][2][lane] = p12[RW - 1];
     xch[wave][3][lane] = p22[RW - 1];
+    if constexpr (GAM) xch[wave][5][lane] = p32[RW - 1];
     if (SPEC && threadIdx.x < M) s_err[threadIdx.x] = 0ull;
     __syncthreads();
 
@@ -131,6 +147,8 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
         // the row above the tile's first row does not exist: any finite value (that row is margin, or cut by negm1 at a = 0)
         const float pa12 = wave > 0 ? xch[wave - 1][2][lane] : 0.f;
         const float pa22 = wave > 0 ? xch[wave - 1][3][lane] : 0.f;
+        float pa32 = 0.f;
+        if constexpr (GAM) pa32 = wave > 0 ? xch[wave - 1][5][lane] : 0.f;
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int a = ys + r;
@@ -141,14 +159,26 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
             const float ab22 = r == 0 ? pa22 : p22[r > 0 ? r - 1 : 0];
             const float div1 = dx1 + fmaf(negm1, ab12, p12[r]);
             const float div2 = dx2 + fmaf(negm1, ab22, p22[r]);
-            const float rho = fmaf(ix[r], u1[r], fmaf(iy[r], u2[r], rc[r]));
+            float rho0 = rc[r];
+            if constexpr (GAM) rho0 = fmaf(gamma, u3[r], rho0);
+            const float rho = fmaf(ix[r], u1[r], fmaf(iy[r], u2[r], rho0));
             const float fi = __builtin_amdgcn_fmed3f(-rho * rg[r], -l_t, l_t);
             const float nu1 = fmaf(theta, div1, fmaf(fi, ix[r], u1[r]));
             const float nu2 = fmaf(theta, div2, fmaf(fi, iy[r], u2[r]));
+            float e3sq = 0.f;
+            if constexpr (GAM) {   // stage_r<.., GAM>, first half
+                const float dx3 = p31[r] - dpp_from_prev(p31[r]);
+                const float ab32 = r == 0 ? pa32 : p32[r > 0 ? r - 1 : 0];
+                const float div3 = dx3 + fmaf(negm1, ab32, p32[r]);
+                const float nu3 = fmaf(theta, div3, fmaf(fi, gamma, u3[r]));
+                if (SPEC) { const float e3 = nu3 - u3[r]; e3sq = e3 * e3 * eu3; }
+                u3[r] = nu3;
+            }
             if (SPEC) {   // stage_r<ERR>: the pixel's term rounded to 2^-24 px^2; es doubles as the row-ownership mask
                 const float es = __uint_as_float((a >= y0 && a < y1) ? 0x4b800000u : 0u);
                 const float e1 = nu1 - u1[r], e2 = nu2 - u2[r];
-                acc += (unsigned long long)__float2uint_rn(fmaf(e1, e1, e2 * e2) * es);
+                const float et = GAM ? fmaf(e1, e1, e2 * e2) + e3sq : fmaf(e1, e1, e2 * e2);
+                acc += (unsigned long long)__float2uint_rn(et * es);
             }
             u1[r] = nu1;
             u2[r] = nu2;
@@ -161,11 +191,14 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
         }
         xch[wave][0][lane] = u1[0];
         xch[wave][1][lane] = u2[0];
+        if constexpr (GAM) xch[wave][4][lane] = u3[0];
         __syncthreads();
         // ---- P phase: p_t(a) for every row (stage_r, second half; :1140-1181).  Below the tile's last row: the row itself
         // (zero y-difference; margin)
         const float nb1 = wave + 1 < NW ? xch[wave + 1][0][lane] : u1[RW - 1];
         const float nb2 = wave + 1 < NW ? xch[wave + 1][1][lane] : u2[RW - 1];
+        float nb3 = 0.f;
+        if constexpr (GAM) nb3 = wave + 1 < NW ? xch[wave + 1][4][lane] : u3[RW - 1];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int a = ys + r;
@@ -188,9 +221,20 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
             p12[r] = fmaf(taum2, d1, p12[r]) * q1;
             p21[r] = fmaf(taut, u2x, p21[r]) * q2;
             p22[r] = fmaf(taum2, d2, p22[r]) * q2;
+            if constexpr (GAM) {   // stage_r<.., GAM>, second half
+                const float r3 = dpp_from_next(u3[r]);
+                const float bl3 = r + 1 < RW ? u3[r + 1 < RW ? r + 1 : r] : nb3;
+                const float u3x = right_ok ? r3 - u3[r] : 0.f;
+                const float d3 = bl3 - u3[r];
+                const float g3 = __builtin_amdgcn_sqrtf(fmaf(d3 * d3, m2, u3x * u3x));
+                const float q3 = __builtin_amdgcn_rcpf(fmaf(taut, g3, 1.0f));
+                p31[r] = fmaf(taut, u3x, p31[r]) * q3;
+                p32[r] = fmaf(taum2, d3, p32[r]) * q3;
+            }
         }
         xch[wave][2][lane] = p12[RW - 1];
         xch[wave][3][lane] = p22[RW - 1];
+        if constexpr (GAM) xch[wave][5][lane] = p32[RW - 1];
         __syncthreads();
     }
 
@@ -206,19 +250,24 @@ __global__ __launch_bounds__(NW * 64) void k_iterate_tile(TileArgs A)
                 const long long o = (long long)a * ld + xl;
                 uout[0][o] = u1[r]; uout[1][o] = u2[r];
                 pout[0][o] = p11[r]; pout[1][o] = p12[r]; pout[2][o] = p21[r]; pout[3][o] = p22[r];
+                if constexpr (GAM) {
+                    (A.pl.u[cur ^ 1][2] + pb)[o] = u3[r];
+                    (A.pl.p[cur ^ 1][4] + pb)[o] = p31[r];
+                    (A.pl.p[cur ^ 1][5] + pb)[o] = p32[r];
+                }
             }
         }
     }
 }
 
-template <int RW, int NW, bool SPEC, int M = TILE_M>
+template <int RW, int NW, bool SPEC, int M = TILE_M, bool GAM = false>
 static int launch_tile(const TileArgs &A, bool pz, hipStream_t s)
 {
     constexpr int LW = 64, STRIDE = LW - 2 * M, BR = NW * RW - 2 * M;
     const int nstrips = A.g.w <= LW - M ? 1 : 1 + div_up(A.g.w - (LW - M), STRIDE);
     const dim3 grid(nstrips, div_up(A.g.h, BR), A.g.batch);
-    if (pz && !SPEC) hipLaunchKernelGGL((k_iterate_tile<RW, NW, true, false, M>), grid, dim3(NW * 64), 0, s, A);
-    else hipLaunchKernelGGL((k_iterate_tile<RW, NW, false, SPEC, M>), grid, dim3(NW * 64), 0, s, A);
+    if (pz && !SPEC) hipLaunchKernelGGL((k_iterate_tile<RW, NW, true, false, M, GAM>), grid, dim3(NW * 64), 0, s, A);
+    else hipLaunchKernelGGL((k_iterate_tile<RW, NW, false, SPEC, M, GAM>), grid, dim3(NW * 64), 0, s, A);
     MI_HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -227,11 +276,14 @@ typedef int (*TileLaunchFn)(const TileArgs &, bool, hipStream_t);
 struct TileEntry {
     int RW, NW;
     TileLaunchFn launch, spec, spec4, spec7;   // spec4 / spec7: blocks of at most 4 / 7 iterations on tiles of that margin
+    TileLaunchFn launch_gam, spec_gam;         // gamma != 0 (margin 10 only); nullptr for the shapes of the experiments build
 };
-#define TILE(RW, NW) {RW, NW, launch_tile<RW, NW, false>, launch_tile<RW, NW, true>, launch_tile<RW, NW, true, 4>, launch_tile<RW, NW, true, 7>}
+#define TILE(RW, NW) {RW, NW, launch_tile<RW, NW, false>, launch_tile<RW, NW, true>, launch_tile<RW, NW, true, 4>, launch_tile<RW, NW, true, 7>, nullptr, nullptr}
+#define TILEG(RW, NW) {RW, NW, launch_tile<RW, NW, false>, launch_tile<RW, NW, true>, launch_tile<RW, NW, true, 4>, launch_tile<RW, NW, true, 7>, \
+                       launch_tile<RW, NW, false, TILE_M, true>, launch_tile<RW, NW, true, TILE_M, true>}
 // [0] = the large-grid shape (64-row tiles of 16 waves), [1] = the small-grid shape (48-row tiles of 8 waves x 6 rows): what a release
 // build runs (auto_variant).  The other shapes of the r02 / r10 sweeps exist in the experiments build only.
-static const TileEntry g_tile[] = {TILE(4, 16), TILE(6, 8),
+static const TileEntry g_tile[] = {TILEG(4, 16), TILEG(6, 8),
 #ifdef MIFLOW_EXPERIMENTS
                                    TILE(6, 16), TILE(8, 16), TILE(8, 8), TILE(3, 16),
 #endif
@@ -286,6 +338,12 @@ int iterate_tile(int variant, int nit, const IterPlanes &pl, const Geo &g, float
         if (shown++ < 40)
             fprintf(stderr, "[tile] rw=%d nw=%d nit=%d %dx%d batch=%d\n", g_tile[variant].RW, g_tile[variant].NW, nit, g.w, g.h, g.batch);
     }
+    if (pl.gamma != 0.f) {
+        if (!g_tile[variant].launch_gam) variant = auto_variant(g) < 2 ? auto_variant(g) : 0;   // the channel exists on the two release shapes
+        MI_REQUIRE(pl.u[0][2] && pl.u[1][2] && pl.p[0][4] && pl.p[0][5] && pl.p[1][4] && pl.p[1][5], MI_ERR_BAD_ARG, "gamma != 0 needs the u3 / p31 / p32 planes");
+        return g_tile[variant].launch_gam(A, p_zero, s);
+    }
+    MI_REQUIRE(pl.g, MI_ERR_BAD_ARG, "the register-tile kernel needs the |grad|^2 plane");
     return g_tile[variant].launch(A, p_zero, s);
 }
 
@@ -301,8 +359,9 @@ int iterate_tile_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, floa
     A.ctl = make_ctlk(&ctl);
     A.sk = sk;
     A.e0 = e0;
-    const TileEntry &e = g_tile[variant];
-    return (T <= 4 ? e.spec4 : T <= 7 ? e.spec7 : e.spec)(A, false, s);
+    const TileEntry &e = g_tile[variant < 2 ? variant : 0];
+    if (pl.gamma != 0.f) return e.spec_gam(A, false, s);   // (margin 10 whatever the block length)
+    return (T <= 4 ? g_tile[variant].spec4 : T <= 7 ? g_tile[variant].spec7 : g_tile[variant].spec)(A, false, s);
 }
 
 }  // namespace tvl1

@@ -549,6 +549,23 @@ def test_gamma_blocked_kernel_with_the_other_knobs(gpu, oracle, kw):
     _assert_flow_close(out, ref, mean_epe=1e-2, ccorr=1e-4, frac_within=(0.05, 0.96))
 
 
+def test_gamma_register_tile_kernel_equals_streaming_kernel(gpu):
+    """Round 6: small levels (the levels of a single pair, the coarse levels of a small batch) run the illumination channel on the register
+    tile (`k_iterate_tile<.., GAM>`), large ones on the streaming kernel (`k_iterate_tbr<.., GAM>`) -- the same operations in the same order.
+    tools/gamma_digest.py: fixed-work and class-default gamma calcs of three frame sizes, both semantics, single and batched, once as is and
+    once with MIFLOW_TILE_MAXPX=0 (every level streams; the switch is read once per process): equal digests and iteration counts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"MIFLOW_TILE_MAXPX": "0"}):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gamma_digest.py")], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("gamma ")])
+    assert len(outs[0]) == 21 and all(l.endswith("True") for l in outs[0] if "batch of 3" in l)
+    assert outs[0] == outs[1]
+
+
 def test_gamma_blocked_batch_equals_single_calcs(gpu):
     """The illumination channel's kernels keep the batch contract: a batch, two lanes or one, is bit-identical to single calcs."""
     import torch
