@@ -294,19 +294,22 @@ int tile_variants() { return kTileVariants; }
 // MIFLOW_TILE_VARIANT < 0 (default): by the size of the grid -- where 64-row tiles of 16 waves give the device fewer than four
 // workgroups per CU (the levels of a single pair, the coarse levels of a small batch) 48-row tiles of 8 waves x 6 rows run the same
 // iterations faster (r10c: one pair per calc 640 x 480 552 -> 606 calcs/s, 1080p 362 -> 375)
-static int auto_variant(const Geo &g)
+// spec: the speculative steps of the convergence-checked path take the small-grid shape up to twice the grid size (round 6, r19k: their
+// blocks are mostly shorter than the margin, and the 48-row tiles' shorter dependent chain per iteration pays for longer -- one 1080p pair
+// per calc() with the class defaults 423 -> 439 calcs/s -- while fixed-work launches lose 2-4 % there)
+static int auto_variant(const Geo &g, bool spec = false)
 {
     const int v = tuning().tile_variant;
     if (v >= 0) return v < kTileVariants ? v : 0;
     constexpr int M = TILE_M, LW = 64, STRIDE = LW - 2 * M;
     const long long nstrips = g.w <= LW - M ? 1 : 1 + div_up(g.w - (LW - M), STRIDE);
     const long long wgs = nstrips * div_up(g.h, 64 - 2 * M) * g.batch;
-    return wgs < tuning().tile_small_wgs ? 1 : 0;
+    return wgs < (long long)tuning().tile_small_wgs * (spec ? 2 : 1) ? 1 : 0;
 }
 int tile_max_block() { return TILE_M; }
 int tile_rows_for(const Geo &g)
 {
-    const TileEntry &e = g_tile[auto_variant(g)];
+    const TileEntry &e = g_tile[auto_variant(g, true)];   // (asked by the cost model of the speculative steps)
     return e.RW * e.NW;
 }
 int tile_owned_rows()
@@ -352,7 +355,7 @@ int iterate_tile_spec(int T, const IterPlanes &pl, const Geo &g, float l_t, floa
                       hipStream_t s)
 {
     if (T < 1 || T > TILE_M) { set_error("register-tile kernel: block of %d iterations (1..%d)", T, TILE_M); return MI_ERR_BAD_ARG; }
-    const int variant = auto_variant(g);
+    const int variant = auto_variant(g, true);
     TileArgs A;
     memset(&A, 0, sizeof(A));
     A.pl = pl; A.g = g; A.l_t = l_t; A.theta = theta; A.taut = taut; A.cur = 0; A.nit = T; A.swz = tuning().tile_swz;
