@@ -1679,6 +1679,18 @@ def main():
                     a1.calc(q0[0], q1[0], one)
                 torch.cuda.synchronize()
                 var[tag] = {"calcs_per_s": 8 / (time.perf_counter() - t1), "executed_iterations_per_warp_mean": float(np.mean(a1.lastIterations(0)))}
+                # the same eight calcs timed ONE BY ONE (synchronised): a rare long calc -- two records of the pool's boxes show one of 20-70 ms
+                # among eight of 1.6-2.3 ms (profiles/r18z, profiles/r19y), none in 4 200 calcs of tools/stall_probe.py -- then shows as
+                # `per_calc_ms_max` instead of silently dividing the rate by five
+                pc = []
+                for i in range(8):
+                    t2 = time.perf_counter()
+                    a1.calc(q0[0], q1[0], one)
+                    torch.cuda.synchronize()
+                    pc.append(1e3 * (time.perf_counter() - t2))
+                var[tag]["per_calc_ms_median"] = float(np.median(pc))
+                var[tag]["per_calc_ms_max"] = float(np.max(pc))
+                var[tag]["calcs_per_s_from_median"] = 1e3 / float(np.median(pc))
                 for i in range(3):
                     a1.calc(q0[i], q1[i], one)
                 torch.cuda.synchronize()
